@@ -1,0 +1,276 @@
+/*
+ * szl_model.c — CPU model of the parallel decomposition of DeflateSlow (see szl_model.h).
+ * TEST INFRASTRUCTURE ONLY.  Every rule cites the reference line it restates
+ * (C/ = /root/reference/src/ICSharpCode.SharpZipLib/Zip/Compression/).
+ */
+#include "szl_model.h"
+#include <stdlib.h>
+#include <string.h>
+
+enum { WSIZE = 32768, MAX_DIST = 32506, MAX_MATCH = 258, MIN_MATCH = 3, TOO_FAR = 4096, BLOCK_TOKENS = 16384 };
+
+int szm_level_params(int level, szm_params *out) { /* C/DeflaterConstants.cs:124-144 */
+    static const int GOOD[10] = {0, 4, 4, 4, 4, 8, 8, 8, 32, 32};
+    static const int NICE[10] = {0, 8, 16, 32, 16, 32, 128, 128, 258, 258};
+    static const int CHAIN[10] = {0, 4, 8, 32, 16, 32, 128, 256, 1024, 4096};
+    if (level == -1) level = 6;
+    if (level < 5 || level > 9) return -1;
+    out->good = GOOD[level]; out->nice = NICE[level]; out->max_chain = CHAIN[level]; out->strategy = 0;
+    return 0;
+}
+
+/* Window base for an iteration that starts at absolute position s: the engine slides (base += 32768)
+ * whenever an iteration starts at window index >= 65274 (C/DeflaterEngine.cs:371, :771-778; the
+ * window index of absolute position a is a + 1 - base because strstart starts at 1, :93). */
+int64_t szm_base_of(int64_t s) {
+    int64_t idx = s + 1;
+    if (idx <= 65273) return 0;
+    return ((idx - 65273 + 32767) / 32768) * 32768;
+}
+
+static inline uint32_t hash3(const uint8_t *d, size_t q) { /* UpdateHash+InsertString :402-419 */
+    return (((uint32_t)d[q] << 10) ^ ((uint32_t)d[q + 1] << 5) ^ d[q + 2]) & 0x7FFF;
+}
+
+void szm_links(const uint8_t *d, size_t n, const size_t *seg_ends, size_t nseg, uint16_t *link) {
+    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * 32768);
+    for (int i = 0; i < 32768; i++) head[i] = -1;
+    size_t seg = 0;
+    for (size_t q = 0; q < n; q++) {
+        while (seg < nseg && q >= seg_ends[seg]) seg++;
+        size_t e = seg < nseg ? seg_ends[seg] : n;
+        link[q] = 0;
+        if (e - q < 3) continue; /* InsertString only runs while lookahead >= MIN_MATCH (:780, :817) */
+        uint32_t h = hash3(d, q);
+        int64_t r = head[h];
+        if (r >= 0 && (int64_t)q - r <= 32767) link[q] = (uint16_t)((int64_t)q - r);
+        head[h] = (int64_t)q;
+    }
+    free(head);
+}
+
+static inline int lcp_cap(const uint8_t *d, size_t c, size_t p, int cap) {
+    int l = 0;
+    while (l < cap && d[c + l] == d[p + l]) l++;
+    return l;
+}
+
+/* One FindLongestMatch walk (:474-612) at position p, inside the segment ending at seg_end.
+ *   best0      = initial matchLen (already max(prevLen,2))
+ *   budget     = chainLength after the goodLength quartering
+ *   snap_at    = if >0, *snap receives the state after that many candidates (quarter-budget result)
+ * Returns final (len | dist<<16) if improved beyond best0, else 0. */
+static uint32_t flm_walk(const uint8_t *d, size_t p, size_t seg_end, const uint16_t *link, const szm_params *P,
+                         int best0, int budget, int snap_at, uint32_t *snap) {
+    if (snap) *snap = 0;
+    size_t rem = seg_end - p;
+    if (rem < MIN_MATCH) return 0; /* :780 */
+    if (P->strategy == 2) return 0; /* HuffmanOnly :786 */
+    uint32_t l0 = link[p];
+    if (l0 == 0) return 0; /* hashHead == 0 */
+    int64_t base = szm_base_of((int64_t)p);
+    int64_t idx_p = (int64_t)p + 1 - base;
+    int64_t c = (int64_t)p - l0;
+    if ((int64_t)p - c > MAX_DIST) return 0;            /* strstart - hashHead <= MAX_DIST :788 */
+    if (c + 1 - base < 1) return 0;                      /* hashHead != 0 (entry clamped by a slide :450-461) */
+    int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;    /* scanMax :479 */
+    int nice = P->nice < (int)rem ? P->nice : (int)rem;  /* :485 */
+    int best = best0;
+    if (best >= cap) return 0;                           /* scan + matchLen > scanMax :489 */
+    int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0; /* :480 */
+    uint32_t res = 0;
+    int count = 0;
+    for (;;) {
+        int L = lcp_cap(d, (size_t)c, p, cap);
+        if (L > best) {
+            best = L;
+            res = (uint32_t)L | ((uint32_t)((int64_t)p - c) << 16);
+            if (best >= nice) { /* :604 */
+                if (snap && snap_at > 0 && count < snap_at) *snap = res;
+                return res;
+            }
+        }
+        count++;
+        if (snap && count == snap_at) *snap = res;
+        uint32_t l = link[c];
+        if (l == 0) break;
+        int64_t c2 = c - l;
+        if (c2 + 1 - base <= limit_idx) break;           /* (curMatch = prev[..]) > limit :609 */
+        if (--budget == 0) break;                        /* 0 != --chainLength :609 */
+        c = c2;
+    }
+    if (snap && snap_at > 0 && count < snap_at) *snap = res;
+    return res;
+}
+
+void szm_match_tables(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link,
+                      const szm_params *P, uint32_t *m2, uint32_t *mq) {
+    for (size_t p = seg_start; p < seg_end; p++) {
+        uint32_t snap = 0;
+        m2[p] = flm_walk(d, p, seg_end, link, P, 2, P->max_chain, P->max_chain >> 2, &snap);
+        mq[p] = snap;
+    }
+}
+
+/* --- the parse as a functional graph ------------------------------------------------------
+ * A "clean" iteration is one entered with matchLen == 2 (after a match was emitted, :826-827, or
+ * after a literal step with no match pending).  From a clean iteration at p everything up to the
+ * next clean iteration is a pure function of p: the node owns its tokens and J(p). */
+typedef struct { uint32_t tok[260]; int ntok; size_t next; } node_t;
+
+static int research(const uint8_t *d, size_t x, size_t seg_end, int L, const uint16_t *link, const uint32_t *m2,
+                    const uint32_t *mq, const szm_params *P, uint32_t *out, uint64_t *stats) {
+    size_t rem = seg_end - x;
+    if (rem < MIN_MATCH) return 0;
+    int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    if (L >= cap) return 0;
+    int nice = P->nice < (int)rem ? P->nice : (int)rem;
+    uint32_t e;
+    if (L < P->good) e = m2[x];          /* same budget, same stop: records > L are the same (App. A.3) */
+    else if (L < nice) e = mq[x];        /* chainLength >>= 2 when matchLen >= goodLength :495 */
+    else {                               /* prevLen >= niceLength': first strictly longer candidate wins */
+        if (stats) stats[0]++;
+        e = flm_walk(d, x, seg_end, link, P, L, P->max_chain >> 2, 0, NULL);
+    }
+    if ((int)(e & 0xFFFF) > L) {
+        if (P->strategy == 1 && (e & 0xFFFF) <= 5) return 0; /* Filtered :794-797 => matchLen=2 <= prevLen */
+        *out = e;
+        return 1;
+    }
+    return 0;
+}
+
+static void node_eval(const uint8_t *d, size_t p, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                      const uint32_t *mq, const szm_params *P, node_t *nd, uint64_t *stats) {
+    nd->ntok = 0;
+    uint32_t m = m2[p];
+    int len = (int)(m & 0xFFFF), dist = (int)(m >> 16);
+    if (len && len <= 5 && (P->strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; /* :794-797 */
+    if (!len) { /* literal step :830-839 ; the byte is tallied by the NEXT iteration (or the final flush :752) */
+        nd->tok[nd->ntok++] = d[p];
+        nd->next = p + 1;
+        return;
+    }
+    size_t x = p + 1;
+    uint32_t cur = (uint32_t)len | ((uint32_t)dist << 16);
+    for (;;) { /* lazy evaluation :802 "previous match was better" */
+        uint32_t better;
+        if (!research(d, x, seg_end, (int)(cur & 0xFFFF), link, m2, mq, P, &better, stats)) break;
+        nd->tok[nd->ntok++] = d[x - 1];
+        cur = better;
+        x++;
+    }
+    nd->tok[nd->ntok++] = cur; /* TallyDist(strstart-1-prevMatch, prevLen) :815 */
+    nd->next = x - 1 + (cur & 0xFFFF);
+}
+
+size_t szm_parse(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                 const uint32_t *mq, const szm_params *P, uint32_t *tok, uint64_t *stats) {
+    size_t p = seg_start, nt = 0;
+    node_t nd;
+    while (p < seg_end) {
+        node_eval(d, p, seg_end, link, m2, mq, P, &nd, stats);
+        memcpy(tok + nt, nd.tok, sizeof(uint32_t) * (size_t)nd.ntok);
+        nt += (size_t)nd.ntok;
+        p = nd.next;
+        if (stats) stats[1]++;
+    }
+    return nt;
+}
+
+size_t szm_parse_ranges(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                        const uint32_t *mq, const szm_params *P, size_t R, uint32_t *tok, uint64_t *stats) {
+    size_t n = seg_end - seg_start;
+    if (n == 0) return 0;
+    size_t nr = (n + R - 1) / R;
+    uint8_t *visited = (uint8_t *)calloc(n + 1, 1);
+    size_t *exitSpec = (size_t *)malloc(sizeof(size_t) * nr);
+    size_t *entry = (size_t *)malloc(sizeof(size_t) * nr);
+    size_t *mergeAt = (size_t *)malloc(sizeof(size_t) * nr); /* (size_t)-1 = went through */
+    size_t *exitThrough = (size_t *)malloc(sizeof(size_t) * nr);
+    node_t nd;
+    /* C1: speculative walk of every range from a fresh (clean) state at its first position */
+    for (size_t r = 0; r < nr; r++) {
+        size_t s = seg_start + r * R, e = s + R < seg_end ? s + R : seg_end;
+        size_t p = s;
+        while (p < e) {
+            visited[p - seg_start] = 1;
+            node_eval(d, p, seg_end, link, m2, mq, P, &nd, NULL);
+            p = nd.next;
+        }
+        exitSpec[r] = p;
+    }
+    /* C2: fix-up walk from the predecessor's speculative exit until it lands on this range's spec path */
+    entry[0] = seg_start; mergeAt[0] = seg_start; exitThrough[0] = 0;
+    for (size_t r = 1; r < nr; r++) {
+        size_t s = seg_start + r * R, e = s + R < seg_end ? s + R : seg_end;
+        size_t p = exitSpec[r - 1];
+        entry[r] = p;
+        mergeAt[r] = (size_t)-1;
+        while (p < e) {
+            if (visited[p - seg_start]) { mergeAt[r] = p; break; }
+            node_eval(d, p, seg_end, link, m2, mq, P, &nd, NULL);
+            p = nd.next;
+        }
+        exitThrough[r] = p;
+        (void)s;
+    }
+    /* C3: sequential validation; redo ranges whose assumed entry was wrong */
+    size_t trueExitPrev = (mergeAt[0] != (size_t)-1) ? exitSpec[0] : exitThrough[0];
+    for (size_t r = 1; r < nr; r++) {
+        size_t s = seg_start + r * R, e = s + R < seg_end ? s + R : seg_end;
+        if (entry[r] != trueExitPrev) {
+            size_t p = trueExitPrev;
+            entry[r] = p;
+            mergeAt[r] = (size_t)-1;
+            while (p < e) {
+                if (p >= s && visited[p - seg_start]) { mergeAt[r] = p; break; }
+                node_eval(d, p, seg_end, link, m2, mq, P, &nd, NULL);
+                p = nd.next;
+            }
+            exitThrough[r] = p;
+        }
+        if (mergeAt[r] == (size_t)-1 && stats) stats[0]++;
+        trueExitPrev = (mergeAt[r] != (size_t)-1) ? exitSpec[r] : exitThrough[r];
+    }
+    /* emission: fix-up prefix, then the speculative suffix from the merge point */
+    size_t nt = 0;
+    for (size_t r = 0; r < nr; r++) {
+        size_t s = seg_start + r * R, e = s + R < seg_end ? s + R : seg_end;
+        size_t p = entry[r];
+        size_t stop = mergeAt[r] != (size_t)-1 ? mergeAt[r] : e;
+        while (p < stop) {
+            node_eval(d, p, seg_end, link, m2, mq, P, &nd, NULL);
+            memcpy(tok + nt, nd.tok, sizeof(uint32_t) * (size_t)nd.ntok);
+            nt += (size_t)nd.ntok;
+            p = nd.next;
+        }
+        if (mergeAt[r] != (size_t)-1) {
+            p = mergeAt[r];
+            while (p < e) {
+                node_eval(d, p, seg_end, link, m2, mq, P, &nd, NULL);
+                memcpy(tok + nt, nd.tok, sizeof(uint32_t) * (size_t)nd.ntok);
+                nt += (size_t)nd.ntok;
+                p = nd.next;
+            }
+        }
+        (void)s;
+    }
+    free(visited); free(exitSpec); free(entry); free(mergeAt); free(exitThrough);
+    return nt;
+}
+
+size_t szm_block_table(const uint32_t *tok, size_t ntok, int finish, int64_t *first, int32_t *count, int32_t *last) {
+    /* A block is cut after every 16384th token emitted by a real iteration (IsFull, :841-852); the
+     * final FlushBlock (:750-768) closes whatever remains — even nothing — unless the 16384th token was
+     * a match ending exactly at the end of input during Finish (lastBlock computed true at :847). */
+    size_t full = ntok / BLOCK_TOKENS, rem = ntok % BLOCK_TOKENS, nb = 0;
+    for (size_t b = 0; b < full; b++) { first[nb] = (int64_t)(b * BLOCK_TOKENS); count[nb] = BLOCK_TOKENS; last[nb] = 0; nb++; }
+    if (rem > 0 || ntok == 0) {
+        first[nb] = (int64_t)(full * BLOCK_TOKENS); count[nb] = (int32_t)rem; last[nb] = 0; nb++;
+    } else if ((tok[ntok - 1] >> 16) != 0 && !finish) { /* last token a match, sync flush: extra empty block */
+        first[nb] = (int64_t)ntok; count[nb] = 0; last[nb] = 0; nb++;
+    }
+    if (finish) last[nb - 1] = 1;
+    return nb;
+}
