@@ -1,0 +1,174 @@
+/*
+ * szl.h — C ABI of libszl_amd.so: the MI355X-native DEFLATE engine behind SharpZipLib's
+ * Deflater / Inflater.  This is the drop-in boundary: the reference has no FFI,
+ * so the boundary is the public member set of ICSharpCode.SharpZipLib.Zip.Compression.Deflater /
+ * Inflater; every entry point below names the member it replaces.  The C# shim classes
+ *  P/Invoke these 1:1; DeflaterOutputStream / InflaterInputStream stay managed
+ * and only see the two codec classes.
+ *
+ * Conventions: opaque handles; caller-owned buffers; plain pointers and sizes; no callbacks.
+ * Functions returning int return >= 0 on success and a negative szl_status on error (the shim
+ * maps each code to the reference's exception type + message).  A handle is single-threaded like
+ * the reference objects (C/Deflater.cs:10-11); the library is re-entrant across handles.
+ * There is NO CPU fallback: every entry point that compresses/decompresses runs HIP kernels on
+ * gfx950 and fails with SZL_E_DEVICE if no device is usable.
+ *
+ * Reference paths: C/ = src/ICSharpCode.SharpZipLib/Zip/Compression/, K/ = .../Checksum/.
+ */
+#ifndef SZL_H
+#define SZL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum szl_status {
+    SZL_OK = 0,
+    SZL_E_ARG = -1,            /* ArgumentOutOfRangeException / ArgumentNullException (C/Deflater.cs:184-187, C/DeflaterEngine.cs:148-176) */
+    SZL_E_STATE = -2,          /* InvalidOperationException ("Finish() already called" C/Deflater.cs:333-336, "Old input was not completely processed" C/DeflaterEngine.cs:163-166, "Dictionary is not needed" C/Inflater.cs:580) */
+    SZL_E_DEVICE = -3,         /* HIP error / no gfx950 device: surfaces as SharpZipBaseException */
+    SZL_E_NOMEM = -4,
+    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not built yet on the device path (see DESIGN.md "out of scope") */
+    SZL_E_OUTPUT_TOO_SMALL = -6,
+    /* Inflater errors == the SharpZipBaseException messages of C/Inflater.cs */
+    SZL_E_HEADER_CHECKSUM = -16,   /* "Header checksum illegal"            C/Inflater.cs:224 */
+    SZL_E_METHOD_UNKNOWN = -17,    /* "Compression Method unknown"         C/Inflater.cs:229 */
+    SZL_E_ILLEGAL_LEN_CODE = -18,  /* "Illegal rep length code"            C/Inflater.cs:325 */
+    SZL_E_ILLEGAL_DIST_CODE = -19, /* "Illegal rep dist code"              C/Inflater.cs:358 */
+    SZL_E_ADLER_MISMATCH = -20,    /* "Adler chksum doesn't match"         C/Inflater.cs:413 */
+    SZL_E_UNKNOWN_BLOCK = -21,     /* "Unknown block type"                 C/Inflater.cs:486 */
+    SZL_E_BROKEN_STORED = -22,     /* "broken uncompressed block"          C/Inflater.cs:511 */
+    SZL_E_CODELEN_ZERO = -23,      /* "Encountered invalid codelength 0"   C/InflaterHuffmanTree.cs:191-193 */
+    SZL_E_DYN_HEADER = -24,        /* ValueOutOfRange/StreamDecodingException C/InflaterDynHeader.cs:50-52,83,106,114 */
+    SZL_E_UNEXPECTED_EOF = -25,    /* batch inflate only: input exhausted before the final block (CS/InflaterInputStream.cs:494) */
+    SZL_E_WINDOW_FULL = -26        /* CS/OutputWindow.cs:37,66 */
+} szl_status;
+
+const char *szl_strerror(int status);
+const char *szl_last_error(void);        /* thread-local detail string of the last failing call */
+int szl_device_count(void);              /* number of usable gfx950 devices (0 => every codec call fails with SZL_E_DEVICE) */
+int szl_set_device(int ordinal);         /* device used by handles created afterwards on this thread */
+
+/* ------------------------------------------------------------------------------------------
+ * Checksums on device memory or host memory (K/Crc32.cs:138, K/Adler32.cs:134).
+ * `value` is the running IChecksum.Value (0 for a fresh Crc32, 1 for a fresh Adler32).
+ * ------------------------------------------------------------------------------------------ */
+int szl_crc32(uint32_t value, const void *host_data, size_t n, uint32_t *out);
+int szl_adler32(uint32_t value, const void *host_data, size_t n, uint32_t *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Deflater — replaces ICSharpCode.SharpZipLib.Zip.Compression.Deflater (C/Deflater.cs)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct szl_deflater szl_deflater;
+
+/* Deflater(int level, bool noZlibHeaderOrFooter) C/Deflater.cs:178 ; level -1 => 6 ; returns NULL and
+ * sets szl_last_error on a bad level (ArgumentOutOfRangeException :184-187) or device failure. */
+szl_deflater *szl_deflater_create(int level, int no_zlib_header_or_footer);
+void szl_deflater_destroy(szl_deflater *d);
+int szl_deflater_reset(szl_deflater *d);                                   /* Reset()          C/Deflater.cs:204 */
+int szl_deflater_set_level(szl_deflater *d, int level);                    /* SetLevel(int)    C/Deflater.cs:349 */
+int szl_deflater_get_level(const szl_deflater *d);                         /* GetLevel()       C/Deflater.cs:371 */
+int szl_deflater_set_strategy(szl_deflater *d, int strategy);              /* SetStrategy      C/Deflater.cs:385 ; 0 Default 1 Filtered 2 HuffmanOnly */
+int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n); /* SetDictionary    C/Deflater.cs:559 */
+/* SetInput(byte[],int,int) C/Deflater.cs:331.  The reference borrows the caller's array until
+ * IsNeedingInput; this library COPIES the bytes into its staging buffer before returning, so the
+ * caller may reuse the array immediately and IsNeedingInput is true again on return. */
+int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n);
+int szl_deflater_flush(szl_deflater *d);                                   /* Flush()          C/Deflater.cs:252 */
+int szl_deflater_finish(szl_deflater *d);                                  /* Finish()         C/Deflater.cs:262 */
+/* Deflate(byte[],int,int) C/Deflater.cs:427 : returns bytes written into out[0..len).  Legal returns
+ * of 0 with IsNeedingInput==true happen before Flush/Finish (the whole pending segment is compressed on
+ * the device inside the first Deflate call after Flush()/Finish(), then drained across calls). */
+int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int len);
+int szl_deflater_needs_input(const szl_deflater *d);                       /* IsNeedingInput   C/Deflater.cs:285 */
+int szl_deflater_is_finished(const szl_deflater *d);                       /* IsFinished       C/Deflater.cs:271 */
+int64_t szl_deflater_total_in(const szl_deflater *d);                      /* TotalIn          C/Deflater.cs:226 */
+int64_t szl_deflater_total_out(const szl_deflater *d);                     /* TotalOut         C/Deflater.cs:237 */
+uint32_t szl_deflater_adler(const szl_deflater *d);                        /* Adler            C/Deflater.cs:215 */
+
+/* ------------------------------------------------------------------------------------------
+ * Batch / device-resident entry points (SURVEY §8b "one-shot batch entry points"): the fast path
+ * for config 2 (one huge stream), config 3 (many small streams, feeds
+ * ZipOutputStream.PutNextPassthroughEntry S/Zip/ZipOutputStream.cs:313) and bench.py.
+ * Each stream is compressed exactly as `new Deflater(level, nowrap)` + SetInput(all) + Finish()
+ * would (bit-identical output), optionally with CRC-32 / Adler-32 of the input computed on device.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct szl_stream {
+    uint64_t in_off;    /* byte offset of this stream's input inside the input buffer */
+    uint64_t in_len;
+    uint64_t out_off;   /* byte offset of this stream's output region inside the output buffer */
+    uint64_t out_cap;   /* size of that region; must be >= szl_deflate_bound(in_len) */
+    uint64_t out_len;   /* [out] compressed bytes written */
+    uint32_t crc32;     /* [out] Crc32.Value of the input if SZL_F_CRC32 */
+    uint32_t adler32;   /* [out] Adler32.Value of the input if SZL_F_ADLER32 or zlib framing */
+    int32_t status;     /* [out] per-stream szl_status */
+    uint32_t reserved;
+} szl_stream;
+
+enum { SZL_F_NOWRAP = 1, SZL_F_CRC32 = 2, SZL_F_ADLER32 = 4, SZL_F_SYNC_FLUSH_BEFORE_FINISH = 8 };
+
+uint64_t szl_deflate_bound(uint64_t in_len);   /* worst-case compressed size the device path may write */
+
+typedef struct szl_engine szl_engine;           /* owns device workspace; reusable across calls; one thread at a time */
+szl_engine *szl_engine_create(void);
+void szl_engine_destroy(szl_engine *e);
+
+/* Device-resident: d_in/d_out are device pointers; nothing crosses PCIe except the stream table.
+ * `hip_stream` is a hipStream_t (NULL = default stream).  Synchronous on return. */
+int szl_deflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_streams,
+                             int level, int strategy, unsigned flags, void *hip_stream);
+/* Host buffers: copies H2D, runs the same pipeline, copies D2H. */
+int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
+                           int level, int strategy, unsigned flags);
+
+/* Per-stage timing of the last batch call on this engine, milliseconds measured with HIP events on the
+ * engine's stream (SURVEY §5 "per-stage hipEvent timing exported through the C ABI"). */
+typedef struct szl_timing {
+    float total_ms, checksum_ms, links_ms, match_ms, parse_ms, blocks_ms, encode_ms;
+    uint64_t in_bytes, out_bytes, tokens, blocks, ranges_unmerged, fallback_walks;
+} szl_timing;
+int szl_engine_last_timing(const szl_engine *e, szl_timing *t);
+
+/* Debug/parity taps (used by tests to diff intermediates against oracle/szl_model.c): copy the
+ * last call's intermediates of stream 0 to host arrays (any pointer may be NULL). */
+int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t *mq, size_t n_positions,
+                           uint32_t *tokens, size_t tok_cap, size_t *n_tokens);
+
+/* Parity tap: block table of the last call; rows of 8 x uint64:
+ * type, last, ntok, bit_start, opt_len, static_len, in_len, hdr_bits. */
+int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows);
+
+/* ------------------------------------------------------------------------------------------
+ * Inflater — replaces ICSharpCode.SharpZipLib.Zip.Compression.Inflater (C/Inflater.cs)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct szl_inflater szl_inflater;
+szl_inflater *szl_inflater_create(int no_header);                           /* Inflater(bool)   C/Inflater.cs:156-180 */
+void szl_inflater_destroy(szl_inflater *s);
+int szl_inflater_reset(szl_inflater *s);                                    /* Reset()          C/Inflater.cs:188 */
+int szl_inflater_set_input(szl_inflater *s, const uint8_t *p, int n);       /* SetInput         C/Inflater.cs:629 */
+int szl_inflater_set_dictionary(szl_inflater *s, const uint8_t *p, int n);  /* SetDictionary    C/Inflater.cs:563 */
+int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count);         /* Inflate          C/Inflater.cs:715 */
+int szl_inflater_needs_input(const szl_inflater *s);                        /* IsNeedingInput   C/Inflater.cs:783 */
+int szl_inflater_needs_dictionary(const szl_inflater *s);                   /* IsNeedingDictionary :794 */
+int szl_inflater_is_finished(const szl_inflater *s);                        /* IsFinished       C/Inflater.cs:806 */
+int szl_inflater_remaining_input(const szl_inflater *s);                    /* RemainingInput   C/Inflater.cs:878 */
+int64_t szl_inflater_total_in(const szl_inflater *s);                       /* TotalIn          C/Inflater.cs:862 */
+int64_t szl_inflater_total_out(const szl_inflater *s);                      /* TotalOut         C/Inflater.cs:848 */
+uint32_t szl_inflater_adler(const szl_inflater *s);                         /* Adler            C/Inflater.cs:823 */
+
+/* Batch inflate of independent raw-deflate / zlib streams (zip entries, gzip members): one
+ * wavefront per stream.  streams[i].in_* = compressed bytes, out_* = region for the decompressed
+ * bytes, out_len = [out] decompressed size, reserved = [out] compressed bytes consumed
+ * (== Inflater.TotalIn at IsFinished).  flags: SZL_F_NOWRAP, SZL_F_CRC32 (crc of OUTPUT), SZL_F_ADLER32. */
+int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_streams,
+                             unsigned flags, void *hip_stream);
+int szl_inflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
+                           unsigned flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SZL_H */

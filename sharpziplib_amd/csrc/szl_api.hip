@@ -1,0 +1,409 @@
+// szl_api.hip — the C ABI of include/szl.h: Deflater state machine + batch entry points.
+// Mirrors C/Deflater.cs (state constants :126-140, Deflate loop :427-522) above the device engine.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "szl_engine.h"
+
+using namespace szl;
+
+struct szl_engine { Engine e; };
+
+static thread_local int g_device = 0;
+
+extern "C" {
+
+const char *szl_strerror(int st) {
+    switch (st) {
+    case SZL_OK: return "ok";
+    case SZL_E_ARG: return "argument out of range";
+    case SZL_E_STATE: return "invalid operation for the current state";
+    case SZL_E_DEVICE: return "HIP device error";
+    case SZL_E_NOMEM: return "out of device memory";
+    case SZL_E_UNSUPPORTED: return "not supported on the device path";
+    case SZL_E_OUTPUT_TOO_SMALL: return "output region too small";
+    case SZL_E_HEADER_CHECKSUM: return "Header checksum illegal";
+    case SZL_E_METHOD_UNKNOWN: return "Compression Method unknown";
+    case SZL_E_ILLEGAL_LEN_CODE: return "Illegal rep length code";
+    case SZL_E_ILLEGAL_DIST_CODE: return "Illegal rep dist code";
+    case SZL_E_ADLER_MISMATCH: return "Adler chksum doesn't match";
+    case SZL_E_UNKNOWN_BLOCK: return "Unknown block type";
+    case SZL_E_BROKEN_STORED: return "broken uncompressed block";
+    case SZL_E_CODELEN_ZERO: return "Encountered invalid codelength 0";
+    case SZL_E_DYN_HEADER: return "invalid dynamic block header";
+    case SZL_E_UNEXPECTED_EOF: return "Unexpected EOF";
+    case SZL_E_WINDOW_FULL: return "Window full";
+    default: return "unknown status";
+    }
+}
+const char *szl_last_error(void) { return szl::last_error(); }
+
+int szl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+int szl_set_device(int ordinal) {
+    if (hipSetDevice(ordinal) != hipSuccess) { set_error("hipSetDevice(%d) failed", ordinal); return SZL_E_DEVICE; }
+    g_device = ordinal;
+    return 0;
+}
+
+uint64_t szl_deflate_bound(uint64_t n) {
+    // Non-stored blocks cost <= 9 bits per literal / <= 31 bits per >=3-byte match (opt_len <= static_len,
+    // C/DeflaterHuffman.cs:824-828); stored blocks add <= 5 bytes per 16384 tokens; plus sync padding / trailer.
+    return n + n / 3 + (n >> 12) + 256;
+}
+
+szl_engine *szl_engine_create(void) {
+    if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return nullptr; }
+    return new (std::nothrow) szl_engine();
+}
+void szl_engine_destroy(szl_engine *e) { delete e; }
+
+int szl_engine_last_timing(const szl_engine *e, szl_timing *t) {
+    if (!e || !t) return SZL_E_ARG;
+    *t = e->e.timing;
+    return 0;
+}
+
+static int build_batch(szl_stream *streams, size_t n, unsigned flags, std::vector<SegDev> &segs, std::vector<uint64_t> &bnds,
+                       uint64_t *in_total, uint64_t *out_total) {
+    segs.clear(); bnds.clear();
+    uint64_t it = 0, ot = 0;
+    const bool nowrap = flags & SZL_F_NOWRAP;
+    for (size_t i = 0; i < n; i++) {
+        szl_stream &s = streams[i];
+        s.status = 0; s.out_len = 0; s.crc32 = 0; s.adler32 = 1;
+        if (s.out_off & 3) { set_error("stream %zu: out_off must be a multiple of 4", i); return SZL_E_ARG; }
+        if (s.out_cap < szl_deflate_bound(s.in_len) + (nowrap ? 0 : 6)) { set_error("stream %zu: out_cap %llu < bound", i, (unsigned long long)s.out_cap); return SZL_E_OUTPUT_TOO_SMALL; }
+        SegDev d{};
+        d.buf_off = s.in_off; d.abs0 = 0; d.seg_start = 0; d.seg_end = (int64_t)s.in_len;
+        d.bnd_off = (uint32_t)bnds.size(); d.bnd_cnt = 1; bnds.push_back(s.in_len);
+        d.out_off = s.out_off; d.out_cap = s.out_cap; d.stream_idx = (uint32_t)i;
+        d.start_bit = nowrap ? 0 : 16; d.adler_init = 1; d.crc_init = 0;
+        if (flags & SZL_F_SYNC_FLUSH_BEFORE_FINISH) { d.finish = 0; d.flags = SEG_SYNC_PAD | SEG_EXTRA_FINAL_EMPTY; }
+        else { d.finish = 1; d.flags = 0; }
+        if (!nowrap) d.flags |= SEG_ZLIB_TRAILER;
+        segs.push_back(d);
+        it = std::max(it, s.in_off + s.in_len);
+        ot = std::max(ot, s.out_off + s.out_cap);
+    }
+    *in_total = it; *out_total = ot;
+    return 0;
+}
+
+static int zlib_header(int level) { // C/Deflater.cs:436-461
+    int header = (8 + ((15 - 8) << 4)) << 8;
+    int level_flags = (level - 1) >> 1;
+    if (level_flags < 0 || level_flags > 3) level_flags = 3;
+    header |= level_flags << 6;
+    header += 31 - (header % 31);
+    return header;
+}
+
+int szl_deflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_streams, int level,
+                             int strategy, unsigned flags, void *hip_stream) {
+    if (!e || (!streams && n_streams)) return SZL_E_ARG;
+    if (level == -1) level = 6;
+    LevelParams P;
+    int rc = level_params(level, strategy, &P);
+    if (rc) { set_error("level %d: %s", level, szl_strerror(rc)); return rc; }
+    if (strategy < 0 || strategy > 2) return SZL_E_ARG;
+    if (((uintptr_t)d_out) & 3) { set_error("d_out must be 4-byte aligned"); return SZL_E_ARG; }
+    std::vector<SegDev> segs; std::vector<uint64_t> bnds; uint64_t in_total, out_total;
+    if ((rc = build_batch(streams, n_streams, flags, segs, bnds, &in_total, &out_total))) return rc;
+    std::vector<SegOut> res;
+    unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !(flags & SZL_F_NOWRAP)) ? 2u : 0u);
+    hipStream_t st = (hipStream_t)hip_stream;
+    rc = e->e.deflate((const uint8_t *)d_in, in_total, (uint8_t *)d_out, out_total, segs, bnds, P, want, res, st);
+    if (rc) return rc;
+    if (!(flags & SZL_F_NOWRAP)) { // zlib header bytes (2 per stream): tiny strided writes
+        int hdr = zlib_header(level);
+        uint8_t hb[2] = {(uint8_t)(hdr >> 8), (uint8_t)hdr};
+        for (size_t i = 0; i < n_streams; i++)
+            if (hipMemcpyAsync((uint8_t *)d_out + streams[i].out_off, hb, 2, hipMemcpyHostToDevice, st) != hipSuccess) return SZL_E_DEVICE;
+        if (hipStreamSynchronize(st) != hipSuccess) return SZL_E_DEVICE;
+    }
+    for (size_t i = 0; i < n_streams; i++) {
+        streams[i].out_len = res[i].out_bytes;
+        streams[i].crc32 = res[i].crc32;
+        streams[i].adler32 = res[i].adler32;
+        streams[i].status = res[i].out_bytes <= streams[i].out_cap ? 0 : SZL_E_OUTPUT_TOO_SMALL;
+    }
+    return 0;
+}
+
+int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams, int level,
+                           int strategy, unsigned flags) {
+    if (!e || (!streams && n_streams)) return SZL_E_ARG;
+    uint64_t in_total = 0, out_total = 0;
+    for (size_t i = 0; i < n_streams; i++) {
+        in_total = std::max(in_total, streams[i].in_off + streams[i].in_len);
+        out_total = std::max(out_total, streams[i].out_off + streams[i].out_cap);
+    }
+    int rc;
+    if ((rc = e->e.stage_in.ensure(in_total + 64))) return rc;
+    if ((rc = e->e.stage_out.ensure(out_total + 64))) return rc;
+    if (in_total && hipMemcpy(e->e.stage_in.p, h_in, in_total, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    rc = szl_deflate_batch_device(e, e->e.stage_in.p, e->e.stage_out.p, streams, n_streams, level, strategy, flags, nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < n_streams; i++) {
+        if (streams[i].status) continue;
+        if (streams[i].out_len && hipMemcpy((uint8_t *)h_out + streams[i].out_off, (uint8_t *)e->e.stage_out.p + streams[i].out_off,
+                                            streams[i].out_len, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    }
+    return 0;
+}
+
+int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t *mq, size_t n_positions, uint32_t *tokens,
+                           size_t tok_cap, size_t *n_tokens) {
+    if (!e) return SZL_E_ARG;
+    Engine &E = e->e;
+    size_t n = std::min<size_t>(n_positions, E.last_in_total);
+    if (link && n && hipMemcpy(link, E.link.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+    if ((m2 || mq) && n) {
+        std::vector<uint2> tmp(n);
+        if (hipMemcpy(tmp.data(), E.mtab.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+        for (size_t i = 0; i < n; i++) { if (m2) m2[i] = tmp[i].x; if (mq) mq[i] = tmp[i].y; }
+    }
+    size_t nt = std::min<size_t>(tok_cap, (size_t)E.timing.tokens);
+    if (tokens && nt && hipMemcpy(tokens, E.tokens.p, nt * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+    if (n_tokens) *n_tokens = (size_t)E.timing.tokens;
+    return 0;
+}
+
+// Parity tap: block table of the last call. rows of 8 x uint64: type,last,ntok,bit_start,opt_len,static_len,in_len,hdr_bits
+int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows) {
+    if (!e) return SZL_E_ARG;
+    Engine &E = e->e;
+    size_t nslots = (size_t)(E.last_blk_slots);
+    std::vector<BlockDesc> tmp(nslots);
+    if (nslots && hipMemcpy(tmp.data(), E.descs.p, nslots * sizeof(BlockDesc), hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+    size_t k = 0;
+    for (size_t i = 0; i < nslots; i++) {
+        if (tmp[i].type == 0xFFu) continue;
+        if (rows && k < cap_rows) {
+            uint64_t *r = rows + 8 * k;
+            r[0] = tmp[i].type; r[1] = tmp[i].last; r[2] = tmp[i].ntok; r[3] = tmp[i].bit_start; r[4] = tmp[i].opt_len;
+            r[5] = tmp[i].static_len; r[6] = tmp[i].in_len; r[7] = tmp[i].hdr_bits;
+        }
+        k++;
+    }
+    if (n_rows) *n_rows = k;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deflater (streaming object).  State constants of C/Deflater.cs:126-140.
+enum { IS_SETDICT = 0x01, IS_FLUSHING = 0x04, IS_FINISHING = 0x08, INIT_STATE = 0x00, SETDICT_STATE = 0x01, BUSY_STATE = 0x10,
+       FLUSHING_STATE = 0x14, FINISHING_STATE = 0x1c, FINISHED_STATE = 0x1e, CLOSED_STATE = 0x7f };
+
+struct szl_deflater {
+    int level = 6, strategy = 0, nowrap = 0, state = 0;
+    int64_t total_in = 0, total_out = 0;
+    std::vector<uint8_t> hist;      // tail (<= 65536 B) of the bytes already compressed
+    uint64_t hist_abs = 0;          // absolute stream position of hist[0]
+    std::vector<uint64_t> bounds;   // absolute positions of earlier segment ends that still lie inside hist
+    std::vector<uint8_t> pend;      // bytes given by SetInput since the last Flush()
+    std::vector<uint8_t> outq;      // compressed bytes not yet handed out
+    size_t outpos = 0;
+    uint32_t carry_bits = 0; uint8_t carry_byte = 0;
+    uint32_t adler = 1;             // running Adler32.Value of everything compressed so far
+    szl_engine *eng = nullptr;
+    DevBuf d_in, d_out;
+    std::vector<uint8_t> h_out;
+};
+
+static void deflater_clear(szl_deflater *d) {
+    d->state = d->nowrap ? BUSY_STATE : INIT_STATE;
+    d->total_in = d->total_out = 0;
+    d->hist.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
+    d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
+}
+
+szl_deflater *szl_deflater_create(int level, int nowrap) {
+    if (level == -1) level = 6;
+    else if (level < 0 || level > 9) { set_error("level out of range"); return nullptr; } // C/Deflater.cs:184-187
+    if (level < 5) { set_error("levels 0-4 (DeflateStored/DeflateFast) are not on the device path yet"); return nullptr; }
+    szl_deflater *d = new (std::nothrow) szl_deflater();
+    if (!d) return nullptr;
+    d->eng = szl_engine_create();
+    if (!d->eng) { delete d; return nullptr; }
+    d->level = level; d->nowrap = nowrap ? 1 : 0;
+    deflater_clear(d);
+    return d;
+}
+void szl_deflater_destroy(szl_deflater *d) {
+    if (!d) return;
+    d->d_in.release(); d->d_out.release();
+    szl_engine_destroy(d->eng);
+    delete d;
+}
+int szl_deflater_reset(szl_deflater *d) { if (!d) return SZL_E_ARG; deflater_clear(d); return 0; }
+int szl_deflater_set_level(szl_deflater *d, int level) {
+    if (!d) return SZL_E_ARG;
+    if (level == -1) level = 6;
+    else if (level < 0 || level > 9) return SZL_E_ARG;
+    if (level == d->level) return 0;
+    if (level < 5) { set_error("levels 0-4 are not on the device path yet"); return SZL_E_UNSUPPORTED; }
+    // DEFLATE_SLOW -> DEFLATE_SLOW only changes the tuning for positions not yet parsed (C/DeflaterEngine.cs:304-361);
+    // that is reproducible only when nothing is buffered.
+    if (!d->pend.empty()) { set_error("SetLevel with unprocessed input is not supported"); return SZL_E_UNSUPPORTED; }
+    d->level = level;
+    return 0;
+}
+int szl_deflater_get_level(const szl_deflater *d) { return d ? d->level : SZL_E_ARG; }
+int szl_deflater_set_strategy(szl_deflater *d, int s) {
+    if (!d || s < 0 || s > 2) return SZL_E_ARG;
+    if (s != d->strategy && !d->pend.empty()) { set_error("SetStrategy with unprocessed input is not supported"); return SZL_E_UNSUPPORTED; }
+    d->strategy = s;
+    return 0;
+}
+int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *, int) {
+    if (!d) return SZL_E_ARG;
+    if (d->state != INIT_STATE) return SZL_E_STATE; // C/Deflater.cs:561-564
+    set_error("preset dictionaries are not on the device path yet");
+    return SZL_E_UNSUPPORTED;
+}
+int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n) {
+    if (!d) return SZL_E_ARG;
+    if ((d->state & IS_FINISHING) != 0) { set_error("Finish() already called"); return SZL_E_STATE; } // :333-336
+    if (n < 0 || (!p && n)) return SZL_E_ARG;
+    d->pend.insert(d->pend.end(), p, p + n);
+    d->total_in += n;
+    return 0;
+}
+int szl_deflater_flush(szl_deflater *d) { if (!d) return SZL_E_ARG; d->state |= IS_FLUSHING; return 0; }
+int szl_deflater_finish(szl_deflater *d) { if (!d) return SZL_E_ARG; d->state |= (IS_FLUSHING | IS_FINISHING); return 0; }
+int szl_deflater_needs_input(const szl_deflater *) { return 1; } // input is copied by SetInput, so it is always consumed
+int szl_deflater_is_finished(const szl_deflater *d) { return d && d->state == FINISHED_STATE && d->outpos == d->outq.size(); }
+int64_t szl_deflater_total_in(const szl_deflater *d) { return d ? d->total_in : 0; }
+int64_t szl_deflater_total_out(const szl_deflater *d) { return d ? d->total_out : 0; }
+uint32_t szl_deflater_adler(const szl_deflater *d) {
+    if (!d || d->nowrap) return 0; // engine has no Adler32 when noZlibHeaderOrFooter (C/DeflaterEngine.cs:84-85)
+    if (d->pend.empty()) return d->adler;
+    uint32_t v = d->adler;
+    if (szl_adler32(d->adler, d->pend.data(), d->pend.size(), &v) != 0) return d->adler;
+    return v;
+}
+
+// Compress the pending bytes as one segment on the device and append the produced bytes to outq.
+static int run_segment(szl_deflater *d, bool finish) {
+    LevelParams P;
+    int rc = level_params(d->level, d->strategy, &P);
+    if (rc) return rc;
+    const uint64_t H = d->hist.size(), n = d->pend.size();
+    const uint64_t in_total = H + n;
+    const uint64_t cap = (szl_deflate_bound(n) + 16 + 3) & ~3ull;
+    if ((rc = d->d_in.ensure(in_total + 64))) return rc;
+    if ((rc = d->d_out.ensure(cap + 64))) return rc;
+    if (H && hipMemcpy(d->d_in.p, d->hist.data(), H, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    if (n && hipMemcpy((uint8_t *)d->d_in.p + H, d->pend.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    std::vector<SegDev> segs(1);
+    std::vector<uint64_t> bnds;
+    for (uint64_t b : d->bounds) if (b > d->hist_abs) bnds.push_back(b - d->hist_abs);
+    bnds.push_back(H + n);
+    SegDev &s = segs[0];
+    s = SegDev{};
+    s.buf_off = 0; s.abs0 = d->hist_abs; s.seg_start = (int64_t)H; s.seg_end = (int64_t)(H + n);
+    s.bnd_off = 0; s.bnd_cnt = (uint32_t)bnds.size();
+    s.finish = finish ? 1 : 0;
+    s.flags = finish ? ((d->nowrap ? 0u : (uint32_t)SEG_ZLIB_TRAILER)) : (uint32_t)SEG_SYNC_PAD;
+    s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = 0;
+    std::vector<SegOut> res;
+    rc = d->eng->e.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, d->nowrap ? 0u : 2u, res, nullptr);
+    if (rc) return rc;
+    const uint64_t end_bit = res[0].end_bit;
+    const uint64_t bytes = (end_bit + 7) >> 3;
+    d->h_out.resize(bytes + 1);
+    if (bytes && hipMemcpy(d->h_out.data(), d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    if (d->carry_bits && bytes) d->h_out[0] |= d->carry_byte;
+    if (!d->nowrap) d->adler = res[0].adler32;
+    uint64_t whole = finish ? bytes : (end_bit >> 3);
+    d->outq.insert(d->outq.end(), d->h_out.begin(), d->h_out.begin() + whole);
+    if (finish) { d->carry_bits = 0; d->carry_byte = 0; }
+    else {
+        d->carry_bits = (uint32_t)(end_bit & 7);
+        d->carry_byte = d->carry_bits ? d->h_out[whole] : 0;
+    }
+    // slide the history: keep the last 65536 bytes (candidates reach 32506 back, their links another 32767)
+    d->bounds.push_back(d->hist_abs + H + n);
+    std::vector<uint8_t> nh;
+    const uint64_t keep = std::min<uint64_t>(H + n, 65536);
+    nh.reserve(keep);
+    if (keep > n) nh.insert(nh.end(), d->hist.end() - (keep - n), d->hist.end());
+    nh.insert(nh.end(), d->pend.end() - std::min<uint64_t>(keep, n), d->pend.end());
+    d->hist_abs = d->hist_abs + H + n - keep;
+    d->hist.swap(nh);
+    d->pend.clear();
+    d->bounds.erase(std::remove_if(d->bounds.begin(), d->bounds.end(), [&](uint64_t b) { return b <= d->hist_abs; }), d->bounds.end());
+    return 0;
+}
+
+int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Deflater.cs:427
+    if (!d || length < 0 || (!out && length)) return SZL_E_ARG;
+    if (d->state == CLOSED_STATE) return SZL_E_STATE;
+    const int orig = length;
+    if (d->state < BUSY_STATE) { // zlib header :436-464
+        int hdr = zlib_header(d->level);
+        d->outq.push_back((uint8_t)(hdr >> 8)); d->outq.push_back((uint8_t)hdr);
+        d->state = BUSY_STATE | (d->state & (IS_FLUSHING | IS_FINISHING));
+    }
+    for (;;) {
+        size_t avail = d->outq.size() - d->outpos;
+        size_t k = std::min<size_t>(avail, (size_t)length);
+        if (k) { memcpy(out, d->outq.data() + d->outpos, k); d->outpos += k; out += k; length -= (int)k; d->total_out += (int64_t)k; }
+        if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }
+        if (length == 0 || d->state == FINISHED_STATE) break;
+        if (d->state == BUSY_STATE) break; // "We need more input now" :482-484
+        int rc;
+        if (d->state == FLUSHING_STATE) { if ((rc = run_segment(d, false))) return rc; d->state = BUSY_STATE; }
+        else if (d->state == FINISHING_STATE) { if ((rc = run_segment(d, true))) return rc; d->state = FINISHED_STATE; }
+        else return SZL_E_STATE;
+    }
+    return orig - length;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-memory checksum helpers (device kernels; used by the shim's Adler getter and by tests)
+int szl_crc32(uint32_t value, const void *host_data, size_t n, uint32_t *out);
+int szl_adler32(uint32_t value, const void *host_data, size_t n, uint32_t *out);
+
+} // extern "C"
+
+namespace szl {
+void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
+                      SegOut *so, unsigned want, hipStream_t st);
+size_t checksum_partial_bytes();
+}
+
+static int checksum_host(unsigned want, uint32_t value, const void *data, size_t n, uint32_t *out) {
+    if (!out || (!data && n)) return SZL_E_ARG;
+    if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
+    DevBuf din, dseg, doff, dparts, dso;
+    int rc = 0;
+    SegDev s{}; s.seg_start = 0; s.seg_end = (int64_t)n; s.adler_init = value; s.crc_init = value;
+    uint64_t off[2] = {0, (n + 4095) / 4096};
+    SegOut so{};
+    if ((rc = din.ensure(n + 64)) || (rc = dseg.ensure(sizeof s)) || (rc = doff.ensure(sizeof off)) ||
+        (rc = dparts.ensure((off[1] + 1) * checksum_partial_bytes())) || (rc = dso.ensure(sizeof so))) goto done;
+    if ((n && hipMemcpy(din.p, data, n, hipMemcpyHostToDevice) != hipSuccess) || hipMemcpy(dseg.p, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(doff.p, off, sizeof off, hipMemcpyHostToDevice) != hipSuccess) { rc = SZL_E_DEVICE; goto done; }
+    launch_checksums((const uint8_t *)din.p, (const SegDev *)dseg.p, 1, (const uint64_t *)doff.p, off[1], dparts.p, (SegOut *)dso.p, want, nullptr);
+    if (hipMemcpy(&so, dso.p, sizeof so, hipMemcpyDeviceToHost) != hipSuccess) { rc = SZL_E_DEVICE; goto done; }
+    *out = (want & 1) ? so.crc32 : so.adler32;
+done:
+    din.release(); dseg.release(); doff.release(); dparts.release(); dso.release();
+    return rc;
+}
+extern "C" int szl_crc32(uint32_t value, const void *p, size_t n, uint32_t *out) { return checksum_host(1, value, p, n, out); }
+extern "C" int szl_adler32(uint32_t value, const void *p, size_t n, uint32_t *out) { return checksum_host(2, value, p, n, out); }

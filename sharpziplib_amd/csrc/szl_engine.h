@@ -1,0 +1,39 @@
+// szl_engine.h — host-side engine object behind the C ABI (include/szl.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <vector>
+#include "../../include/szl.h"
+#include "szl_internal.h"
+
+namespace szl {
+
+void set_error(const char *fmt, ...);
+const char *last_error();
+int level_params(int level, int strategy, LevelParams *P);
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n);   // grow-only; contents are NOT preserved
+    void release();
+};
+
+class Engine {
+  public:
+    Engine();
+    ~Engine();
+    // Compress `segs` (see SegDev) found in the input arena d_in[0..in_total) into d_out[0..out_total).
+    // d_out and every seg.out_off must be 4-byte aligned.  Synchronous.
+    int deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
+                const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st);
+
+    szl_timing timing{};
+    uint64_t last_nranges = 0, last_in_total = 0, last_blk_slots = 0;
+    DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
+        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out;
+    hipEvent_t ev[8];
+};
+
+} // namespace szl

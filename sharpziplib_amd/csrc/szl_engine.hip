@@ -1,0 +1,210 @@
+// szl_engine.hip — host side of the device pipeline: workspace, work tables, launches, timing.
+// Product code: never includes or links anything from oracle/.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "szl_engine.h"
+
+namespace szl {
+
+// ---- launch wrappers implemented in the kernel translation units
+void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans, int nspans,
+                  uint16_t *link, hipStream_t st);
+hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, uint2 *mtab,
+                        LevelParams P, hipStream_t st);
+void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                 LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, hipStream_t st);
+void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st);
+void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st);
+void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts, hipStream_t st);
+void launch_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                 LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
+                 const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos, unsigned long long *counters, hipStream_t st);
+void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so, hipStream_t st);
+void launch_block_build(const SegDev *segs, uint32_t nseg, const SegOut *so, const uint64_t *blk_off, const uint32_t *tokens,
+                        const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, hipStream_t st);
+void launch_block_scan(const SegDev *segs, uint32_t nseg, SegOut *so, BlockDesc *descs, hipStream_t st);
+void launch_block_encode(const uint8_t *in, uint8_t *out, const SegDev *segs, const BlockDesc *descs, const uint32_t *tokens,
+                         uint32_t nslots, hipStream_t st);
+void launch_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint8_t *out, hipStream_t st);
+void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
+                      SegOut *so, unsigned want, hipStream_t st);
+size_t checksum_partial_bytes();
+
+thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return SZL_E_DEVICE; } } while (0)
+
+int level_params(int level, int strategy, LevelParams *P) { // C/DeflaterConstants.cs:124-144
+    static const int GOOD[10] = {0, 4, 4, 4, 4, 8, 8, 8, 32, 32};
+    static const int NICE[10] = {0, 8, 16, 32, 16, 32, 128, 128, 258, 258};
+    static const int CHAIN[10] = {0, 4, 8, 32, 16, 32, 128, 256, 1024, 4096};
+    if (level == -1) level = 6;
+    if (level < 0 || level > 9) return SZL_E_ARG;
+    if (level < 5) return SZL_E_UNSUPPORTED; // DeflateStored / DeflateFast: not on the device path yet
+    P->good = GOOD[level]; P->nice = NICE[level]; P->max_chain = CHAIN[level]; P->strategy = strategy;
+    return 0;
+}
+
+int DevBuf::ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = n + (n >> 3) + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return SZL_E_NOMEM; }
+    cap = want;
+    return 0;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+Engine::Engine() {
+    for (auto &e : ev) e = nullptr;
+}
+Engine::~Engine() {
+    for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out})
+        b->release();
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+}
+
+template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t st) {
+    int rc = b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) { hipError_t e = hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("H2D table copy failed: %s", hipGetErrorString(e)); return SZL_E_DEVICE; } }
+    return 0;
+}
+
+int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
+                    const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st) {
+    const uint32_t nseg = (uint32_t)segs.size();
+    results.assign(nseg, SegOut{});
+    if (nseg == 0) return 0;
+    memset(&timing, 0, sizeof timing);
+    for (auto &e : ev) if (!e) HIPCHK(hipEventCreate(&e));
+
+    // ---------------- work tables
+    uint64_t total_emit = 0, nranges = 0, vis_words = 0, nchunks = 0, ntiles = 0, blk_slots = 0, seg_bytes = 0;
+    for (auto &s : segs) total_emit += (uint64_t)(s.seg_end - std::max<int64_t>(0, s.seg_start - WSIZE));
+    uint64_t span_len = (total_emit + 511) / 512;
+    span_len = std::min<uint64_t>(std::max<uint64_t>(span_len, 1u << 17), 1u << 22);
+    span_len = (span_len + 63) & ~63ull;
+    std::vector<SpanDev> spans;
+    std::vector<TileDev> tiles;
+    std::vector<uint64_t> chunk_off(nseg + 1);
+    for (uint32_t i = 0; i < nseg; i++) {
+        SegDev &s = segs[i];
+        const uint64_t n = (uint64_t)(s.seg_end - s.seg_start);
+        seg_bytes += n;
+        int64_t e0 = std::max<int64_t>(0, s.seg_start - WSIZE);
+        if (n > 0)
+            for (int64_t a = e0; a < s.seg_end; a += (int64_t)span_len)
+                spans.push_back(SpanDev{i, 0, a, std::min<int64_t>(a + (int64_t)span_len, s.seg_end)});
+        for (int64_t a = s.seg_start; a < s.seg_end; a += B_TILE)
+            tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(B_TILE, s.seg_end - a), 0});
+        s.range_off = nranges;
+        s.range_cnt = (uint32_t)((n + C_RANGE - 1) / C_RANGE);
+        nranges += s.range_cnt;
+        s.vis_word_off = vis_words;
+        vis_words += (n + 31) / 32 + 1;
+        chunk_off[i] = nchunks;
+        nchunks += (n + 4095) / 4096;
+        blk_slots += n / BLOCK_TOKENS + 1;
+    }
+    chunk_off[nseg] = nchunks;
+    ntiles = tiles.size();
+    if (blk_slots > 0xFFFFFFF0ull || spans.size() > 0x7FFFFFFFull || ntiles > 0x7FFFFFFFull) { set_error("batch too large"); return SZL_E_ARG; }
+
+    // ---------------- workspace
+    int rc;
+    if ((rc = link.ensure(in_total * 2 + 64))) return rc;
+    if ((rc = mtab.ensure(in_total * 8 + 64))) return rc;
+    if ((rc = tokens.ensure((seg_bytes + 16) * 4))) return rc;
+    if ((rc = visited.ensure((vis_words + 4) * 4))) return rc;
+    if ((rc = ranges.ensure((nranges + 1) * sizeof(RangeDev)))) return rc;
+    if ((rc = counts.ensure((nranges + 2) * 4))) return rc;
+    if ((rc = range_tok.ensure((nranges + 2) * 8))) return rc;
+    if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc)))) return rc;
+    if ((rc = d_so.ensure(nseg * sizeof(SegOut)))) return rc;
+    if ((rc = blk_counts.ensure((nseg + 2) * 4))) return rc;
+    if ((rc = blk_off.ensure((nseg + 2) * 8))) return rc;
+    if ((rc = bsp.ensure((blk_slots + 1) * 8))) return rc;
+    if ((rc = blp.ensure((blk_slots + 1) * 8))) return rc;
+    if ((rc = counters.ensure(64))) return rc;
+    if (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) return rc;
+    if ((rc = upload(d_segs, segs, st))) return rc;
+    if ((rc = upload(d_bnds, bnds, st))) return rc;
+    if ((rc = upload(d_spans, spans, st))) return rc;
+    if ((rc = upload(d_tiles, tiles, st))) return rc;
+    if ((rc = upload(ckoff, chunk_off, st))) return rc;
+    size_t cub_bytes1 = 0, cub_bytes2 = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
+    if ((rc = cubtmp.ensure(std::max(cub_bytes1, cub_bytes2) + 256))) return rc;
+
+    const SegDev *dsegs = (const SegDev *)d_segs.p;
+    SegOut *dso = (SegOut *)d_so.p;
+    unsigned long long *dcnt = (unsigned long long *)counters.p;
+
+    HIPCHK(hipEventRecord(ev[0], st));
+    HIPCHK(hipMemsetAsync(d_out, 0, out_total, st));
+    HIPCHK(hipMemsetAsync(visited.p, 0, (vis_words + 4) * 4, st));
+    HIPCHK(hipMemsetAsync(counters.p, 0, 64, st));
+    HIPCHK(hipMemsetAsync(d_so.p, 0, nseg * sizeof(SegOut), st));
+    HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
+    HIPCHK(hipMemsetAsync(blk_counts.p, 0, (nseg + 2) * 4, st));
+    // checksums (also seeds so[].adler32 / crc32 with the running values when not requested)
+    launch_checksums(d_in, dsegs, nseg, (const uint64_t *)ckoff.p, want_ck ? nchunks : 0, ckparts.p, dso, want_ck, st);
+    HIPCHK(hipEventRecord(ev[1], st));
+    // A: hash links
+    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, st);
+    HIPCHK(hipEventRecord(ev[2], st));
+    // B: match tables
+    HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, (uint2 *)mtab.p, P, st));
+    HIPCHK(hipEventRecord(ev[3], st));
+    // C: parse
+    launch_spec(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
+    launch_fix(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
+    launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
+    launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
+    launch_emit(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p,
+                (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
+    HIPCHK(hipEventRecord(ev[4], st));
+    // D: blocks
+    launch_seg_blocks(dsegs, nseg, (const uint32_t *)tokens.p, (const uint64_t *)blk_off.p, dso, st);
+    launch_block_build(dsegs, nseg, dso, (const uint64_t *)blk_off.p, (const uint32_t *)tokens.p, (const int64_t *)bsp.p, (const int64_t *)blp.p,
+                       (BlockDesc *)descs.p, (uint32_t)blk_slots, st);
+    launch_block_scan(dsegs, nseg, dso, (BlockDesc *)descs.p, st);
+    HIPCHK(hipEventRecord(ev[5], st));
+    launch_block_encode(d_in, d_out, dsegs, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);
+    launch_seg_finish(dsegs, nseg, dso, d_out, st);
+    HIPCHK(hipEventRecord(ev[6], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(results.data(), d_so.p, nseg * sizeof(SegOut), hipMemcpyDeviceToHost, st));
+    unsigned long long hc[8] = {0};
+    HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    float ms[6] = {0};
+    for (int i = 0; i < 6; i++) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    timing.checksum_ms = ms[0]; timing.links_ms = ms[1]; timing.match_ms = ms[2]; timing.parse_ms = ms[3];
+    timing.blocks_ms = ms[4]; timing.encode_ms = ms[5];
+    (void)hipEventElapsedTime(&timing.total_ms, ev[0], ev[6]);
+    timing.in_bytes = seg_bytes;
+    timing.ranges_unmerged = hc[0];
+    timing.fallback_walks = hc[1];
+    for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
+    last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
+    return 0;
+}
+
+} // namespace szl

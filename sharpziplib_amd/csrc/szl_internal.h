@@ -1,0 +1,90 @@
+// szl_internal.h — structures shared by the HIP kernels and the host engine (not part of the C ABI).
+//
+// Data layout in HBM.  One engine call works on an *input arena* (all streams'
+// bytes, device memory) and per-position side arrays indexed by the same byte offset g:
+//     in[g]       u8     input bytes
+//     link[g]     u16    stage A: distance to the previous inserted position with the same 3-byte hash
+//     mtab[g]     uint2  stage B: {M2, Mq} = FindLongestMatch(p) from matchLen 2, full / quarter chain budget
+//     visited     1 bit  stage C: "a speculative parse of this position's range had a clean iteration here"
+//     tokens[]    u32    stage C: dense token stream (literal byte | dist<<16 | len)
+// A *segment* is the span of one stream between two Flush()/Finish() calls; all kernels are driven
+// by small per-segment / per-tile tables built on the host.
+#pragma once
+#include <stdint.h>
+
+namespace szl {
+
+enum : int { WSIZE = 32768, MAX_DIST = 32506, MAX_MATCH = 258, MIN_MATCH = 3, TOO_FAR = 4096, BLOCK_TOKENS = 16384 };
+enum : int { LIT_NUM = 286, DIST_NUM = 30, BL_NUM = 19 };
+
+struct LevelParams { int good, nice, max_chain, strategy; };
+
+struct SegDev {
+    uint64_t buf_off;    // arena offset of buffer position 0 of this segment's stream window
+    uint64_t abs0;       // absolute stream position of buffer position 0 (window base arithmetic)
+    int64_t seg_start;   // buffer position of the first byte to parse (bytes before it are history)
+    int64_t seg_end;     // buffer position one past the last byte
+    uint32_t bnd_off;    // boundaries (segment ends of this stream inside the buffer, ascending, last == seg_end)
+    uint32_t bnd_cnt;
+    uint32_t finish;     // segment closed by Finish() (else by Flush())
+    uint32_t flags;      // SEG_* below
+    uint64_t range_off;  // first stage-C range of this segment
+    uint32_t range_cnt;
+    uint32_t pad0;
+    uint64_t out_off;    // output arena offset of this segment's output region
+    uint64_t out_cap;    // bytes
+    uint32_t start_bit;  // bit offset inside the region at which this segment's first block starts
+    uint32_t stream_idx; // caller's stream index (results)
+    uint64_t vis_word_off; // first 32-bit word of this segment's `visited` bitmap (bit i = position seg_start+i)
+    uint32_t adler_init;   // running Adler32.Value before this segment's bytes (zlib framing)
+    uint32_t crc_init;     // running Crc32.Value before this segment's bytes
+};
+enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4 };
+
+struct SpanDev { uint32_t seg; uint32_t pad; int64_t start, end; };          // stage A: emit links for [start,end)
+struct TileDev { uint32_t seg; uint32_t pad; int64_t start; int32_t len; int32_t pad2; }; // stage B tile
+
+enum : int { B_TILE = 16384, B_HIST = 32512, B_TAIL = 264 };
+enum : int { C_RANGE = 4096 };
+
+// Per-range results of stage C
+struct RangeDev {
+    int64_t exit_spec;   // first clean position >= range end reached by the speculative walk from range start
+    int64_t exit_true;   // same for the true parse (after fix-up / resolve)
+    int64_t entry;       // clean position at which the true parse enters the range
+    uint32_t spec_count; // tokens owned by spec nodes in the range
+    uint32_t true_count; // tokens owned by true nodes in [entry, range end)
+    uint32_t merged;     // 1 if the fix-up walk landed on the speculative path inside the range
+    uint32_t pad;
+};
+
+struct SegOut {          // per-segment results written by the device
+    uint64_t tok_first;  // index of the first token of the segment in tokens[]
+    uint64_t tok_count;
+    uint32_t blk_first;  // index of first block descriptor
+    uint32_t blk_count;
+    uint64_t end_bit;    // bit offset (inside out region) after the last block / trailer
+    uint64_t out_bytes;  // bytes of output (incl. a trailing partial byte)
+    uint32_t crc32, adler32;
+};
+
+struct BlockDesc {
+    uint32_t seg;
+    uint32_t type;        // 0 stored, 1 static, 2 dynamic
+    uint32_t last;
+    uint32_t ntok;
+    uint64_t tok_first;   // global token index
+    int64_t in_start;     // buffer position of first input byte covered
+    uint32_t in_len;      // bytes covered (stored length)
+    uint32_t hdr_bits;    // dynamic header bits (after the 3-bit block header)
+    uint64_t body_bits;   // bits of header(3) + trees + tokens + EOB (non-stored) ; for stored: 3 (before alignment)
+    uint64_t bit_start;   // absolute bit position inside the segment's out region
+    uint16_t lcode[LIT_NUM];
+    uint8_t llen[LIT_NUM];
+    uint16_t dcode[DIST_NUM];
+    uint8_t dlen[DIST_NUM];
+    uint32_t opt_len, static_len; // for the parity taps
+    uint8_t hdr[640];     // pre-rendered dynamic header bitstream, LSB-first
+};
+
+} // namespace szl

@@ -1,0 +1,613 @@
+// szl_kernels_block.hip — stage D: DeflaterHuffman (C/DeflaterHuffman.cs) on the device.
+//   k_seg_blocks   block count per segment            C/DeflaterEngine.cs:841-852, :750-768
+//   k_block_build  per block: tally (TallyLit/TallyDist :873,:894), BuildTree x3 (:196), BuildLength (:475),
+//                  CalcBLFreq (:349), opt_len/static_len/stored decision (FlushBlock :788-857),
+//                  BuildCodes (:151), header rendering (SendAllTrees :676, WriteTree :411)
+//   k_block_scan   bit offset of every block inside its segment's output (PendingBuffer.WriteBits/AlignToByte
+//                  C/PendingBuffer.cs:168,:143 are a running bit position)
+//   k_block_encode CompressBlock (:701) / FlushStoredBlock (:766): tokens -> bits at their final position
+//   k_seg_finish   Deflater.Deflate's FLUSHING/FINISHING tails (C/Deflater.cs:486-517)
+// The Huffman construction is sequential by nature (heap with value<<8|depth keys, strict comparisons, forced
+// second symbol, overflow repair in childs[] order); it is restated verbatim and run by one lane per tree.
+#include <hip/hip_runtime.h>
+#include "szl_internal.h"
+
+namespace szl {
+
+__device__ __forceinline__ int64_t base_of_b(int64_t s_abs) {
+    int64_t idx = s_abs + 1;
+    if (idx <= 65273) return 0;
+    return ((idx - 65273 + 32767) >> 15) << 15;
+}
+
+__device__ __forceinline__ int lcode_of(int l /* len-3 */) { // Lcode :932
+    if (l == 255) return 285;
+    if (l < 8) return 257 + l;
+    int k = 31 - __builtin_clz((unsigned)l);
+    return 257 + 4 * (k - 2) + (l >> (k - 2));
+}
+__device__ __forceinline__ int dcode_of(int dd /* dist-1 */) { // Dcode :948
+    if (dd < 4) return dd;
+    int k = 31 - __builtin_clz((unsigned)dd);
+    return 2 * (k - 1) + (dd >> (k - 1));
+}
+__device__ __forceinline__ uint32_t bitrev16(uint32_t v) { return __builtin_bitreverse32(v) >> 16; } // BitReverse :924
+
+__device__ __forceinline__ void static_lit(int sym, uint32_t &code, int &len) { // static ctor :602-631
+    if (sym < 144) { code = bitrev16((0x030 + sym) << 8); len = 8; }
+    else if (sym < 256) { code = bitrev16((0x190 - 144 + sym) << 7); len = 9; }
+    else if (sym < 280) { code = bitrev16((0x000 - 256 + sym) << 9); len = 7; }
+    else { code = bitrev16((0x0c0 - 280 + sym) << 8); len = 8; }
+}
+
+__global__ void k_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so) {
+    uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nseg) return;
+    const uint64_t T = so[si].tok_count;
+    uint64_t full = T / BLOCK_TOKENS, rem = T % BLOCK_TOKENS;
+    uint64_t nb = full;
+    if (rem > 0 || T == 0) nb++;
+    else if ((tokens[so[si].tok_first + T - 1] >> 16) != 0 && !segs[si].finish) nb++; // sync flush right after a full block
+    so[si].blk_first = (uint32_t)blk_off[si];
+    so[si].blk_count = (uint32_t)nb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree construction in LDS by a single lane (verbatim control flow of Tree.BuildTree / BuildLength).
+struct TreeScratch {
+    int heap[LIT_NUM];
+    int hval[LIT_NUM];         // values[heap[i]] cached next to heap[i]
+    short childs[4 * LIT_NUM];
+    int values[2 * LIT_NUM];
+    unsigned char lengths[2 * LIT_NUM];
+};
+
+__device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, int maxLength, TreeScratch *S,
+                           unsigned char *length /*[numSymbols]*/, int *bl_counts /*[15]*/, int *numCodesOut) {
+    int *heap = S->heap, *hval = S->hval, *values = S->values;
+    short *childs = S->childs;
+    int heapLen = 0, maxCode = 0;
+    for (int n = 0; n < numSymbols; n++) {
+        int freq = freqs[n];
+        if (freq != 0) {
+            int pos = heapLen++;
+            int ppos;
+            while (pos > 0 && freqs[heap[ppos = (pos - 1) / 2]] > freq) { heap[pos] = heap[ppos]; pos = ppos; }
+            heap[pos] = n;
+            maxCode = n;
+        }
+    }
+    while (heapLen < 2) {
+        int node = maxCode < 2 ? ++maxCode : 0;
+        heap[heapLen++] = node;
+    }
+    *numCodesOut = (maxCode + 1 > minNumCodes) ? maxCode + 1 : minNumCodes;
+    const int numLeafs = heapLen;
+    const int childsLen = 4 * heapLen - 2;
+    int numNodes = numLeafs;
+    for (int i = 0; i < heapLen; i++) {
+        int node = heap[i];
+        childs[2 * i] = (short)node;
+        childs[2 * i + 1] = -1;
+        int v = freqs[node] << 8;
+        values[i] = v;
+        heap[i] = i;
+        hval[i] = v;
+    }
+    do {
+        int first = heap[0];
+        int firstVal = hval[0];
+        --heapLen;
+        int last = heap[heapLen];
+        int lastVal = hval[heapLen];
+        int ppos = 0, path = 1;
+        while (path < heapLen) {
+            int pv = hval[path];
+            if (path + 1 < heapLen) { int pv1 = hval[path + 1]; if (pv > pv1) { path++; pv = pv1; } }
+            heap[ppos] = heap[path]; hval[ppos] = pv;
+            ppos = path;
+            path = path * 2 + 1;
+        }
+        while ((path = ppos) > 0) {
+            ppos = (path - 1) / 2;
+            int pv = hval[ppos];
+            if (!(pv > lastVal)) break;
+            heap[path] = heap[ppos]; hval[path] = pv;
+        }
+        heap[path] = last; hval[path] = lastVal;
+
+        int second = heap[0];
+        int secondVal = hval[0];
+        last = numNodes++;
+        childs[2 * last] = (short)first;
+        childs[2 * last + 1] = (short)second;
+        int d1 = firstVal & 0xff, d2 = secondVal & 0xff;
+        int mindepth = d1 < d2 ? d1 : d2;
+        lastVal = firstVal + secondVal - mindepth + 1;
+        values[last] = lastVal;
+
+        ppos = 0; path = 1;
+        while (path < heapLen) {
+            int pv = hval[path];
+            if (path + 1 < heapLen) { int pv1 = hval[path + 1]; if (pv > pv1) { path++; pv = pv1; } }
+            heap[ppos] = heap[path]; hval[ppos] = pv;
+            ppos = path;
+            path = ppos * 2 + 1;
+        }
+        while ((path = ppos) > 0) {
+            ppos = (path - 1) / 2;
+            int pv = hval[ppos];
+            if (!(pv > lastVal)) break;
+            heap[path] = heap[ppos]; hval[path] = pv;
+        }
+        heap[path] = last; hval[path] = lastVal;
+    } while (heapLen > 1);
+
+    // ---- BuildLength :475
+    for (int i = 0; i < numSymbols; i++) length[i] = 0;
+    const int nNodes = childsLen / 2;
+    int overflow = 0;
+    for (int i = 0; i < maxLength; i++) bl_counts[i] = 0;
+    unsigned char *lengths = S->lengths;
+    lengths[nNodes - 1] = 0;
+    for (int i = nNodes - 1; i >= 0; i--) {
+        if (childs[2 * i + 1] != -1) {
+            int bitLength = lengths[i] + 1;
+            if (bitLength > maxLength) { bitLength = maxLength; overflow++; }
+            lengths[childs[2 * i]] = lengths[childs[2 * i + 1]] = (unsigned char)bitLength;
+        } else {
+            int bitLength = lengths[i];
+            bl_counts[bitLength - 1]++;
+            length[childs[2 * i]] = (unsigned char)bitLength;
+        }
+    }
+    if (overflow == 0) return;
+    int incrBitLen = maxLength - 1;
+    do {
+        while (bl_counts[--incrBitLen] == 0) { }
+        do {
+            bl_counts[incrBitLen]--;
+            bl_counts[++incrBitLen]++;
+            overflow -= 1 << (maxLength - 1 - incrBitLen);
+        } while (overflow > 0 && incrBitLen < maxLength - 1);
+    } while (overflow > 0);
+    bl_counts[maxLength - 1] += overflow;
+    bl_counts[maxLength - 2] -= overflow;
+    int nodePtr = 2 * numLeafs;
+    for (int bits = maxLength; bits != 0; bits--) {
+        int n = bl_counts[bits - 1];
+        while (n > 0) {
+            int childPtr = 2 * childs[nodePtr++];
+            if (childs[childPtr + 1] == -1) {
+                length[childs[childPtr]] = (unsigned char)bits;
+                n--;
+            }
+        }
+    }
+}
+
+// CalcBLFreq :349 / WriteTree :411 share this scanner; `emit(sym, extra_val, extra_bits)` is called per bl symbol.
+template <typename F>
+__device__ void scan_code_lengths(const unsigned char *length, int numCodes, F emit) {
+    int max_count, min_count, count, curlen = -1;
+    int i = 0;
+    while (i < numCodes) {
+        count = 1;
+        int nextlen = length[i];
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        else {
+            max_count = 6; min_count = 3;
+            if (curlen != nextlen) { emit(nextlen, 0, 0); count = 0; }
+        }
+        curlen = nextlen;
+        i++;
+        while (i < numCodes && curlen == length[i]) {
+            i++;
+            if (++count >= max_count) break;
+        }
+        if (count < min_count) { while (count-- > 0) emit(curlen, 0, 0); }
+        else if (curlen != 0) emit(16, count - 3, 2);
+        else if (count <= 10) emit(17, count - 3, 3);
+        else emit(18, count - 11, 7);
+    }
+}
+
+struct BitW { // LSB-first bit writer into an LDS byte array
+    unsigned char *p;
+    unsigned long long acc;
+    int nacc;
+    int total;
+    __device__ void put(unsigned v, int n) {
+        acc |= (unsigned long long)v << nacc;
+        nacc += n; total += n;
+        while (nacc >= 8) { *p++ = (unsigned char)acc; acc >>= 8; nacc -= 8; }
+    }
+    __device__ void flush() { if (nacc > 0) { *p++ = (unsigned char)acc; acc = 0; nacc = 0; } }
+};
+
+__constant__ int c_bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; // :37
+
+enum : int { D_THREADS = 256 };
+
+__global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restrict__ segs, uint32_t nseg,
+                                                           const SegOut *__restrict__ so, const uint64_t *__restrict__ blk_off,
+                                                           const uint32_t *__restrict__ tokens,
+                                                           const int64_t *__restrict__ blk_start_pos,
+                                                           const int64_t *__restrict__ blk_lasttok_pos, BlockDesc *descs,
+                                                           uint32_t nblk_slots) {
+    __shared__ int lfreq[LIT_NUM + 2], dfreq[DIST_NUM + 2], blfreq[BL_NUM + 1];
+    __shared__ unsigned char llen[LIT_NUM + 2], dlen[DIST_NUM + 2], bllen[BL_NUM + 1];
+    __shared__ int lblc[15], dblc[15], blblc[15];
+    __shared__ int lnum, dnum, blnum, extra_bits, s_sums[4];
+    __shared__ unsigned short blcode[BL_NUM + 1];
+    __shared__ TreeScratch scrL, scrD;
+    __shared__ unsigned char hdr[640];
+    __shared__ int s_type, s_hdrbits;
+
+    const uint32_t gb = blockIdx.x;
+    if (gb >= nblk_slots) return;
+    // which segment owns block slot gb
+    uint32_t lo = 0, hi = nseg - 1;
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (blk_off[mid] <= gb) lo = mid; else hi = mid - 1; }
+    const uint32_t si = lo;
+    const uint32_t lb = gb - (uint32_t)blk_off[si];
+    BlockDesc *bd = &descs[gb];
+    const int tid = threadIdx.x;
+    if (lb >= so[si].blk_count) { if (tid == 0) bd->type = 0xFFu; return; }
+    const SegDev s = segs[si];
+    const uint64_t T = so[si].tok_count;
+    const uint64_t tfirst = so[si].tok_first + (uint64_t)lb * BLOCK_TOKENS;
+    const uint64_t tdone = (uint64_t)lb * BLOCK_TOKENS;
+    const int ntok = (int)(T > tdone ? (T - tdone < BLOCK_TOKENS ? T - tdone : BLOCK_TOKENS) : 0);
+    const int last = (s.finish && lb == so[si].blk_count - 1) ? 1 : 0;
+
+    for (int i = tid; i < LIT_NUM + 2; i += D_THREADS) lfreq[i] = 0;
+    if (tid < DIST_NUM + 2) dfreq[tid] = 0;
+    if (tid < BL_NUM + 1) blfreq[tid] = 0;
+    if (tid == 0) extra_bits = 0;
+    __syncthreads();
+    int ex = 0;
+    for (int i = tid; i < ntok; i += D_THREADS) {
+        uint32_t t = tokens[tfirst + i];
+        uint32_t dist = t >> 16;
+        if (dist == 0) atomicAdd(&lfreq[t & 0xFF], 1);
+        else {
+            int lc = lcode_of((int)(t & 0xFFFF) - 3), dc = dcode_of((int)dist - 1);
+            atomicAdd(&lfreq[lc], 1);
+            atomicAdd(&dfreq[dc], 1);
+            if (lc >= 265 && lc < 285) ex += (lc - 261) / 4; // :903-906
+            if (dc >= 4) ex += dc / 2 - 1;                   // :910-913
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
+    if ((tid & 63) == 0 && ex) atomicAdd(&extra_bits, ex);
+    __syncthreads();
+    if (tid == 0) lfreq[256]++; // EOF_SYMBOL :790
+    __syncthreads();
+    if (tid == 0) build_tree(lfreq, LIT_NUM, 257, 15, &scrL, llen, lblc, &lnum);
+    if (tid == 64) build_tree(dfreq, DIST_NUM, 1, 15, &scrD, dlen, dblc, &dnum);
+    __syncthreads();
+    if (tid == 0) {
+        scan_code_lengths(llen, lnum, [&](int sym, int, int) { blfreq[sym]++; });
+        scan_code_lengths(dlen, dnum, [&](int sym, int, int) { blfreq[sym]++; });
+        build_tree(blfreq, BL_NUM, 4, 7, &scrD, bllen, blblc, &blnum);
+    }
+    __syncthreads();
+    // encoded lengths (GetEncodedLength :331) and static_len (:815-823) in parallel
+    int a = 0, st = 0, abl = 0;
+    for (int i = tid; i < LIT_NUM; i += D_THREADS) {
+        uint32_t c; int l;
+        static_lit(i, c, l);
+        a += lfreq[i] * llen[i];
+        st += lfreq[i] * l;
+    }
+    if (tid < DIST_NUM) { a += dfreq[tid] * dlen[tid]; st += dfreq[tid] * 5; }
+    if (tid < BL_NUM) abl = blfreq[tid] * bllen[tid];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); st += __shfl_xor(st, o); abl += __shfl_xor(abl, o); }
+    if (tid < 4) s_sums[tid] = 0;
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicAdd(&s_sums[0], a); atomicAdd(&s_sums[1], st); atomicAdd(&s_sums[2], abl); }
+    __syncthreads();
+
+    const int64_t in_start = ntok > 0 ? blk_start_pos[gb] : s.seg_end;
+    int64_t in_next = s.seg_end;
+    if (lb + 1 < so[si].blk_count && T > tdone + BLOCK_TOKENS) in_next = blk_start_pos[gb + 1];
+    const int in_len = (int)(in_next - in_start);
+
+    if (tid == 0) {
+        int blTreeCodes = 4;
+        for (int i = 18; i > blTreeCodes; i--) if (bllen[c_bl_order[i]] > 0) blTreeCodes = i + 1; // :803-810
+        int opt_len = 14 + blTreeCodes * 3 + s_sums[2] + s_sums[0] + extra_bits; // :811-813 (NB: omits the repeat codes' extra bits)
+        int static_len = extra_bits + s_sums[1];
+        if (opt_len >= static_len) opt_len = static_len;             // :824-828
+        // storedOffset = window index of the block start when FlushBlock runs (:830): base of the iteration that
+        // emitted the block's last token, s = min(u+1, n-1)
+        int storedOffsetOk = 0;
+        if (ntok > 0) {
+            int64_t u = blk_lasttok_pos[gb];
+            int64_t sIter = u + 1 < s.seg_end - 1 ? u + 1 : s.seg_end - 1;
+            int64_t base = base_of_b((int64_t)s.abs0 + sIter);
+            storedOffsetOk = ((int64_t)s.abs0 + in_start + 1 - base) >= 0;
+        }
+        int type;
+        if (storedOffsetOk && in_len + 4 < (opt_len >> 3)) type = 0;
+        else if (opt_len == static_len) type = 1;
+        else type = 2;
+        s_type = type;
+        BitW w; w.p = hdr; w.acc = 0; w.nacc = 0; w.total = 0;
+        w.put((unsigned)((type << 1) + last), 3); // :773,:843,:852
+        if (type == 2) { // SendAllTrees :676
+            // bl codes (BuildCodes :151 for the 19-symbol tree)
+            int nextCode[7], code = 0;
+            for (int bits = 0; bits < 7; bits++) { nextCode[bits] = code; code += blblc[bits] << (15 - bits); }
+            for (int i = 0; i < blnum; i++) {
+                int bits = bllen[i];
+                if (bits > 0) { blcode[i] = (unsigned short)bitrev16((uint32_t)nextCode[bits - 1]); nextCode[bits - 1] += 1 << (16 - bits); }
+            }
+            w.put((unsigned)(lnum - 257), 5);
+            w.put((unsigned)(dnum - 1), 5);
+            w.put((unsigned)(blTreeCodes - 4), 4);
+            for (int rank = 0; rank < blTreeCodes; rank++) w.put(bllen[c_bl_order[rank]], 3);
+            auto emit = [&](int sym, int xv, int xb) { w.put(blcode[sym], bllen[sym]); if (xb) w.put((unsigned)xv, xb); };
+            scan_code_lengths(llen, lnum, emit);
+            scan_code_lengths(dlen, dnum, emit);
+        }
+        w.flush();
+        s_hdrbits = w.total;
+        bd->seg = si; bd->type = (uint32_t)type; bd->last = (uint32_t)last; bd->ntok = (uint32_t)ntok;
+        bd->tok_first = tfirst; bd->in_start = in_start; bd->in_len = (uint32_t)in_len;
+        bd->hdr_bits = (uint32_t)w.total;
+        bd->opt_len = (uint32_t)opt_len; bd->static_len = (uint32_t)static_len;
+        // body_bits: everything this block writes when it starts at a byte-agnostic position
+        // body_bits = bits actually written.  opt_len is only the reference's *estimate*: GetEncodedLength (:331)
+        // does not count the 2/3/7 extra bits of bl symbols 16/17/18, so a dynamic block is longer than 3+opt_len.
+        if (type == 0) bd->body_bits = 3;                                  // + alignment + 32 + 8*len, added by the scan
+        else if (type == 1) bd->body_bits = 3 + (uint64_t)static_len;
+        else bd->body_bits = (uint64_t)w.total + (uint64_t)s_sums[0] + (uint64_t)extra_bits;
+    }
+    __syncthreads();
+    const int type = s_type;
+    // code tables (BuildCodes :151) — canonical code of symbol i = nextCode[len] + (#earlier symbols of equal length)
+    for (int i = tid; i < LIT_NUM; i += D_THREADS) {
+        uint32_t code = 0; int len = 0;
+        if (type == 1) static_lit(i, code, len);
+        else if (type == 2) {
+            len = i < lnum ? llen[i] : 0;
+            if (len > 0) {
+                int base = 0;
+                for (int b = 0; b < len - 1; b++) base += lblc[b] << (15 - b);
+                int rank = 0;
+                for (int j = 0; j < i; j++) rank += (llen[j] == len);
+                code = bitrev16((uint32_t)(base + (rank << (16 - len))));
+            }
+        }
+        bd->lcode[i] = (uint16_t)code; bd->llen[i] = (uint8_t)len;
+    }
+    if (tid < DIST_NUM) {
+        uint32_t code = 0; int len = 0;
+        if (type == 1) { code = bitrev16((uint32_t)tid << 11); len = 5; } // :633-642
+        else if (type == 2) {
+            len = tid < dnum ? dlen[tid] : 0;
+            if (len > 0) {
+                int base = 0;
+                for (int b = 0; b < len - 1; b++) base += dblc[b] << (15 - b);
+                int rank = 0;
+                for (int j = 0; j < tid; j++) rank += (dlen[j] == len);
+                code = bitrev16((uint32_t)(base + (rank << (16 - len))));
+            }
+        }
+        bd->dcode[tid] = (uint16_t)code; bd->dlen[tid] = (uint8_t)len;
+    }
+    const int hb = (s_hdrbits + 7) >> 3;
+    for (int i = tid; i < hb; i += D_THREADS) bd->hdr[i] = hdr[i];
+}
+
+// Bit position of every block: one wavefront per segment, 64 blocks per step.  Stored blocks align to a byte
+// after their 3 header bits (FlushStoredBlock :766-779), so the running position is a scan with a per-block
+// function of (position mod 8).  Blocks are few (<= n/16384+1 per segment): a serial carry between
+// 64-wide steps is enough.
+__global__ __launch_bounds__(64) void k_block_scan(const SegDev *segs, uint32_t nseg, SegOut *so, BlockDesc *descs) {
+    uint32_t si = blockIdx.x;
+    if (si >= nseg) return;
+    const int lane = threadIdx.x;
+    const uint32_t nb = so[si].blk_count, b0 = so[si].blk_first;
+    uint64_t pos = segs[si].start_bit;
+    for (uint32_t k0 = 0; k0 < nb; k0 += 64) {
+        uint32_t k = k0 + lane;
+        // delta[r] for r = start mod 8
+        uint64_t body = 0; uint32_t type = 1, inlen = 0;
+        if (k < nb) { body = descs[b0 + k].body_bits; type = descs[b0 + k].type; inlen = descs[b0 + k].in_len; }
+        uint64_t start = pos;
+        // serial within the 64-wide step via shuffles: lane i needs end of lane i-1
+        for (int i = 0; i < 64; i++) {
+            uint64_t st_i = __shfl(start, i);
+            uint64_t b_i = __shfl(body, i);
+            uint32_t t_i = __shfl(type, i);
+            uint32_t l_i = __shfl(inlen, i);
+            uint64_t end_i;
+            if (t_i == 0) end_i = ((st_i + 3 + 7) & ~7ull) + 32 + 8ull * l_i;
+            else end_i = st_i + b_i;
+            if (k0 + i >= nb) end_i = st_i;
+            if (lane == i + 1) start = end_i;
+            if (i == 63) pos = end_i;
+        }
+        pos = __shfl(pos, 0);
+        if (k < nb) descs[b0 + k].bit_start = start;
+    }
+    if (lane == 0) so[si].end_bit = pos;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encode.  One workgroup per block; 256 tokens per step.  Bits are assembled in an LDS staging area
+// with LDS atomic OR (each token code is <= 48 bits at an arbitrary bit offset) and flushed with plain
+// dword stores; only the first and last dword of a step can be shared with a neighbour step/block and
+// use a global atomic OR into the pre-zeroed output.
+enum : int { E_THREADS = 256, E_STAGE_DW = 400 };
+
+__device__ __forceinline__ void lds_or_bits(uint32_t *stage, uint32_t bitoff, unsigned long long v, int nbits) {
+    if (nbits == 0) return;
+    uint32_t w = bitoff >> 5, sh = bitoff & 31;
+    // v has <= 48 significant bits; shifted it spans <= 3 dwords
+    unsigned long long lo = v << sh;
+    atomicOr(&stage[w], (uint32_t)lo);
+    uint32_t mid = (uint32_t)(lo >> 32);
+    if (sh + nbits > 32) atomicOr(&stage[w + 1], mid);
+    if (sh + nbits > 64) atomicOr(&stage[w + 2], (uint32_t)(v >> (64 - sh)));
+}
+
+__device__ void flush_stage(uint32_t *stage, uint32_t *out32, uint64_t bit_lo, uint64_t bit_hi /*exclusive*/, int tid) {
+    // stage[0] corresponds to dword (bit_lo>>5)
+    if (bit_hi <= bit_lo) return;
+    uint64_t w0 = bit_lo >> 5, w1 = (bit_hi - 1) >> 5;
+    int n = (int)(w1 - w0 + 1);
+    for (int i = tid; i < n; i += E_THREADS) {
+        uint32_t v = stage[i];
+        if (i == 0 || i == n - 1) { if (v) atomicOr(&out32[w0 + i], v); }
+        else out32[w0 + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(E_THREADS) void k_block_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                            const SegDev *__restrict__ segs, const BlockDesc *__restrict__ descs,
+                                                            const uint32_t *__restrict__ tokens, uint32_t nblk_slots) {
+    __shared__ uint32_t stage[E_STAGE_DW + 4];
+    __shared__ uint32_t wsum[E_THREADS / 64];
+    __shared__ uint16_t s_lcode[LIT_NUM]; __shared__ uint8_t s_llen[LIT_NUM];
+    __shared__ uint16_t s_dcode[DIST_NUM]; __shared__ uint8_t s_dlen[DIST_NUM];
+    const uint32_t gb = blockIdx.x;
+    if (gb >= nblk_slots) return;
+    const BlockDesc *bd = &descs[gb];
+    if (bd->type == 0xFFu) return;
+    const SegDev s = segs[bd->seg];
+    const int tid = threadIdx.x;
+    uint8_t *obase = out + s.out_off;          // out_off is 4-byte aligned (engine guarantees)
+    uint32_t *out32 = (uint32_t *)obase;
+    const uint64_t bit_start = bd->bit_start;
+
+    if (bd->type == 0) { // FlushStoredBlock :766
+        const uint64_t hdr_end = bit_start + 3;
+        const uint64_t byte0 = (hdr_end + 7) >> 3;
+        if (tid == 0) {
+            uint32_t v = (uint32_t)((0 << 1) + bd->last);
+            if (v) atomicOr(&out32[bit_start >> 5], v << (bit_start & 31)); // 3 bits never straddle... may straddle a dword:
+            if (v && ((bit_start & 31) + 3 > 32)) atomicOr(&out32[(bit_start >> 5) + 1], v >> (32 - (bit_start & 31)));
+            uint32_t len = bd->in_len;
+            obase[byte0 + 0] = (uint8_t)len; obase[byte0 + 1] = (uint8_t)(len >> 8);
+            obase[byte0 + 2] = (uint8_t)~len; obase[byte0 + 3] = (uint8_t)((~len) >> 8);
+        }
+        const uint8_t *src = in + s.buf_off + bd->in_start;
+        uint8_t *dst = obase + byte0 + 4;
+        for (uint32_t i = tid; i < bd->in_len; i += E_THREADS) dst[i] = src[i];
+        return;
+    }
+    for (int i = tid; i < LIT_NUM; i += E_THREADS) { s_lcode[i] = bd->lcode[i]; s_llen[i] = bd->llen[i]; }
+    if (tid < DIST_NUM) { s_dcode[tid] = bd->dcode[tid]; s_dlen[tid] = bd->dlen[tid]; }
+    // ---- header bits (pre-rendered, LSB-first bytes): 8 bits per thread per pass
+    uint64_t pos = bit_start;
+    {
+        const uint32_t hb = bd->hdr_bits;
+        for (uint32_t base = 0; base < hb; base += E_THREADS * 8) {
+            for (int i = tid; i < E_STAGE_DW + 4; i += E_THREADS) stage[i] = 0;
+            __syncthreads();
+            uint32_t chunk = hb - base < (uint32_t)E_THREADS * 8 ? hb - base : (uint32_t)E_THREADS * 8;
+            uint32_t mybit = (uint32_t)tid * 8;
+            if (mybit < chunk) {
+                int nb = chunk - mybit < 8 ? (int)(chunk - mybit) : 8;
+                unsigned v = bd->hdr[(base >> 3) + tid] & ((1u << nb) - 1);
+                lds_or_bits(stage, (uint32_t)(pos & 31) + mybit, v, nb);
+            }
+            __syncthreads();
+            flush_stage(stage, out32, pos, pos + chunk, tid);
+            __syncthreads();
+            pos += chunk;
+        }
+    }
+    // ---- tokens (CompressBlock :701)
+    const uint32_t ntok = bd->ntok;
+    const uint64_t tfirst = bd->tok_first;
+    for (uint32_t t0 = 0; t0 < ntok + 1; t0 += E_THREADS) { // +1: the EOB symbol rides as a pseudo token
+        for (int i = tid; i < E_STAGE_DW + 4; i += E_THREADS) stage[i] = 0;
+        unsigned long long v = 0; int nb = 0;
+        uint32_t ti = t0 + tid;
+        if (ti < ntok) {
+            uint32_t t = tokens[tfirst + ti];
+            uint32_t dist = t >> 16;
+            if (dist == 0) { v = s_lcode[t & 0xFF]; nb = s_llen[t & 0xFF]; }
+            else {
+                int l = (int)(t & 0xFFFF) - 3;
+                int lc = lcode_of(l);
+                v = s_lcode[lc]; nb = s_llen[lc];
+                int bits = (lc - 261) / 4;                       // :716
+                if (bits > 0 && bits <= 5) { v |= (unsigned long long)(l & ((1 << bits) - 1)) << nb; nb += bits; }
+                int dd = (int)dist - 1;
+                int dc = dcode_of(dd);
+                v |= (unsigned long long)s_dcode[dc] << nb; nb += s_dlen[dc];
+                bits = dc / 2 - 1;                               // :725
+                if (bits > 0) { v |= (unsigned long long)(dd & ((1 << bits) - 1)) << nb; nb += bits; }
+            }
+        } else if (ti == ntok) { v = s_lcode[256]; nb = s_llen[256]; } // EOF_SYMBOL :749
+        // exclusive scan of nb over the workgroup
+        int incl = nb;
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
+        if ((tid & 63) == 63) wsum[tid >> 6] = (uint32_t)incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+        for (int w = 0; w < E_THREADS / 64; w++) { uint32_t x = wsum[w]; if (w < (tid >> 6)) woff += x; total += x; }
+        uint32_t myoff = woff + (uint32_t)(incl - nb);
+        lds_or_bits(stage, (uint32_t)(pos & 31) + myoff, v, nb);
+        __syncthreads();
+        flush_stage(stage, out32, pos, pos + total, tid);
+        __syncthreads();
+        pos += total;
+    }
+}
+
+// Deflater.Deflate tails (C/Deflater.cs:486-517): sync-flush padding blocks, the empty final block of a
+// Flush()+Finish() pair, byte alignment, optional zlib Adler-32 trailer.
+__global__ void k_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint8_t *out) {
+    uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nseg) return;
+    const SegDev s = segs[si];
+    uint32_t *out32 = (uint32_t *)(out + s.out_off);
+    uint64_t E = so[si].end_bit;
+    auto put10 = [&](uint32_t v) {
+        atomicOr(&out32[E >> 5], v << (E & 31));
+        if ((E & 31) + 10 > 32) atomicOr(&out32[(E >> 5) + 1], v >> (32 - (E & 31)));
+        E += 10;
+    };
+    if (s.flags & SEG_SYNC_PAD) { // :491-501
+        int neededbits = 8 + (int)((0 - E) & 7);
+        while (neededbits > 0) { put10(2); neededbits -= 10; }
+    }
+    if (s.flags & SEG_EXTRA_FINAL_EMPTY) put10(3); // FlushBlock of an empty final block = static header + EOB
+    uint64_t bytes = (E + 7) >> 3;
+    if (s.flags & SEG_ZLIB_TRAILER) { // :510-515
+        uint32_t a = so[si].adler32;
+        uint8_t *o = out + s.out_off + bytes;
+        o[0] = (uint8_t)(a >> 24); o[1] = (uint8_t)(a >> 16); o[2] = (uint8_t)(a >> 8); o[3] = (uint8_t)a;
+        bytes += 4; E = bytes * 8;
+    }
+    so[si].end_bit = E;
+    so[si].out_bytes = bytes;
+}
+
+void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, tokens, blk_off, so);
+}
+void launch_block_build(const SegDev *segs, uint32_t nseg, const SegOut *so, const uint64_t *blk_off, const uint32_t *tokens,
+                        const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, hipStream_t st) {
+    if (nslots) hipLaunchKernelGGL(k_block_build, dim3(nslots), dim3(D_THREADS), 0, st, segs, nseg, so, blk_off, tokens, bsp, blp, descs, nslots);
+}
+void launch_block_scan(const SegDev *segs, uint32_t nseg, SegOut *so, BlockDesc *descs, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_scan, dim3(nseg), dim3(64), 0, st, segs, nseg, so, descs);
+}
+void launch_block_encode(const uint8_t *in, uint8_t *out, const SegDev *segs, const BlockDesc *descs, const uint32_t *tokens,
+                         uint32_t nslots, hipStream_t st) {
+    if (nslots) hipLaunchKernelGGL(k_block_encode, dim3(nslots), dim3(E_THREADS), 0, st, in, out, segs, descs, tokens, nslots);
+}
+void launch_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint8_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_finish, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, so, out);
+}
+
+} // namespace szl

@@ -1,0 +1,343 @@
+// szl_kernels_parse.hip — stage C: the lazy-match parse of DeflateSlow (C/DeflaterEngine.cs:741-855)
+// resolved as a path in a functional graph.
+//
+// State of the reference loop at an iteration start = (strstart, prevAvailable, matchLen, matchStart).
+// With the match tables of stage B the loop body is a table lookup; an iteration entered with
+// matchLen == 2 ("clean") has a future that does not depend on how it was reached, so two parses
+// that are both clean at the same position are identical from there on.  Ranges of C_RANGE positions
+// are therefore parsed speculatively from a clean state (k_spec), the predecessor's exit is walked
+// into each range until it lands on that speculative path (k_fix), the rare ranges where that does
+// not happen are chained sequentially (k_resolve), and the true path is replayed once to emit tokens.
+#include <hip/hip_runtime.h>
+#include "szl_internal.h"
+
+namespace szl {
+
+__device__ __forceinline__ int64_t base_of_c(int64_t s_abs) {
+    int64_t idx = s_abs + 1;
+    if (idx <= 65273) return 0;
+    return ((idx - 65273 + 32767) >> 15) << 15;
+}
+
+struct ParseCtx {
+    const uint8_t *d;      // stream buffer
+    const uint16_t *lk;    // links
+    const uint2 *mt;       // {M2,Mq}
+    int64_t seg_end;
+    int64_t abs0;
+    LevelParams P;
+};
+
+// FindLongestMatch entered with matchLen = L >= niceLength' (C/DeflaterEngine.cs:474-612): the first
+// candidate among the first max_chain>>2 that is strictly longer wins (it is >= niceLength, :604).
+// Rare (measured per call in szl_timing.fallback_walks) — walks global memory.
+__device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long long *fallbacks) {
+    if (fallbacks) atomicAdd(fallbacks, 1ull);
+    const int64_t rem = c.seg_end - p;
+    uint32_t l0 = c.lk[p];
+    if (l0 == 0) return 0;
+    const int64_t basem = base_of_c(c.abs0 + p) - c.abs0;
+    int64_t cand = p - l0;
+    int64_t firstmin = p - MAX_DIST > basem ? p - MAX_DIST : basem;
+    if (cand < firstmin) return 0;
+    const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    if (L >= cap) return 0;
+    const int64_t minc = p - (MAX_DIST - 1) > basem ? p - (MAX_DIST - 1) : basem;
+    int budget = c.P.max_chain >> 2;
+    for (;;) {
+        int l = 0;
+        if (c.d[cand + L] == c.d[p + L]) { // quick reject :505
+            while (l < cap && c.d[cand + l] == c.d[p + l]) l++;
+        }
+        if (l > L) return (uint32_t)l | ((uint32_t)(p - cand) << 16);
+        uint32_t lnk = c.lk[cand];
+        if (lnk == 0) return 0;
+        int64_t c2 = cand - lnk;
+        if (c2 < minc) return 0;
+        if (--budget == 0) return 0;
+        cand = c2;
+    }
+}
+
+// One iteration of the DeflateSlow loop body at position x with pending match (L,D) (L==0: none).
+// Returns the token emitted by this iteration (0xFFFFFFFF = none) and its input start via *tpos.
+__device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, int64_t &x, int &L, int &D, int64_t *tpos,
+                                               bool want_lit, unsigned long long *fallbacks) {
+    const uint2 e = c.mt[x];
+    if (L == 0) {
+        int len = (int)(e.x & 0xFFFF), dist = (int)(e.x >> 16);
+        if (len != 0 && len <= 5 && (c.P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
+        if (len == 0) { // literal step :830-839 (tallied by the next iteration / final flush :752)
+            uint32_t t = want_lit ? (uint32_t)c.d[x] : 0u;
+            *tpos = x;
+            x += 1;
+            return t;
+        }
+        L = len; D = dist;
+        x += 1;
+        return 0xFFFFFFFFu;
+    }
+    // lazy evaluation at x: is there a strictly longer match than the one found at x-1 ?
+    const int64_t rem = c.seg_end - x;
+    uint32_t better = 0;
+    if (rem >= MIN_MATCH) {
+        const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+        if (L < cap) {
+            const int nice = c.P.nice < (int)rem ? c.P.nice : (int)rem;
+            uint32_t cand;
+            if (L < c.P.good) cand = e.x;
+            else if (L < nice) cand = e.y;               // chainLength >>= 2 (:495)
+            else cand = slow_walk(c, x, L, fallbacks);
+            if ((int)(cand & 0xFFFF) > L && !(c.P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
+        }
+    }
+    if (better) { // previous position becomes a literal (:830-835)
+        uint32_t t = want_lit ? (uint32_t)c.d[x - 1] : 0u;
+        *tpos = x - 1;
+        L = (int)(better & 0xFFFF); D = (int)(better >> 16);
+        x += 1;
+        return t;
+    }
+    // "previous match was better" :802-828
+    uint32_t t = ((uint32_t)D << 16) | (uint32_t)L;
+    *tpos = x - 1;
+    x = x - 1 + L;
+    L = 0;
+    return t;
+}
+
+__device__ __forceinline__ uint32_t find_seg(const SegDev *segs, uint32_t nseg, uint64_t r) {
+    // largest s with segs[s].range_off <= r  (segments with zero ranges share an offset with their successor)
+    uint32_t lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (segs[mid].range_off <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ ParseCtx make_ctx(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev &s,
+                                             LevelParams P) {
+    ParseCtx c;
+    c.d = in + s.buf_off; c.lk = link + s.buf_off; c.mt = mtab + s.buf_off;
+    c.seg_end = s.seg_end; c.abs0 = (int64_t)s.abs0; c.P = P;
+    return c;
+}
+
+// C1: speculative walk of each range from a clean state at its first position.
+__global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+                                              uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
+                                              uint32_t *visited, unsigned long long *counters) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nranges) return;
+    uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    uint64_t lr = r - s.range_off;
+    int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    // each range owns whole words of its segment's bitmap (C_RANGE is a multiple of 32): plain stores, no atomics
+    uint32_t *vis = visited + s.vis_word_off;
+    int64_t x = rs;
+    int L = 0, D = 0;
+    uint32_t count = 0;
+    int64_t tp;
+    uint64_t cw = (uint64_t)(rs - s.seg_start) >> 5;
+    uint32_t acc = 0;
+    for (;;) {
+        if (L == 0) {
+            if (x >= re) break;
+            uint64_t bit = (uint64_t)(x - s.seg_start);
+            if ((bit >> 5) != cw) { if (acc) vis[cw] = acc; cw = bit >> 5; acc = 0; }
+            acc |= 1u << (bit & 31);
+        }
+        uint32_t t = parse_step(c, x, L, D, &tp, false, counters + 1);
+        count += (t != 0xFFFFFFFFu);
+    }
+    if (acc) vis[cw] = acc;
+    RangeDev rd;
+    rd.exit_spec = x; rd.exit_true = x; rd.entry = rs; rd.spec_count = count; rd.true_count = count; rd.merged = 1; rd.pad = 0;
+    ranges[r] = rd;
+}
+
+__device__ __forceinline__ bool is_visited(const uint32_t *vis /* segment bitmap */, uint64_t i) { return (vis[i >> 5] >> (i & 31)) & 1u; }
+
+// Walk from clean position `entry` into range [rs,re): returns through `merged`, `exit`, `count` where count =
+// tokens owned by the true nodes in [entry, re).  If the walk lands on the range's speculative path at y the
+// remainder equals the speculative parse: count = fix + spec_count - (tokens of spec nodes in [rs,y)).
+__device__ void fixup_range(const ParseCtx &c, const uint32_t *vis, int64_t seg_start, int64_t rs, int64_t re,
+                            int64_t entry, uint32_t spec_count, int64_t exit_spec, uint32_t *out_merged,
+                            int64_t *out_exit, uint32_t *out_count, unsigned long long *fallbacks) {
+    int64_t x = entry, tp;
+    int L = 0, D = 0;
+    uint32_t fix = 0;
+    bool merged = false;
+    for (;;) {
+        if (L == 0) {
+            if (x >= re) break;
+            if (x >= rs && is_visited(vis, (uint64_t)(x - seg_start))) { merged = true; break; }
+        }
+        uint32_t t = parse_step(c, x, L, D, &tp, false, fallbacks);
+        fix += (t != 0xFFFFFFFFu);
+    }
+    if (!merged) { *out_merged = 0; *out_exit = x; *out_count = fix; return; }
+    const int64_t y = x;
+    uint32_t skip = 0;
+    x = rs; L = 0; D = 0;
+    for (;;) {
+        if (L == 0 && x >= y) break;
+        uint32_t t = parse_step(c, x, L, D, &tp, false, fallbacks);
+        skip += (t != 0xFFFFFFFFu);
+    }
+    *out_merged = 1; *out_exit = exit_spec; *out_count = fix + spec_count - skip;
+}
+
+// C2: assume the predecessor's true exit is its speculative exit.
+__global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+                                             uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
+                                             const uint32_t *visited, unsigned long long *counters) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nranges) return;
+    uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    uint64_t lr = r - s.range_off;
+    if (lr == 0) return; // first range of a segment: entry = range start, speculative parse is the true one
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    const int64_t entry = ranges[r - 1].exit_spec;
+    uint32_t merged, count;
+    int64_t ex;
+    fixup_range(c, visited + s.vis_word_off, s.seg_start, rs, re, entry, ranges[r].spec_count, ranges[r].exit_spec, &merged, &ex, &count,
+                counters + 1);
+    ranges[r].entry = entry;
+    ranges[r].merged = merged;
+    ranges[r].exit_true = ex;
+    ranges[r].true_count = count;
+    if (!merged) atomicAdd(counters + 0, 1ull);
+}
+
+// C3: one wavefront per segment chains the ranges whose assumed entry was wrong (sequential; rare).
+__global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+                                                uint32_t nseg, LevelParams P, RangeDev *ranges, const uint32_t *visited,
+                                                unsigned long long *counters) {
+    if (counters[0] == 0) return; // every range merged: nothing to do
+    uint32_t si = blockIdx.x;
+    if (si >= nseg) return;
+    const SegDev s = segs[si];
+    if (s.range_cnt < 2) return;
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    const int lane = threadIdx.x;
+    RangeDev *R = ranges + s.range_off;
+    // Invariant: ranges [0, k) are final.  Range k is final iff its assumed entry == exit_true of k-1.
+    for (uint32_t k0 = 1; k0 < s.range_cnt; k0 += 64) {
+        uint32_t k = k0 + lane;
+        for (;;) {
+            bool bad = false;
+            if (k < s.range_cnt) bad = R[k].entry != R[k - 1].exit_true;
+            uint64_t m = __ballot(bad);
+            if (m == 0) break;
+            int l = __builtin_ctzll(m);
+            if (lane == l) { // redo this range from the true exit of its predecessor
+                int64_t rs = s.seg_start + (int64_t)k * C_RANGE;
+                int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+                const int64_t entry = R[k - 1].exit_true;
+                uint32_t merged, count;
+                int64_t ex;
+                fixup_range(c, visited + s.vis_word_off, s.seg_start, rs, re, entry, R[k].spec_count, R[k].exit_spec, &merged, &ex, &count,
+                            counters + 1);
+                R[k].entry = entry; R[k].merged = merged; R[k].exit_true = ex; R[k].true_count = count;
+                __threadfence();
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Token counts per range -> scan input
+__global__ void k_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nranges) counts[r] = ranges[r].true_count;
+}
+
+// Per-segment token totals and block counts (C/DeflaterEngine.cs:841-852, :750-768; oracle/szl_model.c szm_block_table)
+__global__ void k_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok /* exclusive scan, nranges+1 */,
+                             SegOut *so, uint32_t *blk_counts) {
+    uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nseg) return;
+    const SegDev s = segs[si];
+    uint64_t first = range_tok[s.range_off];
+    uint64_t cnt = range_tok[s.range_off + s.range_cnt] - first;
+    so[si].tok_first = first;
+    so[si].tok_count = cnt;
+    // The number of blocks also depends on whether the very last token is a match; that is only known after
+    // emission, so reserve the maximum here (one more than ceil) and let k_block_table fix blk_count.
+    blk_counts[si] = (uint32_t)(cnt / BLOCK_TOKENS) + 1;
+}
+
+// C5: replay the true path of each range and write its tokens; record block edges.
+__global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+                                              uint32_t nseg, uint64_t nranges, LevelParams P, const RangeDev *ranges,
+                                              const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
+                                              const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos,
+                                              unsigned long long *counters) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nranges) return;
+    uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    uint64_t lr = r - s.range_off;
+    int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    int64_t x = lr == 0 ? rs : ranges[r].entry;
+    int L = 0, D = 0;
+    uint64_t ti = range_tok[r];
+    const uint64_t seg_tok0 = so[si].tok_first, seg_ntok = so[si].tok_count;
+    const uint64_t b0 = blk_off[si];
+    int64_t tp;
+    for (;;) {
+        if (L == 0 && x >= re) break;
+        uint32_t t = parse_step(c, x, L, D, &tp, true, nullptr);
+        if (t != 0xFFFFFFFFu) {
+            tokens[ti] = t;
+            uint64_t li = ti - seg_tok0; // token index inside the segment
+            if ((li & (BLOCK_TOKENS - 1)) == 0) blk_start_pos[b0 + li / BLOCK_TOKENS] = tp;
+            if ((li & (BLOCK_TOKENS - 1)) == BLOCK_TOKENS - 1 || li == seg_ntok - 1) blk_lasttok_pos[b0 + li / BLOCK_TOKENS] = tp;
+            ti++;
+        }
+    }
+    (void)counters;
+}
+
+void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg,
+                 uint64_t nranges, LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters,
+                 hipStream_t st) {
+    if (nranges == 0) return;
+    hipLaunchKernelGGL(k_spec, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
+                       ranges, visited, counters);
+}
+void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st) {
+    if (nranges == 0) return;
+    hipLaunchKernelGGL(k_fix, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
+                       ranges, visited, counters);
+    hipLaunchKernelGGL(k_resolve, dim3(nseg), dim3(64), 0, st, in, link, mtab, segs, nseg, P, ranges, visited, counters);
+}
+void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st) {
+    if (nranges == 0) return;
+    hipLaunchKernelGGL(k_range_counts, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, ranges, nranges, counts);
+}
+void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_tokens, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, range_tok, so, blk_counts);
+}
+void launch_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                 LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
+                 const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos, unsigned long long *counters,
+                 hipStream_t st) {
+    if (nranges == 0) return;
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
+                       ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos, counters);
+}
+
+} // namespace szl
