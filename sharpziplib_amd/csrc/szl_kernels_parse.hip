@@ -260,7 +260,7 @@ __global__ void k_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_
     if (r < nranges) counts[r] = ranges[r].true_count;
 }
 
-// Per-segment token totals and block counts (C/DeflaterEngine.cs:841-852, :750-768; oracle/szl_model.c szm_block_table)
+// Per-segment token totals and block counts (C/DeflaterEngine.cs:841-852, :750-768)
 __global__ void k_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok /* exclusive scan, nranges+1 */,
                              SegOut *so, uint32_t *blk_counts) {
     uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;

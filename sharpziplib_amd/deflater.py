@@ -1,0 +1,133 @@
+"""Host-side mirror of ICSharpCode.SharpZipLib.Zip.Compression.Deflater (C/Deflater.cs) over the
+C ABI — same member names, argument meaning and error behaviour, so the parity tests read like the
+reference's own (T/Base/InflaterDeflaterTests.cs).  All compression happens in libszl_amd.so on
+the device; exceptions mirror the reference's types:
+    ArgumentOutOfRangeException -> ValueError, InvalidOperationException -> InvalidOperation,
+    SharpZipBaseException -> SharpZipBaseException.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class SharpZipBaseException(Exception):
+    pass
+
+
+class InvalidOperation(RuntimeError):
+    pass
+
+
+class NotSupportedOnDevice(SharpZipBaseException):
+    pass
+
+
+def _raise(status, where):
+    L = _lib.lib()
+    detail = L.szl_last_error().decode()
+    msg = "%s: %s%s" % (where, L.szl_strerror(status).decode(), (" — " + detail) if detail else "")
+    if status == -1:
+        raise ValueError(msg)
+    if status == -2:
+        raise InvalidOperation(msg)
+    if status == -5:
+        raise NotSupportedOnDevice(msg)
+    raise SharpZipBaseException(msg)
+
+
+class DeflateStrategy:
+    Default, Filtered, HuffmanOnly = 0, 1, 2
+
+
+class Deflater:
+    BEST_COMPRESSION, BEST_SPEED, DEFAULT_COMPRESSION, NO_COMPRESSION, DEFLATED = 9, 1, -1, 0, 8  # C/Deflater.cs:62-83
+
+    def __init__(self, level=DEFAULT_COMPRESSION, noZlibHeaderOrFooter=False):
+        self._L = _lib.lib()
+        if level != -1 and not (0 <= level <= 9):
+            raise ValueError("level")  # ArgumentOutOfRangeException C/Deflater.cs:184-187
+        self._h = self._L.szl_deflater_create(level, 1 if noZlibHeaderOrFooter else 0)
+        if not self._h:
+            msg = self._L.szl_last_error().decode()
+            if "not on the device path" in msg:
+                raise NotSupportedOnDevice(msg)
+            raise SharpZipBaseException(msg)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.szl_deflater_destroy(h)
+            self._h = None
+
+    def Reset(self):
+        s = self._L.szl_deflater_reset(self._h)
+        if s < 0:
+            _raise(s, "Reset")
+
+    def SetInput(self, buffer, offset=0, count=None):
+        a = np.frombuffer(buffer, dtype=np.uint8) if not isinstance(buffer, np.ndarray) else buffer
+        count = a.size - offset if count is None else count
+        if offset < 0 or count < 0 or offset + count > a.size:
+            raise ValueError("count")  # C/DeflaterEngine.cs:148-176
+        a = np.ascontiguousarray(a[offset:offset + count])
+        s = self._L.szl_deflater_set_input(self._h, a.ctypes.data, count)
+        if s < 0:
+            _raise(s, "SetInput")
+
+    def SetLevel(self, level):
+        s = self._L.szl_deflater_set_level(self._h, level)
+        if s < 0:
+            _raise(s, "SetLevel")
+
+    def GetLevel(self):
+        return self._L.szl_deflater_get_level(self._h)
+
+    def SetStrategy(self, strategy):
+        s = self._L.szl_deflater_set_strategy(self._h, strategy)
+        if s < 0:
+            _raise(s, "SetStrategy")
+
+    def SetDictionary(self, dictionary, index=0, count=None):
+        a = np.ascontiguousarray(np.frombuffer(dictionary, dtype=np.uint8))
+        count = a.size - index if count is None else count
+        s = self._L.szl_deflater_set_dictionary(self._h, a[index:].ctypes.data, count)
+        if s < 0:
+            _raise(s, "SetDictionary")
+
+    def Flush(self):
+        self._L.szl_deflater_flush(self._h)
+
+    def Finish(self):
+        self._L.szl_deflater_finish(self._h)
+
+    def Deflate(self, output, offset=0, length=None):
+        """output: writable numpy uint8 array / bytearray. Returns number of bytes written."""
+        a = np.frombuffer(output, dtype=np.uint8) if not isinstance(output, np.ndarray) else output
+        length = a.size - offset if length is None else length
+        if length == 0:
+            n = self._L.szl_deflater_deflate(self._h, None, 0)
+        else:
+            n = self._L.szl_deflater_deflate(self._h, a[offset:].ctypes.data, length)
+        if n < 0:
+            _raise(n, "Deflate")
+        return n
+
+    @property
+    def IsFinished(self):
+        return bool(self._L.szl_deflater_is_finished(self._h))
+
+    @property
+    def IsNeedingInput(self):
+        return bool(self._L.szl_deflater_needs_input(self._h))
+
+    @property
+    def TotalIn(self):
+        return self._L.szl_deflater_total_in(self._h)
+
+    @property
+    def TotalOut(self):
+        return self._L.szl_deflater_total_out(self._h)
+
+    @property
+    def Adler(self):
+        return self._L.szl_deflater_adler(self._h)

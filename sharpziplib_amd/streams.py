@@ -1,0 +1,74 @@
+"""Host-side mirrors of DeflaterOutputStream / InflaterInputStream
+(CS/DeflaterOutputStream.cs, CS/InflaterInputStream.cs): the managed stream adapters of the
+reference stay on the host and only talk to Deflater / Inflater, exactly as in the reference —
+so these are line-for-line *behavioural* mirrors (same loops, same error messages), used by the
+parity tests to drive the C ABI with the reference's call patterns."""
+import io
+
+import numpy as np
+
+from .deflater import Deflater, SharpZipBaseException
+
+
+class DeflaterOutputStream:
+    def __init__(self, baseOutputStream, deflater=None, bufferSize=512):
+        if baseOutputStream is None:
+            raise ValueError("baseOutputStream")
+        if not baseOutputStream.writable():
+            raise ValueError("Must support writing")          # :75-78
+        if bufferSize < 512:
+            raise ValueError("bufferSize")                     # :80-83
+        self.baseOutputStream_ = baseOutputStream
+        self.buffer_ = np.zeros(bufferSize, dtype=np.uint8)
+        self.deflater_ = deflater if deflater is not None else Deflater()
+        self.IsStreamOwner = True
+        self.isClosed_ = False
+
+    def _deflate(self, flushing=False):                        # DeflateSyncOrAsync :242-272
+        while flushing or not self.deflater_.IsNeedingInput:
+            n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
+            if n <= 0:
+                break
+            self.baseOutputStream_.write(self.buffer_[:n].tobytes())
+        if not self.deflater_.IsNeedingInput:
+            raise SharpZipBaseException("DeflaterOutputStream can't deflate all input?")
+
+    def Write(self, buffer, offset=0, count=None):            # :506
+        self.deflater_.SetInput(buffer, offset, count)
+        self._deflate()
+
+    def WriteByte(self, value):                                # :487
+        self.Write(bytes([value & 0xFF]), 0, 1)
+
+    def Flush(self):                                           # :388
+        self.deflater_.Flush()
+        self._deflate(True)
+        self.baseOutputStream_.flush()
+
+    def Finish(self):                                          # :100
+        self.deflater_.Finish()
+        while not self.deflater_.IsFinished:
+            n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
+            if n <= 0:
+                break
+            self.baseOutputStream_.write(self.buffer_[:n].tobytes())
+        if not self.deflater_.IsFinished:
+            raise SharpZipBaseException("Can't deflate all input?")
+        self.baseOutputStream_.flush()
+
+    def Dispose(self):                                         # :412
+        if not self.isClosed_:
+            self.isClosed_ = True
+            try:
+                self.Finish()
+            finally:
+                if self.IsStreamOwner:
+                    self.baseOutputStream_.close()
+
+    Close = Dispose
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.Dispose()

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/deflate_golden.json.
+
+The reference (managed C#) cannot run in this image (no .NET), so these fixtures are outputs of
+oracle/ — the C restatement pinned as described in oracle/szl_oracle.h — for seeded inputs that
+the tests regenerate with sharpziplib_amd.corpus.  They freeze the encoder's bits so that neither
+the oracle nor the HIP path can drift silently.  Run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle_ffi as O  # noqa: E402
+from sharpziplib_amd import corpus as C  # noqa: E402
+
+CASES = [
+    # name, generator spec, levels
+    ("dickens_1m", ("corpus", "dickens", 0xD1CE, 0, 1 << 20), [5, 6, 9]),
+    ("enwik_2m", ("corpus", "enwik", 0xE9, 0, 2 << 20), [6, 9]),
+    ("enwik_off", ("corpus", "enwik", 0xE9, 5 << 20, 300000), [6]),
+    ("logs_1m", ("corpus", "logs", 0x106, 0, 1 << 20), [6, 9]),
+    ("random_100k", ("random", 1, 100000), [6]),
+    ("zeros_200k", ("zeros", 200000), [6, 9]),
+    ("acgt_300k", ("four", 2, 300000), [6]),
+    ("p10_100k", ("p10", 100000), [6]),
+    ("mixed_1m", ("mixed", 3, 1 << 20), [5, 6, 7, 8, 9]),
+    ("dotnet_random5_100k", ("dotnet", 5, 100000), [6]),
+]
+
+
+def make_input(spec):
+    k = spec[0]
+    if k == "corpus":
+        return C.generate(spec[1], spec[2], spec[3], spec[4])
+    if k == "random":
+        return C.random_bytes(spec[2], spec[1])
+    if k == "zeros":
+        return C.zeros(spec[1])
+    if k == "four":
+        return C.four_symbol(spec[2], spec[1])
+    if k == "p10":
+        return C.period10(spec[1])
+    if k == "mixed":
+        return C.mixed(spec[2], spec[1])
+    if k == "dotnet":
+        return O.dotnet_random_bytes(spec[1], spec[2])
+    raise ValueError(k)
+
+
+def main():
+    out = {"_comment": "sha256 of oracle raw-deflate outputs; see make_golden.py", "cases": []}
+    for name, spec, levels in CASES:
+        data = make_input(spec)
+        for lv in levels:
+            comp = O.deflate(data, lv)
+            out["cases"].append({"name": name, "spec": list(spec), "level": lv, "n": int(data.size), "out_len": len(comp),
+                                 "in_sha256": hashlib.sha256(data.tobytes()).hexdigest(),
+                                 "out_sha256": hashlib.sha256(comp).hexdigest(), "crc32": O.crc32(data), "adler32": O.adler32(data)})
+    with open(os.path.join(HERE, "deflate_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", len(out["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,7 @@ def lib():
         ("szm_parse", sz, [vp, sz, sz, vp, vp, vp, vp, vp, vp]),
         ("szm_parse_ranges", sz, [vp, sz, sz, vp, vp, vp, vp, sz, vp, vp]),
         ("szm_block_table", sz, [vp, sz, i32, vp, vp, vp]), ("szm_base_of", i64, [i64]),
+        ("szo_dotnet_random_bytes", None, [ctypes.c_int32, vp, sz]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
     _lib = L
@@ -76,6 +77,136 @@ def lib():
 def _buf(data):
     a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
     return a
+
+
+def dotnet_random_bytes(seed, n):
+    """new System.Random(seed).NextBytes(new byte[n]) — T/TestSupport/Utils.cs:79-85 GetDummyBytes."""
+    out = np.empty(n, dtype=np.uint8)
+    lib().szo_dotnet_random_bytes(seed, out.ctypes.data, n)
+    return out
+
+
+class Deflater:
+    """The oracle's Deflater object (C/Deflater.cs member set) for call-pattern tests."""
+
+    def __init__(self, level=-1, nowrap=False):
+        self.L = lib()
+        self.h = self.L.szo_deflater_new(level, 1 if nowrap else 0)
+        if not self.h:
+            raise ValueError("level")
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.szo_deflater_free(self.h)
+            self.h = None
+
+    def set_input(self, data):
+        self._keep = np.ascontiguousarray(_buf(data))
+        return self.L.szo_deflater_set_input(self.h, self._keep.ctypes.data, self._keep.size)
+
+    def flush(self): self.L.szo_deflater_flush(self.h)
+    def finish(self): self.L.szo_deflater_finish(self.h)
+    def reset(self): self.L.szo_deflater_reset(self.h)
+    def set_level(self, lv): return self.L.szo_deflater_set_level(self.h, lv)
+    def set_strategy(self, s): self.L.szo_deflater_set_strategy(self.h, s)
+    def set_dictionary(self, d):
+        a = np.ascontiguousarray(_buf(d)); return self.L.szo_deflater_set_dictionary(self.h, a.ctypes.data, a.size)
+    @property
+    def needs_input(self): return bool(self.L.szo_deflater_needs_input(self.h))
+    @property
+    def finished(self): return bool(self.L.szo_deflater_is_finished(self.h))
+    @property
+    def total_in(self): return self.L.szo_deflater_total_in(self.h)
+    @property
+    def total_out(self): return self.L.szo_deflater_total_out(self.h)
+    @property
+    def adler(self): return self.L.szo_deflater_adler(self.h)
+
+    def deflate(self, n):
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        k = self.L.szo_deflater_deflate(self.h, out.ctypes.data, n)
+        if k < 0:
+            raise RuntimeError(k)
+        return out[:k].tobytes()
+
+
+class Inflater:
+    def __init__(self, nowrap=False):
+        self.L = lib()
+        self.h = self.L.szo_inflater_new(1 if nowrap else 0)
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.szo_inflater_free(self.h)
+            self.h = None
+
+    def set_input(self, data):
+        self._keep = np.ascontiguousarray(_buf(data))
+        return self.L.szo_inflater_set_input(self.h, self._keep.ctypes.data, self._keep.size)
+
+    def inflate(self, n):
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        k = self.L.szo_inflater_inflate(self.h, out.ctypes.data, n)
+        return k, out[:max(k, 0)].tobytes()
+
+    def reset(self): self.L.szo_inflater_reset(self.h)
+    @property
+    def needs_input(self): return bool(self.L.szo_inflater_needs_input(self.h))
+    @property
+    def finished(self): return bool(self.L.szo_inflater_is_finished(self.h))
+    @property
+    def remaining_input(self): return self.L.szo_inflater_remaining_input(self.h)
+    @property
+    def total_in(self): return self.L.szo_inflater_total_in(self.h)
+    @property
+    def total_out(self): return self.L.szo_inflater_total_out(self.h)
+    @property
+    def adler(self): return self.L.szo_inflater_adler(self.h)
+
+
+def stream_deflate(data, level=6, nowrap=True, chunk=None, flush_every=None, out_chunk=512, strategy=0, final_flush=False):
+    """DeflaterOutputStream.Write/Flush/Finish call pattern (CS/DeflaterOutputStream.cs:506,388,100) on the oracle."""
+    d = Deflater(level, nowrap)
+    d.set_strategy(strategy)
+    a = _buf(data)
+    out = bytearray()
+    chunk = chunk or max(a.size, 1)
+    pos, since = 0, 0
+    while pos < a.size:
+        c = a[pos:pos + chunk]
+        d.set_input(c)
+        while not d.needs_input:
+            b = d.deflate(out_chunk)
+            if not b:
+                break
+            out += b
+        pos += c.size
+        since += c.size
+        if flush_every and since >= flush_every and pos < a.size:
+            d.flush()
+            while True:
+                b = d.deflate(out_chunk)
+                if not b:
+                    break
+                out += b
+            since = 0
+    if final_flush:
+        d.flush()
+        while True:
+            b = d.deflate(out_chunk)
+            if not b:
+                break
+            out += b
+    d.finish()
+    while not d.finished:
+        b = d.deflate(out_chunk)
+        if not b:
+            break
+        out += b
+    assert d.finished
+    return bytes(out), d.total_in, d.total_out
 
 
 def crc32(data, value=0):

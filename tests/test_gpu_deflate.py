@@ -1,0 +1,192 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the oracle on the same seeded inputs — bit-exact (integer/byte work; tolerance 0)."""
+import hashlib
+import io
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from golden.make_golden import make_input
+from sharpziplib_amd import corpus as C
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deflate_golden.json")))["cases"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    assert _lib.lib().szl_device_count() > 0, "no gfx950 device: the HIP path cannot run (and there is no fallback)"
+    e = Engine()
+    yield e
+    e.close()
+
+
+CLASSES = {
+    "dickens": lambda: C.generate("dickens", 0xD1CE, 0, 700000), "enwik": lambda: C.generate("enwik", 0xE9, 0, 1500000),
+    "logs": lambda: C.generate("logs", 0x106, 0, 600000), "random": lambda: C.random_bytes(120000),
+    "zeros": lambda: C.zeros(300000), "acgt": lambda: C.four_symbol(250000), "p10": lambda: C.period10(150000),
+    "mixed": lambda: C.mixed(900000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CLASSES))
+@pytest.mark.parametrize("level", [5, 6, 7, 8, 9])
+def test_batch_bit_exact_vs_oracle(eng, name, level):
+    data = CLASSES[name]()
+    r = eng.deflate([data], level=level, crc32=True, adler32=True)[0]
+    ref = O.deflate(data, level)
+    assert r.status == 0
+    assert r.data == ref
+    assert r.crc32 == O.crc32(data) and r.adler32 == O.adler32(data)
+    assert zlib.decompress(r.data, -15) == data.tobytes()
+
+
+@pytest.mark.parametrize("case", GOLD, ids=lambda c: "%s-L%d" % (c["name"], c["level"]))
+def test_golden_fixtures(eng, case):
+    data = make_input(tuple(case["spec"]))
+    r = eng.deflate([data], level=case["level"], crc32=True, adler32=True)[0]
+    assert len(r.data) == case["out_len"] and hashlib.sha256(r.data).hexdigest() == case["out_sha256"]
+    assert r.crc32 == case["crc32"] and r.adler32 == case["adler32"]
+
+
+def test_reference_fixture_payload(eng):
+    """T/Zip/ZipCorruptionHandling.cs:52-54: the reference's own deflate payload for "testfile contents\\n"."""
+    r = eng.deflate([b"testfile contents\n"], level=6)[0]
+    assert r.data.hex() == "2b492d2e49cbcc495548cecf2b49cd2b29e60200"
+
+
+@pytest.mark.parametrize("data,hexout", [(b"", "0300"), (b"x", "ab0000"), (b"Hello", "f348cdc9c90700"),
+                                         (b"Hello, world", "f348cdc9c9d75128cf2fca490100"), (b"a" * 32, "4b240000"),
+                                         (b"abc" * 10, "4b4c4ac68300")])
+def test_tiny_vectors(eng, data, hexout):
+    assert eng.deflate([data], level=6)[0].data.hex() == hexout
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 261, 262, 263, 4095, 4096, 4097, 16383, 16384, 16385, 32505, 32506, 32507,
+                               65273, 65274, 65275, 65536, 98041, 98042, 131072])
+def test_boundary_sizes(eng, n):
+    data = C.generate("dickens", 21, 0, n) if n else np.zeros(0, np.uint8)
+    for lv in (6, 9):
+        assert eng.deflate([data], level=lv)[0].data == O.deflate(data, lv)
+
+
+def test_token_block_multiple_edges(eng):
+    r = C.random_bytes(16384 * 2)
+    for n in (16384, 16385, 32768):
+        assert eng.deflate([r[:n]], level=6)[0].data == O.deflate(r[:n], 6)
+    base = C.random_bytes(16383, seed=5)
+    data = np.concatenate([base, base[:300]])
+    for cut in range(16383 + 3, 16383 + 300, 37):
+        d = data[:cut]
+        assert eng.deflate([d], level=6)[0].data == O.deflate(d, 6)
+        assert eng.deflate([d], level=6, sync_flush_before_finish=True)[0].data == O.deflate(d, 6, flush=True)
+
+
+def test_many_small_streams_batch(eng):
+    """config 3 shape: many independent streams in one call (ZipOutputStream entries)."""
+    bufs = [C.generate("dickens", 0x21B0 + i, 0, 65536) for i in range(48)]
+    bufs += [C.random_bytes(1000 + 37 * i, seed=i) for i in range(8)] + [np.zeros(0, np.uint8), C.zeros(70000), b"x"]
+    res = eng.deflate(bufs, level=6, crc32=True)
+    for b, r in zip(bufs, res):
+        assert r.data == O.deflate(b, 6) and r.crc32 == O.crc32(b)
+
+
+@pytest.mark.parametrize("strategy", [1, 2])
+def test_strategies(eng, strategy):
+    data = C.mixed(400000, seed=9)
+    assert eng.deflate([data], level=6, strategy=strategy)[0].data == O.deflate(data, 6, strategy=strategy)
+
+
+def test_zlib_framing(eng):
+    data = C.generate("logs", 5, 0, 300000)
+    for lv in (5, 6, 9):
+        r = eng.deflate([data], level=lv, nowrap=False)[0]
+        assert r.data == O.deflate(data, lv, nowrap=False)
+        assert zlib.decompress(r.data) == data.tobytes()
+
+
+def test_stage_intermediates_match_model(eng):
+    """Stage-by-stage diff against oracle/szl_model.c: links, match tables, tokens, block table."""
+    data = C.mixed(600000, seed=4)
+    r = eng.deflate([data], level=6)[0]
+    link, m2, mq, tok = eng.debug_fetch(data.size)
+    M = O.Model(data, 6)
+    assert np.array_equal(link, M.link[:data.size])
+    assert np.array_equal(m2, M.m2[:data.size]) and np.array_equal(mq, M.mq[:data.size])
+    ref, tr = O.deflate(data, 6, trace=True)
+    assert np.array_equal(tok, tr["tokens"])
+    blocks = eng.debug_blocks()
+    assert [(b["type"], b["last"], b["ntokens"], b["bit_start"], b["opt_len"], b["static_len"], b["stored_len"]) for b in blocks] == \
+           [(b["type"], b["last"], b["ntokens"], b["bit_start"], b["opt_len"], b["static_len"], b["stored_len"]) for b in tr["blocks"]]
+    assert r.data == ref
+
+
+# ---- the streaming object: call patterns of the reference's tests through Deflater/DeflaterOutputStream mirrors
+def _deflate_like_reference_test(data, level, zlib_framing):
+    """T/Base/InflaterDeflaterTests.cs:49-62 — Write, Flush, Finish through DeflaterOutputStream."""
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.streams import DeflaterOutputStream
+    ms = io.BytesIO()
+    d = Deflater(level, not zlib_framing)
+    s = DeflaterOutputStream(ms, d)
+    s.IsStreamOwner = False
+    s.Write(data, 0, len(data))
+    s.Flush()
+    s.Finish()
+    return ms.getvalue(), d
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 8, 9])
+@pytest.mark.parametrize("zlib_framing", [True, False])
+def test_random_deflate_inflate_reference_pattern(level, zlib_framing):
+    data = O.dotnet_random_bytes(5, 100000)   # Utils.GetDummyBytes(100000, seed 5)
+    got, d = _deflate_like_reference_test(data, level, zlib_framing)
+    assert got == O.deflate(data, level, nowrap=not zlib_framing, flush=True)
+    assert d.TotalIn == data.size and d.TotalOut == len(got) and d.IsFinished
+    n, out, _ = O.inflate(got, nowrap=not zlib_framing, max_out=data.size + 16)
+    assert out == data.tobytes()
+
+
+def test_streaming_chunks_flushes_and_reset():
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.streams import DeflaterOutputStream
+    data = C.mixed(500000, seed=12)
+    d = Deflater(6, True)
+    for chunk, flush_every in ((4096, None), (65274, None), (7777, 50000), (100000, 100000)):
+        ms = io.BytesIO()
+        d.Reset()
+        s = DeflaterOutputStream(ms, d, 4096)
+        s.IsStreamOwner = False
+        since = 0
+        for pos in range(0, data.size, chunk):
+            c = data[pos:pos + chunk]
+            s.Write(c, 0, c.size)
+            since += c.size
+            if flush_every and since >= flush_every and pos + chunk < data.size:
+                s.Flush()
+                since = 0
+        s.Finish()
+        ref, tin, tout = O.stream_deflate(data, 6, True, chunk=chunk, flush_every=flush_every)
+        assert ms.getvalue() == ref
+        assert d.TotalIn == tin == data.size and d.TotalOut == tout
+
+
+def test_deflater_state_errors():
+    from sharpziplib_amd.deflater import Deflater, InvalidOperation, NotSupportedOnDevice
+    d = Deflater(6, True)
+    d.SetInput(b"abc")
+    d.Finish()
+    with pytest.raises(InvalidOperation):
+        d.SetInput(b"more")       # "Finish() already called" C/Deflater.cs:333-336
+    out = np.zeros(64, np.uint8)
+    n = d.Deflate(out)
+    assert out[:n].tobytes() == O.deflate(b"abc", 6) and d.IsFinished
+    with pytest.raises(NotSupportedOnDevice):
+        Deflater(1, True)

@@ -1,0 +1,232 @@
+"""CPU tests of the oracle (C restatement of the reference) against every known answer the
+reference's own tests hold for this path, plus structural properties."""
+import base64
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from sharpziplib_amd import corpus as C
+
+LEVELS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+
+
+# ---- checksum known answers: T/Checksum/ChecksumTests.cs
+def test_crc32_kat():
+    check = b"123456789"
+    long_check = check * 4
+    assert O.crc32(b"") == 0
+    assert O.crc32(check) == 0xCBF43926            # :114
+    assert O.crc32(long_check) == 0x3E29169C       # :127
+    assert O.crc32(check[3:6]) == 0xB1A8C371       # :136
+    assert O.crc32(long_check[15:33]) == 0x31CA9A2E  # :145
+    # incremental == one shot
+    assert O.crc32(long_check[10:], O.crc32(long_check[:10])) == 0x3E29169C
+
+
+def test_adler32_kat():
+    assert O.adler32(b"") == 1
+    assert O.adler32(b"123456789") == 0x091E01DE   # :31
+
+
+def test_adler32_256mib_dotnet_random():
+    """T/Checksum/ChecksumTests.cs:41-61 — 256 MiB of new Random(1) then "123456789" -> 0xD4897DA3.
+    Pins both the System.Random restatement (used for GetDummyBytes inputs) and Adler32."""
+    buf = O.dotnet_random_bytes(1, 256 * 1024 * 1024)
+    assert O.adler32(b"123456789", O.adler32(buf)) == 0xD4897DA3
+
+
+# ---- Inflater fixtures: T/Zip/ZipCorruptionHandling.cs
+ZERO_CODE_LENGTH = ("UEsDBBQA+AAIANwyZ0U5T8HwjQAAAL8AAAAIABUAbGltZXJpY2t"
+                    "VVAkAAzBXXFR6LmBUVXgEAPQB9AEFjTEOwjAQBHu/YkVDg3gHoUaivjgHtmKfI5+D5d9zbndHM6/AldFJQTIJ"
+                    "PrVkPOkgce9QlJFi5hr9rhD+cUUvZ9qgnuRuBAtId97Qw0AL1Kbw5h6MykeKdlyWdlWs7OlUdgsodRqKVo0v8"
+                    "JWyGWZ6mLpuiii2t2Bl0mZ54QksOIpqXNPATF/eH1BLAQIXAxQAAgAIANxQZ0U5T8HwjQAAAL8AAAAIAA0AAA"
+                    "AAAAEAAACggQAAAABsaW1lcgEAQwAAAMgAAAAAAA==")
+BAD_CD_GOOD_CD64 = ("UEsDBC0AAAAIANhy+k4cj+r8//////////8IABQAdGVzdGZpbGUBABAAAAA"
+                    "AAAAAAAAUAAAAAAAAACtJLS5Jy8xJVUjOzytJzSsp5gIAUEsBAjMALQAAAAgA2HL6ThyP6vz//////////wgAFAAAAAAAA"
+                    "AAAAAAAAAAAAHRlc3RmaWxlAQAQABIAAAAAAAAAFAAAAAAAAABQSwUGAAAAAAEAAQBKAAAATgAAAAAA")
+
+
+def _first_local_entry(zipbytes):
+    sig, ver, flags, method, mt, md, crc, csize, usize, nlen, xlen = struct.unpack_from("<IHHHHHIIIHH", zipbytes, 0)
+    assert sig == 0x04034B50 and method == 8
+    off = 30 + nlen + xlen
+    return zipbytes[off:], crc, csize, usize
+
+
+def test_inflater_fixture_testfile_contents():
+    z = base64.b64decode(BAD_CD_GOOD_CD64)
+    payload, crc, _, _ = _first_local_entry(z)
+    payload = payload[:20]
+    assert payload.hex() == "2b492d2e49cbcc495548cecf2b49cd2b29e60200"
+    n, out, consumed = O.inflate(payload, nowrap=True)
+    assert out == b"testfile contents\n" and n == 18 and consumed == 20
+    assert O.crc32(out) == 0xFCEA8F1C == crc
+    # and the encoder reproduces the reference fixture's payload bit for bit
+    assert O.deflate(b"testfile contents\n", 6) == payload
+
+
+def test_inflater_fixture_zero_code_length_must_fail():
+    z = base64.b64decode(ZERO_CODE_LENGTH)
+    payload, _, csize, _ = _first_local_entry(z)
+    n, _, _ = O.inflate(payload[:csize], nowrap=True)
+    assert n == -8, n  # SZO_ERR_CODELEN_ZERO == "Encountered invalid codelength 0" (C/InflaterHuffmanTree.cs:191-193)
+
+
+# ---- encoder vectors
+VECTORS = [
+    (b"", 6, "0300"), (b"", 0, "010000ffff"), (b"x", 6, "ab0000"), (b"Hello", 6, "f348cdc9c90700"),
+    (b"Hello", 0, "010500faff48656c6c6f"), (b"Hello, world", 6, "f348cdc9c9d75128cf2fca490100"),
+    (b"a" * 32, 6, "4b240000"), (b"abc" * 10, 6, "4b4c4ac68300"),
+]
+
+
+@pytest.mark.parametrize("data,level,hexout", VECTORS)
+def test_encoder_vectors(data, level, hexout):
+    assert O.deflate(data, level).hex() == hexout
+
+
+def test_encoder_flush_finish_vector():
+    assert O.deflate(b"Hello", 6, flush=True).hex() == "f248cdc9c9070820c000"  # Write+Flush+Finish (T/Base/InflaterDeflaterTests.cs:57-59)
+
+
+def test_encoder_sizes_differ_from_zlib():
+    assert len(O.deflate(C.zeros(200000), 6)) == 210 and len(O.deflate(C.zeros(200000), 1)) == 890
+    r = O.dotnet_random_bytes(5, 100000)
+    assert len(O.deflate(r, 0)) == 100015
+    for lv in range(1, 10):
+        assert len(O.deflate(r, lv)) == 100035
+
+
+# ---- T/Base/InflaterDeflaterTests.cs RandomDeflateInflate: levels 0-9 x {zlib, raw}, GetDummyBytes(100000, seed 5)
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("zlib_framing", [True, False])
+def test_random_deflate_inflate(level, zlib_framing):
+    data = O.dotnet_random_bytes(5, 100000)
+    comp = O.deflate(data, level, nowrap=not zlib_framing, flush=True)
+    n, out, consumed = O.inflate(comp, nowrap=not zlib_framing, max_out=data.size + 16)
+    assert n == data.size and out == data.tobytes() and consumed == len(comp)
+    assert (zlib.decompress(comp) if zlib_framing else zlib.decompress(comp, -15)) == data.tobytes()
+
+
+CLASSES = {
+    "dickens": lambda: C.generate("dickens", 0xD1CE, 0, 300000), "enwik": lambda: C.generate("enwik", 0xE9, 0, 300000),
+    "logs": lambda: C.generate("logs", 0x106, 0, 300000), "random": lambda: C.random_bytes(70000),
+    "zeros": lambda: C.zeros(140000), "acgt": lambda: C.four_symbol(150000), "p10": lambda: C.period10(90000),
+    "mixed": lambda: C.mixed(400000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CLASSES))
+@pytest.mark.parametrize("level", [1, 4, 5, 6, 9])
+def test_roundtrip_and_zlib_decodes(name, level):
+    data = CLASSES[name]()
+    comp = O.deflate(data, level)
+    assert zlib.decompress(comp, -15) == data.tobytes()
+    n, out, consumed = O.inflate(comp, max_out=data.size + 16)
+    assert n == data.size and out == data.tobytes() and consumed == len(comp)
+
+
+@pytest.mark.parametrize("level", [5, 6, 9])
+def test_chunk_independence(level):
+    """at L5-9 the output does not depend on how Write/SetInput chunk the data."""
+    data = C.mixed(300000, seed=7)
+    ref = O.deflate(data, level)
+    for chunk in (7, 512, 4096, 32506, 65274):
+        got, tin, tout = O.stream_deflate(data, level, chunk=chunk)
+        assert got == ref and tin == data.size and tout == len(ref)
+
+
+def test_inflater_stops_exactly_and_reports_remaining_input():
+    data = C.generate("dickens", 3, 0, 50000)
+    comp = O.deflate(data, 6) + b"TRAILERBYTES"
+    inf = O.Inflater(nowrap=True)
+    inf.set_input(comp)
+    out = bytearray()
+    while not inf.finished:
+        k, b = inf.inflate(777)
+        assert k >= 0
+        out += b
+        if k == 0 and inf.needs_input:
+            break
+    assert bytes(out) == data.tobytes() and inf.finished
+    assert inf.remaining_input == 12 and inf.total_in == len(comp) - 12 and inf.total_out == data.size
+
+
+def test_inflate_foreign_zlib_streams():
+    """T/Zip/PassthroughTests.cs: the reference inflates BCL/zlib-produced deflate streams."""
+    data = C.generate("enwik", 11, 0, 200000).tobytes()
+    for lv in (1, 6, 9):
+        co = zlib.compressobj(lv, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        n, out, consumed = O.inflate(comp, max_out=len(data) + 16)
+        assert out == data and consumed == len(comp)
+
+
+def test_zlib_framing_and_adler():
+    data = C.generate("logs", 5, 0, 100000)
+    comp = O.deflate(data, 6, nowrap=False)
+    assert comp[:2] == b"\x78\x9c" and zlib.decompress(comp) == data.tobytes()
+    assert struct.unpack(">I", comp[-4:])[0] == zlib.adler32(data.tobytes()) == O.adler32(data)
+    bad = bytearray(comp); bad[-1] ^= 1
+    n, _, _ = O.inflate(bytes(bad), nowrap=False, max_out=data.size + 16)
+    assert n == -5  # Adler chksum doesn't match
+
+
+# ---- the parallel decomposition (what the HIP kernels implement) equals the engine
+@pytest.mark.parametrize("name", sorted(CLASSES))
+@pytest.mark.parametrize("level", [5, 6, 8, 9])
+def test_model_tokens_equal_engine(name, level):
+    data = CLASSES[name]()
+    comp, tr = O.deflate(data, level, trace=True)
+    M = O.Model(data, level)
+    tok, _ = M.parse()
+    assert np.array_equal(tok, tr["tokens"])
+    tok2, _ = M.parse(R=4096)
+    assert np.array_equal(tok2, tr["tokens"])
+    first, cnt, last = M.block_table(tok)
+    assert [b["ntokens"] for b in tr["blocks"]] == list(cnt) and [b["last"] for b in tr["blocks"]] == list(last)
+
+
+@pytest.mark.parametrize("strategy", [1, 2])
+def test_model_strategies(strategy):
+    data = C.mixed(250000, seed=9)
+    comp, tr = O.deflate(data, 6, strategy=strategy, trace=True)
+    M = O.Model(data, 6, strategy=strategy)
+    tok, _ = M.parse()
+    assert np.array_equal(tok, tr["tokens"])
+    assert zlib.decompress(comp, -15) == data.tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 261, 262, 263, 32505, 32506, 32507, 65273, 65274, 65275, 65536, 98041, 98042])
+def test_model_boundary_sizes(n):
+    data = C.generate("dickens", 21, 0, n) if n else np.zeros(0, np.uint8)
+    for lv in (6, 9):
+        comp, tr = O.deflate(data, lv, trace=True)
+        tok, _ = O.Model(data, lv).parse()
+        assert np.array_equal(tok, tr["tokens"])
+
+
+def test_block_table_token_multiple_edges():
+    """Blocks are cut every 16384 tokens; the tail rules depend on the kind of the last token."""
+    r = C.random_bytes(16384 * 2)          # 1 token per byte, last token a literal
+    for n in (16384, 16385, 16384 * 2):
+        comp, tr = O.deflate(r[:n], 6, trace=True)
+        M = O.Model(r[:n], 6); tok, _ = M.parse()
+        assert np.array_equal(tok, tr["tokens"])
+        first, cnt, last = M.block_table(tok)
+        assert [b["ntokens"] for b in tr["blocks"]] == list(cnt) and [b["last"] for b in tr["blocks"]] == list(last)
+    # last token a match and token count a multiple of 16384: random prefix then a long repeat
+    base = C.random_bytes(16383, seed=5)
+    data = np.concatenate([base, base[:300]])
+    for cut in range(16383 + 3, 16383 + 300, 37):
+        d = data[:cut]
+        for flush in (False, True):
+            comp, tr = O.deflate(d, 6, flush=flush, trace=True)
+            M = O.Model(d, 6); tok, _ = M.parse()
+            nblk_first_seg = [b for b in tr["blocks"]]
+            first, cnt, last = M.block_table(tok, finish=not flush)
+            got = [b["ntokens"] for b in nblk_first_seg][:len(cnt)]
+            assert got == list(cnt), (cut, flush, got, list(cnt))

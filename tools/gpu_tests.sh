@@ -1,0 +1,5 @@
+#!/bin/bash
+# Run on the GPU box: parity tests + smoke + bench; logs under gpurun_out/
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu 2>&1 | tail -15
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
