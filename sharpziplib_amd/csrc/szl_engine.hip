@@ -14,7 +14,7 @@ namespace szl {
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans, int nspans,
                   uint16_t *link, hipStream_t st);
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, uint2 *mtab,
-                        LevelParams P, hipStream_t st);
+                        LevelParams P, unsigned long long *dbg, hipStream_t st);
 void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, hipStream_t st);
 void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
@@ -167,7 +167,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, st);
     HIPCHK(hipEventRecord(ev[2], st));
     // B: match tables
-    HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, (uint2 *)mtab.p, P, st));
+    HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, (uint2 *)mtab.p, P, dcnt, st));
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
     launch_spec(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
@@ -202,6 +202,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     timing.in_bytes = seg_bytes;
     timing.ranges_unmerged = hc[0];
     timing.fallback_walks = hc[1];
+    if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] match: wave-iterations %llu, quick lane-steps %llu, verify lane-steps %llu, positions %llu\n", hc[2], hc[3], hc[4], (unsigned long long)seg_bytes);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
     return 0;

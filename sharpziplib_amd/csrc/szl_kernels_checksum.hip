@@ -127,8 +127,22 @@ __global__ __launch_bounds__(CK_THREADS) void k_ck_fold(const SegDev *__restrict
             mylen += p.len;
         }
     }
+    // (crc, x^(8*len)) pairs combine associatively: crc = op_B * crc_A ^ crc_B ; op = op_A * op_B.  Log-tree over threads.
+    __shared__ uint32_t s_op[CK_THREADS];
     s_crc[tid] = mycrc; s_len[tid] = mylen;
+    s_op[tid] = (want & 1) ? x2nmodp(mylen, 3) : (1u << 31);
     __syncthreads();
+    if (want & 1) {
+        for (int stride = 1; stride < CK_THREADS; stride <<= 1) {
+            if ((tid & (2 * stride - 1)) == 0) {
+                const int r = tid + stride;
+                const uint32_t opB = s_op[r];
+                s_crc[tid] = multmodp(opB, s_crc[tid]) ^ s_crc[r];
+                s_op[tid] = multmodp(s_op[tid], opB);
+            }
+            __syncthreads();
+        }
+    }
     if (tid == 0) {
         uint32_t adler = s.adler_init;
         if (want & 2) {
@@ -138,12 +152,7 @@ __global__ __launch_bounds__(CK_THREADS) void k_ck_fold(const SegDev *__restrict
             adler = (uint32_t)((s2 << 16) | s1);
         }
         uint32_t crc = s.crc_init;
-        if (want & 1) {
-            for (int t = 0; t < CK_THREADS; t++) {
-                if (s_len[t] == 0) continue;
-                crc = multmodp(x2nmodp(s_len[t], 3), crc) ^ s_crc[t];
-            }
-        }
+        if (want & 1) crc = (crc ? multmodp(s_op[0], crc) : 0u) ^ s_crc[0];
         so[si].crc32 = crc;
         so[si].adler32 = adler;
     }

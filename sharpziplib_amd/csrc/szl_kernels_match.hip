@@ -56,59 +56,82 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
     int bi = 0;
     const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    for (int64_t q0 = warm0; q0 < span.end; q0 += 64) {
-        if (q0 != warm0 && ((q0 - warm0) & 16383) == 0) {
+    for (int64_t q00 = warm0; q00 < span.end; q00 += 256) {
+        if (q00 != warm0 && ((q00 - warm0) & 16383) == 0) {
             for (int i = lane; i < 2048; i += 64) {
-                uint32_t dist = (uint32_t)(q0 - myhead[i]) & 0xFFFF;
-                if (dist >= 32768u || dist == 0u) myhead[i] = (uint16_t)((q0 - 40000) & 0xFFFF);
+                uint32_t dist = (uint32_t)(q00 - myhead[i]) & 0xFFFF;
+                if (dist >= 32768u || dist == 0u) myhead[i] = (uint16_t)((q00 - 40000) & 0xFFFF);
             }
         }
-        const int64_t q = q0 + lane;
-        while (bi < nb && (int64_t)b[bi] <= q0) bi++; // wave-uniform
-        bool ins = q < span.end;
-        if (bi < nb && (int64_t)b[bi] < q0 + 66) {     // a segment end is near: InsertString needs lookahead >= 3 (:780,:817)
-            int j = bi;
-            while (j < nb && (int64_t)b[j] <= q) j++;
-            ins = ins && j < nb && (int64_t)b[j] - q >= 3;
-        } else if (bi >= nb) {
-            ins = false;
-        }
-        uint32_t idx = 0;
-        bool owned = false;
-        if (ins) {
-            uint32_t b0, b1, b2;
-            if ((uint64_t)q + 4 <= avail) {
-                uint32_t w = load_u32_unaligned(d + q);
-                b0 = w & 0xFF; b1 = (w >> 8) & 0xFF; b2 = (w >> 16) & 0xFF;
-            } else { b0 = d[q]; b1 = d[q + 1]; b2 = d[q + 2]; }
-            uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
-            uint32_t o = (h ^ (h >> 5) ^ (h >> 10)) & 15;         // owner wavefront (bijective with h>>4)
-            idx = (o << 11) | (h >> 4);
-            owned = (int)o == wave;
-        }
-        uint32_t e_old = owned ? head[idx] : 0;
-        uint64_t mm = __ballot(owned);
-        int predlane = -1;
-        bool islast = false;
-        while (mm) {
-            int l = __builtin_ctzll(mm);
-            uint32_t k = __builtin_amdgcn_readlane(idx, l);
-            bool mine = owned && idx == k;
-            uint64_t same = __ballot(mine);
-            if (mine) {
-                uint64_t below = same & lanemask_lt;
-                predlane = below ? 63 - __builtin_clzll(below) : -1;
-                islast = ((same >> lane) >> 1) == 0;
+        // ---- issue the four batches' loads first (one global round trip per 256 positions)
+        while (bi < nb && (int64_t)b[bi] <= q00) bi++; // wave-uniform
+        const bool near_bnd = bi >= nb || (int64_t)b[bi] < q00 + 256 + 2;
+        uint32_t w4[4];
+        bool ins4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t q = q00 + 64 * k + lane;
+            bool ins = q < span.end;
+            if (near_bnd) { // a segment end is near: InsertString needs lookahead >= 3 (:780,:817)
+                int j = bi;
+                while (j < nb && (int64_t)b[j] <= q) j++;
+                ins = ins && j < nb && (int64_t)b[j] - q >= 3;
             }
-            mm &= ~same;
+            uint32_t w = 0;
+            if (ins) {
+                if ((uint64_t)q + 4 <= avail) w = load_u32_unaligned(d + q);
+                else w = (uint32_t)d[q] | ((uint32_t)d[q + 1] << 8) | ((uint32_t)d[q + 2] << 16);
+            }
+            w4[k] = w; ins4[k] = ins;
         }
-        if (owned) {
-            uint32_t dist = predlane >= 0 ? (uint32_t)(lane - predlane) : ((uint32_t)(q - e_old) & 0xFFFF);
-            if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
-            if (q >= span.start) lk[q] = (uint16_t)dist;
-            if (islast) head[idx] = (uint16_t)(q & 0xFFFF);
-        } else if (!ins && wave == 0 && q >= span.start && q < span.end) {
-            lk[q] = 0; // position never inserted (tail of a segment)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t q0 = q00 + 64 * k;
+            if (q0 >= span.end) break;
+            const int64_t q = q0 + lane;
+            const bool ins = ins4[k];
+            const uint32_t w = w4[k];
+            const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
+            const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
+            const uint32_t o = (h ^ (h >> 5) ^ (h >> 10)) & 15;         // owner wavefront (bijective with h>>4)
+            const uint32_t idx = (o << 11) | (h >> 4);
+            const bool owned = ins && (int)o == wave;
+            // Fast path: most batches hold no two owned positions with the same bucket.  All owned lanes store their
+            // position into the bucket and read it back; a lane that reads something else lost to a same-bucket lane.
+            // Only then is the exact "previous lane with my bucket" computed with the ballot loop below.
+            const uint32_t myq16 = (uint32_t)q & 0xFFFF;
+            uint32_t e_old = 0, rb = myq16;
+            if (owned) { // volatile: the read-back must really hit LDS (another lane of this wave may have overwritten it)
+                volatile uint16_t *vh = head;
+                e_old = vh[idx];
+                vh[idx] = (uint16_t)myq16;
+                rb = vh[idx];
+            }
+            int predlane = -1;
+            bool islast = true;
+            if (__ballot(owned && rb != myq16)) {
+                uint64_t mm = __ballot(owned);
+                while (mm) {
+                    int l = __builtin_ctzll(mm);
+                    uint32_t kk = __builtin_amdgcn_readlane(idx, l);
+                    bool mine = owned && idx == kk;
+                    uint64_t same = __ballot(mine);
+                    if (mine) {
+                        uint64_t below = same & lanemask_lt;
+                        predlane = below ? 63 - __builtin_clzll(below) : -1;
+                        islast = ((same >> lane) >> 1) == 0;
+                    }
+                    mm &= ~same;
+                }
+            }
+            if (owned) {
+                uint32_t dist = predlane >= 0 ? (uint32_t)(lane - predlane) : ((uint32_t)(q - e_old) & 0xFFFF);
+                if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
+                if (q >= span.start) lk[q] = (uint16_t)dist;
+                if (islast) head[idx] = (uint16_t)(q & 0xFFFF);
+            } else if (!ins && wave == 0 && q >= span.start && q < span.end) {
+                lk[q] = 0; // position never inserted (tail of a segment)
+            }
         }
     }
 }
@@ -130,7 +153,7 @@ enum : int { B_LDS_BYTES = B_DATA_BYTES + B_LINKS * 2 + 16 };
 
 __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                      const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                     uint2 *__restrict__ mtab, LevelParams P) {
+                                                     uint2 *__restrict__ mtab, LevelParams P, unsigned long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *sdata32 = (uint32_t *)smem;                          // B_DATA_BYTES
     uint16_t *slink = (uint16_t *)(smem + B_DATA_BYTES);           // B_LINKS entries
@@ -178,107 +201,127 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
         uint32_t w0 = sdata32[i >> 2], w1 = sdata32[(i >> 2) + 1];
         return __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(i & 3));
     };
+    const uint8_t *sdata8 = smem;
 
-    const int SNAP = P.max_chain >> 2;
-    enum { M_FETCH = 0, M_CHAIN = 1, M_EXT = 2, M_DONE = 3 };
-    int mode = M_FETCH;
-    int p = 0;        // tile-relative position
-    int pl = 0;       // LDS data index of p
-    int cl = 0;       // LDS data index of the current candidate
-    int mincl = 0;    // lowest admissible candidate (LDS index) for chain continuation
-    int best = 2, cap = 0, nice = 0, budget = 0, cnt = 0, off = 0, qoff = 0;
-    uint32_t pq = 0, res2 = 0, resq = 0;
+    // Three phases per outer iteration, each a tight loop of its own so that the hot one (the chain step, ~80 % of
+    // all lane-steps) is a couple of dozen instructions: FETCH hands out positions, QUICK walks chains — one byte
+    // (quick reject at offset `best`, :505) and one u16 (the candidate's link) from LDS per step — until too many
+    // lanes have dropped out, VERIFY compares the candidates that passed the quick test dword by dword.
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2); // `left` value at which the quarter-budget walk would stop
+    enum { NEED = 0, QUICK = 1, VERIFY = 2, DONE = 3 };
+    enum { Q_THRESH = 36 };
+    int wnext = 0, wend = 0;       // wave-uniform slice of tile positions being handed out
+    bool exhausted = false;
+    int mode = NEED;
+    int pl = B_HIST, cl = B_HIST, off = 0, lnk = 0;
+    int best = 2, cap = 4, nice = 4, mincl = 0, left = 1, p = 0;
+    uint32_t pb = 0, res2 = 0, resq = 0;
+    unsigned long long n_it = 0, n_q = 0, n_v = 0;
 
     for (;;) {
-        if (mode == M_FETCH) {
-            int k = atomicAdd(s_counter, 1);
-            if (k >= tlen) mode = M_DONE;
-            else {
-                p = k;
-                pl = p + B_HIST;
+        // ---------------- retire finished positions, hand out new ones
+        if (mode == DONE) {
+            if (left > SNAPLEFT) resq = res2; // the quarter-budget walk would have ended here as well
+            mt[t0 + p] = make_uint2(res2, resq);
+            mode = NEED;
+        }
+        const uint64_t nm = __ballot(mode == NEED);
+        if (nm) {
+            if (wnext >= wend && !exhausted) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(s_counter, 256);
+                base = __builtin_amdgcn_readfirstlane(base);
+                wnext = base < tlen ? base : tlen;
+                wend = base + 256 < tlen ? base + 256 : tlen;
+                if (wnext >= wend) exhausted = true;
+            }
+            const int rank = __builtin_popcountll(nm & lanemask_lt);
+            if (mode == NEED && wnext + rank < wend) {
+                p = wnext + rank;
                 const int64_t Pp = t0 + p;
                 const int64_t rem = seg_end - Pp;
                 res2 = 0; resq = 0;
-                bool ok = rem >= MIN_MATCH && P.strategy != 2;  // :780, HuffmanOnly :786
-                uint32_t l0 = ok ? slink[pl] : 0;               // hashHead (:782)
-                ok = ok && l0 != 0;
+                bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
                 if (ok) {
+                    pl = p + B_HIST;
+                    const int l0 = (int)slink[pl];                           // hashHead (:782)
                     const int64_t pabs = (int64_t)seg.abs0 + Pp;
-                    const int64_t basem = base_of(pabs) - (int64_t)seg.abs0; // buffer position of window index 1 is basem
+                    const int64_t basem = base_of(pabs) - (int64_t)seg.abs0; // buffer position whose window index is 1
                     // first candidate: strstart - hashHead <= MAX_DIST (:788) and entry not clamped by a slide (index >= 1)
-                    int64_t c = Pp - l0;
-                    int64_t firstmin = Pp - MAX_DIST > basem ? Pp - MAX_DIST : basem;
-                    ok = c >= firstmin;
+                    const int64_t firstmin = Pp - MAX_DIST > basem ? Pp - MAX_DIST : basem;
+                    const int64_t chainmin = Pp - (MAX_DIST - 1) > basem ? Pp - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
+                    cl = pl - l0;
+                    ok = l0 != 0 && cl >= (int)(firstmin - dlo);
                     if (ok) {
+                        mincl = (int)(chainmin - dlo);
                         cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;         // scanMax :479
                         nice = P.nice < (int)rem ? P.nice : (int)rem;        // :485
-                        int64_t minc = Pp - (MAX_DIST - 1) > basem ? Pp - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
-                        mincl = (int)(minc - dlo);
-                        cl = (int)(c - dlo);
-                        best = 2; budget = P.max_chain; cnt = 0; qoff = 0;
-                        pq = ldsdw(pl);
-                        mode = M_CHAIN;
+                        best = 2; left = P.max_chain;
+                        pb = sdata8[pl + 2];
+                        mode = QUICK;
                     }
                 }
                 if (!ok) mt[t0 + p] = make_uint2(0u, 0u);
             }
-        } else if (mode != M_DONE) {
-            int L = -1; // >=0: candidate fully compared with common prefix L
-            if (mode == M_CHAIN) {
-                uint32_t cd = ldsdw(cl + qoff);
-                if (best == 2) {
-                    uint32_t x = cd ^ pq;
-                    int l4 = x ? (__builtin_ctz(x) >> 3) : 4;
-                    if (l4 >= 3) {
-                        if (l4 == 4 && cap > 4) { mode = M_EXT; off = 4; }
-                        else L = l4 < cap ? l4 : cap;
-                    } else L = 0;
-                } else {
-                    if (cd == pq) { mode = M_EXT; off = 0; } // bytes best-3..best agree: compare from the start
-                    else L = 0;
-                }
-            } else { // M_EXT
-                uint32_t x = ldsdw(cl + off) ^ ldsdw(pl + off);
-                if (x == 0) {
-                    off += 4;
-                    if (off >= cap) L = cap;
-                } else {
-                    int l = off + (__builtin_ctz(x) >> 3);
-                    L = l < cap ? l : cap;
-                }
-            }
-            if (L >= 0) {
-                bool finish = false;
-                mode = M_CHAIN;
-                if (L > best) { // :593-607
-                    best = L;
-                    res2 = (uint32_t)L | ((uint32_t)(pl - cl) << 16);
-                    if (best >= nice) {
-                        finish = true;
-                        if (cnt < SNAP) resq = res2;
-                    } else {
-                        qoff = best - 3;
-                        pq = ldsdw(pl + qoff);
-                    }
-                }
-                if (!finish) {
-                    cnt++;
-                    if (cnt == SNAP) resq = res2;
-                    uint32_t l = slink[cl];
-                    int c2 = cl - (int)l;
-                    if (l == 0 || c2 < mincl || --budget == 0) {
-                        finish = true;
-                        if (cnt < SNAP) resq = res2;
-                    } else cl = c2;
-                }
-                if (finish) {
-                    mt[t0 + p] = make_uint2(res2, resq);
-                    mode = M_FETCH;
-                }
-            }
+            const int taken = __builtin_popcountll(nm);
+            wnext = wnext + taken < wend ? wnext + taken : wend;
+            if (exhausted && __all(mode == NEED)) break;
         }
-        if (__all(mode == M_DONE)) break;
+        // ---------------- QUICK: chain steps while most lanes are still walking (branch-free body)
+        uint64_t qm = __ballot(mode == QUICK);
+        while (qm) {
+            n_it++; n_q += __builtin_popcountll(qm);
+            if (mode == QUICK) {
+                const uint32_t qb = sdata8[cl + best];   // a longer match must agree at offset `best` (scan_end, :505)
+                lnk = (int)slink[cl];
+                const bool pass = qb == pb;
+                // next candidate of the chain, or the end of this position (:609)
+                const int left1 = left - 1;
+                const int c2 = cl - lnk;
+                const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
+                resq = (!pass && left1 == SNAPLEFT) ? res2 : resq;
+                left = pass ? left : left1;
+                cl = (pass | end) ? cl : c2;
+                off = 0;
+                mode = pass ? VERIFY : (end ? DONE : QUICK);
+            }
+            qm = __ballot(mode == QUICK);
+            if (__builtin_popcountll(qm) <= Q_THRESH) break;
+        }
+        // ---------------- VERIFY: full comparison of the candidates that passed the quick test
+        uint64_t vm = __ballot(mode == VERIFY);
+        while (vm) {
+            n_it++; n_v += __builtin_popcountll(vm);
+            if (mode == VERIFY) {
+                const uint32_t x = ldsdw(cl + off) ^ ldsdw(pl + off);
+                const bool eq = x == 0;
+                const int l = off + (eq ? 4 : (__builtin_ctz(x) >> 3));
+                const bool more = eq & (l < cap);
+                off = l;
+                if (!more) {
+                    const int L = l < cap ? l : cap;
+                    bool nicehit = false;
+                    if (L > best) { // :593-607
+                        best = L;
+                        res2 = (uint32_t)L | ((uint32_t)(pl - cl) << 16);
+                        nicehit = L >= nice;
+                        if (!nicehit) pb = sdata8[pl + L];
+                    }
+                    const int left1 = left - 1;
+                    const int c2 = cl - lnk;
+                    const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
+                    resq = (!nicehit && left1 == SNAPLEFT) ? res2 : resq;
+                    left = nicehit ? left : left1;
+                    cl = (nicehit | end) ? cl : c2;
+                    mode = (nicehit | end) ? DONE : QUICK;
+                }
+            }
+            vm = __ballot(mode == VERIFY);
+        }
     }
+    if (dbg && lane == 0) { atomicAdd(dbg + 2, n_it); atomicAdd(dbg + 3, n_q); atomicAdd(dbg + 4, n_v); }
 }
 
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
@@ -289,14 +332,14 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
 int match_lds_bytes() { return B_LDS_BYTES; }
 
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
-                        uint2 *mtab, LevelParams P, hipStream_t st) {
+                        uint2 *mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (ntiles > 0) hipLaunchKernelGGL(k_match, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P);
+    if (ntiles > 0) hipLaunchKernelGGL(k_match, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg);
     return hipGetLastError();
 }
 
