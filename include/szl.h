@@ -106,6 +106,7 @@ typedef struct szl_stream {
     uint32_t adler32;   /* [out] Adler32.Value of the input if SZL_F_ADLER32 or zlib framing */
     int32_t status;     /* [out] per-stream szl_status */
     uint32_t reserved;
+    uint64_t in_consumed; /* [out] inflate: compressed bytes consumed (== Inflater.TotalIn at IsFinished) */
 } szl_stream;
 
 enum { SZL_F_NOWRAP = 1, SZL_F_CRC32 = 2, SZL_F_ADLER32 = 4, SZL_F_SYNC_FLUSH_BEFORE_FINISH = 8 };
@@ -161,7 +162,7 @@ uint32_t szl_inflater_adler(const szl_inflater *s);                         /* A
 
 /* Batch inflate of independent raw-deflate / zlib streams (zip entries, gzip members): one
  * wavefront per stream.  streams[i].in_* = compressed bytes, out_* = region for the decompressed
- * bytes, out_len = [out] decompressed size, reserved = [out] compressed bytes consumed
+ * bytes, out_len = [out] decompressed size, in_consumed = [out] compressed bytes consumed
  * (== Inflater.TotalIn at IsFinished).  flags: SZL_F_NOWRAP, SZL_F_CRC32 (crc of OUTPUT), SZL_F_ADLER32. */
 int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_streams,
                              unsigned flags, void *hip_stream);

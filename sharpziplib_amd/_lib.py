@@ -13,7 +13,7 @@ _lib = None
 class Stream(ctypes.Structure):
     _fields_ = [("in_off", ctypes.c_uint64), ("in_len", ctypes.c_uint64), ("out_off", ctypes.c_uint64),
                 ("out_cap", ctypes.c_uint64), ("out_len", ctypes.c_uint64), ("crc32", ctypes.c_uint32),
-                ("adler32", ctypes.c_uint32), ("status", ctypes.c_int32), ("reserved", ctypes.c_uint32)]
+                ("adler32", ctypes.c_uint32), ("status", ctypes.c_int32), ("reserved", ctypes.c_uint32), ("in_consumed", ctypes.c_uint64)]
 
 
 class Timing(ctypes.Structure):

@@ -91,3 +91,21 @@ class Engine:
         _lib.check(self._L.szl_engine_debug_blocks(self._h, rows.ctypes.data, cap, ctypes.byref(nr)), "debug_blocks")
         names = ("type", "last", "ntokens", "bit_start", "opt_len", "static_len", "stored_len", "hdr_bits")
         return [dict(zip(names, (int(v) for v in rows[8 * i:8 * i + 8]))) for i in range(min(nr.value, cap))]
+
+    def inflate(self, buffers, out_sizes, nowrap=True, crc32=False, adler32=False):
+        """Inflate independent streams (host buffers). out_sizes: capacity of each output region.
+        Returns [(Result, consumed)]."""
+        bufs = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b, dtype=np.uint8) for b in buffers]
+        arr = (_lib.Stream * len(bufs))()
+        io = oo = 0
+        for i, (b, cap) in enumerate(zip(bufs, out_sizes)):
+            arr[i].in_off, arr[i].in_len, arr[i].out_off, arr[i].out_cap = io, b.size, oo, cap
+            io += (b.size + 3) & ~3
+            oo += (cap + 3) & ~3
+        hin = np.zeros(io + 8, dtype=np.uint8)
+        for s, b in zip(arr, bufs):
+            hin[s.in_off:s.in_off + s.in_len] = b
+        hout = np.zeros(oo + 8, dtype=np.uint8)
+        flags = (_lib.F_NOWRAP if nowrap else 0) | (_lib.F_CRC32 if crc32 else 0) | (_lib.F_ADLER32 if adler32 else 0)
+        _lib.check(self._L.szl_inflate_batch_host(self._h, hin.ctypes.data, hout.ctypes.data, arr, len(bufs), flags), "szl_inflate_batch_host")
+        return [(Result(hout[s.out_off:s.out_off + s.out_len].tobytes(), s.crc32, s.adler32, s.status), int(s.in_consumed)) for s in arr]

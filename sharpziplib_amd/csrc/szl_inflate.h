@@ -1,0 +1,36 @@
+// szl_inflate.h — device inflater job/state structures (shared by kernel and host API; not part of the C ABI).
+#pragma once
+#include <stdint.h>
+#include "../../include/szl.h"
+
+namespace szl {
+
+// status values written by k_inflate (>= 0); negative values are szl_status error codes
+enum : int { INF_RUNNING = 0, INF_FINISHED = 1, INF_NEED_INPUT = 2, INF_OUTPUT_FULL = 3 };
+// decoder modes (the reference's 13 modes collapse to these because a token is decoded atomically)
+enum : uint32_t { INF_M_HEADER = 0, INF_M_STORED = 1, INF_M_HUFF = 2, INF_M_DONE = 3, INF_M_ZHEADER = 4 };
+
+struct InfJob {
+    uint64_t in_off;     // arena offset of the first byte of the stream (zlib header included)
+    uint64_t in_len;     // bytes of the stream available so far
+    uint64_t out_off;    // arena offset where this call's output goes
+    uint64_t out_cap;    // bytes that may be produced by this call
+    uint8_t *window;     // 32 KiB device buffer holding the last 32 KiB of output between calls (NULL: one-shot)
+    uint32_t zlib;       // 1: zlib framing (header at mode INF_M_ZHEADER, Adler-32 trailer)
+    uint32_t keep_window;
+    // results
+    uint64_t out_written;
+    uint64_t consumed;   // ceil(bits consumed / 8)  == Inflater.TotalIn at this point
+    int32_t status;
+    uint32_t pad;
+};
+
+struct InfState {
+    uint64_t bitpos, outpos;
+    uint32_t mode, last, stored_left, btype, lnum, dnum, pend_len, pend_dist;
+    int32_t status;
+    uint32_t adler_read;
+    uint8_t lens[320];
+};
+
+} // namespace szl

@@ -1,4 +1,452 @@
-// szl_kernels_inflate.hip — placeholder translation unit (device inflate kernels land here).
+// szl_kernels_inflate.hip — Inflater (C/Inflater.cs) on the device: one wavefront per deflate stream.
+//
+// Reference being restated (C/ = /root/reference/src/ICSharpCode.SharpZipLib/Zip/Compression/):
+//   block headers / stored / static / dynamic         C/Inflater.cs:429-552 (Decode), :283-386 (DecodeHuffman)
+//   length/distance base+extra tables                  C/Inflater.cs:39-68
+//   dynamic header (HLIT/HDIST/HCLEN, RLE 16/17/18)    C/InflaterDynHeader.cs:42-120
+//   code construction                                  C/InflaterHuffmanTree.cs:87-169 (canonical, LSB-first lookup)
+//   32 KiB output window with overlap-safe repeat       CS/OutputWindow.cs:63-92
+// The decoder is resumable at any token (NEED_INPUT / OUTPUT_FULL) like the reference's 13-mode state machine;
+// its persistent state lives in InfState.  Decoding a Huffman stream is bit-serial, so lane 0 decodes while the
+// other 63 lanes of the wavefront do the data movement (match copies inside the LDS window, window flushes to
+// HBM, input staging, table construction); independent streams (zip entries, gzip members) run on other
+// wavefronts — 4 per CU, bounded by the 32 KiB window each keeps in LDS.
 #include <hip/hip_runtime.h>
 #include "szl_internal.h"
-namespace szl { }
+#include "szl_inflate.h"
+
+namespace szl {
+
+enum : int { I_WIN = 32768, I_WMASK = I_WIN - 1, I_STAGE = 1024, I_LPB = 10, I_DPB = 9 };
+
+__constant__ uint16_t c_cplens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_cplext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_cpdist[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_cpdext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_meta_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; // C/InflaterDynHeader.cs:23-24
+
+struct HuffTab {            // canonical code of up to 288 symbols; LSB-first primary table + canonical second level
+    uint16_t first[16];     // first canonical code of each length (MSB-first value)
+    uint16_t count[16];
+    uint16_t offs[16];      // index into sorted[] of the first symbol of each length
+    uint16_t sorted[288];   // symbols ordered by (length, symbol)
+};
+
+struct InfLds {
+    uint8_t win[I_WIN];
+    uint32_t stage[I_STAGE / 4 + 4];
+    uint16_t llut[1 << I_LPB];
+    uint16_t dlut[1 << I_DPB];
+    HuffTab lt, dt;
+    uint8_t lens[320];
+    uint16_t codes[320];
+};
+
+// Build decode tables from code lengths lens[0..n) (all lanes). pb = primary bits.
+__device__ void build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut, int pb, uint16_t *codes, int lane) {
+    for (int i = lane; i < (1 << pb); i += 64) lut[i] = 0;
+    if (lane == 0) {
+        int cnt[16];
+        for (int l = 0; l < 16; l++) cnt[l] = 0;
+        for (int i = 0; i < n; i++) cnt[lens[i]]++;
+        cnt[0] = 0;
+        int code = 0, off = 0;
+        for (int l = 1; l < 16; l++) {
+            T->first[l] = (uint16_t)code; T->count[l] = (uint16_t)cnt[l]; T->offs[l] = (uint16_t)off;
+            code = (code + cnt[l]) << 1;
+            off += cnt[l];
+        }
+        int nxt[16], pos[16];
+        for (int l = 1; l < 16; l++) { nxt[l] = T->first[l]; pos[l] = T->offs[l]; }
+        for (int i = 0; i < n; i++) {
+            int l = lens[i];
+            if (l) { codes[i] = (uint16_t)nxt[l]++; T->sorted[pos[l]++] = (uint16_t)i; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int i = lane; i < n; i += 64) {
+        int l = lens[i];
+        if (l == 0) continue;
+        uint32_t rev = (__builtin_bitreverse32((uint32_t)codes[i]) >> (32 - l)) & ((1u << l) - 1);
+        if (l <= pb) {
+            uint16_t e = (uint16_t)((i << 4) | l);
+            for (uint32_t j = rev; j < (1u << pb); j += (1u << l)) lut[j] = e;
+        } else {
+            lut[rev & ((1u << pb) - 1)] = 0xFFFE; // longer than the primary table: canonical second level
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// decode one symbol from the low bits of `bits` (LSB-first); returns sym | len<<16, or -1 invalid
+__device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut, int pb, uint32_t bits) {
+    uint32_t e = lut[bits & ((1u << pb) - 1)];
+    if (e != 0xFFFE) {
+        if (e == 0) return -1;
+        return (int)(e >> 4) | ((int)(e & 15) << 16);
+    }
+    uint32_t rev15 = __builtin_bitreverse32(bits) >> 17; // first 15 stream bits, MSB-first
+    for (int l = pb + 1; l <= 15; l++) {
+        uint32_t c = rev15 >> (15 - l);
+        uint32_t idx = c - T->first[l];
+        if (idx < T->count[l]) return (int)T->sorted[T->offs[l] + idx] | (l << 16);
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
+                                                InfJob *jobs, InfState *states, uint32_t njobs) {
+    __shared__ InfLds S;
+    const uint32_t ji = blockIdx.x;
+    if (ji >= njobs) return;
+    const int lane = threadIdx.x;
+    InfJob job = jobs[ji];
+    InfState *st = &states[ji];
+    const uint8_t *in = in_base + job.in_off;
+    uint8_t *out = out_base + job.out_off;
+    const uint64_t in_bits = job.in_len * 8ull;
+
+    // ---- load persistent state (wave-uniform scalars via lane 0 reads + broadcast is unnecessary: all lanes read)
+    uint64_t bitpos = st->bitpos, outpos = st->outpos;
+    uint32_t mode = st->mode, lastblk = st->last, stored_left = st->stored_left, btype = st->btype;
+    uint32_t lnum = st->lnum, dnum = st->dnum, pend_len = st->pend_len, pend_dist = st->pend_dist;
+    const uint64_t out_start = outpos;             // stream position of out[0] for this call
+    const uint64_t out_limit = outpos + job.out_cap;
+    uint64_t flushed = outpos;
+    int status = INF_RUNNING;
+
+    // window: restore the last 32 KiB of output
+    if (outpos > 0 && job.window) {
+        for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&S.win[i] = *(const uint4 *)&job.window[i];
+    }
+    // zlib header (C/Inflater.cs:211-249)
+    if (mode == INF_M_ZHEADER) {
+        if (in_bits < 16) status = INF_NEED_INPUT;
+        else {
+            uint32_t h = ((uint32_t)in[0] << 8) | in[1];
+            if (h % 31 != 0) status = SZL_E_HEADER_CHECKSUM;
+            else if ((h & 0x0f00) != (8u << 8)) status = SZL_E_METHOD_UNKNOWN;
+            else if (h & 0x0020) status = SZL_E_UNSUPPORTED; // preset dictionary (DECODE_DICT): host API handles SetDictionary later
+            else { bitpos = 16; mode = INF_M_HEADER; }
+        }
+    }
+    auto rebuild_tables = [&]() {
+        if (btype == 1) {
+            for (int i = lane; i < 288; i += 64) S.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)); // C/InflaterHuffmanTree.cs:34-70
+            if (lane < 32) S.lens[288 + lane] = 5;
+            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            build_tab(S.lens, 288, &S.lt, S.llut, I_LPB, S.codes, lane);
+            build_tab(S.lens + 288, 32, &S.dt, S.dlut, I_DPB, S.codes, lane);
+        } else {
+            build_tab(S.lens, (int)lnum, &S.lt, S.llut, I_LPB, S.codes, lane);
+            build_tab(S.lens + lnum, (int)dnum, &S.dt, S.dlut, I_DPB, S.codes, lane);
+        }
+    };
+    if (status == INF_RUNNING && mode == INF_M_HUFF) {
+        if (btype == 2) for (int i = lane; i < 320; i += 64) S.lens[i] = st->lens[i];
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        rebuild_tables();
+    }
+
+    // ---- input staging: S.stage holds input bytes [sbase, sbase + I_STAGE)
+    uint64_t sbase = ~0ull;
+    auto restage = [&](uint64_t bytepos) {
+        sbase = bytepos & ~3ull;
+        for (int i = lane; i < I_STAGE / 4 + 4; i += 64) {
+            uint64_t p = sbase + 4ull * i;
+            uint32_t w = 0;
+            if (p + 4 <= job.in_len) __builtin_memcpy(&w, in + p, 4);
+            else for (int k = 0; k < 4; k++) if (p + k < job.in_len) w |= (uint32_t)in[p + k] << (8 * k);
+            S.stage[i] = w;
+        }
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    };
+    auto flush = [&](uint64_t upto) { // copy window bytes [flushed, upto) to HBM
+        uint64_t n = upto - flushed;
+        for (uint64_t i = lane; i < n; i += 64) out[flushed - out_start + i] = S.win[(flushed + i) & I_WMASK];
+        flushed = upto;
+    };
+
+    // bit reader (lane 0 owns bb/nb; bitpos is the stream position of bit 0 of bb)
+    uint64_t bb = 0; int nb = 0;
+    auto stage_ok = [&](uint64_t bytepos) { return sbase != ~0ull && bytepos >= sbase && bytepos + 8 <= sbase + I_STAGE; };
+    auto refill = [&]() { // lane 0 only; requires stage_ok((bitpos+nb)>>3)
+        while (nb <= 32) {
+            uint32_t o = (uint32_t)(((bitpos + nb) >> 3) - sbase);
+            uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
+            uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, o & 3);
+            bb |= (uint64_t)x << nb;
+            nb += 32;
+        }
+    };
+
+    enum { EV_NONE = 0, EV_MATCH, EV_RESTAGE, EV_FLUSH, EV_TABLES, EV_STORED, EV_STOP };
+    while (status == INF_RUNNING) {
+        int ev = EV_NONE, ea = 0, eb = 0;
+        // pending match tail from a previous OUTPUT_FULL stop
+        if (pend_len) {
+            if (outpos + pend_len > out_limit) { status = INF_OUTPUT_FULL; break; }
+            ev = EV_MATCH; ea = (int)pend_len; eb = (int)pend_dist; pend_len = 0;
+        } else if (lane == 0) {
+            // ---------------- lane 0: run the bit-serial state machine until something needs the whole wavefront
+            for (;;) {
+                const uint64_t bytepos = (bitpos + nb) >> 3;
+                if (!stage_ok(bytepos)) { ev = EV_RESTAGE; break; }
+                refill();
+                const uint64_t avail = in_bits > bitpos ? in_bits - bitpos : 0; // valid bits from bitpos on
+                if (outpos - flushed >= 16384) { ev = EV_FLUSH; break; }
+                if (mode == INF_M_HEADER) {
+                    if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
+                    if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    uint32_t t = (uint32_t)bb & 7;
+                    uint32_t type = t >> 1;
+                    if (type == 3) { ev = EV_STOP; ea = SZL_E_UNKNOWN_BLOCK; break; }
+                    if (type == 0) {
+                        uint32_t skip = 3 + (uint32_t)((0 - (bitpos + 3)) & 7);
+                        if (avail < skip + 32) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                        bb >>= skip; nb -= skip; bitpos += skip;
+                        refill();
+                        uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
+                        if (nlen != (len ^ 0xFFFF)) { ev = EV_STOP; ea = SZL_E_BROKEN_STORED; break; } // :509-512
+                        bb >>= 32; nb -= 32; bitpos += 32;
+                        lastblk |= t & 1;
+                        stored_left = len; mode = INF_M_STORED;
+                        continue;
+                    }
+                    if (type == 1) {
+                        bb >>= 3; nb -= 3; bitpos += 3;
+                        lastblk |= t & 1; btype = 1; mode = INF_M_HUFF;
+                        ev = EV_TABLES; break;
+                    }
+                    // dynamic: parse the whole header here; if input runs out, nothing is consumed (restart at the block header)
+                    {
+                        uint64_t hb = bb; int hn = nb; uint64_t hp = bitpos; // local cursor
+                        auto need = [&](int k) -> bool { // ensure k bits in hb; false = out of input
+                            if ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) return false;
+                            while (hn < k) {
+                                uint64_t bp = (hp + hn) >> 3;
+                                if (!(bp >= sbase && bp + 8 <= sbase + I_STAGE)) return false; // handled by caller: restage
+                                uint32_t o = (uint32_t)(bp - sbase);
+                                uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
+                                hb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, o & 3) << hn;
+                                hn += 32;
+                            }
+                            return true;
+                        };
+                        auto take = [&](int k) -> uint32_t { uint32_t v = (uint32_t)hb & ((1u << k) - 1); hb >>= k; hn -= k; hp += k; return v; };
+                        int fail = 0; // 1 need input, 2 need restage, <0 error
+                        auto want = [&](int k) -> bool {
+                            if (need(k)) return true;
+                            fail = ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) ? 1 : 2;
+                            return false;
+                        };
+                        uint32_t nl = 0, nd = 0, nm = 0;
+                        do {
+                            if (!want(17)) break;
+                            take(3);
+                            nl = take(5) + 257; nd = take(5) + 1; nm = take(4) + 4;
+                            if (nl > 286 || nd > 30) { fail = SZL_E_DYN_HEADER; break; } // :50-52
+                            uint8_t ml[19];
+                            for (int i = 0; i < 19; i++) ml[i] = 0;
+                            for (uint32_t i = 0; i < nm; i++) { if (!want(3)) break; ml[c_meta_order[i]] = (uint8_t)take(3); }
+                            if (fail) break;
+                            // 7-bit LUT for the code-length alphabet, built in registers/LDS scratch (codes[] reused)
+                            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nxt[8];
+                            for (int i = 0; i < 19; i++) cnt[ml[i]]++;
+                            cnt[0] = 0;
+                            int code = 0;
+                            for (int l = 1; l < 8; l++) { nxt[l] = code; code = (code + cnt[l]) << 1; }
+                            uint16_t *mlut = S.codes; // 128 entries
+                            for (int i = 0; i < 128; i++) mlut[i] = 0;
+                            for (int i = 0; i < 19; i++) {
+                                int l = ml[i];
+                                if (!l) continue;
+                                uint32_t rev = (__builtin_bitreverse32((uint32_t)nxt[l]++) >> (32 - l)) & ((1u << l) - 1);
+                                for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint16_t)((i << 4) | l);
+                            }
+                            uint32_t idx = 0, total = nl + nd;
+                            while (idx < total) {
+                                const uint64_t rem = in_bits > hp ? in_bits - hp : 0;
+                                if (!need((int)(rem < 14 ? rem : 14))) { fail = 2; break; } // code (<=7) + extra bits (<=7)
+                                uint32_t e = mlut[(uint32_t)hb & 127];
+                                if (e == 0) { fail = rem < 7 ? 1 : SZL_E_CODELEN_ZERO; break; } // C/InflaterHuffmanTree.cs:191-193
+                                const uint32_t sl = e & 15, sym = e >> 4;
+                                const uint32_t xb = sym < 16 ? 0 : (sym == 16 ? 2 : (sym == 17 ? 3 : 7));
+                                if (rem < sl + xb) { fail = 1; break; }
+                                take((int)sl);
+                                if (sym < 16) { S.lens[idx++] = (uint8_t)sym; continue; }
+                                uint32_t rep, val = 0;
+                                if (sym == 16) {
+                                    if (idx == 0) { fail = SZL_E_DYN_HEADER; break; } // :83
+                                    val = S.lens[idx - 1]; rep = 3 + take(2);
+                                } else if (sym == 17) rep = 3 + take(3);
+                                else rep = 11 + take(7);
+                                if (idx + rep > total) { fail = SZL_E_DYN_HEADER; break; } // :106
+                                while (rep--) S.lens[idx++] = (uint8_t)val;
+                            }
+                            if (fail) break;
+                            if (S.lens[256] == 0) { fail = SZL_E_DYN_HEADER; break; } // :113
+                        } while (0);
+                        if (fail == 1) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                        if (fail == 2) { // header straddles the staged window: restage at the block header and retry
+                            if (((bitpos >> 3) & ~3ull) == sbase) { ev = EV_STOP; ea = SZL_E_DYN_HEADER; break; } // cannot happen: a header is < 1 KiB
+                            ev = EV_RESTAGE; ea = 1; break;
+                        }
+                        if (fail < 0) { ev = EV_STOP; ea = fail; break; }
+                        bb = hb; nb = hn; bitpos = hp;
+                        lastblk |= t & 1; btype = 2; lnum = nl; dnum = nd; mode = INF_M_HUFF;
+                        ev = EV_TABLES; break;
+                    }
+                }
+                if (mode == INF_M_STORED) {
+                    if (stored_left == 0) { mode = INF_M_HEADER; continue; }
+                    ev = EV_STORED; break;
+                }
+                // ---------------- INF_M_HUFF: literals are written by lane 0 itself; a match goes to the wavefront
+                int r = decode_sym(&S.lt, S.llut, I_LPB, (uint32_t)bb);
+                if (r < 0) { ev = EV_STOP; ea = avail < 15 ? INF_NEED_INPUT : SZL_E_CODELEN_ZERO; break; }
+                uint32_t sl = (uint32_t)r >> 16, sym = (uint32_t)r & 0xFFFF;
+                if (avail < sl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                if (sym < 256) {
+                    if (outpos + 1 > out_limit) { ev = EV_STOP; ea = INF_OUTPUT_FULL; break; }
+                    bb >>= sl; nb -= sl; bitpos += sl;
+                    S.win[outpos & I_WMASK] = (uint8_t)sym;
+                    outpos++;
+                    continue;
+                }
+                if (sym == 256) { bb >>= sl; nb -= sl; bitpos += sl; mode = INF_M_HEADER; continue; }
+                if (sym - 257 >= 29) { ev = EV_STOP; ea = SZL_E_ILLEGAL_LEN_CODE; break; } // :323-326
+                // length extra, distance symbol, distance extra: up to 15+5+15+13 = 48 bits, all inside bb (nb > 32 after refill
+                // is not guaranteed to cover 48) -> use a local cursor and refill once in between
+                {
+                    uint64_t tb = bb; int tn = nb; uint64_t used = sl;
+                    tb >>= sl; tn -= sl;
+                    uint32_t xl = c_cplext[sym - 257];
+                    uint32_t len = c_cplens[sym - 257] + ((uint32_t)tb & ((1u << xl) - 1));
+                    tb >>= xl; tn -= xl; used += xl;
+                    if (tn < 28) { // top up (the staged window always has >= 8 readable bytes past bytepos)
+                        uint32_t o = (uint32_t)(((bitpos + used + tn) >> 3) - sbase);
+                        uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
+                        tb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, o & 3) << tn;
+                        tn += 32;
+                    }
+                    int rd = decode_sym(&S.dt, S.dlut, I_DPB, (uint32_t)tb);
+                    if (rd < 0) { ev = EV_STOP; ea = avail < used + 15 ? INF_NEED_INPUT : SZL_E_CODELEN_ZERO; break; }
+                    uint32_t dl = (uint32_t)rd >> 16, dsym = (uint32_t)rd & 0xFFFF;
+                    if (dsym >= 30) { ev = EV_STOP; ea = avail < used + dl ? INF_NEED_INPUT : SZL_E_ILLEGAL_DIST_CODE; break; } // :356-359
+                    tb >>= dl; tn -= dl; used += dl;
+                    uint32_t xd = c_cpdext[dsym];
+                    uint32_t dist = c_cpdist[dsym] + ((uint32_t)tb & ((1u << xd) - 1));
+                    tb >>= xd; tn -= xd; used += xd;
+                    if (avail < used) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    bb = tb; nb = tn; bitpos += used;
+                    ev = EV_MATCH; ea = (int)len; eb = (int)dist;
+                    break;
+                }
+            }
+        }
+        // ---------------- the whole wavefront services the event
+        ev = __builtin_amdgcn_readfirstlane(ev);
+        ea = __builtin_amdgcn_readfirstlane(ea);
+        eb = __builtin_amdgcn_readfirstlane(eb);
+        // lane 0's scalars that other lanes need
+        outpos = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(outpos >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)outpos);
+        bitpos = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(bitpos >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)bitpos);
+        {
+            int nbb = __builtin_amdgcn_readfirstlane(nb);
+            mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
+            lastblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)lastblk);
+            stored_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_left);
+            btype = (uint32_t)__builtin_amdgcn_readfirstlane((int)btype);
+            lnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)lnum);
+            dnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)dnum);
+            if (lane != 0) nb = nbb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        switch (ev) {
+        case EV_MATCH: {
+            const uint32_t len = (uint32_t)ea, dist = (uint32_t)eb;
+            if (outpos + len > out_limit) { // keep the decoded match for the next call (the reference's mode DECODE_HUFFMAN_DISTBITS done)
+                pend_len = len; pend_dist = dist; status = INF_OUTPUT_FULL; break;
+            }
+            if (outpos - flushed + len > I_WIN - 512) flush(outpos);
+            // CS/OutputWindow.cs:63-92: overlap-safe repeat == out[p+k] = out[p-dist+(k mod dist)]
+            for (uint32_t k = lane; k < len; k += 64) {
+                uint32_t kk = dist >= len ? k : k % dist;
+                S.win[(outpos + k) & I_WMASK] = S.win[(outpos - dist + kk) & I_WMASK];
+            }
+            outpos += len;
+        } break;
+        case EV_RESTAGE:
+            if (ea == 1) { // restart the dynamic header at the block start
+                // bb/nb are lane-0 private: drop them and re-read from the restaged window
+            }
+            bb = 0; nb = 0;
+            restage(bitpos >> 3);
+            if (lane == 0 && (bitpos & 7)) { // re-prime the partial first byte
+                uint32_t o = (uint32_t)((bitpos >> 3) - sbase);
+                uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
+                uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, o & 3);
+                uint32_t sh = (uint32_t)(bitpos & 7);
+                bb = (uint64_t)(x >> sh); nb = 32 - (int)sh;
+            }
+            break;
+        case EV_FLUSH:
+            flush(outpos);
+            break;
+        case EV_TABLES:
+            rebuild_tables();
+            break;
+        case EV_STORED: {
+            // bit reader is byte aligned here: give back whole bytes held in bb, then copy bytes input -> window
+            uint64_t bytepos = bitpos >> 3; // bitpos is a multiple of 8 (SkipToByteBoundary :490)
+            uint64_t can_in = job.in_len > bytepos ? job.in_len - bytepos : 0;
+            uint64_t can_out = out_limit - outpos;
+            uint64_t room = (uint64_t)(I_WIN - 512) - (outpos - flushed);
+            uint64_t n = stored_left;
+            if (n > can_in) n = can_in;
+            if (n > can_out) n = can_out;
+            if (n > room) { flush(outpos); room = I_WIN - 512; if (n > room) n = room; }
+            for (uint64_t i = lane; i < n; i += 64) S.win[(outpos + i) & I_WMASK] = in[bytepos + i];
+            outpos += n; bitpos += 8 * n; stored_left -= (uint32_t)n;
+            bb = 0; nb = 0; sbase = ~0ull; // force a restage at the new position
+            if (n == 0) status = can_in == 0 ? INF_NEED_INPUT : INF_OUTPUT_FULL;
+        } break;
+        case EV_STOP:
+            status = ea;
+            break;
+        default: break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    // ---- epilogue: flush, save state
+    flush(outpos);
+    if (status == INF_FINISHED && job.zlib) { // Adler-32 trailer (C/Inflater.cs:397-418): align, 4 bytes big-endian
+        uint64_t bytepos = (bitpos + 7) >> 3;
+        if (bytepos + 4 > job.in_len) { status = INF_NEED_INPUT; mode = INF_M_HEADER; /* lastblk stays set: resumes straight to DONE */ }
+        else {
+            if (lane == 0) st->adler_read = ((uint32_t)in[bytepos] << 24) | ((uint32_t)in[bytepos + 1] << 16) | ((uint32_t)in[bytepos + 2] << 8) | in[bytepos + 3];
+            bitpos = (bytepos + 4) * 8;
+        }
+    }
+    if (job.window && (status != INF_FINISHED || job.keep_window)) {
+        for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&job.window[i] = *(const uint4 *)&S.win[i];
+    }
+    if (btype == 2 && mode == INF_M_HUFF) for (int i = lane; i < 320; i += 64) st->lens[i] = S.lens[i];
+    if (lane == 0) {
+        st->bitpos = bitpos; st->outpos = outpos; st->mode = mode; st->last = lastblk; st->stored_left = stored_left;
+        st->btype = btype; st->lnum = lnum; st->dnum = dnum; st->pend_len = pend_len; st->pend_dist = pend_dist;
+        st->status = status;
+        jobs[ji].out_written = outpos - out_start;
+        jobs[ji].status = status;
+        jobs[ji].consumed = (bitpos + 7) >> 3;
+    }
+}
+
+void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, hipStream_t st) {
+    if (njobs) hipLaunchKernelGGL(k_inflate, dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
+}
+
+} // namespace szl

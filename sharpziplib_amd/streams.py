@@ -72,3 +72,84 @@ class DeflaterOutputStream:
 
     def __exit__(self, *a):
         self.Dispose()
+
+
+class InflaterInputBuffer:
+    """CS/InflaterInputStream.cs:16-330 (the parts the codec path uses)."""
+
+    def __init__(self, stream, bufferSize=4096):
+        self.inputStream = stream
+        if bufferSize < 1024:
+            bufferSize = 1024                                   # :35-38
+        self.rawData = np.zeros(bufferSize, dtype=np.uint8)
+        self.rawLength = 0
+        self.available = 0
+
+    @property
+    def Available(self):
+        return self.available
+
+    @Available.setter
+    def Available(self, v):
+        self.available = v
+
+    def SetInflaterInput(self, inflater):                       # :103
+        if self.available > 0:
+            inflater.SetInput(self.rawData, self.rawLength - self.available, self.available)
+            self.available = 0
+
+    def Fill(self):                                             # :115
+        self.rawLength = 0
+        toRead = self.rawData.size
+        while toRead > 0:
+            b = self.inputStream.read(toRead)
+            if not b:
+                break
+            self.rawData[self.rawLength:self.rawLength + len(b)] = np.frombuffer(b, dtype=np.uint8)
+            self.rawLength += len(b)
+            toRead -= len(b)
+        self.available = self.rawLength
+
+
+class InflaterInputStream:
+    def __init__(self, baseInputStream, inflater=None, bufferSize=4096):
+        from .inflater import Inflater
+        if baseInputStream is None:
+            raise ValueError("baseInputStream")
+        if bufferSize <= 0:
+            raise ValueError("bufferSize")
+        self.baseInputStream = baseInputStream
+        self.inf = inflater if inflater is not None else Inflater()
+        self.inputBuffer = InflaterInputBuffer(baseInputStream, bufferSize)
+        self.IsStreamOwner = True
+
+    @property
+    def Available(self):                                        # :472
+        return 0 if self.inf.IsFinished else 1
+
+    def Fill(self):                                             # :486
+        if self.inputBuffer.Available <= 0:
+            self.inputBuffer.Fill()
+            if self.inputBuffer.Available <= 0:
+                raise SharpZipBaseException("Unexpected EOF")
+        self.inputBuffer.SetInflaterInput(self.inf)
+
+    def Read(self, buffer, offset, count):                      # :658
+        if self.inf.IsNeedingDictionary:
+            raise SharpZipBaseException("Need a dictionary")
+        remaining = count
+        while True:
+            n = self.inf.Inflate(buffer, offset, remaining)
+            offset += n
+            remaining -= n
+            if remaining == 0 or self.inf.IsFinished:
+                break
+            if self.inf.IsNeedingInput:
+                self.Fill()
+            elif n == 0:
+                raise SharpZipBaseException("Invalid input data")
+        return count - remaining
+
+    def Dispose(self):
+        if self.IsStreamOwner:
+            self.baseInputStream.close()

@@ -13,7 +13,7 @@ def run(name, data, level=6, flags=_lib.F_NOWRAP|_lib.F_CRC32|_lib.F_ADLER32):
     cap = int(L.szl_deflate_bound(n)) + 16
     cap = (cap + 3) & ~3
     out = np.zeros(cap, dtype=np.uint8)
-    st = _lib.Stream(0, n, 0, cap, 0, 0, 0, 0, 0)
+    st = _lib.Stream(0, n, 0, cap, 0, 0, 0, 0, 0, 0)
     inb = np.concatenate([data, np.zeros(8, np.uint8)])
     t=time.time()
     rc = L.szl_deflate_batch_host(eng, inb.ctypes.data, out.ctypes.data, ctypes.byref(st), 1, level, 0, flags)

@@ -10,7 +10,7 @@ def run(name, data, level=6, check_oracle=True, reps=2):
     n = data.size
     cap = (int(L.szl_deflate_bound(n)) + 19) & ~3
     out = np.zeros(cap, dtype=np.uint8)
-    st = _lib.Stream(0, n, 0, cap, 0, 0, 0, 0, 0)
+    st = _lib.Stream(0, n, 0, cap, 0, 0, 0, 0, 0, 0)
     for r in range(reps):
         t=time.time()
         rc = L.szl_deflate_batch_host(eng, data.ctypes.data, out.ctypes.data, ctypes.byref(st), 1, level, 0, _lib.F_NOWRAP|_lib.F_CRC32)
