@@ -1,0 +1,161 @@
+// Deflater.Device.cs — drop-in replacement of ICSharpCode.SharpZipLib.Zip.Compression.Deflater
+// (reference: src/ICSharpCode.SharpZipLib/Zip/Compression/Deflater.cs) that P/Invokes libszl_amd.so.
+// Same namespace, same public members, same exceptions; DeflaterOutputStream / GZipOutputStream /
+// ZipOutputStream keep using `new Deflater(level, nowrap)` and the protected `deflater_` field unchanged.
+// NOTE: there is no .NET toolchain in the build image; this file is syntax-reviewed only.  The
+// identical call sequences are exercised through the C ABI by tests/test_gpu_deflate.py.
+using System;
+using System.Runtime.InteropServices;
+
+namespace ICSharpCode.SharpZipLib.Zip.Compression
+{
+	internal static class SzlNative
+	{
+		private const string Lib = "szl_amd"; // libszl_amd.so
+
+		[DllImport(Lib)] internal static extern IntPtr szl_last_error();
+		[DllImport(Lib)] internal static extern IntPtr szl_strerror(int status);
+
+		[DllImport(Lib)] internal static extern IntPtr szl_deflater_create(int level, int noZlibHeaderOrFooter);
+		[DllImport(Lib)] internal static extern void szl_deflater_destroy(IntPtr d);
+		[DllImport(Lib)] internal static extern int szl_deflater_reset(IntPtr d);
+		[DllImport(Lib)] internal static extern int szl_deflater_set_level(IntPtr d, int level);
+		[DllImport(Lib)] internal static extern int szl_deflater_get_level(IntPtr d);
+		[DllImport(Lib)] internal static extern int szl_deflater_set_strategy(IntPtr d, int strategy);
+		[DllImport(Lib)] internal static extern unsafe int szl_deflater_set_dictionary(IntPtr d, byte* p, int n);
+		[DllImport(Lib)] internal static extern unsafe int szl_deflater_set_input(IntPtr d, byte* p, int n);
+		[DllImport(Lib)] internal static extern int szl_deflater_flush(IntPtr d);
+		[DllImport(Lib)] internal static extern int szl_deflater_finish(IntPtr d);
+		[DllImport(Lib)] internal static extern unsafe int szl_deflater_deflate(IntPtr d, byte* output, int len);
+		[DllImport(Lib)] internal static extern int szl_deflater_needs_input(IntPtr d);
+		[DllImport(Lib)] internal static extern int szl_deflater_is_finished(IntPtr d);
+		[DllImport(Lib)] internal static extern long szl_deflater_total_in(IntPtr d);
+		[DllImport(Lib)] internal static extern long szl_deflater_total_out(IntPtr d);
+		[DllImport(Lib)] internal static extern uint szl_deflater_adler(IntPtr d);
+
+		[DllImport(Lib)] internal static extern IntPtr szl_inflater_create(int noHeader);
+		[DllImport(Lib)] internal static extern void szl_inflater_destroy(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_reset(IntPtr s);
+		[DllImport(Lib)] internal static extern unsafe int szl_inflater_set_input(IntPtr s, byte* p, int n);
+		[DllImport(Lib)] internal static extern unsafe int szl_inflater_set_dictionary(IntPtr s, byte* p, int n);
+		[DllImport(Lib)] internal static extern unsafe int szl_inflater_inflate(IntPtr s, byte* output, int count);
+		[DllImport(Lib)] internal static extern int szl_inflater_needs_input(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_needs_dictionary(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_is_finished(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_remaining_input(IntPtr s);
+		[DllImport(Lib)] internal static extern long szl_inflater_total_in(IntPtr s);
+		[DllImport(Lib)] internal static extern long szl_inflater_total_out(IntPtr s);
+		[DllImport(Lib)] internal static extern uint szl_inflater_adler(IntPtr s);
+
+		// szl_status -> the exception the reference throws at the same place
+		internal static Exception Map(int status, string what)
+		{
+			string detail = Marshal.PtrToStringAnsi(szl_last_error());
+			string msg = Marshal.PtrToStringAnsi(szl_strerror(status));
+			switch (status)
+			{
+				case -1: return new ArgumentOutOfRangeException(what, detail);          // SZL_E_ARG
+				case -2: return new InvalidOperationException(detail ?? msg);             // SZL_E_STATE
+				case -5: return new NotSupportedException(detail ?? msg);                 // SZL_E_UNSUPPORTED
+				case -24: return new StreamDecodingException(msg);                         // SZL_E_DYN_HEADER
+				default: return new SharpZipBaseException(msg + (detail != null ? ": " + detail : "")); // incl. -3 device errors
+			}
+		}
+	}
+
+	public class Deflater : IDisposable
+	{
+		public const int BEST_COMPRESSION = 9, BEST_SPEED = 1, DEFAULT_COMPRESSION = -1, NO_COMPRESSION = 0, DEFLATED = 8;
+
+		private IntPtr h;
+
+		public Deflater() : this(DEFAULT_COMPRESSION, false) { }
+		public Deflater(int level) : this(level, false) { }
+		public Deflater(int level, bool noZlibHeaderOrFooter)
+		{
+			if (level != DEFAULT_COMPRESSION && (level < NO_COMPRESSION || level > BEST_COMPRESSION))
+				throw new ArgumentOutOfRangeException(nameof(level));               // Deflater.cs:184-187
+			h = SzlNative.szl_deflater_create(level, noZlibHeaderOrFooter ? 1 : 0);
+			if (h == IntPtr.Zero) throw SzlNative.Map(-3, nameof(level));
+		}
+
+		public void Reset() { Check(SzlNative.szl_deflater_reset(h), nameof(Reset)); }                 // :204
+		public int Adler => unchecked((int)SzlNative.szl_deflater_adler(h));                              // :215
+		public long TotalIn => SzlNative.szl_deflater_total_in(h);                                       // :226
+		public long TotalOut => SzlNative.szl_deflater_total_out(h);                                     // :237
+		public void Flush() { SzlNative.szl_deflater_flush(h); }                                         // :252
+		public void Finish() { SzlNative.szl_deflater_finish(h); }                                       // :262
+		public bool IsFinished => SzlNative.szl_deflater_is_finished(h) != 0;                             // :271
+		public bool IsNeedingInput => SzlNative.szl_deflater_needs_input(h) != 0;                         // :285
+		public void SetInput(byte[] input) { SetInput(input, 0, input.Length); }
+		public unsafe void SetInput(byte[] input, int offset, int count)                                 // :331
+		{
+			if (input == null) throw new ArgumentNullException(nameof(input));
+			if (offset < 0) throw new ArgumentOutOfRangeException(nameof(offset));
+			if (count < 0 || offset > input.Length - count) throw new ArgumentOutOfRangeException(nameof(count));
+			fixed (byte* p = input) Check(SzlNative.szl_deflater_set_input(h, p + offset, count), nameof(SetInput));
+		}
+		public void SetLevel(int level) { Check(SzlNative.szl_deflater_set_level(h, level), nameof(level)); } // :349
+		public int GetLevel() => SzlNative.szl_deflater_get_level(h);                                     // :371
+		public void SetStrategy(DeflateStrategy strategy) { Check(SzlNative.szl_deflater_set_strategy(h, (int)strategy), nameof(strategy)); } // :385
+		public int Deflate(byte[] output) => Deflate(output, 0, output.Length);
+		public unsafe int Deflate(byte[] output, int offset, int length)                                 // :427
+		{
+			fixed (byte* p = output) return Check(SzlNative.szl_deflater_deflate(h, p + offset, length), nameof(Deflate));
+		}
+		public void SetDictionary(byte[] dictionary) { SetDictionary(dictionary, 0, dictionary.Length); }
+		public unsafe void SetDictionary(byte[] dictionary, int index, int count)                        // :559
+		{
+			fixed (byte* p = dictionary) Check(SzlNative.szl_deflater_set_dictionary(h, p + index, count), nameof(SetDictionary));
+		}
+
+		private static int Check(int status, string what) { if (status < 0) throw SzlNative.Map(status, what); return status; }
+		public void Dispose() { if (h != IntPtr.Zero) { SzlNative.szl_deflater_destroy(h); h = IntPtr.Zero; } GC.SuppressFinalize(this); }
+		~Deflater() { if (h != IntPtr.Zero) SzlNative.szl_deflater_destroy(h); }
+	}
+
+	public class Inflater : IDisposable
+	{
+		private IntPtr h;
+		internal bool noHeader;   // read by InflaterPool.Return (src/ICSharpCode.SharpZipLib/Core/InflaterPool.cs:56)
+
+		public Inflater() : this(false) { }
+		public Inflater(bool noHeader)
+		{
+			this.noHeader = noHeader;
+			h = SzlNative.szl_inflater_create(noHeader ? 1 : 0);
+			if (h == IntPtr.Zero) throw SzlNative.Map(-3, nameof(noHeader));
+		}
+		public void Reset() { SzlNative.szl_inflater_reset(h); }                                         // Inflater.cs:188
+		public void SetInput(byte[] buffer) { SetInput(buffer, 0, buffer.Length); }
+		public unsafe void SetInput(byte[] buffer, int index, int count)                                 // :629
+		{
+			fixed (byte* p = buffer) Check(SzlNative.szl_inflater_set_input(h, p + index, count), nameof(SetInput));
+		}
+		public void SetDictionary(byte[] buffer) { SetDictionary(buffer, 0, buffer.Length); }
+		public unsafe void SetDictionary(byte[] buffer, int index, int count)                            // :563
+		{
+			fixed (byte* p = buffer) Check(SzlNative.szl_inflater_set_dictionary(h, p + index, count), nameof(SetDictionary));
+		}
+		public int Inflate(byte[] buffer) => Inflate(buffer, 0, buffer.Length);
+		public unsafe int Inflate(byte[] buffer, int offset, int count)                                  // :715
+		{
+			if (buffer == null) throw new ArgumentNullException(nameof(buffer));
+			if (count < 0) throw new ArgumentOutOfRangeException(nameof(count), "count cannot be negative");
+			if (offset < 0) throw new ArgumentOutOfRangeException(nameof(offset), "offset cannot be negative");
+			if (offset + count > buffer.Length) throw new ArgumentException("count exceeds buffer bounds");
+			fixed (byte* p = buffer) return Check(SzlNative.szl_inflater_inflate(h, p + offset, count), nameof(Inflate));
+		}
+		public bool IsNeedingInput => SzlNative.szl_inflater_needs_input(h) != 0;                          // :783
+		public bool IsNeedingDictionary => SzlNative.szl_inflater_needs_dictionary(h) != 0;                // :794
+		public bool IsFinished => SzlNative.szl_inflater_is_finished(h) != 0;                              // :806
+		public int Adler => unchecked((int)SzlNative.szl_inflater_adler(h));                               // :823
+		public long TotalOut => SzlNative.szl_inflater_total_out(h);                                      // :848
+		public long TotalIn => SzlNative.szl_inflater_total_in(h);                                        // :862
+		public int RemainingInput => SzlNative.szl_inflater_remaining_input(h);                           // :878
+
+		private static int Check(int status, string what) { if (status < 0) throw SzlNative.Map(status, what); return status; }
+		public void Dispose() { if (h != IntPtr.Zero) { SzlNative.szl_inflater_destroy(h); h = IntPtr.Zero; } GC.SuppressFinalize(this); }
+		~Inflater() { if (h != IntPtr.Zero) SzlNative.szl_inflater_destroy(h); }
+	}
+}
