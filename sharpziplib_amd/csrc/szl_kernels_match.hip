@@ -6,6 +6,7 @@
 // Both are *parse-independent* at levels 5-9 (DeflateSlow inserts every position),
 // so they are computed for every position in parallel; the lazy parse (stage C) only looks results up.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "szl_internal.h"
 
 namespace szl {
@@ -151,6 +152,7 @@ enum : int { B_THREADS = 1024 };
 enum : int { B_DATA_BYTES = B_HIST + B_TILE + B_TAIL + 8, B_LINKS = B_HIST + B_TILE };
 enum : int { B_LDS_BYTES = B_DATA_BYTES + B_LINKS * 2 + 16 };
 
+template <bool DBG>
 __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                      const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
                                                      uint2 *__restrict__ mtab, LevelParams P, unsigned long long *dbg) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int SNAPLEFT = P.max_chain - (P.max_chain >> 2); // `left` value at which the quarter-budget walk would stop
     enum { NEED = 0, QUICK = 1, VERIFY = 2, DONE = 3 };
-    enum { Q_THRESH = 36 };
+    enum { Q_THRESH = 36, F_THRESH = 16 };
     int wnext = 0, wend = 0;       // wave-uniform slice of tile positions being handed out
     bool exhausted = false;
     int mode = NEED;
@@ -221,58 +223,63 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     unsigned long long n_it = 0, n_q = 0, n_v = 0;
 
     for (;;) {
-        // ---------------- retire finished positions, hand out new ones
-        if (mode == DONE) {
-            if (left > SNAPLEFT) resq = res2; // the quarter-budget walk would have ended here as well
-            mt[t0 + p] = make_uint2(res2, resq);
-            mode = NEED;
-        }
-        const uint64_t nm = __ballot(mode == NEED);
-        if (nm) {
-            if (wnext >= wend && !exhausted) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(s_counter, 256);
-                base = __builtin_amdgcn_readfirstlane(base);
-                wnext = base < tlen ? base : tlen;
-                wend = base + 256 < tlen ? base + 256 : tlen;
-                if (wnext >= wend) exhausted = true;
+        // ---------------- FETCH: retire finished positions and hand out new ones — only when enough lanes are idle,
+        // because this phase is long (64-bit window arithmetic) and costs the same for 1 lane as for 64
+        const uint64_t idle = __ballot(mode == NEED || mode == DONE);
+        if (__builtin_popcountll(idle) >= F_THRESH || idle == ~0ull) {
+            if (mode == DONE) {
+                mt[t0 + p] = make_uint2(res2, resq);
+                mode = NEED;
             }
-            const int rank = __builtin_popcountll(nm & lanemask_lt);
-            if (mode == NEED && wnext + rank < wend) {
-                p = wnext + rank;
-                const int64_t Pp = t0 + p;
-                const int64_t rem = seg_end - Pp;
-                res2 = 0; resq = 0;
-                bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
-                if (ok) {
-                    pl = p + B_HIST;
-                    const int l0 = (int)slink[pl];                           // hashHead (:782)
-                    const int64_t pabs = (int64_t)seg.abs0 + Pp;
-                    const int64_t basem = base_of(pabs) - (int64_t)seg.abs0; // buffer position whose window index is 1
-                    // first candidate: strstart - hashHead <= MAX_DIST (:788) and entry not clamped by a slide (index >= 1)
-                    const int64_t firstmin = Pp - MAX_DIST > basem ? Pp - MAX_DIST : basem;
-                    const int64_t chainmin = Pp - (MAX_DIST - 1) > basem ? Pp - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
-                    cl = pl - l0;
-                    ok = l0 != 0 && cl >= (int)(firstmin - dlo);
-                    if (ok) {
-                        mincl = (int)(chainmin - dlo);
-                        cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;         // scanMax :479
-                        nice = P.nice < (int)rem ? P.nice : (int)rem;        // :485
-                        best = 2; left = P.max_chain;
-                        pb = sdata8[pl + 2];
-                        mode = QUICK;
-                    }
+            if (!exhausted) {
+                const uint64_t nm = idle;
+                if (wnext >= wend) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(s_counter, 256);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    wnext = base < tlen ? base : tlen;
+                    wend = base + 256 < tlen ? base + 256 : tlen;
+                    if (wnext >= wend) exhausted = true;
                 }
-                if (!ok) mt[t0 + p] = make_uint2(0u, 0u);
+                const int rank = __builtin_popcountll(nm & lanemask_lt);
+                if (mode == NEED && wnext + rank < wend) {
+                    p = wnext + rank;
+                    const int64_t Pp = t0 + p;
+                    const int64_t rem = seg_end - Pp;
+                    res2 = 0; resq = 0;
+                    bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
+                    if (ok) {
+                        pl = p + B_HIST;
+                        const int l0 = (int)slink[pl];                           // hashHead (:782)
+                        const int64_t pabs = (int64_t)seg.abs0 + Pp;
+                        const int64_t basem = base_of(pabs) - (int64_t)seg.abs0; // buffer position whose window index is 1
+                        // first candidate: strstart - hashHead <= MAX_DIST (:788) and entry not clamped by a slide (index >= 1)
+                        const int64_t firstmin = Pp - MAX_DIST > basem ? Pp - MAX_DIST : basem;
+                        const int64_t chainmin = Pp - (MAX_DIST - 1) > basem ? Pp - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
+                        cl = pl - l0;
+                        ok = l0 != 0 && cl >= (int)(firstmin - dlo);
+                        if (ok) {
+                            mincl = (int)(chainmin - dlo);
+                            cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;         // scanMax :479
+                            nice = P.nice < (int)rem ? P.nice : (int)rem;        // :485
+                            best = 2; left = P.max_chain;
+                            pb = sdata8[pl + 2];
+                            mode = QUICK;
+                        }
+                    }
+                    if (!ok) mt[t0 + p] = make_uint2(0u, 0u);
+                }
+                const int taken = __builtin_popcountll(nm);
+                wnext = wnext + taken < wend ? wnext + taken : wend;
             }
-            const int taken = __builtin_popcountll(nm);
-            wnext = wnext + taken < wend ? wnext + taken : wend;
             if (exhausted && __all(mode == NEED)) break;
         }
-        // ---------------- QUICK: chain steps while most lanes are still walking (branch-free body)
+        // ---------------- QUICK: chain steps (branch-free body: one byte + one u16 from LDS, a dozen VALU)
         uint64_t qm = __ballot(mode == QUICK);
         while (qm) {
-            n_it++; n_q += __builtin_popcountll(qm);
+            if (DBG) { n_it++; n_q += __builtin_popcountll(qm); }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
             if (mode == QUICK) {
                 const uint32_t qb = sdata8[cl + best];   // a longer match must agree at offset `best` (scan_end, :505)
                 lnk = (int)slink[cl];
@@ -281,20 +288,24 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                 const int left1 = left - 1;
                 const int c2 = cl - lnk;
                 const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
-                resq = (!pass && left1 == SNAPLEFT) ? res2 : resq;
                 left = pass ? left : left1;
                 cl = (pass | end) ? cl : c2;
-                off = 0;
                 mode = pass ? VERIFY : (end ? DONE : QUICK);
             }
             qm = __ballot(mode == QUICK);
-            if (__builtin_popcountll(qm) <= Q_THRESH) break;
+            if (__builtin_popcountll(qm) <= Q_THRESH) {
+                const uint64_t others = __ballot(mode == VERIFY);
+                const uint64_t idl = __ballot(mode == NEED || mode == DONE);
+                if (others || (__builtin_popcountll(idl) >= F_THRESH && !exhausted) || qm == 0) break;
+            }
         }
         // ---------------- VERIFY: full comparison of the candidates that passed the quick test
         uint64_t vm = __ballot(mode == VERIFY);
+        bool fresh = true;
         while (vm) {
-            n_it++; n_v += __builtin_popcountll(vm);
+            if (DBG) { n_it++; n_v += __builtin_popcountll(vm); }
             if (mode == VERIFY) {
+                if (fresh) off = 0;
                 const uint32_t x = ldsdw(cl + off) ^ ldsdw(pl + off);
                 const bool eq = x == 0;
                 const int l = off + (eq ? 4 : (__builtin_ctz(x) >> 3));
@@ -306,22 +317,23 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                     if (L > best) { // :593-607
                         best = L;
                         res2 = (uint32_t)L | ((uint32_t)(pl - cl) << 16);
+                        if (left > SNAPLEFT) resq = res2; // this candidate is among the first max_chain>>2: the quarter walk sees it too
                         nicehit = L >= nice;
                         if (!nicehit) pb = sdata8[pl + L];
                     }
                     const int left1 = left - 1;
                     const int c2 = cl - lnk;
                     const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
-                    resq = (!nicehit && left1 == SNAPLEFT) ? res2 : resq;
                     left = nicehit ? left : left1;
                     cl = (nicehit | end) ? cl : c2;
                     mode = (nicehit | end) ? DONE : QUICK;
                 }
             }
+            fresh = false;
             vm = __ballot(mode == VERIFY);
         }
     }
-    if (dbg && lane == 0) { atomicAdd(dbg + 2, n_it); atomicAdd(dbg + 3, n_q); atomicAdd(dbg + 4, n_v); }
+    if (DBG && dbg && lane == 0) { atomicAdd(dbg + 2, n_it); atomicAdd(dbg + 3, n_q); atomicAdd(dbg + 4, n_v); }
 }
 
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
@@ -334,12 +346,18 @@ int match_lds_bytes() { return B_LDS_BYTES; }
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                         uint2 *mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     static bool attr_set = false;
+    static const bool want_dbg = getenv("SZL_DEBUG") != nullptr;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)k_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (ntiles > 0) hipLaunchKernelGGL(k_match, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg);
+    if (ntiles > 0) {
+        if (want_dbg) hipLaunchKernelGGL(k_match<true>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg);
+        else hipLaunchKernelGGL(k_match<false>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg);
+    }
     return hipGetLastError();
 }
 
