@@ -74,7 +74,7 @@ static uint32_t flm_walk(const uint8_t *d, size_t p, size_t seg_end, const uint1
     if ((int64_t)p - c > MAX_DIST) return 0;            /* strstart - hashHead <= MAX_DIST :788 */
     if (c + 1 - base < 1) return 0;                      /* hashHead != 0 (entry clamped by a slide :450-461) */
     int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;    /* scanMax :479 */
-    int nice = P->nice < (int)rem ? P->nice : (int)rem;  /* :485 */
+    int nice = rem < (size_t)P->nice ? (int)rem : P->nice;  /* :485 */
     int best = best0;
     if (best >= cap) return 0;                           /* scan + matchLen > scanMax :489 */
     int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0; /* :480 */
@@ -124,7 +124,7 @@ static int research(const uint8_t *d, size_t x, size_t seg_end, int L, const uin
     if (rem < MIN_MATCH) return 0;
     int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
     if (L >= cap) return 0;
-    int nice = P->nice < (int)rem ? P->nice : (int)rem;
+    int nice = rem < (size_t)P->nice ? (int)rem : P->nice;
     uint32_t e;
     if (L < P->good) e = m2[x];          /* same budget, same stop: records > L are the same (App. A.3) */
     else if (L < nice) e = mq[x];        /* chainLength >>= 2 when matchLen >= goodLength :495 */

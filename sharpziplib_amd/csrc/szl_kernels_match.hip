@@ -261,7 +261,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                         if (ok) {
                             mincl = (int)(chainmin - dlo);
                             cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;         // scanMax :479
-                            nice = P.nice < (int)rem ? P.nice : (int)rem;        // :485
+                            nice = rem < (int64_t)P.nice ? (int)rem : P.nice;       // :485 (64-bit compare: rem can exceed 2^31)
                             best = 2; left = P.max_chain;
                             pb = sdata8[pl + 2];
                             mode = QUICK;

@@ -83,7 +83,7 @@ __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, int64_t &x, in
     if (rem >= MIN_MATCH) {
         const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
         if (L < cap) {
-            const int nice = c.P.nice < (int)rem ? c.P.nice : (int)rem;
+            const int nice = rem < (int64_t)c.P.nice ? (int)rem : c.P.nice;
             uint32_t cand;
             if (L < c.P.good) cand = e.x;
             else if (L < nice) cand = e.y;               // chainLength >>= 2 (:495)

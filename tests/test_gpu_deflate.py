@@ -190,3 +190,122 @@ def test_deflater_state_errors():
     assert out[:n].tobytes() == O.deflate(b"abc", 6) and d.IsFinished
     with pytest.raises(NotSupportedOnDevice):
         Deflater(1, True)
+
+
+def test_streaming_random_chunks_and_flushes():
+    """Randomised Write/Flush call patterns (seeded): every segment boundary moves the bit phase and the history."""
+    from sharpziplib_amd.deflater import Deflater
+    rng = np.random.default_rng(12345)
+    data = C.mixed(400000, seed=77)
+    for trial in range(6):
+        level = int(rng.choice([5, 6, 9]))
+        d = Deflater(level, True)
+        o = O.Deflater(level, True)
+        got, ref = bytearray(), bytearray()
+        buf = np.zeros(8192, np.uint8)
+        pos = 0
+        while pos < data.size:
+            n = int(rng.choice([1, 2, 3, 17, 300, 5000, 40000, 70000, 131072]))
+            c = data[pos:pos + n]
+            pos += c.size
+            d.SetInput(c)
+            o.set_input(c)
+            while not o.needs_input:
+                b = o.deflate(8192)
+                if not b:
+                    break
+                ref += b
+            if rng.random() < 0.5:
+                d.Flush(); o.flush()
+                while True:
+                    k = d.Deflate(buf)
+                    if k <= 0:
+                        break
+                    got += buf[:k].tobytes()
+                while True:
+                    b = o.deflate(8192)
+                    if not b:
+                        break
+                    ref += b
+                assert bytes(got) == bytes(ref), (trial, pos)
+        d.Finish(); o.finish()
+        while not d.IsFinished:
+            k = d.Deflate(buf)
+            assert k > 0
+            got += buf[:k].tobytes()
+        while not o.finished:
+            ref += o.deflate(8192)
+        assert bytes(got) == bytes(ref), trial
+        assert d.TotalIn == o.total_in == data.size and d.TotalOut == o.total_out == len(ref)
+
+
+def test_flush_after_every_small_write():
+    from sharpziplib_amd.deflater import Deflater
+    data = C.generate("logs", 8, 0, 3000)
+    d = Deflater(6, True); o = O.Deflater(6, True)
+    got, ref = bytearray(), bytearray()
+    buf = np.zeros(4096, np.uint8)
+    for pos in range(0, data.size, 7):
+        c = data[pos:pos + 7]
+        d.SetInput(c); o.set_input(c)
+        while not o.needs_input:
+            b = o.deflate(4096)
+            if not b:
+                break
+            ref += b
+        d.Flush(); o.flush()
+        while True:
+            k = d.Deflate(buf)
+            if k <= 0:
+                break
+            got += buf[:k].tobytes()
+        while True:
+            b = o.deflate(4096)
+            if not b:
+                break
+            ref += b
+    d.Finish(); o.finish()
+    while not d.IsFinished:
+        got += buf[:d.Deflate(buf)].tobytes()
+    while not o.finished:
+        ref += o.deflate(4096)
+    assert bytes(got) == bytes(ref)
+    assert zlib.decompress(bytes(got), -15) == data.tobytes()
+
+
+def test_history_across_window_slides():
+    """Segments longer than the 64 KiB window so that base_of() and the retained history are exercised."""
+    from sharpziplib_amd.deflater import Deflater
+    data = C.generate("enwik", 31, 0, 700000)
+    cuts = [65273, 65274, 65275, 98041, 163840, 300001, 700000]
+    d = Deflater(9, True); o = O.Deflater(9, True)
+    got, ref = bytearray(), bytearray()
+    buf = np.zeros(65536, np.uint8)
+    prev = 0
+    for cut in cuts:
+        c = data[prev:cut]; prev = cut
+        d.SetInput(c); o.set_input(c)
+        while not o.needs_input:
+            b = o.deflate(65536)
+            if not b:
+                break
+            ref += b
+        if cut != cuts[-1]:
+            d.Flush(); o.flush()
+            while True:
+                k = d.Deflate(buf)
+                if k <= 0:
+                    break
+                got += buf[:k].tobytes()
+            while True:
+                b = o.deflate(65536)
+                if not b:
+                    break
+                ref += b
+            assert bytes(got) == bytes(ref), cut
+    d.Finish(); o.finish()
+    while not d.IsFinished:
+        got += buf[:d.Deflate(buf)].tobytes()
+    while not o.finished:
+        ref += o.deflate(65536)
+    assert bytes(got) == bytes(ref)
