@@ -202,7 +202,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     timing.in_bytes = seg_bytes;
     timing.ranges_unmerged = hc[0];
     timing.fallback_walks = hc[1];
-    if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] match: wave-iterations %llu, quick lane-steps %llu, verify lane-steps %llu, positions %llu\n", hc[2], hc[3], hc[4], (unsigned long long)seg_bytes);
+    if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
     return 0;

@@ -155,7 +155,7 @@ enum : int { B_LDS_BYTES = B_DATA_BYTES + B_LINKS * 2 + 16 };
 template <bool DBG>
 __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                      const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                     uint2 *__restrict__ mtab, LevelParams P, unsigned long long *dbg) {
+                                                     uint2 *__restrict__ mtab, LevelParams P, unsigned long long *dbg, int fth, int vth) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *sdata32 = (uint32_t *)smem;                          // B_DATA_BYTES
     uint16_t *slink = (uint16_t *)(smem + B_DATA_BYTES);           // B_LINKS entries
@@ -209,30 +209,38 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     // all lane-steps) is a couple of dozen instructions: FETCH hands out positions, QUICK walks chains — one byte
     // (quick reject at offset `best`, :505) and one u16 (the candidate's link) from LDS per step — until too many
     // lanes have dropped out, VERIFY compares the candidates that passed the quick test dword by dword.
+    // Window base (App. A.2) for the first and last position of the tile; inside a tile it changes at most once.
+    const int64_t base_lo = base_of((int64_t)seg.abs0 + t0), base_hi = base_of((int64_t)seg.abs0 + t0 + tlen - 1);
+    // first tile position that already uses base_hi: smallest s with s+1-base_lo > 65273
+    const int64_t sw = base_lo == base_hi ? (int64_t)1 << 40 : (base_lo + 65273) - (int64_t)seg.abs0 - t0; // tile-relative
+    const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo); // LDS index of window index 1... (clamped below)
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int SNAPLEFT = P.max_chain - (P.max_chain >> 2); // `left` value at which the quarter-budget walk would stop
-    enum { NEED = 0, QUICK = 1, VERIFY = 2, DONE = 3 };
-    enum { Q_THRESH = 36, F_THRESH = 16 };
+    enum { NEED = 0, DONE = 1, QUICK = 2, VERIFY = 3 }; // idle lanes are those with mode < QUICK
+    const int F_THRESH = fth, V_THRESH = vth;
     int wnext = 0, wend = 0;       // wave-uniform slice of tile positions being handed out
     bool exhausted = false;
     int mode = NEED;
     int pl = B_HIST, cl = B_HIST, off = 0, lnk = 0;
     int best = 2, cap = 4, nice = 4, mincl = 0, left = 1, p = 0;
     uint32_t pb = 0, res2 = 0, resq = 0;
-    unsigned long long n_it = 0, n_q = 0, n_v = 0;
+    unsigned long long n_q = 0, n_qs = 0, n_v = 0, n_vs = 0;
 
+    // A small scheduler picks, per visit, the phase that has enough lanes waiting for it: the phases cost the same
+    // for one lane as for 64, so each is run only when it is well occupied (or nothing else can make progress).
     for (;;) {
-        // ---------------- FETCH: retire finished positions and hand out new ones — only when enough lanes are idle,
-        // because this phase is long (64-bit window arithmetic) and costs the same for 1 lane as for 64
-        const uint64_t idle = __ballot(mode == NEED || mode == DONE);
-        if (__builtin_popcountll(idle) >= F_THRESH || idle == ~0ull) {
+        const uint64_t idle = __ballot(mode < QUICK);
+        const uint64_t vm = __ballot(mode == VERIFY);
+        const int ni = __builtin_popcountll(idle), nv = __builtin_popcountll(vm);
+        const int nq = 64 - ni - nv;
+        if ((ni >= F_THRESH && !exhausted) || (nq == 0 && nv == 0)) {
+            // ---------------- FETCH: retire finished positions and hand out new ones
             if (mode == DONE) {
                 mt[t0 + p] = make_uint2(res2, resq);
                 mode = NEED;
             }
             if (!exhausted) {
-                const uint64_t nm = idle;
                 if (wnext >= wend) {
                     int base = 0;
                     if (lane == 0) base = atomicAdd(s_counter, 256);
@@ -241,25 +249,23 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                     wend = base + 256 < tlen ? base + 256 : tlen;
                     if (wnext >= wend) exhausted = true;
                 }
-                const int rank = __builtin_popcountll(nm & lanemask_lt);
+                const int rank = __builtin_popcountll(idle & lanemask_lt);
                 if (mode == NEED && wnext + rank < wend) {
                     p = wnext + rank;
-                    const int64_t Pp = t0 + p;
-                    const int64_t rem = seg_end - Pp;
+                    const int64_t rem = seg_end - (t0 + p);
                     res2 = 0; resq = 0;
                     bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
                     if (ok) {
                         pl = p + B_HIST;
                         const int l0 = (int)slink[pl];                           // hashHead (:782)
-                        const int64_t pabs = (int64_t)seg.abs0 + Pp;
-                        const int64_t basem = base_of(pabs) - (int64_t)seg.abs0; // buffer position whose window index is 1
-                        // first candidate: strstart - hashHead <= MAX_DIST (:788) and entry not clamped by a slide (index >= 1)
-                        const int64_t firstmin = Pp - MAX_DIST > basem ? Pp - MAX_DIST : basem;
-                        const int64_t chainmin = Pp - (MAX_DIST - 1) > basem ? Pp - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
+                        // LDS index of the buffer position whose window index is 1 (entries below it were clamped by a slide, :450-461)
+                        const int basem = (int64_t)p >= sw ? basem_hi : basem_lo;
+                        // first candidate: strstart - hashHead <= MAX_DIST (:788); chain: curMatch > limit (:609)
+                        const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem;
                         cl = pl - l0;
-                        ok = l0 != 0 && cl >= (int)(firstmin - dlo);
+                        ok = l0 != 0 && cl >= firstmin;
                         if (ok) {
-                            mincl = (int)(chainmin - dlo);
+                            mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem;
                             cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;         // scanMax :479
                             nice = rem < (int64_t)P.nice ? (int)rem : P.nice;       // :485 (64-bit compare: rem can exceed 2^31)
                             best = 2; left = P.max_chain;
@@ -269,43 +275,17 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                     }
                     if (!ok) mt[t0 + p] = make_uint2(0u, 0u);
                 }
-                const int taken = __builtin_popcountll(nm);
-                wnext = wnext + taken < wend ? wnext + taken : wend;
+                wnext = wnext + ni < wend ? wnext + ni : wend;
             }
             if (exhausted && __all(mode == NEED)) break;
+            continue;
         }
-        // ---------------- QUICK: chain steps (branch-free body: one byte + one u16 from LDS, a dozen VALU)
-        uint64_t qm = __ballot(mode == QUICK);
-        while (qm) {
-            if (DBG) { n_it++; n_q += __builtin_popcountll(qm); }
+        if (nv >= V_THRESH || nq == 0) {
+            // ---------------- VERIFY: dword-by-dword comparison of candidates that passed the quick test (2 steps per visit)
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-            if (mode == QUICK) {
-                const uint32_t qb = sdata8[cl + best];   // a longer match must agree at offset `best` (scan_end, :505)
-                lnk = (int)slink[cl];
-                const bool pass = qb == pb;
-                // next candidate of the chain, or the end of this position (:609)
-                const int left1 = left - 1;
-                const int c2 = cl - lnk;
-                const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
-                left = pass ? left : left1;
-                cl = (pass | end) ? cl : c2;
-                mode = pass ? VERIFY : (end ? DONE : QUICK);
-            }
-            qm = __ballot(mode == QUICK);
-            if (__builtin_popcountll(qm) <= Q_THRESH) {
-                const uint64_t others = __ballot(mode == VERIFY);
-                const uint64_t idl = __ballot(mode == NEED || mode == DONE);
-                if (others || (__builtin_popcountll(idl) >= F_THRESH && !exhausted) || qm == 0) break;
-            }
-        }
-        // ---------------- VERIFY: full comparison of the candidates that passed the quick test
-        uint64_t vm = __ballot(mode == VERIFY);
-        bool fresh = true;
-        while (vm) {
-            if (DBG) { n_it++; n_v += __builtin_popcountll(vm); }
+            for (int u = 0; u < 2; u++)
             if (mode == VERIFY) {
-                if (fresh) off = 0;
+                if (DBG) { n_vs++; n_v += __builtin_popcountll(__ballot(true)); }
                 const uint32_t x = ldsdw(cl + off) ^ ldsdw(pl + off);
                 const bool eq = x == 0;
                 const int l = off + (eq ? 4 : (__builtin_ctz(x) >> 3));
@@ -329,11 +309,39 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                     mode = (nicehit | end) ? DONE : QUICK;
                 }
             }
-            fresh = false;
-            vm = __ballot(mode == VERIFY);
+            continue;
+        }
+        // ---------------- QUICK: chain steps (branch-free body: one byte + one u16 from LDS, a dozen VALU), 4 per visit
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        if (mode == QUICK) {
+            if (DBG) { n_qs++; n_q += __builtin_popcountll(__ballot(true)); }
+            const uint32_t qb = sdata8[cl + best];   // a longer match must agree at offset `best` (scan_end, :505)
+            lnk = (int)slink[cl];
+            const bool pass = qb == pb;
+            // next candidate of the chain, or the end of this position (:609)
+            const int left1 = left - 1;
+            const int c2 = cl - lnk;
+            const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
+            left = pass ? left : left1;
+            cl = (pass | end) ? cl : c2;
+            off = 0;
+            mode = pass ? VERIFY : (end ? DONE : QUICK);
         }
     }
-    if (DBG && dbg && lane == 0) { atomicAdd(dbg + 2, n_it); atomicAdd(dbg + 3, n_q); atomicAdd(dbg + 4, n_v); }
+    if (DBG && dbg) {
+        // per-wave totals: n_qs/n_vs are per-lane participation counts, so reduce with max over the wave
+        unsigned long long qs = n_qs, vs = n_vs;
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long a = __shfl_xor(qs, o), c = __shfl_xor(vs, o);
+            qs = a > qs ? a : qs; vs = c > vs ? c : vs;
+        }
+        if (lane == 0) { atomicAdd(dbg + 2, qs); atomicAdd(dbg + 5, vs); }
+        // lane-steps: every participating lane counted the ballot, so divide by participation via lane 0 only is wrong; sum 1 per lane-step instead
+        unsigned long long ql = n_qs, vl = n_vs;
+        for (int o = 32; o > 0; o >>= 1) { ql += __shfl_xor(ql, o); vl += __shfl_xor(vl, o); }
+        if (lane == 0) { atomicAdd(dbg + 3, ql); atomicAdd(dbg + 4, vl); }
+    }
 }
 
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
@@ -347,6 +355,7 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
                         uint2 *mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     static bool attr_set = false;
     static const bool want_dbg = getenv("SZL_DEBUG") != nullptr;
+    static const int fth = getenv("SZL_FTH") ? atoi(getenv("SZL_FTH")) : 16, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -355,8 +364,8 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
         attr_set = true;
     }
     if (ntiles > 0) {
-        if (want_dbg) hipLaunchKernelGGL(k_match<true>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg);
-        else hipLaunchKernelGGL(k_match<false>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg);
+        if (want_dbg) hipLaunchKernelGGL(k_match<true>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth);
+        else hipLaunchKernelGGL(k_match<false>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth);
     }
     return hipGetLastError();
 }
