@@ -29,8 +29,8 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 // Stage A: k_links.  One workgroup (16 wavefronts) walks a span of a stream front to back.
 // The 32768-entry head table (C/DeflaterEngine.cs:87 `head`) lives in LDS as u16, partitioned by
 // hash between the 16 wavefronts: wavefront w owns the 2048 buckets whose mixed hash nibble == w and
-// handles ONLY positions that hash into them, so table updates need no inter-wave ordering and no
-// barriers; every wavefront reads the whole span (L1/L2-served after the first).  Inside a
+// handles ONLY positions that hash into them, so table updates need no inter-wave ordering; the span is
+// hashed once per 1024-position chunk (each wavefront hashes one 64-position slice into LDS, one barrier).  Inside a
 // 64-position batch, "previous lane with the same bucket" is found with a ballot loop over the
 // distinct buckets present (≈4 per batch per wave).  Stale entries are aged out every 16384
 // positions exactly like SlideWindow's clamp (:450-461), which keeps 16-bit entries unambiguous.
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
                                                      const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link) {
     __shared__ uint16_t head[32768];
+    __shared__ uint16_t hidx[2][A_THREADS]; // bucket index of each position of the current 1024-position chunk (0xFFFF: not inserted)
     const SpanDev span = spans[blockIdx.x];
     const SegDev seg = segs[span.seg];
     const uint8_t *d = in + seg.buf_off;
@@ -57,49 +58,49 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
     int bi = 0;
     const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    for (int64_t q00 = warm0; q00 < span.end; q00 += 256) {
-        if (q00 != warm0 && ((q00 - warm0) & 16383) == 0) {
+    int buf = 0;
+    for (int64_t c0 = warm0; c0 < span.end; c0 += A_THREADS, buf ^= 1) {
+        if (c0 != warm0 && ((c0 - warm0) & 16383) == 0) {
             for (int i = lane; i < 2048; i += 64) {
-                uint32_t dist = (uint32_t)(q00 - myhead[i]) & 0xFFFF;
-                if (dist >= 32768u || dist == 0u) myhead[i] = (uint16_t)((q00 - 40000) & 0xFFFF);
+                uint32_t dist = (uint32_t)(c0 - myhead[i]) & 0xFFFF;
+                if (dist >= 32768u || dist == 0u) myhead[i] = (uint16_t)((c0 - 40000) & 0xFFFF);
             }
         }
-        // ---- issue the four batches' loads first (one global round trip per 256 positions)
-        while (bi < nb && (int64_t)b[bi] <= q00) bi++; // wave-uniform
-        const bool near_bnd = bi >= nb || (int64_t)b[bi] < q00 + 256 + 2;
-        uint32_t w4[4];
-        bool ins4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int64_t q = q00 + 64 * k + lane;
+        // ---- phase 1: every wavefront hashes ITS 64-position slice of the chunk once (instead of all 16 hashing everything)
+        {
+            const int64_t q = c0 + threadIdx.x;
+            while (bi < nb && (int64_t)b[bi] <= c0) bi++; // uniform
             bool ins = q < span.end;
-            if (near_bnd) { // a segment end is near: InsertString needs lookahead >= 3 (:780,:817)
+            if (bi >= nb) ins = false;
+            else if ((int64_t)b[bi] < c0 + A_THREADS + 2) { // a segment end is near: InsertString needs lookahead >= 3 (:780,:817)
                 int j = bi;
                 while (j < nb && (int64_t)b[j] <= q) j++;
                 ins = ins && j < nb && (int64_t)b[j] - q >= 3;
             }
-            uint32_t w = 0;
+            uint32_t idx = 0xFFFF;
             if (ins) {
+                uint32_t w;
                 if ((uint64_t)q + 4 <= avail) w = load_u32_unaligned(d + q);
                 else w = (uint32_t)d[q] | ((uint32_t)d[q + 1] << 8) | ((uint32_t)d[q + 2] << 16);
+                const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
+                const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
+                const uint32_t o = (h ^ (h >> 5) ^ (h >> 10)) & 15;         // owner wavefront (bijective with h>>4)
+                idx = (o << 11) | (h >> 4);
             }
-            w4[k] = w; ins4[k] = ins;
+            hidx[buf][threadIdx.x] = (uint16_t)idx;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int64_t q0 = q00 + 64 * k;
+        __syncthreads(); // one barrier per chunk; double buffering makes the second one unnecessary
+        // ---- phase 2: each wavefront walks the 16 slices in order and handles the positions whose bucket it owns
+#pragma unroll 4
+        for (int k = 0; k < A_WAVES; k++) {
+            const int64_t q0 = c0 + 64 * k;
             if (q0 >= span.end) break;
             const int64_t q = q0 + lane;
-            const bool ins = ins4[k];
-            const uint32_t w = w4[k];
-            const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
-            const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
-            const uint32_t o = (h ^ (h >> 5) ^ (h >> 10)) & 15;         // owner wavefront (bijective with h>>4)
-            const uint32_t idx = (o << 11) | (h >> 4);
-            const bool owned = ins && (int)o == wave;
+            const uint32_t idx = hidx[buf][64 * k + lane];
+            const bool owned = (idx >> 11) == (uint32_t)wave; // 0xFFFF>>11 == 31: never a wave id
             // Fast path: most batches hold no two owned positions with the same bucket.  All owned lanes store their
             // position into the bucket and read it back; a lane that reads something else lost to a same-bucket lane.
-            // Only then is the exact "previous lane with my bucket" computed with the ballot loop below.
+            // Only then is the exact "previous lane with my bucket" computed, with a ballot loop over the buckets in conflict.
             const uint32_t myq16 = (uint32_t)q & 0xFFFF;
             uint32_t e_old = 0, rb = myq16;
             if (owned) { // volatile: the read-back must really hit LDS (another lane of this wave may have overwritten it)
@@ -110,27 +111,25 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
             }
             int predlane = -1;
             bool islast = true;
-            if (__ballot(owned && rb != myq16)) {
-                uint64_t mm = __ballot(owned);
-                while (mm) {
-                    int l = __builtin_ctzll(mm);
-                    uint32_t kk = __builtin_amdgcn_readlane(idx, l);
-                    bool mine = owned && idx == kk;
-                    uint64_t same = __ballot(mine);
-                    if (mine) {
-                        uint64_t below = same & lanemask_lt;
-                        predlane = below ? 63 - __builtin_clzll(below) : -1;
-                        islast = ((same >> lane) >> 1) == 0;
-                    }
-                    mm &= ~same;
+            uint64_t mm = __ballot(owned && rb != myq16);
+            while (mm) {
+                int l = __builtin_ctzll(mm);
+                uint32_t kk = __builtin_amdgcn_readlane(idx, l);
+                bool mine = owned && idx == kk;
+                uint64_t same = __ballot(mine);
+                if (mine) {
+                    uint64_t below = same & lanemask_lt;
+                    predlane = below ? 63 - __builtin_clzll(below) : -1;
+                    islast = ((same >> lane) >> 1) == 0;
                 }
+                mm &= ~same;
             }
             if (owned) {
                 uint32_t dist = predlane >= 0 ? (uint32_t)(lane - predlane) : ((uint32_t)(q - e_old) & 0xFFFF);
                 if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
                 if (q >= span.start) lk[q] = (uint16_t)dist;
-                if (islast) head[idx] = (uint16_t)(q & 0xFFFF);
-            } else if (!ins && wave == 0 && q >= span.start && q < span.end) {
+                if (!islast || predlane >= 0 || rb != myq16) { if (islast) head[idx] = (uint16_t)myq16; }
+            } else if (idx == 0xFFFF && wave == 0 && q >= span.start && q < span.end) {
                 lk[q] = 0; // position never inserted (tail of a segment)
             }
         }
