@@ -105,11 +105,13 @@ typedef struct szl_stream {
     uint32_t crc32;     /* [out] Crc32.Value of the input if SZL_F_CRC32 */
     uint32_t adler32;   /* [out] Adler32.Value of the input if SZL_F_ADLER32 or zlib framing */
     int32_t status;     /* [out] per-stream szl_status */
-    uint32_t reserved;
+    uint32_t reserved;  /* [in] SZL_F_GZIP: MTIME field of the member header */
     uint64_t in_consumed; /* [out] inflate: compressed bytes consumed (== Inflater.TotalIn at IsFinished) */
 } szl_stream;
 
-enum { SZL_F_NOWRAP = 1, SZL_F_CRC32 = 2, SZL_F_ADLER32 = 4, SZL_F_SYNC_FLUSH_BEFORE_FINISH = 8 };
+enum { SZL_F_NOWRAP = 1, SZL_F_CRC32 = 2, SZL_F_ADLER32 = 4, SZL_F_SYNC_FLUSH_BEFORE_FINISH = 8,
+       SZL_F_GZIP = 16 /* deflate only: emit a complete RFC 1952 member per stream exactly as GZipOutputStream would with
+                          ModifiedTime = streams[i].reserved seconds since the epoch (S/GZip/GzipOutputStream.cs:315-375) */ };
 
 uint64_t szl_deflate_bound(uint64_t in_len);   /* worst-case compressed size the device path may write */
 

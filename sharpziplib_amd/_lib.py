@@ -21,7 +21,7 @@ class Timing(ctypes.Structure):
                [(n, ctypes.c_uint64) for n in ("in_bytes", "out_bytes", "tokens", "blocks", "ranges_unmerged", "fallback_walks")]
 
 
-F_NOWRAP, F_CRC32, F_ADLER32, F_SYNC_FLUSH_BEFORE_FINISH = 1, 2, 4, 8
+F_NOWRAP, F_CRC32, F_ADLER32, F_SYNC_FLUSH_BEFORE_FINISH, F_GZIP = 1, 2, 4, 8, 16
 
 
 def build(force=False):

@@ -39,28 +39,32 @@ class Engine:
         return int(_lib.lib().szl_deflate_bound(n))
 
     @staticmethod
-    def layout(lengths, nowrap=True):
+    def layout(lengths, nowrap=True, extra=0):
         """Stream table for inputs packed back to back (4-byte aligned output regions)."""
         L = _lib.lib()
         arr = (_lib.Stream * len(lengths))()
         io = oo = 0
         for i, n in enumerate(lengths):
-            cap = (int(L.szl_deflate_bound(n)) + (0 if nowrap else 6) + 3) & ~3
+            cap = (int(L.szl_deflate_bound(n)) + (0 if nowrap else 6) + extra + 3) & ~3
             arr[i].in_off, arr[i].in_len, arr[i].out_off, arr[i].out_cap = io, n, oo, cap
             io += n
             oo += cap
         return arr, io, oo
 
-    def deflate(self, buffers, level=6, strategy=0, nowrap=True, crc32=False, adler32=False, sync_flush_before_finish=False):
+    def deflate(self, buffers, level=6, strategy=0, nowrap=True, crc32=False, adler32=False, sync_flush_before_finish=False,
+                gzip_mtime=None):
         """Compress host buffers (list of bytes/ndarray); returns [Result]."""
         bufs = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b, dtype=np.uint8) for b in buffers]
-        arr, in_total, out_total = self.layout([b.size for b in bufs], nowrap)
+        arr, in_total, out_total = self.layout([b.size for b in bufs], nowrap, 18 if gzip_mtime is not None else 0)
+        if gzip_mtime is not None:
+            for s in arr:
+                s.reserved = gzip_mtime
         hin = np.empty(in_total + 8, dtype=np.uint8)
         for s, b in zip(arr, bufs):
             hin[s.in_off:s.in_off + s.in_len] = b
         hout = np.zeros(out_total + 8, dtype=np.uint8)
         flags = (_lib.F_NOWRAP if nowrap else 0) | (_lib.F_CRC32 if crc32 else 0) | (_lib.F_ADLER32 if adler32 else 0) | \
-                (_lib.F_SYNC_FLUSH_BEFORE_FINISH if sync_flush_before_finish else 0)
+                (_lib.F_SYNC_FLUSH_BEFORE_FINISH if sync_flush_before_finish else 0) | (_lib.F_GZIP if gzip_mtime is not None else 0)
         _lib.check(self._L.szl_deflate_batch_host(self._h, hin.ctypes.data, hout.ctypes.data, arr, len(bufs), level, strategy, flags),
                    "szl_deflate_batch_host")
         return [Result(hout[s.out_off:s.out_off + s.out_len].tobytes(), s.crc32, s.adler32, s.status) for s in arr]

@@ -75,24 +75,28 @@ int szl_engine_last_timing(const szl_engine *e, szl_timing *t) {
     return 0;
 }
 
-static int build_batch(szl_stream *streams, size_t n, unsigned flags, std::vector<SegDev> &segs, std::vector<uint64_t> &bnds,
+static int zlib_header(int level);
+static int build_batch(szl_stream *streams, size_t n, unsigned flags, int level, std::vector<SegDev> &segs, std::vector<uint64_t> &bnds,
                        uint64_t *in_total, uint64_t *out_total) {
     segs.clear(); bnds.clear();
     uint64_t it = 0, ot = 0;
-    const bool nowrap = flags & SZL_F_NOWRAP;
+    const bool gzip = flags & SZL_F_GZIP;
+    const bool nowrap = (flags & SZL_F_NOWRAP) || gzip;
     for (size_t i = 0; i < n; i++) {
         szl_stream &s = streams[i];
         s.status = 0; s.out_len = 0; s.crc32 = 0; s.adler32 = 1;
         if (s.out_off & 3) { set_error("stream %zu: out_off must be a multiple of 4", i); return SZL_E_ARG; }
-        if (s.out_cap < szl_deflate_bound(s.in_len) + (nowrap ? 0 : 6)) { set_error("stream %zu: out_cap %llu < bound", i, (unsigned long long)s.out_cap); return SZL_E_OUTPUT_TOO_SMALL; }
+        if (s.out_cap < szl_deflate_bound(s.in_len) + (gzip ? 18 : (nowrap ? 0 : 6))) { set_error("stream %zu: out_cap %llu < bound", i, (unsigned long long)s.out_cap); return SZL_E_OUTPUT_TOO_SMALL; }
         SegDev d{};
         d.buf_off = s.in_off; d.abs0 = 0; d.seg_start = 0; d.seg_end = (int64_t)s.in_len;
         d.bnd_off = (uint32_t)bnds.size(); d.bnd_cnt = 1; bnds.push_back(s.in_len);
         d.out_off = s.out_off; d.out_cap = s.out_cap; d.stream_idx = (uint32_t)i;
-        d.start_bit = nowrap ? 0 : 16; d.adler_init = 1; d.crc_init = 0;
+        d.start_bit = gzip ? 80 : (nowrap ? 0 : 16); d.adler_init = 1; d.crc_init = 0;
+        d.hdr_word = gzip ? s.reserved : (uint32_t)zlib_header(level);
         if (flags & SZL_F_SYNC_FLUSH_BEFORE_FINISH) { d.finish = 0; d.flags = SEG_SYNC_PAD | SEG_EXTRA_FINAL_EMPTY; }
         else { d.finish = 1; d.flags = 0; }
-        if (!nowrap) d.flags |= SEG_ZLIB_TRAILER;
+        if (!nowrap) d.flags |= SEG_ZLIB_TRAILER | SEG_ZLIB_HEADER;
+        if (gzip) d.flags |= SEG_GZIP;
         segs.push_back(d);
         it = std::max(it, s.in_off + s.in_len);
         ot = std::max(ot, s.out_off + s.out_cap);
@@ -120,19 +124,12 @@ int szl_deflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     if (strategy < 0 || strategy > 2) return SZL_E_ARG;
     if (((uintptr_t)d_out) & 3) { set_error("d_out must be 4-byte aligned"); return SZL_E_ARG; }
     std::vector<SegDev> segs; std::vector<uint64_t> bnds; uint64_t in_total, out_total;
-    if ((rc = build_batch(streams, n_streams, flags, segs, bnds, &in_total, &out_total))) return rc;
+    if ((rc = build_batch(streams, n_streams, flags, level, segs, bnds, &in_total, &out_total))) return rc;
     std::vector<SegOut> res;
-    unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !(flags & SZL_F_NOWRAP)) ? 2u : 0u);
+    unsigned want = ((flags & (SZL_F_CRC32 | SZL_F_GZIP)) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !(flags & (SZL_F_NOWRAP | SZL_F_GZIP))) ? 2u : 0u);
     hipStream_t st = (hipStream_t)hip_stream;
     rc = e->e.deflate((const uint8_t *)d_in, in_total, (uint8_t *)d_out, out_total, segs, bnds, P, want, res, st);
     if (rc) return rc;
-    if (!(flags & SZL_F_NOWRAP)) { // zlib header bytes (2 per stream): tiny strided writes
-        int hdr = zlib_header(level);
-        uint8_t hb[2] = {(uint8_t)(hdr >> 8), (uint8_t)hdr};
-        for (size_t i = 0; i < n_streams; i++)
-            if (hipMemcpyAsync((uint8_t *)d_out + streams[i].out_off, hb, 2, hipMemcpyHostToDevice, st) != hipSuccess) return SZL_E_DEVICE;
-        if (hipStreamSynchronize(st) != hipSuccess) return SZL_E_DEVICE;
-    }
     for (size_t i = 0; i < n_streams; i++) {
         streams[i].out_len = res[i].out_bytes;
         streams[i].crc32 = res[i].crc32;

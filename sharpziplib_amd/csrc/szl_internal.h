@@ -30,7 +30,7 @@ struct SegDev {
     uint32_t flags;      // SEG_* below
     uint64_t range_off;  // first stage-C range of this segment
     uint32_t range_cnt;
-    uint32_t pad0;
+    uint32_t hdr_word;   // SEG_ZLIB_HEADER: the 16-bit zlib header; SEG_GZIP: MTIME of the member header
     uint64_t out_off;    // output arena offset of this segment's output region
     uint64_t out_cap;    // bytes
     uint32_t start_bit;  // bit offset inside the region at which this segment's first block starts
@@ -39,7 +39,7 @@ struct SegDev {
     uint32_t adler_init;   // running Adler32.Value before this segment's bytes (zlib framing)
     uint32_t crc_init;     // running Crc32.Value before this segment's bytes
 };
-enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4 };
+enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4, SEG_ZLIB_HEADER = 8, SEG_GZIP = 16 };
 
 struct SpanDev { uint32_t seg; uint32_t pad; int64_t start, end; };          // stage A: emit links for [start,end)
 struct TileDev { uint32_t seg; uint32_t pad; int64_t start; int32_t len; int32_t pad2; }; // stage B tile

@@ -587,6 +587,18 @@ __global__ void k_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint
         o[0] = (uint8_t)(a >> 24); o[1] = (uint8_t)(a >> 16); o[2] = (uint8_t)(a >> 8); o[3] = (uint8_t)a;
         bytes += 4; E = bytes * 8;
     }
+    if (s.flags & SEG_GZIP) { // RFC 1952 member trailer: CRC32 | ISIZE, little endian (S/GZip/GzipOutputStream.cs:315-337)
+        uint32_t c = so[si].crc32, n = (uint32_t)((uint64_t)(s.seg_end - s.seg_start) & 0xffffffffu);
+        uint8_t *o = out + s.out_off + bytes;
+        o[0] = (uint8_t)c; o[1] = (uint8_t)(c >> 8); o[2] = (uint8_t)(c >> 16); o[3] = (uint8_t)(c >> 24);
+        o[4] = (uint8_t)n; o[5] = (uint8_t)(n >> 8); o[6] = (uint8_t)(n >> 16); o[7] = (uint8_t)(n >> 24);
+        bytes += 8; E = bytes * 8;
+        uint8_t *h = out + s.out_off; // header (S/GZip/GzipOutputStream.cs:339-375): ID1 ID2 CM FLG MTIME XFL OS
+        uint32_t t = s.hdr_word;
+        h[0] = 0x1F; h[1] = 0x8B; h[2] = 8; h[3] = 0; h[4] = (uint8_t)t; h[5] = (uint8_t)(t >> 8); h[6] = (uint8_t)(t >> 16);
+        h[7] = (uint8_t)(t >> 24); h[8] = 0; h[9] = 255;
+    }
+    if (s.flags & SEG_ZLIB_HEADER) { uint8_t *h = out + s.out_off; h[0] = (uint8_t)(s.hdr_word >> 8); h[1] = (uint8_t)s.hdr_word; } // C/Deflater.cs:436-461
     so[si].end_bit = E;
     so[si].out_bytes = bytes;
 }

@@ -309,3 +309,20 @@ def test_history_across_window_slides():
     while not o.finished:
         ref += o.deflate(65536)
     assert bytes(got) == bytes(ref)
+
+
+def test_gzip_members_on_device(eng):
+    """§8f-1: complete RFC 1952 members produced on the device == GZipOutputStream(level 6, ModifiedTime = t)
+    (S/GZip/GzipOutputStream.cs:315-375: header 1F 8B 08 00 MTIME 00 FF, trailer CRC32 | ISIZE)."""
+    import gzip
+    import struct
+    datas = [C.generate("enwik", 0xE9, 0, 300000), np.zeros(0, np.uint8), C.random_bytes(70000)]
+    mtime = 1_700_000_000
+    res = eng.deflate(datas, level=6, gzip_mtime=mtime)
+    for d, r in zip(datas, res):
+        raw = O.deflate(d, 6)
+        want = bytes([0x1F, 0x8B, 8, 0]) + struct.pack("<I", mtime) + bytes([0, 255]) + raw + struct.pack("<II", O.crc32(d), d.size & 0xFFFFFFFF)
+        assert r.data == want
+        assert gzip.decompress(r.data) == d.tobytes()
+    # concatenated members form a multi-member .gz (what GZipInputStream reads, S/GZip/GzipInputStream.cs:109-153)
+    assert gzip.decompress(b"".join(r.data for r in res)) == b"".join(d.tobytes() for d in datas)
