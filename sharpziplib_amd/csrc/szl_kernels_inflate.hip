@@ -183,6 +183,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     };
 
     enum { EV_NONE = 0, EV_MATCH, EV_RESTAGE, EV_FLUSH, EV_TABLES, EV_STORED, EV_STOP };
+    // Decode state (bit buffer, block mode, table sizes) is private to lane 0; only what the data movers need is
+    // broadcast per event: the event code, two operands and the output position.
     while (status == INF_RUNNING) {
         int ev = EV_NONE, ea = 0, eb = 0;
         // pending match tail from a previous OUTPUT_FULL stop
@@ -193,10 +195,24 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
             // ---------------- lane 0: run the bit-serial state machine until something needs the whole wavefront
             for (;;) {
                 const uint64_t bytepos = (bitpos + nb) >> 3;
-                if (!stage_ok(bytepos)) { ev = EV_RESTAGE; break; }
+                if (!stage_ok(bytepos)) { ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break; }
                 refill();
-                const uint64_t avail = in_bits > bitpos ? in_bits - bitpos : 0; // valid bits from bitpos on
                 if (outpos - flushed >= 16384) { ev = EV_FLUSH; break; }
+                uint64_t avail = in_bits > bitpos ? in_bits - bitpos : 0; // valid bits from bitpos on
+                if (mode == INF_M_HUFF && avail >= 64) {
+                    // ---- fast path: literals (code length <= 10 bits) straight from the primary table into the window
+                    const uint64_t lim_out = out_limit < flushed + 16384 ? out_limit : flushed + 16384;
+                    for (;;) {
+                        const uint32_t e = S.llut[(uint32_t)bb & ((1u << I_LPB) - 1)];
+                        if (e - 1 >= (256u << 4) - 1 || outpos >= lim_out || nb < 16) break; // not a short literal / no room / refill
+                        const uint32_t sl = e & 15;
+                        S.win[outpos & I_WMASK] = (uint8_t)(e >> 4);
+                        outpos++;
+                        bb >>= sl; nb -= (int)sl; bitpos += sl;
+                    }
+                    if (nb < 33) continue; // refill (and re-check staging / flush) before a token that may need 48 bits
+                    avail = in_bits > bitpos ? in_bits - bitpos : 0;
+                }
                 if (mode == INF_M_HEADER) {
                     if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
                     if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
@@ -218,16 +234,15 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                     if (type == 1) {
                         bb >>= 3; nb -= 3; bitpos += 3;
                         lastblk |= t & 1; btype = 1; mode = INF_M_HUFF;
-                        ev = EV_TABLES; break;
+                        ev = EV_TABLES; ea = 1; break;
                     }
                     // dynamic: parse the whole header here; if input runs out, nothing is consumed (restart at the block header)
                     {
                         uint64_t hb = bb; int hn = nb; uint64_t hp = bitpos; // local cursor
-                        auto need = [&](int k) -> bool { // ensure k bits in hb; false = out of input
-                            if ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) return false;
+                        auto need = [&](int k) -> bool { // ensure k bits in hb; false = out of staged window
                             while (hn < k) {
                                 uint64_t bp = (hp + hn) >> 3;
-                                if (!(bp >= sbase && bp + 8 <= sbase + I_STAGE)) return false; // handled by caller: restage
+                                if (!(bp >= sbase && bp + 8 <= sbase + I_STAGE)) return false;
                                 uint32_t o = (uint32_t)(bp - sbase);
                                 uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
                                 hb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, o & 3) << hn;
@@ -238,9 +253,9 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                         auto take = [&](int k) -> uint32_t { uint32_t v = (uint32_t)hb & ((1u << k) - 1); hb >>= k; hn -= k; hp += k; return v; };
                         int fail = 0; // 1 need input, 2 need restage, <0 error
                         auto want = [&](int k) -> bool {
-                            if (need(k)) return true;
-                            fail = ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) ? 1 : 2;
-                            return false;
+                            if ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) { fail = 1; return false; }
+                            if (!need(k)) { fail = 2; return false; }
+                            return true;
                         };
                         uint32_t nl = 0, nd = 0, nm = 0;
                         do {
@@ -252,7 +267,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                             for (int i = 0; i < 19; i++) ml[i] = 0;
                             for (uint32_t i = 0; i < nm; i++) { if (!want(3)) break; ml[c_meta_order[i]] = (uint8_t)take(3); }
                             if (fail) break;
-                            // 7-bit LUT for the code-length alphabet, built in registers/LDS scratch (codes[] reused)
                             int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nxt[8];
                             for (int i = 0; i < 19; i++) cnt[ml[i]]++;
                             cnt[0] = 0;
@@ -292,19 +306,33 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                         if (fail == 1) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                         if (fail == 2) { // header straddles the staged window: restage at the block header and retry
                             if (((bitpos >> 3) & ~3ull) == sbase) { ev = EV_STOP; ea = SZL_E_DYN_HEADER; break; } // cannot happen: a header is < 1 KiB
-                            ev = EV_RESTAGE; ea = 1; break;
+                            ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break;
                         }
                         if (fail < 0) { ev = EV_STOP; ea = fail; break; }
                         bb = hb; nb = hn; bitpos = hp;
                         lastblk |= t & 1; btype = 2; lnum = nl; dnum = nd; mode = INF_M_HUFF;
-                        ev = EV_TABLES; break;
+                        ev = EV_TABLES; ea = 2 | (int)(nl << 8) | (int)(nd << 20); break;
                     }
                 }
                 if (mode == INF_M_STORED) {
                     if (stored_left == 0) { mode = INF_M_HEADER; continue; }
-                    ev = EV_STORED; break;
+                    // byte aligned here (SkipToByteBoundary :490): copy bytes input -> window with the whole wavefront
+                    const uint64_t bp = bitpos >> 3;
+                    uint64_t can_in = job.in_len > bp ? job.in_len - bp : 0;
+                    uint64_t can_out = out_limit - outpos;
+                    uint64_t room = (uint64_t)(I_WIN - 512) - (outpos - flushed);
+                    uint64_t n = stored_left;
+                    if (n > can_in) n = can_in;
+                    if (n > can_out) n = can_out;
+                    if (n == 0) { ev = EV_STOP; ea = can_in == 0 ? INF_NEED_INPUT : INF_OUTPUT_FULL; break; }
+                    if (n > room) { if (room < 4096) { ev = EV_FLUSH; break; } n = room; }
+                    if (n > 0x7FFFFFFF) n = 0x7FFFFFFF;
+                    ev = EV_STORED; ea = (int)n; eb = 0;
+                    // lane 0 advances its own cursor; the copy itself reads in[] directly (no bit buffer)
+                    stored_left -= (uint32_t)n;
+                    break;
                 }
-                // ---------------- INF_M_HUFF: literals are written by lane 0 itself; a match goes to the wavefront
+                // ---------------- INF_M_HUFF general path: one token
                 int r = decode_sym(&S.lt, S.llut, I_LPB, (uint32_t)bb);
                 if (r < 0) { ev = EV_STOP; ea = avail < 15 ? INF_NEED_INPUT : SZL_E_CODELEN_ZERO; break; }
                 uint32_t sl = (uint32_t)r >> 16, sym = (uint32_t)r & 0xFFFF;
@@ -318,8 +346,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                 }
                 if (sym == 256) { bb >>= sl; nb -= sl; bitpos += sl; mode = INF_M_HEADER; continue; }
                 if (sym - 257 >= 29) { ev = EV_STOP; ea = SZL_E_ILLEGAL_LEN_CODE; break; } // :323-326
-                // length extra, distance symbol, distance extra: up to 15+5+15+13 = 48 bits, all inside bb (nb > 32 after refill
-                // is not guaranteed to cover 48) -> use a local cursor and refill once in between
                 {
                     uint64_t tb = bb; int tn = nb; uint64_t used = sl;
                     tb >>= sl; tn -= sl;
@@ -351,24 +377,12 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
         ev = __builtin_amdgcn_readfirstlane(ev);
         ea = __builtin_amdgcn_readfirstlane(ea);
         eb = __builtin_amdgcn_readfirstlane(eb);
-        // lane 0's scalars that other lanes need
         outpos = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(outpos >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)outpos);
-        bitpos = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(bitpos >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)bitpos);
-        {
-            int nbb = __builtin_amdgcn_readfirstlane(nb);
-            mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
-            lastblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)lastblk);
-            stored_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_left);
-            btype = (uint32_t)__builtin_amdgcn_readfirstlane((int)btype);
-            lnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)lnum);
-            dnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)dnum);
-            if (lane != 0) nb = nbb;
-        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         switch (ev) {
         case EV_MATCH: {
             const uint32_t len = (uint32_t)ea, dist = (uint32_t)eb;
-            if (outpos + len > out_limit) { // keep the decoded match for the next call (the reference's mode DECODE_HUFFMAN_DISTBITS done)
+            if (outpos + len > out_limit) { // keep the decoded match for the next call
                 pend_len = len; pend_dist = dist; status = INF_OUTPUT_FULL; break;
             }
             if (outpos - flushed + len > I_WIN - 512) flush(outpos);
@@ -379,40 +393,35 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
             }
             outpos += len;
         } break;
-        case EV_RESTAGE:
-            if (ea == 1) { // restart the dynamic header at the block start
-                // bb/nb are lane-0 private: drop them and re-read from the restaged window
-            }
-            bb = 0; nb = 0;
-            restage(bitpos >> 3);
-            if (lane == 0 && (bitpos & 7)) { // re-prime the partial first byte
-                uint32_t o = (uint32_t)((bitpos >> 3) - sbase);
+        case EV_RESTAGE: {
+            const uint64_t bp = ((uint64_t)(uint32_t)eb << 32) | (uint32_t)ea;
+            restage(bp);
+            if (lane == 0) { // re-prime lane 0's bit buffer at bitpos (possibly mid-byte)
+                uint32_t o = (uint32_t)(bp - sbase);
                 uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
                 uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, o & 3);
                 uint32_t sh = (uint32_t)(bitpos & 7);
                 bb = (uint64_t)(x >> sh); nb = 32 - (int)sh;
             }
-            break;
+        } break;
         case EV_FLUSH:
             flush(outpos);
             break;
         case EV_TABLES:
+            btype = (uint32_t)ea & 3; lnum = ((uint32_t)ea >> 8) & 0xFFF; dnum = ((uint32_t)ea >> 20) & 0xFF;
             rebuild_tables();
             break;
         case EV_STORED: {
-            // bit reader is byte aligned here: give back whole bytes held in bb, then copy bytes input -> window
-            uint64_t bytepos = bitpos >> 3; // bitpos is a multiple of 8 (SkipToByteBoundary :490)
-            uint64_t can_in = job.in_len > bytepos ? job.in_len - bytepos : 0;
-            uint64_t can_out = out_limit - outpos;
-            uint64_t room = (uint64_t)(I_WIN - 512) - (outpos - flushed);
-            uint64_t n = stored_left;
-            if (n > can_in) n = can_in;
-            if (n > can_out) n = can_out;
-            if (n > room) { flush(outpos); room = I_WIN - 512; if (n > room) n = room; }
-            for (uint64_t i = lane; i < n; i += 64) S.win[(outpos + i) & I_WMASK] = in[bytepos + i];
-            outpos += n; bitpos += 8 * n; stored_left -= (uint32_t)n;
-            bb = 0; nb = 0; sbase = ~0ull; // force a restage at the new position
-            if (n == 0) status = can_in == 0 ? INF_NEED_INPUT : INF_OUTPUT_FULL;
+            const uint64_t n = (uint32_t)ea;
+            uint64_t bp = 0;
+            { // lane 0 holds bitpos: broadcast the byte position of the stored data
+                uint64_t v = bitpos >> 3;
+                bp = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            }
+            for (uint64_t i = lane; i < n; i += 64) S.win[(outpos + i) & I_WMASK] = in[bp + i];
+            outpos += n;
+            if (lane == 0) { bitpos += 8 * n; bb = 0; nb = 0; }
+            sbase = ~0ull; // force a restage at the new position
         } break;
         case EV_STOP:
             status = ea;
@@ -423,6 +432,14 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     }
     // ---- epilogue: flush, save state
     flush(outpos);
+    // lane 0 owns the decode state: make the scalars the other lanes use uniform again
+    bitpos = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(bitpos >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)bitpos);
+    mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
+    btype = (uint32_t)__builtin_amdgcn_readfirstlane((int)btype);
+    lastblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)lastblk);
+    stored_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_left);
+    lnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)lnum);
+    dnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)dnum);
     if (status == INF_FINISHED && job.zlib) { // Adler-32 trailer (C/Inflater.cs:397-418): align, 4 bytes big-endian
         uint64_t bytepos = (bitpos + 7) >> 3;
         if (bytepos + 4 > job.in_len) { status = INF_NEED_INPUT; mode = INF_M_HEADER; /* lastblk stays set: resumes straight to DONE */ }
