@@ -32,7 +32,7 @@ class Engine {
     szl_timing timing{};
     uint64_t last_nranges = 0, last_in_total = 0, last_blk_slots = 0;
     DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
-        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out;
+        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap;
     hipEvent_t ev[8];
 };
 

@@ -18,7 +18,14 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
 void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, hipStream_t st);
 void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
-                LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st);
+                LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
+                uint64_t *bad_range, hipStream_t st);
+void launch_resolve(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+                    RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st);
+int exitmap_width();
+void launch_exitmaps(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+                     RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint64_t *bad_range, uint64_t nbad,
+                     uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st);
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st);
 void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts, hipStream_t st);
 void launch_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
@@ -70,7 +77,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 }
@@ -130,6 +137,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if ((rc = visited.ensure((vis_words + 4) * 4))) return rc;
     if ((rc = ranges.ensure((nranges + 1) * sizeof(RangeDev)))) return rc;
     if ((rc = counts.ensure((nranges + 2) * 4))) return rc;
+    if ((rc = bad_slot.ensure((nranges + 2) * 4))) return rc;
+    if ((rc = bad_range.ensure((nranges + 2) * 8))) return rc;
     if ((rc = range_tok.ensure((nranges + 2) * 8))) return rc;
     if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc)))) return rc;
     if ((rc = d_so.ensure(nseg * sizeof(SegOut)))) return rc;
@@ -171,7 +180,22 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
     launch_spec(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
-    launch_fix(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
+    launch_fix(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt,
+               (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
+    {   // how many ranges never merged?  (one 8-byte read-back; the common answer is 0)
+        unsigned long long nbad = 0;
+        HIPCHK(hipMemcpyAsync(&nbad, counters.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nbad > 0 && nbad <= 48) {
+            launch_resolve(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
+        } else if (nbad > 48) {
+            const size_t W = (size_t)exitmap_width();
+            if ((rc = exmap.ensure(nbad * W * 2 + 64))) return rc;
+            if ((rc = cnmap.ensure(nbad * W * 2 + 64))) return rc;
+            launch_exitmaps(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p,
+                            (const uint32_t *)bad_slot.p, (const uint64_t *)bad_range.p, nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st);
+        }
+    }
     launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
     launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);

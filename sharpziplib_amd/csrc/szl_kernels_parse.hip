@@ -195,12 +195,14 @@ __device__ void fixup_range(const ParseCtx &c, const uint32_t *vis, int64_t seg_
 // C2: assume the predecessor's true exit is its speculative exit.
 __global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
                                              uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
-                                             const uint32_t *visited, unsigned long long *counters) {
+                                             const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
+                                             uint64_t *bad_range) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nranges) return;
     uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
     uint64_t lr = r - s.range_off;
+    bad_slot[r] = 0xFFFFFFFFu;
     if (lr == 0) return; // first range of a segment: entry = range start, speculative parse is the true one
     ParseCtx c = make_ctx(in, link, mtab, s, P);
     int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
@@ -214,7 +216,11 @@ __global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *
     ranges[r].merged = merged;
     ranges[r].exit_true = ex;
     ranges[r].true_count = count;
-    if (!merged) atomicAdd(counters + 0, 1ull);
+    if (!merged) { // remember it: if there are many, their entry->exit maps are built instead of chaining walks
+        unsigned long long slot = atomicAdd(counters + 0, 1ull);
+        bad_slot[r] = (uint32_t)slot;
+        bad_range[slot] = r;
+    }
 }
 
 // C3: one wavefront per segment chains the ranges whose assumed entry was wrong (sequential; rare).
@@ -251,6 +257,109 @@ __global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// ---- Ranges that never merge (all-zero / period-258 data lock the two parses into different phases).
+// For each such range the map "entry position -> (exit position, tokens)" is computed for every possible entry in
+// parallel (a true entry lies < 513 positions past the range start: a node is at most 255 lazy literals + a 258 match),
+// then the ranges are chained by table lookups instead of by re-walking them one after the other.
+enum : int { X_W = 576 }; // entries per map (multiple of 64, > 513)
+
+__global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+                                                uint32_t nseg, LevelParams P, const uint64_t *bad_range, uint64_t nbad,
+                                                uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters) {
+    const uint64_t slot = blockIdx.x / (X_W / 64);
+    const int j = (int)(blockIdx.x % (X_W / 64)) * 64 + (int)threadIdx.x;
+    if (slot >= nbad) return;
+    const uint64_t r = bad_range[slot];
+    const uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    const uint64_t lr = r - s.range_off;
+    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    int64_t x = rs + j, tp;
+    uint32_t count = 0;
+    if (x < s.seg_end) {
+        int L = 0, D = 0;
+        for (;;) {
+            if (L == 0 && x >= re) break;
+            uint32_t t = parse_step(c, x, L, D, &tp, false, counters + 1);
+            count += (t != 0xFFFFFFFFu);
+        }
+    }
+    int64_t off = x - re;
+    if (off < 0) off = 0;            // entry beyond the segment end: nothing to do
+    exmap[slot * X_W + j] = (uint16_t)(off > 65535 ? 65535 : off);
+    cnmap[slot * X_W + j] = (uint16_t)(count > 65535 ? 65535 : count);
+}
+
+enum : int { CH_RANGES = 32 };
+__global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+                                              uint32_t nseg, LevelParams P, RangeDev *ranges, const uint32_t *visited,
+                                              const uint32_t *bad_slot, const uint16_t *exmap, const uint16_t *cnmap,
+                                              unsigned long long *counters) {
+    __shared__ uint16_t s_ex[CH_RANGES][X_W];
+    __shared__ int64_t s_entry[CH_RANGES], s_exit[CH_RANGES];
+    __shared__ uint32_t s_slot[CH_RANGES], s_chg[CH_RANGES], s_cnt[CH_RANGES], s_mrg[CH_RANGES];
+    const uint32_t si = blockIdx.x;
+    if (si >= nseg) return;
+    const SegDev s = segs[si];
+    if (s.range_cnt < 2) return;
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    const int lane = threadIdx.x;
+    RangeDev *R = ranges + s.range_off;
+    const uint32_t *slots = bad_slot + s.range_off;
+    int64_t prev_exit = R[0].exit_true;
+    for (uint32_t k0 = 1; k0 < s.range_cnt; k0 += CH_RANGES) {
+        const uint32_t nk = s.range_cnt - k0 < CH_RANGES ? s.range_cnt - k0 : CH_RANGES;
+        if ((uint32_t)lane < nk) {
+            s_entry[lane] = R[k0 + lane].entry; s_exit[lane] = R[k0 + lane].exit_true;
+            s_slot[lane] = slots[k0 + lane]; s_chg[lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t i = 0; i < nk; i++) { // stage the exit maps of the flagged ranges of this chunk (coalesced)
+            const uint32_t sl = s_slot[i];
+            if (sl == 0xFFFFFFFFu) continue;
+            const uint4 *src = (const uint4 *)(exmap + (uint64_t)sl * X_W);
+            uint4 *dst = (uint4 *)&s_ex[i][0];
+            for (int q = lane; q < X_W * 2 / 16; q += 64) dst[q] = src[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane == 0) {
+            for (uint32_t i = 0; i < nk; i++) {
+                const uint32_t k = k0 + i;
+                const int64_t rs = s.seg_start + (int64_t)k * C_RANGE;
+                const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+                const int64_t e = prev_exit;
+                if (e == s_entry[i]) { prev_exit = s_exit[i]; continue; }           // the assumption of k_fix holds
+                s_entry[i] = e;
+                const int64_t j = e - rs;
+                if (s_slot[i] != 0xFFFFFFFFu && j >= 0 && j < X_W && s_ex[i][j] != 65535) {
+                    prev_exit = (e >= re ? e : re + s_ex[i][j]);
+                    s_exit[i] = prev_exit; s_chg[i] = 1;
+                } else { // unexpected entry into a range without a map: walk it (rare)
+                    uint32_t merged, count; int64_t ex;
+                    fixup_range(c, visited + s.vis_word_off, s.seg_start, rs, re, e, R[k].spec_count, R[k].exit_spec, &merged, &ex, &count, counters + 1);
+                    prev_exit = ex; s_exit[i] = ex; s_cnt[i] = count; s_mrg[i] = merged; s_chg[i] = 2;
+                }
+            }
+        }
+        prev_exit = ((int64_t)__builtin_amdgcn_readfirstlane((int)(prev_exit >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)prev_exit);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if ((uint32_t)lane < nk && s_chg[lane]) {
+            const uint32_t k = k0 + lane;
+            const int64_t rs = s.seg_start + (int64_t)k * C_RANGE;
+            uint32_t cnt = s_cnt[lane], mrg = s_mrg[lane];
+            if (s_chg[lane] == 1) {
+                const int64_t j = s_entry[lane] - rs;
+                cnt = s_entry[lane] >= (rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end) ? 0u : cnmap[(uint64_t)s_slot[lane] * X_W + j];
+                mrg = 0;
+            }
+            R[k].entry = s_entry[lane]; R[k].exit_true = s_exit[lane]; R[k].true_count = cnt; R[k].merged = mrg;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
 }
 
@@ -317,11 +426,25 @@ void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, con
                        ranges, visited, counters);
 }
 void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
-                LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st) {
+                LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
+                uint64_t *bad_range, hipStream_t st) {
     if (nranges == 0) return;
     hipLaunchKernelGGL(k_fix, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
-                       ranges, visited, counters);
+                       ranges, visited, counters, bad_slot, bad_range);
+}
+void launch_resolve(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+                    RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, dim3(nseg), dim3(64), 0, st, in, link, mtab, segs, nseg, P, ranges, visited, counters);
+}
+int exitmap_width() { return X_W; }
+void launch_exitmaps(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+                     RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint64_t *bad_range, uint64_t nbad,
+                     uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st) {
+    if (nbad == 0) return;
+    hipLaunchKernelGGL(k_exitmap, dim3((unsigned)(nbad * (X_W / 64))), dim3(64), 0, st, in, link, mtab, segs, nseg, P, bad_range, nbad,
+                       exmap, cnmap, counters);
+    hipLaunchKernelGGL(k_chain, dim3(nseg), dim3(64), 0, st, in, link, mtab, segs, nseg, P, ranges, visited, bad_slot, exmap, cnmap,
+                       counters);
 }
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st) {
     if (nranges == 0) return;

@@ -326,3 +326,18 @@ def test_gzip_members_on_device(eng):
         assert gzip.decompress(r.data) == d.tobytes()
     # concatenated members form a multi-member .gz (what GZipInputStream reads, S/GZip/GzipInputStream.cs:109-153)
     assert gzip.decompress(b"".join(r.data for r in res)) == b"".join(d.tobytes() for d in datas)
+
+
+def test_never_merging_ranges_use_exit_maps(eng):
+    """All-zero / periodic stretches never re-synchronise: > 48 such ranges take the exit-map path
+    (k_exitmap + k_chain); mixtures exercise the hand-over between mapped and ordinary ranges."""
+    parts = [C.generate("dickens", 5, 0, 300000), C.zeros(600000), C.generate("enwik", 6, 0, 200001), C.period10(500003),
+             C.random_bytes(100000, seed=9), C.zeros(300017), C.generate("logs", 7, 0, 250000),
+             np.resize(np.frombuffer(bytes(range(256)) + b"xyz", np.uint8), 400000), C.four_symbol(150000)]
+    data = np.concatenate(parts)
+    for lv in (6, 9):
+        r = eng.deflate([data], level=lv)[0]
+        assert eng.timing()["ranges_unmerged"] > 48
+        assert r.data == O.deflate(data, lv)
+    for z in (C.zeros(2_000_000), C.period10(1_500_000)):
+        assert eng.deflate([z], level=6)[0].data == O.deflate(z, 6)
