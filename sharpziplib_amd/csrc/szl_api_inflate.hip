@@ -78,11 +78,15 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     auto cleanup = [&]() { djobs.release(); dstates.release(); };
     if (hipMemcpyAsync(djobs.p, jobs.data(), n * sizeof(InfJob), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(dstates.p, states.data(), n * sizeof(InfState), hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); set_error("H2D failed"); return SZL_E_DEVICE; }
+    for (int i = 0; i < 2; i++) if (!e->e.ev[i]) (void)hipEventCreate(&e->e.ev[i]);
+    (void)hipEventRecord(e->e.ev[0], st);
     launch_inflate((const uint8_t *)d_in, (uint8_t *)d_out, (InfJob *)djobs.p, (InfState *)dstates.p, (uint32_t)n, st);
+    (void)hipEventRecord(e->e.ev[1], st);
     if (hipMemcpyAsync(jobs.data(), djobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(states.data(), dstates.p, n * sizeof(InfState), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { cleanup(); set_error("inflate kernel/D2H failed: %s", hipGetErrorString(hipGetLastError())); return SZL_E_DEVICE; }
     cleanup();
+    (void)hipEventElapsedTime(&e->e.timing.inflate_ms, e->e.ev[0], e->e.ev[1]);
     unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !nowrap) ? 2u : 0u);
     std::vector<std::pair<uint32_t, uint32_t>> cks;
     if (want) {

@@ -17,7 +17,7 @@
 
 namespace szl {
 
-enum : int { I_WIN = 32768, I_WMASK = I_WIN - 1, I_STAGE = 1024, I_LPB = 10, I_DPB = 9 };
+enum : int { I_WIN = 32768, I_WMASK = I_WIN - 1, I_STAGE = 1024, I_LPB = 10, I_DPB = 9, MAX_MATCH_I = 258 };
 
 __constant__ uint16_t c_cplens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_cplext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -40,6 +40,7 @@ struct InfLds {
     HuffTab lt, dt;
     uint8_t lens[320];
     uint16_t codes[320];
+    uint32_t queue[64];
 };
 
 // Build decode tables from code lengths lens[0..n) (all lanes). pb = primary bits.
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     // ---- load persistent state (wave-uniform scalars via lane 0 reads + broadcast is unnecessary: all lanes read)
     uint64_t bitpos = st->bitpos, outpos = st->outpos;
     uint32_t mode = st->mode, lastblk = st->last, stored_left = st->stored_left, btype = st->btype;
-    uint32_t lnum = st->lnum, dnum = st->dnum, pend_len = st->pend_len, pend_dist = st->pend_dist;
+    uint32_t lnum = st->lnum, dnum = st->dnum;
+    const uint32_t pend_len = 0, pend_dist = 0; // a token that does not fit is simply not consumed
     const uint64_t out_start = outpos;             // stream position of out[0] for this call
     const uint64_t out_limit = outpos + job.out_cap;
     uint64_t flushed = outpos;
@@ -182,176 +184,106 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
         }
     };
 
-    enum { EV_NONE = 0, EV_MATCH, EV_RESTAGE, EV_FLUSH, EV_TABLES, EV_STORED, EV_STOP };
-    // Decode state (bit buffer, block mode, table sizes) is private to lane 0; only what the data movers need is
-    // broadcast per event: the event code, two operands and the output position.
+    enum { EV_NONE = 0, EV_RESTAGE, EV_TABLES, EV_STORED, EV_STOP };
+    enum { QN = 64 };
+    // Decode state (bit buffer, block mode, table sizes) is private to lane 0.  Each round lane 0 decodes up to 64
+    // tokens into an LDS queue; then the whole wavefront applies them (prefix sum of lengths, literals in parallel,
+    // matches in order with all lanes copying), flushes the window when half full, and services lane 0's request.
     while (status == INF_RUNNING) {
-        int ev = EV_NONE, ea = 0, eb = 0;
-        // pending match tail from a previous OUTPUT_FULL stop
-        if (pend_len) {
-            if (outpos + pend_len > out_limit) { status = INF_OUTPUT_FULL; break; }
-            ev = EV_MATCH; ea = (int)pend_len; eb = (int)pend_dist; pend_len = 0;
-        } else if (lane == 0) {
-            // ---------------- lane 0: run the bit-serial state machine until something needs the whole wavefront
+        int ev = EV_NONE, ea = 0, eb = 0, ntok = 0;
+        if (lane == 0) {
+            uint64_t opos = outpos;                       // position after the queued tokens
+            const uint64_t room_lim = flushed + (I_WIN - 300);
+            // ---- fast round: when the staged input, the remaining input, the output limit and the window room all
+            // cover the worst case of a full queue (64 tokens x 48 bits, 64 x 258 bytes), tokens are decoded with no
+            // per-token limit checks; anything unusual (long codes, end of block, errors) falls through to the careful loop.
+            if (mode == INF_M_HUFF && sbase != ~0ull) {
+                const uint64_t bytepos0 = (bitpos + nb) >> 3;
+                if (bytepos0 + QN * 6 + 16 > sbase + I_STAGE && bytepos0 >= sbase + 256 && bytepos0 + QN * 6 + 16 <= job.in_len) {
+                    // the staged window is nearly used up: slide it now (cheap, cooperative) instead of crawling through the careful loop
+                    ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32);
+                }
+                const uint64_t availb = in_bits > bitpos ? in_bits - bitpos : 0;
+                const uint64_t olim = out_limit < room_lim ? out_limit : room_lim;
+                if (ev == EV_NONE && bytepos0 >= sbase && bytepos0 + QN * 6 + 16 <= sbase + I_STAGE && availb >= (uint64_t)(QN * 48 + 64) &&
+                    opos + (uint64_t)QN * MAX_MATCH_I <= olim) {
+                    uint32_t so = (uint32_t)(bytepos0 - sbase); // stage offset of the next unread byte
+                    uint32_t used = 0;                          // bits consumed in this round
+                    uint32_t olen = 0;
+                    while (ntok < QN) {
+                        if (nb <= 32) { // one 32-bit refill
+                            uint32_t w0 = S.stage[so >> 2], w1 = S.stage[(so >> 2) + 1];
+                            bb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, so & 3) << nb;
+                            nb += 32; so += 4;
+                        }
+                        const uint32_t e = S.llut[(uint32_t)bb & ((1u << I_LPB) - 1)];
+                        if (e - 1 >= 0xFFFDu) break;                  // invalid (0) or long code (0xFFFE): careful loop
+                        const uint32_t sl = e & 15, sym = e >> 4;
+                        if (sym < 256) {
+                            bb >>= sl; nb -= (int)sl; used += sl;
+                            S.queue[ntok++] = sym; olen++;
+                            continue;
+                        }
+                        if (sym == 256 || sym > 285) break;           // end of block / illegal: careful loop
+                        const uint32_t ls = sym - 257;
+                        const uint32_t xl = (ls < 8 || ls == 28) ? 0u : ((ls - 4) >> 2);
+                        const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << xl));
+                        uint64_t tb = bb >> sl;
+                        int tn = nb - (int)sl;
+                        const uint32_t len = lbase + ((uint32_t)tb & ((1u << xl) - 1));
+                        tb >>= xl; tn -= (int)xl;
+                        uint32_t so2 = so;
+                        if (tn < 28) {
+                            uint32_t w0 = S.stage[so2 >> 2], w1 = S.stage[(so2 >> 2) + 1];
+                            tb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, so2 & 3) << tn;
+                            tn += 32; so2 += 4;
+                        }
+                        const uint32_t de = S.dlut[(uint32_t)tb & ((1u << I_DPB) - 1)];
+                        if (de - 1 >= 0xFFFDu) break;
+                        const uint32_t dl = de & 15, dsym = de >> 4;
+                        if (dsym >= 30) break;
+                        tb >>= dl; tn -= (int)dl;
+                        const uint32_t xd = dsym < 4 ? 0u : ((dsym >> 1) - 1);
+                        const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << xd);
+                        const uint32_t dist = dbase + ((uint32_t)tb & ((1u << xd) - 1));
+                        tb >>= xd; tn -= (int)xd;
+                        used += sl + xl + dl + xd;
+                        bb = tb; nb = tn; so = so2;
+                        S.queue[ntok++] = len | (dist << 16); olen += len;
+                    }
+                    bitpos += used;
+                    opos += olen;
+                }
+            }
             for (;;) {
+                if (ntok == QN || ev != EV_NONE) break;
                 const uint64_t bytepos = (bitpos + nb) >> 3;
                 if (!stage_ok(bytepos)) { ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break; }
                 refill();
-                if (outpos - flushed >= 16384) { ev = EV_FLUSH; break; }
-                uint64_t avail = in_bits > bitpos ? in_bits - bitpos : 0; // valid bits from bitpos on
-                if (mode == INF_M_HUFF && avail >= 64) {
-                    // ---- fast path: literals (code length <= 10 bits) straight from the primary table into the window
-                    const uint64_t lim_out = out_limit < flushed + 16384 ? out_limit : flushed + 16384;
-                    for (;;) {
-                        const uint32_t e = S.llut[(uint32_t)bb & ((1u << I_LPB) - 1)];
-                        if (e - 1 >= (256u << 4) - 1 || outpos >= lim_out || nb < 16) break; // not a short literal / no room / refill
-                        const uint32_t sl = e & 15;
-                        S.win[outpos & I_WMASK] = (uint8_t)(e >> 4);
-                        outpos++;
+                const uint64_t avail = in_bits > bitpos ? in_bits - bitpos : 0; // valid bits from bitpos on
+                if (mode == INF_M_HUFF) {
+                    if (opos + MAX_MATCH_I > room_lim) break;              // apply + flush first
+                    int r = decode_sym(&S.lt, S.llut, I_LPB, (uint32_t)bb);
+                    if (r < 0) { ev = EV_STOP; ea = avail < 15 ? INF_NEED_INPUT : SZL_E_CODELEN_ZERO; break; }
+                    const uint32_t sl = (uint32_t)r >> 16, sym = (uint32_t)r & 0xFFFF;
+                    if (avail < sl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    if (sym < 256) {
+                        if (opos + 1 > out_limit) { ev = EV_STOP; ea = INF_OUTPUT_FULL; break; }
                         bb >>= sl; nb -= (int)sl; bitpos += sl;
-                    }
-                    if (nb < 33) continue; // refill (and re-check staging / flush) before a token that may need 48 bits
-                    avail = in_bits > bitpos ? in_bits - bitpos : 0;
-                }
-                if (mode == INF_M_HEADER) {
-                    if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
-                    if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                    uint32_t t = (uint32_t)bb & 7;
-                    uint32_t type = t >> 1;
-                    if (type == 3) { ev = EV_STOP; ea = SZL_E_UNKNOWN_BLOCK; break; }
-                    if (type == 0) {
-                        uint32_t skip = 3 + (uint32_t)((0 - (bitpos + 3)) & 7);
-                        if (avail < skip + 32) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                        bb >>= skip; nb -= skip; bitpos += skip;
-                        refill();
-                        uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
-                        if (nlen != (len ^ 0xFFFF)) { ev = EV_STOP; ea = SZL_E_BROKEN_STORED; break; } // :509-512
-                        bb >>= 32; nb -= 32; bitpos += 32;
-                        lastblk |= t & 1;
-                        stored_left = len; mode = INF_M_STORED;
+                        S.queue[ntok++] = sym; opos++;
                         continue;
                     }
-                    if (type == 1) {
-                        bb >>= 3; nb -= 3; bitpos += 3;
-                        lastblk |= t & 1; btype = 1; mode = INF_M_HUFF;
-                        ev = EV_TABLES; ea = 1; break;
-                    }
-                    // dynamic: parse the whole header here; if input runs out, nothing is consumed (restart at the block header)
-                    {
-                        uint64_t hb = bb; int hn = nb; uint64_t hp = bitpos; // local cursor
-                        auto need = [&](int k) -> bool { // ensure k bits in hb; false = out of staged window
-                            while (hn < k) {
-                                uint64_t bp = (hp + hn) >> 3;
-                                if (!(bp >= sbase && bp + 8 <= sbase + I_STAGE)) return false;
-                                uint32_t o = (uint32_t)(bp - sbase);
-                                uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
-                                hb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, o & 3) << hn;
-                                hn += 32;
-                            }
-                            return true;
-                        };
-                        auto take = [&](int k) -> uint32_t { uint32_t v = (uint32_t)hb & ((1u << k) - 1); hb >>= k; hn -= k; hp += k; return v; };
-                        int fail = 0; // 1 need input, 2 need restage, <0 error
-                        auto want = [&](int k) -> bool {
-                            if ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) { fail = 1; return false; }
-                            if (!need(k)) { fail = 2; return false; }
-                            return true;
-                        };
-                        uint32_t nl = 0, nd = 0, nm = 0;
-                        do {
-                            if (!want(17)) break;
-                            take(3);
-                            nl = take(5) + 257; nd = take(5) + 1; nm = take(4) + 4;
-                            if (nl > 286 || nd > 30) { fail = SZL_E_DYN_HEADER; break; } // :50-52
-                            uint8_t ml[19];
-                            for (int i = 0; i < 19; i++) ml[i] = 0;
-                            for (uint32_t i = 0; i < nm; i++) { if (!want(3)) break; ml[c_meta_order[i]] = (uint8_t)take(3); }
-                            if (fail) break;
-                            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nxt[8];
-                            for (int i = 0; i < 19; i++) cnt[ml[i]]++;
-                            cnt[0] = 0;
-                            int code = 0;
-                            for (int l = 1; l < 8; l++) { nxt[l] = code; code = (code + cnt[l]) << 1; }
-                            uint16_t *mlut = S.codes; // 128 entries
-                            for (int i = 0; i < 128; i++) mlut[i] = 0;
-                            for (int i = 0; i < 19; i++) {
-                                int l = ml[i];
-                                if (!l) continue;
-                                uint32_t rev = (__builtin_bitreverse32((uint32_t)nxt[l]++) >> (32 - l)) & ((1u << l) - 1);
-                                for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint16_t)((i << 4) | l);
-                            }
-                            uint32_t idx = 0, total = nl + nd;
-                            while (idx < total) {
-                                const uint64_t rem = in_bits > hp ? in_bits - hp : 0;
-                                if (!need((int)(rem < 14 ? rem : 14))) { fail = 2; break; } // code (<=7) + extra bits (<=7)
-                                uint32_t e = mlut[(uint32_t)hb & 127];
-                                if (e == 0) { fail = rem < 7 ? 1 : SZL_E_CODELEN_ZERO; break; } // C/InflaterHuffmanTree.cs:191-193
-                                const uint32_t sl = e & 15, sym = e >> 4;
-                                const uint32_t xb = sym < 16 ? 0 : (sym == 16 ? 2 : (sym == 17 ? 3 : 7));
-                                if (rem < sl + xb) { fail = 1; break; }
-                                take((int)sl);
-                                if (sym < 16) { S.lens[idx++] = (uint8_t)sym; continue; }
-                                uint32_t rep, val = 0;
-                                if (sym == 16) {
-                                    if (idx == 0) { fail = SZL_E_DYN_HEADER; break; } // :83
-                                    val = S.lens[idx - 1]; rep = 3 + take(2);
-                                } else if (sym == 17) rep = 3 + take(3);
-                                else rep = 11 + take(7);
-                                if (idx + rep > total) { fail = SZL_E_DYN_HEADER; break; } // :106
-                                while (rep--) S.lens[idx++] = (uint8_t)val;
-                            }
-                            if (fail) break;
-                            if (S.lens[256] == 0) { fail = SZL_E_DYN_HEADER; break; } // :113
-                        } while (0);
-                        if (fail == 1) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                        if (fail == 2) { // header straddles the staged window: restage at the block header and retry
-                            if (((bitpos >> 3) & ~3ull) == sbase) { ev = EV_STOP; ea = SZL_E_DYN_HEADER; break; } // cannot happen: a header is < 1 KiB
-                            ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break;
-                        }
-                        if (fail < 0) { ev = EV_STOP; ea = fail; break; }
-                        bb = hb; nb = hn; bitpos = hp;
-                        lastblk |= t & 1; btype = 2; lnum = nl; dnum = nd; mode = INF_M_HUFF;
-                        ev = EV_TABLES; ea = 2 | (int)(nl << 8) | (int)(nd << 20); break;
-                    }
-                }
-                if (mode == INF_M_STORED) {
-                    if (stored_left == 0) { mode = INF_M_HEADER; continue; }
-                    // byte aligned here (SkipToByteBoundary :490): copy bytes input -> window with the whole wavefront
-                    const uint64_t bp = bitpos >> 3;
-                    uint64_t can_in = job.in_len > bp ? job.in_len - bp : 0;
-                    uint64_t can_out = out_limit - outpos;
-                    uint64_t room = (uint64_t)(I_WIN - 512) - (outpos - flushed);
-                    uint64_t n = stored_left;
-                    if (n > can_in) n = can_in;
-                    if (n > can_out) n = can_out;
-                    if (n == 0) { ev = EV_STOP; ea = can_in == 0 ? INF_NEED_INPUT : INF_OUTPUT_FULL; break; }
-                    if (n > room) { if (room < 4096) { ev = EV_FLUSH; break; } n = room; }
-                    if (n > 0x7FFFFFFF) n = 0x7FFFFFFF;
-                    ev = EV_STORED; ea = (int)n; eb = 0;
-                    // lane 0 advances its own cursor; the copy itself reads in[] directly (no bit buffer)
-                    stored_left -= (uint32_t)n;
-                    break;
-                }
-                // ---------------- INF_M_HUFF general path: one token
-                int r = decode_sym(&S.lt, S.llut, I_LPB, (uint32_t)bb);
-                if (r < 0) { ev = EV_STOP; ea = avail < 15 ? INF_NEED_INPUT : SZL_E_CODELEN_ZERO; break; }
-                uint32_t sl = (uint32_t)r >> 16, sym = (uint32_t)r & 0xFFFF;
-                if (avail < sl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                if (sym < 256) {
-                    if (outpos + 1 > out_limit) { ev = EV_STOP; ea = INF_OUTPUT_FULL; break; }
-                    bb >>= sl; nb -= sl; bitpos += sl;
-                    S.win[outpos & I_WMASK] = (uint8_t)sym;
-                    outpos++;
-                    continue;
-                }
-                if (sym == 256) { bb >>= sl; nb -= sl; bitpos += sl; mode = INF_M_HEADER; continue; }
-                if (sym - 257 >= 29) { ev = EV_STOP; ea = SZL_E_ILLEGAL_LEN_CODE; break; } // :323-326
-                {
+                    if (sym == 256) { bb >>= sl; nb -= (int)sl; bitpos += sl; mode = INF_M_HEADER; continue; }
+                    if (sym - 257 >= 29) { ev = EV_STOP; ea = SZL_E_ILLEGAL_LEN_CODE; break; } // :323-326
                     uint64_t tb = bb; int tn = nb; uint64_t used = sl;
-                    tb >>= sl; tn -= sl;
-                    uint32_t xl = c_cplext[sym - 257];
-                    uint32_t len = c_cplens[sym - 257] + ((uint32_t)tb & ((1u << xl) - 1));
-                    tb >>= xl; tn -= xl; used += xl;
+                    tb >>= sl; tn -= (int)sl;
+                    // CPLENS/CPLEXT (C/Inflater.cs:39-48) in closed form: constant-memory tables indexed per lane are a
+                    // vector load from HBM on this hardware (≈1 µs each) — arithmetic keeps the token loop in registers/LDS
+                    const uint32_t ls = sym - 257;
+                    const uint32_t xl = (ls < 8 || ls == 28) ? 0u : ((ls - 4) >> 2);
+                    const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << xl));
+                    const uint32_t len = lbase + ((uint32_t)tb & ((1u << xl) - 1));
+                    tb >>= xl; tn -= (int)xl; used += xl;
                     if (tn < 28) { // top up (the staged window always has >= 8 readable bytes past bytepos)
                         uint32_t o = (uint32_t)(((bitpos + used + tn) >> 3) - sbase);
                         uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
@@ -360,39 +292,177 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                     }
                     int rd = decode_sym(&S.dt, S.dlut, I_DPB, (uint32_t)tb);
                     if (rd < 0) { ev = EV_STOP; ea = avail < used + 15 ? INF_NEED_INPUT : SZL_E_CODELEN_ZERO; break; }
-                    uint32_t dl = (uint32_t)rd >> 16, dsym = (uint32_t)rd & 0xFFFF;
+                    const uint32_t dl = (uint32_t)rd >> 16, dsym = (uint32_t)rd & 0xFFFF;
                     if (dsym >= 30) { ev = EV_STOP; ea = avail < used + dl ? INF_NEED_INPUT : SZL_E_ILLEGAL_DIST_CODE; break; } // :356-359
-                    tb >>= dl; tn -= dl; used += dl;
-                    uint32_t xd = c_cpdext[dsym];
-                    uint32_t dist = c_cpdist[dsym] + ((uint32_t)tb & ((1u << xd) - 1));
-                    tb >>= xd; tn -= xd; used += xd;
+                    tb >>= dl; tn -= (int)dl; used += dl;
+                    const uint32_t xd = dsym < 4 ? 0u : ((dsym >> 1) - 1);                        // CPDIST/CPDEXT :50-68
+                    const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << xd);
+                    const uint32_t dist = dbase + ((uint32_t)tb & ((1u << xd) - 1));
+                    tb >>= xd; tn -= (int)xd; used += xd;
                     if (avail < used) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    if (opos + len > out_limit) { ev = EV_STOP; ea = INF_OUTPUT_FULL; break; } // not consumed: decoded again next call
                     bb = tb; nb = tn; bitpos += used;
-                    ev = EV_MATCH; ea = (int)len; eb = (int)dist;
+                    S.queue[ntok++] = len | (dist << 16); opos += len;
+                    continue;
+                }
+                if (mode == INF_M_STORED) {
+                    if (stored_left == 0) { mode = INF_M_HEADER; continue; }
+                    if (ntok) break; // apply what is queued first
+                    // byte aligned here (SkipToByteBoundary :490): copy bytes input -> window with the whole wavefront
+                    const uint64_t bp = bitpos >> 3;
+                    const uint64_t can_in = job.in_len > bp ? job.in_len - bp : 0;
+                    const uint64_t can_out = out_limit - outpos;
+                    const uint64_t room = (uint64_t)(I_WIN - 512) - (outpos - flushed);
+                    uint64_t n = stored_left;
+                    if (n > can_in) n = can_in;
+                    if (n > can_out) n = can_out;
+                    if (n == 0) { ev = EV_STOP; ea = can_in == 0 ? INF_NEED_INPUT : INF_OUTPUT_FULL; break; }
+                    if (n > room) n = room;    // room >= 16 KiB - 512: the window is flushed whenever it is half full
+                    ev = EV_STORED; ea = (int)n; eb = 0;
+                    stored_left -= (uint32_t)n;
                     break;
+                }
+                // ---------------- INF_M_HEADER
+                if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
+                if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                const uint32_t t = (uint32_t)bb & 7;
+                const uint32_t type = t >> 1;
+                if (type == 3) { ev = EV_STOP; ea = SZL_E_UNKNOWN_BLOCK; break; }
+                if (type == 0) {
+                    const uint32_t skip = 3 + (uint32_t)((0 - (bitpos + 3)) & 7);
+                    if (avail < skip + 32) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    bb >>= skip; nb -= (int)skip; bitpos += skip;
+                    refill();
+                    const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
+                    if (nlen != (len ^ 0xFFFF)) { ev = EV_STOP; ea = SZL_E_BROKEN_STORED; break; } // :509-512
+                    bb >>= 32; nb -= 32; bitpos += 32;
+                    lastblk |= t & 1;
+                    stored_left = len; mode = INF_M_STORED;
+                    continue;
+                }
+                if (type == 1) {
+                    bb >>= 3; nb -= 3; bitpos += 3;
+                    lastblk |= t & 1; btype = 1; mode = INF_M_HUFF;
+                    ev = EV_TABLES; ea = 1; break;
+                }
+                // dynamic: parse the whole header here; if input runs out, nothing is consumed (restart at the block header)
+                {
+                    uint64_t hb = bb; int hn = nb; uint64_t hp = bitpos; // local cursor
+                    auto need = [&](int k) -> bool { // ensure k bits in hb; false = out of staged window
+                        while (hn < k) {
+                            uint64_t bp = (hp + hn) >> 3;
+                            if (!(bp >= sbase && bp + 8 <= sbase + I_STAGE)) return false;
+                            uint32_t o = (uint32_t)(bp - sbase);
+                            uint32_t w0 = S.stage[o >> 2], w1 = S.stage[(o >> 2) + 1];
+                            hb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, o & 3) << hn;
+                            hn += 32;
+                        }
+                        return true;
+                    };
+                    auto take = [&](int k) -> uint32_t { uint32_t v = (uint32_t)hb & ((1u << k) - 1); hb >>= k; hn -= k; hp += k; return v; };
+                    int fail = 0; // 1 need input, 2 need restage, <0 error
+                    auto want = [&](int k) -> bool {
+                        if ((in_bits > hp ? in_bits - hp : 0) < (uint64_t)k) { fail = 1; return false; }
+                        if (!need(k)) { fail = 2; return false; }
+                        return true;
+                    };
+                    uint32_t nl = 0, nd = 0, nm = 0;
+                    do {
+                        if (!want(17)) break;
+                        take(3);
+                        nl = take(5) + 257; nd = take(5) + 1; nm = take(4) + 4;
+                        if (nl > 286 || nd > 30) { fail = SZL_E_DYN_HEADER; break; } // :50-52
+                        // code lengths of the code-length alphabet, kept in LDS (S.codes[128..147]) to stay out of scratch
+                        uint16_t *ml = S.codes + 128;
+                        for (int i = 0; i < 19; i++) ml[i] = 0;
+                        for (uint32_t i = 0; i < nm; i++) { if (!want(3)) break; ml[c_meta_order[i]] = (uint16_t)take(3); }
+                        if (fail) break;
+                        uint16_t *mlut = S.codes; // 128 entries
+                        for (int i = 0; i < 128; i++) mlut[i] = 0;
+                        int code = 0;
+                        for (int l = 1; l < 8; l++) { // canonical codes, length by length, symbols in order
+                            for (int i = 0; i < 19; i++) {
+                                if (ml[i] != l) continue;
+                                uint32_t rev = (__builtin_bitreverse32((uint32_t)code++) >> (32 - l)) & ((1u << l) - 1);
+                                for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint16_t)((i << 4) | l);
+                            }
+                            code <<= 1;
+                        }
+                        uint32_t idx = 0, total = nl + nd;
+                        while (idx < total) {
+                            const uint64_t rem = in_bits > hp ? in_bits - hp : 0;
+                            if (!need((int)(rem < 14 ? rem : 14))) { fail = 2; break; } // code (<=7) + extra bits (<=7)
+                            uint32_t e = mlut[(uint32_t)hb & 127];
+                            if (e == 0) { fail = rem < 7 ? 1 : SZL_E_CODELEN_ZERO; break; } // C/InflaterHuffmanTree.cs:191-193
+                            const uint32_t sl = e & 15, sym = e >> 4;
+                            const uint32_t xb = sym < 16 ? 0 : (sym == 16 ? 2 : (sym == 17 ? 3 : 7));
+                            if (rem < sl + xb) { fail = 1; break; }
+                            take((int)sl);
+                            if (sym < 16) { S.lens[idx++] = (uint8_t)sym; continue; }
+                            uint32_t rep, val = 0;
+                            if (sym == 16) {
+                                if (idx == 0) { fail = SZL_E_DYN_HEADER; break; } // :83
+                                val = S.lens[idx - 1]; rep = 3 + take(2);
+                            } else if (sym == 17) rep = 3 + take(3);
+                            else rep = 11 + take(7);
+                            if (idx + rep > total) { fail = SZL_E_DYN_HEADER; break; } // :106
+                            while (rep--) S.lens[idx++] = (uint8_t)val;
+                        }
+                        if (fail) break;
+                        if (S.lens[256] == 0) { fail = SZL_E_DYN_HEADER; break; } // :113
+                    } while (0);
+                    if (fail == 1) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    if (fail == 2) { // header straddles the staged window: restage at the block header and retry
+                        if (((bitpos >> 3) & ~3ull) == sbase) { ev = EV_STOP; ea = SZL_E_DYN_HEADER; break; } // cannot happen: a header is < 1 KiB
+                        ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break;
+                    }
+                    if (fail < 0) { ev = EV_STOP; ea = fail; break; }
+                    bb = hb; nb = hn; bitpos = hp;
+                    lastblk |= t & 1; btype = 2; lnum = nl; dnum = nd; mode = INF_M_HUFF;
+                    ev = EV_TABLES; ea = 2 | (int)(nl << 8) | (int)(nd << 20); break;
                 }
             }
         }
-        // ---------------- the whole wavefront services the event
+        // ---------------- the whole wavefront: apply the queue
         ev = __builtin_amdgcn_readfirstlane(ev);
         ea = __builtin_amdgcn_readfirstlane(ea);
         eb = __builtin_amdgcn_readfirstlane(eb);
-        outpos = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(outpos >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)outpos);
+        ntok = __builtin_amdgcn_readfirstlane(ntok);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (ntok) {
+            const uint32_t tok = lane < ntok ? S.queue[lane] : 0;
+            const uint32_t dist = tok >> 16;
+            const uint32_t mylen = lane < ntok ? (dist ? (tok & 0xFFFF) : 1u) : 0u;
+            uint32_t incl = mylen;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            const uint64_t mypos = outpos + (incl - mylen);
+            // Tokens are applied in stream order: the window is circular, so a literal written early could overwrite
+            // history (32768 positions back) that an earlier far-distance match of the same round still has to read.
+            uint64_t mm = __ballot(lane < ntok && dist != 0);
+            int done_upto = 0; // lanes < done_upto have been applied
+            while (mm) { // matches in stream order; CS/OutputWindow.cs:63-92: out[p+k] = out[p-dist+(k mod dist)]
+                const int l = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                if (lane >= done_upto && lane < l && dist == 0) S.win[mypos & I_WMASK] = (uint8_t)tok; // literals before this match
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const uint32_t t2 = __builtin_amdgcn_readlane(tok, l);
+                const uint32_t off = __builtin_amdgcn_readlane(incl - mylen, l);
+                const uint32_t len = t2 & 0xFFFF, d2 = t2 >> 16;
+                const uint64_t p = outpos + off;
+                if (d2 >= len) { // no overlap (wave-uniform test): plain copy
+                    for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k) & I_WMASK];
+                } else {
+                    for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k % d2) & I_WMASK];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                done_upto = l + 1;
+            }
+            if (lane >= done_upto && lane < ntok && dist == 0) S.win[mypos & I_WMASK] = (uint8_t)tok; // trailing literals
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            outpos += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (outpos - flushed >= 16384) flush(outpos);
         switch (ev) {
-        case EV_MATCH: {
-            const uint32_t len = (uint32_t)ea, dist = (uint32_t)eb;
-            if (outpos + len > out_limit) { // keep the decoded match for the next call
-                pend_len = len; pend_dist = dist; status = INF_OUTPUT_FULL; break;
-            }
-            if (outpos - flushed + len > I_WIN - 512) flush(outpos);
-            // CS/OutputWindow.cs:63-92: overlap-safe repeat == out[p+k] = out[p-dist+(k mod dist)]
-            for (uint32_t k = lane; k < len; k += 64) {
-                uint32_t kk = dist >= len ? k : k % dist;
-                S.win[(outpos + k) & I_WMASK] = S.win[(outpos - dist + kk) & I_WMASK];
-            }
-            outpos += len;
-        } break;
         case EV_RESTAGE: {
             const uint64_t bp = ((uint64_t)(uint32_t)eb << 32) | (uint32_t)ea;
             restage(bp);
@@ -404,9 +474,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                 bb = (uint64_t)(x >> sh); nb = 32 - (int)sh;
             }
         } break;
-        case EV_FLUSH:
-            flush(outpos);
-            break;
         case EV_TABLES:
             btype = (uint32_t)ea & 3; lnum = ((uint32_t)ea >> 8) & 0xFFF; dnum = ((uint32_t)ea >> 20) & 0xFF;
             rebuild_tables();
