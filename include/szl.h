@@ -75,7 +75,9 @@ int szl_deflater_set_strategy(szl_deflater *d, int strategy);              /* Se
 int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n); /* SetDictionary    C/Deflater.cs:559 */
 /* SetInput(byte[],int,int) C/Deflater.cs:331.  The reference borrows the caller's array until
  * IsNeedingInput; this library COPIES the bytes into its staging buffer before returning, so the
- * caller may reuse the array immediately and IsNeedingInput is true again on return. */
+ * caller may reuse the array immediately.  As in the reference, IsNeedingInput is false until the next
+ * Deflate() call has "consumed" the input (it returns 0 before Flush/Finish), and a second SetInput before
+ * that fails with SZL_E_STATE ("Old input was not completely processed", C/DeflaterEngine.cs:163-166). */
 int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n);
 int szl_deflater_flush(szl_deflater *d);                                   /* Flush()          C/Deflater.cs:252 */
 int szl_deflater_finish(szl_deflater *d);                                  /* Finish()         C/Deflater.cs:262 */
@@ -141,6 +143,9 @@ int szl_engine_last_timing(const szl_engine *e, szl_timing *t);
  * last call's intermediates of stream 0 to host arrays (any pointer may be NULL). */
 int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t *mq, size_t n_positions,
                            uint32_t *tokens, size_t tok_cap, size_t *n_tokens);
+
+/* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
+int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);
 
 /* Parity tap: block table of the last call; rows of 8 x uint64:
  * type, last, ntok, bit_start, opt_len, static_len, in_len, hdr_bits. */

@@ -75,7 +75,7 @@ int szl_engine_last_timing(const szl_engine *e, szl_timing *t) {
     return 0;
 }
 
-static int zlib_header(int level);
+static int zlib_header(int level, bool preset_dict = false);
 static int build_batch(szl_stream *streams, size_t n, unsigned flags, int level, std::vector<SegDev> &segs, std::vector<uint64_t> &bnds,
                        uint64_t *in_total, uint64_t *out_total) {
     segs.clear(); bnds.clear();
@@ -105,19 +105,133 @@ static int build_batch(szl_stream *streams, size_t n, unsigned flags, int level,
     return 0;
 }
 
-static int zlib_header(int level) { // C/Deflater.cs:436-461
+// ---------------------------------------------------------------------------------------------
+// Level 0: DeflaterEngine.DeflateStored (C/DeflaterEngine.cs:614-649) driven by FillWindow (:366-400).  Block cuts depend
+// only on how many bytes each engine call sees, i.e. on the SetInput chunk sizes — pure arithmetic, replayed here.
+struct L0State { int64_t base = 0; int strstart = 1, blockStart = 1, lookahead = 0; uint64_t fed = 0; /* bytes FillWindow has copied (== engine.TotalIn) */ };
+struct L0Blk { uint64_t abs_off; uint32_t len; uint32_t last; };
+static bool l0_engine_deflate(L0State &s, uint64_t &avail, bool flush, bool finish, std::vector<L0Blk> &out) { // Deflate :104
+    enum { MIN_LOOKAHEAD = 262, MAX_BLOCK_SIZE = 65531 };
+    for (;;) {
+        if (s.strstart >= WSIZE + MAX_DIST) { s.strstart -= WSIZE; s.blockStart -= WSIZE; s.base += WSIZE; } // SlideWindow :441
+        if (s.lookahead < MIN_LOOKAHEAD && avail > 0) {
+            int64_t more = 2 * WSIZE - s.lookahead - s.strstart;
+            if ((uint64_t)more > avail) more = (int64_t)avail;
+            avail -= (uint64_t)more; s.lookahead += (int)more; s.fed += (uint64_t)more;
+        }
+        const bool canFlush = flush && avail == 0;
+        bool progress, emitted = false;
+        if (!canFlush && s.lookahead == 0) progress = false;                                           // :616-619
+        else {
+            s.strstart += s.lookahead; s.lookahead = 0;
+            int storedLength = s.strstart - s.blockStart;
+            if (storedLength >= MAX_BLOCK_SIZE || (s.blockStart < WSIZE && storedLength >= MAX_DIST) || canFlush) { // :626-628
+                bool last = finish;
+                if (storedLength > MAX_BLOCK_SIZE) { storedLength = MAX_BLOCK_SIZE; last = false; }
+                out.push_back(L0Blk{(uint64_t)(s.blockStart - 1 + s.base), (uint32_t)storedLength, last ? 1u : 0u});
+                s.blockStart += storedLength;
+                emitted = true;
+                progress = !(last || storedLength == 0);
+            } else progress = true;
+        }
+        if (emitted || !progress) return progress; // `while (pending.IsFlushed && progress)` :135 — a block makes pending non-empty
+    }
+}
+// Replays Write(chunk)... then Flush()/Finish() (CS/DeflaterOutputStream.cs:506,388,100)
+// The first `ndrained` chunks were followed by Deflate() calls before Flush()/Finish() (the DeflaterOutputStream.Write pattern),
+// so the engine saw them with flush = finish = false; later chunks are first seen with the final flags — which matters at
+// level 0: DeflateStored marks a block final as soon as `finish` is set, even if input remains (:630-631).
+static void l0_replay(L0State &s, const std::vector<uint64_t> &chunks, size_t ndrained, bool flush, bool finish, std::vector<L0Blk> &out) {
+    uint64_t tail = 0;
+    for (size_t i = 0; i < chunks.size(); i++) {
+        if (i >= ndrained) { tail += chunks[i]; continue; }
+        uint64_t avail = chunks[i];
+        while (l0_engine_deflate(s, avail, false, false, out)) { } // Deflater.Deflate keeps calling the engine until it returns false
+    }
+    if (flush || finish) {
+        uint64_t avail = tail;
+        while (l0_engine_deflate(s, avail, true, finish, out)) { }
+    }
+}
+// Parity tap (host arithmetic only, no device): block list of a level-0 stream. rows: abs_off, len, last.
+int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows) {
+    // flush_before_finish bit 0: Flush() before Finish(); bits 8..: number of chunks NOT followed by a Deflate() call (counted
+    // from the end); bits 32.. are not available in an int, so the dictionary length rides in rows[0] on entry.
+    L0State s; std::vector<L0Blk> out;
+    std::vector<uint64_t> cs(chunks, chunks + nchunks);
+    const size_t undrained = (size_t)((unsigned)flush_before_finish >> 8);
+    const size_t nd = cs.size() >= undrained ? cs.size() - undrained : 0;
+    const int dict_len = (rows && cap_rows) ? (int)rows[0] : 0;
+    s.strstart = s.blockStart = 1 + dict_len;
+    if (flush_before_finish & 1) { l0_replay(s, cs, nd, true, false, out); l0_replay(s, {}, 0, false, true, out); }
+    else l0_replay(s, cs, nd, false, true, out);
+    for (size_t i = 0; i < out.size() && i < cap_rows; i++) { rows[3 * i] = out[i].abs_off; rows[3 * i + 1] = out[i].len; rows[3 * i + 2] = out[i].last; }
+    if (n_rows) *n_rows = out.size();
+    return 0;
+}
+
+static int zlib_header(int level, bool preset_dict) { // C/Deflater.cs:436-461
     int header = (8 + ((15 - 8) << 4)) << 8;
     int level_flags = (level - 1) >> 1;
     if (level_flags < 0 || level_flags > 3) level_flags = 3;
     header |= level_flags << 6;
+    if (preset_dict) header |= 0x20; // PRESET_DICT :451-455
     header += 31 - (header % 31);
     return header;
+}
+
+extern "C++" {
+namespace szl {
+int region_checksums(const uint8_t *base, const std::vector<std::pair<uint64_t, uint64_t>> &regs, unsigned want,
+                     std::vector<std::pair<uint32_t, uint32_t>> &out, const std::vector<std::pair<uint32_t, uint32_t>> *init, hipStream_t st);
+}
+}
+// Level 0 batch: every stream == new Deflater(0, nowrap); SetInput(all, in <= 1 GiB pieces); [Flush();] Finish()
+static int deflate_batch_stored(szl_engine *e, const uint8_t *d_in, uint8_t *d_out, szl_stream *streams, size_t n, unsigned flags, hipStream_t st) {
+    if (flags & SZL_F_GZIP) { set_error("SZL_F_GZIP needs level 5-9"); return SZL_E_UNSUPPORTED; }
+    const bool nowrap = flags & SZL_F_NOWRAP;
+    std::vector<StoredBlk> sb;
+    std::vector<std::pair<uint64_t, uint64_t>> regs(n);
+    for (size_t i = 0; i < n; i++) {
+        szl_stream &s = streams[i];
+        std::vector<uint64_t> chunks;
+        for (uint64_t o = 0; o < s.in_len; o += (1ull << 30)) chunks.push_back(std::min<uint64_t>(1ull << 30, s.in_len - o));
+        if (chunks.empty()) chunks.push_back(0);
+        L0State st0; std::vector<L0Blk> blks;
+        if (flags & SZL_F_SYNC_FLUSH_BEFORE_FINISH) { l0_replay(st0, chunks, chunks.size(), true, false, blks); l0_replay(st0, {}, 0, false, true, blks); }
+        else l0_replay(st0, chunks, chunks.size(), false, true, blks);
+        uint64_t o = s.out_off + (nowrap ? 0 : 2);
+        for (auto &b : blks) { sb.push_back(StoredBlk{s.in_off + b.abs_off, o, b.len, b.last}); o += 5 + (uint64_t)b.len; }
+        s.out_len = o - s.out_off + (nowrap ? 0 : 4);
+        s.status = s.out_len <= s.out_cap ? 0 : SZL_E_OUTPUT_TOO_SMALL;
+        if (s.status) { set_error("stream %zu: out_cap too small for level 0", i); return SZL_E_OUTPUT_TOO_SMALL; }
+        regs[i] = {s.in_off, s.in_len};
+    }
+    int rc = e->e.deflate_stored(d_in, d_out, sb, 0, 0, 0, 0, 1, nullptr, nullptr, st);
+    if (rc) return rc;
+    unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !nowrap) ? 2u : 0u);
+    std::vector<std::pair<uint32_t, uint32_t>> cks(n, {0u, 1u});
+    if (want && (rc = szl::region_checksums(d_in, regs, want, cks, nullptr, st))) return rc;
+    for (size_t i = 0; i < n; i++) {
+        streams[i].crc32 = cks[i].first; streams[i].adler32 = cks[i].second;
+        if (!nowrap) { // zlib header (level_flags = 3 for level 0: (0-1)>>1 < 0 -> 3, C/Deflater.cs:440-444) and Adler trailer
+            int hdr = zlib_header(0);
+            uint8_t hb[2] = {(uint8_t)(hdr >> 8), (uint8_t)hdr};
+            uint32_t a = cks[i].second;
+            uint8_t tb[4] = {(uint8_t)(a >> 24), (uint8_t)(a >> 16), (uint8_t)(a >> 8), (uint8_t)a};
+            if (hipMemcpyAsync(d_out + streams[i].out_off, hb, 2, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_out + streams[i].out_off + streams[i].out_len - 4, tb, 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return SZL_E_DEVICE;
+        }
+    }
+    return 0;
 }
 
 int szl_deflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_streams, int level,
                              int strategy, unsigned flags, void *hip_stream) {
     if (!e || (!streams && n_streams)) return SZL_E_ARG;
     if (level == -1) level = 6;
+    if (level == 0) return deflate_batch_stored(e, (const uint8_t *)d_in, (uint8_t *)d_out, streams, n_streams, flags, (hipStream_t)hip_stream);
     LevelParams P;
     int rc = level_params(level, strategy, &P);
     if (rc) { set_error("level %d: %s", level, szl_strerror(rc)); return rc; }
@@ -211,10 +325,15 @@ struct szl_deflater {
     uint64_t hist_abs = 0;          // absolute stream position of hist[0]
     std::vector<uint64_t> bounds;   // absolute positions of earlier segment ends that still lie inside hist
     std::vector<uint8_t> pend;      // bytes given by SetInput since the last Flush()
+    std::vector<uint64_t> chunks;   // SetInput sizes since the last Flush() (level 0 block cuts depend on them)
+    L0State l0;
+    size_t chunks_drained = 0;      // chunks after which Deflate() ran while no Flush/Finish was pending
+    uint64_t l0_dict = 0;           // bytes of preset dictionary in front of the stream (window positions, not TotalIn)
     std::vector<uint8_t> outq;      // compressed bytes not yet handed out
     size_t outpos = 0;
     uint32_t carry_bits = 0; uint8_t carry_byte = 0;
     uint32_t adler = 1;             // running Adler32.Value of everything compressed so far
+    uint32_t dict_adler = 0;        // Adler-32 of the preset dictionary (SETDICT state)
     szl_engine *eng = nullptr;
     DevBuf d_in, d_out;
     std::vector<uint8_t> h_out;
@@ -224,13 +343,14 @@ static void deflater_clear(szl_deflater *d) {
     d->state = d->nowrap ? BUSY_STATE : INIT_STATE;
     d->total_in = d->total_out = 0;
     d->hist.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
+    d->chunks.clear(); d->chunks_drained = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
     d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
 }
 
 szl_deflater *szl_deflater_create(int level, int nowrap) {
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) { set_error("level out of range"); return nullptr; } // C/Deflater.cs:184-187
-    if (level < 5) { set_error("levels 0-4 (DeflateStored/DeflateFast) are not on the device path yet"); return nullptr; }
+    if (level >= 1 && level <= 4) { set_error("levels 1-4 (DeflateFast) are not on the device path yet"); return nullptr; }
     szl_deflater *d = new (std::nothrow) szl_deflater();
     if (!d) return nullptr;
     d->eng = szl_engine_create();
@@ -251,10 +371,12 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) return SZL_E_ARG;
     if (level == d->level) return 0;
-    if (level < 5) { set_error("levels 0-4 are not on the device path yet"); return SZL_E_UNSUPPORTED; }
+    if (level >= 1 && level <= 4) { set_error("levels 1-4 (DeflateFast) are not on the device path yet"); return SZL_E_UNSUPPORTED; }
     // DEFLATE_SLOW -> DEFLATE_SLOW only changes the tuning for positions not yet parsed (C/DeflaterEngine.cs:304-361);
     // that is reproducible only when nothing is buffered.
     if (!d->pend.empty()) { set_error("SetLevel with unprocessed input is not supported"); return SZL_E_UNSUPPORTED; }
+    // stored <-> slow: data stored at level 0 was never inserted into the hash chains (:319-329); only a fresh stream may switch
+    if ((level == 0) != (d->level == 0) && d->total_in != 0) { set_error("switching between level 0 and levels 5-9 mid-stream is not supported"); return SZL_E_UNSUPPORTED; }
     d->level = level;
     return 0;
 }
@@ -265,23 +387,39 @@ int szl_deflater_set_strategy(szl_deflater *d, int s) {
     d->strategy = s;
     return 0;
 }
-int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *, int) {
-    if (!d) return SZL_E_ARG;
-    if (d->state != INIT_STATE) return SZL_E_STATE; // C/Deflater.cs:561-564
-    set_error("preset dictionaries are not on the device path yet");
-    return SZL_E_UNSUPPORTED;
+int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n) { // C/Deflater.cs:559 + C/DeflaterEngine.cs:198-229
+    if (!d || n < 0 || (!p && n)) return SZL_E_ARG;
+    if (d->state != INIT_STATE) { set_error("SetDictionary is only legal before the first Deflate of a zlib stream"); return SZL_E_STATE; } // :561-564
+    uint32_t a = 1;
+    int rc = szl_adler32(1, p, (size_t)n, &a);   // adler?.Update(dictionary) :204
+    if (rc) return rc;
+    d->dict_adler = a;
+    d->state = SETDICT_STATE;
+    if (n < MIN_MATCH) return 0;                   // :205-208: too short to be inserted, the window is not touched
+    int off = 0, len = n;
+    if (len > MAX_DIST) { off = len - MAX_DIST; len = MAX_DIST; } // :210-214
+    // The dictionary is the history of the stream: window indices 1..len, inserted like any other position except its last
+    // two bytes (the insert loop :218-225 stops at length-2), exactly what a segment boundary at `len` expresses.
+    d->hist.assign(p + off, p + off + len);
+    d->hist_abs = 0;
+    d->bounds.assign(1, (uint64_t)len);
+    d->l0.strstart = d->l0.blockStart = 1 + len;
+    d->l0_dict = (uint64_t)len;
+    return 0;
 }
 int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n) {
     if (!d) return SZL_E_ARG;
     if ((d->state & IS_FINISHING) != 0) { set_error("Finish() already called"); return SZL_E_STATE; } // :333-336
     if (n < 0 || (!p && n)) return SZL_E_ARG;
+    if (d->chunks_drained != d->chunks.size()) { set_error("Old input was not completely processed"); return SZL_E_STATE; } // C/DeflaterEngine.cs:163-166
     d->pend.insert(d->pend.end(), p, p + n);
+    d->chunks.push_back((uint64_t)n);
     d->total_in += n;
     return 0;
 }
 int szl_deflater_flush(szl_deflater *d) { if (!d) return SZL_E_ARG; d->state |= IS_FLUSHING; return 0; }
 int szl_deflater_finish(szl_deflater *d) { if (!d) return SZL_E_ARG; d->state |= (IS_FLUSHING | IS_FINISHING); return 0; }
-int szl_deflater_needs_input(const szl_deflater *) { return 1; } // input is copied by SetInput, so it is always consumed
+int szl_deflater_needs_input(const szl_deflater *d) { return d && d->chunks_drained == d->chunks.size(); } // true again after the next Deflate() call
 int szl_deflater_is_finished(const szl_deflater *d) { return d && d->state == FINISHED_STATE && d->outpos == d->outq.size(); }
 int64_t szl_deflater_total_in(const szl_deflater *d) { return d ? d->total_in : 0; }
 int64_t szl_deflater_total_out(const szl_deflater *d) { return d ? d->total_out : 0; }
@@ -294,7 +432,45 @@ uint32_t szl_deflater_adler(const szl_deflater *d) {
 }
 
 // Compress the pending bytes as one segment on the device and append the produced bytes to outq.
+static int run_segment_stored(szl_deflater *d, bool finish) {
+    std::vector<L0Blk> blks;
+    const uint64_t fed0 = d->l0.fed;
+    l0_replay(d->l0, d->chunks, d->chunks_drained, !finish, finish, blks);
+    // Bytes the engine really took in.  Normally all of them; the reference stops early when Finish() precedes the first
+    // Deflate() on > 64 KiB of level-0 input (DeflateStored marks the block final while input remains, :630-631) — the Adler-32
+    // trailer then only covers what FillWindow copied (:389), and so does ours.
+    const uint64_t fed_now = d->l0.fed - fed0;
+    d->chunks.clear(); d->chunks_drained = 0;
+    // absolute positions count the preset dictionary (if any) as a prefix of the stream
+    const uint64_t n = d->pend.size(), pend_abs = (uint64_t)d->total_in - n + d->l0_dict;
+    std::vector<StoredBlk> sb(blks.size());
+    uint64_t out_total = 0;
+    for (size_t i = 0; i < blks.size(); i++) {
+        if (blks[i].abs_off < pend_abs || blks[i].abs_off + blks[i].len > pend_abs + n) { set_error("level-0 block outside the pending data"); return SZL_E_STATE; }
+        sb[i] = StoredBlk{blks[i].abs_off - pend_abs, out_total, blks[i].len, blks[i].last};
+        out_total += 5 + (uint64_t)blks[i].len;
+    }
+    int rc;
+    if ((rc = d->d_in.ensure(n + 64)) || (rc = d->d_out.ensure(out_total + 64))) return rc;
+    if (n && hipMemcpy(d->d_in.p, d->pend.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    uint32_t adler = d->adler;
+    rc = d->eng->e.deflate_stored((const uint8_t *)d->d_in.p, (uint8_t *)d->d_out.p, sb, d->nowrap ? 0u : 2u, 0, fed_now < n ? fed_now : n, 0, d->adler, nullptr, &adler, nullptr);
+    if (rc) return rc;
+    if (!d->nowrap) d->adler = adler;
+    const size_t old = d->outq.size();
+    d->outq.resize(old + out_total + (finish && !d->nowrap ? 4 : 0));
+    if (out_total && hipMemcpy(d->outq.data() + old, d->d_out.p, out_total, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    if (finish && !d->nowrap) { // C/Deflater.cs:510-515
+        uint8_t *t = d->outq.data() + old + out_total;
+        t[0] = (uint8_t)(d->adler >> 24); t[1] = (uint8_t)(d->adler >> 16); t[2] = (uint8_t)(d->adler >> 8); t[3] = (uint8_t)d->adler;
+    }
+    d->pend.clear();
+    return 0;
+}
+
 static int run_segment(szl_deflater *d, bool finish) {
+    if (d->level == 0) return run_segment_stored(d, finish);
+    d->chunks.clear(); d->chunks_drained = 0;
     LevelParams P;
     int rc = level_params(d->level, d->strategy, &P);
     if (rc) return rc;
@@ -351,8 +527,12 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Defla
     if (d->state == CLOSED_STATE) return SZL_E_STATE;
     const int orig = length;
     if (d->state < BUSY_STATE) { // zlib header :436-464
-        int hdr = zlib_header(d->level);
+        int hdr = zlib_header(d->level, (d->state & IS_SETDICT) != 0);
         d->outq.push_back((uint8_t)(hdr >> 8)); d->outq.push_back((uint8_t)hdr);
+        if (d->state & IS_SETDICT) { // the dictionary's Adler-32, then the running Adler restarts :458-463
+            const uint32_t a = d->dict_adler;
+            d->outq.push_back((uint8_t)(a >> 24)); d->outq.push_back((uint8_t)(a >> 16)); d->outq.push_back((uint8_t)(a >> 8)); d->outq.push_back((uint8_t)a);
+        }
         d->state = BUSY_STATE | (d->state & (IS_FLUSHING | IS_FINISHING));
     }
     for (;;) {
@@ -361,7 +541,7 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Defla
         if (k) { memcpy(out, d->outq.data() + d->outpos, k); d->outpos += k; out += k; length -= (int)k; d->total_out += (int64_t)k; }
         if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }
         if (length == 0 || d->state == FINISHED_STATE) break;
-        if (d->state == BUSY_STATE) break; // "We need more input now" :482-484
+        if (d->state == BUSY_STATE) { d->chunks_drained = d->chunks.size(); break; } // "We need more input now" :482-484 (the engine has seen every chunk)
         int rc;
         if (d->state == FLUSHING_STATE) { if ((rc = run_segment(d, false))) return rc; d->state = BUSY_STATE; }
         else if (d->state == FINISHING_STATE) { if ((rc = run_segment(d, true))) return rc; d->state = FINISHED_STATE; }

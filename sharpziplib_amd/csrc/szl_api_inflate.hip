@@ -22,7 +22,8 @@ struct szl_engine { Engine e; };
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return SZL_E_DEVICE; } } while (0)
 
 // checksums of device regions described by (off,len) pairs; results[i] = {crc, adler}
-static int region_checksums(const uint8_t *base, const std::vector<std::pair<uint64_t, uint64_t>> &regs, unsigned want,
+namespace szl {
+int region_checksums(const uint8_t *base, const std::vector<std::pair<uint64_t, uint64_t>> &regs, unsigned want,
                             std::vector<std::pair<uint32_t, uint32_t>> &out, const std::vector<std::pair<uint32_t, uint32_t>> *init, hipStream_t st) {
     const uint32_t n = (uint32_t)regs.size();
     out.assign(n, {0u, 1u});
@@ -52,6 +53,7 @@ done:
     dseg.release(); doff.release(); dparts.release(); dso.release();
     return rc;
 }
+} // namespace szl
 
 extern "C" {
 
@@ -106,6 +108,7 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
             if (!nowrap && states[i].adler_read != cks[i].second) s.status = SZL_E_ADLER_MISMATCH; // C/Inflater.cs:411-414
         } else if (stt == INF_NEED_INPUT) s.status = SZL_E_UNEXPECTED_EOF;
         else if (stt == INF_OUTPUT_FULL) s.status = SZL_E_OUTPUT_TOO_SMALL;
+        else if (stt == INF_NEED_DICT) s.status = SZL_E_UNSUPPORTED; // batch call cannot supply a preset dictionary
         else s.status = stt < 0 ? stt : SZL_E_STATE;
     }
     return 0;
@@ -145,6 +148,7 @@ struct szl_inflater {
     int dec_status = INF_NEED_INPUT;  // last status of the decoder
     int err = 0;                   // sticky error
     bool fresh_input = false;      // bytes were added since the decoder last reported NEED_INPUT
+    bool have_dict = false;        // a preset dictionary sits in the device window
     uint32_t adler = 1;            // Adler-32 of the bytes handed out so far (zlib mode), excluding `unsummed`
     std::vector<uint8_t> unsummed; // handed-out bytes not yet folded into `adler` (folded on the device, lazily)
     uint32_t adler_dec = 1;        // Adler-32 of everything decoded so far
@@ -156,7 +160,7 @@ static void inflater_clear(szl_inflater *s) {
     s->hin.clear(); s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0;
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
-    s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
+    s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
 }
 
 szl_inflater *szl_inflater_create(int no_header) {
@@ -185,9 +189,10 @@ int szl_inflater_remaining_input(const szl_inflater *s) { // C/Inflater.cs:878
 int szl_inflater_needs_input(const szl_inflater *s) { // :783 — all given input was taken by the decoder
     if (!s) return 0;
     if (s->dec_status == INF_FINISHED) return szl_inflater_remaining_input(s) == 0;
+    if (s->dec_status == INF_NEED_DICT) return s->hin.size() * 8 <= s->st.bitpos;
     return s->dec_status == INF_NEED_INPUT && !s->fresh_input;
 }
-int szl_inflater_needs_dictionary(const szl_inflater *) { return 0; }
+int szl_inflater_needs_dictionary(const szl_inflater *s) { return s && s->dec_status == INF_NEED_DICT; } // :794
 int szl_inflater_is_finished(const szl_inflater *s) { return s && s->dec_status == INF_FINISHED && s->pend_pos == s->pend.size(); } // :806
 int64_t szl_inflater_total_in(const szl_inflater *s) { return s ? (int64_t)s->given - szl_inflater_remaining_input(s) : 0; } // :862
 int64_t szl_inflater_total_out(const szl_inflater *s) { return s ? s->total_out : 0; }
@@ -200,6 +205,7 @@ static void fold_adler(szl_inflater *s) {
 uint32_t szl_inflater_adler(const szl_inflater *cs) { // :823
     szl_inflater *s = const_cast<szl_inflater *>(cs);
     if (!s || s->no_header) return 0;
+    if (s->dec_status == INF_NEED_DICT) return s->st.adler_read; // IsNeedingDictionary => readAdler (:827-830)
     fold_adler(s);
     return s->adler;
 }
@@ -212,10 +218,23 @@ int szl_inflater_set_input(szl_inflater *s, const uint8_t *p, int n) { // :629
     if (n) s->fresh_input = true;
     return 0;
 }
-int szl_inflater_set_dictionary(szl_inflater *s, const uint8_t *, int) {
-    if (!s) return SZL_E_ARG;
-    set_error("Dictionary is not needed"); // IsNeedingDictionary is never true on this path (:573-576)
-    return SZL_E_STATE;
+int szl_inflater_set_dictionary(szl_inflater *s, const uint8_t *p, int n) { // :563
+    if (!s || n < 0 || (!p && n)) return SZL_E_ARG;
+    if (s->dec_status != INF_NEED_DICT) { set_error("Dictionary is not needed"); return SZL_E_STATE; } // :573-576
+    uint32_t a = 1;
+    int rc = szl_adler32(1, p, (size_t)n, &a);
+    if (rc) return rc;
+    if (a != s->st.adler_read) { set_error("Wrong adler checksum"); s->err = SZL_E_ADLER_MISMATCH; return SZL_E_ADLER_MISMATCH; } // :583-586
+    // OutputWindow.CopyDict (CS/OutputWindow.cs:130): the last 32 KiB of the dictionary become the history of the stream.
+    // The device window is circular with index = position & 32767, so a byte at distance k before output position 0 lives at 32768-k.
+    const int len = n > 32768 ? 32768 : n;
+    if ((rc = s->d_win.ensure(32768))) return rc;
+    if (hipMemset(s->d_win.p, 0, 32768) != hipSuccess) return SZL_E_DEVICE;
+    if (len && hipMemcpy((uint8_t *)s->d_win.p + (32768 - len), p + (n - len), (size_t)len, hipMemcpyHostToDevice) != hipSuccess) return SZL_E_DEVICE;
+    s->have_dict = true;
+    s->dec_status = INF_NEED_INPUT;
+    s->fresh_input = !s->hin.empty(); // the bytes after the DICTID are still waiting
+    return 0;
 }
 
 // Run the decoder once over the input given so far.
@@ -226,7 +245,7 @@ static int inflater_step(szl_inflater *s) {
         (rc = s->d_job.ensure(sizeof(InfJob))) || (rc = s->d_state.ensure(sizeof(InfState)))) return rc;
     InfJob j{};
     j.in_off = 0; j.in_len = nin; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
-    j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1;
+    j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1; j.load_window = s->have_dict ? 1 : 0;
     if (nin) HIPCHK(hipMemcpy(s->d_in.p, s->hin.data(), nin, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_job.p, &j, sizeof j, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_state.p, &s->st, sizeof s->st, hipMemcpyHostToDevice));
@@ -278,6 +297,7 @@ int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count) { // :715
             if (count == 0) return copied;
         }
         if (s->dec_status == INF_FINISHED) return copied;
+        if (s->dec_status == INF_NEED_DICT) return copied;                      // IsNeedingDictionary: the caller must SetDictionary
         if (s->dec_status == INF_NEED_INPUT && !s->fresh_input) return copied; // IsNeedingInput
         int rc = inflater_step(s);
         if (rc) return rc;

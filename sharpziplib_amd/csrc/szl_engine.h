@@ -29,10 +29,13 @@ class Engine {
     int deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
                 const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st);
 
+    // Level 0: write the stored blocks `blks` (host-built) and, if want_ck, the checksums of d_in[ck_off, ck_off+ck_len).
+    int deflate_stored(const uint8_t *d_in, uint8_t *d_out, const std::vector<StoredBlk> &blks, unsigned want_ck, uint64_t ck_off,
+                       uint64_t ck_len, uint32_t crc_init, uint32_t adler_init, uint32_t *crc_out, uint32_t *adler_out, hipStream_t st);
     szl_timing timing{};
     uint64_t last_nranges = 0, last_in_total = 0, last_blk_slots = 0;
     DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
-        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap;
+        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored;
     hipEvent_t ev[8];
 };
 

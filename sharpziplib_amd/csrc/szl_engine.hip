@@ -41,6 +41,7 @@ void launch_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint8_t *o
 void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
+void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint32_t n, hipStream_t st);
 
 thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
@@ -77,7 +78,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 }
@@ -229,6 +230,29 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
+    return 0;
+}
+
+int Engine::deflate_stored(const uint8_t *d_in, uint8_t *d_out, const std::vector<StoredBlk> &blks, unsigned want_ck, uint64_t ck_off,
+                           uint64_t ck_len, uint32_t crc_init, uint32_t adler_init, uint32_t *crc_out, uint32_t *adler_out, hipStream_t st) {
+    int rc;
+    if ((rc = upload(d_stored, blks, st))) return rc;
+    launch_stored(d_in, d_out, (const StoredBlk *)d_stored.p, (uint32_t)blks.size(), st);
+    if (want_ck) {
+        std::vector<SegDev> segs(1);
+        segs[0] = SegDev{};
+        segs[0].buf_off = ck_off; segs[0].seg_start = 0; segs[0].seg_end = (int64_t)ck_len; segs[0].crc_init = crc_init; segs[0].adler_init = adler_init;
+        std::vector<uint64_t> coff{0, (ck_len + 4095) / 4096};
+        if ((rc = upload(d_segs, segs, st)) || (rc = upload(ckoff, coff, st)) || (rc = ckparts.ensure((coff[1] + 1) * checksum_partial_bytes())) ||
+            (rc = d_so.ensure(sizeof(SegOut)))) return rc;
+        launch_checksums(d_in, (const SegDev *)d_segs.p, 1, (const uint64_t *)ckoff.p, coff[1], ckparts.p, (SegOut *)d_so.p, want_ck, st);
+        SegOut so{};
+        HIPCHK(hipMemcpyAsync(&so, d_so.p, sizeof so, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (crc_out) *crc_out = so.crc32;
+        if (adler_out) *adler_out = so.adler32;
+    } else HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -6,7 +6,7 @@
 namespace szl {
 
 // status values written by k_inflate (>= 0); negative values are szl_status error codes
-enum : int { INF_RUNNING = 0, INF_FINISHED = 1, INF_NEED_INPUT = 2, INF_OUTPUT_FULL = 3 };
+enum : int { INF_RUNNING = 0, INF_FINISHED = 1, INF_NEED_INPUT = 2, INF_OUTPUT_FULL = 3, INF_NEED_DICT = 4 };
 // decoder modes (the reference's 13 modes collapse to these because a token is decoded atomically)
 enum : uint32_t { INF_M_HEADER = 0, INF_M_STORED = 1, INF_M_HUFF = 2, INF_M_DONE = 3, INF_M_ZHEADER = 4 };
 
@@ -18,6 +18,8 @@ struct InfJob {
     uint8_t *window;     // 32 KiB device buffer holding the last 32 KiB of output between calls (NULL: one-shot)
     uint32_t zlib;       // 1: zlib framing (header at mode INF_M_ZHEADER, Adler-32 trailer)
     uint32_t keep_window;
+    uint32_t load_window; // 1: restore the window even at outpos 0 (preset dictionary)
+    uint32_t pad1;
     // results
     uint64_t out_written;
     uint64_t consumed;   // ceil(bits consumed / 8)  == Inflater.TotalIn at this point

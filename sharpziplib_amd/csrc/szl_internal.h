@@ -68,6 +68,8 @@ struct SegOut {          // per-segment results written by the device
     uint32_t crc32, adler32;
 };
 
+struct StoredBlk { uint64_t in_off; uint64_t out_off; uint32_t len; uint32_t last; }; // level 0: one stored block
+
 struct BlockDesc {
     uint32_t seg;
     uint32_t type;        // 0 stored, 1 static, 2 dynamic

@@ -603,6 +603,25 @@ __global__ void k_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint
     so[si].out_bytes = bytes;
 }
 
+// Level 0 (DeflateStored, C/DeflaterEngine.cs:614-649 + FlushStoredBlock C/DeflaterHuffman.cs:766-779): the block list is
+// pure arithmetic on lengths (host); the device moves the bytes.  Every block of a level-0 stream starts byte aligned.
+__global__ __launch_bounds__(256) void k_stored(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const StoredBlk *blks, uint32_t n) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const StoredBlk k = blks[b];
+    uint8_t *o = out + k.out_off;
+    if (threadIdx.x == 0) {
+        o[0] = (uint8_t)k.last;                       // 3 header bits (BFINAL, BTYPE=00) + 5 alignment bits
+        o[1] = (uint8_t)k.len; o[2] = (uint8_t)(k.len >> 8);
+        o[3] = (uint8_t)~k.len; o[4] = (uint8_t)((~k.len) >> 8);
+    }
+    const uint8_t *src = in + k.in_off;
+    for (uint32_t i = threadIdx.x; i < k.len; i += 256) o[5 + i] = src[i];
+}
+void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint32_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_stored, dim3(n), dim3(256), 0, st, in, out, blks, n);
+}
+
 void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so,
                        hipStream_t st) {
     hipLaunchKernelGGL(k_seg_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, tokens, blk_off, so);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     int status = INF_RUNNING;
 
     // window: restore the last 32 KiB of output
-    if (outpos > 0 && job.window) {
+    if ((outpos > 0 || job.load_window) && job.window) {
         for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&S.win[i] = *(const uint4 *)&job.window[i];
     }
     // zlib header (C/Inflater.cs:211-249)
@@ -130,8 +130,13 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
             uint32_t h = ((uint32_t)in[0] << 8) | in[1];
             if (h % 31 != 0) status = SZL_E_HEADER_CHECKSUM;
             else if ((h & 0x0f00) != (8u << 8)) status = SZL_E_METHOD_UNKNOWN;
-            else if (h & 0x0020) status = SZL_E_UNSUPPORTED; // preset dictionary (DECODE_DICT): host API handles SetDictionary later
-            else { bitpos = 16; mode = INF_M_HEADER; }
+            else if (h & 0x0020) { // FDICT: DECODE_DICT (:254-270) — the caller must SetDictionary; DICTID is bytes 2..5
+                if (in_bits < 48) status = INF_NEED_INPUT;
+                else {
+                    if (lane == 0) st->adler_read = ((uint32_t)in[2] << 24) | ((uint32_t)in[3] << 16) | ((uint32_t)in[4] << 8) | in[5];
+                    bitpos = 48; mode = INF_M_HEADER; status = INF_NEED_DICT;
+                }
+            } else { bitpos = 16; mode = INF_M_HEADER; }
         }
     }
     auto rebuild_tables = [&]() {

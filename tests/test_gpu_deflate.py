@@ -189,7 +189,7 @@ def test_deflater_state_errors():
     n = d.Deflate(out)
     assert out[:n].tobytes() == O.deflate(b"abc", 6) and d.IsFinished
     with pytest.raises(NotSupportedOnDevice):
-        Deflater(1, True)
+        Deflater(1, True)     # DeflateFast (levels 1-4) is the one engine mode not on the device yet
 
 
 def test_streaming_random_chunks_and_flushes():
@@ -209,6 +209,7 @@ def test_streaming_random_chunks_and_flushes():
             c = data[pos:pos + n]
             pos += c.size
             d.SetInput(c)
+            assert not d.IsNeedingInput and d.Deflate(buf) == 0 and d.IsNeedingInput   # the adapter's drain loop
             o.set_input(c)
             while not o.needs_input:
                 b = o.deflate(8192)
@@ -248,6 +249,7 @@ def test_flush_after_every_small_write():
     for pos in range(0, data.size, 7):
         c = data[pos:pos + 7]
         d.SetInput(c); o.set_input(c)
+        d.Deflate(buf)
         while not o.needs_input:
             b = o.deflate(4096)
             if not b:
@@ -285,6 +287,7 @@ def test_history_across_window_slides():
     for cut in cuts:
         c = data[prev:cut]; prev = cut
         d.SetInput(c); o.set_input(c)
+        d.Deflate(buf)
         while not o.needs_input:
             b = o.deflate(65536)
             if not b:
@@ -341,3 +344,140 @@ def test_never_merging_ranges_use_exit_maps(eng):
         assert r.data == O.deflate(data, lv)
     for z in (C.zeros(2_000_000), C.period10(1_500_000)):
         assert eng.deflate([z], level=6)[0].data == O.deflate(z, 6)
+
+
+# ---- level 0 (DeflateStored): block cuts replayed on the host, bytes moved by the device
+@pytest.mark.parametrize("n", [0, 1, 65530, 65531, 65532, 100000, 32506, 32507, 300000])
+def test_level0_batch(eng, n):
+    data = C.random_bytes(n, seed=4) if n else np.zeros(0, np.uint8)
+    r = eng.deflate([data], level=0, crc32=True)[0]
+    assert r.data == O.deflate(data, 0) and r.crc32 == O.crc32(data)
+    assert eng.deflate([data], level=0, sync_flush_before_finish=True)[0].data == O.deflate(data, 0, flush=True)
+    assert eng.deflate([data], level=0, nowrap=False)[0].data == O.deflate(data, 0, nowrap=False)
+
+
+def test_level0_streaming_chunk_dependence():
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.streams import DeflaterOutputStream
+    data = C.generate("dickens", 2, 0, 400000)
+    for chunk, flush_every, zl in ((4096, None, False), (70000, None, True), (7777, 50000, False), (32506, 65012, True), (1, None, False)):
+        d = data[:3000] if chunk == 1 else data
+        ms = io.BytesIO()
+        s = DeflaterOutputStream(ms, Deflater(0, not zl), 512)
+        s.IsStreamOwner = False
+        since = 0
+        for pos in range(0, d.size, chunk):
+            c = d[pos:pos + chunk]
+            s.Write(c, 0, c.size)
+            since += c.size
+            if flush_every and since >= flush_every and pos + chunk < d.size:
+                s.Flush(); since = 0
+        s.Finish()
+        ref, tin, tout = O.stream_deflate(d, 0, not zl, chunk=chunk, flush_every=flush_every)
+        assert ms.getvalue() == ref, (chunk, flush_every, zl)
+        assert s.deflater_.TotalIn == tin and s.deflater_.TotalOut == tout
+
+
+# ---- preset dictionary (zlib framing): Deflater.SetDictionary C/Deflater.cs:559, Inflater.SetDictionary C/Inflater.cs:563
+@pytest.mark.parametrize("level", [0, 6, 9])
+@pytest.mark.parametrize("dlen", [2, 3, 500, 32506, 40000])
+def test_preset_dictionary_roundtrip(level, dlen):
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.inflater import Inflater
+    dic = C.generate("dickens", 77, 0, dlen)
+    data = np.concatenate([dic[-min(dlen, 300):], C.generate("dickens", 78, 0, 90000), dic[:min(dlen, 2000)]])
+    d = Deflater(level, False)
+    d.SetDictionary(dic.tobytes())
+    d.SetInput(data)
+    out = np.zeros(200000, np.uint8)
+    n = 0
+    while not d.IsNeedingInput:                       # DeflaterOutputStream.Write's drain loop
+        k = d.Deflate(out, n, 4096)
+        n += k
+        if k <= 0:
+            break
+    d.Finish()
+    while not d.IsFinished:
+        n += d.Deflate(out, n, 4096)
+    got = out[:n].tobytes()
+    o = O.Deflater(level, False)
+    assert o.set_dictionary(dic) == 0
+    o.set_input(data)
+    ref = bytearray()
+    while not o.needs_input:
+        b = o.deflate(4096)
+        if not b:
+            break
+        ref += b
+    o.finish()
+    while not o.finished:
+        ref += o.deflate(4096)
+    assert got == bytes(ref)
+    assert zlib.decompressobj(zdict=dic.tobytes()).decompress(got) == data.tobytes()
+    # and back through the device Inflater
+    inf = Inflater(False)
+    inf.SetInput(got)
+    buf = np.zeros(data.size + 6000, np.uint8)
+    assert inf.Inflate(buf, 0, 1000) == 0 and inf.IsNeedingDictionary
+    assert inf.Adler == O.adler32(dic)
+    inf.SetDictionary(dic.tobytes())
+    k = 0
+    while not inf.IsFinished:
+        r = inf.Inflate(buf, k, 5000)
+        k += r
+        if r == 0 and inf.IsNeedingInput:
+            break
+    assert inf.IsFinished and buf[:k].tobytes() == data.tobytes() and inf.Adler == O.adler32(data)
+
+
+def test_level0_finish_before_first_deflate_quirk():
+    """Write(1000); Flush(); SetInput(90000); Finish(); Deflate(): the reference's DeflateStored marks the 64535-byte block
+    final while input remains (C/DeflaterEngine.cs:630-631) and stops — reproduced bit for bit (it is what the reference emits)."""
+    from sharpziplib_amd.deflater import Deflater
+    data = C.random_bytes(91000, seed=1)
+    d = Deflater(0, True)
+    o = O.Deflater(0, True)
+    out = np.zeros(200000, np.uint8)
+    n = 0
+    ref = bytearray()
+    d.SetInput(data[:1000]); o.set_input(data[:1000])
+    n += d.Deflate(out, n, 4096)
+    while not o.needs_input:
+        b = o.deflate(4096)
+        if not b:
+            break
+        ref += b
+    d.Flush(); o.flush()
+    while True:
+        k = d.Deflate(out, n, 4096)
+        if k <= 0:
+            break
+        n += k
+    while True:
+        b = o.deflate(4096)
+        if not b:
+            break
+        ref += b
+    d.SetInput(data[1000:]); o.set_input(data[1000:])
+    d.Finish(); o.finish()
+    while not d.IsFinished:
+        n += d.Deflate(out, n, 4096)
+    while not o.finished:
+        ref += o.deflate(4096)
+    assert out[:n].tobytes() == bytes(ref)
+    assert len(ref) < data.size          # the reference really drops the tail in this call pattern
+
+
+def test_wrong_dictionary_is_rejected():
+    from sharpziplib_amd.deflater import SharpZipBaseException
+    from sharpziplib_amd.inflater import Inflater
+    dic = b"hello hello hello dictionary"
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, zdict=dic)
+    comp = co.compress(b"hello dictionary hello") + co.flush()
+    inf = Inflater(False)
+    inf.SetInput(comp)
+    buf = np.zeros(100, np.uint8)
+    inf.Inflate(buf)
+    assert inf.IsNeedingDictionary
+    with pytest.raises(SharpZipBaseException):
+        inf.SetDictionary(b"another dictionary")
