@@ -282,9 +282,9 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
     size_t n = std::min<size_t>(n_positions, E.last_in_total);
     if (link && n && hipMemcpy(link, E.link.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
     if ((m2 || mq) && n) {
-        std::vector<uint2> tmp(n);
-        if (hipMemcpy(tmp.data(), E.mtab.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
-        for (size_t i = 0; i < n; i++) { if (m2) m2[i] = tmp[i].x; if (mq) mq[i] = tmp[i].y; }
+        const uint32_t *dm = (const uint32_t *)E.mtab.p;
+        if (m2 && hipMemcpy(m2, dm, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+        if (mq && hipMemcpy(mq, dm + E.last_mt_stride, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
     }
     size_t nt = std::min<size_t>(tok_cap, (size_t)E.timing.tokens);
     if (tokens && nt && hipMemcpy(tokens, E.tokens.p, nt * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;

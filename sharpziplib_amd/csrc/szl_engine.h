@@ -34,9 +34,13 @@ class Engine {
                        uint64_t ck_len, uint32_t crc_init, uint32_t adler_init, uint32_t *crc_out, uint32_t *adler_out, hipStream_t st);
     szl_timing timing{};
     uint64_t last_nranges = 0, last_in_total = 0, last_blk_slots = 0;
+    size_t last_mt_stride = 0;
     DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
         bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored;
     hipEvent_t ev[8];
+    // checksum kernels run beside stages A-C on this stream (they only share the input bytes)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 } // namespace szl

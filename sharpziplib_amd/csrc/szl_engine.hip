@@ -13,22 +13,22 @@ namespace szl {
 // ---- launch wrappers implemented in the kernel translation units
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans, int nspans,
                   uint16_t *link, hipStream_t st);
-hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, uint2 *mtab,
+hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
-void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, hipStream_t st);
-void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+void launch_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                 LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
                 uint64_t *bad_range, hipStream_t st);
-void launch_resolve(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+void launch_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                     RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st);
 int exitmap_width();
-void launch_exitmaps(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+void launch_exitmaps(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                      RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint64_t *bad_range, uint64_t nbad,
                      uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st);
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st);
 void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts, hipStream_t st);
-void launch_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
                  const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos, unsigned long long *counters, hipStream_t st);
 void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so, hipStream_t st);
@@ -81,6 +81,9 @@ Engine::~Engine() {
                       &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
 }
 
 template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t st) {
@@ -133,7 +136,10 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     // ---------------- workspace
     int rc;
     if ((rc = link.ensure(in_total * 2 + 64))) return rc;
-    if ((rc = mtab.ensure(in_total * 8 + 64))) return rc;
+    const size_t mt_stride = (in_total + 63) & ~(size_t)63; // M2 array, then Mq array
+    if ((rc = mtab.ensure(mt_stride * 8 + 64))) return rc;
+    const MTab mt = {(uint32_t *)mtab.p, (uint32_t *)mtab.p + mt_stride};
+    last_mt_stride = mt_stride;
     if ((rc = tokens.ensure((seg_bytes + 16) * 4))) return rc;
     if ((rc = visited.ensure((vis_words + 4) * 4))) return rc;
     if ((rc = ranges.ensure((nranges + 1) * sizeof(RangeDev)))) return rc;
@@ -171,29 +177,41 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
     HIPCHK(hipMemsetAsync(blk_counts.p, 0, (nseg + 2) * 4, st));
     // checksums (also seeds so[].adler32 / crc32 with the running values when not requested)
-    launch_checksums(d_in, dsegs, nseg, (const uint64_t *)ckoff.p, want_ck ? nchunks : 0, ckparts.p, dso, want_ck, st);
+    static const bool ck_overlap = !(getenv("SZL_CK_OVERLAP") && atoi(getenv("SZL_CK_OVERLAP")) == 0);
+    const bool forked = want_ck && ck_overlap;
+    if (forked) {
+        if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        if (!ev_fork) HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        if (!ev_join) HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
+        launch_checksums(d_in, dsegs, nseg, (const uint64_t *)ckoff.p, nchunks, ckparts.p, dso, want_ck, side);
+        HIPCHK(hipEventRecord(ev_join, side));
+    } else {
+        launch_checksums(d_in, dsegs, nseg, (const uint64_t *)ckoff.p, want_ck ? nchunks : 0, ckparts.p, dso, want_ck, st);
+    }
     HIPCHK(hipEventRecord(ev[1], st));
     // A: hash links
     launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, st);
     HIPCHK(hipEventRecord(ev[2], st));
     // B: match tables
-    HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, (uint2 *)mtab.p, P, dcnt, st));
+    HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
-    launch_spec(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
-    launch_fix(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt,
+    launch_spec(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
+    launch_fix(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt,
                (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
     {   // how many ranges never merged?  (one 8-byte read-back; the common answer is 0)
         unsigned long long nbad = 0;
         HIPCHK(hipMemcpyAsync(&nbad, counters.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (nbad > 0 && nbad <= 48) {
-            launch_resolve(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
+            launch_resolve(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
         } else if (nbad > 48) {
             const size_t W = (size_t)exitmap_width();
             if ((rc = exmap.ensure(nbad * W * 2 + 64))) return rc;
             if ((rc = cnmap.ensure(nbad * W * 2 + 64))) return rc;
-            launch_exitmaps(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p,
+            launch_exitmaps(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p,
                             (const uint32_t *)bad_slot.p, (const uint64_t *)bad_range.p, nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st);
         }
     }
@@ -201,7 +219,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
     launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
-    launch_emit(d_in, (const uint16_t *)link.p, (const uint2 *)mtab.p, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p,
+    launch_emit(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p,
                 (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
     HIPCHK(hipEventRecord(ev[4], st));
     // D: blocks
@@ -211,6 +229,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     launch_block_scan(dsegs, nseg, dso, (BlockDesc *)descs.p, st);
     HIPCHK(hipEventRecord(ev[5], st));
     launch_block_encode(d_in, d_out, dsegs, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);
+    if (forked) HIPCHK(hipStreamWaitEvent(st, ev_join, 0));
     launch_seg_finish(dsegs, nseg, dso, d_out, st);
     HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());

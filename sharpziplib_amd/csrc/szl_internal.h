@@ -19,6 +19,12 @@ enum : int { LIT_NUM = 286, DIST_NUM = 30, BL_NUM = 19 };
 
 struct LevelParams { int good, nice, max_chain, strategy; };
 
+// Stage-B output: two u32 arrays (len | dist<<16) indexed like the input buffer.
+struct MTab {
+    uint32_t *m2;
+    uint32_t *mq;
+};
+
 struct SegDev {
     uint64_t buf_off;    // arena offset of buffer position 0 of this segment's stream window
     uint64_t abs0;       // absolute stream position of buffer position 0 (window base arithmetic)

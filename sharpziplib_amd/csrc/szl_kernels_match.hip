@@ -154,7 +154,7 @@ enum : int { B_LDS_BYTES = B_DATA_BYTES + B_LINKS * 2 + 16 };
 template <bool DBG>
 __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                      const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                     uint2 *__restrict__ mtab, LevelParams P, unsigned long long *dbg, int fth, int vth) {
+                                                     MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *sdata32 = (uint32_t *)smem;                          // B_DATA_BYTES
     uint16_t *slink = (uint16_t *)(smem + B_DATA_BYTES);           // B_LINKS entries
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     const SegDev seg = segs[tile.seg];
     const uint8_t *d = in + seg.buf_off;
     const uint16_t *lk = link + seg.buf_off;
-    uint2 *mt = mtab + seg.buf_off;
+    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
+    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
     const int64_t t0 = tile.start;
     const int tlen = tile.len;
     const int64_t dlo = t0 - B_HIST; // buffer position of LDS data byte 0 (may be negative)
@@ -193,6 +194,10 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
             if (pos >= 0 && pos < t0 + tlen) w |= lk[pos];
             if (pos + 1 >= 0 && pos + 1 < t0 + tlen) w |= (uint32_t)lk[pos + 1] << 16;
         }
+        // "no previous position" (0) is staged as 0xFFFF: cl - 0xFFFF is below every limit, so the chain-end test
+        // needs no separate zero check (real links are <= 32767)
+        if ((w & 0xFFFFu) == 0) w |= 0xFFFFu;
+        if ((w >> 16) == 0) w |= 0xFFFF0000u;
         ((uint32_t *)slink)[i] = w;
     }
     if (threadIdx.x == 0) *s_counter = 0;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
         if ((ni >= F_THRESH && !exhausted) || (nq == 0 && nv == 0)) {
             // ---------------- FETCH: retire finished positions and hand out new ones
             if (mode == DONE) {
-                mt[t0 + p] = make_uint2(res2, resq);
+                { mt2[t0 + p] = res2; mtq[t0 + p] = resq; }
                 mode = NEED;
             }
             if (!exhausted) {
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                         // first candidate: strstart - hashHead <= MAX_DIST (:788); chain: curMatch > limit (:609)
                         const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem;
                         cl = pl - l0;
-                        ok = l0 != 0 && cl >= firstmin;
+                        ok = cl >= firstmin; // l0 == 0xFFFF (none) fails this too
                         if (ok) {
                             mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem;
                             cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;         // scanMax :479
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                             mode = QUICK;
                         }
                     }
-                    if (!ok) mt[t0 + p] = make_uint2(0u, 0u);
+                    if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
                 }
                 wnext = wnext + ni < wend ? wnext + ni : wend;
             }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                     }
                     const int left1 = left - 1;
                     const int c2 = cl - lnk;
-                    const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
+                    const bool end = (c2 < mincl) | (left1 == 0);
                     left = nicehit ? left : left1;
                     cl = (nicehit | end) ? cl : c2;
                     mode = (nicehit | end) ? DONE : QUICK;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
             // next candidate of the chain, or the end of this position (:609)
             const int left1 = left - 1;
             const int c2 = cl - lnk;
-            const bool end = (lnk == 0) | (c2 < mincl) | (left1 == 0);
+            const bool end = (c2 < mincl) | (left1 == 0);
             left = pass ? left : left1;
             cl = (pass | end) ? cl : c2;
             off = 0;
@@ -351,7 +356,7 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
 int match_lds_bytes() { return B_LDS_BYTES; }
 
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
-                        uint2 *mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
+                        MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     static bool attr_set = false;
     static const bool want_dbg = getenv("SZL_DEBUG") != nullptr;
     static const int fth = getenv("SZL_FTH") ? atoi(getenv("SZL_FTH")) : 16, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;

@@ -22,7 +22,8 @@ __device__ __forceinline__ int64_t base_of_c(int64_t s_abs) {
 struct ParseCtx {
     const uint8_t *d;      // stream buffer
     const uint16_t *lk;    // links
-    const uint2 *mt;       // {M2,Mq}
+    const uint32_t *m2;    // M2 (full-budget search from matchLen 2)
+    const uint32_t *mq;    // Mq (state after max_chain>>2 candidates); read only when L >= good
     int64_t seg_end;
     int64_t abs0;
     LevelParams P;
@@ -61,14 +62,24 @@ __device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long
 
 // One iteration of the DeflateSlow loop body at position x with pending match (L,D) (L==0: none).
 // Returns the token emitted by this iteration (0xFFFFFFFF = none) and its input start via *tpos.
-__device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, int64_t &x, int &L, int &D, int64_t *tpos,
+// `A` supplies M2 entries and literal bytes: straight from global memory (GlobalAcc) or from a window a wave
+// staged in LDS (WinAcc, k_spec_win / k_emit_win).
+struct GlobalAcc {
+    const uint32_t *m2p, *mqp; const uint8_t *dp;
+    __device__ __forceinline__ uint32_t m2(int64_t x) const { return m2p[x]; }
+    __device__ __forceinline__ uint32_t mq(int64_t x) const { return mqp[x]; }
+    __device__ __forceinline__ uint32_t lit(int64_t x) const { return dp[x]; }
+};
+
+template <typename A>
+__device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, const A &acc, int64_t &x, int &L, int &D, int64_t *tpos,
                                                bool want_lit, unsigned long long *fallbacks) {
-    const uint2 e = c.mt[x];
+    const uint32_t e2 = acc.m2(x);
     if (L == 0) {
-        int len = (int)(e.x & 0xFFFF), dist = (int)(e.x >> 16);
+        int len = (int)(e2 & 0xFFFF), dist = (int)(e2 >> 16);
         if (len != 0 && len <= 5 && (c.P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
         if (len == 0) { // literal step :830-839 (tallied by the next iteration / final flush :752)
-            uint32_t t = want_lit ? (uint32_t)c.d[x] : 0u;
+            uint32_t t = want_lit ? acc.lit(x) : 0u;
             *tpos = x;
             x += 1;
             return t;
@@ -85,14 +96,14 @@ __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, int64_t &x, in
         if (L < cap) {
             const int nice = rem < (int64_t)c.P.nice ? (int)rem : c.P.nice;
             uint32_t cand;
-            if (L < c.P.good) cand = e.x;
-            else if (L < nice) cand = e.y;               // chainLength >>= 2 (:495)
+            if (L < c.P.good) cand = e2;
+            else if (L < nice) cand = acc.mq(x);              // chainLength >>= 2 (:495)
             else cand = slow_walk(c, x, L, fallbacks);
             if ((int)(cand & 0xFFFF) > L && !(c.P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
         }
     }
     if (better) { // previous position becomes a literal (:830-835)
-        uint32_t t = want_lit ? (uint32_t)c.d[x - 1] : 0u;
+        uint32_t t = want_lit ? acc.lit(x - 1) : 0u;
         *tpos = x - 1;
         L = (int)(better & 0xFFFF); D = (int)(better >> 16);
         x += 1;
@@ -106,6 +117,12 @@ __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, int64_t &x, in
     return t;
 }
 
+__device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, int64_t &x, int &L, int &D, int64_t *tpos,
+                                               bool want_lit, unsigned long long *fallbacks) {
+    const GlobalAcc acc{c.m2, c.mq, c.d};
+    return parse_step(c, acc, x, L, D, tpos, want_lit, fallbacks);
+}
+
 __device__ __forceinline__ uint32_t find_seg(const SegDev *segs, uint32_t nseg, uint64_t r) {
     // largest s with segs[s].range_off <= r  (segments with zero ranges share an offset with their successor)
     uint32_t lo = 0, hi = nseg - 1;
@@ -116,16 +133,16 @@ __device__ __forceinline__ uint32_t find_seg(const SegDev *segs, uint32_t nseg, 
     return lo;
 }
 
-__device__ __forceinline__ ParseCtx make_ctx(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev &s,
+__device__ __forceinline__ ParseCtx make_ctx(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev &s,
                                              LevelParams P) {
     ParseCtx c;
-    c.d = in + s.buf_off; c.lk = link + s.buf_off; c.mt = mtab + s.buf_off;
+    c.d = in + s.buf_off; c.lk = link + s.buf_off; c.m2 = mtab.m2 + s.buf_off; c.mq = mtab.mq + s.buf_off;
     c.seg_end = s.seg_end; c.abs0 = (int64_t)s.abs0; c.P = P;
     return c;
 }
 
 // C1: speculative walk of each range from a clean state at its first position.
-__global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+__global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                               uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
                                               uint32_t *visited, unsigned long long *counters) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,7 +210,7 @@ __device__ void fixup_range(const ParseCtx &c, const uint32_t *vis, int64_t seg_
 }
 
 // C2: assume the predecessor's true exit is its speculative exit.
-__global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+__global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                              uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
                                              const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
                                              uint64_t *bad_range) {
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *
 }
 
 // C3: one wavefront per segment chains the ranges whose assumed entry was wrong (sequential; rare).
-__global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+__global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                                 uint32_t nseg, LevelParams P, RangeDev *ranges, const uint32_t *visited,
                                                 unsigned long long *counters) {
     if (counters[0] == 0) return; // every range merged: nothing to do
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_
 // then the ranges are chained by table lookups instead of by re-walking them one after the other.
 enum : int { X_W = 576 }; // entries per map (multiple of 64, > 513)
 
-__global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+__global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                                 uint32_t nseg, LevelParams P, const uint64_t *bad_range, uint64_t nbad,
                                                 uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters) {
     const uint64_t slot = blockIdx.x / (X_W / 64);
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_
 }
 
 enum : int { CH_RANGES = 32 };
-__global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+__global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                               uint32_t nseg, LevelParams P, RangeDev *ranges, const uint32_t *visited,
                                               const uint32_t *bad_slot, const uint16_t *exmap, const uint16_t *cnmap,
                                               unsigned long long *counters) {
@@ -385,7 +402,7 @@ __global__ void k_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *
 }
 
 // C5: replay the true path of each range and write its tokens; record block edges.
-__global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs,
+__global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                               uint32_t nseg, uint64_t nranges, LevelParams P, const RangeDev *ranges,
                                               const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
                                               const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos,
@@ -418,26 +435,213 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t 
     (void)counters;
 }
 
-void launch_spec(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg,
+// ============================================================================================
+// Windowed variants of C1 / C5.  The per-lane walks above touch 4 bytes of a cache line per step and
+// come back to the same line dozens of times, by which time 64 lanes x 16 waves have evicted it from the
+// CU's 32 KiB vector cache (measured: k_emit fetched 6x its algorithmic bytes).  Here a wave works in
+// rounds: it stages, for each of its 64 ranges, the next W entries of M2 and Mq (and the bytes) with
+// coalesced loads into LDS, every lane then walks its own window out of LDS, and the tokens produced
+// are written back range by range, again coalesced.  Tokens are staged in the M2 window itself: the
+// k-th token of a round is produced by a step that has already consumed M2 entries 0..k.
+// ============================================================================================
+template <int W> struct WinCfg { enum : int { STRIDE = W + 1, BSTRIDE = W + 8 }; };
+
+struct WinAcc {
+    const uint32_t *m2p, *mqp; const uint8_t *bp; int64_t w0; // bp[0] is the byte at w0-1
+    __device__ __forceinline__ uint32_t m2(int64_t x) const { return m2p[(int)(x - w0)]; }
+    __device__ __forceinline__ uint32_t mq(int64_t x) const { return mqp[(int)(x - w0)]; }
+    __device__ __forceinline__ uint32_t lit(int64_t x) const { return bp[(int)(x - w0) + 1]; }
+};
+
+__device__ __forceinline__ int64_t shfl64(int64_t v, int l) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, l), hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Stage the window [x, x+W) of every active lane: one load instruction covers 64/W windows.
+template <int W, bool WITH_BYTES>
+__device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool active, int lane, uint32_t *sm2, uint32_t *smq, uint8_t *sb) {
+    constexpr int PER = 64 / W;          // windows per load instruction
+    constexpr int STRIDE = WinCfg<W>::STRIDE, BSTRIDE = WinCfg<W>::BSTRIDE;
+    const int64_t navail = active ? c.seg_end - x : 0; // entries valid from x on
+    const int64_t pm_l = (int64_t)(c.m2 + x), pq_l = (int64_t)(c.mq + x), pd_l = (int64_t)(c.d + x) - 1;
+    const int sub = lane / W, i = lane % W;
+    constexpr int BATCH = 8;
+    for (int kb = 0; kb < W; kb += BATCH) { // W instructions per array, BATCH of them in flight
+        uint32_t v[BATCH], q[BATCH], bv[BATCH], be[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const int j = (kb + u) * PER + sub;
+            const int64_t nv = shfl64(navail, j);
+            const uint32_t *pm = (const uint32_t *)shfl64(pm_l, j);
+            const uint32_t *pq = (const uint32_t *)shfl64(pq_l, j);
+            const bool ok = (int64_t)i < nv;
+            v[u] = ok ? pm[i] : 0u;
+            q[u] = ok ? pq[i] : 0u;
+            if (WITH_BYTES) {
+                const uint8_t *pd = (const uint8_t *)shfl64(pd_l, j);
+                const int64_t xj = shfl64(x, j);
+                bv[u] = ((i > 0 || xj > 0) && (int64_t)i - 1 < nv) ? (uint32_t)pd[i] : 0u; // byte x-1+i
+                be[u] = (i == 0 && (int64_t)W - 1 < nv) ? (uint32_t)pd[W] : 0u;            // byte x+W-1
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const int j = (kb + u) * PER + sub;
+            sm2[j * STRIDE + i] = v[u];
+            smq[j * STRIDE + i] = q[u];
+            if (WITH_BYTES) {
+                sb[j * BSTRIDE + i] = (uint8_t)bv[u];
+                if (i == 0) sb[j * BSTRIDE + W] = (uint8_t)be[u];
+            }
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
+                                                 uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
+                                                 uint32_t *visited, unsigned long long *counters) {
+    constexpr int STRIDE = WinCfg<W>::STRIDE;
+    __shared__ uint32_t sm2[64 * STRIDE];
+    __shared__ uint32_t smq[64 * STRIDE];
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 64 + lane;
+    const bool mine = r0 < nranges;
+    bool active = mine;
+    const uint64_t r = mine ? r0 : nranges - 1;
+    const uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    const uint64_t lr = r - s.range_off;
+    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    uint32_t *vis = visited + s.vis_word_off;
+    int64_t x = rs;
+    int L = 0, D = 0;
+    uint32_t count = 0;
+    int64_t tp;
+    uint64_t cw = (uint64_t)(rs - s.seg_start) >> 5;
+    uint32_t acc = 0;
+    if (x >= re) active = false;
+    while (__any(active)) {
+        win_refill<W, false>(c, x, active, lane, sm2, smq, nullptr);
+        __syncthreads();
+        const WinAcc wa{sm2 + lane * STRIDE, smq + lane * STRIDE, nullptr, x};
+        const int64_t wend = x + W;
+        while (active && x < wend) {
+            if (L == 0) {
+                if (x >= re) { active = false; break; }
+                uint64_t bit = (uint64_t)(x - s.seg_start);
+                if ((bit >> 5) != cw) { if (acc) vis[cw] = acc; cw = bit >> 5; acc = 0; }
+                acc |= 1u << (bit & 31);
+            }
+            uint32_t t = parse_step(c, wa, x, L, D, &tp, false, counters + 1);
+            count += (t != 0xFFFFFFFFu);
+        }
+        if (active && L == 0 && x >= re) active = false;
+        __syncthreads();
+    }
+    if (!mine) return;
+    if (acc) vis[cw] = acc;
+    RangeDev rd;
+    rd.exit_spec = x; rd.exit_true = x; rd.entry = rs; rd.spec_count = count; rd.true_count = count; rd.merged = 1; rd.pad = 0;
+    ranges[r] = rd;
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void k_emit_win(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
+                                                 uint32_t nseg, uint64_t nranges, LevelParams P, const RangeDev *ranges,
+                                                 const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
+                                                 const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos) {
+    constexpr int STRIDE = WinCfg<W>::STRIDE, BSTRIDE = WinCfg<W>::BSTRIDE;
+    __shared__ uint32_t sm2[64 * STRIDE];
+    __shared__ uint32_t smq[64 * STRIDE];
+    __shared__ uint8_t sb[64 * BSTRIDE];
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 64 + lane;
+    bool active = r0 < nranges;
+    const uint64_t r = active ? r0 : nranges - 1;
+    const uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    const uint64_t lr = r - s.range_off;
+    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    int64_t x = lr == 0 ? rs : ranges[r].entry;
+    int L = 0, D = 0;
+    uint64_t ti = range_tok[r];
+    const uint64_t seg_tok0 = so[si].tok_first, seg_ntok = so[si].tok_count;
+    const uint64_t b0 = blk_off[si];
+    int64_t tp;
+    if (x >= re) active = false;
+    while (__any(active)) {
+        win_refill<W, true>(c, x, active, lane, sm2, smq, sb);
+        __syncthreads();
+        uint32_t *win = sm2 + lane * STRIDE;
+        const WinAcc wa{win, smq + lane * STRIDE, sb + lane * BSTRIDE, x};
+        const int64_t wend = x + W;
+        int nt = 0;
+        while (active && x < wend) {
+            if (L == 0 && x >= re) { active = false; break; }
+            uint32_t t = parse_step(c, wa, x, L, D, &tp, true, nullptr);
+            if (t != 0xFFFFFFFFu) {
+                win[nt] = t; // entry nt of the M2 window is dead by now (see the header comment)
+                const uint64_t li = ti + nt - seg_tok0; // token index inside the segment
+                if ((li & (BLOCK_TOKENS - 1)) == 0) blk_start_pos[b0 + li / BLOCK_TOKENS] = tp;
+                if ((li & (BLOCK_TOKENS - 1)) == BLOCK_TOKENS - 1 || li == seg_ntok - 1) blk_lasttok_pos[b0 + li / BLOCK_TOKENS] = tp;
+                nt++;
+            }
+        }
+        if (active && L == 0 && x >= re) active = false;
+        __syncthreads();
+        for (uint64_t m = __ballot(nt > 0); m; m &= m - 1) {
+            const int j = __builtin_ctzll(m);
+            const int ntj = __builtin_amdgcn_readlane(nt, j);
+            uint32_t *dst = tokens + readlane64((int64_t)ti, j);
+            if (lane < ntj) dst[lane] = sm2[j * STRIDE + lane];
+        }
+        ti += nt;
+        __syncthreads();
+    }
+}
+
+static int cwin_mode() {
+    static const int m = getenv("SZL_CWIN") ? atoi(getenv("SZL_CWIN")) : 16;
+    return m;
+}
+
+void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg,
                  uint64_t nranges, LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters,
                  hipStream_t st) {
     if (nranges == 0) return;
+    const int cw = cwin_mode();
+    const dim3 wg((unsigned)((nranges + 63) / 64));
+    if (cw == 64) { hipLaunchKernelGGL(k_spec_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
+    if (cw == 32) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
+    if (cw == 16) { hipLaunchKernelGGL(k_spec_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
+    if (cw == 8) { hipLaunchKernelGGL(k_spec_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
     hipLaunchKernelGGL(k_spec, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, visited, counters);
 }
-void launch_fix(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+void launch_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                 LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
                 uint64_t *bad_range, hipStream_t st) {
     if (nranges == 0) return;
     hipLaunchKernelGGL(k_fix, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, visited, counters, bad_slot, bad_range);
 }
-void launch_resolve(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+void launch_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                     RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st) {
     hipLaunchKernelGGL(k_resolve, dim3(nseg), dim3(64), 0, st, in, link, mtab, segs, nseg, P, ranges, visited, counters);
 }
 int exitmap_width() { return X_W; }
-void launch_exitmaps(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
+void launch_exitmaps(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                      RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint64_t *bad_range, uint64_t nbad,
                      uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st) {
     if (nbad == 0) return;
@@ -454,11 +658,17 @@ void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_
                        hipStream_t st) {
     hipLaunchKernelGGL(k_seg_tokens, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, range_tok, so, blk_counts);
 }
-void launch_emit(const uint8_t *in, const uint16_t *link, const uint2 *mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
                  const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos, unsigned long long *counters,
                  hipStream_t st) {
     if (nranges == 0) return;
+    const int cw = cwin_mode();
+    const dim3 wg((unsigned)((nranges + 63) / 64));
+    if (cw == 64) { hipLaunchKernelGGL(k_emit_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos); return; }
+    if (cw == 32) { hipLaunchKernelGGL(k_emit_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos); return; }
+    if (cw == 16) { hipLaunchKernelGGL(k_emit_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos); return; }
+    if (cw == 8) { hipLaunchKernelGGL(k_emit_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos); return; }
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos, counters);
 }
