@@ -274,3 +274,143 @@ size_t szm_block_table(const uint32_t *tok, size_t ntok, int finish, int64_t *fi
     if (finish) last[nb - 1] = 1;
     return nb;
 }
+
+/* =====================================================================================================
+ * DeflateFast (levels 1-4, C/DeflaterEngine.cs:651-739) — model of the device formulation.
+ *
+ * The greedy parse inserts a position into the hash chains only if the parse visits it or it lies inside a
+ * match of length <= max_lazy (:697-708); positions inside longer matches are skipped.  The reference's
+ * head/prev chain of a position is therefore the ALL-positions chain of stage A (szm_links) filtered by an
+ * "inserted" flag: a non-inserted hop costs no chain budget.  The set of flags depends on the parse, so the
+ * device runs a fixpoint iteration over ranges (szm_fast_parse_fixpoint): every range is parsed from the
+ * exit of its predecessor in the previous iteration, reading flags below its entry from the previous
+ * iteration.  When an iteration reproduces (flags, exits) exactly, it IS the sequential parse (induction over
+ * positions); range k is exact after iteration k+1 at the latest, in practice after a handful.
+ * ===================================================================================================== */
+int szm_fast_level_params(int level, szm_fast_params *out) { /* C/DeflaterConstants.cs:124-144 */
+    static const int LAZY[5] = {0, 4, 5, 6, 4}, NICE[5] = {0, 8, 16, 32, 16}, CHAIN[5] = {0, 4, 8, 32, 16};
+    if (level < 1 || level > 4) return -1;
+    out->nice = NICE[level]; out->max_chain = CHAIN[level]; out->max_lazy = LAZY[level]; out->strategy = 0;
+    return 0;
+}
+
+/* DeflateFast slides when an iteration starts at window index > 65274 (:680, strict), not >= as DeflateSlow. */
+int64_t szm_base_of_fast(int64_t s) {
+    int64_t idx = s + 1;
+    if (idx <= 65274) return 0;
+    return ((idx - 65274 + 32767) / 32768) * 32768;
+}
+
+/* FindLongestMatch at p over the filtered chain.  ins(q) = is q inserted.  Returns len | dist<<16, 0 = none. */
+typedef struct { const uint8_t *fa, *fb; size_t split; } flag_view; /* q >= split ? fb[q] : fa[q] */
+static inline int fv_get(const flag_view *v, size_t q) { return q >= v->split ? v->fb[q] : v->fa[q]; }
+
+static uint32_t flm_fast(const uint8_t *d, size_t p, size_t seg_end, const uint16_t *link, const flag_view *fv,
+                         const szm_fast_params *P) {
+    size_t rem = seg_end - p;
+    if (P->strategy == 2) return 0; /* HuffmanOnly :686 */
+    int64_t base = szm_base_of_fast((int64_t)p);
+    int64_t idx_p = (int64_t)p + 1 - base;
+    int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0; /* :480 */
+    /* hashHead = newest inserted position with this hash (:686): skip hops over positions never inserted */
+    int64_t c = (int64_t)p;
+    for (;;) {
+        uint32_t l = link[c];
+        if (l == 0) return 0;
+        c -= l;
+        if ((int64_t)p - c > MAX_DIST) return 0;   /* strstart - hashHead <= MAX_DIST :687 (older ones are farther still) */
+        if (c + 1 - base < 1) return 0;            /* entry clamped to 0 by a slide :450-461 */
+        if (fv_get(fv, (size_t)c)) break;
+    }
+    int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    int nice = rem < (size_t)P->nice ? (int)rem : P->nice;
+    int best = 2, budget = P->max_chain; /* matchLen == 2 < goodLength: full budget */
+    if (best >= cap) return 0;
+    uint32_t res = 0;
+    for (;;) {
+        int L = lcp_cap(d, (size_t)c, p, cap);
+        if (L > best) {
+            best = L;
+            res = (uint32_t)L | ((uint32_t)((int64_t)p - c) << 16);
+            if (best >= nice) return res;
+        }
+        /* curMatch = prev[curMatch] : next INSERTED position down the chain */
+        int64_t c2 = c;
+        for (;;) {
+            uint32_t l = link[c2];
+            if (l == 0) return res;
+            c2 -= l;
+            if (c2 + 1 - base <= limit_idx) return res; /* > limit :609 (monotone: older hops fail too) */
+            if (fv_get(fv, (size_t)c2)) break;
+        }
+        if (--budget == 0) return res;
+        c = c2;
+    }
+}
+
+/* One greedy step at x.  Writes the token, updates flags in fnew[x ..), returns the next position. */
+static size_t fast_step(const uint8_t *d, size_t x, size_t seg_end, const uint16_t *link, const flag_view *fv,
+                        uint8_t *fnew, const szm_fast_params *P, uint32_t *tok) {
+    size_t rem = seg_end - x;
+    uint32_t m = 0;
+    fnew[x] = 0;
+    if (rem >= MIN_MATCH) { /* InsertString :686 */
+        m = flm_fast(d, x, seg_end, link, fv, P);
+        fnew[x] = 1;
+    }
+    if (!m) { *tok = d[x]; return x + 1; }
+    size_t len = m & 0xFFFF;
+    *tok = m;
+    int ins = (int)len <= P->max_lazy && rem - len >= MIN_MATCH; /* :697 */
+    for (size_t k = 1; k < len; k++) fnew[x + k] = (uint8_t)ins;
+    return x + len;
+}
+
+size_t szm_fast_parse(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link,
+                      const szm_fast_params *P, uint8_t *flags, uint32_t *tok) {
+    flag_view fv = {flags, flags, 0};
+    size_t x = seg_start, nt = 0;
+    while (x < seg_end) x = fast_step(d, x, seg_end, link, &fv, flags, P, &tok[nt++]);
+    return nt;
+}
+
+size_t szm_fast_parse_fixpoint(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link,
+                               const szm_fast_params *P, size_t R, uint8_t *flags /* in: history flags below seg_start; out: all */,
+                               uint32_t *tok, uint64_t *iters) {
+    size_t n = seg_end - seg_start, nr = (n + R - 1) / R;
+    if (nr == 0) return 0;
+    uint8_t *fold = (uint8_t *)malloc(seg_end + 1), *fnew = (uint8_t *)malloc(seg_end + 1);
+    size_t *entry = (size_t *)malloc(sizeof(size_t) * nr), *exitp = (size_t *)malloc(sizeof(size_t) * nr);
+    uint32_t *stage = (uint32_t *)malloc(sizeof(uint32_t) * (nr * R + 1));
+    uint32_t *cnt = (uint32_t *)malloc(sizeof(uint32_t) * nr);
+    memcpy(fold, flags, seg_start);
+    memset(fold + seg_start, 1, n); /* first guess: everything inserted */
+    for (size_t r = 0; r < nr; r++) exitp[r] = seg_start + (r + 1) * R < seg_end ? seg_start + (r + 1) * R : seg_end;
+    uint64_t it = 0;
+    for (;;) {
+        it++;
+        memcpy(fnew, flags, seg_start);
+        memset(fnew + seg_start, 0, n);
+        int changed = 0;
+        for (size_t r = 0; r < nr; r++) entry[r] = r == 0 ? seg_start : exitp[r - 1]; /* exits of the previous iteration */
+        for (size_t r = 0; r < nr; r++) { /* independent of each other: this is the parallel loop */
+            size_t re = seg_start + (r + 1) * R < seg_end ? seg_start + (r + 1) * R : seg_end;
+            size_t x = entry[r], k = 0;
+            flag_view fv = {fold, fnew, entry[r]};
+            while (x < re) x = fast_step(d, x, seg_end, link, &fv, fnew, P, &stage[r * R + k++]);
+            cnt[r] = (uint32_t)k;
+            size_t ex = x > re ? x : re; /* a range whose entry is already past its end is skipped */
+            if (entry[r] >= re) ex = entry[r];
+            if (ex != exitp[r]) changed = 1;
+            exitp[r] = ex;
+        }
+        if (!changed && memcmp(fold + seg_start, fnew + seg_start, n) == 0) break;
+        uint8_t *t = fold; fold = fnew; fnew = t;
+    }
+    size_t nt = 0;
+    for (size_t r = 0; r < nr; r++) { memcpy(tok + nt, stage + r * R, sizeof(uint32_t) * cnt[r]); nt += cnt[r]; }
+    memcpy(flags + seg_start, fnew + seg_start, n);
+    if (iters) *iters = it;
+    free(fold); free(fnew); free(entry); free(exitp); free(stage); free(cnt);
+    return nt;
+}

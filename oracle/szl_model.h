@@ -55,6 +55,18 @@ size_t szm_block_table(const uint32_t *tok, size_t ntok, int finish, int64_t *fi
 /* base_of(s): window base in effect for an iteration starting at absolute position s (App. A.2). */
 int64_t szm_base_of(int64_t s);
 
+/* ---- DeflateFast (levels 1-4), see szl_model.c ---- */
+typedef struct szm_fast_params { int nice, max_chain, max_lazy, strategy; } szm_fast_params;
+int szm_fast_level_params(int level, szm_fast_params *out); /* 0, or -1 if level is not 1..4 */
+int64_t szm_base_of_fast(int64_t s);
+/* Sequential greedy parse over the flag-filtered all-positions chain. flags[q] (bytes) in: history below
+ * seg_start, out: inserted flag of every position in the segment. Returns the token count. */
+size_t szm_fast_parse(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link,
+                      const szm_fast_params *P, uint8_t *flags, uint32_t *tok);
+/* Range-parallel fixpoint form (what the kernels do); *iters = iterations until (flags, exits) repeat. */
+size_t szm_fast_parse_fixpoint(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link,
+                               const szm_fast_params *P, size_t R, uint8_t *flags, uint32_t *tok, uint64_t *iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -282,6 +282,11 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
     size_t n = std::min<size_t>(n_positions, E.last_in_total);
     if (link && n && hipMemcpy(link, E.link.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
     if ((m2 || mq) && n) {
+        if (!E.mtab.p || E.last_mt_stride < n) { // DeflateFast calls build no match tables
+            if (m2) memset(m2, 0, n * 4);
+            if (mq) memset(mq, 0, n * 4);
+            m2 = mq = nullptr;
+        }
         const uint32_t *dm = (const uint32_t *)E.mtab.p;
         if (m2 && hipMemcpy(m2, dm, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
         if (mq && hipMemcpy(mq, dm + E.last_mt_stride, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
@@ -322,6 +327,7 @@ struct szl_deflater {
     int level = 6, strategy = 0, nowrap = 0, state = 0;
     int64_t total_in = 0, total_out = 0;
     std::vector<uint8_t> hist;      // tail (<= 65536 B) of the bytes already compressed
+    std::vector<uint32_t> hist_flags; // levels 1-4: "inserted into the hash chains" bit per hist byte (DeflateFast skips long matches)
     uint64_t hist_abs = 0;          // absolute stream position of hist[0]
     std::vector<uint64_t> bounds;   // absolute positions of earlier segment ends that still lie inside hist
     std::vector<uint8_t> pend;      // bytes given by SetInput since the last Flush()
@@ -342,7 +348,7 @@ struct szl_deflater {
 static void deflater_clear(szl_deflater *d) {
     d->state = d->nowrap ? BUSY_STATE : INIT_STATE;
     d->total_in = d->total_out = 0;
-    d->hist.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
+    d->hist.clear(); d->hist_flags.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
     d->chunks.clear(); d->chunks_drained = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
     d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
 }
@@ -350,7 +356,6 @@ static void deflater_clear(szl_deflater *d) {
 szl_deflater *szl_deflater_create(int level, int nowrap) {
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) { set_error("level out of range"); return nullptr; } // C/Deflater.cs:184-187
-    if (level >= 1 && level <= 4) { set_error("levels 1-4 (DeflateFast) are not on the device path yet"); return nullptr; }
     szl_deflater *d = new (std::nothrow) szl_deflater();
     if (!d) return nullptr;
     d->eng = szl_engine_create();
@@ -371,12 +376,13 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) return SZL_E_ARG;
     if (level == d->level) return 0;
-    if (level >= 1 && level <= 4) { set_error("levels 1-4 (DeflateFast) are not on the device path yet"); return SZL_E_UNSUPPORTED; }
     // DEFLATE_SLOW -> DEFLATE_SLOW only changes the tuning for positions not yet parsed (C/DeflaterEngine.cs:304-361);
     // that is reproducible only when nothing is buffered.
     if (!d->pend.empty()) { set_error("SetLevel with unprocessed input is not supported"); return SZL_E_UNSUPPORTED; }
-    // stored <-> slow: data stored at level 0 was never inserted into the hash chains (:319-329); only a fresh stream may switch
-    if ((level == 0) != (d->level == 0) && d->total_in != 0) { set_error("switching between level 0 and levels 5-9 mid-stream is not supported"); return SZL_E_UNSUPPORTED; }
+    // stored / fast / slow keep different hash-chain contents (level 0 inserts nothing, 1-4 skip long matches, :319-329,:697):
+    // only a fresh stream may change the compression function
+    auto kind = [](int lv) { return lv == 0 ? 0 : (lv < 5 ? 1 : 2); };
+    if (kind(level) != kind(d->level) && d->total_in != 0) { set_error("switching between DeflateStored / DeflateFast / DeflateSlow levels mid-stream is not supported"); return SZL_E_UNSUPPORTED; }
     d->level = level;
     return 0;
 }
@@ -401,6 +407,8 @@ int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n) { // C
     // The dictionary is the history of the stream: window indices 1..len, inserted like any other position except its last
     // two bytes (the insert loop :218-225 stops at length-2), exactly what a segment boundary at `len` expresses.
     d->hist.assign(p + off, p + off + len);
+    d->hist_flags.assign(((size_t)len + 31) / 32, 0u);
+    for (int q = 0; q + 2 < len; q++) d->hist_flags[(size_t)q >> 5] |= 1u << (q & 31); // every dictionary position but the last two is inserted
     d->hist_abs = 0;
     d->bounds.assign(1, (uint64_t)len);
     d->l0.strstart = d->l0.blockStart = 1 + len;
@@ -493,7 +501,11 @@ static int run_segment(szl_deflater *d, bool finish) {
     s.flags = finish ? ((d->nowrap ? 0u : (uint32_t)SEG_ZLIB_TRAILER)) : (uint32_t)SEG_SYNC_PAD;
     s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = 0;
     std::vector<SegOut> res;
-    rc = d->eng->e.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, d->nowrap ? 0u : 2u, res, nullptr);
+    Engine &E = d->eng->e;
+    E.fast_hist_in.clear(); E.fast_want_tail = false;
+    if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = true; }
+    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, d->nowrap ? 0u : 2u, res, nullptr);
+    E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (rc) return rc;
     const uint64_t end_bit = res[0].end_bit;
     const uint64_t bytes = (end_bit + 7) >> 3;
@@ -515,6 +527,15 @@ static int run_segment(szl_deflater *d, bool finish) {
     nh.reserve(keep);
     if (keep > n) nh.insert(nh.end(), d->hist.end() - (keep - n), d->hist.end());
     nh.insert(nh.end(), d->pend.end() - std::min<uint64_t>(keep, n), d->pend.end());
+    if (P.fast) { // inserted bits of the bytes that stay as history (the engine returns those of the last 32 Ki positions)
+        std::vector<uint32_t> nf((keep + 31) / 32, 0u);
+        const int64_t first = (int64_t)(H + n - keep);
+        for (uint64_t q = 0; q < keep; q++) {
+            const int64_t p = first + (int64_t)q - E.fast_tail_start;
+            if (p >= 0 && (size_t)(p >> 5) < E.fast_tail_bits.size() && ((E.fast_tail_bits[(size_t)(p >> 5)] >> (p & 31)) & 1u)) nf[q >> 5] |= 1u << (q & 31);
+        }
+        d->hist_flags.swap(nf);
+    } else d->hist_flags.clear();
     d->hist_abs = d->hist_abs + H + n - keep;
     d->hist.swap(nh);
     d->pend.clear();

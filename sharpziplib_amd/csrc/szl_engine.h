@@ -35,6 +35,11 @@ class Engine {
     szl_timing timing{};
     uint64_t last_nranges = 0, last_in_total = 0, last_blk_slots = 0;
     size_t last_mt_stride = 0;
+    // DeflateFast, single-segment calls (streaming Deflater): "inserted" bits of the buffer's history in (bit q = buffer
+    // position q), and of the last 32 Ki positions out (bit 0 of fast_tail_bits = position fast_tail_start).
+    std::vector<uint32_t> fast_hist_in, fast_tail_bits;
+    bool fast_want_tail = false;
+    int64_t fast_tail_start = 0;
     DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
         bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored;
     hipEvent_t ev[8];

@@ -31,9 +31,11 @@ void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_
 void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
                  const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos, unsigned long long *counters, hipStream_t st);
-void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so, hipStream_t st);
+void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so, int fast, hipStream_t st);
+hipError_t launch_fast(const uint8_t *in, const uint16_t *link, const SegDev *segs, uint32_t nseg, LevelParams P, uint32_t *fbits,
+                       SegOut *so, uint32_t *tokens, const uint64_t *blk_off, int64_t *bsp, int64_t *blp, hipStream_t st);
 void launch_block_build(const SegDev *segs, uint32_t nseg, const SegOut *so, const uint64_t *blk_off, const uint32_t *tokens,
-                        const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, hipStream_t st);
+                        const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, int fast, hipStream_t st);
 void launch_block_scan(const SegDev *segs, uint32_t nseg, SegOut *so, BlockDesc *descs, hipStream_t st);
 void launch_block_encode(const uint8_t *in, uint8_t *out, const SegDev *segs, const BlockDesc *descs, const uint32_t *tokens,
                          uint32_t nslots, hipStream_t st);
@@ -57,8 +59,10 @@ int level_params(int level, int strategy, LevelParams *P) { // C/DeflaterConstan
     static const int CHAIN[10] = {0, 4, 8, 32, 16, 32, 128, 256, 1024, 4096};
     if (level == -1) level = 6;
     if (level < 0 || level > 9) return SZL_E_ARG;
-    if (level < 5) return SZL_E_UNSUPPORTED; // DeflateStored / DeflateFast: not on the device path yet
+    static const int LAZY[10] = {0, 4, 5, 6, 4, 16, 16, 32, 128, 258};
+    if (level < 1) return SZL_E_UNSUPPORTED; // DeflateStored has its own entry point (Engine::deflate_stored)
     P->good = GOOD[level]; P->nice = NICE[level]; P->max_chain = CHAIN[level]; P->strategy = strategy;
+    P->max_lazy = LAZY[level]; P->fast = level < 5; // COMPR_FUNC :144
     return 0;
 }
 
@@ -110,9 +114,28 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     std::vector<SpanDev> spans;
     std::vector<TileDev> tiles;
     std::vector<uint64_t> chunk_off(nseg + 1);
+    const bool fast = P.fast != 0;             // DeflateFast: one wavefront per segment instead of stages B and C
+    std::vector<uint64_t> fast_blk_off;        // (its block slots are laid out here, not by a device scan)
+    if (fast) fast_blk_off.resize(nseg + 1);
     for (uint32_t i = 0; i < nseg; i++) {
         SegDev &s = segs[i];
         const uint64_t n = (uint64_t)(s.seg_end - s.seg_start);
+        if (fast) {
+            int64_t e0f = std::max<int64_t>(0, s.seg_start - WSIZE);
+            if (n > 0)
+                for (int64_t a = e0f; a < s.seg_end; a += (int64_t)span_len)
+                    spans.push_back(SpanDev{i, 0, a, std::min<int64_t>(a + (int64_t)span_len, s.seg_end)});
+            s.range_off = seg_bytes; // token base
+            s.range_cnt = 0;
+            s.vis_word_off = vis_words;
+            vis_words += ((uint64_t)s.seg_end + 31) / 32 + 1;
+            fast_blk_off[i] = blk_slots;
+            blk_slots += n / BLOCK_TOKENS + 2;
+            seg_bytes += n;
+            chunk_off[i] = nchunks;
+            nchunks += (n + 4095) / 4096;
+            continue;
+        }
         seg_bytes += n;
         int64_t e0 = std::max<int64_t>(0, s.seg_start - WSIZE);
         if (n > 0)
@@ -130,6 +153,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         blk_slots += n / BLOCK_TOKENS + 1;
     }
     chunk_off[nseg] = nchunks;
+    if (fast) fast_blk_off[nseg] = blk_slots;
     ntiles = tiles.size();
     if (blk_slots > 0xFFFFFFF0ull || spans.size() > 0x7FFFFFFFull || ntiles > 0x7FFFFFFFull) { set_error("batch too large"); return SZL_E_ARG; }
 
@@ -137,9 +161,9 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     int rc;
     if ((rc = link.ensure(in_total * 2 + 64))) return rc;
     const size_t mt_stride = (in_total + 63) & ~(size_t)63; // M2 array, then Mq array
-    if ((rc = mtab.ensure(mt_stride * 8 + 64))) return rc;
+    if (!fast && (rc = mtab.ensure(mt_stride * 8 + 64))) return rc;
     const MTab mt = {(uint32_t *)mtab.p, (uint32_t *)mtab.p + mt_stride};
-    last_mt_stride = mt_stride;
+    last_mt_stride = fast ? 0 : mt_stride;
     if ((rc = tokens.ensure((seg_bytes + 16) * 4))) return rc;
     if ((rc = visited.ensure((vis_words + 4) * 4))) return rc;
     if ((rc = ranges.ensure((nranges + 1) * sizeof(RangeDev)))) return rc;
@@ -194,6 +218,26 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     // A: hash links
     launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, st);
     HIPCHK(hipEventRecord(ev[2], st));
+    if (fast) {
+        // B+C for DeflateFast: sequential greedy parse, one wavefront per segment (szl_kernels_fast.hip)
+        if ((rc = upload(blk_off, fast_blk_off, st))) return rc;
+        if (!fast_hist_in.empty() && nseg == 1) // inserted bits of the history (streaming Deflater / preset dictionary)
+            HIPCHK(hipMemcpyAsync((uint32_t *)visited.p + segs[0].vis_word_off, fast_hist_in.data(),
+                                  std::min<size_t>(fast_hist_in.size(), ((size_t)segs[0].seg_start + 31) / 32) * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(launch_fast(d_in, (const uint16_t *)link.p, dsegs, nseg, P, (uint32_t *)visited.p, dso, (uint32_t *)tokens.p,
+                           (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, st));
+        HIPCHK(hipEventRecord(ev[3], st));
+        if (fast_want_tail && nseg == 1) {
+            const int64_t t0 = std::max<int64_t>(0, segs[0].seg_end - WSIZE);
+            fast_tail_start = t0 & ~(int64_t)31;
+            const size_t w0 = (size_t)(fast_tail_start >> 5), w1 = ((size_t)segs[0].seg_end + 31) >> 5;
+            fast_tail_bits.assign(w1 - w0, 0u);
+            if (w1 > w0)
+                HIPCHK(hipMemcpyAsync(fast_tail_bits.data(), (const uint32_t *)visited.p + segs[0].vis_word_off + w0, (w1 - w0) * 4,
+                                      hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipEventRecord(ev[4], st));
+    } else {
     // B: match tables
     HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     HIPCHK(hipEventRecord(ev[3], st));
@@ -222,10 +266,11 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     launch_emit(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p,
                 (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
     HIPCHK(hipEventRecord(ev[4], st));
+    }
     // D: blocks
-    launch_seg_blocks(dsegs, nseg, (const uint32_t *)tokens.p, (const uint64_t *)blk_off.p, dso, st);
+    launch_seg_blocks(dsegs, nseg, (const uint32_t *)tokens.p, (const uint64_t *)blk_off.p, dso, fast ? 1 : 0, st);
     launch_block_build(dsegs, nseg, dso, (const uint64_t *)blk_off.p, (const uint32_t *)tokens.p, (const int64_t *)bsp.p, (const int64_t *)blp.p,
-                       (BlockDesc *)descs.p, (uint32_t)blk_slots, st);
+                       (BlockDesc *)descs.p, (uint32_t)blk_slots, fast ? 1 : 0, st);
     launch_block_scan(dsegs, nseg, dso, (BlockDesc *)descs.p, st);
     HIPCHK(hipEventRecord(ev[5], st));
     launch_block_encode(d_in, d_out, dsegs, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);

@@ -17,7 +17,8 @@ namespace szl {
 enum : int { WSIZE = 32768, MAX_DIST = 32506, MAX_MATCH = 258, MIN_MATCH = 3, TOO_FAR = 4096, BLOCK_TOKENS = 16384 };
 enum : int { LIT_NUM = 286, DIST_NUM = 30, BL_NUM = 19 };
 
-struct LevelParams { int good, nice, max_chain, strategy; };
+// fast != 0: DeflateFast (levels 1-4): max_lazy is the longest match whose interior is still inserted (:697)
+struct LevelParams { int good, nice, max_chain, strategy, max_lazy, fast; };
 
 // Stage-B output: two u32 arrays (len | dist<<16) indexed like the input buffer.
 struct MTab {
@@ -34,14 +35,15 @@ struct SegDev {
     uint32_t bnd_cnt;
     uint32_t finish;     // segment closed by Finish() (else by Flush())
     uint32_t flags;      // SEG_* below
-    uint64_t range_off;  // first stage-C range of this segment
+    uint64_t range_off;  // first stage-C range of this segment (DeflateFast: index of the segment's first token)
     uint32_t range_cnt;
     uint32_t hdr_word;   // SEG_ZLIB_HEADER: the 16-bit zlib header; SEG_GZIP: MTIME of the member header
     uint64_t out_off;    // output arena offset of this segment's output region
     uint64_t out_cap;    // bytes
     uint32_t start_bit;  // bit offset inside the region at which this segment's first block starts
     uint32_t stream_idx; // caller's stream index (results)
-    uint64_t vis_word_off; // first 32-bit word of this segment's `visited` bitmap (bit i = position seg_start+i)
+    uint64_t vis_word_off; // first 32-bit word of this segment's `visited` bitmap (bit i = position seg_start+i);
+                           // DeflateFast: of its "inserted" bitmap (bit q = buffer position q)
     uint32_t adler_init;   // running Adler32.Value before this segment's bytes (zlib framing)
     uint32_t crc_init;     // running Crc32.Value before this segment's bytes
 };

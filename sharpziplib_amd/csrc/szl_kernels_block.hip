@@ -40,13 +40,14 @@ __device__ __forceinline__ void static_lit(int sym, uint32_t &code, int &len) { 
     else { code = bitrev16((0x0c0 - 280 + sym) << 8); len = 8; }
 }
 
-__global__ void k_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so) {
+__global__ void k_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so, int fast) {
     uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
     if (si >= nseg) return;
     const uint64_t T = so[si].tok_count;
     uint64_t full = T / BLOCK_TOKENS, rem = T % BLOCK_TOKENS;
     uint64_t nb = full;
     if (rem > 0 || T == 0) nb++;
+    else if (fast) { if (!segs[si].finish) nb++; } // DeflateFast: the full block was the last one iff finishing (:729); a flush adds an empty block (:664)
     else if ((tokens[so[si].tok_first + T - 1] >> 16) != 0 && !segs[si].finish) nb++; // sync flush right after a full block
     so[si].blk_first = (uint32_t)blk_off[si];
     so[si].blk_count = (uint32_t)nb;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
                                                            const uint32_t *__restrict__ tokens,
                                                            const int64_t *__restrict__ blk_start_pos,
                                                            const int64_t *__restrict__ blk_lasttok_pos, BlockDesc *descs,
-                                                           uint32_t nblk_slots) {
+                                                           uint32_t nblk_slots, int fast) {
     __shared__ int lfreq[LIT_NUM + 2], dfreq[DIST_NUM + 2], blfreq[BL_NUM + 1];
     __shared__ unsigned char llen[LIT_NUM + 2], dlen[DIST_NUM + 2], bllen[BL_NUM + 1];
     __shared__ int lblc[15], dblc[15], blblc[15];
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
             int64_t u = blk_lasttok_pos[gb];
             int64_t sIter = u + 1 < s.seg_end - 1 ? u + 1 : s.seg_end - 1;
             int64_t base = base_of_b((int64_t)s.abs0 + sIter);
+            if (fast) base = u; // DeflateFast: k_fast recorded the window base at FlushBlock time in this table
             storedOffsetOk = ((int64_t)s.abs0 + in_start + 1 - base) >= 0;
         }
         int type;
@@ -623,12 +625,12 @@ void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint3
 }
 
 void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, tokens, blk_off, so);
+                       int fast, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, tokens, blk_off, so, fast);
 }
 void launch_block_build(const SegDev *segs, uint32_t nseg, const SegOut *so, const uint64_t *blk_off, const uint32_t *tokens,
-                        const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, hipStream_t st) {
-    if (nslots) hipLaunchKernelGGL(k_block_build, dim3(nslots), dim3(D_THREADS), 0, st, segs, nseg, so, blk_off, tokens, bsp, blp, descs, nslots);
+                        const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, int fast, hipStream_t st) {
+    if (nslots) hipLaunchKernelGGL(k_block_build, dim3(nslots), dim3(D_THREADS), 0, st, segs, nseg, so, blk_off, tokens, bsp, blp, descs, nslots, fast);
 }
 void launch_block_scan(const SegDev *segs, uint32_t nseg, SegOut *so, BlockDesc *descs, hipStream_t st) {
     hipLaunchKernelGGL(k_block_scan, dim3(nseg), dim3(64), 0, st, segs, nseg, so, descs);

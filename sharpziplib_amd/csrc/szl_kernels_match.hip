@@ -203,14 +203,16 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     if (threadIdx.x == 0) *s_counter = 0;
     __syncthreads();
 
-    auto ldsdw = [&](int i) -> uint32_t { // unaligned 32-bit read at LDS data byte i
+    // Unaligned 32-bit read at LDS data byte i from two aligned dwords.  (gfx950 LDS does accept unaligned
+    // ds_read_b32 / ds_read_u16, but measured slower here: the kernel is co-limited by LDS bank conflicts.)
+    auto ldsdw = [&](int i) -> uint32_t {
         uint32_t w0 = sdata32[i >> 2], w1 = sdata32[(i >> 2) + 1];
         return __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(i & 3));
     };
     const uint8_t *sdata8 = smem;
 
     // Three phases per outer iteration, each a tight loop of its own so that the hot one (the chain step, ~80 % of
-    // all lane-steps) is a couple of dozen instructions: FETCH hands out positions, QUICK walks chains — one byte
+    // all lane-steps) is a couple of dozen instructions: FETCH hands out positions, QUICK walks chains — two bytes
     // (quick reject at offset `best`, :505) and one u16 (the candidate's link) from LDS per step — until too many
     // lanes have dropped out, VERIFY compares the candidates that passed the quick test dword by dword.
     // Window base (App. A.2) for the first and last position of the tile; inside a tile it changes at most once.
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
             }
             continue;
         }
-        // ---------------- QUICK: chain steps (branch-free body: one byte + one u16 from LDS, a dozen VALU), 4 per visit
+        // ---------------- QUICK: chain steps (branch-free body: two u16 from LDS, a dozen VALU), 4 per visit
 #pragma unroll
         for (int u = 0; u < 4; u++)
         if (mode == QUICK) {

@@ -37,7 +37,7 @@ CLASSES = {
 
 
 @pytest.mark.parametrize("name", sorted(CLASSES))
-@pytest.mark.parametrize("level", [5, 6, 7, 8, 9])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_batch_bit_exact_vs_oracle(eng, name, level):
     data = CLASSES[name]()
     r = eng.deflate([data], level=level, crc32=True, adler32=True)[0]
@@ -73,40 +73,45 @@ def test_tiny_vectors(eng, data, hexout):
                                65273, 65274, 65275, 65536, 98041, 98042, 131072])
 def test_boundary_sizes(eng, n):
     data = C.generate("dickens", 21, 0, n) if n else np.zeros(0, np.uint8)
-    for lv in (6, 9):
+    for lv in (1, 3, 6, 9):
         assert eng.deflate([data], level=lv)[0].data == O.deflate(data, lv)
 
 
 def test_token_block_multiple_edges(eng):
     r = C.random_bytes(16384 * 2)
-    for n in (16384, 16385, 32768):
-        assert eng.deflate([r[:n]], level=6)[0].data == O.deflate(r[:n], 6)
+    for lv in (1, 4, 6):   # DeflateFast and DeflateSlow close a full token buffer differently (:727-736 vs :841-852)
+        for n in (16384, 16385, 32768):
+            assert eng.deflate([r[:n]], level=lv)[0].data == O.deflate(r[:n], lv)
+            assert eng.deflate([r[:n]], level=lv, sync_flush_before_finish=True)[0].data == O.deflate(r[:n], lv, flush=True)
     base = C.random_bytes(16383, seed=5)
     data = np.concatenate([base, base[:300]])
     for cut in range(16383 + 3, 16383 + 300, 37):
         d = data[:cut]
-        assert eng.deflate([d], level=6)[0].data == O.deflate(d, 6)
-        assert eng.deflate([d], level=6, sync_flush_before_finish=True)[0].data == O.deflate(d, 6, flush=True)
+        for lv in (2, 6):
+            assert eng.deflate([d], level=lv)[0].data == O.deflate(d, lv)
+            assert eng.deflate([d], level=lv, sync_flush_before_finish=True)[0].data == O.deflate(d, lv, flush=True)
 
 
 def test_many_small_streams_batch(eng):
     """config 3 shape: many independent streams in one call (ZipOutputStream entries)."""
     bufs = [C.generate("dickens", 0x21B0 + i, 0, 65536) for i in range(48)]
     bufs += [C.random_bytes(1000 + 37 * i, seed=i) for i in range(8)] + [np.zeros(0, np.uint8), C.zeros(70000), b"x"]
-    res = eng.deflate(bufs, level=6, crc32=True)
-    for b, r in zip(bufs, res):
-        assert r.data == O.deflate(b, 6) and r.crc32 == O.crc32(b)
+    for lv in (6, 1):
+        res = eng.deflate(bufs, level=lv, crc32=True)
+        for b, r in zip(bufs, res):
+            assert r.data == O.deflate(b, lv) and r.crc32 == O.crc32(b)
 
 
 @pytest.mark.parametrize("strategy", [1, 2])
 def test_strategies(eng, strategy):
     data = C.mixed(400000, seed=9)
-    assert eng.deflate([data], level=6, strategy=strategy)[0].data == O.deflate(data, 6, strategy=strategy)
+    for lv in (6, 3):
+        assert eng.deflate([data], level=lv, strategy=strategy)[0].data == O.deflate(data, lv, strategy=strategy)
 
 
 def test_zlib_framing(eng):
     data = C.generate("logs", 5, 0, 300000)
-    for lv in (5, 6, 9):
+    for lv in (1, 2, 4, 5, 6, 9):
         r = eng.deflate([data], level=lv, nowrap=False)[0]
         assert r.data == O.deflate(data, lv, nowrap=False)
         assert zlib.decompress(r.data) == data.tobytes()
@@ -121,6 +126,20 @@ def test_stage_intermediates_match_model(eng):
     assert np.array_equal(link, M.link[:data.size])
     assert np.array_equal(m2, M.m2[:data.size]) and np.array_equal(mq, M.mq[:data.size])
     ref, tr = O.deflate(data, 6, trace=True)
+    assert np.array_equal(tok, tr["tokens"])
+    blocks = eng.debug_blocks()
+    assert [(b["type"], b["last"], b["ntokens"], b["bit_start"], b["opt_len"], b["static_len"], b["stored_len"]) for b in blocks] == \
+           [(b["type"], b["last"], b["ntokens"], b["bit_start"], b["opt_len"], b["static_len"], b["stored_len"]) for b in tr["blocks"]]
+    assert r.data == ref
+
+
+@pytest.mark.parametrize("level", [1, 4])
+def test_fast_levels_tokens_and_blocks_match_oracle_trace(eng, level):
+    """DeflateFast (C/DeflaterEngine.cs:651-739): the device's sequential-per-stream parse against the oracle's token and block trace."""
+    data = np.concatenate([C.mixed(500000, seed=6), C.zeros(70000), C.generate("logs", 3, 0, 200000)])
+    r = eng.deflate([data], level=level)[0]
+    _, _, _, tok = eng.debug_fetch(data.size)
+    ref, tr = O.deflate(data, level, trace=True)
     assert np.array_equal(tok, tr["tokens"])
     blocks = eng.debug_blocks()
     assert [(b["type"], b["last"], b["ntokens"], b["bit_start"], b["opt_len"], b["static_len"], b["stored_len"]) for b in blocks] == \
@@ -143,7 +162,7 @@ def _deflate_like_reference_test(data, level, zlib_framing):
     return ms.getvalue(), d
 
 
-@pytest.mark.parametrize("level", [5, 6, 7, 8, 9])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("zlib_framing", [True, False])
 def test_random_deflate_inflate_reference_pattern(level, zlib_framing):
     data = O.dotnet_random_bytes(5, 100000)   # Utils.GetDummyBytes(100000, seed 5)
@@ -188,8 +207,11 @@ def test_deflater_state_errors():
     out = np.zeros(64, np.uint8)
     n = d.Deflate(out)
     assert out[:n].tobytes() == O.deflate(b"abc", 6) and d.IsFinished
+    d = Deflater(1, True)     # DeflateFast -> DeflateSlow mid-stream changes what the hash chains hold: not reproducible here
+    d.SetInput(b"abcabcabc"); d.Flush()
+    d.Deflate(out)
     with pytest.raises(NotSupportedOnDevice):
-        Deflater(1, True)     # DeflateFast (levels 1-4) is the one engine mode not on the device yet
+        d.SetLevel(6)
 
 
 def test_streaming_random_chunks_and_flushes():
@@ -198,7 +220,7 @@ def test_streaming_random_chunks_and_flushes():
     rng = np.random.default_rng(12345)
     data = C.mixed(400000, seed=77)
     for trial in range(6):
-        level = int(rng.choice([5, 6, 9]))
+        level = int(rng.choice([1, 3, 4, 5, 6, 9]))
         d = Deflater(level, True)
         o = O.Deflater(level, True)
         got, ref = bytearray(), bytearray()
@@ -275,12 +297,14 @@ def test_flush_after_every_small_write():
     assert zlib.decompress(bytes(got), -15) == data.tobytes()
 
 
-def test_history_across_window_slides():
-    """Segments longer than the 64 KiB window so that base_of() and the retained history are exercised."""
+@pytest.mark.parametrize("level", [9, 2])
+def test_history_across_window_slides(level):
+    """Segments longer than the 64 KiB window so that base_of() and the retained history are exercised
+    (levels 1-4: also the "inserted" bits carried from one segment to the next)."""
     from sharpziplib_amd.deflater import Deflater
     data = C.generate("enwik", 31, 0, 700000)
     cuts = [65273, 65274, 65275, 98041, 163840, 300001, 700000]
-    d = Deflater(9, True); o = O.Deflater(9, True)
+    d = Deflater(level, True); o = O.Deflater(level, True)
     got, ref = bytearray(), bytearray()
     buf = np.zeros(65536, np.uint8)
     prev = 0
@@ -379,7 +403,7 @@ def test_level0_streaming_chunk_dependence():
 
 
 # ---- preset dictionary (zlib framing): Deflater.SetDictionary C/Deflater.cs:559, Inflater.SetDictionary C/Inflater.cs:563
-@pytest.mark.parametrize("level", [0, 6, 9])
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
 @pytest.mark.parametrize("dlen", [2, 3, 500, 32506, 40000])
 def test_preset_dictionary_roundtrip(level, dlen):
     from sharpziplib_amd.deflater import Deflater
