@@ -7,6 +7,7 @@
 // so they are computed for every position in parallel; the lazy parse (stage C) only looks results up.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstdint>
 #include "szl_internal.h"
 
 namespace szl {
@@ -131,6 +132,150 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
                 if (!islast || predlane >= 0 || rb != myq16) { if (islast) head[idx] = (uint16_t)myq16; }
             } else if (idx == 0xFFFF && wave == 0 && q >= span.start && q < span.end) {
                 lk[q] = 0; // position never inserted (tail of a segment)
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// Stage A, compacted form (default).  Same partition of the head table, but instead of every wavefront scanning
+// all 1024 positions of a chunk for the ~64 it owns (6 % lane use), the chunk is first bucketed by owner:
+//   phase 1  wave w hashes its 64 positions; 16 ballots give, per owner, this wave's count and every lane's rank;
+//   (barrier) every wave scans the 16x16 count table privately (owner-major) -> list offsets; lanes scatter
+//            (position, bucket) into one 1024-entry list, grouped by owner, in position order;
+//   (barrier) phase 2  owner wave o walks ITS group (≈64 entries, dense lanes) with the same store/read-back
+//            protocol as above.
+// Lists and counts are double-buffered, so a chunk costs two barriers and ≈3.5x fewer wave instructions.
+// ============================================================================================
+__global__ __launch_bounds__(A_THREADS) void k_links2(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                      const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
+                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link) {
+    __shared__ uint16_t head[32768];
+    __shared__ uint32_t cnt[2][A_WAVES * 16];  // [owner*16 + wave] = positions of that wave's slice owned by `owner`
+    __shared__ uint32_t list[2][A_THREADS];    // (position in chunk) << 16 | bucket (11 bits), grouped by owner
+    const SpanDev span = spans[blockIdx.x];
+    const SegDev seg = segs[span.seg];
+    const uint8_t *d = in + seg.buf_off;
+    uint16_t *lk = link + seg.buf_off;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t warm0 = span.start - WSIZE > 0 ? span.start - WSIZE : 0;
+    const uint64_t avail = in_total - seg.buf_off;
+
+    uint16_t *myhead = head + wave * 2048;
+    for (int i = lane; i < 2048; i += 64) myhead[i] = (uint16_t)((warm0 - 40000) & 0xFFFF);
+
+    const uint64_t *b = bnds + seg.bnd_off;
+    const int nb = (int)seg.bnd_cnt;
+    int bi = 0;
+    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // The chunk's bytes are fetched one chunk ahead (a span is walked strictly in order by one workgroup, so the
+    // HBM latency of a just-in-time load would be paid 2048 times per 2 MiB span), and the next segment boundary is
+    // kept in a register.
+    auto fetch = [&](int64_t qn) -> uint32_t { return (qn < span.end && (uint64_t)qn + 4 <= avail) ? load_u32_unaligned(d + qn) : 0u; };
+    uint32_t wnext = fetch(warm0 + threadIdx.x);
+    int64_t bcur = bi < nb ? (int64_t)b[bi] : INT64_MAX;
+    int buf = 0;
+    for (int64_t c0 = warm0; c0 < span.end; c0 += A_THREADS, buf ^= 1) {
+        const uint32_t wcur = wnext;
+        wnext = fetch(c0 + A_THREADS + threadIdx.x);
+        if (c0 != warm0 && ((c0 - warm0) & 16383) == 0) {
+            for (int i = lane; i < 2048; i += 64) {
+                uint32_t dist = (uint32_t)(c0 - myhead[i]) & 0xFFFF;
+                if (dist >= 32768u || dist == 0u) myhead[i] = (uint16_t)((c0 - 40000) & 0xFFFF);
+            }
+        }
+        // ---- phase 1: hash my position, rank it among this wave's positions of the same owner
+        const int64_t q = c0 + threadIdx.x;
+        while (bcur <= c0) { bi++; bcur = bi < nb ? (int64_t)b[bi] : INT64_MAX; } // uniform
+        bool ins = q < span.end;
+        if (bi >= nb) ins = false;
+        else if (bcur < c0 + A_THREADS + 2) { // a segment end is near: InsertString needs lookahead >= 3 (:780,:817)
+            int j = bi;
+            while (j < nb && (int64_t)b[j] <= q) j++;
+            ins = ins && j < nb && (int64_t)b[j] - q >= 3;
+        }
+        uint32_t owner = 16, bucket = 0;
+        if (ins) {
+            uint32_t w = wcur;
+            if ((uint64_t)q + 4 > avail) w = (uint32_t)d[q] | ((uint32_t)d[q + 1] << 8) | ((uint32_t)d[q + 2] << 16);
+            const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
+            const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
+            owner = (h ^ (h >> 5) ^ (h >> 10)) & 15;                   // owner wavefront (bijective with h>>4)
+            bucket = h >> 4;
+        } else if (q >= span.start && q < span.end) {
+            lk[q] = 0; // position never inserted (tail of a segment)
+        }
+        uint32_t rank = 0, mycnt = 0;
+#pragma unroll
+        for (int o = 0; o < 16; o++) {
+            const uint64_t m = __ballot(owner == (uint32_t)o);
+            if (owner == (uint32_t)o) rank = (uint32_t)__builtin_popcountll(m & lanemask_lt);
+            if (lane == o) mycnt = (uint32_t)__builtin_popcountll(m);
+        }
+        if (lane < 16) cnt[buf][lane * 16 + wave] = mycnt;
+        __syncthreads();
+        // ---- private exclusive scan of the 256 counts in owner-major order: lane l holds elements 4l..4l+3 (all of owner l>>2)
+        uint32_t c4[4], e4[4];
+        {
+            const uint4 v = *(const uint4 *)&cnt[buf][4 * lane];
+            c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w;
+            uint32_t sum = c4[0] + c4[1] + c4[2] + c4[3], incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            uint32_t ex = incl - sum;
+            e4[0] = ex; e4[1] = ex + c4[0]; e4[2] = e4[1] + c4[1]; e4[3] = e4[2] + c4[2];
+        }
+        { // my slot: element owner*16 + wave, held by lane (owner*4 + wave/4), component wave&3 (shuffles stay convergent)
+            const int src = owner < 16 ? (int)owner * 4 + (wave >> 2) : 0;
+            const uint32_t a0 = __shfl(e4[0], src), a1 = __shfl(e4[1], src), a2 = __shfl(e4[2], src), a3 = __shfl(e4[3], src);
+            const int comp = wave & 3;
+            const uint32_t base = comp == 0 ? a0 : (comp == 1 ? a1 : (comp == 2 ? a2 : a3));
+            if (owner < 16) list[buf][base + rank] = ((uint32_t)threadIdx.x << 16) | bucket;
+        }
+        // my group as owner wave: elements [wave*16, wave*16+16) = lanes 4*wave .. 4*wave+3
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)e4[0], 4 * wave);
+        const uint32_t g1 = wave == 15 ? (uint32_t)(__builtin_amdgcn_readlane((int)e4[3], 63) + __builtin_amdgcn_readlane((int)c4[3], 63))
+                                       : (uint32_t)__builtin_amdgcn_readlane((int)e4[0], 4 * (wave + 1) & 63);
+        __syncthreads();
+        // ---- phase 2: the positions whose bucket this wavefront owns, in position order, 64 at a time
+        for (uint32_t k0 = g0; k0 < g1; k0 += 64) {
+            const bool owned = k0 + lane < g1;
+            const uint32_t e = owned ? list[buf][k0 + lane] : 0u;
+            const int64_t qq = c0 + (int64_t)(e >> 16);
+            const uint32_t idx = ((uint32_t)wave << 11) | (e & 0x7FF);
+            const uint32_t myq16 = (uint32_t)qq & 0xFFFF;
+            uint32_t e_old = 0, rb = myq16;
+            if (owned) { // volatile: the read-back must really hit LDS (another lane of this wave may have overwritten it)
+                volatile uint16_t *vh = head;
+                e_old = vh[idx];
+                vh[idx] = (uint16_t)myq16;
+                rb = vh[idx];
+            }
+            int predlane = -1;
+            bool islast = true;
+            uint64_t mm = __ballot(owned && rb != myq16);
+            while (mm) {
+                int l = __builtin_ctzll(mm);
+                uint32_t kk = __builtin_amdgcn_readlane(idx, l);
+                bool mine = owned && idx == kk;
+                uint64_t same = __ballot(mine);
+                if (mine) {
+                    uint64_t below = same & lanemask_lt;
+                    predlane = below ? 63 - __builtin_clzll(below) : -1;
+                    islast = ((same >> lane) >> 1) == 0;
+                }
+                mm &= ~same;
+            }
+            if (owned) {
+                uint32_t dist;
+                if (predlane >= 0) { // previous owned lane with my bucket: its position comes from its list entry
+                    const uint32_t pe = list[buf][k0 + predlane];
+                    dist = (uint32_t)((e >> 16) - (pe >> 16));
+                } else dist = (uint32_t)(qq - e_old) & 0xFFFF;
+                if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
+                if (qq >= span.start) lk[qq] = (uint16_t)dist;
+                if (!islast || predlane >= 0 || rb != myq16) { if (islast) head[idx] = (uint16_t)myq16; }
             }
         }
     }
@@ -352,7 +497,10 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
 
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
                   int nspans, uint16_t *link, hipStream_t st) {
-    if (nspans > 0) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
+    static const bool v1 = getenv("SZL_LINKS") && atoi(getenv("SZL_LINKS")) == 1;
+    if (nspans <= 0) return;
+    if (v1) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
+    else hipLaunchKernelGGL(k_links2, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
 }
 
 int match_lds_bytes() { return B_LDS_BYTES; }
