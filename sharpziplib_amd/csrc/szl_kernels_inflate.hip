@@ -7,10 +7,12 @@
 //   code construction                                  C/InflaterHuffmanTree.cs:87-169 (canonical, LSB-first lookup)
 //   32 KiB output window with overlap-safe repeat       CS/OutputWindow.cs:63-92
 // The decoder is resumable at any token (NEED_INPUT / OUTPUT_FULL) like the reference's 13-mode state machine;
-// its persistent state lives in InfState.  Decoding a Huffman stream is bit-serial, so lane 0 decodes while the
-// other 63 lanes of the wavefront do the data movement (match copies inside the LDS window, window flushes to
-// HBM, input staging, table construction); independent streams (zip entries, gzip members) run on other
-// wavefronts — 4 per CU, bounded by the 32 KiB window each keeps in LDS.
+// its persistent state lives in InfState.  Inside a Huffman block the wavefront decodes speculatively: every lane
+// decodes the token that would start at its bit offset of a 128-bit span and a readlane walk picks the real token
+// starts; block headers, long codes, stored blocks and stream ends go through lane 0's careful path.  All lanes
+// do the data movement (match copies inside the LDS window, window flushes to HBM, input staging, table
+// construction); independent streams (zip entries, gzip members) run on other wavefronts — 4 per CU, bounded
+// by the 32 KiB window each keeps in LDS.
 #include <hip/hip_runtime.h>
 #include "szl_internal.h"
 #include "szl_inflate.h"
@@ -190,78 +192,100 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     };
 
     enum { EV_NONE = 0, EV_RESTAGE, EV_TABLES, EV_STORED, EV_STOP };
-    enum { QN = 64 };
+    enum { QN = 64, PAR_W = 128, PAR_BYTES = PAR_W / 8 + 24 }; // bytes the parallel round may touch from its first byte on
     // Decode state (bit buffer, block mode, table sizes) is private to lane 0.  Each round lane 0 decodes up to 64
     // tokens into an LDS queue; then the whole wavefront applies them (prefix sum of lengths, literals in parallel,
     // matches in order with all lanes copying), flushes the window when half full, and services lane 0's request.
     while (status == INF_RUNNING) {
         int ev = EV_NONE, ea = 0, eb = 0, ntok = 0;
+        // ---------------- wave-parallel round (the common case inside a Huffman block)
+        // Every lane decodes the complete token that WOULD start at two bit offsets of a 128-bit span (offset = lane,
+        // lane+64): literal/length code through the primary table, length extra bits, distance code, distance extra bits
+        // (C/Inflater.cs:283-386).  Which offsets really are token starts is then a walk from offset 0 over the decoded
+        // bit counts, done with readlane (no memory traffic): one round yields ~9 tokens on text instead of lane 0
+        // crawling through them.  Anything unusual at a real token start — code longer than the primary table, end of
+        // block, an invalid code — stops the walk there and is left to the careful single-token path below.
+        bool par_ok = false;   // preconditions of the parallel round held (then the careful path handles one token only)
+        uint64_t par_bitpos = 0;
+        {
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
+            const uint64_t P = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bitpos >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bitpos);
+            if (m0 == INF_M_HUFF && sbase != ~0ull) {
+                const uint64_t byte0 = P >> 3;
+                const uint64_t availb = in_bits > P ? in_bits - P : 0;
+                const uint64_t room_lim = flushed + (I_WIN - 300);
+                const uint64_t olim = out_limit < room_lim ? out_limit : room_lim;
+                par_ok = byte0 >= sbase && byte0 + PAR_BYTES <= sbase + I_STAGE && availb >= (uint64_t)(PAR_W + 64) &&
+                         outpos + (uint64_t)QN * MAX_MATCH_I <= olim;
+                if (!par_ok && byte0 >= sbase + 256 && byte0 + PAR_BYTES > sbase + I_STAGE && byte0 + PAR_BYTES <= job.in_len) {
+                    // the staged input is nearly used up: slide it (cooperative) instead of crawling through the careful loop
+                    ev = EV_RESTAGE; ea = (int)(uint32_t)byte0; eb = (int)(uint32_t)(byte0 >> 32);
+                }
+            }
+            if (par_ok) {
+                uint32_t nbits[2], tokv[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const uint64_t bp = P + (uint32_t)(lane + 64 * jj);
+                    const uint32_t so = (uint32_t)((bp >> 3) - sbase);
+                    const uint32_t w0 = S.stage[so >> 2], w1 = S.stage[(so >> 2) + 1], w2 = S.stage[(so >> 2) + 2];
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, so & 3), hi = __builtin_amdgcn_alignbyte(w2, w1, so & 3);
+                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (uint32_t)(bp & 7); // >= 57 stream bits from bp on
+                    const uint32_t e = S.llut[(uint32_t)bits & ((1u << I_LPB) - 1)];
+                    const uint32_t sl = e & 15, sym = e >> 4;
+                    uint32_t nbv = 0, tk = 0;
+                    if (e - 1 < 0xFFFDu) { // neither invalid (0) nor a long code (0xFFFE)
+                        if (sym < 256) { nbv = sl; tk = sym; }
+                        else if (sym > 256 && sym <= 285) {
+                            const uint32_t ls = sym - 257;
+                            const uint32_t xl = (ls < 8 || ls == 28) ? 0u : ((ls - 4) >> 2);             // CPLEXT :44-48
+                            const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << xl)); // CPLENS :39-43
+                            uint64_t tb = bits >> sl;
+                            const uint32_t len = lbase + ((uint32_t)tb & ((1u << xl) - 1));
+                            tb >>= xl;
+                            const uint32_t de = S.dlut[(uint32_t)tb & ((1u << I_DPB) - 1)];
+                            const uint32_t dl = de & 15, dsym = de >> 4;
+                            if (de - 1 < 0xFFFDu && dsym < 30) {
+                                tb >>= dl;
+                                const uint32_t xd = dsym < 4 ? 0u : ((dsym >> 1) - 1);                 // CPDEXT :62-68
+                                const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << xd); // CPDIST :50-60
+                                const uint32_t dist = dbase + ((uint32_t)tb & ((1u << xd) - 1));
+                                nbv = sl + xl + dl + xd;
+                                tk = len | (dist << 16);
+                            }
+                        }
+                    }
+                    nbits[jj] = nbv; tokv[jj] = tk;
+                }
+                uint32_t o = 0;
+                while (ntok < QN && o < (uint32_t)PAR_W) {
+                    const int l = (int)(o & 63);
+                    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nbits[0], l), n1 = (uint32_t)__builtin_amdgcn_readlane((int)nbits[1], l);
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[0], l), t1 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[1], l);
+                    const uint32_t nx = o < 64 ? n0 : n1, tk = o < 64 ? t0 : t1;
+                    if (nx == 0) break;
+                    if (lane == 0) S.queue[ntok] = tk;
+                    ntok++;
+                    o += nx;
+                }
+                par_bitpos = P + o;
+            }
+        }
+        const int npar = ntok;
         if (lane == 0) {
             uint64_t opos = outpos;                       // position after the queued tokens
             const uint64_t room_lim = flushed + (I_WIN - 300);
-            // ---- fast round: when the staged input, the remaining input, the output limit and the window room all
-            // cover the worst case of a full queue (64 tokens x 48 bits, 64 x 258 bytes), tokens are decoded with no
-            // per-token limit checks; anything unusual (long codes, end of block, errors) falls through to the careful loop.
-            if (mode == INF_M_HUFF && sbase != ~0ull) {
-                const uint64_t bytepos0 = (bitpos + nb) >> 3;
-                if (bytepos0 + QN * 6 + 16 > sbase + I_STAGE && bytepos0 >= sbase + 256 && bytepos0 + QN * 6 + 16 <= job.in_len) {
-                    // the staged window is nearly used up: slide it now (cheap, cooperative) instead of crawling through the careful loop
-                    ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32);
-                }
-                const uint64_t availb = in_bits > bitpos ? in_bits - bitpos : 0;
-                const uint64_t olim = out_limit < room_lim ? out_limit : room_lim;
-                if (ev == EV_NONE && bytepos0 >= sbase && bytepos0 + QN * 6 + 16 <= sbase + I_STAGE && availb >= (uint64_t)(QN * 48 + 64) &&
-                    opos + (uint64_t)QN * MAX_MATCH_I <= olim) {
-                    uint32_t so = (uint32_t)(bytepos0 - sbase); // stage offset of the next unread byte
-                    uint32_t used = 0;                          // bits consumed in this round
-                    uint32_t olen = 0;
-                    while (ntok < QN) {
-                        if (nb <= 32) { // one 32-bit refill
-                            uint32_t w0 = S.stage[so >> 2], w1 = S.stage[(so >> 2) + 1];
-                            bb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, so & 3) << nb;
-                            nb += 32; so += 4;
-                        }
-                        const uint32_t e = S.llut[(uint32_t)bb & ((1u << I_LPB) - 1)];
-                        if (e - 1 >= 0xFFFDu) break;                  // invalid (0) or long code (0xFFFE): careful loop
-                        const uint32_t sl = e & 15, sym = e >> 4;
-                        if (sym < 256) {
-                            bb >>= sl; nb -= (int)sl; used += sl;
-                            S.queue[ntok++] = sym; olen++;
-                            continue;
-                        }
-                        if (sym == 256 || sym > 285) break;           // end of block / illegal: careful loop
-                        const uint32_t ls = sym - 257;
-                        const uint32_t xl = (ls < 8 || ls == 28) ? 0u : ((ls - 4) >> 2);
-                        const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << xl));
-                        uint64_t tb = bb >> sl;
-                        int tn = nb - (int)sl;
-                        const uint32_t len = lbase + ((uint32_t)tb & ((1u << xl) - 1));
-                        tb >>= xl; tn -= (int)xl;
-                        uint32_t so2 = so;
-                        if (tn < 28) {
-                            uint32_t w0 = S.stage[so2 >> 2], w1 = S.stage[(so2 >> 2) + 1];
-                            tb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, so2 & 3) << tn;
-                            tn += 32; so2 += 4;
-                        }
-                        const uint32_t de = S.dlut[(uint32_t)tb & ((1u << I_DPB) - 1)];
-                        if (de - 1 >= 0xFFFDu) break;
-                        const uint32_t dl = de & 15, dsym = de >> 4;
-                        if (dsym >= 30) break;
-                        tb >>= dl; tn -= (int)dl;
-                        const uint32_t xd = dsym < 4 ? 0u : ((dsym >> 1) - 1);
-                        const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << xd);
-                        const uint32_t dist = dbase + ((uint32_t)tb & ((1u << xd) - 1));
-                        tb >>= xd; tn -= (int)xd;
-                        used += sl + xl + dl + xd;
-                        bb = tb; nb = tn; so = so2;
-                        S.queue[ntok++] = len | (dist << 16); olen += len;
-                    }
-                    bitpos += used;
-                    opos += olen;
-                }
+            if (npar > 0) { // adopt the parallel round's result: new bit position, bit buffer re-primed (possibly mid-byte)
+                bitpos = par_bitpos;
+                const uint32_t o2 = (uint32_t)((bitpos >> 3) - sbase);
+                const uint32_t w0 = S.stage[o2 >> 2], w1 = S.stage[(o2 >> 2) + 1];
+                const uint32_t sh = (uint32_t)(bitpos & 7);
+                bb = (uint64_t)(__builtin_amdgcn_alignbyte(w1, w0, o2 & 3) >> sh); nb = 32 - (int)sh;
             }
+            const int careful_cap = npar > 0 ? npar : (par_ok ? 1 : QN); // after a parallel round: nothing more this round
             for (;;) {
-                if (ntok == QN || ev != EV_NONE) break;
+                if (ntok >= careful_cap || ev != EV_NONE) break;
                 const uint64_t bytepos = (bitpos + nb) >> 3;
                 if (!stage_ok(bytepos)) { ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break; }
                 refill();
