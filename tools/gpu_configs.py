@@ -1,5 +1,5 @@
 """Exercise the other BASELINE configs at reduced/full size on the GPU box (timings + correctness spot checks)."""
-import sys, ctypes, time, zlib
+import sys, ctypes, time, zlib, os
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np
 import oracle_ffi as O
@@ -10,7 +10,7 @@ eng = Engine()
 which = sys.argv[1:] or ['c3', 'c4', 'c5']
 
 if 'c3' in which:   # many small streams: N x 64 KiB
-    N = int(20000)
+    N = int(os.environ.get('SZL_C3_N', '20000'))
     t = time.time(); data = C.generate('dickens', 0x21B0, 0, N * 65536); print(f'gen {time.time()-t:.1f}s', flush=True)
     arr, in_total, out_total = Engine.layout([65536] * N)
     hout = np.zeros(out_total + 8, np.uint8)
