@@ -140,22 +140,29 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
             const int64_t basem = base - (int64_t)s.abs0;                            // buffer position of window index 0
             const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
             const int nice = rem < (int64_t)P.nice ? (int)rem : P.nice;
-            // hashHead: newest INSERTED position of this hash
+            // One LDS round trip per chain hop: the hop's link, its inserted bit and its bytes (lane i: bytes 4i..4i+3,
+            // compared against the position's own bytes fetched once) are requested together.
+            const uint32_t off = 4u * (uint32_t)lane;
+            const uint32_t xdw = ldsdw((uint32_t)x + off);
+            int lnk = rfl((int)S.link[(uint32_t)x & (F_LINKS - 1)]);
             int64_t c = x;
-            bool have = false;
-            for (;;) {
-                const int l = rfl((int)S.link[(uint32_t)c & (F_LINKS - 1)]);
-                if (l == 0) break;
-                c -= l;
-                if (x - c > MAX_DIST) break;              // :687
-                if (c + 1 - basem < 1) break;             // head entry clamped by a slide :450-461
-                if (rfl(flag_get(c))) { have = true; break; }
-            }
+            bool first = true;   // still looking for hashHead, the newest INSERTED position of this hash (:686)
             int budget = P.max_chain;
-            while (have) {
+            for (;;) {
+                if (lnk == 0) break;
+                c -= lnk;
+                if (first) {
+                    if (x - c > MAX_DIST) break;              // strstart - hashHead <= MAX_DIST :687 (older hops are farther still)
+                    if (c + 1 - basem < 1) break;             // head entry clamped to 0 by a slide :450-461
+                } else if (c + 1 - basem <= limit_idx) break; // (curMatch = prev[..]) > limit :609
+                const uint32_t l2 = S.link[(uint32_t)c & (F_LINKS - 1)];
+                const uint32_t fw = S.flag[((uint32_t)c >> 5) & (F_FLAGW - 1)];
+                const uint32_t cdw = ldsdw((uint32_t)c + off);
+                lnk = rfl((int)l2);
+                if (((rfl((int)fw) >> ((uint32_t)c & 31)) & 1) == 0) continue; // never inserted: not part of the reference's chain
+                first = false;
                 // length of the common prefix of c and x, capped (:505-591)
-                const uint32_t off = 4u * (uint32_t)lane;
-                const uint32_t xr = ldsdw((uint32_t)c + off) ^ ldsdw((uint32_t)x + off);
+                const uint32_t xr = cdw ^ xdw;
                 const uint64_t ne = __ballot(xr != 0);
                 int L;
                 if (ne) {
@@ -174,19 +181,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
                     best = (uint32_t)L; bdist = (uint32_t)(x - c);
                     if (L >= nice) break; // :604
                 }
-                // curMatch = prev[curMatch]: next inserted position down the chain, while > limit (:609)
-                int64_t c2 = c;
-                bool found = false;
-                for (;;) {
-                    const int l = rfl((int)S.link[(uint32_t)c2 & (F_LINKS - 1)]);
-                    if (l == 0) break;
-                    c2 -= l;
-                    if (c2 + 1 - basem <= limit_idx) break;
-                    if (rfl(flag_get(c2))) { found = true; break; }
-                }
-                if (!found) break;
-                if (--budget == 0) break;
-                c = c2;
+                if (--budget == 0) break; // 0 != --chainLength :609
             }
         }
         // ---- token, inserted bits, advance (:689-725)
@@ -195,10 +190,12 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
         if (best >= MIN_MATCH) {
             tok = (bdist << 16) | best;
             const int ins = ((int)best <= P.max_lazy && rem - (int64_t)best >= MIN_MATCH) ? 1 : 0; // :697
-            flag_set(x, x + 1, 1);
-            // (two calls: the bits of x and of the interior can share a word, and flag_set gives each lane one word)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            flag_set(x + 1, x + best, ins);
+            if (ins) flag_set(x, x + best, 1);
+            else { // (two calls: the bits of x and of the interior can share a word, and flag_set gives each lane one word)
+                flag_set(x, x + 1, 1);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                flag_set(x + 1, x + best, 0);
+            }
             nx = x + best;
         } else {
             tok = (uint32_t)sdata8[(uint32_t)x & (F_DATA - 1)];
