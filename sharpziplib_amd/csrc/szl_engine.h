@@ -35,6 +35,10 @@ class Engine {
     szl_timing timing{};
     uint64_t last_nranges = 0, last_in_total = 0, last_blk_slots = 0;
     size_t last_mt_stride = 0;
+    // stage B on demand: positions evaluated by walkers / by the parse itself, pilot result, form used by the last call
+    uint64_t last_evaluated = 0, last_eval_fallbacks = 0;
+    double last_pilot_frac = -1.0;
+    bool last_lazy = false;
     // DeflateFast, single-segment calls (streaming Deflater): "inserted" bits of the buffer's history in (bit q = buffer
     // position q), and of the last 32 Ki positions out (bit 0 of fast_tail_bits = position fast_tail_start).
     std::vector<uint32_t> fast_hist_in, fast_tail_bits;

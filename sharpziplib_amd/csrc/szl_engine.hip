@@ -15,6 +15,8 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
                   uint16_t *link, hipStream_t st);
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
+hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
+                             const uint16_t *link, MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st);
 void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, hipStream_t st);
 void launch_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
@@ -115,6 +117,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     std::vector<TileDev> tiles;
     std::vector<uint64_t> chunk_off(nseg + 1);
     const bool fast = P.fast != 0;             // DeflateFast: one wavefront per segment instead of stages B and C
+    bool lazy = false;                         // stage B ran in its on-demand form
     std::vector<uint64_t> fast_blk_off;        // (its block slots are laid out here, not by a device scan)
     if (fast) fast_blk_off.resize(nseg + 1);
     for (uint32_t i = 0; i < nseg; i++) {
@@ -239,7 +242,31 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         HIPCHK(hipEventRecord(ev[4], st));
     } else {
     // B: match tables
-    HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
+    // Two forms of stage B (szl_kernels_match.hip): search every position, or only the positions a parse can reach.
+    // The second evaluates far fewer positions on repetitive data but each evaluation costs ~3x more, so a pilot on a
+    // sample of tiles measures the evaluated fraction first (results are identical either way).
+    static const int match_mode = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 2; // 0 full, 1 on demand, 2 pilot
+    static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.28; // break-even measured at ~1/3
+    last_pilot_frac = -1.0;
+    if (match_mode == 1 || (match_mode == 2 && ntiles >= 64)) { // (inputs under 1 MiB: not worth a pilot)
+        if (match_mode == 2) { // the pilot's own entries are overwritten by whichever form runs afterwards
+            const uint64_t step = ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8);
+            const int nb = (int)((ntiles + step - 1) / step);
+            uint64_t sampled = 0;
+            for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
+            HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)d_tiles.p, nb, 0, (int)step, (const uint16_t *)link.p, mt, P, dcnt, st));
+            unsigned long long ne = 0;
+            HIPCHK(hipMemcpyAsync(&ne, (unsigned long long *)counters.p + 6, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            last_pilot_frac = sampled ? (double)ne / (double)sampled : 1.0;
+            lazy = last_pilot_frac < lazy_max_frac;
+        } else lazy = true;
+        if (lazy) {
+            HIPCHK(hipMemsetAsync(mt.m2, 0xFF, mt_stride * 4, st)); // M_UNSET
+            HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, 0, 1, (const uint16_t *)link.p, mt, P, dcnt, st));
+        }
+    }
+    if (!lazy) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
     launch_spec(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
@@ -249,6 +276,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         unsigned long long nbad = 0;
         HIPCHK(hipMemcpyAsync(&nbad, counters.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (nbad > 0 && lazy) // ranges that never re-synchronise are chained position by position: evaluate everything first
+            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
         if (nbad > 0 && nbad <= 48) {
             launch_resolve(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
         } else if (nbad > 48) {
@@ -291,7 +320,9 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     timing.in_bytes = seg_bytes;
     timing.ranges_unmerged = hc[0];
     timing.fallback_walks = hc[1];
+    last_evaluated = hc[6]; last_eval_fallbacks = hc[7]; last_lazy = lazy;
     if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
+    if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] stage B %s (pilot fraction %.3f): %llu of %llu positions evaluated by walkers, %llu by the parse (eval_global), slow walks %llu, unmerged %llu\n", lazy ? "on demand" : "full", last_pilot_frac, hc[6], (unsigned long long)seg_bytes, hc[7], hc[1], hc[0]);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
     return 0;

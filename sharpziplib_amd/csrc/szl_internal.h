@@ -26,6 +26,8 @@ struct MTab {
     uint32_t *mq;
 };
 
+enum : uint32_t { M_UNSET = 0xFFFFFFFFu }; // M2 entry of a position no stage-B walker evaluated (valid entries have len <= 258)
+
 struct SegDev {
     uint64_t buf_off;    // arena offset of buffer position 0 of this segment's stream window
     uint64_t abs0;       // absolute stream position of buffer position 0 (window base arithmetic)

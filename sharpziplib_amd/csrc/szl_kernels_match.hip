@@ -495,6 +495,254 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     }
 }
 
+// ============================================================================================
+// Stage B, on-demand form: k_match_lazy.
+// The parse of stage C only ever reads M2/Mq at the positions it visits — a clean iteration, or the lazy look at the
+// position after a match start; everything inside an emitted match is skipped (C/DeflaterEngine.cs:802-828).  On
+// repetitive data (logs: ≈10 % of the positions) searching every position is mostly wasted work.  Here the tile's lanes
+// WALK instead: a lane takes a start (every STRIDE positions), evaluates FindLongestMatch there, applies the DeflateSlow
+// step to learn which position is needed next, evaluates that, and so on, until it lands on a clean position another
+// walker has already passed (from there on the two parses are identical) or leaves the tile.  Every path
+// that starts at a stride position — in particular at every stage-C range start — is thereby fully evaluated inside the
+// tile; entries nobody needed keep M_UNSET, and the handful stage C does touch (where the true path crosses a tile
+// boundary) are evaluated there on demand (eval_global, szl_kernels_parse.hip).
+// A walker is a dependent chain (evaluate -> step -> evaluate), so an evaluation costs 2.5-4x what it costs the
+// independent dispenser of k_match: the engine runs a pilot on a sample of tiles and uses this kernel only when the
+// evaluated fraction is small enough to pay for that (szl_engine.hip).
+// tile_step/tile_first: the launch handles tiles tile_first, tile_first + tile_step, ... (pilot: a sample).
+// ============================================================================================
+template <int STRIDE>
+__global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
+                                                          const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
+                                                          MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth,
+                                                          int tile_first, int tile_step) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *sdata32 = (uint32_t *)smem;
+    uint16_t *slink = (uint16_t *)(smem + B_DATA_BYTES);
+    int *s_counter = (int *)(smem + B_DATA_BYTES + B_LINKS * 2);
+    uint32_t *s_vis = (uint32_t *)(smem + B_DATA_BYTES + B_LINKS * 2 + 16); // B_TILE bits: clean iteration seen at this tile position
+
+    const TileDev tile = tiles[tile_first + (int)blockIdx.x * tile_step];
+    const SegDev seg = segs[tile.seg];
+    const uint8_t *d = in + seg.buf_off;
+    const uint16_t *lk = link + seg.buf_off;
+    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
+    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
+    const int64_t t0 = tile.start;
+    const int tlen = tile.len;
+    const int64_t dlo = t0 - B_HIST;
+    const int64_t seg_end = seg.seg_end;
+
+    for (int i = threadIdx.x; i < B_DATA_BYTES / 4; i += B_THREADS) {
+        int64_t pos = dlo + 4 * (int64_t)i;
+        uint32_t w = 0;
+        if (pos >= 0 && pos + 4 <= seg_end) w = load_u32_unaligned(d + pos);
+        else {
+            for (int k = 0; k < 4; k++) {
+                int64_t pk = pos + k;
+                if (pk >= 0 && pk < seg_end) w |= (uint32_t)d[pk] << (8 * k);
+            }
+        }
+        sdata32[i] = w;
+    }
+    for (int i = threadIdx.x; i < B_LINKS / 2; i += B_THREADS) {
+        int64_t pos = dlo + 2 * (int64_t)i;
+        uint32_t w = 0;
+        if (pos >= 0 && pos + 2 <= t0 + tlen) {
+            uint16_t a = lk[pos], c = lk[pos + 1];
+            w = (uint32_t)a | ((uint32_t)c << 16);
+        } else {
+            if (pos >= 0 && pos < t0 + tlen) w |= lk[pos];
+            if (pos + 1 >= 0 && pos + 1 < t0 + tlen) w |= (uint32_t)lk[pos + 1] << 16;
+        }
+        if ((w & 0xFFFFu) == 0) w |= 0xFFFFu;     // "no previous position": see k_match
+        if ((w >> 16) == 0) w |= 0xFFFF0000u;
+        ((uint32_t *)slink)[i] = w;
+    }
+    for (int i = threadIdx.x; i < B_TILE / 32; i += B_THREADS) s_vis[i] = 0;
+    if (threadIdx.x == 0) *s_counter = 0;
+    __syncthreads();
+
+    auto ldsdw = [&](int i) -> uint32_t {
+        uint32_t w0 = sdata32[i >> 2], w1 = sdata32[(i >> 2) + 1];
+        return __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(i & 3));
+    };
+    const uint8_t *sdata8 = smem;
+    const int64_t base_lo = base_of((int64_t)seg.abs0 + t0), base_hi = base_of((int64_t)seg.abs0 + t0 + tlen - 1);
+    const int64_t sw = base_lo == base_hi ? (int64_t)1 << 40 : (base_lo + 65273) - (int64_t)seg.abs0 - t0;
+    const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo);
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);
+    const int nstarts = (tlen + STRIDE - 1) / STRIDE;
+    enum { NEED = 0, DONE = 1, QUICK = 2, VERIFY = 3 }; // NEED: no walker; DONE: evaluation of position p finished
+    const int F_THRESH = fth, V_THRESH = vth;
+    int wnext = 0, wend = 0;
+    bool exhausted = false;
+    int mode = NEED;
+    int pl = B_HIST, cl = B_HIST, off = 0, lnk = 0;
+    int best = 2, cap = 4, nice = 4, mincl = 0, left = 1, p = 0;
+    uint32_t pb = 0, res2 = 0, resq = 0;
+    int wL = 0;           // the walker's pending match length (0: clean)
+    unsigned long long n_eval = 0;
+
+    for (;;) {
+        const int nd = __builtin_popcountll(__ballot(mode == DONE)), nn = __builtin_popcountll(__ballot(mode == NEED));
+        const int nv = __builtin_popcountll(__ballot(mode == VERIFY));
+        const int nq = 64 - nd - nn - nv;
+        const int actionable = nd + (exhausted ? 0 : nn); // lanes the STEP phase can move forward
+        if ((actionable >= F_THRESH) || (nq == 0 && nv == 0)) {
+            // ---------------- STEP: consume finished evaluations (DeflateSlow step), start new walkers, launch the next evaluation
+            int nx = -1; // tile position to evaluate next
+            if (mode == DONE) {
+                mt2[t0 + p] = res2; mtq[t0 + p] = resq;
+                const int x = p;
+                if (wL == 0) { // clean iteration at x (:780-800)
+                    int len = (int)(res2 & 0xFFFF);
+                    const int dist = (int)(res2 >> 16);
+                    if (len != 0 && len <= 5 && (P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
+                    wL = len;
+                    nx = x + 1;
+                } else { // lazy evaluation at x: is there a strictly longer match than the one found at x-1 ? (:802)
+                    const int64_t rem = seg_end - (t0 + x);
+                    uint32_t better = 0;
+                    if (rem >= MIN_MATCH) {
+                        const int capx = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+                        if (wL < capx) {
+                            const int nicex = rem < (int64_t)P.nice ? (int)rem : P.nice;
+                            uint32_t cand;
+                            if (wL < P.good) cand = res2;
+                            else if (wL < nicex) cand = resq; // chainLength >>= 2 (:495)
+                            else { // entered with matchLen >= niceLength': first strictly longer candidate among max_chain>>2 wins (rare)
+                                cand = 0;
+                                const int c = x + B_HIST;
+                                int budget = P.max_chain >> 2;
+                                const int basem = (int64_t)x >= sw ? basem_hi : basem_lo;
+                                const int firstmin = c - MAX_DIST > basem ? c - MAX_DIST : basem;
+                                const int minc = c - (MAX_DIST - 1) > basem ? c - (MAX_DIST - 1) : basem;
+                                int cc = c - (int)slink[c];
+                                if (cc >= firstmin) {
+                                    for (;;) {
+                                        int l = 0;
+                                        if (sdata8[cc + wL] == sdata8[c + wL]) { while (l < capx && sdata8[cc + l] == sdata8[c + l]) l++; }
+                                        if (l > wL) { cand = (uint32_t)l | ((uint32_t)(c - cc) << 16); break; }
+                                        const int c2 = cc - (int)slink[cc];
+                                        if (c2 < minc) break;
+                                        if (--budget == 0) break;
+                                        cc = c2;
+                                    }
+                                }
+                            }
+                            if ((int)(cand & 0xFFFF) > wL && !(P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
+                        }
+                    }
+                    if (better) { wL = (int)(better & 0xFFFF); nx = x + 1; }
+                    else { nx = x - 1 + wL; wL = 0; }
+                }
+                mode = NEED;
+                if (nx >= tlen) { nx = -1; wL = 0; } // the walker leaves the tile (its continuation belongs to the next tile's walkers)
+            }
+            // lanes without a walker take a start
+            const uint64_t want = __ballot(mode == NEED && nx < 0);
+            if (!exhausted && want) {
+                if (wnext >= wend) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(s_counter, 64);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    wnext = base < nstarts ? base : nstarts;
+                    wend = base + 64 < nstarts ? base + 64 : nstarts;
+                    if (wnext >= wend) exhausted = true;
+                }
+                const int rank = __builtin_popcountll(want & lanemask_lt);
+                if (mode == NEED && nx < 0 && wnext + rank < wend) { nx = (wnext + rank) * STRIDE; wL = 0; }
+                const int nw = __builtin_popcountll(want);
+                wnext = wnext + nw < wend ? wnext + nw : wend;
+            }
+            if (nx >= 0) {
+                bool go = true;
+                if (wL == 0) { // clean: merge with any walker that has been here
+                    const uint32_t bit = 1u << (nx & 31);
+                    const uint32_t old = atomicOr(&s_vis[nx >> 5], bit);
+                    if (old & bit) go = false;
+                }
+                if (go) {
+                    p = nx;
+                    n_eval++;
+                    const int64_t rem = seg_end - (t0 + p);
+                    res2 = 0; resq = 0;
+                    bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
+                    if (ok) {
+                        pl = p + B_HIST;
+                        const int l0 = (int)slink[pl];
+                        const int basem = (int64_t)p >= sw ? basem_hi : basem_lo;
+                        const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem;
+                        cl = pl - l0;
+                        ok = cl >= firstmin;
+                        if (ok) {
+                            mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem;
+                            cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+                            nice = rem < (int64_t)P.nice ? (int)rem : P.nice;
+                            best = 2; left = P.max_chain;
+                            pb = sdata8[pl + 2];
+                            mode = QUICK;
+                        } else cl = B_HIST;
+                    }
+                    if (!ok) mode = DONE; // nothing to search: the step above consumes (0, 0) on the next visit
+                }
+            }
+            if (exhausted && __all(mode == NEED)) break;
+            continue;
+        }
+        if (nv >= V_THRESH || nq == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+            if (mode == VERIFY) {
+                const uint32_t x = ldsdw(cl + off) ^ ldsdw(pl + off);
+                const bool eq = x == 0;
+                const int l = off + (eq ? 4 : (__builtin_ctz(x) >> 3));
+                const bool more = eq & (l < cap);
+                off = l;
+                if (!more) {
+                    const int L = l < cap ? l : cap;
+                    bool nicehit = false;
+                    if (L > best) { // :593-607
+                        best = L;
+                        res2 = (uint32_t)L | ((uint32_t)(pl - cl) << 16);
+                        if (left > SNAPLEFT) resq = res2;
+                        nicehit = L >= nice;
+                        if (!nicehit) pb = sdata8[pl + L];
+                    }
+                    const int left1 = left - 1;
+                    const int c2 = cl - lnk;
+                    const bool end = (c2 < mincl) | (left1 == 0);
+                    left = nicehit ? left : left1;
+                    cl = (nicehit | end) ? cl : c2;
+                    mode = (nicehit | end) ? DONE : QUICK;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        if (mode == QUICK) {
+            const uint32_t qb = sdata8[cl + best];
+            lnk = (int)slink[cl];
+            const bool pass = qb == pb;
+            const int left1 = left - 1;
+            const int c2 = cl - lnk;
+            const bool end = (c2 < mincl) | (left1 == 0);
+            left = pass ? left : left1;
+            cl = (pass | end) ? cl : c2;
+            off = 0;
+            mode = pass ? VERIFY : (end ? DONE : QUICK);
+        }
+    }
+    if (dbg) {
+        for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o);
+        if (lane == 0) atomicAdd(dbg + 6, n_eval);
+    }
+}
+
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
                   int nspans, uint16_t *link, hipStream_t st) {
     static const bool v1 = getenv("SZL_LINKS") && atoi(getenv("SZL_LINKS")) == 1;
@@ -521,6 +769,27 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
         if (want_dbg) hipLaunchKernelGGL(k_match<true>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth);
         else hipLaunchKernelGGL(k_match<false>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth);
     }
+    return hipGetLastError();
+}
+
+// On-demand stage B over the tiles tile_first, tile_first + tile_step, ... (count of them = nblocks).
+hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
+                             const uint16_t *link, MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
+    static bool attr_set = false;
+    static const int fth = getenv("SZL_LAZY_FTH") ? atoi(getenv("SZL_LAZY_FTH")) : 4, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
+    static const int stride = getenv("SZL_STRIDE") ? atoi(getenv("SZL_STRIDE")) : 16;
+    const int lds = B_LDS_BYTES + B_TILE / 8;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_match_lazy<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (nblocks <= 0) return hipSuccess;
+    if (stride == 16) hipLaunchKernelGGL(k_match_lazy<16>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+    else if (stride == 64) hipLaunchKernelGGL(k_match_lazy<64>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+    else hipLaunchKernelGGL(k_match_lazy<32>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
     return hipGetLastError();
 }
 

@@ -60,6 +60,45 @@ __device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long
     }
 }
 
+// Stage B can evaluate positions on demand (k_match_lazy): an entry still holding M_UNSET was never reached by any of
+// its tile's walkers — e.g. the few positions where the true path enters a tile from its predecessor.  The parse then
+// runs the same FindLongestMatch walk here, out of global memory (same rules as k_match; returns M2 and Mq).
+__device__ void eval_global(const ParseCtx &c, int64_t p, uint32_t &m2, uint32_t &mq, unsigned long long *count) {
+    if (count) atomicAdd(count, 1ull);
+    m2 = 0; mq = 0;
+    const int64_t rem = c.seg_end - p;
+    if (rem < MIN_MATCH || c.P.strategy == 2) return;       // :780, HuffmanOnly :786
+    const uint32_t l0 = c.lk[p];
+    if (l0 == 0) return;
+    const int64_t basem = base_of_c(c.abs0 + p) - c.abs0;
+    int64_t cand = p - l0;
+    const int64_t firstmin = p - MAX_DIST > basem ? p - MAX_DIST : basem; // :788, :450-461
+    if (cand < firstmin) return;
+    const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    const int nice = rem < (int64_t)c.P.nice ? (int)rem : c.P.nice;
+    const int64_t minc = p - (MAX_DIST - 1) > basem ? p - (MAX_DIST - 1) : basem; // :609
+    const int snapleft = c.P.max_chain - (c.P.max_chain >> 2);
+    int best = 2, left = c.P.max_chain;
+    for (;;) {
+        int l = 0;
+        if (c.d[cand + best] == c.d[p + best]) { // quick reject :505
+            while (l < cap && c.d[cand + l] == c.d[p + l]) l++;
+        }
+        if (l > best) {
+            best = l;
+            m2 = (uint32_t)l | ((uint32_t)(p - cand) << 16);
+            if (left > snapleft) mq = m2;
+            if (l >= nice) return;
+        }
+        const uint32_t lnk = c.lk[cand];
+        if (lnk == 0) return;
+        const int64_t c2 = cand - lnk;
+        if (c2 < minc) return;
+        if (--left == 0) return;
+        cand = c2;
+    }
+}
+
 // One iteration of the DeflateSlow loop body at position x with pending match (L,D) (L==0: none).
 // Returns the token emitted by this iteration (0xFFFFFFFF = none) and its input start via *tpos.
 // `A` supplies M2 entries and literal bytes: straight from global memory (GlobalAcc) or from a window a wave
@@ -74,7 +113,9 @@ struct GlobalAcc {
 template <typename A>
 __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, const A &acc, int64_t &x, int &L, int &D, int64_t *tpos,
                                                bool want_lit, unsigned long long *fallbacks) {
-    const uint32_t e2 = acc.m2(x);
+    uint32_t e2 = acc.m2(x), eq = 0;
+    const bool unset = e2 == M_UNSET;
+    if (unset) eval_global(c, x, e2, eq, fallbacks ? fallbacks + 6 : nullptr);
     if (L == 0) {
         int len = (int)(e2 & 0xFFFF), dist = (int)(e2 >> 16);
         if (len != 0 && len <= 5 && (c.P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
@@ -97,7 +138,7 @@ __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, const A &acc, 
             const int nice = rem < (int64_t)c.P.nice ? (int)rem : c.P.nice;
             uint32_t cand;
             if (L < c.P.good) cand = e2;
-            else if (L < nice) cand = acc.mq(x);              // chainLength >>= 2 (:495)
+            else if (L < nice) cand = unset ? eq : acc.mq(x);              // chainLength >>= 2 (:495)
             else cand = slow_walk(c, x, L, fallbacks);
             if ((int)(cand & 0xFFFF) > L && !(c.P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
         }

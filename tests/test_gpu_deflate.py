@@ -124,7 +124,9 @@ def test_stage_intermediates_match_model(eng):
     link, m2, mq, tok = eng.debug_fetch(data.size)
     M = O.Model(data, 6)
     assert np.array_equal(link, M.link[:data.size])
-    assert np.array_equal(m2, M.m2[:data.size]) and np.array_equal(mq, M.mq[:data.size])
+    ev = m2 != 0xFFFFFFFF      # on-demand stage B leaves entries no parse can reach unset (a full search sets all of them)
+    assert ev.mean() > 0.1
+    assert np.array_equal(m2[ev], M.m2[:data.size][ev]) and np.array_equal(mq[ev], M.mq[:data.size][ev])
     ref, tr = O.deflate(data, 6, trace=True)
     assert np.array_equal(tok, tr["tokens"])
     blocks = eng.debug_blocks()
