@@ -507,3 +507,52 @@ def test_wrong_dictionary_is_rejected():
     assert inf.IsNeedingDictionary
     with pytest.raises(SharpZipBaseException):
         inf.SetDictionary(b"another dictionary")
+
+
+def _structured_random(rng, n):
+    """Seeded input with the features that steer the encoder: literals from alphabets of different sizes, copies of earlier
+    spans at distances spread over the whole window (incl. just inside / outside MAX_DIST = 32506 and beyond TooFar = 4096),
+    runs, and periodic stretches."""
+    out = np.empty(n, np.uint8)
+    pos = 0
+    while pos < n:
+        kind = rng.integers(0, 6)
+        ln = int(min(n - pos, rng.choice([1, 2, 3, 4, 5, 8, 17, 64, 258, 259, 300, 1000, 5000])))
+        if kind == 0 or pos < 4:
+            out[pos:pos + ln] = rng.integers(0, int(rng.choice([2, 4, 16, 64, 256])), ln, dtype=np.uint8)
+        elif kind == 1:
+            out[pos:pos + ln] = rng.integers(0, 256, dtype=np.uint8)
+        elif kind == 2:
+            per = int(rng.integers(1, 12))
+            pat = rng.integers(0, 256, per, dtype=np.uint8)
+            out[pos:pos + ln] = np.resize(pat, ln)
+        else:
+            dist = int(rng.choice([1, 2, 3, 7, 100, 4095, 4096, 4097, 20000, 32505, 32506, 32507, 32768, 40000]))
+            dist = min(dist, pos)
+            for k in range(ln):   # overlapping copy semantics (dist < ln repeats the pattern)
+                out[pos + k] = out[pos + k - dist]
+        pos += ln
+    return out
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_differential_all_modes(eng, seed):
+    """Seeded differential test: every level / strategy / framing on structured random inputs, device == oracle bit for bit,
+    then back through the device Inflater."""
+    rng = np.random.default_rng(1000 + seed)
+    sizes = [0, 1, 2, 3, 4, 5, 262, 263] + [int(rng.integers(6, 3000)) for _ in range(10)] + \
+            [int(rng.integers(3000, 70000)) for _ in range(6)] + [int(rng.integers(70000, 200000)) for _ in range(2)]
+    bufs = [_structured_random(rng, n) for n in sizes]
+    for trial in range(6):
+        level = int(rng.integers(0, 10))
+        strategy = int(rng.integers(0, 3))
+        nowrap = bool(rng.integers(0, 2))
+        flush = bool(rng.integers(0, 2))
+        res = eng.deflate(bufs, level=level, strategy=strategy, nowrap=nowrap, crc32=True, sync_flush_before_finish=flush)
+        for b, r in zip(bufs, res):
+            ref = O.deflate(b, level, nowrap=nowrap, strategy=strategy, flush=flush)
+            assert r.status == 0 and r.data == ref, (seed, trial, level, strategy, nowrap, flush, b.size)
+            assert r.crc32 == O.crc32(b)
+        back = eng.inflate([r.data for r in res], [b.size for b in bufs], nowrap=nowrap)
+        for b, (r, consumed), c in zip(bufs, back, res):
+            assert r.status == 0 and r.data == b.tobytes() and consumed == len(c.data), (seed, trial, level, b.size)
