@@ -17,9 +17,18 @@
 // base at each FlushBlock go to the stage-D tables; stage D then runs unchanged apart from the two DeflateFast
 // rules flagged by LevelParams.fast (k_seg_blocks, k_block_build).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "szl_internal.h"
 
 namespace szl {
+
+// hipFuncSetAttribute is per device: remember which devices have the large-LDS attribute for a kernel group
+static bool lds_attr_needed(std::atomic<uint64_t> &mask, uint64_t &bit) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bit = 1ull << (dev & 63);
+    return (mask.load(std::memory_order_acquire) & bit) == 0;
+}
 
 enum : int { F_DATA = 65536, F_LINKS = 32768, F_FLAGW = 1024 };
 
@@ -96,7 +105,6 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
     load_links(seg_start);
     __syncthreads();
 
-    auto flag_get = [&](int64_t q) -> int { return (int)((S.flag[((uint32_t)q >> 5) & (F_FLAGW - 1)] >> ((uint32_t)q & 31)) & 1u); };
     // set bits [q0, q1) to v (q1 - q0 <= 258): lane k owns word (q0>>5)+k
     auto flag_set = [&](int64_t q0, int64_t q1, int v) {
         const int64_t w = (q0 >> 5) + lane;
@@ -231,11 +239,12 @@ int fast_lds_bytes() { return (int)sizeof(FastLds); }
 
 hipError_t launch_fast(const uint8_t *in, const uint16_t *link, const SegDev *segs, uint32_t nseg, LevelParams P, uint32_t *fbits,
                        SegOut *so, uint32_t *tokens, const uint64_t *blk_off, int64_t *bsp, int64_t *blp, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_mask{0};
+    uint64_t attr_bit = 0;
+    if (lds_attr_needed(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FastLds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
     if (nseg) hipLaunchKernelGGL(k_fast, dim3(nseg), dim3(64), sizeof(FastLds), st, in, link, segs, nseg, P, fbits, so, tokens, blk_off, bsp, blp);
     return hipSuccess;

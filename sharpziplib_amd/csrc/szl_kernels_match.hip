@@ -6,11 +6,20 @@
 // Both are *parse-independent* at levels 5-9 (DeflateSlow inserts every position),
 // so they are computed for every position in parallel; the lazy parse (stage C) only looks results up.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 #include <cstdint>
 #include "szl_internal.h"
 
 namespace szl {
+
+// hipFuncSetAttribute is per device: remember which devices have the large-LDS attribute for a kernel group
+static bool lds_attr_needed(std::atomic<uint64_t> &mask, uint64_t &bit) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bit = 1ull << (dev & 63);
+    return (mask.load(std::memory_order_acquire) & bit) == 0;
+}
 
 __device__ __forceinline__ int64_t base_of(int64_t s_abs) {
     // Window base in effect for an iteration starting at absolute position s: the engine slides by 32768
@@ -755,15 +764,16 @@ int match_lds_bytes() { return B_LDS_BYTES; }
 
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_mask{0};
+    uint64_t attr_bit = 0;
     static const bool want_dbg = getenv("SZL_DEBUG") != nullptr;
     static const int fth = getenv("SZL_FTH") ? atoi(getenv("SZL_FTH")) : 16, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
-    if (!attr_set) {
+    if (lds_attr_needed(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void *)k_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
     if (ntiles > 0) {
         if (want_dbg) hipLaunchKernelGGL(k_match<true>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth);
@@ -775,16 +785,17 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
 // On-demand stage B over the tiles tile_first, tile_first + tile_step, ... (count of them = nblocks).
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
                              const uint16_t *link, MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_mask{0};
+    uint64_t attr_bit = 0;
     static const int fth = getenv("SZL_LAZY_FTH") ? atoi(getenv("SZL_LAZY_FTH")) : 4, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
     static const int stride = getenv("SZL_STRIDE") ? atoi(getenv("SZL_STRIDE")) : 16;
     const int lds = B_LDS_BYTES + B_TILE / 8;
-    if (!attr_set) {
+    if (lds_attr_needed(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match_lazy<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
     if (nblocks <= 0) return hipSuccess;
     if (stride == 16) hipLaunchKernelGGL(k_match_lazy<16>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
