@@ -385,7 +385,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     int pl = B_HIST, cl = B_HIST, off = 0, lnk = 0;
     int best = 2, cap = 4, nice = 4, mincl = 0, left = 1, p = 0;
     uint32_t pb = 0, res2 = 0, resq = 0;
-    unsigned long long n_q = 0, n_qs = 0, n_v = 0, n_vs = 0;
+    unsigned long long n_qs = 0, n_vs = 0; // DBG: steps this lane took part in
 
     // A small scheduler picks, per visit, the phase that has enough lanes waiting for it: the phases cost the same
     // for one lane as for 64, so each is run only when it is well occupied (or nothing else can make progress).
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
 #pragma unroll
             for (int u = 0; u < 2; u++)
             if (mode == VERIFY) {
-                if (DBG) { n_vs++; n_v += __builtin_popcountll(__ballot(true)); }
+                if (DBG) n_vs++;
                 const uint32_t x = ldsdw(cl + off) ^ ldsdw(pl + off);
                 const bool eq = x == 0;
                 const int l = off + (eq ? 4 : (__builtin_ctz(x) >> 3));
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; u++)
         if (mode == QUICK) {
-            if (DBG) { n_qs++; n_q += __builtin_popcountll(__ballot(true)); }
+            if (DBG) n_qs++;
             const uint32_t qb = sdata8[cl + best];   // a longer match must agree at offset `best` (scan_end, :505)
             lnk = (int)slink[cl];
             const bool pass = qb == pb;
