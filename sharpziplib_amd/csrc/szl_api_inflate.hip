@@ -12,7 +12,7 @@
 using namespace szl;
 
 namespace szl {
-void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, hipStream_t st);
+void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, bool one_shot, hipStream_t st);
 void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
@@ -82,7 +82,7 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
         hipMemcpyAsync(dstates.p, states.data(), n * sizeof(InfState), hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); set_error("H2D failed"); return SZL_E_DEVICE; }
     for (int i = 0; i < 2; i++) if (!e->e.ev[i]) (void)hipEventCreate(&e->e.ev[i]);
     (void)hipEventRecord(e->e.ev[0], st);
-    launch_inflate((const uint8_t *)d_in, (uint8_t *)d_out, (InfJob *)djobs.p, (InfState *)dstates.p, (uint32_t)n, st);
+    launch_inflate((const uint8_t *)d_in, (uint8_t *)d_out, (InfJob *)djobs.p, (InfState *)dstates.p, (uint32_t)n, true, st);
     (void)hipEventRecord(e->e.ev[1], st);
     if (hipMemcpyAsync(jobs.data(), djobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(states.data(), dstates.p, n * sizeof(InfState), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -249,7 +249,7 @@ static int inflater_step(szl_inflater *s) {
     if (nin) HIPCHK(hipMemcpy(s->d_in.p, s->hin.data(), nin, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_job.p, &j, sizeof j, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_state.p, &s->st, sizeof s->st, hipMemcpyHostToDevice));
-    launch_inflate((const uint8_t *)s->d_in.p, (uint8_t *)s->d_out.p, (InfJob *)s->d_job.p, (InfState *)s->d_state.p, 1, nullptr);
+    launch_inflate((const uint8_t *)s->d_in.p, (uint8_t *)s->d_out.p, (InfJob *)s->d_job.p, (InfState *)s->d_state.p, 1, false, nullptr);
     HIPCHK(hipMemcpy(&j, s->d_job.p, sizeof j, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&s->st, s->d_state.p, sizeof s->st, hipMemcpyDeviceToHost));
     s->fresh_input = false;

@@ -14,12 +14,17 @@
 // construction); independent streams (zip entries, gzip members) run on other wavefronts — 4 per CU, bounded
 // by the 32 KiB window each keeps in LDS.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "szl_internal.h"
 #include "szl_inflate.h"
 
 namespace szl {
 
-enum : int { I_WIN = 32768, I_WMASK = I_WIN - 1, I_STAGE = 1024, I_LPB = 10, I_DPB = 9, MAX_MATCH_I = 258 };
+enum : int { I_WIN = 32768, I_STAGE = 1024, I_LPB = 10, I_DPB = 9, MAX_MATCH_I = 258 };
+// One-shot jobs (batch API: the whole output of a stream is one contiguous region) use the SHORT-window form: only the
+// last 8 KiB of output live in LDS and matches that reach farther back read the output region itself, which lets a CU keep
+// 10 streams in flight instead of 4.  Streaming jobs (window saved between calls, preset dictionary) keep all 32 KiB in LDS.
+enum : int { I_WIN_SHORT = 8192 };
 
 __constant__ uint16_t c_cplens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_cplext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -34,8 +39,9 @@ struct HuffTab {            // canonical code of up to 288 symbols; LSB-first pr
     uint16_t sorted[288];   // symbols ordered by (length, symbol)
 };
 
+template <int WIN>
 struct InfLds {
-    uint8_t win[I_WIN];
+    uint8_t win[WIN];
     uint32_t stage[I_STAGE / 4 + 4];
     uint16_t llut[1 << I_LPB];
     uint16_t dlut[1 << I_DPB];
@@ -99,9 +105,18 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
     return -1;
 }
 
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
+// (second launch-bound: waves per SIMD the register allocation must allow — LDS admits 10 streams per CU in the short-window form)
+template <bool SHORTWIN>
+__global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
-    __shared__ InfLds S;
+    constexpr int WIN = SHORTWIN ? I_WIN_SHORT : I_WIN;
+    constexpr uint64_t I_WMASK = WIN - 1;
+    // SHORTWIN: bytes older than FAR_DIST are read from the output region; everything older than ROOM is flushed there first
+    constexpr uint32_t FAR_DIST = WIN - 512;
+    constexpr uint64_t ROOM = SHORTWIN ? 4096 : (uint64_t)(I_WIN - 300);
+    constexpr uint64_t FLUSH_AT = SHORTWIN ? 1024 : 16384;
+    constexpr uint32_t ROUND_MAX = SHORTWIN ? 2048 : 64u * MAX_MATCH_I; // output bytes one parallel round may queue
+    __shared__ InfLds<WIN> S;
     const uint32_t ji = blockIdx.x;
     if (ji >= njobs) return;
     const int lane = threadIdx.x;
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     int status = INF_RUNNING;
 
     // window: restore the last 32 KiB of output
-    if ((outpos > 0 || job.load_window) && job.window) {
+    if (!SHORTWIN && (outpos > 0 || job.load_window) && job.window) {
         for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&S.win[i] = *(const uint4 *)&job.window[i];
     }
     // zlib header (C/Inflater.cs:211-249)
@@ -176,6 +191,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
         uint64_t n = upto - flushed;
         for (uint64_t i = lane; i < n; i += 64) out[flushed - out_start + i] = S.win[(flushed + i) & I_WMASK];
         flushed = upto;
+        if (SHORTWIN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // later far matches read these bytes back
     };
 
     // bit reader (lane 0 owns bb/nb; bitpos is the stream position of bit 0 of bb)
@@ -214,10 +230,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
             if (m0 == INF_M_HUFF && sbase != ~0ull) {
                 const uint64_t byte0 = P >> 3;
                 const uint64_t availb = in_bits > P ? in_bits - P : 0;
-                const uint64_t room_lim = flushed + (I_WIN - 300);
+                const uint64_t room_lim = flushed + ROOM;
                 const uint64_t olim = out_limit < room_lim ? out_limit : room_lim;
                 par_ok = byte0 >= sbase && byte0 + PAR_BYTES <= sbase + I_STAGE && availb >= (uint64_t)(PAR_W + 64) &&
-                         outpos + (uint64_t)QN * MAX_MATCH_I <= olim;
+                         outpos + (uint64_t)ROUND_MAX + MAX_MATCH_I <= olim;
                 if (!par_ok && byte0 >= sbase + 256 && byte0 + PAR_BYTES > sbase + I_STAGE && byte0 + PAR_BYTES <= job.in_len) {
                     // the staged input is nearly used up: slide it (cooperative) instead of crawling through the careful loop
                     ev = EV_RESTAGE; ea = (int)(uint32_t)byte0; eb = (int)(uint32_t)(byte0 >> 32);
@@ -258,8 +274,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                     }
                     nbits[jj] = nbv; tokv[jj] = tk;
                 }
-                uint32_t o = 0;
-                while (ntok < QN && o < (uint32_t)PAR_W) {
+                uint32_t o = 0, olen = 0;
+                while (ntok < QN && o < (uint32_t)PAR_W && olen <= ROUND_MAX) {
                     const int l = (int)(o & 63);
                     const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nbits[0], l), n1 = (uint32_t)__builtin_amdgcn_readlane((int)nbits[1], l);
                     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[0], l), t1 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[1], l);
@@ -267,6 +283,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                     if (nx == 0) break;
                     if (lane == 0) S.queue[ntok] = tk;
                     ntok++;
+                    olen += (tk >> 16) ? (tk & 0xFFFF) : 1u;
                     o += nx;
                 }
                 par_bitpos = P + o;
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
         const int npar = ntok;
         if (lane == 0) {
             uint64_t opos = outpos;                       // position after the queued tokens
-            const uint64_t room_lim = flushed + (I_WIN - 300);
+            const uint64_t room_lim = flushed + ROOM;
             if (npar > 0) { // adopt the parallel round's result: new bit position, bit buffer re-primed (possibly mid-byte)
                 bitpos = par_bitpos;
                 const uint32_t o2 = (uint32_t)((bitpos >> 3) - sbase);
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                     const uint64_t bp = bitpos >> 3;
                     const uint64_t can_in = job.in_len > bp ? job.in_len - bp : 0;
                     const uint64_t can_out = out_limit - outpos;
-                    const uint64_t room = (uint64_t)(I_WIN - 512) - (outpos - flushed);
+                    const uint64_t room = (SHORTWIN ? ROOM : (uint64_t)(I_WIN - 512)) - (outpos - flushed);
                     uint64_t n = stored_left;
                     if (n > can_in) n = can_in;
                     if (n > can_out) n = can_out;
@@ -478,7 +495,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
                 const uint32_t off = __builtin_amdgcn_readlane(incl - mylen, l);
                 const uint32_t len = t2 & 0xFFFF, d2 = t2 >> 16;
                 const uint64_t p = outpos + off;
-                if (d2 >= len) { // no overlap (wave-uniform test): plain copy
+                if (SHORTWIN && d2 > FAR_DIST) { // older than the LDS window: already flushed to the output region (ROOM < FAR_DIST - 258)
+                    const uint8_t *src = out + (p - d2 - out_start);
+                    for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = __atomic_load_n(src + k, __ATOMIC_RELAXED);
+                } else if (d2 >= len) { // no overlap (wave-uniform test): plain copy
                     for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k) & I_WMASK];
                 } else {
                     for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k % d2) & I_WMASK];
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             outpos += __builtin_amdgcn_readlane(incl, 63);
         }
-        if (outpos - flushed >= 16384) flush(outpos);
+        if (outpos - flushed >= FLUSH_AT) flush(outpos);
         switch (ev) {
         case EV_RESTAGE: {
             const uint64_t bp = ((uint64_t)(uint32_t)eb << 32) | (uint32_t)ea;
@@ -544,7 +564,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
             bitpos = (bytepos + 4) * 8;
         }
     }
-    if (job.window && (status != INF_FINISHED || job.keep_window)) {
+    if (!SHORTWIN && job.window && (status != INF_FINISHED || job.keep_window)) {
         for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&job.window[i] = *(const uint4 *)&S.win[i];
     }
     if (btype == 2 && mode == INF_M_HUFF) for (int i = lane; i < 320; i += 64) st->lens[i] = S.lens[i];
@@ -558,8 +578,12 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in_b
     }
 }
 
-void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, hipStream_t st) {
-    if (njobs) hipLaunchKernelGGL(k_inflate, dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
+// one_shot: every job starts at outpos 0, has no saved window / dictionary and owns one contiguous output region
+void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, bool one_shot, hipStream_t st) {
+    static const bool allow_short = !(getenv("SZL_INF_SHORT") && atoi(getenv("SZL_INF_SHORT")) == 0);
+    if (!njobs) return;
+    if (one_shot && allow_short) hipLaunchKernelGGL(k_inflate<true>, dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
+    else hipLaunchKernelGGL(k_inflate<false>, dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
 }
 
 } // namespace szl
