@@ -135,7 +135,7 @@ typedef struct szl_timing {
     float total_ms, checksum_ms, links_ms, match_ms, parse_ms, blocks_ms, encode_ms;
     uint64_t in_bytes, out_bytes, tokens, blocks, ranges_unmerged, fallback_walks;
     float inflate_ms;   /* last szl_inflate_batch_* call: k_inflate time (HIP events) */
-    float pad;
+    float pilot_ms;     /* stage-B pilot (sample of tiles + read-back) that picks the search form; in total_ms, not in match_ms */
 } szl_timing;
 int szl_engine_last_timing(const szl_engine *e, szl_timing *t);
 

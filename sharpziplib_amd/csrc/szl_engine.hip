@@ -248,6 +248,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     static const int match_mode = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 2; // 0 full, 1 on demand, 2 pilot
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.28; // break-even measured at ~1/3
     last_pilot_frac = -1.0;
+    bool b_event = false; // ev[7]: start of the stage-B search proper (after the pilot)
     if (match_mode == 1 || (match_mode == 2 && ntiles >= 64)) { // (inputs under 1 MiB: not worth a pilot)
         if (match_mode == 2) { // the pilot's own entries are overwritten by whichever form runs afterwards
             const uint64_t step = ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8);
@@ -261,11 +262,14 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
             last_pilot_frac = sampled ? (double)ne / (double)sampled : 1.0;
             lazy = last_pilot_frac < lazy_max_frac;
         } else lazy = true;
+        HIPCHK(hipEventRecord(ev[7], st));
+        b_event = true;
         if (lazy) {
             HIPCHK(hipMemsetAsync(mt.m2, 0xFF, mt_stride * 4, st)); // M_UNSET
             HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, 0, 1, (const uint16_t *)link.p, mt, P, dcnt, st));
         }
     }
+    if (!b_event) HIPCHK(hipEventRecord(ev[7], st));
     if (!lazy) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
@@ -314,7 +318,14 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
 
     float ms[6] = {0};
     for (int i = 0; i < 6; i++) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
-    timing.checksum_ms = ms[0]; timing.links_ms = ms[1]; timing.match_ms = ms[2]; timing.parse_ms = ms[3];
+    timing.checksum_ms = ms[0]; timing.links_ms = ms[1]; timing.match_ms = ms[2];
+    timing.parse_ms = ms[3];
+    if (!fast) { // ev[7] separates the pilot (tile sample + read-back) from the search proper
+        float pm = 0, mm = 0;
+        (void)hipEventElapsedTime(&pm, ev[2], ev[7]);
+        (void)hipEventElapsedTime(&mm, ev[7], ev[3]);
+        timing.pilot_ms = pm; timing.match_ms = mm;
+    }
     timing.blocks_ms = ms[4]; timing.encode_ms = ms[5];
     (void)hipEventElapsedTime(&timing.total_ms, ev[0], ev[6]);
     timing.in_bytes = seg_bytes;
