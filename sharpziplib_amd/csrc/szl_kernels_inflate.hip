@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                 }
             }
             if (par_ok) {
-                uint32_t nbits[2], tokv[2];
+                uint32_t tokv[2];
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) {
                     const uint64_t bp = P + (uint32_t)(lane + 64 * jj);
@@ -272,18 +272,18 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                             }
                         }
                     }
-                    nbits[jj] = nbv; tokv[jj] = tk;
+                    tokv[jj] = tk | (nbv << 10); // bits 10..15 (free: literal/length use 9 bits): bit count of the token, 0 = stop
                 }
                 uint32_t o = 0, olen = 0;
                 while (ntok < QN && o < (uint32_t)PAR_W && olen <= ROUND_MAX) {
                     const int l = (int)(o & 63);
-                    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nbits[0], l), n1 = (uint32_t)__builtin_amdgcn_readlane((int)nbits[1], l);
                     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[0], l), t1 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[1], l);
-                    const uint32_t nx = o < 64 ? n0 : n1, tk = o < 64 ? t0 : t1;
+                    const uint32_t tp = o < 64 ? t0 : t1;
+                    const uint32_t nx = (tp >> 10) & 63u, tk = tp & 0xFFFF03FFu;
                     if (nx == 0) break;
                     if (lane == 0) S.queue[ntok] = tk;
                     ntok++;
-                    olen += (tk >> 16) ? (tk & 0xFFFF) : 1u;
+                    olen += (tk >> 16) ? (tk & 0x3FF) : 1u;
                     o += nx;
                 }
                 par_bitpos = P + o;
