@@ -251,7 +251,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     bool b_event = false; // ev[7]: start of the stage-B search proper (after the pilot)
     if (match_mode == 1 || (match_mode == 2 && ntiles >= 64)) { // (inputs under 1 MiB: not worth a pilot)
         if (match_mode == 2) { // the pilot's own entries are overwritten by whichever form runs afterwards
-            const uint64_t step = ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8);
+            const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8)); // >= 64 sampled tiles
             const int nb = (int)((ntiles + step - 1) / step);
             uint64_t sampled = 0;
             for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
