@@ -518,9 +518,12 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
 // A walker is a dependent chain (evaluate -> step -> evaluate), so an evaluation costs 2.5-4x what it costs the
 // independent dispenser of k_match: the engine runs a pilot on a sample of tiles and uses this kernel only when the
 // evaluated fraction is small enough to pay for that (szl_engine.hip).
+// PAIR: lanes work in pairs — the even lane is the walker and evaluates x, the odd lane is its scout and evaluates x+1
+// at the same time (x+1 is always needed after a clean x, and after a lazy x whenever a longer match is found), which
+// halves the length of the dependent chain; the step phase then consumes both positions at once.
 // tile_step/tile_first: the launch handles tiles tile_first, tile_first + tile_step, ... (pilot: a sample).
 // ============================================================================================
-template <int STRIDE>
+template <int STRIDE, bool PAIR>
 __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                           const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
                                                           MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth,
@@ -595,64 +598,123 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
     int wL = 0;           // the walker's pending match length (0: clean)
     unsigned long long n_eval = 0;
 
-    for (;;) {
-        const int nd = __builtin_popcountll(__ballot(mode == DONE)), nn = __builtin_popcountll(__ballot(mode == NEED));
-        const int nv = __builtin_popcountll(__ballot(mode == VERIFY));
-        const int nq = 64 - nd - nn - nv;
-        const int actionable = nd + (exhausted ? 0 : nn); // lanes the STEP phase can move forward
-        if ((actionable >= F_THRESH) || (nq == 0 && nv == 0)) {
-            // ---------------- STEP: consume finished evaluations (DeflateSlow step), start new walkers, launch the next evaluation
-            int nx = -1; // tile position to evaluate next
-            if (mode == DONE) {
-                mt2[t0 + p] = res2; mtq[t0 + p] = resq;
-                const int x = p;
-                if (wL == 0) { // clean iteration at x (:780-800)
-                    int len = (int)(res2 & 0xFFFF);
-                    const int dist = (int)(res2 >> 16);
-                    if (len != 0 && len <= 5 && (P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
-                    wL = len;
-                    nx = x + 1;
-                } else { // lazy evaluation at x: is there a strictly longer match than the one found at x-1 ? (:802)
-                    const int64_t rem = seg_end - (t0 + x);
-                    uint32_t better = 0;
-                    if (rem >= MIN_MATCH) {
-                        const int capx = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
-                        if (wL < capx) {
-                            const int nicex = rem < (int64_t)P.nice ? (int)rem : P.nice;
-                            uint32_t cand;
-                            if (wL < P.good) cand = res2;
-                            else if (wL < nicex) cand = resq; // chainLength >>= 2 (:495)
-                            else { // entered with matchLen >= niceLength': first strictly longer candidate among max_chain>>2 wins (rare)
-                                cand = 0;
-                                const int c = x + B_HIST;
-                                int budget = P.max_chain >> 2;
-                                const int basem = (int64_t)x >= sw ? basem_hi : basem_lo;
-                                const int firstmin = c - MAX_DIST > basem ? c - MAX_DIST : basem;
-                                const int minc = c - (MAX_DIST - 1) > basem ? c - (MAX_DIST - 1) : basem;
-                                int cc = c - (int)slink[c];
-                                if (cc >= firstmin) {
-                                    for (;;) {
-                                        int l = 0;
-                                        if (sdata8[cc + wL] == sdata8[c + wL]) { while (l < capx && sdata8[cc + l] == sdata8[c + l]) l++; }
-                                        if (l > wL) { cand = (uint32_t)l | ((uint32_t)(c - cc) << 16); break; }
-                                        const int c2 = cc - (int)slink[cc];
-                                        if (c2 < minc) break;
-                                        if (--budget == 0) break;
-                                        cc = c2;
-                                    }
-                                }
-                            }
-                            if ((int)(cand & 0xFFFF) > wL && !(P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
+    // The DeflateSlow step at tile position x given FindLongestMatch's results there (r2 full budget, rq quarter budget)
+    // and the pending match length wL (0: clean iteration).  Returns the next position the parse needs; updates wL.
+    auto consume = [&](int x, uint32_t r2, uint32_t rq, int &wl) -> int {
+        if (wl == 0) { // clean iteration at x (:780-800)
+            int len = (int)(r2 & 0xFFFF);
+            const int dist = (int)(r2 >> 16);
+            if (len != 0 && len <= 5 && (P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
+            wl = len;
+            return x + 1;
+        }
+        // lazy evaluation at x: is there a strictly longer match than the one found at x-1 ? (:802)
+        const int64_t rem = seg_end - (t0 + x);
+        uint32_t better = 0;
+        if (rem >= MIN_MATCH) {
+            const int capx = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+            if (wl < capx) {
+                const int nicex = rem < (int64_t)P.nice ? (int)rem : P.nice;
+                uint32_t cand;
+                if (wl < P.good) cand = r2;
+                else if (wl < nicex) cand = rq; // chainLength >>= 2 (:495)
+                else { // entered with matchLen >= niceLength': first strictly longer candidate among max_chain>>2 wins (rare)
+                    cand = 0;
+                    const int c = x + B_HIST;
+                    int budget = P.max_chain >> 2;
+                    const int basem = (int64_t)x >= sw ? basem_hi : basem_lo;
+                    const int firstmin = c - MAX_DIST > basem ? c - MAX_DIST : basem;
+                    const int minc = c - (MAX_DIST - 1) > basem ? c - (MAX_DIST - 1) : basem;
+                    int cc = c - (int)slink[c];
+                    if (cc >= firstmin) {
+                        for (;;) {
+                            int l = 0;
+                            if (sdata8[cc + wl] == sdata8[c + wl]) { while (l < capx && sdata8[cc + l] == sdata8[c + l]) l++; }
+                            if (l > wl) { cand = (uint32_t)l | ((uint32_t)(c - cc) << 16); break; }
+                            const int c2 = cc - (int)slink[cc];
+                            if (c2 < minc) break;
+                            if (--budget == 0) break;
+                            cc = c2;
                         }
                     }
-                    if (better) { wL = (int)(better & 0xFFFF); nx = x + 1; }
-                    else { nx = x - 1 + wL; wL = 0; }
                 }
+                if ((int)(cand & 0xFFFF) > wl && !(P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
+            }
+        }
+        if (better) { wl = (int)(better & 0xFFFF); return x + 1; }
+        const int nx = x - 1 + wl;
+        wl = 0;
+        return nx;
+    };
+    // start FindLongestMatch at tile position q on this lane
+    auto launch = [&](int q) {
+        p = q;
+        n_eval++;
+        const int64_t rem = seg_end - (t0 + p);
+        res2 = 0; resq = 0;
+        bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
+        if (ok) {
+            pl = p + B_HIST;
+            const int l0 = (int)slink[pl];
+            const int basem = (int64_t)p >= sw ? basem_hi : basem_lo;
+            const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem;
+            cl = pl - l0;
+            ok = cl >= firstmin;
+            if (ok) {
+                mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem;
+                cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+                nice = rem < (int64_t)P.nice ? (int)rem : P.nice;
+                best = 2; left = P.max_chain;
+                pb = sdata8[pl + 2];
+                mode = QUICK;
+            } else cl = B_HIST;
+        }
+        if (!ok) mode = DONE; // nothing to search: consumed as (0, 0) on the next STEP visit
+    };
+    auto visit_clean = [&](int q) -> bool { // true if this walker is the first at clean position q
+        const uint32_t bit = 1u << (q & 31);
+        return (atomicOr(&s_vis[q >> 5], bit) & bit) == 0;
+    };
+    const bool head = !PAIR || (lane & 1) == 0;  // PAIR: even lane = walker (evaluates x), odd lane = its scout (evaluates x+1)
+    const uint64_t EVEN = 0x5555555555555555ull;
+
+    for (;;) {
+        const uint64_t dm = __ballot(mode == DONE), nm = __ballot(mode == NEED);
+        const int nv = __builtin_popcountll(__ballot(mode == VERIFY));
+        const int nq = 64 - __builtin_popcountll(dm) - __builtin_popcountll(nm) - nv;
+        // lanes (pairs) the STEP phase can move forward
+        int actionable;
+        if (PAIR) actionable = 2 * (__builtin_popcountll(dm & ((dm | nm) >> 1) & EVEN) + (exhausted ? 0 : __builtin_popcountll(nm & EVEN)));
+        else actionable = __builtin_popcountll(dm) + (exhausted ? 0 : __builtin_popcountll(nm));
+        if ((actionable >= F_THRESH) || (nq == 0 && nv == 0)) {
+            // ---------------- STEP: consume finished evaluations (DeflateSlow step), start new walkers, launch the next evaluations
+            int nx = -1; // tile position the walker needs next
+            if (PAIR) {
+                const int s_mode = __shfl_down(mode, 1);
+                const uint32_t s_r2 = (uint32_t)__shfl_down((int)res2, 1), s_rq = (uint32_t)__shfl_down((int)resq, 1);
+                const int s_p = __shfl_down(p, 1);
+                const bool ready = head && mode == DONE && (s_mode == DONE || s_mode == NEED);
+                const bool h_ready = __shfl((int)ready, lane & ~1) != 0;
+                if (h_ready && mode == DONE) { mt2[t0 + p] = res2; mtq[t0 + p] = resq; }
+                if (ready) {
+                    const int x = p;
+                    nx = consume(x, res2, resq, wL);
+                    if (nx == x + 1 && s_mode == DONE && s_p == x + 1) { // the scout already has x+1
+                        if (wL == 0 && !visit_clean(x + 1)) nx = -1;    // x+1 is a clean iteration another walker has passed: merge
+                        else nx = consume(x + 1, s_r2, s_rq, wL);
+                    }
+                    if (nx >= tlen) { nx = -1; wL = 0; } // the walker leaves the tile
+                    if (nx < 0) wL = 0;
+                }
+                if (h_ready) mode = NEED;
+            } else if (mode == DONE) {
+                mt2[t0 + p] = res2; mtq[t0 + p] = resq;
+                nx = consume(p, res2, resq, wL);
                 mode = NEED;
                 if (nx >= tlen) { nx = -1; wL = 0; } // the walker leaves the tile (its continuation belongs to the next tile's walkers)
             }
-            // lanes without a walker take a start
-            const uint64_t want = __ballot(mode == NEED && nx < 0);
+            // walkers without a path take a start
+            const uint64_t want = __ballot(head && mode == NEED && nx < 0);
             if (!exhausted && want) {
                 if (wnext >= wend) {
                     int base = 0;
@@ -663,42 +725,19 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
                     if (wnext >= wend) exhausted = true;
                 }
                 const int rank = __builtin_popcountll(want & lanemask_lt);
-                if (mode == NEED && nx < 0 && wnext + rank < wend) { nx = (wnext + rank) * STRIDE; wL = 0; }
+                if (head && mode == NEED && nx < 0 && wnext + rank < wend) { nx = (wnext + rank) * STRIDE; wL = 0; }
                 const int nw = __builtin_popcountll(want);
                 wnext = wnext + nw < wend ? wnext + nw : wend;
             }
-            if (nx >= 0) {
-                bool go = true;
-                if (wL == 0) { // clean: merge with any walker that has been here
-                    const uint32_t bit = 1u << (nx & 31);
-                    const uint32_t old = atomicOr(&s_vis[nx >> 5], bit);
-                    if (old & bit) go = false;
-                }
-                if (go) {
-                    p = nx;
-                    n_eval++;
-                    const int64_t rem = seg_end - (t0 + p);
-                    res2 = 0; resq = 0;
-                    bool ok = rem >= MIN_MATCH && P.strategy != 2; // :780, HuffmanOnly :786
-                    if (ok) {
-                        pl = p + B_HIST;
-                        const int l0 = (int)slink[pl];
-                        const int basem = (int64_t)p >= sw ? basem_hi : basem_lo;
-                        const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem;
-                        cl = pl - l0;
-                        ok = cl >= firstmin;
-                        if (ok) {
-                            mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem;
-                            cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
-                            nice = rem < (int64_t)P.nice ? (int)rem : P.nice;
-                            best = 2; left = P.max_chain;
-                            pb = sdata8[pl + 2];
-                            mode = QUICK;
-                        } else cl = B_HIST;
-                    }
-                    if (!ok) mode = DONE; // nothing to search: the step above consumes (0, 0) on the next visit
-                }
+            bool go = head && nx >= 0;
+            if (go && wL == 0 && !visit_clean(nx)) go = false; // clean: merge with any walker that has been here
+            int q = nx;
+            if (PAIR) { // the scout follows its walker one position ahead (x+1 is needed after x whenever x is clean, usually otherwise)
+                const bool h_go = __shfl((int)go, lane & ~1) != 0;
+                const int h_q = __shfl(q, lane & ~1);
+                if (!head) { go = h_go && h_q + 1 < tlen; q = h_q + 1; }
             }
+            if (go) launch(q);
             if (exhausted && __all(mode == NEED)) break;
             continue;
         }
@@ -789,18 +828,24 @@ hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDe
     uint64_t attr_bit = 0;
     static const int fth = getenv("SZL_LAZY_FTH") ? atoi(getenv("SZL_LAZY_FTH")) : 4, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
     static const int stride = getenv("SZL_STRIDE") ? atoi(getenv("SZL_STRIDE")) : 16;
+    static const bool pair = !(getenv("SZL_PAIR") && atoi(getenv("SZL_PAIR")) == 0); // walker + scout pairs (measured best on the data this form is used for)
     const int lds = B_LDS_BYTES + B_TILE / 8;
     if (lds_attr_needed(attr_mask, attr_bit)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_match_lazy<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_match_lazy<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match_lazy<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
     if (nblocks <= 0) return hipSuccess;
-    if (stride == 16) hipLaunchKernelGGL(k_match_lazy<16>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
-    else if (stride == 64) hipLaunchKernelGGL(k_match_lazy<64>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
-    else hipLaunchKernelGGL(k_match_lazy<32>, dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+    if (pair) {
+        if (stride == 16) hipLaunchKernelGGL((k_match_lazy<16, true>), dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+        else hipLaunchKernelGGL((k_match_lazy<32, true>), dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+    } else {
+        if (stride == 32) hipLaunchKernelGGL((k_match_lazy<32, false>), dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+        else hipLaunchKernelGGL((k_match_lazy<16, false>), dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
+    }
     return hipGetLastError();
 }
 
