@@ -144,6 +144,11 @@ int szl_engine_last_timing(const szl_engine *e, szl_timing *t);
 int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t *mq, size_t n_positions,
                            uint32_t *tokens, size_t tok_cap, size_t *n_tokens);
 
+/* Parity tap: choose the form of stage B (FindLongestMatch over all positions = 0, only over the positions a parse can
+ * reach = 1, pilot decides = 2, library default = -1; any other value only queries).  Returns 1 if the last call used the
+ * on-demand form.  Results are identical either way (C/DeflaterEngine.cs:474-612 is restated by both). */
+int szl_engine_debug_match_mode(szl_engine *e, int mode);
+
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);
 

@@ -89,6 +89,10 @@ class Engine:
                                                   tok.ctypes.data, n_positions, ctypes.byref(nt)), "debug_fetch")
         return link[:n_positions], m2[:n_positions], mq[:n_positions], tok[:nt.value]
 
+    def debug_match_mode(self, mode=99):
+        """Force the stage-B form (0 full, 1 on demand, 2 pilot, -1 default); returns True if the last call ran on demand."""
+        return bool(self._L.szl_engine_debug_match_mode(self._h, mode))
+
     def debug_blocks(self, cap=1 << 16):
         rows = np.zeros(8 * cap, np.uint64)
         nr = ctypes.c_size_t(0)

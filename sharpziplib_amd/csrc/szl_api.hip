@@ -297,6 +297,14 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
     return 0;
 }
 
+// Parity tap: force the stage-B form of this engine (0 full search, 1 on demand, 2 pilot, -1 default); returns the form the
+// last call used (1 = on demand) so that tests can tell what they exercised.
+int szl_engine_debug_match_mode(szl_engine *e, int mode) {
+    if (!e) return SZL_E_ARG;
+    if (mode >= -1 && mode <= 2) e->e.match_mode_override = mode;
+    return e->e.last_lazy ? 1 : 0;
+}
+
 // Parity tap: block table of the last call. rows of 8 x uint64: type,last,ntok,bit_start,opt_len,static_len,in_len,hdr_bits
 int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows) {
     if (!e) return SZL_E_ARG;

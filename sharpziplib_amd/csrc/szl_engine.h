@@ -39,6 +39,7 @@ class Engine {
     uint64_t last_evaluated = 0, last_eval_fallbacks = 0;
     double last_pilot_frac = -1.0;
     bool last_lazy = false;
+    int match_mode_override = -1; // debug tap: -1 = SZL_MATCH_MODE / default (2 = pilot), 0 full, 1 on demand
     // DeflateFast, single-segment calls (streaming Deflater): "inserted" bits of the buffer's history in (bit q = buffer
     // position q), and of the last 32 Ki positions out (bit 0 of fast_tail_bits = position fast_tail_start).
     std::vector<uint32_t> fast_hist_in, fast_tail_bits;

@@ -245,7 +245,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     // Two forms of stage B (szl_kernels_match.hip): search every position, or only the positions a parse can reach.
     // The second evaluates far fewer positions on repetitive data but each evaluation costs ~3x more, so a pilot on a
     // sample of tiles measures the evaluated fraction first (results are identical either way).
-    static const int match_mode = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 2; // 0 full, 1 on demand, 2 pilot
+    static const int match_mode_env = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 2; // 0 full, 1 on demand, 2 pilot
+    const int match_mode = match_mode_override >= 0 ? match_mode_override : match_mode_env;
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.30; // break-even measured at 0.36-0.40
     last_pilot_frac = -1.0;
     bool b_event = false; // ev[7]: start of the stage-B search proper (after the pilot)

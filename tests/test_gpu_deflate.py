@@ -556,3 +556,22 @@ def test_randomised_differential_all_modes(eng, seed):
         back = eng.inflate([r.data for r in res], [b.size for b in bufs], nowrap=nowrap)
         for b, (r, consumed), c in zip(bufs, back, res):
             assert r.status == 0 and r.data == b.tobytes() and consumed == len(c.data), (seed, trial, level, b.size)
+
+
+@pytest.mark.parametrize("name", ["logs", "enwik", "zeros", "mixed", "p10"])
+@pytest.mark.parametrize("level", [5, 6, 9])
+def test_on_demand_stage_b_is_bit_exact(eng, name, level):
+    """Both forms of stage B (search every position / only the positions a parse can reach + eval_global for the gaps) must give
+    the reference's bits; the pilot picks one per call, so force the on-demand form here."""
+    data = CLASSES[name]() if name != "logs" else C.generate("logs", 0x106, 0, 3 << 20)
+    ref = O.deflate(data, level)
+    try:
+        eng.debug_match_mode(1)
+        assert eng.deflate([data], level=level, crc32=True)[0].data == ref
+        assert eng.debug_match_mode() or name in ("zeros", "p10")   # (never-merging ranges fall back to the full search)
+        eng.debug_match_mode(2)
+        assert eng.deflate([data], level=level)[0].data == ref      # pilot (inputs >= 1 MiB) or full
+        if name == "logs":
+            assert eng.debug_match_mode()                            # repetitive data: the pilot picks the on-demand form
+    finally:
+        eng.debug_match_mode(-1)
