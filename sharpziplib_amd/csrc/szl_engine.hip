@@ -18,7 +18,12 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
                              const uint16_t *link, MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st);
 void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
-                 LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, hipStream_t st);
+                 LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, uint32_t *spec_tok, hipStream_t st);
+bool emit_copy_enabled();
+void launch_emit_copy(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                      LevelParams P, const RangeDev *ranges, const uint32_t *visited, const uint32_t *spec_tok,
+                      const uint64_t *range_tok, const SegOut *so, uint32_t *tokens, const uint64_t *blk_off, int64_t *blk_start_pos,
+                      int64_t *blk_lasttok_pos, hipStream_t st);
 void launch_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                 LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
                 uint64_t *bad_range, hipStream_t st);
@@ -84,7 +89,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -274,7 +279,10 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (!lazy) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
-    launch_spec(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, st);
+    const bool emit_copy = emit_copy_enabled(); // the speculative walk keeps its tokens; emission copies them (szl_kernels_parse.hip)
+    if (emit_copy && (rc = spec_tok.ensure(in_total * 4 + 1024))) return rc;
+    launch_spec(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt,
+                emit_copy ? (uint32_t *)spec_tok.p : nullptr, st);
     launch_fix(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt,
                (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
     {   // how many ranges never merged?  (one 8-byte read-back; the common answer is 0)
@@ -297,7 +305,12 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
     launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
-    launch_emit(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p,
+    if (emit_copy)
+        launch_emit_copy(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p, (const uint32_t *)visited.p,
+                         (const uint32_t *)spec_tok.p, (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p,
+                         (int64_t *)bsp.p, (int64_t *)blp.p, st);
+    else
+        launch_emit(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p,
                 (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
     HIPCHK(hipEventRecord(ev[4], st));
     }

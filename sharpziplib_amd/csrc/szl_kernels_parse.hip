@@ -547,7 +547,7 @@ __device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool ac
 template <int W>
 __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                                  uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
-                                                 uint32_t *visited, unsigned long long *counters) {
+                                                 uint32_t *visited, unsigned long long *counters, uint32_t *spec_tok) {
     constexpr int STRIDE = WinCfg<W>::STRIDE;
     __shared__ uint32_t sm2[64 * STRIDE];
     __shared__ uint32_t smq[64 * STRIDE];
@@ -573,8 +573,10 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
     while (__any(active)) {
         win_refill<W, false>(c, x, active, lane, sm2, smq, nullptr);
         __syncthreads();
-        const WinAcc wa{sm2 + lane * STRIDE, smq + lane * STRIDE, nullptr, x};
+        uint32_t *win = sm2 + lane * STRIDE;
+        const WinAcc wa{win, smq + lane * STRIDE, nullptr, x};
         const int64_t wend = x + W;
+        int nt = 0;
         while (active && x < wend) {
             if (L == 0) {
                 if (x >= re) { active = false; break; }
@@ -583,10 +585,20 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
                 acc |= 1u << (bit & 31);
             }
             uint32_t t = parse_step(c, wa, x, L, D, &tp, false, counters + 1);
-            count += (t != 0xFFFFFFFFu);
+            if (t != 0xFFFFFFFFu) { if (spec_tok) win[nt] = t; nt++; } // literal = 0, match = dist<<16|len; entry nt of the window is dead by now
         }
         if (active && L == 0 && x >= re) active = false;
         __syncthreads();
+        if (spec_tok) { // the k-th token of this range's speculative path goes to spec_tok[range start + k] (k_emit_copy reads them back)
+            for (uint64_t m = __ballot(nt > 0); m; m &= m - 1) {
+                const int j = __builtin_ctzll(m);
+                const int ntj = __builtin_amdgcn_readlane(nt, j);
+                uint32_t *dst = spec_tok + readlane64((int64_t)(s.buf_off + (uint64_t)rs + count), j);
+                if (lane < ntj) dst[lane] = sm2[j * STRIDE + lane];
+            }
+            __syncthreads();
+        }
+        count += (uint32_t)nt;
     }
     if (!mine) return;
     if (acc) vis[cw] = acc;
@@ -652,6 +664,90 @@ __global__ __launch_bounds__(64) void k_emit_win(const uint8_t *in, const uint16
     }
 }
 
+// C5, copy form (default).  The speculative walk already produced every range's tokens (k_spec_win -> spec_tok); the true
+// path of a merged range is a short fix-up prefix (entry -> merge point y, walked here like k_fix does) followed by the
+// speculative tokens from y on, so emission is a coalesced copy instead of a second walk: each lane does the prefix of its
+// range, then the wave copies range by range, turning literal placeholders into bytes (their positions are a running sum of
+// the token lengths) and recording block edges.  A range the true path never merges with is walked in full by its lane.
+__global__ __launch_bounds__(64) void k_emit_copy(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
+                                                  uint32_t nseg, uint64_t nranges, LevelParams P, const RangeDev *ranges,
+                                                  const uint32_t *visited, const uint32_t *spec_tok,
+                                                  const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
+                                                  const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos) {
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 64 + lane;
+    const bool mine = r0 < nranges;
+    const uint64_t r = mine ? r0 : nranges - 1;
+    const uint32_t si = find_seg(segs, nseg, r);
+    const SegDev s = segs[si];
+    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    const uint64_t lr = r - s.range_off;
+    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
+    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    const uint32_t *vis = visited + s.vis_word_off;
+    const RangeDev rd = ranges[r];
+    uint64_t ti = range_tok[r];
+    const uint64_t seg_tok0 = so[si].tok_first, seg_ntok = so[si].tok_count;
+    const uint64_t b0 = blk_off[si];
+    auto edges = [&](uint64_t tindex, int64_t tpos) { // block starts / last-token positions (C/DeflaterEngine.cs:841-852)
+        const uint64_t li = tindex - seg_tok0;
+        if ((li & (BLOCK_TOKENS - 1)) == 0) blk_start_pos[b0 + li / BLOCK_TOKENS] = tpos;
+        if ((li & (BLOCK_TOKENS - 1)) == BLOCK_TOKENS - 1 || li == seg_ntok - 1) blk_lasttok_pos[b0 + li / BLOCK_TOKENS] = tpos;
+    };
+    // ---- per lane: fix-up prefix from the true entry to the merge point y
+    int64_t y = -1;
+    uint32_t ncopy = 0, skip = 0;
+    if (mine && rs < re) {
+        int64_t x = lr == 0 ? rs : rd.entry, tp;
+        int L = 0, D = 0;
+        for (;;) {
+            if (L == 0) {
+                if (x >= re) break;
+                if (x >= rs && is_visited(vis, (uint64_t)(x - s.seg_start))) { y = x; break; }
+            }
+            const uint32_t t = parse_step(c, x, L, D, &tp, true, nullptr);
+            if (t != 0xFFFFFFFFu) { tokens[ti] = t; edges(ti, tp); ti++; }
+        }
+        if (y >= 0) { // tokens of speculative nodes before y are not on the true path
+            x = rs; L = 0; D = 0;
+            for (;;) {
+                if (L == 0 && x >= y) break;
+                const uint32_t t = parse_step(c, x, L, D, &tp, false, nullptr);
+                skip += (t != 0xFFFFFFFFu);
+            }
+            ncopy = rd.spec_count - skip;
+        }
+    }
+    // ---- the wave: copy each range's speculative tokens from y on
+    for (uint64_t m = __ballot(ncopy > 0); m; m &= m - 1) {
+        const int j = __builtin_ctzll(m);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ncopy, j);
+        const uint32_t *src = spec_tok + readlane64((int64_t)(s.buf_off + (uint64_t)rs + skip), j);
+        const uint64_t dst0 = (uint64_t)readlane64((int64_t)ti, j);
+        int64_t pos = readlane64(y, j);                                   // input position of the next token
+        const uint8_t *dj = (const uint8_t *)readlane64((int64_t)c.d, j);
+        const uint64_t j_tok0 = (uint64_t)readlane64((int64_t)seg_tok0, j), j_ntok = (uint64_t)readlane64((int64_t)seg_ntok, j);
+        const uint64_t j_b0 = (uint64_t)readlane64((int64_t)b0, j);
+        for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+            const bool on = k0 + lane < n;
+            uint32_t t = on ? src[k0 + lane] : 0u;
+            const uint32_t len = on ? ((t >> 16) ? (t & 0xFFFF) : 1u) : 0u;
+            uint32_t incl = len;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            const int64_t tpos = pos + (incl - len);
+            if (on) {
+                if ((t >> 16) == 0) t = dj[tpos];                          // literal placeholder -> the byte
+                const uint64_t tindex = dst0 + k0 + lane;
+                tokens[tindex] = t;
+                const uint64_t li = tindex - j_tok0;
+                if ((li & (BLOCK_TOKENS - 1)) == 0) blk_start_pos[j_b0 + li / BLOCK_TOKENS] = tpos;
+                if ((li & (BLOCK_TOKENS - 1)) == BLOCK_TOKENS - 1 || li == j_ntok - 1) blk_lasttok_pos[j_b0 + li / BLOCK_TOKENS] = tpos;
+            }
+            pos += (int64_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+}
+
 static int cwin_mode() {
     static const int m = getenv("SZL_CWIN") ? atoi(getenv("SZL_CWIN")) : 16;
     return m;
@@ -659,14 +755,14 @@ static int cwin_mode() {
 
 void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg,
                  uint64_t nranges, LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters,
-                 hipStream_t st) {
+                 uint32_t *spec_tok, hipStream_t st) {
     if (nranges == 0) return;
     const int cw = cwin_mode();
     const dim3 wg((unsigned)((nranges + 63) / 64));
-    if (cw == 64) { hipLaunchKernelGGL(k_spec_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
-    if (cw == 32) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
-    if (cw == 16) { hipLaunchKernelGGL(k_spec_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
-    if (cw == 8) { hipLaunchKernelGGL(k_spec_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters); return; }
+    if (cw == 64) { hipLaunchKernelGGL(k_spec_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+    if (cw == 32) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+    if (cw == 16) { hipLaunchKernelGGL(k_spec_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+    if (cw == 8) { hipLaunchKernelGGL(k_spec_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
     hipLaunchKernelGGL(k_spec, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, visited, counters);
 }
@@ -698,6 +794,18 @@ void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *cou
 void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts,
                        hipStream_t st) {
     hipLaunchKernelGGL(k_seg_tokens, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, range_tok, so, blk_counts);
+}
+bool emit_copy_enabled() {
+    static const bool on = cwin_mode() != 0 && !(getenv("SZL_EMIT_COPY") && atoi(getenv("SZL_EMIT_COPY")) == 0);
+    return on;
+}
+void launch_emit_copy(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
+                      LevelParams P, const RangeDev *ranges, const uint32_t *visited, const uint32_t *spec_tok,
+                      const uint64_t *range_tok, const SegOut *so, uint32_t *tokens, const uint64_t *blk_off, int64_t *blk_start_pos,
+                      int64_t *blk_lasttok_pos, hipStream_t st) {
+    if (nranges == 0) return;
+    hipLaunchKernelGGL(k_emit_copy, dim3((unsigned)((nranges + 63) / 64)), dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges,
+                       visited, spec_tok, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos);
 }
 void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
