@@ -420,7 +420,16 @@ __global__ __launch_bounds__(64) void k_block_scan(const SegDev *segs, uint32_t 
         uint64_t body = 0; uint32_t type = 1, inlen = 0;
         if (k < nb) { body = descs[b0 + k].body_bits; type = descs[b0 + k].type; inlen = descs[b0 + k].in_len; }
         uint64_t start = pos;
-        // serial within the 64-wide step via shuffles: lane i needs end of lane i-1
+        if (__ballot(k < nb && type == 0) == 0) { // no stored block among these 64 (the rule): positions are a plain prefix sum
+            const uint64_t mine = k < nb ? body : 0;
+            uint64_t incl = mine;
+            for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            start = pos + (incl - mine);
+            pos += __shfl(incl, 63);
+            if (k < nb) descs[b0 + k].bit_start = start;
+            continue;
+        }
+        // a stored block aligns to a byte (FlushStoredBlock :766-779): serial within the 64-wide step, lane i needs the end of lane i-1
         for (int i = 0; i < 64; i++) {
             uint64_t st_i = __shfl(start, i);
             uint64_t b_i = __shfl(body, i);

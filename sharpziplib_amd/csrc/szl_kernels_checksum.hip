@@ -3,6 +3,7 @@
 // Both checksums are sums over GF(2)/Z_65521 of per-byte terms, so chunks are computed independently
 // and folded: CRC with the x^(8·len) mod P operator, Adler with its closed form.
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include "szl_internal.h"
 
 namespace szl {
@@ -61,6 +62,27 @@ __global__ __launch_bounds__(CK_THREADS) void k_ck_partial(const uint8_t *__rest
     uint32_t crc = 0xFFFFFFFFu;
     uint32_t a = 0, b = 0; // a = sum d_i ; b = sum (len - i) d_i   (both < 2^32: 4096*255*4096 < 2^32)
     int i = 0;
+    // 16 bytes per load when the chunk start is 16-byte aligned (a lane strides 4 KiB: fewer, wider requests per cache line)
+    if ((((uintptr_t)p) & 15) == 0) {
+        for (; i + 16 <= len; i += 16) {
+            const uint4 v = *(const uint4 *)(p + i);
+            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t w = ws[q];
+                const int ii = i + 4 * q;
+                if (want & 1) {
+                    crc ^= w;
+                    crc = tab[3][crc & 0xFF] ^ tab[2][(crc >> 8) & 0xFF] ^ tab[1][(crc >> 16) & 0xFF] ^ tab[0][crc >> 24];
+                }
+                if (want & 2) {
+                    uint32_t d0 = w & 0xFF, d1 = (w >> 8) & 0xFF, d2 = (w >> 16) & 0xFF, d3 = w >> 24;
+                    a += d0 + d1 + d2 + d3;
+                    b += (uint32_t)(len - ii) * d0 + (uint32_t)(len - ii - 1) * d1 + (uint32_t)(len - ii - 2) * d2 + (uint32_t)(len - ii - 3) * d3;
+                }
+            }
+        }
+    }
     for (; i + 4 <= len; i += 4) {
         uint32_t w;
         __builtin_memcpy(&w, p + i, 4);
