@@ -105,13 +105,13 @@ def main():
         alg_bytes = n * (1.0 + ratio)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
-        tpath = next((t for t in (os.path.join(ROOT, "profiles", "r01", f) for f in ("f_traffic_pmc.json", "e_traffic_pmc.json", "d_traffic_pmc.json", "b_traffic_pmc.json"))
+        tpath = next((t for t in (os.path.join(ROOT, "profiles", "r01", f) for f in ("g_traffic_pmc.json", "f_traffic_pmc.json", "e_traffic_pmc.json", "d_traffic_pmc.json", "b_traffic_pmc.json"))
                       if os.path.exists(t)), "")
         if args.mib == 1024 and args.level == 6 and tpath:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units) of this same command, per launch of k_match;
             # FETCH_SIZE doubled for wide coalesced streaming reads on gfx950 (MI355X_MICROARCH.md §HBM)
             rec = json.load(open(tpath))
-            k = next((v for kk, v in rec.items() if "k_match" in kk), None)
+            k = next((v for kk, v in rec.items() if "k_match<" in kk), None)   # the search proper, not the pilot (k_match_lazy)
             if k:
                 traffic = int((2 * k["fetch"] + k["write"]) * 1024 / max(1, k.get("dispatches", 1)))
         line = {
