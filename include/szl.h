@@ -31,7 +31,7 @@ typedef enum szl_status {
     SZL_E_STATE = -2,          /* InvalidOperationException ("Finish() already called" C/Deflater.cs:333-336, "Old input was not completely processed" C/DeflaterEngine.cs:163-166, "Dictionary is not needed" C/Inflater.cs:580) */
     SZL_E_DEVICE = -3,         /* HIP error / no gfx950 device: surfaces as SharpZipBaseException */
     SZL_E_NOMEM = -4,
-    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not built yet on the device path (see DESIGN.md "out of scope") */
+    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not reproducible by a segment-at-a-time backend (SetLevel / SetStrategy mid-stream) */
     SZL_E_OUTPUT_TOO_SMALL = -6,
     /* Inflater errors == the SharpZipBaseException messages of C/Inflater.cs */
     SZL_E_HEADER_CHECKSUM = -16,   /* "Header checksum illegal"            C/Inflater.cs:224 */

@@ -4,7 +4,8 @@
 // bytes, device memory) and per-position side arrays indexed by the same byte offset g:
 //     in[g]       u8     input bytes
 //     link[g]     u16    stage A: distance to the previous inserted position with the same 3-byte hash
-//     mtab[g]     uint2  stage B: {M2, Mq} = FindLongestMatch(p) from matchLen 2, full / quarter chain budget
+//     m2[g],mq[g] u32    stage B: FindLongestMatch(p) from matchLen 2 with the full / quarter chain budget (M_UNSET = not evaluated)
+//     spec_tok[g] u32    stage C: tokens of each range's speculative path, stored at the range's first positions
 //     visited     1 bit  stage C: "a speculative parse of this position's range had a clean iteration here"
 //     tokens[]    u32    stage C: dense token stream (literal byte | dist<<16 | len)
 // A *segment* is the span of one stream between two Flush()/Finish() calls; all kernels are driven

@@ -11,7 +11,7 @@
 // decodes the token that would start at its bit offset of a 128-bit span and a readlane walk picks the real token
 // starts; block headers, long codes, stored blocks and stream ends go through lane 0's careful path.  All lanes
 // do the data movement (match copies inside the LDS window, window flushes to HBM, input staging, table
-// construction); independent streams (zip entries, gzip members) run on other wavefronts — 4 per CU, bounded
+// construction); independent streams (zip entries, gzip members) run on other wavefronts — 4 (10 in the short-window form) per CU, bounded
 // by the 32 KiB window each keeps in LDS.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
