@@ -414,3 +414,28 @@ size_t szm_fast_parse_fixpoint(const uint8_t *d, size_t seg_start, size_t seg_en
     free(fold); free(fnew); free(entry); free(exitp); free(stage); free(cnt);
     return nt;
 }
+
+/* ---- analysis helper (round-2 planning, not used by any kernel): which positions does the parse read? -----------------
+ * needed[p] = 1 if DeflateSlow's parse reads FindLongestMatch's result at p (clean iteration or lazy re-search). */
+size_t szm_parse_needed(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                        const uint32_t *mq, const szm_params *P, uint8_t *needed) {
+    size_t p = seg_start, count = 0;
+    while (p < seg_end) {
+        if (!needed[p]) { needed[p] = 1; count++; }
+        uint32_t m = m2[p];
+        int len = (int)(m & 0xFFFF), dist = (int)(m >> 16);
+        if (len && len <= 5 && (P->strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0;
+        if (!len) { p++; continue; }
+        size_t x = p + 1;
+        uint32_t cur = (uint32_t)len | ((uint32_t)dist << 16);
+        for (;;) {
+            uint32_t better;
+            if (x < seg_end && !needed[x]) { needed[x] = 1; count++; }
+            if (!research(d, x, seg_end, (int)(cur & 0xFFFF), link, m2, mq, P, &better, NULL)) break;
+            cur = better;
+            x++;
+        }
+        p = x - 1 + (cur & 0xFFFF);
+    }
+    return count;
+}

@@ -55,6 +55,10 @@ size_t szm_block_table(const uint32_t *tok, size_t ntok, int finish, int64_t *fi
 /* base_of(s): window base in effect for an iteration starting at absolute position s (App. A.2). */
 int64_t szm_base_of(int64_t s);
 
+/* Analysis helper: marks the positions at which the parse reads the match tables; returns how many. */
+size_t szm_parse_needed(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                        const uint32_t *mq, const szm_params *P, uint8_t *needed);
+
 /* ---- DeflateFast (levels 1-4), see szl_model.c ---- */
 typedef struct szm_fast_params { int nice, max_chain, max_lazy, strategy; } szm_fast_params;
 int szm_fast_level_params(int level, szm_fast_params *out); /* 0, or -1 if level is not 1..4 */
