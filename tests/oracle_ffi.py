@@ -25,6 +25,10 @@ class Trace(ctypes.Structure):
                 ("blk", ctypes.c_void_p), ("blk_cap", ctypes.c_size_t), ("blk_n", ctypes.c_size_t)]
 
 
+class FastParams(ctypes.Structure):
+    _fields_ = [("nice", ctypes.c_int), ("max_chain", ctypes.c_int), ("max_lazy", ctypes.c_int), ("strategy", ctypes.c_int)]
+
+
 class Params(ctypes.Structure):
     _fields_ = [("good", ctypes.c_int), ("nice", ctypes.c_int), ("max_chain", ctypes.c_int), ("strategy", ctypes.c_int)]
 
@@ -68,6 +72,10 @@ def lib():
         ("szm_parse_ranges", sz, [vp, sz, sz, vp, vp, vp, vp, sz, vp, vp]),
         ("szm_block_table", sz, [vp, sz, i32, vp, vp, vp]), ("szm_base_of", i64, [i64]),
         ("szo_dotnet_random_bytes", None, [ctypes.c_int32, vp, sz]),
+        ("szm_fast_level_params", i32, [i32, vp]), ("szm_base_of_fast", i64, [i64]),
+        ("szm_fast_parse", sz, [vp, sz, sz, vp, vp, vp, vp]),
+        ("szm_fast_parse_fixpoint", sz, [vp, sz, sz, vp, vp, sz, vp, vp, vp]),
+        ("szm_parse_needed", sz, [vp, sz, sz, vp, vp, vp, vp, vp]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
     _lib = L
