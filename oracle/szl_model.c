@@ -439,3 +439,43 @@ size_t szm_parse_needed(const uint8_t *d, size_t seg_start, size_t seg_end, cons
     }
     return count;
 }
+
+/* ---- model of stage B's on-demand form (k_match_lazy): which positions do the tile walkers evaluate? ------------------
+ * Inside every tile of `tile` positions a walker starts at each multiple of `stride`, follows the DeflateSlow step from
+ * position to position and stops on a clean position another walker has passed or when it leaves the tile.  The union
+ * does not depend on the order in which walkers run (each path is cut only where another one continues it). */
+size_t szm_lazy_eval_set(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                         const uint32_t *mq, const szm_params *P, size_t tile, size_t stride, uint8_t *evaluated) {
+    size_t count = 0;
+    uint8_t *clean = (uint8_t *)calloc(seg_end + 1, 1);
+    for (size_t t0 = seg_start; t0 < seg_end; t0 += tile) {
+        size_t t1 = t0 + tile < seg_end ? t0 + tile : seg_end;
+        for (size_t st = t0; st < t1; st += stride) {
+            size_t p = st;
+            while (p < t1) {
+                if (clean[p]) break;                 /* merge */
+                clean[p] = 1;
+                if (!evaluated[p]) { evaluated[p] = 1; count++; }
+                uint32_t m = m2[p];
+                int len = (int)(m & 0xFFFF), dist = (int)(m >> 16);
+                if (len && len <= 5 && (P->strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0;
+                if (!len) { p++; continue; }
+                size_t x = p + 1;
+                uint32_t cur = (uint32_t)len | ((uint32_t)dist << 16);
+                int left_tile = 0;
+                for (;;) {
+                    if (x >= t1) { left_tile = 1; break; }   /* the lazy look belongs to the next tile: not evaluated here */
+                    if (!evaluated[x]) { evaluated[x] = 1; count++; }
+                    uint32_t better;
+                    if (!research(d, x, seg_end, (int)(cur & 0xFFFF), link, m2, mq, P, &better, NULL)) break;
+                    cur = better;
+                    x++;
+                }
+                if (left_tile) break;
+                p = x - 1 + (cur & 0xFFFF);
+            }
+        }
+    }
+    free(clean);
+    return count;
+}

@@ -59,6 +59,10 @@ int64_t szm_base_of(int64_t s);
 size_t szm_parse_needed(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
                         const uint32_t *mq, const szm_params *P, uint8_t *needed);
 
+/* Model of k_match_lazy: positions evaluated by walkers started every `stride` positions inside tiles of `tile` positions. */
+size_t szm_lazy_eval_set(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
+                         const uint32_t *mq, const szm_params *P, size_t tile, size_t stride, uint8_t *evaluated);
+
 /* ---- DeflateFast (levels 1-4), see szl_model.c ---- */
 typedef struct szm_fast_params { int nice, max_chain, max_lazy, strategy; } szm_fast_params;
 int szm_fast_level_params(int level, szm_fast_params *out); /* 0, or -1 if level is not 1..4 */

@@ -76,6 +76,7 @@ def lib():
         ("szm_fast_parse", sz, [vp, sz, sz, vp, vp, vp, vp]),
         ("szm_fast_parse_fixpoint", sz, [vp, sz, sz, vp, vp, sz, vp, vp, vp]),
         ("szm_parse_needed", sz, [vp, sz, sz, vp, vp, vp, vp, vp]),
+        ("szm_lazy_eval_set", sz, [vp, sz, sz, vp, vp, vp, vp, sz, sz, vp]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
     _lib = L

@@ -76,3 +76,22 @@ def test_parse_reads_about_a_third_of_the_match_tables_on_text():
     k = L.szm_parse_needed(M._dpad.ctypes.data, 0, M.n, M.link.ctypes.data, M.m2.ctypes.data, M.mq.ctypes.data, ctypes.byref(M.P),
                            need.ctypes.data)
     assert k == int(need.sum()) and 0.25 < k / M.n < 0.45
+
+
+@pytest.mark.parametrize("kind,lo,hi", [("enwik", 0.40, 0.60), ("logs", 0.08, 0.30)])
+def test_on_demand_walkers_cover_the_parse_except_at_tile_crossings(kind, lo, hi):
+    """Model of k_match_lazy (stride 16, tiles of 16384): the positions the true parse reads are all evaluated by the tile
+    walkers except a handful right after the path crosses into a tile (those are what eval_global serves on the device)."""
+    L = O.lib()
+    data = C.generate(kind, 0xE9, 0, 1 << 20)
+    M = O.Model(data, 6)
+    args = (M._dpad.ctypes.data, 0, M.n, M.link.ctypes.data, M.m2.ctypes.data, M.mq.ctypes.data, ctypes.byref(M.P))
+    need = np.zeros(M.n + 8, np.uint8)
+    L.szm_parse_needed(*args, need.ctypes.data)
+    ev = np.zeros(M.n + 8, np.uint8)
+    k = L.szm_lazy_eval_set(*args, 16384, 16, ev.ctypes.data)
+    assert lo < k / M.n < hi
+    miss = np.nonzero((need[:M.n] == 1) & (ev[:M.n] == 0))[0]
+    ntiles = M.n // 16384
+    assert miss.size <= 6 * ntiles                                   # a few per tile boundary at most
+    assert np.all(miss % 16384 < 600)                                # and only right behind a tile start (before the paths merge)
