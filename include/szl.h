@@ -44,7 +44,10 @@ typedef enum szl_status {
     SZL_E_CODELEN_ZERO = -23,      /* "Encountered invalid codelength 0"   C/InflaterHuffmanTree.cs:191-193 */
     SZL_E_DYN_HEADER = -24,        /* ValueOutOfRange/StreamDecodingException C/InflaterDynHeader.cs:50-52,83,106,114 */
     SZL_E_UNEXPECTED_EOF = -25,    /* batch inflate only: input exhausted before the final block (CS/InflaterInputStream.cs:494) */
-    SZL_E_WINDOW_FULL = -26        /* CS/OutputWindow.cs:37,66 */
+    SZL_E_WINDOW_FULL = -26,       /* CS/OutputWindow.cs:37,66 */
+    SZL_E_CODE_OVERSUBSCRIBED = -27 /* over-subscribed code lengths in a dynamic header: the reference's InflaterHuffmanTree.BuildTree
+                                       throws IndexOutOfRangeException out of DeflaterHuffman.BitReverse (C/InflaterHuffmanTree.cs:133-166,
+                                       C/DeflaterHuffman.cs:924-930); the shim rethrows that type */
 } szl_status;
 
 const char *szl_strerror(int status);
@@ -122,7 +125,10 @@ szl_engine *szl_engine_create(void);
 void szl_engine_destroy(szl_engine *e);
 
 /* Device-resident: d_in/d_out are device pointers; nothing crosses PCIe except the stream table.
- * `hip_stream` is a hipStream_t (NULL = default stream).  Synchronous on return. */
+ * `hip_stream` is a hipStream_t (NULL = default stream).  Synchronous on return.
+ * Only the streams' own regions d_out[out_off, out_off + out_cap) are written (zero-filled, then encoded into); bytes of
+ * d_out before, between and after them are left untouched, so a caller may pre-place container framing (zip local
+ * headers) around the regions. */
 int szl_deflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_streams,
                              int level, int strategy, unsigned flags, void *hip_stream);
 /* Host buffers: copies H2D, runs the same pipeline, copies D2H. */

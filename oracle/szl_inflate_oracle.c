@@ -172,7 +172,12 @@ static int ow_copy_output(OW *w, uint8_t *output, int offset, int len) { /* :182
 
 /* ================================================================= InflaterHuffmanTree.cs */
 static const uint8_t bit4Reverse[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-static int bit_reverse16(int v) { /* DeflaterHuffman.BitReverse returns short; used as index after int promotion */
+/* DeflaterHuffman.BitReverse (C/DeflaterHuffman.cs:924-930) returns short; used as index after int promotion.
+ * `bit4Reverse[toReverse >> 12]` indexes a 16-entry array: for toReverse >= 65536 (over-subscribed code lengths) the
+ * reference throws IndexOutOfRangeException inside BuildTree — reported here as BR_RANGE (never UB). */
+#define BR_RANGE 0x40000000
+static int bit_reverse16(int v) {
+    if (v < 0 || (v >> 12) > 15) return BR_RANGE;
     return (int)(int16_t)(bit4Reverse[v & 0xF] << 12 | bit4Reverse[(v >> 4) & 0xF] << 8 |
                           bit4Reverse[(v >> 8) & 0xF] << 4 | bit4Reverse[v >> 12]);
 }
@@ -211,7 +216,8 @@ static int iht_build(IHT *t, const uint8_t *codeLengths, int n) { /* :87 */
         int start = code & 0x1ff80;
         for (int i = start; i < end; i += 1 << 7) {
             int idx = bit_reverse16(i);
-            if (idx < 0 || idx >= cap) return SZO_ERR_DYN_HEADER;
+            if (idx == BR_RANGE) return SZO_ERR_INDEX_RANGE;
+            if (idx < 0 || idx >= cap) return SZO_ERR_INDEX_RANGE; /* tree[] index outside new short[treeSize] */
             t->tree[idx] = (int16_t)(((-treePtr) * 16) | bits);
             treePtr += 1 << (bits - 9);
         }
@@ -221,9 +227,10 @@ static int iht_build(IHT *t, const uint8_t *codeLengths, int n) { /* :87 */
         if (bits == 0) continue;
         code = nextCode[bits];
         int revcode = bit_reverse16(code);
+        if (revcode == BR_RANGE) return SZO_ERR_INDEX_RANGE;
         if (bits <= 9) {
             do {
-                if (revcode < 0 || revcode >= cap) return SZO_ERR_DYN_HEADER;
+                if (revcode < 0 || revcode >= cap) return SZO_ERR_INDEX_RANGE;
                 t->tree[revcode] = (int16_t)((i << 4) | bits);
                 revcode += 1 << bits;
             } while (revcode < 512);
@@ -233,7 +240,7 @@ static int iht_build(IHT *t, const uint8_t *codeLengths, int n) { /* :87 */
             subTree = -(subTree >> 4);
             do {
                 int idx = subTree | (revcode >> 9);
-                if (idx < 0 || idx >= cap) return SZO_ERR_DYN_HEADER;
+                if (idx < 0 || idx >= cap) return SZO_ERR_INDEX_RANGE;
                 t->tree[idx] = (int16_t)((i << 4) | bits);
                 revcode += 1 << bits;
             } while (revcode < treeLen);
@@ -691,6 +698,39 @@ int64_t szo_inflate_oneshot(const uint8_t *in, size_t n, int noHeader, uint8_t *
         }
     }
     if (consumed) *consumed = (size_t)szo_inflater_total_in(s);
+    szo_inflater_free(s);
+    return rc;
+}
+
+/* Test helper: like szo_inflate_oneshot, but output is requested ONE byte per Inflate() call, which is the finest
+ * grain at which the reference hands out bytes (C/Inflater.cs:749-774: copy from the window first, Decode() only when the
+ * window is drained) — so *produced is the longest prefix a caller of the reference can have received before the
+ * exception that ends the stream.  Returns total bytes (finished) or the negative error. */
+int64_t szo_inflate_probe(const uint8_t *in, size_t n, int noHeader, uint8_t *out, size_t out_cap, size_t *consumed,
+                          size_t *produced) {
+    szo_inflater *s = szo_inflater_new(noHeader);
+    if (!s) return SZO_ERR_ARG;
+    size_t op = 0;
+    int64_t rc = 0;
+    int fed = 0;
+    uint8_t scratch[2];
+    for (;;) {
+        int k = szo_inflater_inflate(s, op < out_cap ? out + op : scratch, 1);
+        if (k < 0) { rc = k; break; }
+        if (k > 0 && op >= out_cap) { rc = -100; break; }
+        op += (size_t)k;
+        if (szo_inflater_is_finished(s)) { rc = (int64_t)op; break; }
+        if (k == 0) {
+            if (szo_inflater_needs_dictionary(s)) { rc = SZO_ERR_STATE; break; }
+            if (szo_inflater_needs_input(s)) {
+                if (fed || n >= ((size_t)1 << 30)) { rc = -102; break; }
+                szo_inflater_set_input(s, in, (int)n);
+                fed = 1;
+            } else { rc = -103; break; }
+        }
+    }
+    if (consumed) *consumed = (size_t)szo_inflater_total_in(s);
+    if (produced) *produced = op;
     szo_inflater_free(s);
     return rc;
 }

@@ -43,7 +43,10 @@ enum {
     SZO_ERR_DYN_HEADER = -9,        /* ValueOutOfRange / StreamDecodingException C/InflaterDynHeader.cs:50-52,83,106,114 */
     SZO_ERR_WINDOW_FULL = -10,      /* "Window full" CS/OutputWindow.cs:37,66 */
     SZO_ERR_STATE = -11,            /* InvalidOperationException family */
-    SZO_ERR_ARG = -12               /* ArgumentOutOfRange family */
+    SZO_ERR_ARG = -12,              /* ArgumentOutOfRange family */
+    SZO_ERR_INDEX_RANGE = -13       /* IndexOutOfRangeException out of InflaterHuffmanTree.BuildTree (C/InflaterHuffmanTree.cs:133-166):
+                                       over-subscribed code lengths push a canonical code to >= 65536 and
+                                       DeflaterHuffman.BitReverse (C/DeflaterHuffman.cs:924-930) indexes bit4Reverse[16+] */
 };
 
 /* ------------------------------------------------------------------ checksums (K/) */
@@ -115,6 +118,9 @@ uint32_t szo_inflater_adler(const szo_inflater *s);
 /* One-shot: inflate `in` fully into out; returns bytes or negative error; *consumed = TotalIn. */
 int64_t szo_inflate_oneshot(const uint8_t *in, size_t n, int no_header, uint8_t *out, size_t out_cap,
                             size_t *consumed);
+/* Same, asking for one byte per Inflate() call: *produced = bytes delivered before the error (or in total). */
+int64_t szo_inflate_probe(const uint8_t *in, size_t n, int no_header, uint8_t *out, size_t out_cap, size_t *consumed,
+                          size_t *produced);
 
 #ifdef __cplusplus
 }

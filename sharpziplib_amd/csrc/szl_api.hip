@@ -36,6 +36,7 @@ const char *szl_strerror(int st) {
     case SZL_E_DYN_HEADER: return "invalid dynamic block header";
     case SZL_E_UNEXPECTED_EOF: return "Unexpected EOF";
     case SZL_E_WINDOW_FULL: return "Window full";
+    case SZL_E_CODE_OVERSUBSCRIBED: return "Index was outside the bounds of the array (over-subscribed code lengths)";
     default: return "unknown status";
     }
 }

@@ -243,18 +243,25 @@ static int inflater_step(szl_inflater *s) {
     const size_t nin = s->hin.size();
     if ((rc = s->d_in.ensure(nin + 64)) || (rc = s->d_out.ensure(szl_inflater::OUT_CHUNK + 64)) || (rc = s->d_win.ensure(32768)) ||
         (rc = s->d_job.ensure(sizeof(InfJob))) || (rc = s->d_state.ensure(sizeof(InfState)))) return rc;
+    // One step produces at most OUT_CHUNK bytes, so it cannot need more than about that much input (stored data is 1:1):
+    // upload a bounded prefix instead of the whole unconsumed input every step (a large SetInput would cost O(n^2) H2D).
+    const size_t nup = std::min<size_t>(nin, szl_inflater::OUT_CHUNK + (64u << 10));
     InfJob j{};
-    j.in_off = 0; j.in_len = nin; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
+    j.in_off = 0; j.in_len = nup; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
     j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1; j.load_window = s->have_dict ? 1 : 0;
-    if (nin) HIPCHK(hipMemcpy(s->d_in.p, s->hin.data(), nin, hipMemcpyHostToDevice));
+    if (nup) HIPCHK(hipMemcpy(s->d_in.p, s->hin.data(), nup, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_job.p, &j, sizeof j, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_state.p, &s->st, sizeof s->st, hipMemcpyHostToDevice));
     launch_inflate((const uint8_t *)s->d_in.p, (uint8_t *)s->d_out.p, (InfJob *)s->d_job.p, (InfState *)s->d_state.p, 1, false, nullptr);
     HIPCHK(hipMemcpy(&j, s->d_job.p, sizeof j, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&s->st, s->d_state.p, sizeof s->st, hipMemcpyDeviceToHost));
     s->fresh_input = false;
-    if (j.status < 0) { s->err = j.status; return j.status; }
-    s->dec_status = j.status;
+    // A corrupt token stops the decoder, but everything it decoded before that point is still delivered (the reference hands
+    // those bytes out over earlier Inflate() calls and throws only when it reaches the bad token): record the error, keep the
+    // bytes; szl_inflater_inflate returns the error once they are drained.
+    if (j.status < 0) s->err = j.status;
+    else s->dec_status = j.status;
+    if (j.status == INF_NEED_INPUT && nup < nin) s->fresh_input = true; // only the uploaded prefix ran dry
     if (j.out_written) {
         size_t old = s->pend.size();
         if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
@@ -267,7 +274,8 @@ static int inflater_step(szl_inflater *s) {
             s->adler_dec = out[0].second;
         }
     }
-    if (s->dec_status == INF_FINISHED && !s->no_header && s->st.adler_read != s->adler_dec) { s->err = SZL_E_ADLER_MISMATCH; return s->err; }
+    if (s->err) return 0;
+    if (s->dec_status == INF_FINISHED && !s->no_header && s->st.adler_read != s->adler_dec) { s->err = SZL_E_ADLER_MISMATCH; return 0; }
     // drop the consumed whole dwords of input; keep bitpos relative to the new base
     uint64_t drop = (s->st.bitpos >> 3) & ~3ull;
     if (s->st.mode == INF_M_ZHEADER) drop = 0;
@@ -282,10 +290,11 @@ static int inflater_step(szl_inflater *s) {
 
 int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count) { // :715
     if (!s || count < 0 || (!out && count)) return SZL_E_ARG;
-    if (s->err) return s->err;
+    if (s->err && s->pend_pos == s->pend.size()) return s->err;
     int copied = 0;
     for (;;) {
         size_t avail = s->pend.size() - s->pend_pos;
+        if (s->err && avail == 0) return copied ? copied : s->err; // bytes decoded before the error went out first
         if (avail && count) {
             size_t k = std::min<size_t>(avail, (size_t)count);
             memcpy(out, s->pend.data() + s->pend_pos, k);
@@ -299,6 +308,7 @@ int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count) { // :715
         if (s->dec_status == INF_FINISHED) return copied;
         if (s->dec_status == INF_NEED_DICT) return copied;                      // IsNeedingDictionary: the caller must SetDictionary
         if (s->dec_status == INF_NEED_INPUT && !s->fresh_input) return copied; // IsNeedingInput
+        if (s->err) return copied; // (count == 0 with bytes still pending: nothing to hand out, nothing more to decode)
         int rc = inflater_step(s);
         if (rc) return rc;
         if (count == 0) return copied; // Inflate(…, 0): "count may be zero" still advances the decoder (:738-745)

@@ -51,6 +51,8 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
 void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint32_t n, hipStream_t st);
+void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st);
+int zero_piece_bytes();
 
 thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
@@ -89,7 +91,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -120,7 +122,11 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     span_len = (span_len + 63) & ~63ull;
     std::vector<SpanDev> spans;
     std::vector<TileDev> tiles;
-    std::vector<uint64_t> chunk_off(nseg + 1);
+    std::vector<uint64_t> chunk_off(nseg + 1), zero_off(nseg + 1);
+    uint64_t nzero = 0;
+    for (uint32_t i = 0; i < nseg; i++) { zero_off[i] = nzero; nzero += (segs[i].out_cap + (uint64_t)zero_piece_bytes() - 1) / (uint64_t)zero_piece_bytes(); }
+    zero_off[nseg] = nzero;
+    if (nzero > 0x7FFFFFFFull) { set_error("batch too large"); return SZL_E_ARG; }
     const bool fast = P.fast != 0;             // DeflateFast: one wavefront per segment instead of stages B and C
     bool lazy = false;                         // stage B ran in its on-demand form
     std::vector<uint64_t> fast_blk_off;        // (its block slots are laid out here, not by a device scan)
@@ -192,6 +198,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if ((rc = upload(d_spans, spans, st))) return rc;
     if ((rc = upload(d_tiles, tiles, st))) return rc;
     if ((rc = upload(ckoff, chunk_off, st))) return rc;
+    if ((rc = upload(d_zoff, zero_off, st))) return rc;
     size_t cub_bytes1 = 0, cub_bytes2 = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
@@ -202,7 +209,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     unsigned long long *dcnt = (unsigned long long *)counters.p;
 
     HIPCHK(hipEventRecord(ev[0], st));
-    HIPCHK(hipMemsetAsync(d_out, 0, out_total, st));
+    launch_zero_regions(dsegs, nseg, (const uint64_t *)d_zoff.p, nzero, d_out, st); // only the streams' own regions (szl.h)
     HIPCHK(hipMemsetAsync(visited.p, 0, (vis_words + 4) * 4, st));
     HIPCHK(hipMemsetAsync(counters.p, 0, 64, st));
     HIPCHK(hipMemsetAsync(d_so.p, 0, nseg * sizeof(SegOut), st));

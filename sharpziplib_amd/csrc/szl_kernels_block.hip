@@ -638,6 +638,38 @@ void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint3
     if (n) hipLaunchKernelGGL(k_stored, dim3(n), dim3(256), 0, st, in, out, blks, n);
 }
 
+
+// The encoder ORs bits into its output, so every segment's region [out_off, out_off + out_cap) starts as zeros — and ONLY the
+// regions: bytes of the caller's buffer before, between and after them (zip local headers in the passthrough layout,
+// INTEGRATION.md §3) are never touched.  zoff[i] = index of segment i's first 64 KiB piece (host-built prefix sum).
+enum : int { Z_PIECE = 65536 };
+__global__ __launch_bounds__(256) void k_zero_regions(const SegDev *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ zoff,
+                                                      uint8_t *__restrict__ out) {
+    const uint64_t b = blockIdx.x;
+    uint32_t lo = 0, hi = nseg; // last segment with zoff[seg] <= b
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (zoff[mid] <= b) lo = mid; else hi = mid; }
+    const SegDev s = segs[lo];
+    const uint64_t a = (b - zoff[lo]) * (uint64_t)Z_PIECE;
+    if (a >= s.out_cap) return;
+    const uint64_t len = s.out_cap - a < (uint64_t)Z_PIECE ? s.out_cap - a : (uint64_t)Z_PIECE;
+    uint8_t *o = out + s.out_off + a;          // out_off is 4-byte aligned, a is a multiple of 64 KiB
+    const uint64_t ndw = len >> 2;
+    uint32_t *o32 = (uint32_t *)o;
+    if ((((uintptr_t)o) & 15) == 0) {
+        uint4 *o128 = (uint4 *)o;
+        const uint64_t n16 = ndw >> 2;
+        for (uint64_t i = threadIdx.x; i < n16; i += 256) o128[i] = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = (n16 << 2) + threadIdx.x; i < ndw; i += 256) o32[i] = 0;
+    } else {
+        for (uint64_t i = threadIdx.x; i < ndw; i += 256) o32[i] = 0;
+    }
+    for (uint64_t i = (ndw << 2) + threadIdx.x; i < len; i += 256) o[i] = 0;
+}
+void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st) {
+    if (npieces) hipLaunchKernelGGL(k_zero_regions, dim3((unsigned)npieces), dim3(256), 0, st, segs, nseg, zoff, out);
+}
+int zero_piece_bytes() { return Z_PIECE; }
+
 void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens, const uint64_t *blk_off, SegOut *so,
                        int fast, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, tokens, blk_off, so, fast);

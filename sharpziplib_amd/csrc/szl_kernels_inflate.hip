@@ -52,19 +52,26 @@ struct InfLds {
 };
 
 // Build decode tables from code lengths lens[0..n) (all lanes). pb = primary bits.
-__device__ void build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut, int pb, uint16_t *codes, int lane) {
+// Returns false for an over-subscribed set (wave-uniform): the reference's BuildTree then throws IndexOutOfRangeException
+// out of DeflaterHuffman.BitReverse as soon as a canonical code reaches 65536 (C/InflaterHuffmanTree.cs:133-166,
+// C/DeflaterHuffman.cs:924-930) — always, because the last code of the longest length is >= 65536 exactly when the
+// lengths' Kraft sum exceeds 1.  Incomplete sets are accepted like there (:116-121 commented out).
+__device__ bool build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut, int pb, uint16_t *codes, int lane) {
     for (int i = lane; i < (1 << pb); i += 64) lut[i] = 0;
+    int over = 0;
     if (lane == 0) {
         int cnt[16];
         for (int l = 0; l < 16; l++) cnt[l] = 0;
         for (int i = 0; i < n; i++) cnt[lens[i]]++;
         cnt[0] = 0;
-        int code = 0, off = 0;
+        int code = 0, off = 0, kraft = 0;
         for (int l = 1; l < 16; l++) {
             T->first[l] = (uint16_t)code; T->count[l] = (uint16_t)cnt[l]; T->offs[l] = (uint16_t)off;
             code = (code + cnt[l]) << 1;
             off += cnt[l];
+            kraft += cnt[l] << (16 - l);
         }
+        over = kraft > 65536;
         int nxt[16], pos[16];
         for (int l = 1; l < 16; l++) { nxt[l] = T->first[l]; pos[l] = T->offs[l]; }
         for (int i = 0; i < n; i++) {
@@ -74,6 +81,7 @@ __device__ void build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut,
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (__builtin_amdgcn_readfirstlane(over)) return false;
     for (int i = lane; i < n; i += 64) {
         int l = lens[i];
         if (l == 0) continue;
@@ -87,6 +95,7 @@ __device__ void build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut,
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return true;
 }
 
 // decode one symbol from the low bits of `bits` (LSB-first); returns sym | len<<16, or -1 invalid
@@ -139,7 +148,12 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
     // window: restore the last 32 KiB of output
     if (!SHORTWIN && (outpos > 0 || job.load_window) && job.window) {
         for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&S.win[i] = *(const uint4 *)&job.window[i];
+    } else {
+        // A fresh stream starts on the reference's zero-initialised window (CS/OutputWindow.cs:22): a match whose distance
+        // reaches before the first output byte yields zeros there, never stale LDS of another workgroup.
+        for (int i = lane * 16; i < WIN; i += 64 * 16) *(uint4 *)&S.win[i] = make_uint4(0, 0, 0, 0);
     }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     // zlib header (C/Inflater.cs:211-249)
     if (mode == INF_M_ZHEADER) {
         if (in_bits < 16) status = INF_NEED_INPUT;
@@ -156,22 +170,23 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
             } else { bitpos = 16; mode = INF_M_HEADER; }
         }
     }
-    auto rebuild_tables = [&]() {
+    auto rebuild_tables = [&]() -> bool {
         if (btype == 1) {
             for (int i = lane; i < 288; i += 64) S.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)); // C/InflaterHuffmanTree.cs:34-70
             if (lane < 32) S.lens[288 + lane] = 5;
             __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             build_tab(S.lens, 288, &S.lt, S.llut, I_LPB, S.codes, lane);
             build_tab(S.lens + 288, 32, &S.dt, S.dlut, I_DPB, S.codes, lane);
-        } else {
-            build_tab(S.lens, (int)lnum, &S.lt, S.llut, I_LPB, S.codes, lane);
-            build_tab(S.lens + lnum, (int)dnum, &S.dt, S.dlut, I_DPB, S.codes, lane);
+            return true;
         }
+        // literal/length tree first, then the distance tree (C/InflaterDynHeader.cs:126-134 via C/Inflater.cs DECODE_DYN_HEADER)
+        if (!build_tab(S.lens, (int)lnum, &S.lt, S.llut, I_LPB, S.codes, lane)) return false;
+        return build_tab(S.lens + lnum, (int)dnum, &S.dt, S.dlut, I_DPB, S.codes, lane);
     };
     if (status == INF_RUNNING && mode == INF_M_HUFF) {
         if (btype == 2) for (int i = lane; i < 320; i += 64) S.lens[i] = st->lens[i];
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        rebuild_tables();
+        (void)rebuild_tables(); // a resumed block: these lengths were accepted when its header was read
     }
 
     // ---- input staging: S.stage holds input bytes [sbase, sbase + I_STAGE)
@@ -425,6 +440,11 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                         if (fail) break;
                         uint16_t *mlut = S.codes; // 128 entries
                         for (int i = 0; i < 128; i++) mlut[i] = 0;
+                        { // new InflaterHuffmanTree(codeLengths) of the code-length alphabet (C/InflaterDynHeader.cs:64): over-subscribed => throws
+                            int kraft = 0;
+                            for (int i = 0; i < 19; i++) if (ml[i]) kraft += 1 << (16 - ml[i]);
+                            if (kraft > 65536) { fail = SZL_E_CODE_OVERSUBSCRIBED; break; }
+                        }
                         int code = 0;
                         for (int l = 1; l < 8; l++) { // canonical codes, length by length, symbols in order
                             for (int i = 0; i < 19; i++) {
@@ -496,8 +516,11 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                 const uint32_t len = t2 & 0xFFFF, d2 = t2 >> 16;
                 const uint64_t p = outpos + off;
                 if (SHORTWIN && d2 > FAR_DIST) { // older than the LDS window: already flushed to the output region (ROOM < FAR_DIST - 258)
-                    const uint8_t *src = out + (p - d2 - out_start);
-                    for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = __atomic_load_n(src + k, __ATOMIC_RELAXED);
+                    // (one-shot jobs: out_start == 0.)  Bytes before the start of the stream are the zeros of a fresh
+                    // OutputWindow — never another stream's output region in front of this one.
+                    const int64_t s0 = (int64_t)(p - out_start) - (int64_t)d2;
+                    for (uint32_t k = lane; k < len; k += 64)
+                        S.win[(p + k) & I_WMASK] = s0 + (int64_t)k >= 0 ? __atomic_load_n(out + (s0 + (int64_t)k), __ATOMIC_RELAXED) : (uint8_t)0;
                 } else if (d2 >= len) { // no overlap (wave-uniform test): plain copy
                     for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k) & I_WMASK];
                 } else {
@@ -525,7 +548,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
         } break;
         case EV_TABLES:
             btype = (uint32_t)ea & 3; lnum = ((uint32_t)ea >> 8) & 0xFFF; dnum = ((uint32_t)ea >> 20) & 0xFF;
-            rebuild_tables();
+            if (!rebuild_tables()) status = SZL_E_CODE_OVERSUBSCRIBED;
             break;
         case EV_STORED: {
             const uint64_t n = (uint32_t)ea;

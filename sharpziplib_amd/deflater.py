@@ -32,6 +32,8 @@ def _raise(status, where):
         raise InvalidOperation(msg)
     if status == -5:
         raise NotSupportedOnDevice(msg)
+    if status == -27:
+        raise IndexError(msg)  # IndexOutOfRangeException out of InflaterHuffmanTree.BuildTree (over-subscribed code lengths)
     raise SharpZipBaseException(msg)
 
 
@@ -90,7 +92,9 @@ class Deflater:
     def SetDictionary(self, dictionary, index=0, count=None):
         a = np.ascontiguousarray(np.frombuffer(dictionary, dtype=np.uint8))
         count = a.size - index if count is None else count
-        s = self._L.szl_deflater_set_dictionary(self._h, a[index:].ctypes.data, count)
+        if index < 0 or count < 0 or index + count > a.size:
+            raise ValueError("count")  # the reference reads buffer[offset..offset+length) (C/DeflaterEngine.cs:198-229)
+        s = self._L.szl_deflater_set_dictionary(self._h, a[index:].ctypes.data if count else None, count)
         if s < 0:
             _raise(s, "SetDictionary")
 
@@ -104,6 +108,8 @@ class Deflater:
         """output: writable numpy uint8 array / bytearray. Returns number of bytes written."""
         a = np.frombuffer(output, dtype=np.uint8) if not isinstance(output, np.ndarray) else output
         length = a.size - offset if length is None else length
+        if offset < 0 or length < 0 or offset + length > a.size:
+            raise IndexError("output[offset..offset+length) does not fit the array")  # C/Deflater.cs:427 indexes the array itself
         if length == 0:
             n = self._L.szl_deflater_deflate(self._h, None, 0)
         else:

@@ -58,6 +58,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 				case -2: return new InvalidOperationException(detail ?? msg);             // SZL_E_STATE
 				case -5: return new NotSupportedException(detail ?? msg);                 // SZL_E_UNSUPPORTED
 				case -24: return new StreamDecodingException(msg);                         // SZL_E_DYN_HEADER
+				case -27: return new IndexOutOfRangeException(msg);                        // SZL_E_CODE_OVERSUBSCRIBED (what BuildTree throws there)
 				default: return new SharpZipBaseException(msg + (detail != null ? ": " + detail : "")); // incl. -3 device errors
 			}
 		}
@@ -101,11 +102,17 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		public int Deflate(byte[] output) => Deflate(output, 0, output.Length);
 		public unsafe int Deflate(byte[] output, int offset, int length)                                 // :427
 		{
+			// Deflater.cs:427 indexes output[offset..offset+length) itself (IndexOutOfRangeException when it does not fit);
+			// native code must never see a range outside the managed array
+			if (output == null) throw new ArgumentNullException(nameof(output));
+			if (offset < 0 || length < 0 || offset > output.Length - length) throw new IndexOutOfRangeException();
 			fixed (byte* p = output) return Check(SzlNative.szl_deflater_deflate(h, p + offset, length), nameof(Deflate));
 		}
 		public void SetDictionary(byte[] dictionary) { SetDictionary(dictionary, 0, dictionary.Length); }
 		public unsafe void SetDictionary(byte[] dictionary, int index, int count)                        // :559
 		{
+			if (dictionary == null) throw new ArgumentNullException(nameof(dictionary));
+			if (index < 0 || count < 0 || index > dictionary.Length - count) throw new ArgumentOutOfRangeException(nameof(count)); // DeflaterEngine.cs:198-229 reads buffer[offset..offset+length)
 			fixed (byte* p = dictionary) Check(SzlNative.szl_deflater_set_dictionary(h, p + index, count), nameof(SetDictionary));
 		}
 
@@ -130,11 +137,19 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		public void SetInput(byte[] buffer) { SetInput(buffer, 0, buffer.Length); }
 		public unsafe void SetInput(byte[] buffer, int index, int count)                                 // :629
 		{
+			if (buffer == null) throw new ArgumentNullException(nameof(buffer));                          // StreamManipulator.SetInput CS/StreamManipulator.cs:244-262
+			if (index < 0) throw new ArgumentOutOfRangeException(nameof(index), "Cannot be negative");
+			if (count < 0) throw new ArgumentOutOfRangeException(nameof(count), "Cannot be negative");
+			if (index > buffer.Length - count) throw new ArgumentOutOfRangeException(nameof(count));
 			fixed (byte* p = buffer) Check(SzlNative.szl_inflater_set_input(h, p + index, count), nameof(SetInput));
 		}
 		public void SetDictionary(byte[] buffer) { SetDictionary(buffer, 0, buffer.Length); }
 		public unsafe void SetDictionary(byte[] buffer, int index, int count)                            // :563
 		{
+			if (buffer == null) throw new ArgumentNullException(nameof(buffer));                          // Inflater.cs:565-571
+			if (index < 0) throw new ArgumentOutOfRangeException(nameof(index));
+			if (count < 0) throw new ArgumentOutOfRangeException(nameof(count));
+			if (index > buffer.Length - count) throw new ArgumentOutOfRangeException(nameof(count));
 			fixed (byte* p = buffer) Check(SzlNative.szl_inflater_set_dictionary(h, p + index, count), nameof(SetDictionary));
 		}
 		public int Inflate(byte[] buffer) => Inflate(buffer, 0, buffer.Length);

@@ -34,7 +34,10 @@ class Inflater:
 
     def SetDictionary(self, buffer, index=0, count=None):
         a = np.ascontiguousarray(np.frombuffer(buffer, dtype=np.uint8))
-        s = self._L.szl_inflater_set_dictionary(self._h, a.ctypes.data, a.size if count is None else count)
+        count = a.size - index if count is None else count
+        if index < 0 or count < 0 or index + count > a.size:
+            raise ValueError("count")  # C/Inflater.cs:565-571
+        s = self._L.szl_inflater_set_dictionary(self._h, a[index:].ctypes.data if count else None, count)
         if s < 0:
             _raise(s, "SetDictionary")
 

@@ -52,6 +52,8 @@ def lib():
     L.szo_deflate_oneshot.argtypes = [vp, sz, i32, i32, i32, i32, vp, sz, vp]
     L.szo_inflate_oneshot.restype = i64
     L.szo_inflate_oneshot.argtypes = [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]
+    L.szo_inflate_probe.restype = i64
+    L.szo_inflate_probe.argtypes = [vp, sz, i32, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     for name, res, args in [
         ("szo_deflater_new", vp, [i32, i32]), ("szo_deflater_free", None, [vp]), ("szo_deflater_reset", None, [vp]),
         ("szo_deflater_set_level", i32, [vp, i32]), ("szo_deflater_set_strategy", None, [vp, i32]),
@@ -261,6 +263,16 @@ def inflate(data, nowrap=True, max_out=None):
     cons = ctypes.c_size_t(0)
     n = lib().szo_inflate_oneshot(a.ctypes.data, a.size, 1 if nowrap else 0, out.ctypes.data, cap, ctypes.byref(cons))
     return n, out[:max(n, 0)].tobytes(), cons.value
+
+
+def inflate_probe(data, nowrap=True, max_out=1 << 20):
+    """(status_or_len, delivered_bytes, consumed): one byte per Inflate() call, so `delivered_bytes` is the longest prefix a
+    caller of the reference can have received before the exception that ends a corrupt stream."""
+    a = _buf(data)
+    out = np.empty(max_out, dtype=np.uint8)
+    cons, prod = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    n = lib().szo_inflate_probe(a.ctypes.data, a.size, 1 if nowrap else 0, out.ctypes.data, max_out, ctypes.byref(cons), ctypes.byref(prod))
+    return n, out[:prod.value].tobytes(), cons.value
 
 
 class Model:

@@ -230,3 +230,45 @@ def test_block_table_token_multiple_edges():
             first, cnt, last = M.block_table(tok, finish=not flush)
             got = [b["ntokens"] for b in nblk_first_seg][:len(cnt)]
             assert got == list(cnt), (cut, flush, got, list(cnt))
+
+
+# ---- corrupted / hand-assembled streams (tests/corrupt_streams.py): the oracle side of the device differential tests
+def test_crafted_streams_on_the_oracle():
+    import zlib
+    import corrupt_streams as CS
+    want = {"illegal_len_286": -3, "illegal_len_287": -3, "illegal_dist_30": -4, "illegal_dist_31": -4, "block_type_3": -6,
+            "stored_bad_nlen": -7, "stored_truncated": -102, "dyn_incomplete_unassigned_pattern": -8,
+            "dyn_oversubscribed_litlen": -13, "dyn_oversubscribed_dist": -13, "dyn_oversubscribed_meta": -13,
+            "dyn_no_eob_code": -9, "dyn_too_many_litlen": -9, "dyn_too_many_dist": -9, "dyn_repeat_first": -9, "dyn_repeat_overrun": -9}
+    for name, s in CS.crafted():
+        n, delivered, cons = O.inflate_probe(s)
+        n1, out1, cons1 = O.inflate(s, max_out=1 << 20)
+        assert (n >= 0) == (n1 >= 0) and (n < 0 or (delivered == out1 and cons == cons1)), name
+        if name in want:
+            assert n == want[name], (name, n)
+        else:
+            assert n >= 0, (name, n)
+        if name.startswith("dist_before_start"):
+            assert delivered.count(0) > 0   # zeros of the fresh window (CS/OutputWindow.cs:22)
+        try:    # wherever zlib accepts the stream, the bytes agree (zlib rejects distances before the start and incomplete sets)
+            zo = zlib.decompressobj(-15)
+            z = zo.decompress(s)
+            if zo.eof:
+                assert n >= 0 and z == delivered, name
+        except zlib.error:
+            pass
+
+
+def test_mutated_streams_do_not_break_the_oracle():
+    import corrupt_streams as CS
+    rng = np.random.default_rng(7)
+    valid = [("dickens", O.deflate(C.generate("dickens", 11, 0, 6000), 6)), ("logs9", O.deflate(C.generate("logs", 13, 0, 12000), 9)),
+             ("stored", O.deflate(C.random_bytes(5000, seed=5), 6))]
+    for name, s in CS.mutations(valid, rng, n_flip=40, n_trunc=10):
+        n, delivered, cons = O.inflate_probe(s, max_out=1 << 18)
+        n1, out1, _ = O.inflate(s, max_out=1 << 18)
+        assert (n >= 0) == (n1 >= 0), name
+        if n >= 0:
+            assert delivered == out1, name
+        else:
+            assert out1 == b"" and (n == n1 or {n, n1} <= {-100, -102, -103}), (name, n, n1)
