@@ -90,11 +90,23 @@ def main():
     out_len = int(streams[0].out_len)
     ratio = out_len / n
     # correctness of what was timed: CRC of the input from the device vs zlib, and the stream inflates back (rank 0, cheap)
+    parity = {"checked_bytes": 0, "how": []}
     if rank == 0:
+        import hashlib
         import zlib
         comp = d_out[:out_len].cpu().numpy().tobytes()
         assert zlib.crc32(host.tobytes()) == streams[0].crc32, "device CRC-32 mismatch"
         assert zlib.decompress(comp, -15) == host.tobytes(), "device output does not inflate to the input"
+        # bit-exactness of the very stream that was timed: sha256 of the oracle's output for this workload, frozen in
+        # tests/golden/headline_golden.json (tests/golden/make_headline.py; tests/test_gpu_headline.py also runs the oracle itself)
+        gpath = os.path.join(ROOT, "tests", "golden", "headline_golden.json")
+        if args.mib == 1024 and args.level == 6 and os.path.exists(gpath):
+            g = json.load(open(gpath))["cases"]["cfg2_enwik_1g_l6"]
+            assert out_len == g["out_len"] and hashlib.sha256(comp).hexdigest() == g["out_sha256"], \
+                "the timed stream's device output differs from the oracle's (golden sha256)"
+            assert int(streams[0].crc32) == g["crc32"]
+            parity["checked_bytes"] += n
+            parity["how"].append("timed 1 GiB stream: sha256 == oracle golden")
 
     if rank == 0:
         value = world * n * args.steps / elapsed / 2 ** 20
@@ -105,7 +117,10 @@ def main():
         alg_bytes = n * (1.0 + ratio)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
-        tpath = next((t for t in (os.path.join(ROOT, "profiles", "r01", f) for f in ("g_traffic_pmc.json", "f_traffic_pmc.json", "e_traffic_pmc.json", "d_traffic_pmc.json", "b_traffic_pmc.json"))
+        # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 --pmc passes of this
+        # same command (tools/gpu_traffic.sh -> profiles/rNN/*traffic_pmc.json); `traffic_source` says which file
+        tpath = next((t for t in ([os.path.join(ROOT, "profiles", "r02", f) for f in ("traffic_pmc.json",)] +
+                                  [os.path.join(ROOT, "profiles", "r01", f) for f in ("g_traffic_pmc.json",)])
                       if os.path.exists(t)), "")
         if args.mib == 1024 and args.level == 6 and tpath:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units) of this same command, per launch of k_match;
@@ -125,6 +140,7 @@ def main():
                        "level": args.level, "shard_mib": args.mib, "parallelism": "stream-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                         "traffic_source": (os.path.relpath(tpath, ROOT) + " (rocprofv3 PMC pass of this command; not measured in this run)") if traffic else None,
                          "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg_bytes)},
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         }
@@ -134,9 +150,42 @@ def main():
             t1 = time.perf_counter()
             ref = O.deflate(host[:sample], args.level)
             dt = time.perf_counter() - t1
+            cpu_model = ""
+            try:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                pass
             line["cpu_baseline"] = {"value": round(sample / dt / 2 ** 20, 2), "unit": "MiB/s", "cores": 1, "kind": "port",
+                                    "cpu": cpu_model, "host_cores": os.cpu_count(),
                                     "sample": "first %d MiB of the same shard through oracle/ (C restatement of the managed Deflater, "
                                               "single thread like the reference); %d bytes out" % (sample >> 20, len(ref))}
+            # the same prefix as its own stream on the device: byte-for-byte against what the oracle just produced
+            pstreams, _, pout_total = Engine.layout([sample])
+            p_out = torch.empty(pout_total + 64, dtype=torch.uint8, device=dev)
+            eng.deflate_device(d_in.data_ptr(), p_out.data_ptr(), pstreams, level=args.level, flags=flags, hip_stream=hip_stream)
+            got = p_out[:int(pstreams[0].out_len)].cpu().numpy().tobytes()
+            assert got == ref, "device output of the cpu_baseline sample differs from the oracle's"
+            parity["checked_bytes"] += sample
+            parity["how"].append("first %d MiB as its own stream: bytes == oracle run in this process" % (sample >> 20))
+            # all host cores: one independent oracle Deflater per core on disjoint 16 MiB slices (what a host-side
+            # "shard = stream" run over the same corpus could reach; the reference itself is single-threaded per Deflater)
+            import threading
+            ncore = min(os.cpu_count() or 1, max(1, n // (16 << 20)))
+            outs = [0] * ncore
+
+            def work(i):
+                outs[i] = len(O.deflate(host[i * (16 << 20):(i + 1) * (16 << 20)], args.level))
+            th = [threading.Thread(target=work, args=(i,)) for i in range(ncore)]
+            t2 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt2 = time.perf_counter() - t2
+            line["cpu_baseline_all_cores"] = {"value": round(ncore * 16 / dt2, 1), "unit": "MiB/s", "cores": ncore, "kind": "port",
+                                              "sample": "%d independent 16 MiB slices, one oracle Deflater per thread" % ncore}
+        line["parity_checked_bytes"] = parity["checked_bytes"]
+        line["parity"] = parity["how"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -155,6 +155,10 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
  * on-demand form.  Results are identical either way (C/DeflaterEngine.cs:474-612 is restated by both). */
 int szl_engine_debug_match_mode(szl_engine *e, int mode);
 
+/* Experiment / parity knob: sets a named tuning value for this process (the same names are read from the environment as a
+ * fallback): SZL_MATCH_KERNEL, SZL_NCTX, SZL_FTH2, SZL_VTH2, SZL_QKEEP, SZL_VKEEP, SZL_DEBUG, ...  Results never depend on them. */
+int szl_debug_set(const char *name, int value);
+
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);
 

@@ -306,6 +306,9 @@ int szl_engine_debug_match_mode(szl_engine *e, int mode) {
     return e->e.last_lazy ? 1 : 0;
 }
 
+// Experiment / parity knob (see knob() in szl_engine.hip): overrides the environment variable of the same name for this process.
+int szl_debug_set(const char *name, int value) { return name ? szl::knob_set(name, value) : SZL_E_ARG; }
+
 // Parity tap: block table of the last call. rows of 8 x uint64: type,last,ntok,bit_start,opt_len,static_len,in_len,hdr_bits
 int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows) {
     if (!e) return SZL_E_ARG;

@@ -12,6 +12,8 @@ namespace szl {
 void set_error(const char *fmt, ...);
 const char *last_error();
 int level_params(int level, int strategy, LevelParams *P);
+int knob(const char *name, int dflt);   // szl_debug_set() value, else environment variable, else dflt
+int knob_set(const char *name, int value);
 
 struct DevBuf {
     void *p = nullptr;

@@ -54,6 +54,23 @@ void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint3
 void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st);
 int zero_piece_bytes();
 
+// Tuning knobs for experiments and parity taps: a value set through szl_debug_set() wins, else the environment variable of
+// the same name, else the default.  Read at every launch (a handful of string compares).
+struct Knob { char name[32]; int value; };
+static Knob g_knobs[32];
+static int g_nknobs = 0;
+int knob_set(const char *name, int value) {
+    for (int i = 0; i < g_nknobs; i++) if (!strcmp(g_knobs[i].name, name)) { g_knobs[i].value = value; return 0; }
+    if (g_nknobs >= 32 || strlen(name) >= sizeof g_knobs[0].name) return SZL_E_ARG;
+    strcpy(g_knobs[g_nknobs].name, name); g_knobs[g_nknobs].value = value; g_nknobs++;
+    return 0;
+}
+int knob(const char *name, int dflt) {
+    for (int i = 0; i < g_nknobs; i++) if (!strcmp(g_knobs[i].name, name)) return g_knobs[i].value;
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
@@ -191,7 +208,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if ((rc = blk_off.ensure((nseg + 2) * 8))) return rc;
     if ((rc = bsp.ensure((blk_slots + 1) * 8))) return rc;
     if ((rc = blp.ensure((blk_slots + 1) * 8))) return rc;
-    if ((rc = counters.ensure(64))) return rc;
+    if ((rc = counters.ensure(256))) return rc;
     if (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) return rc;
     if ((rc = upload(d_segs, segs, st))) return rc;
     if ((rc = upload(d_bnds, bnds, st))) return rc;
@@ -211,7 +228,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipEventRecord(ev[0], st));
     launch_zero_regions(dsegs, nseg, (const uint64_t *)d_zoff.p, nzero, d_out, st); // only the streams' own regions (szl.h)
     HIPCHK(hipMemsetAsync(visited.p, 0, (vis_words + 4) * 4, st));
-    HIPCHK(hipMemsetAsync(counters.p, 0, 64, st));
+    HIPCHK(hipMemsetAsync(counters.p, 0, 256, st));
     HIPCHK(hipMemsetAsync(d_so.p, 0, nseg * sizeof(SegOut), st));
     HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
     HIPCHK(hipMemsetAsync(blk_counts.p, 0, (nseg + 2) * 4, st));
@@ -333,7 +350,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results.data(), d_so.p, nseg * sizeof(SegOut), hipMemcpyDeviceToHost, st));
-    unsigned long long hc[8] = {0};
+    unsigned long long hc[32] = {0};
     HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
 
@@ -353,8 +370,12 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     timing.ranges_unmerged = hc[0];
     timing.fallback_walks = hc[1];
     last_evaluated = hc[6]; last_eval_fallbacks = hc[7]; last_lazy = lazy;
-    if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
-    if (getenv("SZL_DEBUG")) fprintf(stderr, "[szl] stage B %s (pilot fraction %.3f): %llu of %llu positions evaluated by walkers, %llu by the parse (eval_global), slow walks %llu, unmerged %llu\n", lazy ? "on demand" : "full", last_pilot_frac, hc[6], (unsigned long long)seg_bytes, hc[7], hc[1], hc[0]);
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
+    if (knob("SZL_DEBUG", 0) && hc[9]) // k_match2: per-phase visits, wave-steps and the lanes that took part (64 = full)
+        fprintf(stderr, "[szl] match2: quick visits %llu steps %llu lanes/step %.1f | verify visits %llu steps %llu lanes/step %.1f | fetch visits %llu lanes/visit %.1f | swaps %llu lanes/swap %.1f | per position: quick wave-steps %.3f verify %.3f fetch %.3f swaps %.3f\n",
+                hc[8], hc[9], (double)hc[10] / hc[9], hc[11], hc[12], hc[12] ? (double)hc[13] / hc[12] : 0.0, hc[14], hc[14] ? (double)hc[15] / hc[14] : 0.0, hc[16],
+                hc[16] ? (double)hc[17] / hc[16] : 0.0, (double)hc[9] / seg_bytes, (double)hc[12] / seg_bytes, (double)hc[14] / seg_bytes, (double)hc[16] / seg_bytes);
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] stage B %s (pilot fraction %.3f): %llu of %llu positions evaluated by walkers, %llu by the parse (eval_global), slow walks %llu, unmerged %llu\n", lazy ? "on demand" : "full", last_pilot_frac, hc[6], (unsigned long long)seg_bytes, hc[7], hc[1], hc[0]);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
     return 0;

@@ -12,6 +12,7 @@
 #include "szl_internal.h"
 
 namespace szl {
+int knob(const char *name, int dflt);
 
 // hipFuncSetAttribute is per device: remember which devices have the large-LDS attribute for a kernel group
 static bool lds_attr_needed(std::atomic<uint64_t> &mask, uint64_t &bit) {
@@ -801,12 +802,18 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
 
 int match_lds_bytes() { return B_LDS_BYTES; }
 
+hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
+                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st);
+
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
+    // SZL_MATCH_KERNEL: 2 = two positions in flight per lane (szl_kernels_match2.hip, default), 1 = k_match below
+    const int which = knob("SZL_MATCH_KERNEL", 2);
+    if (which == 2) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
-    static const bool want_dbg = getenv("SZL_DEBUG") != nullptr;
-    static const int fth = getenv("SZL_FTH") ? atoi(getenv("SZL_FTH")) : 16, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
+    const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
+    const int fth = knob("SZL_FTH", 16), vth = knob("SZL_VTH", 20);
     if (lds_attr_needed(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
