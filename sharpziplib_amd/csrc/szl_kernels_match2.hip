@@ -1,17 +1,26 @@
-// szl_kernels_match2.hip — stage B (FindLongestMatch for every position), second form of the full search.
+// szl_kernels_match2.hip — stage B (FindLongestMatch for every position), the form of the full search used by default.
 //
 // Reference being restated: FindLongestMatch, C/DeflaterEngine.cs:474-612 (same results as k_match in
 // szl_kernels_match.hip: M2 = walk entered with matchLen 2 and the full max_chain budget, Mq = that walk's state after
 // max_chain>>2 candidates).
 //
-// Why a second form.  k_match is bound by VALU issue at ≈46 wave-instructions per position, of which the chain steps and
-// compares themselves need ≈12: the rest is lane under-use.  A wavefront runs three kinds of work — FETCH (start a position),
-// QUICK (one chain step), VERIFY (4-byte compare step) — and a lane can only take part in the kind its one position is in,
-// so each kind runs with about half of the lanes (measured: profiles/r02).  Here every lane holds TWO positions in flight
-// (contexts A and B, all in registers: LDS is full with the window).  Before a phase runs, lanes whose A context is not in
-// that phase's state but whose B context is exchange the two (one v_swap per field under the lanes' exec mask), so the phase
-// sees a lane as busy if EITHER of its positions can use it.  The phases themselves are loops that keep going while enough
-// lanes remain in them, instead of a fixed number of predicated steps per scheduler visit.
+// Why a second form (measurements: profiles/r02/pmc_stage_b.json, lab_*.log).  k_match is bound by VALU issue: 43.8 VALU +
+// 25.7 SALU wave-instructions per position with the SIMDs' VALU slots ~100 % busy — and only 42 % of the lanes take part in
+// an average chain step, because a lane can only work on the phase its one position is in.  Two things do NOT fix that
+// (both built and measured this round): exchanging a lane's two positions so that either can serve the running phase
+// (the selects of the exchange cost more than the lanes gained), and cheaper steps alone (with 4 waves per SIMD — all the
+// 147 KiB window leaves room for — a wave that needs one LDS round trip per step stalls instead).  What does:
+//   * the chain walk (QUICK) and the byte compare (VERIFY) are hand-written loops in which a lane that leaves the phase is
+//     cleared from the exec mask by v_cmpx, so the surviving lanes update their state in place: 7 VALU per chain step
+//     instead of 13 (no per-step select of every state variable, no mode bookkeeping; the states are SGPR lane masks);
+//   * every lane holds TWO walks whose LDS reads are in flight together, software-pipelined across steps, so a wave waits
+//     for one LDS round trip per two steps;
+//   * VERIFY compares 8 bytes per step from ALIGNED dwords + v_alignbyte (32-bit LDS reads at byte addresses are replayed:
+//     SQ_LDS_UNALIGNED_STALL made the LDS pipe the bottleneck in the first version);
+//   * a freshly fetched position goes straight to VERIFY with its first candidate (same 3-byte hash: the scan_end test at
+//     offset 2 all but always passes), saving one chain step per position.
+// Result: 24.6 VALU + 21.5 SALU per position, 89.9 -> 64 ms per GiB of text at level 6, 475 -> 306 ms per GiB of logs at
+// level 9 (full search), bit-identical tables.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdlib>
@@ -32,28 +41,126 @@ enum : int { B2_THREADS = 1024 };
 enum : int { B2_DATA_BYTES = B_HIST + B_TILE + B_TAIL + 8, B2_LINKS = B_HIST + B_TILE };
 enum : int { B2_LDS_BYTES = B2_DATA_BYTES + B2_LINKS * 2 + 16 };
 
-// One FindLongestMatch walk in flight (a lane holds NCTX of them).  Kept small: every field is one v_swap_b32 per exchange.
-struct WalkCtx {
-    int p;          // tile position being searched
-    int cl;         // LDS data index of the current candidate (curMatch)
-    int best;       // best_len (:483)
-    int left;       // chainLength still available (:477)
-    int off;        // VERIFY: bytes of the candidate already known to match
-    int mincl;      // candidates below this LDS index end the walk (limit / window index 0, :609)
-    int mode;
-    uint32_t pb;    // byte of the position at offset best (scan_end, :505)
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+// ---- the hand-written engine ---------------------------------------------------------------------------------------------
+// Every lane holds TWO walks (contexts A and B); a context is in one of four states kept as wave-level lane masks in SGPRs:
+// q (QUICK: walking its chain), v (VERIFY: comparing a candidate), d (DONE: results wait to be stored), none (NEED: free).
+// The engine runs QUICK and VERIFY phases until enough contexts are free for a FETCH (done in C++), with both contexts'
+// LDS reads of a step in flight together: per step-pair one LDS round trip instead of two (the kernel is otherwise bound by
+// that latency: 16 waves per CU is all the 147 KiB window leaves room for).
+//   QUICK step of a context (C/DeflaterEngine.cs:502-507,:609): read the candidate's scan_end byte and its prev[] hop; v_cmpx
+//   clears from exec the lanes whose byte matches (-> VERIFY), whose next candidate is out of the window and whose chain budget
+//   is spent (-> DONE); the lanes left move to the next candidate in place.
+//   VERIFY step (:515-591): 8 bytes of candidate and position per step from the byte address; exec keeps the lanes that matched
+//   all 8 and are below `cap`.  Completed lanes run :593-609.
+#define SZL_Q_ISSUE(X) \
+    "v_lshl_add_u32 %[t0" #X "], %[cl" #X "], 1, %[lbase]\n\t" \
+    "v_add3_u32 %[t1" #X "], %[cl" #X "], %[best" #X "], %[dbase]\n\t" \
+    "ds_read_u16 %[t0" #X "], %[t0" #X "]\n\t" \
+    "ds_read_u8 %[t1" #X "], %[t1" #X "]\n\t"
+// t0 = prev[] hop, t1 = scan_end byte of the candidate
+#define SZL_Q_FINISH(X) \
+    "v_sub_u32 %[t0" #X "], %[cl" #X "], %[t0" #X "]\n\t" \
+    "v_cmpx_ne_u32 vcc, %[pb" #X "], %[t1" #X "]\n\t" \
+    "v_cmpx_ge_i32 vcc, %[t0" #X "], %[mincl" #X "]\n\t" \
+    "v_subrev_co_u32 %[left" #X "], vcc, 1, %[left" #X "]\n\t" \
+    "s_andn2_b64 exec, exec, vcc\n\t" \
+    "v_mov_b32 %[cl" #X "], %[t0" #X "]\n\t" \
+    "s_mov_b64 %[m" #X "], exec\n\t"
+// leavers of context X: lanes of q that are no longer in m; the byte read last says which way (a match wins over the chain end)
+#define SZL_Q_CLASSIFY(X) \
+    "s_andn2_b64 exec, %[q" #X "], %[m" #X "]\n\t" \
+    "v_cmp_eq_u32 vcc, %[pb" #X "], %[t1" #X "]\n\t" \
+    "v_mov_b32 %[off" #X "], 0\n\t" \
+    "s_or_b64 %[v" #X "], %[v" #X "], vcc\n\t" \
+    "s_andn2_b64 %[sc], exec, vcc\n\t" \
+    "s_or_b64 %[d" #X "], %[d" #X "], %[sc]\n\t" \
+    "s_mov_b64 %[q" #X "], %[m" #X "]\n\t"
+// 8 bytes of each side from three ALIGNED dwords + v_alignbyte (a 32-bit LDS read at a byte address that is not a multiple of
+// 4 is replayed: SQ_LDS_UNALIGNED_STALL made the LDS pipe the bottleneck when this loop read at the byte address directly)
+#define SZL_V_ISSUE(X) \
+    "v_add3_u32 %[t0" #X "], %[cl" #X "], %[off" #X "], %[dbase]\n\t" \
+    "v_add3_u32 %[t1" #X "], %[p" #X "], %[off" #X "], %[pbase]\n\t" \
+    "v_and_b32 %[t4" #X "], -4, %[t0" #X "]\n\t" \
+    "v_and_b32 %[t5" #X "], -4, %[t1" #X "]\n\t" \
+    "ds_read_b32 %[t2" #X "], %[t4" #X "]\n\t" \
+    "ds_read_b32 %[t3" #X "], %[t4" #X "] offset:4\n\t" \
+    "ds_read_b32 %[t4" #X "], %[t4" #X "] offset:8\n\t" \
+    "ds_read_b32 %[t6" #X "], %[t5" #X "]\n\t" \
+    "ds_read_b32 %[t7" #X "], %[t5" #X "] offset:4\n\t" \
+    "ds_read_b32 %[t5" #X "], %[t5" #X "] offset:8\n\t"
+// candidate: dwords t2,t3,t4 shifted by t0[1:0] bytes; position: t6,t7,t5 shifted by t1[1:0]
+#define SZL_V_FINISH(X) \
+    "v_alignbyte_b32 %[t2" #X "], %[t3" #X "], %[t2" #X "], %[t0" #X "]\n\t" \
+    "v_alignbyte_b32 %[t3" #X "], %[t4" #X "], %[t3" #X "], %[t0" #X "]\n\t" \
+    "v_alignbyte_b32 %[t6" #X "], %[t7" #X "], %[t6" #X "], %[t1" #X "]\n\t" \
+    "v_alignbyte_b32 %[t7" #X "], %[t5" #X "], %[t7" #X "], %[t1" #X "]\n\t" \
+    "v_xor_b32 %[t2" #X "], %[t2" #X "], %[t6" #X "]\n\t" \
+    "v_xor_b32 %[t0" #X "], %[t3" #X "], %[t7" #X "]\n\t" \
+    "v_ffbl_b32 %[t2" #X "], %[t2" #X "]\n\t" \
+    "v_ffbl_b32 %[t0" #X "], %[t0" #X "]\n\t" \
+    "v_or_b32 %[t0" #X "], 32, %[t0" #X "]\n\t" \
+    "v_min_u32 %[t2" #X "], %[t2" #X "], %[t0" #X "]\n\t" \
+    "v_lshrrev_b32 %[t2" #X "], 3, %[t2" #X "]\n\t" \
+    "v_min_u32 %[t2" #X "], 8, %[t2" #X "]\n\t" \
+    "v_add_u32 %[off" #X "], %[off" #X "], %[t2" #X "]\n\t" \
+    "v_cmpx_eq_u32 vcc, 8, %[t2" #X "]\n\t" \
+    "v_cmpx_lt_i32 vcc, %[off" #X "], %[cap" #X "]\n\t" \
+    "s_mov_b64 %[m" #X "], exec\n\t"
+// :593-609 for the lanes of v that are no longer in m (comparison complete)
+#define SZL_V_COMPLETE(X) \
+    "s_andn2_b64 %[cm], %[v" #X "], %[m" #X "]\n\t" \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "v_lshl_add_u32 %[t0" #X "], %[cl" #X "], 1, %[lbase]\n\t" \
+    "ds_read_u16 %[t0" #X "], %[t0" #X "]\n\t"                              /* prev[] hop of this candidate */ \
+    "v_min_i32 %[t2" #X "], %[off" #X "], %[cap" #X "]\n\t"                /* L */ \
+    "v_cmp_gt_i32 %[sc], %[t2" #X "], %[best" #X "]\n\t"                   /* strictly longer: the new best */ \
+    "s_mov_b64 exec, %[sc]\n\t" \
+    "v_mov_b32 %[best" #X "], %[t2" #X "]\n\t" \
+    "v_sub_u32 %[t1" #X "], %[p" #X "], %[cl" #X "]\n\t" \
+    "v_add_u32 %[t1" #X "], %[bhist], %[t1" #X "]\n\t"                       /* distance = (p + B_HIST) - cl */ \
+    "v_lshl_or_b32 %[res2" #X "], %[t1" #X "], 16, %[t2" #X "]\n\t" \
+    "v_cmp_ge_i32 vcc, %[left" #X "], %[snap]\n\t"                           /* seen by the quarter-budget walk too (:495) */ \
+    "v_cndmask_b32 %[resq" #X "], %[resq" #X "], %[res2" #X "], vcc\n\t" \
+    "v_add3_u32 %[t1" #X "], %[p" #X "], %[t2" #X "], %[pbase]\n\t" \
+    "ds_read_u8 %[t1" #X "], %[t1" #X "]\n\t"                               /* scan_end byte for the new best_len */ \
+    "v_cmp_ge_i32 %[sc], %[t2" #X "], %[nice" #X "]\n\t"                   /* >= niceLength: stop (:603) */ \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_mov_b32 %[pb" #X "], %[t1" #X "]\n\t" \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "v_sub_u32 %[t0" #X "], %[cl" #X "], %[t0" #X "]\n\t"                  /* next candidate */ \
+    "v_cmp_lt_i32 vcc, %[t0" #X "], %[mincl" #X "]\n\t" \
+    "s_or_b64 %[sc], %[sc], vcc\n\t" \
+    "v_cmp_eq_u32 vcc, 0, %[left" #X "]\n\t" \
+    "s_or_b64 %[sc], %[sc], vcc\n\t"                                         /* sc = lanes whose walk ends here */ \
+    "v_mov_b32 %[off" #X "], 0\n\t" \
+    "s_or_b64 %[d" #X "], %[d" #X "], %[sc]\n\t" \
+    "s_andn2_b64 exec, %[cm], %[sc]\n\t" \
+    "v_mov_b32 %[cl" #X "], %[t0" #X "]\n\t" \
+    "v_add_u32 %[left" #X "], -1, %[left" #X "]\n\t" \
+    "s_or_b64 %[q" #X "], %[q" #X "], exec\n\t" \
+    "s_mov_b64 %[v" #X "], %[m" #X "]\n\t"
+
+struct WalkCtx {      // one FindLongestMatch walk in flight (all of it in registers)
+    int p;            // tile position being searched
+    int cl;           // LDS data index of the current candidate (curMatch)
+    int best;         // best_len (:483)
+    int left;         // candidates that may still FOLLOW the current one (= the reference's chainLength - 1)
+    int off;          // VERIFY: bytes of the candidate already known to match
+    int mincl;        // candidates below this LDS index end the walk (limit / window index 0, :609)
+    int cap, nice;    // min(258, lookahead), min(niceLength, lookahead) (:479,:485)
+    uint32_t pb;      // byte of the position at offset best_len (scan_end, :505)
     uint32_t res2, resq;
 };
 
-__device__ __forceinline__ void vswap(int &a, int &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void vswap(uint32_t &a, uint32_t &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-
-// EDGE: the tile reaches within 258 bytes of the end of its segment, so min(258, lookahead) / min(niceLength, lookahead)
-// (:479,:485) depend on the position; everywhere else they are the constants 258 and niceLength.
-template <int NCTX, bool EDGE, bool DBG>
-__device__ __forceinline__ void match2_body(uint8_t *smem, const TileDev &tile, const SegDev &seg, const uint8_t *__restrict__ in,
-                                            const uint16_t *__restrict__ link, MTab mtab, LevelParams P, unsigned long long *dbg,
-                                            int fth, int vth, int qkeep, int vkeep) {
+template <bool DBG>
+__global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
+                                                       const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
+                                                       MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth, int qkeep, int vkeep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const TileDev tile = tiles[blockIdx.x];
+    const SegDev seg = segs[tile.seg];
     uint32_t *sdata32 = (uint32_t *)smem;                          // B2_DATA_BYTES
     uint16_t *slink = (uint16_t *)(smem + B2_DATA_BYTES);          // B2_LINKS entries
     int *s_counter = (int *)(smem + B2_DATA_BYTES + B2_LINKS * 2);
@@ -96,12 +203,16 @@ __device__ __forceinline__ void match2_body(uint8_t *smem, const TileDev &tile, 
     }
     if (threadIdx.x == 0) *s_counter = 0;
     __syncthreads();
+    if (DBG && fth < 0) { // timing experiment (lab only): staging + one coalesced pass of result stores, no search
+        for (int i = threadIdx.x; i < tlen; i += B2_THREADS) { mt2[t0 + i] = sdata32[i & 1023] == 0xDEADBEEFu && slink[i] == 0x1234 ? 3u : 0u; mtq[t0 + i] = 0; }
+        return;
+    }
 
-    auto ldsdw = [&](int i) -> uint32_t { // unaligned 32-bit read of LDS data byte i from two aligned dwords
-        uint32_t w0 = sdata32[i >> 2], w1 = sdata32[(i >> 2) + 1];
-        return __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(i & 3));
-    };
     const uint8_t *sdata8 = smem;
+    // LDS byte offsets of the two arrays for the hand-written loops
+    const uint32_t dbase = (uint32_t)(uintptr_t)(lds_u8 *)smem;
+    const uint32_t lbase = dbase + (uint32_t)B2_DATA_BYTES;
+    const uint32_t pbase = dbase + (uint32_t)B_HIST;
 
     const int64_t base_lo = base_of2((int64_t)seg.abs0 + t0), base_hi = base_of2((int64_t)seg.abs0 + t0 + tlen - 1);
     const int64_t sw64 = base_lo == base_hi ? (int64_t)1 << 30 : (base_lo + 65273) - (int64_t)seg.abs0 - t0; // first tile position on base_hi
@@ -112,185 +223,168 @@ __device__ __forceinline__ void match2_body(uint8_t *smem, const TileDev &tile, 
     const int rem0 = rem0_64 > (int64_t)(1 << 24) ? (1 << 24) : (int)rem0_64;
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2); // `left` value at which the quarter-budget walk would stop
-    enum { NEED = 0, DONE = 1, QUICK = 2, VERIFY = 3 };       // idle contexts are those with mode < QUICK
+    // The quarter-budget walk (:495) has seen a candidate iff the reference's chainLength was > max_chain - (max_chain >> 2)
+    // when it was examined, i.e. left >= that value (left = chainLength - 1).
+    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);
+    const int bhist = B_HIST;
     int wnext = 0, wend = 0;       // wave-uniform slice of tile positions being handed out
     bool exhausted = false;
 
     WalkCtx A, B;
-    A.p = 0; A.cl = B_HIST; A.best = 2; A.left = 1; A.off = 0; A.mincl = 0; A.mode = NEED;
-    A.pb = 0; A.res2 = 0; A.resq = 0;
+    A.p = 0; A.cl = B_HIST; A.best = 2; A.left = 0; A.off = 0; A.mincl = 0; A.cap = MAX_MATCH; A.nice = P.nice; A.pb = 0; A.res2 = 0; A.resq = 0;
     B = A;
-    auto cap_of = [&](int p) -> int { if (!EDGE) return MAX_MATCH; const int rem = rem0 - p; return rem < MAX_MATCH ? rem : MAX_MATCH; };   // scanMax :479
-    auto nice_of = [&](int p) -> int { if (!EDGE) return P.nice; const int rem = rem0 - p; return rem < P.nice ? rem : P.nice; };          // :485
-    unsigned long long c_qvis = 0, c_qsteps = 0, c_qlanes = 0, c_vvis = 0, c_vsteps = 0, c_vlanes = 0, c_fvis = 0, c_flanes = 0,
-                       c_swaps = 0, c_swaplanes = 0;
+    uint64_t qA = 0, vA = 0, dA = 0, qB = 0, vB = 0, dB = 0;   // state masks (wave-uniform)
+    unsigned long long c_fvis = 0, c_flanes = 0, c_eng = 0;
 
-    auto swap_ab = [&](bool need) { // branch-free exchange (two selects per field)
-        if (NCTX == 2) {
-#define SZL_SW(f) { const auto ta = A.f, tb = B.f; A.f = need ? tb : ta; B.f = need ? ta : tb; }
-            SZL_SW(p) SZL_SW(cl) SZL_SW(best) SZL_SW(left) SZL_SW(off) SZL_SW(mincl) SZL_SW(mode) SZL_SW(pb) SZL_SW(res2) SZL_SW(resq)
-#undef SZL_SW
+    // FETCH for one context: retire its finished walks, start new ones on its free lanes
+    auto fetch = [&](WalkCtx &C, uint64_t &q, uint64_t &v, uint64_t &dm) {
+        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; }
+        dm = 0;
+        if (exhausted) return;
+        const uint64_t idle = ~(q | v);
+        const int ni = __builtin_popcountll(idle);
+        if (ni == 0) return;
+        if (wnext >= wend) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(s_counter, 512);
+            base = __builtin_amdgcn_readfirstlane(base);
+            wnext = base < tlen ? base : tlen;
+            wend = base + 512 < tlen ? base + 512 : tlen;
+            if (wnext >= wend) { exhausted = true; return; }
         }
-    };
-    auto retire = [&](WalkCtx &C) { // results of a finished walk
-        if (C.mode == DONE) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; C.mode = NEED; }
+        const int rank = __builtin_popcountll(idle & lanemask_lt);
+        if (DBG) { c_fvis++; c_flanes += (wend - wnext) < ni ? (wend - wnext) : ni; }
+        bool toverify = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(idle) && wnext + rank < wend) {
+            const int p = wnext + rank;
+            C.p = p;
+            const int rem = rem0 - p;                                   // lookahead (clamped high)
+            C.res2 = 0; C.resq = 0;
+            bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
+            if (ok) {
+                const int pl = p + B_HIST;
+                const int l0 = (int)slink[pl];                           // hashHead (:782)
+                const int basem = p >= sw ? basem_hi : basem_lo;        // LDS index of window index 1 (entries below were clamped by a slide, :450-461)
+                const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem; // first candidate: strstart - hashHead <= MAX_DIST (:788)
+                const int c = pl - l0;
+                ok = c >= firstmin;                                      // l0 == 0xFFFF (none) fails this too
+                if (ok) {
+                    C.cl = c;
+                    C.mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem; // chain: curMatch > limit (:609)
+                    C.cap = rem < MAX_MATCH ? rem : MAX_MATCH;            // scanMax :479
+                    C.nice = rem < P.nice ? rem : P.nice;                 // :485
+                    C.best = 2; C.left = P.max_chain - 1;
+                    C.pb = sdata8[pl + 2];
+                    // the first candidate shares the position's 3-byte hash, so the scan_end test at offset 2 (:505) all but
+                    // always passes: compare it right away instead of spending a chain step on that test
+                    C.off = 0;
+                    toverify = true;
+                }
+            }
+            if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
+        }
+        v |= __ballot(toverify);
+        wnext = wnext + ni < wend ? wnext + ni : wend;
     };
 
     for (;;) {
-        uint64_t ia = __ballot(A.mode < QUICK), va = __ballot(A.mode == VERIFY);
-        uint64_t ib = 0, vb = 0;
-        if (NCTX == 2) { ib = __ballot(B.mode < QUICK); vb = __ballot(B.mode == VERIFY); }
-        const uint64_t qa = ~(ia | va), qb = NCTX == 2 ? ~(ib | vb) : 0ull;
-        const int ni = __builtin_popcountll(ia | ib), nv = __builtin_popcountll(va | vb), nq = __builtin_popcountll(qa | qb);
-        if ((ni >= fth && !exhausted) || (nq == 0 && nv == 0)) {
-            // ---------------- FETCH: retire finished walks, hand out new positions (lanes whose A is busy but B is idle bring B forward)
-            retire(A);
-            if (NCTX == 2) retire(B);
-            if (!exhausted) {
-                if (NCTX == 2) {
-                    const bool sw_need = A.mode >= QUICK && B.mode < QUICK;
-                    if (DBG) { const uint64_t m = __ballot(sw_need); if (m) { c_swaps++; c_swaplanes += __builtin_popcountll(m); } }
-                    swap_ab(sw_need);
-                }
-                const uint64_t idle = __ballot(A.mode == NEED);
-                const int nidle = __builtin_popcountll(idle);
-                if (wnext >= wend) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(s_counter, 512);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    wnext = base < tlen ? base : tlen;
-                    wend = base + 512 < tlen ? base + 512 : tlen;
-                    if (wnext >= wend) exhausted = true;
-                }
-                if (!exhausted) {
-                    const int rank = __builtin_popcountll(idle & lanemask_lt);
-                    if (DBG) { c_fvis++; c_flanes += (wend - wnext) < nidle ? (wend - wnext) : nidle; }
-                    if (A.mode == NEED && wnext + rank < wend) {
-                        const int p = wnext + rank;
-                        A.p = p;
-                        const int rem = rem0 - p;                                   // lookahead (clamped high)
-                        A.res2 = 0; A.resq = 0;
-                        bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
-                        if (ok) {
-                            const int pl = p + B_HIST;
-                            const int l0 = (int)slink[pl];                           // hashHead (:782)
-                            const int basem = p >= sw ? basem_hi : basem_lo;        // LDS index of window index 1 (entries below were clamped by a slide, :450-461)
-                            const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem; // first candidate: strstart - hashHead <= MAX_DIST (:788)
-                            const int c = pl - l0;
-                            ok = c >= firstmin;                                      // l0 == 0xFFFF (none) fails this too
-                            if (ok) {
-                                A.cl = c;
-                                A.mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem; // chain: curMatch > limit (:609)
-                                A.best = 2; A.left = P.max_chain;
-                                A.pb = sdata8[pl + 2];
-                                // the first candidate shares the position's 3-byte hash, so the scan_end test at offset 2 (:505) all but
-                                // always passes: compare it right away instead of spending a chain step on that test
-                                A.off = 0;
-                                A.mode = VERIFY;
-                            }
-                        }
-                        if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
-                    }
-                    wnext = wnext + nidle < wend ? wnext + nidle : wend;
-                }
-            }
-            if (exhausted) {
-                const bool busy = A.mode != NEED || (NCTX == 2 && B.mode != NEED);
-                if (!__any(busy)) break;
-            }
-            continue;
-        }
-        if (nv >= vth || nq == 0) {
-            // ---------------- VERIFY: dword-by-dword comparison of the candidates that passed the scan_end test
-            if (NCTX == 2) {
-                const bool sw_need = A.mode != VERIFY && B.mode == VERIFY;
-                if (DBG) { const uint64_t m = __ballot(sw_need); if (m) { c_swaps++; c_swaplanes += __builtin_popcountll(m); } }
-                swap_ab(sw_need);
-            }
-            if (DBG) c_vvis++;
-            uint64_t vm = __ballot(A.mode == VERIFY);
-            do {
-                if (DBG) { c_vsteps++; c_vlanes += __builtin_popcountll(vm); }
-                if (__builtin_amdgcn_inverse_ballot_w64(vm)) {
-                    const int pl = A.p + B_HIST;
-                    const int cap = cap_of(A.p);
-                    const uint32_t x = ldsdw(A.cl + A.off) ^ ldsdw(pl + A.off);
-                    const bool eq = x == 0;
-                    const int l = A.off + (eq ? 4 : (__builtin_ctz(x) >> 3));
-                    const bool more = eq & (l < cap);
-                    A.off = l;
-                    if (!more) {
-                        const int L = l < cap ? l : cap;
-                        const int lnk = (int)slink[A.cl];          // prev[] hop of this candidate
-                        bool nicehit = false;
-                        if (L > A.best) { // :593-607
-                            A.best = L;
-                            A.res2 = (uint32_t)L | ((uint32_t)(pl - A.cl) << 16);
-                            if (A.left > SNAPLEFT) A.resq = A.res2; // among the first max_chain>>2 candidates: the quarter walk sees it too
-                            nicehit = L >= nice_of(A.p);
-                            if (!nicehit) A.pb = sdata8[pl + L];
-                        }
-                        const int left1 = A.left - 1;
-                        const int c2 = A.cl - lnk;
-                        const bool end = (c2 < A.mincl) | (left1 == 0);
-                        A.left = nicehit ? A.left : left1;
-                        A.cl = (nicehit | end) ? A.cl : c2;
-                        A.off = 0;
-                        A.mode = (nicehit | end) ? DONE : QUICK;
-                    }
-                }
-                vm = __ballot(A.mode == VERIFY);
-            } while (__builtin_popcountll(vm) >= vkeep);
-            continue;
-        }
-        // ---------------- QUICK: chain steps — two LDS reads (scan_end byte of the candidate, its prev[] hop) and a dozen VALU
-        if (NCTX == 2) {
-            const bool sw_need = A.mode != QUICK && B.mode == QUICK;
-            if (DBG) { const uint64_t m = __ballot(sw_need); if (m) { c_swaps++; c_swaplanes += __builtin_popcountll(m); } }
-            swap_ab(sw_need);
-        }
-        if (DBG) c_qvis++;
+        fetch(A, qA, vA, dA);
+        fetch(B, qB, vB, dB);
+        if ((qA | vA | qB | vB) == 0) { if (exhausted) break; else continue; }
+        // run until at least `fth` contexts are free again (after the last batch: until all of them are)
+        const uint32_t busy_exit = exhausted ? 0u : (uint32_t)(128 - fth);
+        if (DBG) c_eng++;
         {
-            uint64_t qm = __ballot(A.mode == QUICK);
-            do {
-                if (DBG) { c_qsteps++; c_qlanes += __builtin_popcountll(qm); }
-                if (__builtin_amdgcn_inverse_ballot_w64(qm)) {
-                    const uint32_t qbyte = sdata8[A.cl + A.best];  // a longer match must agree at offset `best` (scan_end, :505)
-                    const int lnk = (int)slink[A.cl];
-                    const bool pass = qbyte == A.pb;
-                    const int left1 = A.left - 1;
-                    const int c2 = A.cl - lnk;                    // next candidate of the chain, or the end of this position (:609)
-                    const bool end = (c2 < A.mincl) | (left1 == 0);
-                    A.left = pass ? A.left : left1;
-                    A.cl = (pass | end) ? A.cl : c2;
-                    A.mode = pass ? VERIFY : (end ? DONE : QUICK);
-                }
-                qm = __ballot(A.mode == QUICK);
-            } while (__builtin_popcountll(qm) >= qkeep);
+            uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
+            uint64_t mA, mB, sc, cm, sv;
+            uint32_t n0, n1, n2;
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n"
+                "10:\n\t"                                           // ---- census
+                "s_or_b64 %[sc], %[qA], %[vA]\n\t"
+                "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
+                "s_or_b64 %[sc], %[qB], %[vB]\n\t"
+                "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
+                "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
+                "s_cmp_le_u32 %[n0], %[bexit]\n\t"
+                "s_cbranch_scc1 19f\n\t"
+                "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
+                "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
+                "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
+                "s_cmp_ge_u32 %[n1], %[vth]\n\t"
+                "s_cbranch_scc1 14f\n\t"
+                "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
+                "s_cbranch_scc1 14f\n"
+                // ---- QUICK phase
+                "s_mov_b64 %[mA], %[qA]\n\t"
+                "s_mov_b64 %[mB], %[qB]\n"
+                "11:\n\t"
+                "s_mov_b64 exec, %[mA]\n\t"
+                SZL_Q_ISSUE(A)
+                "s_mov_b64 exec, %[mB]\n\t"
+                SZL_Q_ISSUE(B)
+                "s_mov_b64 exec, %[mA]\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                SZL_Q_FINISH(A)
+                SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
+                "s_mov_b64 exec, %[mB]\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                SZL_Q_FINISH(B)
+                SZL_Q_ISSUE(B)
+                "s_mov_b64 exec, %[mA]\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                SZL_Q_FINISH(A)
+                "s_mov_b64 exec, %[mB]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                SZL_Q_FINISH(B)
+                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+                "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
+                "s_add_u32 %[n0], %[n0], %[n1]\n\t"
+                "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
+                "s_cbranch_scc1 11b\n\t"
+                SZL_Q_CLASSIFY(A)
+                SZL_Q_CLASSIFY(B)
+                "s_branch 10b\n"
+                // ---- VERIFY phase
+                "14:\n\t"
+                "s_mov_b64 %[mA], %[vA]\n\t"
+                "s_mov_b64 %[mB], %[vB]\n"
+                "15:\n\t"
+                "s_mov_b64 exec, %[mA]\n\t"
+                SZL_V_ISSUE(A)
+                "s_mov_b64 exec, %[mB]\n\t"
+                SZL_V_ISSUE(B)
+                "s_mov_b64 exec, %[mA]\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
+                SZL_V_FINISH(A)
+                "s_mov_b64 exec, %[mB]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                SZL_V_FINISH(B)
+                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+                "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
+                "s_add_u32 %[n0], %[n0], %[n1]\n\t"
+                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+                "s_cbranch_scc1 15b\n\t"
+                SZL_V_COMPLETE(A)
+                SZL_V_COMPLETE(B)
+                "s_branch 10b\n"
+                "19:\n\t"
+                "s_mov_b64 exec, %[sv]\n\t"
+                : [pA] "+v"(A.p), [clA] "+v"(A.cl), [bestA] "+v"(A.best), [leftA] "+v"(A.left), [offA] "+v"(A.off), [pbA] "+v"(A.pb),
+                  [res2A] "+v"(A.res2), [resqA] "+v"(A.resq),
+                  [pB] "+v"(B.p), [clB] "+v"(B.cl), [bestB] "+v"(B.best), [leftB] "+v"(B.left), [offB] "+v"(B.off), [pbB] "+v"(B.pb),
+                  [res2B] "+v"(B.res2), [resqB] "+v"(B.resq),
+                  [qA] "+s"(qA), [vA] "+s"(vA), [dA] "+s"(dA), [qB] "+s"(qB), [vB] "+s"(vB), [dB] "+s"(dB),
+                  [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A),
+                  [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B),
+                  [mA] "=&s"(mA), [mB] "=&s"(mB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2)
+                : [minclA] "v"(A.mincl), [capA] "v"(A.cap), [niceA] "v"(A.nice), [minclB] "v"(B.mincl), [capB] "v"(B.cap), [niceB] "v"(B.nice),
+                  [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(pbase), [bhist] "s"(bhist), [snap] "s"(SNAPLEFT),
+                  [bexit] "s"(busy_exit), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep)
+                : "vcc", "scc", "memory");
         }
     }
-    if (DBG && dbg) {
-        if (lane == 0) {
-            atomicAdd(dbg + 8, c_qvis); atomicAdd(dbg + 9, c_qsteps); atomicAdd(dbg + 10, c_qlanes);
-            atomicAdd(dbg + 11, c_vvis); atomicAdd(dbg + 12, c_vsteps); atomicAdd(dbg + 13, c_vlanes);
-            atomicAdd(dbg + 14, c_fvis); atomicAdd(dbg + 15, c_flanes); atomicAdd(dbg + 16, c_swaps); atomicAdd(dbg + 17, c_swaplanes);
-        }
-    }
-}
-
-template <int NCTX, bool DBG>
-__global__ __launch_bounds__(B2_THREADS) void k_match2(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
-                                                       const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                       MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth, int qkeep, int vkeep) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_k2[];
-    const TileDev tile = tiles[blockIdx.x];
-    const SegDev seg = segs[tile.seg];
-    // lookahead of the tile's last position >= 258 (wave-uniform: one of the two bodies runs)
-    if (seg.seg_end - (tile.start + tile.len - 1) >= (int64_t)MAX_MATCH)
-        match2_body<NCTX, false, DBG>(smem_k2, tile, seg, in, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
-    else
-        match2_body<NCTX, true, DBG>(smem_k2, tile, seg, in, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
+    if (DBG && dbg && lane == 0) { atomicAdd(dbg + 14, c_fvis); atomicAdd(dbg + 15, c_flanes); atomicAdd(dbg + 8, c_eng); }
 }
 
 static bool lds_attr_needed2(std::atomic<uint64_t> &mask, uint64_t &bit) {
@@ -305,28 +399,26 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
-    const int nctx = knob("SZL_NCTX", 2);
-    const int fth = knob("SZL_FTH2", 16), vth = knob("SZL_VTH2", 24), qkeep = knob("SZL_QKEEP", 40), vkeep = knob("SZL_VKEEP", 16);
-    // the kernel body exists in two forms: tiles that touch the end of their segment (EDGE) and all the others
+    // thresholds count CONTEXTS (two per lane, 128 per wavefront)
+    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 12), qkeep = knob("SZL_QKEEP", 48), vkeep = knob("SZL_VKEEP", 4); // swept: profiles/r02/lab_s6_k_match4_sweep.log
     auto attr = [&](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); };
     if (lds_attr_needed2(attr_mask, attr_bit)) {
-        hipError_t e = attr((const void *)k_match2<1, false>);
-        if (e == hipSuccess) e = attr((const void *)k_match2<2, false>);
-        if (e == hipSuccess) e = attr((const void *)k_match2<1, true>);
-        if (e == hipSuccess) e = attr((const void *)k_match2<2, true>);
+        hipError_t e = attr((const void *)k_match4<false>);
+        if (e == hipSuccess) e = attr((const void *)k_match4<true>);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
-    const int qk = qkeep < 1 ? 1 : qkeep, vk = vkeep < 1 ? 1 : vkeep;
+    if (want_dbg && knob("SZL_B_EXP", 0) == 1) fth = -1;      // lab: stage-only timing experiment (results are garbage)
+    else if (fth < 1) fth = 1;
+    if (fth > 128) fth = 128;
+    if (knob("SZL_B_CHAIN", 0) > 0) P.max_chain = knob("SZL_B_CHAIN", 0); // lab: shorter chains (results differ from the reference)
+    if (vth < 1) vth = 1;
+    if (qkeep < 1) qkeep = 1;
+    if (vkeep < 1) vkeep = 1;
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B2_THREADS);
-        if (nctx == 2) {
-            if (want_dbg) hipLaunchKernelGGL((k_match2<2, true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qk, vk);
-            else hipLaunchKernelGGL((k_match2<2, false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qk, vk);
-        } else {
-            if (want_dbg) hipLaunchKernelGGL((k_match2<1, true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qk, vk);
-            else hipLaunchKernelGGL((k_match2<1, false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qk, vk);
-        }
+        if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
+        else hipLaunchKernelGGL((k_match4<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
     }
     return hipGetLastError();
 }
