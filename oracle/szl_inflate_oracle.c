@@ -185,6 +185,8 @@ typedef struct {
     int16_t *tree;
     int treeSize;
 } IHT;
+static int g_szo_quirk_sets = 0; /* see iht_build */
+int szo_quirk_sets_seen(int reset) { int v = g_szo_quirk_sets; if (reset) g_szo_quirk_sets = 0; return v; }
 
 static int iht_build(IHT *t, const uint8_t *codeLengths, int n) { /* :87 */
     int blCount[16] = {0}, nextCode[16] = {0};
@@ -204,6 +206,10 @@ static int iht_build(IHT *t, const uint8_t *codeLengths, int n) { /* :87 */
         }
     }
     if (treeSize < 512) treeSize = 512;
+    /* Test aid: an INCOMPLETE set that holds codes of 10+ bits makes the reference's table differ from any canonical decoder —
+     * unassigned second-level slots decode as "symbol 0, 0 bits" (:200-203) and codes in the last, partial 9-bit prefix are
+     * written into the primary table instead (:153-163).  The differential tests record that such a set was seen. */
+    if (code < 65536) { int longc = 0; for (int b = 10; b <= 15; b++) longc += blCount[b]; if (longc) g_szo_quirk_sets++; }
     /* The reference is lenient about over-subscribed sets (:116-121) and would index out of
      * range (exception) in the fill loops below; we allocate generously and bounds-check. */
     int cap = treeSize;

@@ -118,6 +118,8 @@ uint32_t szo_inflater_adler(const szo_inflater *s);
 /* One-shot: inflate `in` fully into out; returns bytes or negative error; *consumed = TotalIn. */
 int64_t szo_inflate_oneshot(const uint8_t *in, size_t n, int no_header, uint8_t *out, size_t out_cap,
                             size_t *consumed);
+/* Test aid: number of incomplete code-length sets with codes of 10+ bits built since the last reset (see iht_build). */
+int szo_quirk_sets_seen(int reset);
 /* Same, asking for one byte per Inflate() call: *produced = bytes delivered before the error (or in total). */
 int64_t szo_inflate_probe(const uint8_t *in, size_t n, int no_header, uint8_t *out, size_t out_cap, size_t *consumed,
                           size_t *produced);

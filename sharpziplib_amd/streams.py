@@ -23,12 +23,22 @@ class DeflaterOutputStream:
         self.deflater_ = deflater if deflater is not None else Deflater()
         self.IsStreamOwner = True
         self.isClosed_ = False
+        # ICryptoTransform of the reference (:200): any object with TransformBlock(in, inOff, count, out, outOff) -> count.
+        # The hook stays on the host exactly where the reference has it: AFTER the codec, on each block of compressed bytes,
+        # in the order they are written.
+        self.cryptoTransform_ = None
+
+    def EncryptBlock(self, buffer, offset, length):            # :227-231
+        if self.cryptoTransform_ is None:
+            return
+        self.cryptoTransform_.TransformBlock(buffer, 0, length, buffer, 0)
 
     def _deflate(self, flushing=False):                        # DeflateSyncOrAsync :242-272
         while flushing or not self.deflater_.IsNeedingInput:
             n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
             if n <= 0:
                 break
+            self.EncryptBlock(self.buffer_, 0, n)              # :256
             self.baseOutputStream_.write(self.buffer_[:n].tobytes())
         if not self.deflater_.IsNeedingInput:
             raise SharpZipBaseException("DeflaterOutputStream can't deflate all input?")
@@ -51,10 +61,12 @@ class DeflaterOutputStream:
             n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
             if n <= 0:
                 break
+            self.EncryptBlock(self.buffer_, 0, n)              # :111
             self.baseOutputStream_.write(self.buffer_[:n].tobytes())
         if not self.deflater_.IsFinished:
             raise SharpZipBaseException("Can't deflate all input?")
         self.baseOutputStream_.flush()
+        self.cryptoTransform_ = None                           # :122-130 (disposed after the last block)
 
     def Dispose(self):                                         # :412
         if not self.isClosed_:
@@ -84,6 +96,24 @@ class InflaterInputBuffer:
         self.rawData = np.zeros(bufferSize, dtype=np.uint8)
         self.rawLength = 0
         self.available = 0
+        self.clearText = self.rawData                           # :41: same array until a transform is set
+        self.clearTextLength = 0
+        self.cryptoTransform = None
+        self.internalClearText = None
+
+    def SetCryptoTransform(self, value):                        # CryptoTransform setter :276-305: decrypt BEFORE the codec sees the bytes
+        self.cryptoTransform = value
+        if value is not None:
+            if self.clearText is self.rawData:
+                if self.internalClearText is None:
+                    self.internalClearText = np.zeros(self.rawData.size, dtype=np.uint8)
+                self.clearText = self.internalClearText
+            self.clearTextLength = self.rawLength
+            if self.available > 0:
+                value.TransformBlock(self.rawData, self.rawLength - self.available, self.available, self.clearText, self.rawLength - self.available)
+        else:
+            self.clearText = self.rawData
+            self.clearTextLength = self.rawLength
 
     @property
     def Available(self):
@@ -95,7 +125,7 @@ class InflaterInputBuffer:
 
     def SetInflaterInput(self, inflater):                       # :103
         if self.available > 0:
-            inflater.SetInput(self.rawData, self.rawLength - self.available, self.available)
+            inflater.SetInput(self.clearText, self.clearTextLength - self.available, self.available)
             self.available = 0
 
     def Fill(self):                                             # :115
@@ -108,7 +138,11 @@ class InflaterInputBuffer:
             self.rawData[self.rawLength:self.rawLength + len(b)] = np.frombuffer(b, dtype=np.uint8)
             self.rawLength += len(b)
             toRead -= len(b)
-        self.available = self.rawLength
+        if self.cryptoTransform is not None:                    # :131-138
+            self.clearTextLength = self.cryptoTransform.TransformBlock(self.rawData, 0, self.rawLength, self.clearText, 0)
+        else:
+            self.clearTextLength = self.rawLength
+        self.available = self.clearTextLength
 
 
 class InflaterInputStream:

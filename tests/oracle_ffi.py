@@ -52,6 +52,7 @@ def lib():
     L.szo_deflate_oneshot.argtypes = [vp, sz, i32, i32, i32, i32, vp, sz, vp]
     L.szo_inflate_oneshot.restype = i64
     L.szo_inflate_oneshot.argtypes = [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]
+    L.szo_quirk_sets_seen.restype = i32; L.szo_quirk_sets_seen.argtypes = [i32]
     L.szo_inflate_probe.restype = i64
     L.szo_inflate_probe.argtypes = [vp, sz, i32, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     for name, res, args in [
@@ -271,7 +272,9 @@ def inflate_probe(data, nowrap=True, max_out=1 << 20):
     a = _buf(data)
     out = np.empty(max_out, dtype=np.uint8)
     cons, prod = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    lib().szo_quirk_sets_seen(1)
     n = lib().szo_inflate_probe(a.ctypes.data, a.size, 1 if nowrap else 0, out.ctypes.data, max_out, ctypes.byref(cons), ctypes.byref(prod))
+    inflate_probe.quirk_sets = lib().szo_quirk_sets_seen(1)
     return n, out[:prod.value].tobytes(), cons.value
 
 

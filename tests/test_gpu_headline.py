@@ -114,7 +114,7 @@ def test_config3_4096_entries_bit_exact(eng):
 def test_arena_offsets_above_4gib(eng):
     """A stream whose input AND output regions start above 2^32 in the arenas (64-bit offsets in every per-position array),
     next to one at offset 0; device-resident call like bench.py's."""
-    import torch
+    import hip_ffi as H
     from sharpziplib_amd import _lib
     c, data = _case_input("off4g_enwik_8m_l6")
     small = C.generate("dickens", 77, 0, 300000)
@@ -124,26 +124,27 @@ def test_arena_offsets_above_4gib(eng):
     n = data.size
     cap0 = (int(L.szl_deflate_bound(small.size)) + 3) & ~3
     cap1 = (int(L.szl_deflate_bound(n)) + 3) & ~3
-    dev = torch.device("cuda", 0)
-    d_in = torch.empty(big_in + n + 64, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(big_out + cap1 + 64, dtype=torch.uint8, device=dev)
-    d_in[:small.size].copy_(torch.from_numpy(small))
-    d_in[big_in:big_in + n].copy_(torch.from_numpy(data))
-    # canaries around the output regions: the engine may only touch [out_off, out_off + out_cap)
-    d_out[cap0:cap0 + 4096].fill_(0xA5)
-    d_out[big_out - 4096:big_out].fill_(0x5A)
-    arr = (_lib.Stream * 2)()
-    arr[0].in_off, arr[0].in_len, arr[0].out_off, arr[0].out_cap = 0, small.size, 0, cap0
-    arr[1].in_off, arr[1].in_len, arr[1].out_off, arr[1].out_cap = big_in, n, big_out, cap1
-    torch.cuda.synchronize(dev)
-    eng.deflate_device(d_in.data_ptr(), d_out.data_ptr(), arr, level=c["level"], flags=_lib.F_NOWRAP | _lib.F_CRC32)
-    assert arr[0].status == 0 and arr[1].status == 0
-    got1 = d_out[big_out:big_out + int(arr[1].out_len)].cpu().numpy().tobytes()
-    assert len(got1) == c["out_len"] and hashlib.sha256(got1).hexdigest() == c["out_sha256"]
-    assert int(arr[1].crc32) == c["crc32"]
-    got0 = d_out[:int(arr[0].out_len)].cpu().numpy().tobytes()
-    assert got0 == O.deflate(small, c["level"])
-    assert bool((d_out[cap0:cap0 + 4096] == 0xA5).all()) and bool((d_out[big_out - 4096:big_out] == 0x5A).all()), \
-        "the engine wrote outside the streams' output regions"
-    del d_in, d_out
-    torch.cuda.empty_cache()
+    d_in = H.DevBuf(big_in + n + 64)
+    d_out = H.DevBuf(big_out + cap1 + 64)
+    try:
+        d_in.upload(0, small)
+        d_in.upload(big_in, data)
+        # canaries around the output regions: the engine may only touch [out_off, out_off + out_cap)
+        d_out.fill(cap0, 4096, 0xA5)
+        d_out.fill(big_out - 4096, 4096, 0x5A)
+        arr = (_lib.Stream * 2)()
+        arr[0].in_off, arr[0].in_len, arr[0].out_off, arr[0].out_cap = 0, small.size, 0, cap0
+        arr[1].in_off, arr[1].in_len, arr[1].out_off, arr[1].out_cap = big_in, n, big_out, cap1
+        H.hip().hipDeviceSynchronize()
+        eng.deflate_device(d_in.addr, d_out.addr, arr, level=c["level"], flags=_lib.F_NOWRAP | _lib.F_CRC32)
+        assert arr[0].status == 0 and arr[1].status == 0
+        got1 = d_out.download(big_out, int(arr[1].out_len)).tobytes()
+        assert len(got1) == c["out_len"] and hashlib.sha256(got1).hexdigest() == c["out_sha256"]
+        assert int(arr[1].crc32) == c["crc32"]
+        got0 = d_out.download(0, int(arr[0].out_len)).tobytes()
+        assert got0 == O.deflate(small, c["level"])
+        assert bool((d_out.download(cap0, 4096) == 0xA5).all()) and bool((d_out.download(big_out - 4096, 4096) == 0x5A).all()), \
+            "the engine wrote outside the streams' output regions"
+    finally:
+        d_in.free()
+        d_out.free()
