@@ -135,6 +135,15 @@ int szl_deflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
 int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                            int level, int strategy, unsigned flags);
 
+/* Several devices of one node behind the same call (SURVEY §8e "shard per GPU": ZipOutputStream entries S/Zip/ZipOutputStream.cs:494,
+ * gzip members S/GZip/GzipInputStream.cs:353-357): the streams are cut into n_dev contiguous groups of about equal input bytes and
+ * group g is compressed on devices[g] by its own host thread and engine; only a group's own bytes travel to its device.  Results
+ * are identical to the single-device calls (every stream is independent).  The same ordinal may appear more than once. */
+int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
+                                 int level, int strategy, unsigned flags);
+int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
+                                 unsigned flags);
+
 /* Per-stage timing of the last batch call on this engine, milliseconds measured with HIP events on the
  * engine's stream (SURVEY §5 "per-stage hipEvent timing exported through the C ABI"). */
 typedef struct szl_timing {
@@ -158,6 +167,10 @@ int szl_engine_debug_match_mode(szl_engine *e, int mode);
 /* Experiment / parity knob: sets a named tuning value for this process (the same names are read from the environment as a
  * fallback): SZL_MATCH_KERNEL, SZL_NCTX, SZL_FTH2, SZL_VTH2, SZL_QKEEP, SZL_VKEEP, SZL_DEBUG, ...  Results never depend on them. */
 int szl_debug_set(const char *name, int value);
+
+/* Parity tap: device bytes held by the engine's per-position side arrays at the peak of the last deflate call.  A single stream
+ * longer than SZL_WINDOW_KIB (default 256 MiB) is processed window by window, so this stays bounded by the window. */
+uint64_t szl_engine_debug_workspace(const szl_engine *e);
 
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);

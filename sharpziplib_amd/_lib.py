@@ -56,11 +56,14 @@ def lib():
         "szl_deflate_bound": (u64, [u64]), "szl_engine_create": (vp, []), "szl_engine_destroy": (None, [vp]),
         "szl_deflate_batch_device": (i32, [vp, vp, vp, vp, sz, i32, i32, ctypes.c_uint, vp]),
         "szl_deflate_batch_host": (i32, [vp, vp, vp, vp, sz, i32, i32, ctypes.c_uint]),
+        "szl_deflate_batch_multi_host": (i32, [vp, i32, vp, vp, vp, sz, i32, i32, ctypes.c_uint]),
+        "szl_inflate_batch_multi_host": (i32, [vp, i32, vp, vp, vp, sz, ctypes.c_uint]),
         "szl_engine_last_timing": (i32, [vp, vp]),
         "szl_engine_debug_fetch": (i32, [vp, vp, vp, vp, sz, vp, sz, ctypes.POINTER(sz)]),
         "szl_engine_debug_blocks": (i32, [vp, vp, sz, ctypes.POINTER(sz)]),
         "szl_engine_debug_match_mode": (i32, [vp, i32]),
         "szl_debug_set": (i32, [ctypes.c_char_p, i32]),
+        "szl_engine_debug_workspace": (u64, [vp]),
         "szl_debug_stored_layout": (i32, [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]),
         "szl_inflater_create": (vp, [i32]), "szl_inflater_destroy": (None, [vp]), "szl_inflater_reset": (i32, [vp]),
         "szl_inflater_set_input": (i32, [vp, vp, i32]), "szl_inflater_set_dictionary": (i32, [vp, vp, i32]),

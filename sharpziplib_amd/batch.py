@@ -117,3 +117,41 @@ class Engine:
         flags = (_lib.F_NOWRAP if nowrap else 0) | (_lib.F_CRC32 if crc32 else 0) | (_lib.F_ADLER32 if adler32 else 0)
         _lib.check(self._L.szl_inflate_batch_host(self._h, hin.ctypes.data, hout.ctypes.data, arr, len(bufs), flags), "szl_inflate_batch_host")
         return [(Result(hout[s.out_off:s.out_off + s.out_len].tobytes(), s.crc32, s.adler32, s.status), int(s.in_consumed)) for s in arr]
+
+
+def deflate_multi(buffers, devices, level=6, strategy=0, nowrap=True, crc32=False, adler32=False):
+    """Compress independent host buffers on several devices (szl_deflate_batch_multi_host): contiguous groups of streams, one
+    host thread + engine per device, no exchange between the groups.  Returns [Result] in input order."""
+    L = _lib.lib()
+    bufs = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b, dtype=np.uint8) for b in buffers]
+    arr, in_total, out_total = Engine.layout([b.size for b in bufs], nowrap)
+    hin = np.empty(in_total + 8, dtype=np.uint8)
+    for s, b in zip(arr, bufs):
+        hin[s.in_off:s.in_off + s.in_len] = b
+    hout = np.zeros(out_total + 8, dtype=np.uint8)
+    flags = (_lib.F_NOWRAP if nowrap else 0) | (_lib.F_CRC32 if crc32 else 0) | (_lib.F_ADLER32 if adler32 else 0)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    _lib.check(L.szl_deflate_batch_multi_host(devs, len(devices), hin.ctypes.data, hout.ctypes.data, arr, len(bufs), level, strategy, flags),
+               "szl_deflate_batch_multi_host")
+    return [Result(hout[s.out_off:s.out_off + s.out_len].tobytes(), s.crc32, s.adler32, s.status) for s in arr]
+
+
+def inflate_multi(buffers, out_sizes, devices, nowrap=True, crc32=False):
+    """Inflate independent streams on several devices (szl_inflate_batch_multi_host). Returns [(Result, consumed)]."""
+    L = _lib.lib()
+    bufs = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b, dtype=np.uint8) for b in buffers]
+    arr = (_lib.Stream * len(bufs))()
+    io = oo = 0
+    for i, (b, cap) in enumerate(zip(bufs, out_sizes)):
+        arr[i].in_off, arr[i].in_len, arr[i].out_off, arr[i].out_cap = io, b.size, oo, cap
+        io += (b.size + 3) & ~3
+        oo += (cap + 3) & ~3
+    hin = np.zeros(io + 8, dtype=np.uint8)
+    for s, b in zip(arr, bufs):
+        hin[s.in_off:s.in_off + s.in_len] = b
+    hout = np.zeros(oo + 8, dtype=np.uint8)
+    flags = (_lib.F_NOWRAP if nowrap else 0) | (_lib.F_CRC32 if crc32 else 0)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    _lib.check(L.szl_inflate_batch_multi_host(devs, len(devices), hin.ctypes.data, hout.ctypes.data, arr, len(bufs), flags),
+               "szl_inflate_batch_multi_host")
+    return [(Result(hout[s.out_off:s.out_off + s.out_len].tobytes(), s.crc32, s.adler32, s.status), int(s.in_consumed)) for s in arr]

@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 #include "szl_engine.h"
 
@@ -276,6 +279,77 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Several devices behind the C ABI (configs 3 and 4 shard by independent streams — zip entries, gzip members).
+// The streams are cut into n_dev contiguous groups of about equal input bytes; group g runs on devices[g] in its own host
+// thread with its own engine (kept for the next call), staging only the bytes of its group.  No data-path collective: the
+// groups never exchange anything.  One stream is never split.
+struct MultiSlot { szl_engine *eng = nullptr; int device = -1; };
+static std::mutex g_multi_mu;
+static std::vector<MultiSlot> g_multi_slots;
+
+static int multi_run(bool inflate, const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n,
+                     int level, int strategy, unsigned flags) {
+    if ((!streams && n) || !devices || n_dev <= 0) return SZL_E_ARG;
+    if (n == 0) return 0;
+    int ndev_avail = 0;
+    if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
+    for (int g = 0; g < n_dev; g++) if (devices[g] < 0 || devices[g] >= ndev_avail) { set_error("device ordinal %d out of range", devices[g]); return SZL_E_ARG; }
+    // contiguous groups balanced by input bytes
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += streams[i].in_len + 1;
+    std::vector<size_t> cut(n_dev + 1, n);
+    cut[0] = 0;
+    { uint64_t acc = 0; int g = 1;
+      for (size_t i = 0; i < n && g < n_dev; i++) { acc += streams[i].in_len + 1; while (g < n_dev && acc * (uint64_t)n_dev >= total * (uint64_t)g) cut[g++] = i + 1; } }
+    for (int g = 1; g <= n_dev; g++) if (cut[g] < cut[g - 1]) cut[g] = cut[g - 1];
+    cut[n_dev] = n;
+    { std::lock_guard<std::mutex> lk(g_multi_mu); if ((int)g_multi_slots.size() < n_dev) g_multi_slots.resize(n_dev); }
+    std::vector<int> rcs(n_dev, 0);
+    std::vector<std::string> errs(n_dev);
+    auto work = [&](int g) {
+        const size_t a = cut[g], b = cut[g + 1];
+        if (a >= b) return;
+        if (hipSetDevice(devices[g]) != hipSuccess) { rcs[g] = SZL_E_DEVICE; errs[g] = "hipSetDevice failed"; return; }
+        MultiSlot &slot = g_multi_slots[g];                       // slot g is only ever used by group g's thread of one call at a time
+        if (slot.eng && slot.device != devices[g]) { szl_engine_destroy(slot.eng); slot.eng = nullptr; }
+        if (!slot.eng) { slot.eng = szl_engine_create(); slot.device = devices[g]; }
+        if (!slot.eng) { rcs[g] = SZL_E_DEVICE; errs[g] = last_error(); return; }
+        // rebase the group's byte spans so that only its own bytes cross PCIe
+        uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
+        for (size_t i = a; i < b; i++) {
+            in_lo = std::min(in_lo, streams[i].in_off); in_hi = std::max(in_hi, streams[i].in_off + streams[i].in_len);
+            out_lo = std::min(out_lo, streams[i].out_off); out_hi = std::max(out_hi, streams[i].out_off + streams[i].out_cap);
+        }
+        out_lo &= ~3ull;                                          // output regions stay 4-byte aligned after the shift
+        std::vector<szl_stream> local(streams + a, streams + b);
+        for (auto &s : local) { s.in_off -= in_lo; s.out_off -= out_lo; }
+        int rc = inflate ? szl_inflate_batch_host(slot.eng, (const uint8_t *)h_in + in_lo, (uint8_t *)h_out + out_lo, local.data(), local.size(), flags)
+                         : szl_deflate_batch_host(slot.eng, (const uint8_t *)h_in + in_lo, (uint8_t *)h_out + out_lo, local.data(), local.size(), level, strategy, flags);
+        if (rc) { rcs[g] = rc; errs[g] = last_error(); return; }
+        for (size_t i = a; i < b; i++) {
+            const szl_stream &r = local[i - a];
+            streams[i].out_len = r.out_len; streams[i].crc32 = r.crc32; streams[i].adler32 = r.adler32; streams[i].status = r.status;
+            streams[i].in_consumed = r.in_consumed;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < n_dev; g++) th.emplace_back(work, g);
+    work(0);
+    for (auto &t : th) t.join();
+    (void)hipSetDevice(g_device);
+    for (int g = 0; g < n_dev; g++) if (rcs[g]) { set_error("device %d (group %d): %s", devices[g], g, errs[g].c_str()); return rcs[g]; }
+    return 0;
+}
+int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
+                                 int level, int strategy, unsigned flags) {
+    return multi_run(false, devices, n_dev, h_in, h_out, streams, n_streams, level, strategy, flags);
+}
+int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
+                                 unsigned flags) {
+    return multi_run(true, devices, n_dev, h_in, h_out, streams, n_streams, 0, 0, flags);
+}
+
 int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t *mq, size_t n_positions, uint32_t *tokens,
                            size_t tok_cap, size_t *n_tokens) {
     if (!e) return SZL_E_ARG;
@@ -308,6 +382,9 @@ int szl_engine_debug_match_mode(szl_engine *e, int mode) {
 
 // Experiment / parity knob (see knob() in szl_engine.hip): overrides the environment variable of the same name for this process.
 int szl_debug_set(const char *name, int value) { return name ? szl::knob_set(name, value) : SZL_E_ARG; }
+
+// Parity tap: device bytes held by the per-position side arrays (links, match tables, tokens, ...) at the peak of the last call.
+uint64_t szl_engine_debug_workspace(const szl_engine *e) { return e ? e->e.last_workspace_bytes : 0; }
 
 // Parity tap: block table of the last call. rows of 8 x uint64: type,last,ntok,bit_start,opt_len,static_len,in_len,hdr_bits
 int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows) {

@@ -31,6 +31,17 @@ class Engine {
     int deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
                 const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st);
 
+    // One long stream (a single segment, levels 5-9) as a software pipeline of windows: stages A-C run window by window on
+    // side arrays sized for ONE window — the parse of a window starts at the clean iteration the previous one ended on — and
+    // stage D runs once over the whole token stream.  Output is bit-identical to deflate()'s (tests force tiny windows).
+    int deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
+                         const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st,
+                         uint64_t window);
+    // progress of an overlapped host->device copy of the input arena (szl_deflate_batch_host): the engine waits until the bytes a
+    // window needs have arrived.  nullptr: everything is resident.
+    const volatile uint64_t *in_ready = nullptr;
+    uint64_t last_workspace_bytes = 0; // device bytes held by the side arrays after the last call (parity tap / DESIGN §3)
+
     // Level 0: write the stored blocks `blks` (host-built) and, if want_ck, the checksums of d_in[ck_off, ck_off+ck_len).
     int deflate_stored(const uint8_t *d_in, uint8_t *d_out, const std::vector<StoredBlk> &blks, unsigned want_ck, uint64_t ck_off,
                        uint64_t ck_len, uint32_t crc_init, uint32_t adler_init, uint32_t *crc_out, uint32_t *adler_out, hipStream_t st);

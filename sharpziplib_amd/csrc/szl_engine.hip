@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
+#include <thread>
 #include <cstring>
 #include <vector>
 #include "szl_engine.h"
@@ -128,6 +130,12 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     const uint32_t nseg = (uint32_t)segs.size();
     results.assign(nseg, SegOut{});
     if (nseg == 0) return 0;
+    for (auto &s : segs) if (s.look_end < s.seg_end) s.look_end = s.seg_end;
+    {   // a single long stream at a DeflateSlow level goes through the window pipeline (workspace of one window, not of the stream)
+        const uint64_t window = (uint64_t)knob("SZL_WINDOW_KIB", 256 * 1024) * 1024;
+        if (nseg == 1 && !P.fast && window >= (uint64_t)B_TILE && (uint64_t)(segs[0].seg_end - segs[0].seg_start) > window + window / 4)
+            return deflate_windowed(d_in, in_total, d_out, out_total, segs[0], bnds, P, want_ck, results, st, window / B_TILE * B_TILE);
+    }
     memset(&timing, 0, sizeof timing);
     for (auto &e : ev) if (!e) HIPCHK(hipEventCreate(&e));
 
@@ -378,6 +386,232 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] stage B %s (pilot fraction %.3f): %llu of %llu positions evaluated by walkers, %llu by the parse (eval_global), slow walks %llu, unmerged %llu\n", lazy ? "on demand" : "full", last_pilot_frac, hc[6], (unsigned long long)seg_bytes, hc[7], hc[1], hc[0]);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;
+    last_workspace_bytes = 0;
+    for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &bsp, &blp, &spec_tok, &bad_slot, &bad_range, &ckparts})
+        last_workspace_bytes += b->cap;
+    return 0;
+}
+
+// ---- window pipeline -----------------------------------------------------------------------------------------------------
+__global__ void k_add_base(uint64_t *v, uint64_t n, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += base;
+}
+
+static int grow_preserve(DevBuf &b, size_t need, size_t used, hipStream_t st) { // like ensure(), but keeps the first `used` bytes
+    if (need <= b.cap) return 0;
+    void *np = nullptr;
+    const size_t want = need + (need >> 1) + 256;
+    if (hipMalloc(&np, want) != hipSuccess) { set_error("hipMalloc(%zu) failed", want); return SZL_E_NOMEM; }
+    if (b.p && used) {
+        if (hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(np); return SZL_E_DEVICE; }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np; b.cap = want;
+    return 0;
+}
+
+int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
+                             const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st,
+                             uint64_t window) {
+    (void)out_total;
+    memset(&timing, 0, sizeof timing);
+    for (auto &e : ev) if (!e) HIPCHK(hipEventCreate(&e));
+    const int64_t S0 = seg.seg_start, N = seg.seg_end;           // the real segment [S0, N) inside its stream buffer
+    const uint64_t n = (uint64_t)(N - S0);
+    seg.look_end = N; seg.range_off = 0; seg.vis_word_off = 0;
+    int rc;
+    // ---- whole-stream tables and buffers
+    const uint64_t blk_slots = n / BLOCK_TOKENS + 1;
+    const uint64_t nchunks = (n + 4095) / 4096;
+    std::vector<uint64_t> chunk_off{0, nchunks}, zero_off{0, (seg.out_cap + (uint64_t)zero_piece_bytes() - 1) / (uint64_t)zero_piece_bytes()};
+    std::vector<uint64_t> fixed_blk_off{0, blk_slots};
+    if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc))) || (rc = d_so.ensure(2 * sizeof(SegOut))) || (rc = blk_counts.ensure(16)) ||
+        (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(256)) ||
+        (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) ||
+        (rc = upload(d_bnds, bnds, st)) || (rc = upload(ckoff, chunk_off, st)) || (rc = upload(d_zoff, zero_off, st)) || (rc = upload(blk_off, fixed_blk_off, st)))
+        return rc;
+    // d_segs: [0] = the real segment (checksums, zeroing, stage D), [1] = the current window's pseudo-segment (stages A-C)
+    if ((rc = d_segs.ensure(2 * sizeof(SegDev)))) return rc;
+    HIPCHK(hipMemcpyAsync(d_segs.p, &seg, sizeof seg, hipMemcpyHostToDevice, st));
+    const SegDev *dseg_real = (const SegDev *)d_segs.p, *dseg_win = dseg_real + 1;
+    SegOut *dso = (SegOut *)d_so.p;                               // [0] real, [1] window view (token indices are global: tok_first 0)
+    unsigned long long *dcnt = (unsigned long long *)counters.p;
+    HIPCHK(hipEventRecord(ev[0], st));
+    auto wait_input = [&](uint64_t upto) { // overlapped H2D of the arena (szl_deflate_batch_host): bytes [0, upto) must have landed
+        if (!in_ready) return;
+        const uint64_t need = seg.buf_off + upto;
+        while (*in_ready < (need < in_total ? need : in_total)) std::this_thread::yield();
+    };
+    launch_zero_regions(dseg_real, 1, (const uint64_t *)d_zoff.p, zero_off[1], d_out, st);
+    HIPCHK(hipMemsetAsync(d_so.p, 0, 2 * sizeof(SegOut), st));
+    HIPCHK(hipMemsetAsync(counters.p, 0, 256, st));
+    const bool forked = want_ck && !in_ready;                      // (with an overlapped copy the checksums run at the end, when all bytes are there)
+    if (forked) {
+        if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        if (!ev_fork) HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        if (!ev_join) HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
+        launch_checksums(d_in, dseg_real, 1, (const uint64_t *)ckoff.p, nchunks, ckparts.p, dso, want_ck, side);
+        HIPCHK(hipEventRecord(ev_join, side));
+    } else if (!want_ck) {
+        launch_checksums(d_in, dseg_real, 1, (const uint64_t *)ckoff.p, 0, ckparts.p, dso, 0, st); // seeds the running values
+    }
+    size_t cub_bytes = 0;
+    const uint64_t max_ranges = (window + window / 4) / C_RANGE + 2;
+    if ((rc = counts.ensure((max_ranges + 2) * 4)) || (rc = range_tok.ensure((max_ranges + 2) * 8)) || (rc = ranges.ensure((max_ranges + 1) * sizeof(RangeDev))) ||
+        (rc = bad_slot.ensure((max_ranges + 2) * 4)) || (rc = bad_range.ensure((max_ranges + 2) * 8))) return rc;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(max_ranges + 1), st));
+    if ((rc = cubtmp.ensure(cub_bytes + 256))) return rc;
+
+    const int match_mode = match_mode_override >= 0 ? match_mode_override : knob("SZL_MATCH_MODE", 2);
+    static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25;
+    const bool emit_copy = emit_copy_enabled();
+    bool lazy = match_mode == 1;
+    last_pilot_frac = -1.0;
+    uint64_t tok_base = 0, total_unmerged = 0, peak = 0;
+    float ms_links = 0, ms_match = 0, ms_parse = 0, ms_pilot = 0;
+    int64_t e = S0;                                                // clean iteration the next window starts on
+    for (uint32_t wi = 0; e < N || (wi == 0 && n == 0); wi++) {
+        int64_t wend = e + (int64_t)window;
+        if (N - wend < (int64_t)(window / 4)) wend = N;            // no sliver at the end
+        const bool last = wend >= N;
+        if (last) wend = N;
+        const int64_t hi = last ? N : std::min<int64_t>(N, wend + C_WIN_HALO);   // links / table entries exist for [.., hi)
+        const int64_t lo = std::max<int64_t>(0, e - WSIZE);                      // links from here (stage B stages 32512 of history)
+        wait_input((uint64_t)std::min<int64_t>(N, hi + MAX_MATCH + 8));
+        SegDev w = seg;
+        w.seg_start = e; w.seg_end = wend; w.look_end = N;
+        const uint64_t wn = (uint64_t)(wend - e);
+        const uint64_t nranges = (wn + C_RANGE - 1) / C_RANGE;
+        w.range_cnt = (uint32_t)nranges;
+        if (nranges > max_ranges) { set_error("window bookkeeping"); return SZL_E_STATE; }
+        HIPCHK(hipMemcpyAsync((void *)dseg_win, &w, sizeof w, hipMemcpyHostToDevice, st));
+        std::vector<SpanDev> spans;
+        std::vector<TileDev> tiles;
+        uint64_t span_len = ((uint64_t)(hi - lo) + 511) / 512;
+        span_len = std::min<uint64_t>(std::max<uint64_t>(span_len, 1u << 17), 1u << 22);
+        span_len = (span_len + 63) & ~63ull;
+        for (int64_t a = lo; a < hi; a += (int64_t)span_len) spans.push_back(SpanDev{1, 0, a, std::min<int64_t>(a + (int64_t)span_len, hi)});
+        for (int64_t a = e; a < wend; a += B_TILE) tiles.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(B_TILE, wend - a), 0});
+        const uint64_t ntiles = tiles.size();
+        // side arrays of this window, addressed with the stream's own indices (pointer minus the window's first index)
+        const uint64_t nlink = (uint64_t)(hi - lo), ntab = (uint64_t)(hi - e);
+        const size_t mt_stride = (ntab + 63) & ~(size_t)63;
+        if ((rc = link.ensure(nlink * 2 + 64)) || (rc = mtab.ensure(mt_stride * 8 + 64)) || (rc = visited.ensure((wn / 32 + 8) * 4)) ||
+            (emit_copy && (rc = spec_tok.ensure(ntab * 4 + 1024))) || (rc = upload(d_spans, spans, st)) || (rc = upload(d_tiles, tiles, st))) return rc;
+        uint16_t *lk = (uint16_t *)link.p - (seg.buf_off + (uint64_t)lo);
+        const MTab mt = {(uint32_t *)mtab.p - (seg.buf_off + (uint64_t)e), (uint32_t *)mtab.p + mt_stride - (seg.buf_off + (uint64_t)e)};
+        uint32_t *stok = emit_copy ? (uint32_t *)spec_tok.p - (seg.buf_off + (uint64_t)e) : nullptr;
+        if ((rc = grow_preserve(tokens, (tok_base + wn + 16) * 4, tok_base * 4, st))) return rc;
+        HIPCHK(hipMemsetAsync(visited.p, 0, (wn / 32 + 8) * 4, st));
+        HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
+        HIPCHK(hipMemsetAsync(counters.p, 0, 8, st));             // counter 0: ranges of THIS window that never merged
+        HIPCHK(hipEventRecord(ev[1], st));
+        // the launch wrappers index segs[span.seg] / segs[tile.seg]: entry 1 of d_segs is the window
+        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, st);
+        HIPCHK(hipEventRecord(ev[2], st));
+        if (wi == 0 && match_mode == 2 && ntiles >= 64) {          // the pilot (see deflate()): once, on the first window
+            const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8));
+            uint64_t sampled = 0;
+            for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
+            HIPCHK(launch_match_lazy(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)((ntiles + step - 1) / step), 0, (int)step, lk, mt, P, dcnt, st));
+            unsigned long long ne = 0;
+            HIPCHK(hipMemcpyAsync(&ne, (unsigned long long *)counters.p + 6, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            last_pilot_frac = sampled ? (double)ne / (double)sampled : 1.0;
+            lazy = last_pilot_frac < lazy_max_frac;
+        }
+        HIPCHK(hipEventRecord(ev[7], st));
+        if (lazy) {
+            HIPCHK(hipMemsetAsync(mtab.p, 0xFF, mt_stride * 4, st)); // M_UNSET
+            HIPCHK(launch_match_lazy(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, 0, 1, lk, mt, P, dcnt, st));
+        } else {
+            HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mt, P, dcnt, st));
+            if (!last) HIPCHK(hipMemsetAsync((uint32_t *)mtab.p + wn, 0xFF, (size_t)(hi - wend) * 4, st)); // the tail past the parse end: evaluated on demand
+        }
+        HIPCHK(hipEventRecord(ev[3], st));
+        // ---- stage C on the window's ranges (as in deflate(); the window is "a segment with history" that starts on a clean iteration)
+        launch_spec(d_in, lk, mt, dseg_win, 1, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, stok, st);
+        launch_fix(d_in, lk, mt, dseg_win, 1, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
+        unsigned long long nbad = 0;
+        HIPCHK(hipMemcpyAsync(&nbad, counters.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        total_unmerged += nbad;
+        if (nbad > 0 && lazy) HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mt, P, dcnt, st));
+        if (nbad > 0 && nbad <= 48) launch_resolve(d_in, lk, mt, dseg_win, 1, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
+        else if (nbad > 48) {
+            const size_t W = (size_t)exitmap_width();
+            if ((rc = exmap.ensure(nbad * W * 2 + 64)) || (rc = cnmap.ensure(nbad * W * 2 + 64))) return rc;
+            launch_exitmaps(d_in, lk, mt, dseg_win, 1, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, (const uint32_t *)bad_slot.p, (const uint64_t *)bad_range.p,
+                            nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st);
+        }
+        launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
+        hipLaunchKernelGGL(k_add_base, dim3((unsigned)((nranges + 1 + 255) / 256)), dim3(256), 0, st, (uint64_t *)range_tok.p, nranges + 1, tok_base);
+        // window's end: the clean iteration the true parse leaves it on, and its token count
+        RangeDev lastr{};
+        uint64_t tok_after = 0;
+        HIPCHK(hipMemcpyAsync(&lastr, (RangeDev *)ranges.p + (nranges - 1), sizeof lastr, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&tok_after, (uint64_t *)range_tok.p + nranges, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // emission view of the window: global token indices; only the stream's very last token closes a block early
+        SegOut view{};
+        view.tok_first = 0; view.tok_count = last ? tok_after : ~0ull >> 2;
+        HIPCHK(hipMemcpyAsync(dso + 1, &view, sizeof view, hipMemcpyHostToDevice, st));
+        if (emit_copy)
+            launch_emit_copy(d_in, lk, mt, dseg_win, 1, nranges, P, (const RangeDev *)ranges.p, (const uint32_t *)visited.p, stok, (const uint64_t *)range_tok.p,
+                             dso + 1, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, st);
+        else
+            launch_emit(d_in, lk, mt, dseg_win, 1, nranges, P, (const RangeDev *)ranges.p, (const uint64_t *)range_tok.p, dso + 1, (uint32_t *)tokens.p,
+                        (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
+        HIPCHK(hipEventRecord(ev[4], st));
+        HIPCHK(hipStreamSynchronize(st));
+        float a = 0, b = 0, c = 0, pm = 0;
+        (void)hipEventElapsedTime(&a, ev[1], ev[2]); (void)hipEventElapsedTime(&pm, ev[2], ev[7]); (void)hipEventElapsedTime(&b, ev[7], ev[3]); (void)hipEventElapsedTime(&c, ev[3], ev[4]);
+        ms_links += a; ms_pilot += pm; ms_match += b; ms_parse += c;
+        uint64_t ws = 0;
+        for (DevBuf *bb : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &bsp, &blp, &spec_tok, &bad_slot, &bad_range, &ckparts}) ws += bb->cap;
+        peak = std::max(peak, ws);
+        tok_base = tok_after;
+        if (last) break;
+        e = lastr.exit_true;                                       // >= wend: the next window starts here, on a clean iteration
+        if (e < wend || e > wend + 1024) { set_error("window hand-over out of range"); return SZL_E_STATE; }
+        if (e >= N) { set_error("window hand-over reached the end of the stream"); return SZL_E_STATE; } // (the last window absorbs slivers)
+    }
+    // ---- stage D over the whole token stream (as in deflate())
+    SegOut whole{};
+    whole.tok_first = 0; whole.tok_count = tok_base;
+    if (!want_ck || forked) { // keep the checksum fields the kernels wrote into dso[0]
+        HIPCHK(hipMemcpyAsync((char *)dso, &whole, offsetof(SegOut, blk_first), hipMemcpyHostToDevice, st));
+    }
+    if (want_ck && !forked) { // overlapped copy: every byte is there now
+        wait_input((uint64_t)N);
+        HIPCHK(hipMemcpyAsync((char *)dso, &whole, offsetof(SegOut, blk_first), hipMemcpyHostToDevice, st));
+        launch_checksums(d_in, dseg_real, 1, (const uint64_t *)ckoff.p, nchunks, ckparts.p, dso, want_ck, st);
+    }
+    HIPCHK(hipEventRecord(ev[4], st));
+    launch_seg_blocks(dseg_real, 1, (const uint32_t *)tokens.p, (const uint64_t *)blk_off.p, dso, 0, st);
+    launch_block_build(dseg_real, 1, dso, (const uint64_t *)blk_off.p, (const uint32_t *)tokens.p, (const int64_t *)bsp.p, (const int64_t *)blp.p,
+                       (BlockDesc *)descs.p, (uint32_t)blk_slots, 0, st);
+    launch_block_scan(dseg_real, 1, dso, (BlockDesc *)descs.p, st);
+    HIPCHK(hipEventRecord(ev[5], st));
+    launch_block_encode(d_in, d_out, dseg_real, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);
+    if (forked) HIPCHK(hipStreamWaitEvent(st, ev_join, 0));
+    launch_seg_finish(dseg_real, 1, dso, d_out, st);
+    HIPCHK(hipEventRecord(ev[6], st));
+    HIPCHK(hipGetLastError());
+    results.assign(1, SegOut{});
+    HIPCHK(hipMemcpyAsync(results.data(), d_so.p, sizeof(SegOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float d1 = 0, d2 = 0;
+    (void)hipEventElapsedTime(&d1, ev[4], ev[5]); (void)hipEventElapsedTime(&d2, ev[5], ev[6]); (void)hipEventElapsedTime(&timing.total_ms, ev[0], ev[6]);
+    timing.links_ms = ms_links; timing.match_ms = ms_match; timing.parse_ms = ms_parse; timing.pilot_ms = ms_pilot; timing.blocks_ms = d1; timing.encode_ms = d2;
+    timing.in_bytes = n; timing.ranges_unmerged = total_unmerged;
+    timing.out_bytes = results[0].out_bytes; timing.tokens = results[0].tok_count; timing.blocks = results[0].blk_count;
+    last_lazy = lazy; last_in_total = in_total; last_blk_slots = blk_slots; last_nranges = 0; last_mt_stride = 0;
+    last_workspace_bytes = peak;
     return 0;
 }
 

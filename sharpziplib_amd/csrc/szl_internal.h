@@ -49,6 +49,9 @@ struct SegDev {
                            // DeflateFast: of its "inserted" bitmap (bit q = buffer position q)
     uint32_t adler_init;   // running Adler32.Value before this segment's bytes (zlib framing)
     uint32_t crc_init;     // running Crc32.Value before this segment's bytes
+    int64_t look_end;      // buffer position one past the last byte the ENGINE HAS SEEN (lookahead, FillWindow :379-394).  Equals
+                           // seg_end except for the windows of a long stream (Engine::deflate_windowed): there seg_end only ends
+                           // the window's parse ranges, while matches and the insert rule look on to the true end of the input.
 };
 enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4, SEG_ZLIB_HEADER = 8, SEG_GZIP = 16 };
 
@@ -57,6 +60,7 @@ struct TileDev { uint32_t seg; uint32_t pad; int64_t start; int32_t len; int32_t
 
 enum : int { B_TILE = 16384, B_HIST = 32512, B_TAIL = 264 };
 enum : int { C_RANGE = 4096 };
+enum : int { C_WIN_HALO = 2048 }; // match-table / link entries kept past a window's parse end (a walk crosses it by < 513 positions)
 
 // Per-range results of stage C
 struct RangeDev {

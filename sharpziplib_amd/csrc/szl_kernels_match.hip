@@ -324,7 +324,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
     const int64_t t0 = tile.start;
     const int tlen = tile.len;
     const int64_t dlo = t0 - B_HIST; // buffer position of LDS data byte 0 (may be negative)
-    const int64_t seg_end = seg.seg_end;
+    const int64_t seg_end = seg.look_end; // lookahead end
 
     // ---- stage the window into LDS
     for (int i = threadIdx.x; i < B_DATA_BYTES / 4; i += B_THREADS) {
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
     const int64_t t0 = tile.start;
     const int tlen = tile.len;
     const int64_t dlo = t0 - B_HIST;
-    const int64_t seg_end = seg.seg_end;
+    const int64_t seg_end = seg.look_end; // lookahead end
 
     for (int i = threadIdx.x; i < B_DATA_BYTES / 4; i += B_THREADS) {
         int64_t pos = dlo + 4 * (int64_t)i;

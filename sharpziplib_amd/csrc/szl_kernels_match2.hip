@@ -171,7 +171,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
     const int64_t t0 = tile.start;
     const int tlen = tile.len;
     const int64_t dlo = t0 - B_HIST; // buffer position of LDS data byte 0 (may be negative)
-    const int64_t seg_end = seg.seg_end;
+    const int64_t seg_end = seg.look_end; // lookahead end
 
     // ---- stage the window into LDS (bytes and links of history + tile)
     for (int i = threadIdx.x; i < B2_DATA_BYTES / 4; i += B2_THREADS) {

@@ -24,7 +24,9 @@ struct ParseCtx {
     const uint16_t *lk;    // links
     const uint32_t *m2;    // M2 (full-budget search from matchLen 2)
     const uint32_t *mq;    // Mq (state after max_chain>>2 candidates); read only when L >= good
-    int64_t seg_end;
+    int64_t seg_end;       // end of the parse ranges
+    int64_t look_end;      // end of the input the engine has seen (lookahead); == seg_end except in the windows of a long stream
+    int64_t tab_end;       // match-table entries exist for positions < tab_end
     int64_t abs0;
     LevelParams P;
 };
@@ -34,7 +36,7 @@ struct ParseCtx {
 // Rare (measured per call in szl_timing.fallback_walks) — walks global memory.
 __device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long long *fallbacks) {
     if (fallbacks) atomicAdd(fallbacks, 1ull);
-    const int64_t rem = c.seg_end - p;
+    const int64_t rem = c.look_end - p;
     uint32_t l0 = c.lk[p];
     if (l0 == 0) return 0;
     const int64_t basem = base_of_c(c.abs0 + p) - c.abs0;
@@ -66,7 +68,7 @@ __device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long
 __device__ void eval_global(const ParseCtx &c, int64_t p, uint32_t &m2, uint32_t &mq, unsigned long long *count) {
     if (count) atomicAdd(count, 1ull);
     m2 = 0; mq = 0;
-    const int64_t rem = c.seg_end - p;
+    const int64_t rem = c.look_end - p;
     if (rem < MIN_MATCH || c.P.strategy == 2) return;       // :780, HuffmanOnly :786
     const uint32_t l0 = c.lk[p];
     if (l0 == 0) return;
@@ -130,7 +132,7 @@ __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, const A &acc, 
         return 0xFFFFFFFFu;
     }
     // lazy evaluation at x: is there a strictly longer match than the one found at x-1 ?
-    const int64_t rem = c.seg_end - x;
+    const int64_t rem = c.look_end - x;
     uint32_t better = 0;
     if (rem >= MIN_MATCH) {
         const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
@@ -178,7 +180,9 @@ __device__ __forceinline__ ParseCtx make_ctx(const uint8_t *in, const uint16_t *
                                              LevelParams P) {
     ParseCtx c;
     c.d = in + s.buf_off; c.lk = link + s.buf_off; c.m2 = mtab.m2 + s.buf_off; c.mq = mtab.mq + s.buf_off;
-    c.seg_end = s.seg_end; c.abs0 = (int64_t)s.abs0; c.P = P;
+    c.seg_end = s.seg_end; c.look_end = s.look_end; c.abs0 = (int64_t)s.abs0; c.P = P;
+    // windows of a long stream keep a short tail of (unset) table entries past their parse end for the walk that crosses it
+    c.tab_end = s.look_end > s.seg_end ? (s.seg_end + (int64_t)C_WIN_HALO < s.look_end ? s.seg_end + (int64_t)C_WIN_HALO : s.look_end) : s.seg_end;
     return c;
 }
 
@@ -509,7 +513,7 @@ template <int W, bool WITH_BYTES>
 __device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool active, int lane, uint32_t *sm2, uint32_t *smq, uint8_t *sb) {
     constexpr int PER = 64 / W;          // windows per load instruction
     constexpr int STRIDE = WinCfg<W>::STRIDE, BSTRIDE = WinCfg<W>::BSTRIDE;
-    const int64_t navail = active ? c.seg_end - x : 0; // entries valid from x on
+    const int64_t navail = active ? c.tab_end - x : 0; // entries valid from x on
     const int64_t pm_l = (int64_t)(c.m2 + x), pq_l = (int64_t)(c.mq + x), pd_l = (int64_t)(c.d + x) - 1;
     const int sub = lane / W, i = lane % W;
     constexpr int BATCH = 8;
