@@ -172,6 +172,11 @@ int szl_debug_set(const char *name, int value);
  * longer than SZL_WINDOW_KIB (default 256 MiB) is processed window by window, so this stays bounded by the window. */
 uint64_t szl_engine_debug_workspace(const szl_engine *e);
 
+/* Parity tap: number of chunk jobs the last szl_inflate_batch_* call decoded single members with (0: every stream went through
+ * the one-wavefront-per-stream decoder).  A member of SZL_INF_PAR_MIN_KIB (default 2048) compressed KiB or more is decoded by
+ * one wavefront per SZL_INF_CHUNK_KIB (default 128) of compressed bytes. */
+uint32_t szl_engine_debug_par_jobs(const szl_engine *e);
+
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);
 

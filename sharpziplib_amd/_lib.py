@@ -64,6 +64,7 @@ def lib():
         "szl_engine_debug_match_mode": (i32, [vp, i32]),
         "szl_debug_set": (i32, [ctypes.c_char_p, i32]),
         "szl_engine_debug_workspace": (u64, [vp]),
+        "szl_engine_debug_par_jobs": (ctypes.c_uint32, [vp]),
         "szl_debug_stored_layout": (i32, [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]),
         "szl_inflater_create": (vp, [i32]), "szl_inflater_destroy": (None, [vp]), "szl_inflater_reset": (i32, [vp]),
         "szl_inflater_set_input": (i32, [vp, vp, i32]), "szl_inflater_set_dictionary": (i32, [vp, vp, i32]),

@@ -268,9 +268,40 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
     int rc;
     if ((rc = e->e.stage_in.ensure(in_total + 64))) return rc;
     if ((rc = e->e.stage_out.ensure(out_total + 64))) return rc;
+    // One long stream that will go through the window pipeline: the input is copied by a second host thread, 32 MiB at a time
+    // on its own stream, while the engine already works on the windows that have arrived (Engine::in_ready).
+    const uint64_t window = (uint64_t)szl::knob("SZL_WINDOW_KIB", 256 * 1024) * 1024;
+    const int lv = level == -1 ? 6 : level;
+    if (n_streams == 1 && lv >= 5 && window >= (uint64_t)B_TILE && streams[0].in_len > window + window / 4 &&
+        streams[0].in_len >= (uint64_t)szl::knob("SZL_WINDOW_FROM_KIB", 2048 * 1024) * 1024 && szl::knob("SZL_H2D_OVERLAP", 1)) {
+        volatile uint64_t ready = 0;
+        int copy_rc = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        std::thread copier([&]() {
+            if (hipSetDevice(dev) != hipSuccess) { copy_rc = SZL_E_DEVICE; ready = in_total; return; }
+            hipStream_t cs = nullptr;
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { copy_rc = SZL_E_DEVICE; ready = in_total; return; }
+            const uint64_t piece = 32ull << 20;
+            for (uint64_t o = 0; o < in_total; o += piece) {
+                const uint64_t k = std::min<uint64_t>(piece, in_total - o);
+                if (hipMemcpyAsync((uint8_t *)e->e.stage_in.p + o, (const uint8_t *)h_in + o, k, hipMemcpyHostToDevice, cs) != hipSuccess ||
+                    hipStreamSynchronize(cs) != hipSuccess) { copy_rc = SZL_E_DEVICE; break; }
+                __atomic_store_n((uint64_t *)&ready, o + k, __ATOMIC_RELEASE);
+            }
+            __atomic_store_n((uint64_t *)&ready, in_total, __ATOMIC_RELEASE); // (also on failure: never leave the engine waiting)
+            (void)hipStreamDestroy(cs);
+        });
+        e->e.in_ready = &ready;
+        rc = szl_deflate_batch_device(e, e->e.stage_in.p, e->e.stage_out.p, streams, n_streams, level, strategy, flags, nullptr);
+        e->e.in_ready = nullptr;
+        copier.join();
+        if (copy_rc) { set_error("H2D failed"); return copy_rc; }
+        if (rc) return rc;
+    } else {
     if (in_total && hipMemcpy(e->e.stage_in.p, h_in, in_total, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
     rc = szl_deflate_batch_device(e, e->e.stage_in.p, e->e.stage_out.p, streams, n_streams, level, strategy, flags, nullptr);
     if (rc) return rc;
+    }
     for (size_t i = 0; i < n_streams; i++) {
         if (streams[i].status) continue;
         if (streams[i].out_len && hipMemcpy((uint8_t *)h_out + streams[i].out_off, (uint8_t *)e->e.stage_out.p + streams[i].out_off,
@@ -385,6 +416,7 @@ int szl_debug_set(const char *name, int value) { return name ? szl::knob_set(nam
 
 // Parity tap: device bytes held by the per-position side arrays (links, match tables, tokens, ...) at the peak of the last call.
 uint64_t szl_engine_debug_workspace(const szl_engine *e) { return e ? e->e.last_workspace_bytes : 0; }
+uint32_t szl_engine_debug_par_jobs(const szl_engine *e) { return e ? e->e.last_par_jobs : 0; }
 
 // Parity tap: block table of the last call. rows of 8 x uint64: type,last,ntok,bit_start,opt_len,static_len,in_len,hdr_bits
 int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows) {

@@ -16,6 +16,10 @@ void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *sta
 void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
+void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st);
+void launch_find_blocks(const uint8_t *in, uint64_t in_len, uint64_t chunk_bytes, uint32_t nchunks, uint64_t *start_bit, hipStream_t st);
+void launch_resolve_wins(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, uint8_t *wins, hipStream_t st);
+void launch_convert(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, const uint8_t *wins, uint8_t *out, uint64_t total, hipStream_t st);
 }
 struct szl_engine { Engine e; };
 
@@ -55,61 +59,233 @@ done:
 }
 } // namespace szl
 
+// ---------------------------------------------------------------------------------------------
+// One member decoded by many wavefronts (SURVEY §7.5 stage 1; kernels in szl_kernels_inflate_par.hip).
+//   1. k_find_blocks: a dynamic block header in every chunk of compressed bytes -> candidate start bits
+//   2. count pass (k_inflate<.,1>): each chunk decodes from its start to the next chunk's start, producing nothing but its
+//      output length; chunk k must END exactly on chunk k+1's start bit — the proof that every start is a real block boundary
+//      (chunk 0 starts at the member's first block, so the chain is anchored).  Starts that are not on the chain are dropped,
+//      a chain end nobody starts at becomes a new start, and the pass is repeated for the changed chunks.
+//   3. symbol pass (k_inflate<.,2>): the same decode into 16-bit symbols at each chunk's final output offset; a back-reference
+//      that reaches in front of the chunk becomes "byte i of the preceding 32 KiB"
+//   4. k_resolve_wins (front to back, 32 KiB per chunk) and k_convert (everything else, in parallel).
+// Returns 1 = decoded (*res filled like a finished sequential job), 0 = not taken (anything unusual: stream errors, truncated
+// input, output too small, no chain) — the caller then runs the ordinary decoder, whose status/partial-output behaviour is
+// the one checked against the reference — or a negative szl_status for device failures.
+struct ParResult { uint64_t out_written, consumed; uint32_t adler_read; };
+
+static int inflate_member_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_out, const szl_stream &s, bool zlib, hipStream_t st, ParResult *res) {
+    const uint64_t chunk_bytes = (uint64_t)std::max(16, knob("SZL_INF_CHUNK_KIB", 128)) * 1024;
+    if (s.in_len < 4 * chunk_bytes || s.in_len >= (1ull << 60)) return 0;
+    const uint8_t *in = d_in + s.in_off;
+    uint64_t first_bit = 0;
+    if (zlib) { // C/Inflater.cs:211-249; a preset dictionary or a bad header is the sequential decoder's business
+        uint8_t h[2];
+        HIPCHK(hipMemcpyAsync(E.pin, in, 2, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+        memcpy(h, E.pin, 2);
+        const uint32_t hv = ((uint32_t)h[0] << 8) | h[1];
+        if (hv % 31 != 0 || (hv & 0x0f00) != (8u << 8) || (hv & 0x0020)) return 0;
+        first_bit = 16;
+    }
+    const uint32_t nchunks = (uint32_t)std::min<uint64_t>((s.in_len + chunk_bytes - 1) / chunk_bytes, 1u << 20);
+    int rc;
+    if ((rc = E.inf_misc.ensure((uint64_t)nchunks * 8 + 64))) return rc;
+    uint64_t *d_start = (uint64_t *)E.inf_misc.p;
+    launch_find_blocks(in, s.in_len, chunk_bytes, nchunks, d_start, st);
+    std::vector<uint64_t> starts(nchunks);
+    HIPCHK(hipMemcpyAsync(starts.data(), d_start, (uint64_t)nchunks * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> sb;            // start bits of the jobs, ascending
+    sb.push_back(first_bit);
+    for (uint32_t c = 1; c < nchunks; c++) if (starts[c] != ~0ull && starts[c] > sb.back()) sb.push_back(starts[c]);
+    if (sb.size() < 4) return 0;
+
+    struct Cnt { uint64_t end_bit, out; int status; };
+    std::vector<InfJob> jobs;
+    std::vector<Cnt> cnt;                // count-pass result per job, keyed like sb
+    std::vector<char> have;
+    auto run_pass = [&](int pass, const std::vector<uint32_t> &which, uint16_t *sym, const std::vector<uint64_t> *ooff) -> int {
+        const uint32_t n = (uint32_t)which.size();
+        jobs.assign(n, InfJob{});
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t j = which[k];
+            InfJob &jb = jobs[k];
+            jb.in_off = 0; jb.in_len = s.in_len; jb.out_cap = ~0ull >> 2;
+            jb.start_bit = sb[j]; jb.stop_bit = j + 1 < sb.size() ? sb[j + 1] : ~0ull;
+            jb.sym_out = sym ? sym + (*ooff)[j] : nullptr;
+        }
+        int r;
+        if ((r = E.inf_jobs.ensure((uint64_t)n * sizeof(InfJob))) || (r = E.inf_states.ensure((uint64_t)n * sizeof(InfState)))) return r;
+        HIPCHK(hipMemcpyAsync(E.inf_jobs.p, jobs.data(), (uint64_t)n * sizeof(InfJob), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(E.inf_states.p, 0, (uint64_t)n * sizeof(InfState), st));
+        launch_inflate_chunks(in, (InfJob *)E.inf_jobs.p, (InfState *)E.inf_states.p, n, pass, st);
+        HIPCHK(hipMemcpyAsync(jobs.data(), E.inf_jobs.p, (uint64_t)n * sizeof(InfJob), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    };
+
+    // ---- count pass + chain repair
+    cnt.assign(sb.size(), Cnt{});
+    have.assign(sb.size(), 0);
+    bool ok = false;
+    for (int iter = 0; iter < 6 && !ok; iter++) {
+        std::vector<uint32_t> which;
+        for (uint32_t j = 0; j < sb.size(); j++) if (!have[j]) which.push_back(j);
+        if (!which.empty()) {
+            if ((rc = run_pass(1, which, nullptr, nullptr))) return rc;
+            for (uint32_t k = 0; k < which.size(); k++) { cnt[which[k]] = Cnt{jobs[k].end_bit, jobs[k].out_written, jobs[k].status}; have[which[k]] = 1; }
+        }
+        // walk the chain from job 0; keep the starts it visits
+        std::vector<uint64_t> nsb; std::vector<Cnt> ncnt; std::vector<char> nhave;
+        uint32_t j = 0;
+        ok = true;
+        for (;;) {
+            nsb.push_back(sb[j]); ncnt.push_back(cnt[j]); nhave.push_back(1);
+            const Cnt &c = cnt[j];
+            if (c.status == INF_FINISHED) break;                   // the member's last block ended inside this job
+            if (c.status != INF_CHUNK_END) return 0;               // an error on the chain is a real error of the stream
+            uint32_t m = j + 1;
+            while (m < sb.size() && sb[m] < c.end_bit) m++;        // starts the real decode ran over: false candidates
+            if (m < sb.size() && sb[m] == c.end_bit) { j = m; continue; }
+            // nobody starts where this job ended: a new job starts there (its stop is the next candidate), counted next round.
+            // The job that ended there ran with a different stop before, but a decode that stops at the first block boundary
+            // >= stop also stops there for any stop in (previous boundary, end_bit] — its count stays valid.
+            ok = false;
+            nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
+            for (; m < sb.size(); m++) { nsb.push_back(sb[m]); ncnt.push_back(cnt[m]); nhave.push_back(have[m]); }
+            break;
+        }
+        if (!ok) {
+            // jobs in front of a changed stop must be recounted unless they ended on the chain already (those are kept above)
+            sb.swap(nsb); cnt.swap(ncnt); have.swap(nhave);
+            continue;
+        }
+        sb.swap(nsb); cnt.swap(ncnt); have.swap(nhave);
+    }
+    if (!ok) return 0;
+    const uint32_t nj = (uint32_t)sb.size();
+    if (cnt[nj - 1].status != INF_FINISHED) return 0;              // truncated member: NEED_INPUT semantics belong to the sequential path
+    std::vector<uint64_t> ooff(nj + 1);
+    uint64_t total = 0;
+    for (uint32_t j = 0; j < nj; j++) { ooff[j] = total; total += cnt[j].out; }
+    ooff[nj] = total;
+    if (total > s.out_cap) return 0;                               // SZL_E_OUTPUT_TOO_SMALL with the bytes that fit: sequential path
+    uint64_t end_byte = (cnt[nj - 1].end_bit + 7) >> 3;
+    uint32_t adler_read = 0;
+    if (zlib) {
+        if (end_byte + 4 > s.in_len) return 0;
+        HIPCHK(hipMemcpyAsync(E.pin, in + end_byte, 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+        adler_read = ((uint32_t)E.pin[0] << 24) | ((uint32_t)E.pin[1] << 16) | ((uint32_t)E.pin[2] << 8) | E.pin[3];
+        end_byte += 4;
+    }
+    // ---- symbol pass, windows, bytes
+    if ((rc = E.inf_sym.ensure(total * 2 + 64)) || (rc = E.inf_wins.ensure((uint64_t)(nj + 1) * 32768)) ||
+        (rc = E.inf_misc.ensure((uint64_t)(nj + 1) * 8))) return rc;
+    std::vector<uint32_t> all(nj);
+    for (uint32_t j = 0; j < nj; j++) all[j] = j;
+    if ((rc = run_pass(2, all, (uint16_t *)E.inf_sym.p, &ooff))) return rc;
+    for (uint32_t j = 0; j < nj; j++)
+        if (jobs[j].end_bit != cnt[j].end_bit || jobs[j].out_written != cnt[j].out) { set_error("parallel inflate: pass 2 disagrees with pass 1 at job %u", j); return SZL_E_STATE; }
+    HIPCHK(hipMemcpyAsync(E.inf_misc.p, ooff.data(), (uint64_t)(nj + 1) * 8, hipMemcpyHostToDevice, st));
+    launch_resolve_wins((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, nj, (uint8_t *)E.inf_wins.p, st);
+    launch_convert((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, nj, (const uint8_t *)E.inf_wins.p, d_out + s.out_off, total, st);
+    HIPCHK(hipStreamSynchronize(st));
+    res->out_written = total; res->consumed = end_byte; res->adler_read = adler_read;
+    E.last_par_jobs = nj;
+    return 1;
+}
+
 extern "C" {
 
-int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n, unsigned flags, void *hip_stream) {
-    if (!e || (!streams && n)) return SZL_E_ARG;
-    if (n == 0) return 0;
-    if (n > 0x7FFFFFFFull) return SZL_E_ARG;
+int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_all, unsigned flags, void *hip_stream) {
+    if (!e || (!streams && n_all)) return SZL_E_ARG;
+    if (n_all == 0) return 0;
+    if (n_all > 0x7FFFFFFFull) return SZL_E_ARG;
     hipStream_t st = (hipStream_t)hip_stream;
     const bool nowrap = flags & SZL_F_NOWRAP;
+    const unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !nowrap) ? 2u : 0u);
+    int rc;
+    for (int i = 0; i < 2; i++) if (!e->e.ev[i]) (void)hipEventCreate(&e->e.ev[i]);
+    if (!e->e.pin && hipHostMalloc((void **)&e->e.pin, 256) != hipSuccess) { set_error("hipHostMalloc failed"); return SZL_E_NOMEM; }
+    e->e.timing.inflate_ms = 0;
+    e->e.last_par_jobs = 0;
+
+    // long members first: each is decoded by many wavefronts (inflate_member_parallel); whatever it does not take joins the batch
+    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", 2048)) * 1024;
+    std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
+    std::vector<char> par_done(n_all, 0);
+    std::vector<ParResult> par_res(n_all);
+    for (size_t i = 0; i < n_all; i++) {
+        if (streams[i].in_len >= par_min) {
+            (void)hipEventRecord(e->e.ev[0], st);
+            rc = inflate_member_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams[i], !nowrap, st, &par_res[i]);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                (void)hipEventRecord(e->e.ev[1], st); (void)hipEventSynchronize(e->e.ev[1]);
+                float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
+                par_done[i] = 1; continue;
+            }
+        }
+        idx.push_back(i);
+    }
+    const size_t n = idx.size();
     std::vector<InfJob> jobs(n);
     std::vector<InfState> states(n);
-    for (size_t i = 0; i < n; i++) {
+    for (size_t k = 0; k < n; k++) {
+        const szl_stream &s = streams[idx[k]];
         InfJob j{};
-        j.in_off = streams[i].in_off; j.in_len = streams[i].in_len; j.out_off = streams[i].out_off; j.out_cap = streams[i].out_cap;
+        j.in_off = s.in_off; j.in_len = s.in_len; j.out_off = s.out_off; j.out_cap = s.out_cap;
         j.window = nullptr; j.zlib = nowrap ? 0 : 1; j.keep_window = 0;
-        jobs[i] = j;
-        InfState s{};
-        s.mode = nowrap ? INF_M_HEADER : INF_M_ZHEADER;
-        states[i] = s;
+        jobs[k] = j;
+        InfState is{};
+        is.mode = nowrap ? INF_M_HEADER : INF_M_ZHEADER;
+        states[k] = is;
     }
-    DevBuf djobs, dstates;
-    int rc;
-    if ((rc = djobs.ensure(n * sizeof(InfJob))) || (rc = dstates.ensure(n * sizeof(InfState)))) { djobs.release(); dstates.release(); return rc; }
-    auto cleanup = [&]() { djobs.release(); dstates.release(); };
-    if (hipMemcpyAsync(djobs.p, jobs.data(), n * sizeof(InfJob), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(dstates.p, states.data(), n * sizeof(InfState), hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); set_error("H2D failed"); return SZL_E_DEVICE; }
-    for (int i = 0; i < 2; i++) if (!e->e.ev[i]) (void)hipEventCreate(&e->e.ev[i]);
-    (void)hipEventRecord(e->e.ev[0], st);
-    launch_inflate((const uint8_t *)d_in, (uint8_t *)d_out, (InfJob *)djobs.p, (InfState *)dstates.p, (uint32_t)n, true, st);
-    (void)hipEventRecord(e->e.ev[1], st);
-    if (hipMemcpyAsync(jobs.data(), djobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(states.data(), dstates.p, n * sizeof(InfState), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { cleanup(); set_error("inflate kernel/D2H failed: %s", hipGetErrorString(hipGetLastError())); return SZL_E_DEVICE; }
-    cleanup();
-    (void)hipEventElapsedTime(&e->e.timing.inflate_ms, e->e.ev[0], e->e.ev[1]);
-    unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !nowrap) ? 2u : 0u);
+    if (n) {
+        DevBuf djobs, dstates;
+        if ((rc = djobs.ensure(n * sizeof(InfJob))) || (rc = dstates.ensure(n * sizeof(InfState)))) { djobs.release(); dstates.release(); return rc; }
+        auto cleanup = [&]() { djobs.release(); dstates.release(); };
+        if (hipMemcpyAsync(djobs.p, jobs.data(), n * sizeof(InfJob), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dstates.p, states.data(), n * sizeof(InfState), hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); set_error("H2D failed"); return SZL_E_DEVICE; }
+        (void)hipEventRecord(e->e.ev[0], st);
+        launch_inflate((const uint8_t *)d_in, (uint8_t *)d_out, (InfJob *)djobs.p, (InfState *)dstates.p, (uint32_t)n, true, st);
+        (void)hipEventRecord(e->e.ev[1], st);
+        if (hipMemcpyAsync(jobs.data(), djobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(states.data(), dstates.p, n * sizeof(InfState), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { cleanup(); set_error("inflate kernel/D2H failed: %s", hipGetErrorString(hipGetLastError())); return SZL_E_DEVICE; }
+        cleanup();
+        float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
+    }
     std::vector<std::pair<uint32_t, uint32_t>> cks;
     if (want) {
-        std::vector<std::pair<uint64_t, uint64_t>> regs(n);
-        for (size_t i = 0; i < n; i++) regs[i] = {jobs[i].out_off, jobs[i].out_written};
+        std::vector<std::pair<uint64_t, uint64_t>> regs(n_all);
+        size_t k = 0;
+        for (size_t i = 0; i < n_all; i++) {
+            if (par_done[i]) regs[i] = {streams[i].out_off, par_res[i].out_written};
+            else { regs[i] = {jobs[k].out_off, jobs[k].out_written}; k++; }
+        }
         if ((rc = region_checksums((const uint8_t *)d_out, regs, want, cks, nullptr, st))) return rc;
     }
-    for (size_t i = 0; i < n; i++) {
+    size_t k = 0;
+    for (size_t i = 0; i < n_all; i++) {
         szl_stream &s = streams[i];
-        s.out_len = jobs[i].out_written;
-        s.in_consumed = jobs[i].consumed;
         s.reserved = 0;
         s.crc32 = want ? cks[i].first : 0; s.adler32 = want ? cks[i].second : 1;
-        int stt = jobs[i].status;
+        if (par_done[i]) {
+            s.out_len = par_res[i].out_written; s.in_consumed = par_res[i].consumed;
+            s.status = (!nowrap && par_res[i].adler_read != cks[i].second) ? SZL_E_ADLER_MISMATCH : 0;
+            continue;
+        }
+        s.out_len = jobs[k].out_written;
+        s.in_consumed = jobs[k].consumed;
+        int stt = jobs[k].status;
         if (stt == INF_FINISHED) {
             s.status = 0;
-            if (!nowrap && states[i].adler_read != cks[i].second) s.status = SZL_E_ADLER_MISMATCH; // C/Inflater.cs:411-414
+            if (!nowrap && states[k].adler_read != cks[i].second) s.status = SZL_E_ADLER_MISMATCH; // C/Inflater.cs:411-414
         } else if (stt == INF_NEED_INPUT) s.status = SZL_E_UNEXPECTED_EOF;
         else if (stt == INF_OUTPUT_FULL) s.status = SZL_E_OUTPUT_TOO_SMALL;
         else if (stt == INF_NEED_DICT) s.status = SZL_E_UNSUPPORTED; // batch call cannot supply a preset dictionary
         else s.status = stt < 0 ? stt : SZL_E_STATE;
+        k++;
     }
     return 0;
 }

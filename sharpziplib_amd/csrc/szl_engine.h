@@ -40,6 +40,8 @@ class Engine {
     // progress of an overlapped host->device copy of the input arena (szl_deflate_batch_host): the engine waits until the bytes a
     // window needs have arrived.  nullptr: everything is resident.
     const volatile uint64_t *in_ready = nullptr;
+    uint8_t *pin = nullptr;            // 256 bytes of pinned host memory: few-byte read-backs into pageable memory cost ~1 ms each
+    uint32_t last_par_jobs = 0;        // chunk jobs of the last parallel single-member inflate
     uint64_t last_workspace_bytes = 0; // device bytes held by the side arrays after the last call (parity tap / DESIGN §3)
 
     // Level 0: write the stored blocks `blks` (host-built) and, if want_ck, the checksums of d_in[ck_off, ck_off+ck_len).
@@ -59,7 +61,8 @@ class Engine {
     bool fast_want_tail = false;
     int64_t fast_tail_start = 0;
     DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
-        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored, spec_tok, d_zoff;
+        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored, spec_tok, d_zoff,
+        inf_sym, inf_wins, inf_jobs, inf_states, inf_misc;   // parallel decode of one member (szl_api_inflate.hip)
     hipEvent_t ev[8];
     // checksum kernels run beside stages A-C on this stream (they only share the input bytes)
     hipStream_t side = nullptr;

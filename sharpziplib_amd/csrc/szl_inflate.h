@@ -6,7 +6,8 @@
 namespace szl {
 
 // status values written by k_inflate (>= 0); negative values are szl_status error codes
-enum : int { INF_RUNNING = 0, INF_FINISHED = 1, INF_NEED_INPUT = 2, INF_OUTPUT_FULL = 3, INF_NEED_DICT = 4 };
+enum : int { INF_RUNNING = 0, INF_FINISHED = 1, INF_NEED_INPUT = 2, INF_OUTPUT_FULL = 3, INF_NEED_DICT = 4,
+             INF_CHUNK_END = 5 /* chunked decode of one member: reached the block boundary at which the next chunk starts */ };
 // decoder modes (the reference's 13 modes collapse to these because a token is decoded atomically)
 enum : uint32_t { INF_M_HEADER = 0, INF_M_STORED = 1, INF_M_HUFF = 2, INF_M_DONE = 3, INF_M_ZHEADER = 4 };
 
@@ -20,6 +21,12 @@ struct InfJob {
     uint32_t keep_window;
     uint32_t load_window; // 1: restore the window even at outpos 0 (preset dictionary)
     uint32_t pad1;
+    // chunked decode of ONE member (szl_api_inflate.hip, inflate_member_parallel): this job decodes the blocks from bit `start_bit`
+    // (a block header) up to the block boundary `stop_bit` (~0: to the end of the stream); `sym_out` receives 16-bit symbols —
+    // a byte, or 0x8000 | i for "byte i of the 32 KiB of output in front of this chunk", unknown until the chunks before are done
+    uint64_t start_bit, stop_bit;
+    uint16_t *sym_out;
+    uint64_t end_bit;    // [out] bit position the decoder stopped at
     // results
     uint64_t out_written;
     uint64_t consumed;   // ceil(bits consumed / 8)  == Inflater.TotalIn at this point

@@ -15,6 +15,7 @@
 // by the 32 KiB window each keeps in LDS.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "szl_internal.h"
 #include "szl_inflate.h"
 
@@ -39,9 +40,9 @@ struct HuffTab {            // canonical code of up to 288 symbols; LSB-first pr
     uint16_t sorted[288];   // symbols ordered by (length, symbol)
 };
 
-template <int WIN>
+template <int WIN, typename WT>
 struct InfLds {
-    uint8_t win[WIN];
+    WT win[WIN];
     uint32_t stage[I_STAGE / 4 + 4];
     uint16_t llut[1 << I_LPB];
     uint16_t dlut[1 << I_DPB];
@@ -115,8 +116,12 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
 }
 
 // (second launch-bound: waves per SIMD the register allocation must allow — LDS admits 10 streams per CU in the short-window form)
-template <bool SHORTWIN>
-__global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
+// PMODE: chunked decode of ONE member (szl_api_inflate.hip, inflate_member_parallel).  0 = ordinary job.  1 = count pass: decode
+// the blocks from job.start_bit up to the block boundary job.stop_bit, produce no bytes, report the output length and the bit
+// position reached.  2 = symbol pass: the same decode, writing 16-bit symbols to job.sym_out — a byte, or 0x8000 | i for
+// "byte i of the 32 KiB in front of this chunk" (what a back-reference reaching before the chunk reads; resolved afterwards).
+template <bool SHORTWIN, int PMODE>
+__global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
     constexpr int WIN = SHORTWIN ? I_WIN_SHORT : I_WIN;
     constexpr uint64_t I_WMASK = WIN - 1;
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
     constexpr uint64_t ROOM = SHORTWIN ? 4096 : (uint64_t)(I_WIN - 300);
     constexpr uint64_t FLUSH_AT = SHORTWIN ? 1024 : 16384;
     constexpr uint32_t ROUND_MAX = SHORTWIN ? 2048 : 64u * MAX_MATCH_I; // output bytes one parallel round may queue
-    __shared__ InfLds<WIN> S;
+    using WT = typename std::conditional<PMODE == 2, uint16_t, uint8_t>::type;
+    __shared__ InfLds<WIN, WT> S;
     const uint32_t ji = blockIdx.x;
     if (ji >= njobs) return;
     const int lane = threadIdx.x;
@@ -136,17 +142,22 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
     const uint64_t in_bits = job.in_len * 8ull;
 
     // ---- load persistent state (wave-uniform scalars via lane 0 reads + broadcast is unnecessary: all lanes read)
-    uint64_t bitpos = st->bitpos, outpos = st->outpos;
-    uint32_t mode = st->mode, lastblk = st->last, stored_left = st->stored_left, btype = st->btype;
+    uint64_t bitpos = PMODE ? job.start_bit : st->bitpos, outpos = PMODE ? 0 : st->outpos;
+    uint32_t mode = PMODE ? (uint32_t)INF_M_HEADER : st->mode, lastblk = PMODE ? 0u : st->last, stored_left = st->stored_left, btype = st->btype;
     uint32_t lnum = st->lnum, dnum = st->dnum;
     const uint32_t pend_len = 0, pend_dist = 0; // a token that does not fit is simply not consumed
     const uint64_t out_start = outpos;             // stream position of out[0] for this call
-    const uint64_t out_limit = outpos + job.out_cap;
+    const uint64_t out_limit = PMODE ? ~0ull >> 1 : outpos + job.out_cap;
     uint64_t flushed = outpos;
     int status = INF_RUNNING;
 
     // window: restore the last 32 KiB of output
-    if (!SHORTWIN && (outpos > 0 || job.load_window) && job.window) {
+    if (PMODE == 2) {
+        // the bytes in front of the chunk are not known yet: window position -j (ring index WIN - j) holds the symbol "byte
+        // 32768 - j of the preceding 32 KiB"
+        for (int i = lane; i < WIN; i += 64) S.win[i] = (WT)(0x8000u | (uint32_t)(32768 - WIN + i));
+    } else if (PMODE == 1) {
+    } else if (!SHORTWIN && (outpos > 0 || job.load_window) && job.window) {
         for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&S.win[i] = *(const uint4 *)&job.window[i];
     } else {
         // A fresh stream starts on the reference's zero-initialised window (CS/OutputWindow.cs:22): a match whose distance
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
         if (!build_tab(S.lens, (int)lnum, &S.lt, S.llut, I_LPB, S.codes, lane)) return false;
         return build_tab(S.lens + lnum, (int)dnum, &S.dt, S.dlut, I_DPB, S.codes, lane);
     };
-    if (status == INF_RUNNING && mode == INF_M_HUFF) {
+    if (PMODE == 0 && status == INF_RUNNING && mode == INF_M_HUFF) {
         if (btype == 2) for (int i = lane; i < 320; i += 64) S.lens[i] = st->lens[i];
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         (void)rebuild_tables(); // a resumed block: these lengths were accepted when its header was read
@@ -204,7 +215,8 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
     };
     auto flush = [&](uint64_t upto) { // copy window bytes [flushed, upto) to HBM
         uint64_t n = upto - flushed;
-        for (uint64_t i = lane; i < n; i += 64) out[flushed - out_start + i] = S.win[(flushed + i) & I_WMASK];
+        if (PMODE == 2) { for (uint64_t i = lane; i < n; i += 64) job.sym_out[flushed + i] = (uint16_t)S.win[(flushed + i) & I_WMASK]; }
+        else if (PMODE == 0) { for (uint64_t i = lane; i < n; i += 64) out[flushed - out_start + i] = (uint8_t)S.win[(flushed + i) & I_WMASK]; }
         flushed = upto;
         if (SHORTWIN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // later far matches read these bytes back
     };
@@ -385,6 +397,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                 }
                 // ---------------- INF_M_HEADER
                 if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
+                if (PMODE && bitpos >= job.stop_bit) { ev = EV_STOP; ea = INF_CHUNK_END; break; } // the next chunk's block starts here
                 if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                 const uint32_t t = (uint32_t)bb & 7;
                 const uint32_t type = t >> 1;
@@ -506,10 +519,11 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
             // history (32768 positions back) that an earlier far-distance match of the same round still has to read.
             uint64_t mm = __ballot(lane < ntok && dist != 0);
             int done_upto = 0; // lanes < done_upto have been applied
+            if (PMODE == 1) mm = 0;   // count pass: only the lengths matter
             while (mm) { // matches in stream order; CS/OutputWindow.cs:63-92: out[p+k] = out[p-dist+(k mod dist)]
                 const int l = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                if (lane >= done_upto && lane < l && dist == 0) S.win[mypos & I_WMASK] = (uint8_t)tok; // literals before this match
+                if (lane >= done_upto && lane < l && dist == 0) S.win[mypos & I_WMASK] = (WT)(uint8_t)tok; // literals before this match
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 const uint32_t t2 = __builtin_amdgcn_readlane(tok, l);
                 const uint32_t off = __builtin_amdgcn_readlane(incl - mylen, l);
@@ -519,8 +533,14 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                     // (one-shot jobs: out_start == 0.)  Bytes before the start of the stream are the zeros of a fresh
                     // OutputWindow — never another stream's output region in front of this one.
                     const int64_t s0 = (int64_t)(p - out_start) - (int64_t)d2;
+                    if (PMODE == 2) { // symbols already flushed to sym_out, or — before the chunk — "byte 32768 + s of the preceding 32 KiB"
+                        for (uint32_t k = lane; k < len; k += 64) {
+                            const int64_t sp = s0 + (int64_t)k;
+                            S.win[(p + k) & I_WMASK] = sp >= 0 ? (WT)__atomic_load_n(job.sym_out + sp, __ATOMIC_RELAXED) : (WT)(0x8000u | (uint32_t)(32768 + sp));
+                        }
+                    } else
                     for (uint32_t k = lane; k < len; k += 64)
-                        S.win[(p + k) & I_WMASK] = s0 + (int64_t)k >= 0 ? __atomic_load_n(out + (s0 + (int64_t)k), __ATOMIC_RELAXED) : (uint8_t)0;
+                        S.win[(p + k) & I_WMASK] = s0 + (int64_t)k >= 0 ? (WT)__atomic_load_n(out + (s0 + (int64_t)k), __ATOMIC_RELAXED) : (WT)0;
                 } else if (d2 >= len) { // no overlap (wave-uniform test): plain copy
                     for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k) & I_WMASK];
                 } else {
@@ -529,7 +549,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 done_upto = l + 1;
             }
-            if (lane >= done_upto && lane < ntok && dist == 0) S.win[mypos & I_WMASK] = (uint8_t)tok; // trailing literals
+            if (PMODE != 1 && lane >= done_upto && lane < ntok && dist == 0) S.win[mypos & I_WMASK] = (WT)(uint8_t)tok; // trailing literals
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             outpos += __builtin_amdgcn_readlane(incl, 63);
         }
@@ -557,7 +577,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
                 uint64_t v = bitpos >> 3;
                 bp = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
             }
-            for (uint64_t i = lane; i < n; i += 64) S.win[(outpos + i) & I_WMASK] = in[bp + i];
+            if (PMODE != 1) for (uint64_t i = lane; i < n; i += 64) S.win[(outpos + i) & I_WMASK] = (WT)in[bp + i];
             outpos += n;
             if (lane == 0) { bitpos += 8 * n; bb = 0; nb = 0; }
             sbase = ~0ull; // force a restage at the new position
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
     stored_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_left);
     lnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)lnum);
     dnum = (uint32_t)__builtin_amdgcn_readfirstlane((int)dnum);
-    if (status == INF_FINISHED && job.zlib) { // Adler-32 trailer (C/Inflater.cs:397-418): align, 4 bytes big-endian
+    if (PMODE == 0 && status == INF_FINISHED && job.zlib) { // Adler-32 trailer (C/Inflater.cs:397-418): align, 4 bytes big-endian
         uint64_t bytepos = (bitpos + 7) >> 3;
         if (bytepos + 4 > job.in_len) { status = INF_NEED_INPUT; mode = INF_M_HEADER; /* lastblk stays set: resumes straight to DONE */ }
         else {
@@ -587,10 +607,10 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
             bitpos = (bytepos + 4) * 8;
         }
     }
-    if (!SHORTWIN && job.window && (status != INF_FINISHED || job.keep_window)) {
+    if (PMODE == 0 && !SHORTWIN && job.window && (status != INF_FINISHED || job.keep_window)) {
         for (int i = lane * 16; i < I_WIN; i += 64 * 16) *(uint4 *)&job.window[i] = *(const uint4 *)&S.win[i];
     }
-    if (btype == 2 && mode == INF_M_HUFF) for (int i = lane; i < 320; i += 64) st->lens[i] = S.lens[i];
+    if (PMODE == 0 && btype == 2 && mode == INF_M_HUFF) for (int i = lane; i < 320; i += 64) st->lens[i] = S.lens[i];
     if (lane == 0) {
         st->bitpos = bitpos; st->outpos = outpos; st->mode = mode; st->last = lastblk; st->stored_left = stored_left;
         st->btype = btype; st->lnum = lnum; st->dnum = dnum; st->pend_len = pend_len; st->pend_dist = pend_dist;
@@ -598,6 +618,7 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
         jobs[ji].out_written = outpos - out_start;
         jobs[ji].status = status;
         jobs[ji].consumed = (bitpos + 7) >> 3;
+        jobs[ji].end_bit = bitpos;
     }
 }
 
@@ -605,8 +626,14 @@ __global__ __launch_bounds__(64, SHORTWIN ? 3 : 1) void k_inflate(const uint8_t 
 void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, bool one_shot, hipStream_t st) {
     static const bool allow_short = !(getenv("SZL_INF_SHORT") && atoi(getenv("SZL_INF_SHORT")) == 0);
     if (!njobs) return;
-    if (one_shot && allow_short) hipLaunchKernelGGL(k_inflate<true>, dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
-    else hipLaunchKernelGGL(k_inflate<false>, dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
+    if (one_shot && allow_short) hipLaunchKernelGGL((k_inflate<true, 0>), dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
+    else hipLaunchKernelGGL((k_inflate<false, 0>), dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
+}
+// chunk jobs of one member: pass 1 (count) or 2 (symbols); `in` = first byte of the member
+void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st) {
+    if (!njobs) return;
+    if (pass == 1) hipLaunchKernelGGL((k_inflate<true, 1>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
+    else hipLaunchKernelGGL((k_inflate<true, 2>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
 }
 
 } // namespace szl

@@ -1,0 +1,189 @@
+// szl_kernels_inflate_par.hip — helpers that let ONE deflate member be inflated by thousands of wavefronts
+// (SURVEY §7.5 stage 1 / §8e "single-member gzip": the pugz / rapidgzip two-pass shape).
+//
+// Reference being restated: the decode itself is C/Inflater.cs:283-552 as in szl_kernels_inflate.hip (k_inflate's chunk modes);
+// what is new here has no counterpart in the reference, which decodes a member strictly front to back:
+//   k_find_blocks   for every chunk of compressed bytes, the first bit offset at which a complete, valid DYNAMIC block header
+//                   parses (C/InflaterDynHeader.cs:42-120 with strict completeness checks) — a place to start decoding from;
+//   k_resolve_wins  front to back over the chunks: the last 32 KiB of output of each chunk with its "byte i of the preceding
+//                   32 KiB" symbols replaced — the window (CS/OutputWindow.cs) the next chunk's back-references read;
+//   k_convert       all symbols -> bytes.
+// A wrong guess of k_find_blocks cannot produce wrong output: the count pass must end every chunk exactly on the next chunk's
+// start bit, otherwise the member is decoded by the ordinary single-wavefront path.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "szl_internal.h"
+#include "szl_inflate.h"
+
+namespace szl {
+
+__constant__ uint8_t c_meta_order2[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; // C/InflaterDynHeader.cs:23-24
+
+// 64 stream bits starting at bit position bp (LSB-first), zero beyond the end of the input
+__device__ __forceinline__ uint64_t bits_at(const uint8_t *in, uint64_t in_len, uint64_t bp) {
+    const uint64_t b = bp >> 3;
+    uint64_t v = 0;
+    if (b + 9 <= in_len) {
+        uint64_t lo; uint8_t hi;
+        __builtin_memcpy(&lo, in + b, 8);
+        hi = in[b + 8];
+        const uint32_t sh = (uint32_t)(bp & 7);
+        v = sh ? (lo >> sh) | ((uint64_t)hi << (64 - sh)) : lo;
+    } else {
+        for (int k = 0; k < 9; k++) {
+            const uint64_t by = b + k < in_len ? in[b + k] : 0;
+            const int pos = 8 * k - (int)(bp & 7);
+            if (pos >= 0 && pos < 64) v |= by << pos;
+            else if (pos < 0) v |= by >> (-pos);
+        }
+    }
+    return v;
+}
+
+// Full parse of a dynamic block header at bit position p (one lane).  True iff it is complete and consistent.
+__device__ bool header_ok(const uint8_t *in, uint64_t in_len, uint64_t p, uint8_t *lens /* 320 */, uint16_t *mlut /* 128 */) {
+    uint64_t bp = p;
+    uint64_t w = bits_at(in, in_len, bp);
+    if ((w & 7) != 4) return false;                               // BFINAL = 0, BTYPE = 2 (the final block is left to its predecessor's decode)
+    const uint32_t nl = (uint32_t)((w >> 3) & 31) + 257, nd = (uint32_t)((w >> 8) & 31) + 1, nm = (uint32_t)((w >> 13) & 15) + 4;
+    if (nl > 286 || nd > 30) return false;                        // :50-52
+    bp += 17;
+    uint8_t ml[19];
+    for (int i = 0; i < 19; i++) ml[i] = 0;
+    w = bits_at(in, in_len, bp);
+    int kraft = 0;
+    for (uint32_t i = 0; i < nm; i++) { const uint32_t l = (uint32_t)(w >> (3 * i)) & 7; ml[c_meta_order2[i]] = (uint8_t)l; if (l) kraft += 128 >> l; }
+    if (kraft != 128) return false;                               // a complete code-length code (what every encoder writes)
+    bp += 3 * nm;
+    if (bp + 64 > in_len * 8) return false;
+    for (int i = 0; i < 128; i++) mlut[i] = 0;
+    int code = 0;
+    for (int l = 1; l < 8; l++) {
+        for (int i = 0; i < 19; i++) {
+            if (ml[i] != l) continue;
+            const uint32_t rev = (__builtin_bitreverse32((uint32_t)code++) >> (32 - l)) & ((1u << l) - 1);
+            for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint16_t)((i << 4) | l);
+        }
+        code <<= 1;
+    }
+    uint32_t idx = 0;
+    const uint32_t total = nl + nd;
+    int kl = 0, kd = 0, ndist = 0;                                // Kraft sums in units of 2^-15
+    while (idx < total) {
+        if (bp + 16 > in_len * 8) return false;
+        w = bits_at(in, in_len, bp);
+        const uint32_t e = mlut[(uint32_t)w & 127];
+        if (e == 0) return false;
+        const uint32_t sl = e & 15, sym = e >> 4;
+        bp += sl; w >>= sl;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) { if (idx == 0) return false; val = lens[idx - 1]; rep = 3 + ((uint32_t)w & 3); bp += 2; }        // :83
+        else if (sym == 17) { val = 0; rep = 3 + ((uint32_t)w & 7); bp += 3; }
+        else if (sym == 18) { val = 0; rep = 11 + ((uint32_t)w & 127); bp += 7; }
+        if (idx + rep > total) return false;                       // :106
+        for (uint32_t r = 0; r < rep; r++, idx++) {
+            lens[idx] = (uint8_t)val;
+            if (val) { if (idx < nl) kl += 32768 >> val; else { kd += 32768 >> val; ndist++; } }
+        }
+        if (kl > 32768 || kd > 32768) return false;               // over-subscribed
+    }
+    if (lens[256] == 0) return false;                              // :113
+    if (kl != 32768) return false;                                 // complete literal/length code
+    if (!(kd == 32768 || ndist <= 1)) return false;               // complete distance code, or the one-code / no-code tree of zlib
+    return true;
+}
+
+// One wavefront per chunk c >= 1: first valid dynamic header at a bit offset in [c*chunk_bytes*8, (c+1)*chunk_bytes*8).
+__global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ in, uint64_t in_len, uint64_t chunk_bytes, uint32_t nchunks,
+                                                    uint64_t *__restrict__ start_bit) {
+    __shared__ uint8_t s_lens[320];
+    __shared__ uint16_t s_mlut[128];
+    const uint32_t c = blockIdx.x + 1;
+    if (c >= nchunks) return;
+    const int lane = threadIdx.x;
+    const uint64_t lo = (uint64_t)c * chunk_bytes * 8;
+    uint64_t hi = lo + chunk_bytes * 8;
+    if (hi + 128 > in_len * 8) hi = in_len * 8 > 128 ? in_len * 8 - 128 : 0;
+    uint64_t found = ~0ull;
+    for (uint64_t base = lo; base < hi && found == ~0ull; base += 64) {
+        const uint64_t p = base + lane;
+        bool cand = false;
+        if (p < hi) {
+            const uint64_t w = bits_at(in, in_len, p);
+            if ((w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29) {
+                const uint32_t nm = (uint32_t)((w >> 13) & 15) + 4;
+                const uint64_t m = bits_at(in, in_len, p + 17);
+                int kraft = 0;
+                for (uint32_t i = 0; i < nm; i++) { const uint32_t l = (uint32_t)(m >> (3 * i)) & 7; if (l) kraft += 128 >> l; }
+                cand = kraft == 128;
+            }
+        }
+        uint64_t mm = __ballot(cand);
+        while (mm) {                                               // candidates in bit order; the full parse runs on one lane
+            const int l = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            int ok = 0;
+            if (lane == 0) ok = header_ok(in, in_len, base + (uint64_t)l, s_lens, s_mlut) ? 1 : 0;
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            if (ok) { found = base + (uint64_t)l; break; }
+        }
+    }
+    if (lane == 0) start_bit[c] = found;
+}
+
+// Front to back over the jobs: W_j = the 32 KiB of output that end where job j's output ends, as bytes.
+// wins[(j + 1) * 32768 ..] = W_j ; wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).
+__global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ out_off /* njobs + 1 */,
+                                                       uint32_t njobs, uint8_t *__restrict__ wins) {
+    __shared__ uint8_t s_w[2][32768];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 32768; i += 1024) { s_w[0][i] = 0; wins[i] = 0; }
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t j = 0; j < njobs; j++) {
+        const uint64_t o0 = out_off[j], o1 = out_off[j + 1];
+        const uint64_t len = o1 - o0;
+        const uint8_t *prev = s_w[cur];
+        uint8_t *next = s_w[cur ^ 1];
+        uint8_t *dst = wins + (uint64_t)(j + 1) * 32768;
+        for (int t = tid; t < 32768; t += 1024) {
+            uint8_t b;
+            if ((uint64_t)(32768 - t) <= len) {                    // position o1 - 32768 + t lies inside job j's output
+                const uint32_t sv = sym[o1 - 32768 + (uint64_t)t];
+                b = sv < 0x8000u ? (uint8_t)sv : prev[sv & 0x7FFF];
+            } else b = prev[(uint64_t)t + len];                    // still the previous window, shifted by this job's output
+            next[t] = b;
+            dst[t] = b;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// symbols -> bytes; one workgroup per 16 KiB of output
+__global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ out_off, uint32_t njobs,
+                                                 const uint8_t *__restrict__ wins, uint8_t *__restrict__ out, uint64_t total) {
+    const uint64_t b0 = (uint64_t)blockIdx.x * 16384;
+    if (b0 >= total) return;
+    const uint64_t b1 = b0 + 16384 < total ? b0 + 16384 : total;
+    uint32_t lo = 0, hi = njobs;                                   // last job with out_off <= b0
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (out_off[mid] <= b0) lo = mid; else hi = mid; }
+    uint32_t j = lo;
+    for (uint64_t q = b0 + threadIdx.x; q < b1; q += 256) {
+        while (j + 1 < njobs && out_off[j + 1] <= q) j++;
+        const uint32_t sv = sym[q];
+        out[q] = sv < 0x8000u ? (uint8_t)sv : wins[(uint64_t)j * 32768 + (sv & 0x7FFF)];   // window in front of job j = W_{j-1}
+    }
+}
+
+void launch_find_blocks(const uint8_t *in, uint64_t in_len, uint64_t chunk_bytes, uint32_t nchunks, uint64_t *start_bit, hipStream_t st) {
+    if (nchunks > 1) hipLaunchKernelGGL(k_find_blocks, dim3(nchunks - 1), dim3(64), 0, st, in, in_len, chunk_bytes, nchunks, start_bit);
+}
+void launch_resolve_wins(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, uint8_t *wins, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve_wins, dim3(1), dim3(1024), 0, st, sym, out_off, njobs, wins);
+}
+void launch_convert(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, const uint8_t *wins, uint8_t *out, uint64_t total, hipStream_t st) {
+    if (total) hipLaunchKernelGGL(k_convert, dim3((unsigned)((total + 16383) / 16384)), dim3(256), 0, st, sym, out_off, njobs, wins, out, total);
+}
+
+} // namespace szl

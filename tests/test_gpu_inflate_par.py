@@ -1,0 +1,172 @@
+"""One deflate member decoded by many wavefronts (run with -m gpu): szl_inflate_batch_* on members of SZL_INF_PAR_MIN_KIB or more.
+
+The parallel decode (csrc/szl_kernels_inflate_par.hip + inflate_member_parallel in csrc/szl_api_inflate.hip) must be
+indistinguishable from the one-wavefront decoder, which is the path checked against the oracle (test_gpu_inflate*.py):
+same bytes, same in_consumed, same checksums — and for anything unusual (corrupt, truncated, output too small) it must step
+aside, so the status and partial output are the sequential decoder's.  Reference behaviour: C/Inflater.cs:283-552.
+The knobs shrink the chunks so that a few MiB already give hundreds of chunk boundaries of every kind.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from sharpziplib_amd import corpus as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    e = Engine()
+    yield e
+    for k, v in (("SZL_INF_CHUNK_KIB", 128), ("SZL_INF_PAR_MIN_KIB", 2048)):
+        _lib.lib().szl_debug_set(k.encode(), v)
+    e.close()
+
+
+def _knobs(chunk_kib, min_kib):
+    from sharpziplib_amd import _lib
+    _lib.lib().szl_debug_set(b"SZL_INF_CHUNK_KIB", chunk_kib)
+    _lib.lib().szl_debug_set(b"SZL_INF_PAR_MIN_KIB", min_kib)
+
+
+def _par_jobs(eng):
+    from sharpziplib_amd import _lib
+    return int(_lib.lib().szl_engine_debug_par_jobs(eng._h))
+
+
+def _both(eng, stream, cap, nowrap=True, chunk_kib=16):
+    """(parallel result, sequential result, chunk jobs used)"""
+    _knobs(chunk_kib, 64)
+    rp = eng.inflate([stream], [cap], nowrap=nowrap, crc32=True)[0]
+    jobs = _par_jobs(eng)
+    _knobs(chunk_kib, 1 << 22)                     # nothing is long enough: the one-wavefront decoder
+    rs = eng.inflate([stream], [cap], nowrap=nowrap, crc32=True)[0]
+    assert _par_jobs(eng) == 0
+    return rp, rs, jobs
+
+
+def _same(rp, rs):
+    (a, ca), (b, cb) = rp, rs
+    assert a.status == b.status and ca == cb and a.crc32 == b.crc32 and a.adler32 == b.adler32
+    assert a.data == b.data
+
+
+@pytest.mark.parametrize("kind,level", [("enwik", 6), ("dickens", 9), ("logs", 6), ("logs", 3), ("enwik", 1)])
+def test_member_bit_exact(eng, kind, level):
+    data = C.generate(kind, 31, 0, 6 << 20)
+    stream = O.deflate(data, level)                 # the reference's own blocks (one per 16 383 tokens at most)
+    rp, rs, jobs = _both(eng, stream, data.size)
+    assert jobs >= 8, jobs
+    _same(rp, rs)
+    assert rp[0].status == 0 and rp[0].data == data.tobytes() and rp[1] == len(stream)
+    assert rp[0].crc32 == zlib.crc32(data.tobytes())
+
+
+def test_zeros_and_long_runs(eng):
+    """distance-1 runs across chunk boundaries: the overlapping copy must carry the 'byte before the chunk' symbol along"""
+    parts = []
+    for i in range(24):
+        parts.append(np.full(1 << 20, i & 1 and 0x41, np.uint8))
+        parts.append(C.generate("enwik", 300 + i, 0, 150000))
+        parts.append(C.period10(40000) if hasattr(C, "period10") else np.zeros(40000, np.uint8))
+    z = np.concatenate(parts)
+    stream = O.deflate(z, 6)
+    rp, rs, jobs = _both(eng, stream, z.size)
+    assert jobs >= 8
+    _same(rp, rs)
+    assert rp[0].status == 0 and rp[0].data == z.tobytes()
+
+
+def test_stored_and_flush_blocks(eng):
+    """stored blocks (incompressible stretches), empty stored blocks of sync/full flushes, static blocks — as zlib writes them"""
+    rng = np.random.default_rng(5)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts, raw = [], []
+    for i in range(40):
+        if i % 5 == 3:
+            d = C.random_bytes(int(rng.integers(20000, 200000)), seed=100 + i).tobytes()
+        else:
+            d = C.generate(("enwik", "logs", "dickens")[i % 3], 200 + i, 0, int(rng.integers(50000, 400000))).tobytes()
+        raw.append(d)
+        parts.append(co.compress(d))
+        parts.append(co.flush(zlib.Z_SYNC_FLUSH if i % 2 else zlib.Z_FULL_FLUSH))
+    parts.append(co.flush())
+    stream, data = b"".join(parts), b"".join(raw)
+    rp, rs, jobs = _both(eng, stream, len(data))
+    assert jobs >= 8
+    _same(rp, rs)
+    assert rp[0].status == 0 and rp[0].data == data and rp[1] == len(stream)
+
+
+def test_zlib_framing_and_adler(eng):
+    data = C.generate("enwik", 77, 0, 5 << 20).tobytes()
+    stream = zlib.compress(data, 6)
+    rp, rs, jobs = _both(eng, stream, len(data), nowrap=False)
+    assert jobs >= 8
+    _same(rp, rs)
+    assert rp[0].status == 0 and rp[0].data == data and rp[0].adler32 == zlib.adler32(data) and rp[1] == len(stream)
+    bad = bytearray(stream); bad[-1] ^= 1           # wrong Adler-32 in the trailer (C/Inflater.cs:411-414)
+    rp, rs, jobs = _both(eng, bytes(bad), len(data), nowrap=False)
+    _same(rp, rs)
+    assert rp[0].status == -26 or rp[0].status < 0
+
+
+def test_static_only_member_steps_aside(eng):
+    """no dynamic block header anywhere -> no chunk starts -> the ordinary decoder"""
+    data = C.generate("logs", 9, 0, 3 << 20).tobytes()
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+    stream = co.compress(data) + co.flush()
+    rp, rs, jobs = _both(eng, stream, len(data))
+    assert jobs == 0
+    _same(rp, rs)
+    assert rp[0].data == data
+
+
+def test_errors_are_the_sequential_decoders(eng):
+    data = C.generate("enwik", 41, 0, 4 << 20)
+    stream = np.frombuffer(O.deflate(data, 6), np.uint8)
+    rng = np.random.default_rng(8)
+    cases = [("truncated", stream[:stream.size * 2 // 3].tobytes(), data.size), ("cap_too_small", stream.tobytes(), data.size - 100000)]
+    for k in range(10):
+        pos = int(rng.integers(stream.size // 8, stream.size)) * 8 + int(rng.integers(0, 8))
+        m = stream.copy(); m[pos >> 3] ^= 1 << (pos & 7)
+        cases.append(("flip@%d" % pos, m.tobytes(), data.size + 65536))
+    for name, s, cap in cases:
+        rp, rs, jobs = _both(eng, s, cap)
+        try:
+            _same(rp, rs)
+        except AssertionError:
+            raise AssertionError(name)
+
+
+def test_mixed_batch(eng):
+    """a long member between short streams in one call"""
+    big = C.generate("enwik", 51, 0, 5 << 20)
+    smalls = [C.generate("dickens", 60 + i, 0, 30000 + 1000 * i) for i in range(6)]
+    streams = [O.deflate(smalls[0], 6), O.deflate(big, 6)] + [O.deflate(s, 6) for s in smalls[1:]]
+    want = [smalls[0], big] + smalls[1:]
+    _knobs(16, 64)
+    res = eng.inflate(streams, [w.size for w in want], crc32=True)
+    assert _par_jobs(eng) >= 8
+    for (r, consumed), s, w in zip(res, streams, want):
+        assert r.status == 0 and r.data == w.tobytes() and consumed == len(s) and r.crc32 == zlib.crc32(w.tobytes())
+
+
+def test_default_knobs_256mib_member(eng):
+    """library defaults on a member of the size they are meant for; the device's own level-6 stream"""
+    from sharpziplib_amd import _lib
+    _knobs(128, 2048)
+    data = C.generate("enwik", 0xE9, 0, 256 << 20)
+    comp = eng.deflate([data], level=6, crc32=True)[0]
+    assert comp.status == 0
+    (r, consumed), = eng.inflate([comp.data], [data.size], crc32=True)
+    assert _par_jobs(eng) >= 256
+    assert r.status == 0 and consumed == len(comp.data) and r.crc32 == comp.crc32
+    assert r.data == data.tobytes()
+    ms = eng.timing()["inflate_ms"]
+    print("parallel inflate of a 256 MiB member: %.2f ms = %.0f MiB/s (%d chunk jobs)" % (ms, 256e3 / ms, _par_jobs(eng)))

@@ -20,8 +20,10 @@ def small_windows():
 
     def set_kib(k):
         L.szl_debug_set(b"SZL_WINDOW_KIB", k)
+        L.szl_debug_set(b"SZL_WINDOW_FROM_KIB", 0)
     yield set_kib
     L.szl_debug_set(b"SZL_WINDOW_KIB", 256 * 1024)
+    L.szl_debug_set(b"SZL_WINDOW_FROM_KIB", 2048 * 1024)
 
 
 CASES = {
@@ -117,6 +119,7 @@ def test_default_window_bounds_the_workspace_of_a_long_stream():
     from sharpziplib_amd.batch import Engine
     data = C.generate("enwik", 0xE9, 0, 600 << 20)
     eng = Engine()
+    eng._L.szl_debug_set(b"SZL_WINDOW_FROM_KIB", 0)
     try:
         r = eng.deflate([data], level=6, crc32=True)[0]
         ws = eng._L.szl_engine_debug_workspace(eng._h)
@@ -128,4 +131,5 @@ def test_default_window_bounds_the_workspace_of_a_long_stream():
         # 5.6 GiB here and about the same for a stream ten times longer (an unwindowed call would hold 19 B per stream byte = 11 GiB)
         assert ws < (7 << 30)
     finally:
+        eng._L.szl_debug_set(b"SZL_WINDOW_FROM_KIB", 2048 * 1024)
         eng.close()
