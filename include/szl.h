@@ -165,7 +165,7 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
 int szl_engine_debug_match_mode(szl_engine *e, int mode);
 
 /* Experiment / parity knob: sets a named tuning value for this process (the same names are read from the environment as a
- * fallback): SZL_MATCH_KERNEL, SZL_NCTX, SZL_FTH2, SZL_VTH2, SZL_QKEEP, SZL_VKEEP, SZL_DEBUG, ...  Results never depend on them. */
+ * fallback): SZL_MATCH_KERNEL, SZL_NCTX, SZL_FTH2, SZL_VTH2, SZL_QKEEP, SZL_VKEEP, SZL_DEBUG, ...  Results never depend on them.  value INT_MIN forgets the name again. */
 int szl_debug_set(const char *name, int value);
 
 /* Parity tap: device bytes held by the engine's per-position side arrays at the peak of the last deflate call.  A single stream

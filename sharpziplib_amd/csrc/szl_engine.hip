@@ -61,8 +61,12 @@ int zero_piece_bytes();
 struct Knob { char name[32]; int value; };
 static Knob g_knobs[32];
 static int g_nknobs = 0;
-int knob_set(const char *name, int value) {
-    for (int i = 0; i < g_nknobs; i++) if (!strcmp(g_knobs[i].name, name)) { g_knobs[i].value = value; return 0; }
+int knob_set(const char *name, int value) {   // value INT_MIN: forget the name (environment / default apply again)
+    for (int i = 0; i < g_nknobs; i++) if (!strcmp(g_knobs[i].name, name)) {
+        if (value == INT32_MIN) { g_knobs[i] = g_knobs[g_nknobs - 1]; g_nknobs--; } else g_knobs[i].value = value;
+        return 0;
+    }
+    if (value == INT32_MIN) return 0;
     if (g_nknobs >= 32 || strlen(name) >= sizeof g_knobs[0].name) return SZL_E_ARG;
     strcpy(g_knobs[g_nknobs].name, name); g_knobs[g_nknobs].value = value; g_nknobs++;
     return 0;
@@ -385,10 +389,13 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     timing.fallback_walks = hc[1];
     last_evaluated = hc[6]; last_eval_fallbacks = hc[7]; last_lazy = lazy;
     if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
-    if (knob("SZL_DEBUG", 0) && hc[9]) // k_match2: per-phase visits, wave-steps and the lanes that took part (64 = full)
-        fprintf(stderr, "[szl] match2: quick visits %llu steps %llu lanes/step %.1f | verify visits %llu steps %llu lanes/step %.1f | fetch visits %llu lanes/visit %.1f | swaps %llu lanes/swap %.1f | per position: quick wave-steps %.3f verify %.3f fetch %.3f swaps %.3f\n",
-                hc[8], hc[9], (double)hc[10] / hc[9], hc[11], hc[12], hc[12] ? (double)hc[13] / hc[12] : 0.0, hc[14], hc[14] ? (double)hc[15] / hc[14] : 0.0, hc[16],
-                hc[16] ? (double)hc[17] / hc[16] : 0.0, (double)hc[9] / seg_bytes, (double)hc[12] / seg_bytes, (double)hc[14] / seg_bytes, (double)hc[16] / seg_bytes);
+    if (knob("SZL_DEBUG", 0) && hc[16]) { // k_match4 (two-context engine): loop iterations of each phase and the contexts (of 128) that took part
+        const double np = (double)seg_bytes;
+        fprintf(stderr, "[szl] match4: engine calls %llu | fetch visits %llu lanes/visit %.1f | QUICK iterations %llu contexts/iter %.1f (x2 steps) | VERIFY iterations %llu contexts/iter %.1f | "
+                        "COMPLETE passes %llu contexts/pass %.1f | per position: quick ctx-steps %.2f verify ctx-steps %.2f completes %.2f\n",
+                hc[8], hc[14], hc[14] ? (double)hc[15] / hc[14] : 0.0, hc[16], (double)hc[17] / hc[16], hc[18], hc[18] ? (double)hc[19] / hc[18] : 0.0,
+                hc[20], hc[20] ? (double)hc[21] / hc[20] : 0.0, 2.0 * hc[17] / np, hc[19] / np, hc[21] / np);
+    }
     if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] stage B %s (pilot fraction %.3f): %llu of %llu positions evaluated by walkers, %llu by the parse (eval_global), slow walks %llu, unmerged %llu\n", lazy ? "on demand" : "full", last_pilot_frac, hc[6], (unsigned long long)seg_bytes, hc[7], hc[1], hc[0]);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }
     last_nranges = nranges; last_in_total = in_total; last_blk_slots = blk_slots;

@@ -809,7 +809,7 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     // SZL_MATCH_KERNEL: 2 = two positions in flight per lane (szl_kernels_match2.hip, default), 1 = k_match below
     const int which = knob("SZL_MATCH_KERNEL", 2);
-    if (which == 2) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
+    if (which == 2 || which == 3) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // 3 = run-ahead engine (k_match5)
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;

@@ -33,8 +33,12 @@ ref_sha = None
 if a.oracle:
     import oracle_ffi as O
     t = time.time(); ref_sha = hashlib.sha256(O.deflate(host, a.level)).hexdigest(); print("oracle %.1fs" % (time.time() - t), flush=True)
+seen = set()
 for cfg in (a.cfgs or ["SZL_MATCH_KERNEL=2"]):
     kv = dict(x.split("=") for x in cfg.split(","))
+    for k in seen - set(kv):                       # knobs are sticky in the library: forget what this configuration does not name
+        L.szl_debug_set(k.encode(), -2147483648)
+    seen |= set(kv)
     for k, v in kv.items():
         L.szl_debug_set(k.encode(), int(v))
     L.szl_debug_set(b"SZL_DEBUG", 1 if a.debug else 0)
