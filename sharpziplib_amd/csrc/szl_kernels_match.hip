@@ -292,6 +292,179 @@ __global__ __launch_bounds__(A_THREADS) void k_links2(const uint8_t *__restrict_
 }
 
 // ============================================================================================
+// Stage A, pipelined form (default).  k_links2 spends ~12 wave instructions per position on bucketing a chunk by owner
+// wavefront (16 ballots per slice, a 256-entry scan, a scatter, two workgroup barriers per 1024 positions) so that table
+// updates need no ordering between wavefronts.  Here the order is kept instead: the head table is ONE 32768-entry array
+// of 32-bit positions in LDS (no ageing: a span is far shorter than 2^32), the span is cut into 64-position slices, four
+// slices form a group, group t belongs to wavefront t mod 16, and an LDS ticket passes from group to group.  Loading and
+// hashing the slices and computing / storing the links happen outside the ticket; the holder issues one
+// ds_wrxchg_rtn_b32 per slice — "old = head[h]; head[h] = position" for 64 positions at once — and passes the ticket on
+// (LDS executes a wavefront's instructions in order, so the next holder sees the updates).
+// Positions of one slice that share a bucket need no special care IF the LDS unit serves the lanes of one exchange
+// instruction in ascending lane order: each lane then receives the position of the previous lane with its bucket, and the
+// highest lane's position stays in the table — InsertString (C/DeflaterEngine.cs:404-424) executed 64 times in order.
+// That order is a property of the hardware, not of the ISA manual, so k_probe_xchg_order checks it once per device
+// (all-equal, paired, random and strided bucket patterns); launch_links falls back to k_links2 if the probe ever fails.
+// Same results as k_links/k_links2: link = distance to the previous position with the same hash, 0 when there is none
+// within 32767 or the position is not inserted (:780,:817).
+// ============================================================================================
+enum : int { A3_HEAD_BYTES = 32768 * 4, A3_LDS_BYTES = A3_HEAD_BYTES + 16 };
+enum : int { A3_U = 4 };   // 64-position slices per ticket: a ticket covers 256 positions
+
+typedef __attribute__((address_space(3))) uint8_t a3_lds_u8;
+
+// One wavefront, `rounds` patterns: lane l exchanges (l + 1) into slot[pat(l)]; ok unless some lane got something else than
+// "the lane below with my slot" or a slot does not end up holding its highest lane.
+__global__ __launch_bounds__(64) void k_probe_xchg_order(int rounds, int *ok_out) {
+    __shared__ uint32_t slot[64];
+    const int lane = threadIdx.x;
+    const uint32_t base = (uint32_t)(uintptr_t)(a3_lds_u8 *)slot;
+    int ok = 1;
+    uint32_t rng = 0x9E3779B9u * (uint32_t)(lane + 1);
+    for (int r = 0; r < rounds; r++) {
+        slot[lane] = 0;
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        rng = rng * 1664525u + 1013904223u;
+        uint32_t h;
+        switch (r & 7) {
+            case 0: h = 0; break;                                  // every lane the same slot
+            case 1: h = (uint32_t)lane >> 1; break;                // neighbours in pairs
+            case 2: h = (uint32_t)lane & 1; break;                 // two interleaved chains
+            case 3: h = (uint32_t)lane & 7; break;
+            case 4: h = (uint32_t)(63 - lane) >> 2; break;
+            case 5: h = (rng >> 16) & 3; break;
+            case 6: h = (rng >> 16) & 15; break;
+            default: h = (rng >> 16) & 63; break;
+        }
+        uint32_t got;
+        const uint32_t addr = base + 4u * h, mine = (uint32_t)lane + 1u;
+        asm volatile("ds_wrxchg_rtn_b32 %[g], %[a], %[m]\n\ts_waitcnt lgkmcnt(0)\n\t" : [g] "=&v"(got) : [a] "v"(addr), [m] "v"(mine) : "memory");
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        uint32_t want = 0, last = 0;
+        for (int l = 0; l < 64; l++) {
+            const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, l);
+            if (hl == h) { if (l < lane) want = (uint32_t)l + 1u; last = (uint32_t)l + 1u; }
+        }
+        if (got != want || slot[h] != last) ok = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int all = __builtin_popcountll(__ballot(ok != 0)) == 64;
+    if (lane == 0) *ok_out = all;
+}
+
+__global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                      const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
+                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem3[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // LDS byte addresses for the hand-written part (the compiler turns volatile accesses through generic pointers into
+    // FLAT instructions followed by s_waitcnt vmcnt(0), which is exactly what the ticket chain cannot afford)
+    const uint32_t head_a = (uint32_t)(uintptr_t)(a3_lds_u8 *)smem3;
+    const uint32_t turn_a = head_a + A3_HEAD_BYTES;
+    const SpanDev span = spans[blockIdx.x];
+    const SegDev seg = segs[span.seg];
+    const uint8_t *d = in + seg.buf_off;
+    uint16_t *lk = link + seg.buf_off;
+    const int64_t warm0 = span.start - WSIZE > 0 ? span.start - WSIZE : 0;
+    const uint64_t avail = in_total - seg.buf_off;
+
+    {   // every bucket starts "far away": q - head > 32767 for every q of the span
+        const uint32_t far = (uint32_t)(warm0 - 40000);
+        uint4 *h4 = (uint4 *)smem3;
+        for (int i = threadIdx.x; i < 32768 / 4; i += A_THREADS) h4[i] = make_uint4(far, far, far, far);
+        if (threadIdx.x == 0) *(int *)(smem3 + A3_HEAD_BYTES) = 0;
+    }
+    __syncthreads();
+
+    const uint64_t *b = bnds + seg.bnd_off;
+    const int nb = (int)seg.bnd_cnt;
+    int bi = 0;
+    int64_t bcur = bi < nb ? (int64_t)b[bi] : INT64_MAX;
+    const int64_t ngr = (span.end - warm0 + 64 * A3_U - 1) / (64 * A3_U);
+    auto fetch = [&](int64_t qn) -> uint32_t { return (qn < span.end && (uint64_t)qn + 4 <= avail) ? load_u32_unaligned(d + qn) : 0u; };
+    uint32_t wnext[A3_U];
+#pragma unroll
+    for (int u = 0; u < A3_U; u++) wnext[u] = fetch(warm0 + 64 * (A3_U * (int64_t)wave + u) + lane);
+    for (int64_t t = wave; t < ngr; t += A_WAVES) {
+        uint32_t haddr[A3_U], e_old[A3_U];
+        uint64_t m_ins[A3_U];
+#pragma unroll
+        for (int u = 0; u < A3_U; u++) {
+            const int64_t q0 = warm0 + 64 * (A3_U * t + u), q = q0 + lane;
+            const uint32_t wcur = wnext[u];
+            wnext[u] = fetch(q + 64 * A3_U * A_WAVES);
+            while (bcur <= q0) { bi++; bcur = bi < nb ? (int64_t)b[bi] : INT64_MAX; } // uniform
+            bool ins = q < span.end;
+            if (bi >= nb) ins = false;
+            else if (bcur < q0 + 64 + 2) { // a segment end is near: InsertString needs lookahead >= 3 (:780,:817)
+                int j = bi;
+                while (j < nb && (int64_t)b[j] <= q) j++;
+                ins = ins && j < nb && (int64_t)b[j] - q >= 3;
+            }
+            uint32_t h = 0;
+            if (ins) {
+                uint32_t w = wcur;
+                if ((uint64_t)q + 4 > avail) w = (uint32_t)d[q] | ((uint32_t)d[q + 1] << 8) | ((uint32_t)d[q + 2] << 16);
+                const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
+                h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
+            }
+            haddr[u] = head_a + 4u * h; m_ins[u] = __ballot(ins);
+            e_old[u] = 0;
+        }
+        // ---- the ticket: wait for it, exchange the four slices into the table in order, pass it on
+        {
+            static_assert(A3_U == 4, "the ticket section is written out for four slices");
+            uint32_t c, sc;
+            uint64_t sv;
+            const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);   // wave-uniform (the compiler cannot see it)
+            const uint32_t qb = (uint32_t)(warm0 + 64 * A3_U * t) + (uint32_t)lane;   // position of this lane in slice 0 (low 32 bits)
+            const uint32_t q1 = qb + 64u, q2 = qb + 128u, q3 = qb + 192u, tn = tt + 1u;
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n"
+                "1:\n\t"
+                "ds_read_b32 %[c], %[ta]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readfirstlane_b32 %[sc], %[c]\n\t"
+                "s_cmp_eq_u32 %[sc], %[tt]\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_sub_u32 %[sc], %[tt], %[sc]\n\t"
+                "s_cmp_lt_u32 %[sc], 3\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_sleep 3\n\t"
+                "s_branch 1b\n"
+                "2:\n\t"
+                "s_mov_b64 exec, %[mi0]\n\t" "ds_wrxchg_rtn_b32 %[e0], %[a0], %[q0]\n\t"
+                "s_mov_b64 exec, %[mi1]\n\t" "ds_wrxchg_rtn_b32 %[e1], %[a1], %[q1]\n\t"
+                "s_mov_b64 exec, %[mi2]\n\t" "ds_wrxchg_rtn_b32 %[e2], %[a2], %[q2]\n\t"
+                "s_mov_b64 exec, %[mi3]\n\t" "ds_wrxchg_rtn_b32 %[e3], %[a3], %[q3]\n\t"
+                "s_mov_b64 exec, %[sv]\n\t"
+                "ds_write_b32 %[ta], %[tn]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                : [e0] "+&v"(e_old[0]), [e1] "+&v"(e_old[1]), [e2] "+&v"(e_old[2]), [e3] "+&v"(e_old[3]),
+                  [c] "=&v"(c), [sc] "=&s"(sc), [sv] "=&s"(sv)
+                : [ta] "v"(turn_a), [tt] "s"(tt), [tn] "v"(tn),
+                  [a0] "v"(haddr[0]), [a1] "v"(haddr[1]), [a2] "v"(haddr[2]), [a3] "v"(haddr[3]),
+                  [q0] "v"(qb), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3),
+                  [mi0] "s"(m_ins[0]), [mi1] "s"(m_ins[1]), [mi2] "s"(m_ins[2]), [mi3] "s"(m_ins[3])
+                : "scc", "memory");
+        }
+        // ---- links of the four slices
+#pragma unroll
+        for (int u = 0; u < A3_U; u++) {
+            const int64_t q = warm0 + 64 * (A3_U * t + u) + lane;
+            if (q >= span.start && q < span.end) {
+                uint32_t dist = 0;
+                if ((m_ins[u] >> lane) & 1) {
+                    dist = (uint32_t)q - e_old[u];
+                    if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
+                }
+                lk[q] = (uint16_t)dist;
+            }
+        }
+    }
+}
+
+// ============================================================================================
 // Stage B: k_match.  One workgroup per 16384-position tile.  The tile's bytes plus 32512 bytes of
 // history and the u16 links of both are staged in LDS (≈144 KiB of the CU's 160 KiB), so every chain
 // step — prev[] hop, quick reject, byte compare — is an LDS access.  Lanes pull positions from an LDS
@@ -794,9 +967,25 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
 
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
                   int nspans, uint16_t *link, hipStream_t st) {
-    static const bool v1 = getenv("SZL_LINKS") && atoi(getenv("SZL_LINKS")) == 1;
     if (nspans <= 0) return;
-    if (v1) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
+    const int which = knob("SZL_LINKS", 3);   // 3 = pipelined (ticket) form, 2 = bucketed by owner wavefront, 1 = first form
+    static std::atomic<uint64_t> probe_done{0}, probe_ok{0};   // per device: does ds_wrxchg serve the lanes in ascending order?
+    uint64_t dev_bit = 0;
+    if (which == 3 && lds_attr_needed(probe_done, dev_bit)) {
+        int *d_ok = nullptr, h_ok = 0;
+        if (hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess) {
+            hipLaunchKernelGGL(k_probe_xchg_order, dim3(1), dim3(64), 0, st, 4096, d_ok);
+            if (hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) h_ok = 0;
+            (void)hipFree(d_ok);
+        }
+        if (h_ok && hipFuncSetAttribute((const void *)k_links3, hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES) == hipSuccess)
+            probe_ok.fetch_or(dev_bit, std::memory_order_release);
+        else if (!h_ok) fprintf(stderr, "[szl] stage A: the LDS exchange order probe failed on this device; using the bucketed form (k_links2)\n");
+        probe_done.fetch_or(dev_bit, std::memory_order_release);
+    }
+    if (which == 3 && (probe_ok.load(std::memory_order_acquire) & dev_bit)) {
+        hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link);
+    } else if (which == 1) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
     else hipLaunchKernelGGL(k_links2, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
 }
 
@@ -809,7 +998,7 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     // SZL_MATCH_KERNEL: 2 = two positions in flight per lane (szl_kernels_match2.hip, default), 1 = k_match below
     const int which = knob("SZL_MATCH_KERNEL", 2);
-    if (which == 2 || which == 3) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // 3 = run-ahead engine (k_match5)
+    if (which == 2) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;

@@ -19,8 +19,18 @@
 //     SQ_LDS_UNALIGNED_STALL made the LDS pipe the bottleneck in the first version);
 //   * a freshly fetched position goes straight to VERIFY with its first candidate (same 3-byte hash: the scan_end test at
 //     offset 2 all but always passes), saving one chain step per position.
-// Result: 24.6 VALU + 21.5 SALU per position, 89.9 -> 64 ms per GiB of text at level 6, 475 -> 306 ms per GiB of logs at
+//   * QUICK tests the two bytes the reference tests first (scan_end and scan_end1, :505-506) instead of one: 40 % fewer
+//     candidates reach VERIFY on text, 3x fewer on logs at level 9 (no gain on text — a third LDS read per step pays for it —
+//     but 271 -> 238 ms per GiB of logs).
+// Result: 24.6 VALU + 21.5 SALU per position, 89.9 -> 64 ms per GiB of text at level 6, 475 -> 238 ms per GiB of logs at
 // level 9 (full search), bit-identical tables.
+//
+// Built, measured and dropped again this round (sources in the history, logs under profiles/r02): four contexts per lane
+// (lab_s11: 99 ms per GiB — every issue slot is paid per context whatever its lane count); a run-ahead engine in which a
+// candidate that passes the filter waits in a per-context pending slot while the walk goes on (lab_s13/s14: QUICK runs with
+// 54 % of the contexts instead of 40 %, but the per-pass cost of VERIFY/COMPLETE grows by the same amount: 65-70 ms).  With
+// VALU ~80 %, SALU ~70 % and the LDS pipe ~60 % busy at four waves per SIMD every variant lands at 64-66 ms: the next step
+// has to remove chain steps (34 per position), not re-balance them.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdlib>
@@ -507,350 +517,6 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
     }
 }
 
-// =============================================================================================================================
-// k_match5 — the same search with VERIFY taken off the walk's critical path ("run-ahead").
-//
-// Counters of k_match4 (profiles/r02/lab_s12_phase_counters.log, 128 MiB of text, level 6): 35.1 QUICK steps, 3.55 candidates
-// compared and 1 fetch per position; the QUICK loop runs with 40 % of the contexts, the VERIFY loop with 21 %, COMPLETE with
-// 32 % — a walk that found a candidate to compare waits, out of QUICK, until enough others did too.  Here a context has ONE
-// pending slot: a candidate that passes the scan_end test moves into the slot and the walk goes on (with the old best_len:
-// every candidate that can beat the *new* best_len also passes the old test, so nothing is missed and the extra compares are
-// harmless — FindLongestMatch is a running strict maximum over the chain, C/DeflaterEngine.cs:502-607, and the slot keeps the
-// chain order).  Only a second passing candidate blocks the walk.  VERIFY then serves every context with a pending candidate,
-// walking or not, so both loops run fuller.  A compare that reaches niceLength ends the walk (:603) and discards the run-ahead.
-//
-// Lane masks per context (SGPR pairs): q = walking, hp = has a pending candidate, bl = blocked on a second candidate (implies
-// hp), d = finished (results wait for the store), ps = the pending candidate is also seen by the quarter-budget walk (:495).
-// hp without q and bl = the chain is finished, only the pending compare is outstanding.
-#define SZL5_Q_FINISH(X) \
-    "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 8, %[t2" #X "]\n\t" \
-    "v_cmpx_ne_u32 vcc, %[pb" #X "], %[t1" #X "]\n\t"                       /* scan_end differs: stay in the walk (:505) */ \
-    "v_sub_u32 %[cl" #X "], %[cl" #X "], %[t0" #X "]\n\t"                  /* next candidate, in place */ \
-    "v_cmpx_ge_i32 vcc, %[cl" #X "], %[mincl" #X "]\n\t"                    /* curMatch > limit (:609) */ \
-    "v_subrev_co_u32 %[left" #X "], vcc, 1, %[left" #X "]\n\t"              /* --chainLength != 0 */ \
-    "s_andn2_b64 exec, exec, vcc\n\t" \
-    "s_mov_b64 %[m" #X "], exec\n\t"
-// lanes that left the QUICK loop: scan_end matched -> pending slot (or blocked when it is taken); otherwise the chain is over
-#define SZL5_Q_CLASSIFY(X) \
-    "s_andn2_b64 exec, %[q" #X "], %[m" #X "]\n\t" \
-    "v_cmp_eq_u32 vcc, %[pb" #X "], %[t1" #X "]\n\t" \
-    "s_andn2_b64 %[sc], exec, vcc\n\t" \
-    "s_andn2_b64 %[cm], %[sc], %[hp" #X "]\n\t" \
-    "s_or_b64 %[d" #X "], %[d" #X "], %[cm]\n\t"                           /* chain over, nothing pending: done */ \
-    "s_mov_b64 %[q" #X "], %[m" #X "]\n\t" \
-    "s_and_b64 %[sc], vcc, %[hp" #X "]\n\t" \
-    "s_or_b64 %[bl" #X "], %[bl" #X "], %[sc]\n\t"                         /* slot taken: blocked on this candidate */ \
-    "s_andn2_b64 exec, vcc, %[hp" #X "]\n\t" \
-    "s_or_b64 %[hp" #X "], %[hp" #X "], exec\n\t"                          /* slot free: the candidate waits there, the walk goes on */ \
-    "v_mov_b32 %[pcl" #X "], %[cl" #X "]\n\t" \
-    "v_mov_b32 %[off" #X "], 0\n\t" \
-    "v_cmp_ge_i32 vcc, %[left" #X "], %[snap]\n\t" \
-    "s_andn2_b64 %[ps" #X "], %[ps" #X "], exec\n\t" \
-    "s_or_b64 %[ps" #X "], %[ps" #X "], vcc\n\t" \
-    "v_sub_u32 %[cl" #X "], %[cl" #X "], %[t0" #X "]\n\t"                  /* these lanes left before the in-place advance */ \
-    "v_cmp_ge_i32 vcc, %[cl" #X "], %[mincl" #X "]\n\t" \
-    "v_cmp_ne_u32 %[sc], 0, %[left" #X "]\n\t" \
-    "s_and_b64 vcc, vcc, %[sc]\n\t" \
-    "v_add_u32 %[left" #X "], -1, %[left" #X "]\n\t" \
-    "s_or_b64 %[q" #X "], %[q" #X "], vcc\n\t"
-#define SZL5_V_ISSUE(X) \
-    "v_add3_u32 %[t0" #X "], %[pcl" #X "], %[off" #X "], %[dbase]\n\t" \
-    "v_add3_u32 %[t1" #X "], %[p" #X "], %[off" #X "], %[pbase]\n\t" \
-    "v_and_b32 %[t4" #X "], -4, %[t0" #X "]\n\t" \
-    "v_and_b32 %[t5" #X "], -4, %[t1" #X "]\n\t" \
-    "ds_read_b32 %[t2" #X "], %[t4" #X "]\n\t" \
-    "ds_read_b32 %[t3" #X "], %[t4" #X "] offset:4\n\t" \
-    "ds_read_b32 %[t4" #X "], %[t4" #X "] offset:8\n\t" \
-    "ds_read_b32 %[t6" #X "], %[t5" #X "]\n\t" \
-    "ds_read_b32 %[t7" #X "], %[t5" #X "] offset:4\n\t" \
-    "ds_read_b32 %[t5" #X "], %[t5" #X "] offset:8\n\t"
-// :593-607 for the compares that finished (hp & ~m), first half: new best_len, its scan_end byte, and — for a lane blocked on
-// its next candidate — that candidate's prev[] hop.  sc<X> = lanes whose walk ends at niceLength.
-#define SZL5_C_ISSUE(X) \
-    "s_andn2_b64 %[cm], %[hp" #X "], %[m" #X "]\n\t" \
-    "s_mov_b64 exec, %[cm]\n\t" \
-    "v_min_i32 %[t2" #X "], %[off" #X "], %[cap" #X "]\n\t" \
-    "v_cmp_gt_i32 vcc, %[t2" #X "], %[best" #X "]\n\t" \
-    "s_mov_b64 exec, vcc\n\t" \
-    "v_mov_b32 %[best" #X "], %[t2" #X "]\n\t" \
-    "v_sub_u32 %[t1" #X "], %[p" #X "], %[pcl" #X "]\n\t" \
-    "v_add_u32 %[t1" #X "], %[bhist], %[t1" #X "]\n\t" \
-    "v_lshl_or_b32 %[res2" #X "], %[t1" #X "], 16, %[t2" #X "]\n\t" \
-    "v_cndmask_b32 %[resq" #X "], %[resq" #X "], %[res2" #X "], %[ps" #X "]\n\t" \
-    "v_cmp_ge_i32 %[sc" #X "], %[t2" #X "], %[nice" #X "]\n\t" \
-    "s_mov_b64 exec, %[cm]\n\t" \
-    "v_add3_u32 %[t1" #X "], %[p" #X "], %[best" #X "], %[pbm1]\n\t" \
-    "v_lshl_add_u32 %[t0" #X "], %[cl" #X "], 1, %[lbase]\n\t" \
-    "ds_read_u8 %[t3" #X "], %[t1" #X "]\n\t" \
-    "ds_read_u8 %[t1" #X "], %[t1" #X "] offset:1\n\t" \
-    "ds_read_u16 %[t0" #X "], %[t0" #X "]\n\t"
-#define SZL5_C_FINISH(X) \
-    "s_andn2_b64 %[cm], %[hp" #X "], %[m" #X "]\n\t" \
-    "s_mov_b64 exec, %[cm]\n\t" \
-    "v_lshl_or_b32 %[pb" #X "], %[t1" #X "], 8, %[t3" #X "]\n\t" \
-    "s_mov_b64 %[hp" #X "], %[m" #X "]\n\t"                                /* the slots of the finished compares are free */ \
-    "s_andn2_b64 %[q" #X "], %[q" #X "], %[sc" #X "]\n\t"                  /* niceLength reached: the walk is over (:603) */ \
-    "s_andn2_b64 %[bl" #X "], %[bl" #X "], %[sc" #X "]\n\t" \
-    "s_or_b64 %[d" #X "], %[d" #X "], %[sc" #X "]\n\t" \
-    "s_andn2_b64 %[cm], %[cm], %[sc" #X "]\n\t" \
-    "s_or_b64 %[sc], %[q" #X "], %[bl" #X "]\n\t" \
-    "s_andn2_b64 %[sc], %[cm], %[sc]\n\t" \
-    "s_or_b64 %[d" #X "], %[d" #X "], %[sc]\n\t"                           /* chain was over already: done */ \
-    "s_and_b64 exec, %[cm], %[bl" #X "]\n\t"                                /* blocked: that candidate takes the slot, the walk resumes */ \
-    "s_andn2_b64 %[bl" #X "], %[bl" #X "], exec\n\t" \
-    "s_or_b64 %[hp" #X "], %[hp" #X "], exec\n\t" \
-    "v_mov_b32 %[pcl" #X "], %[cl" #X "]\n\t" \
-    "v_mov_b32 %[off" #X "], 0\n\t" \
-    "v_cmp_ge_i32 vcc, %[left" #X "], %[snap]\n\t" \
-    "s_andn2_b64 %[ps" #X "], %[ps" #X "], exec\n\t" \
-    "s_or_b64 %[ps" #X "], %[ps" #X "], vcc\n\t" \
-    "v_sub_u32 %[cl" #X "], %[cl" #X "], %[t0" #X "]\n\t" \
-    "v_cmp_ge_i32 vcc, %[cl" #X "], %[mincl" #X "]\n\t" \
-    "v_cmp_ne_u32 %[sc], 0, %[left" #X "]\n\t" \
-    "s_and_b64 vcc, vcc, %[sc]\n\t" \
-    "v_add_u32 %[left" #X "], -1, %[left" #X "]\n\t" \
-    "s_or_b64 %[q" #X "], %[q" #X "], vcc\n\t"
-
-#define SZL5_CNT2(R, PFX) \
-    "s_bcnt1_i32_b64 %[" #R "], %[" #PFX "A]\n\t" \
-    "s_bcnt1_i32_b64 %[n2], %[" #PFX "B]\n\t" \
-    "s_add_u32 %[" #R "], %[" #R "], %[n2]\n\t"
-// HQ / HV / HC: counter hooks of the lab build (empty strings otherwise)
-#define SZL5_BODY(HQ, HV, HC) \
-    "s_mov_b64 %[sv], exec\n" \
-    "10:\n\t" \
-    "s_or_b64 %[sc], %[qA], %[hpA]\n\t" \
-    "s_or_b64 %[sc], %[sc], %[blA]\n\t" \
-    "s_bcnt1_i32_b64 %[n0], %[sc]\n\t" \
-    "s_or_b64 %[sc], %[qB], %[hpB]\n\t" \
-    "s_or_b64 %[sc], %[sc], %[blB]\n\t" \
-    "s_bcnt1_i32_b64 %[n1], %[sc]\n\t" \
-    "s_add_u32 %[n0], %[n0], %[n1]\n\t"                                     /* busy contexts */ \
-    "s_cmp_le_u32 %[n0], %[bexit]\n\t" \
-    "s_cbranch_scc1 19f\n\t" \
-    SZL5_CNT2(n1, hp)                                                       /* candidates waiting for a compare */ \
-    "s_cmp_ge_u32 %[n1], %[vth]\n\t" \
-    "s_cbranch_scc1 14f\n\t" \
-    "s_cmp_eq_u32 %[n1], 0\n\t" \
-    "s_cbranch_scc1 13f\n\t" \
-    SZL5_CNT2(n0, q) \
-    "s_cmp_lt_u32 %[n0], %[qmin]\n\t"                                       /* too few walkers left: compare what there is */ \
-    "s_cbranch_scc1 14f\n" \
-    "13:\n\t" \
-    "s_mov_b64 %[mA], %[qA]\n\t" \
-    "s_mov_b64 %[mB], %[qB]\n" \
-    "11:\n\t" \
-    HQ \
-    "s_mov_b64 exec, %[mA]\n\t" \
-    SZL_Q_ISSUE(A) \
-    "s_mov_b64 exec, %[mB]\n\t" \
-    SZL_Q_ISSUE(B) \
-    "s_mov_b64 exec, %[mA]\n\t" \
-    "s_waitcnt lgkmcnt(3)\n\t" \
-    SZL5_Q_FINISH(A) \
-    SZL_Q_ISSUE(A) \
-    "s_mov_b64 exec, %[mB]\n\t" \
-    "s_waitcnt lgkmcnt(3)\n\t" \
-    SZL5_Q_FINISH(B) \
-    SZL_Q_ISSUE(B) \
-    "s_mov_b64 exec, %[mA]\n\t" \
-    "s_waitcnt lgkmcnt(3)\n\t" \
-    SZL5_Q_FINISH(A) \
-    "s_mov_b64 exec, %[mB]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    SZL5_Q_FINISH(B) \
-    SZL5_CNT2(n0, m) \
-    "s_cmp_ge_u32 %[n0], %[qkeep]\n\t" \
-    "s_cbranch_scc1 11b\n\t" \
-    SZL5_Q_CLASSIFY(A) \
-    SZL5_Q_CLASSIFY(B) \
-    "s_branch 10b\n" \
-    "14:\n\t" \
-    "s_mov_b64 %[mA], %[hpA]\n\t" \
-    "s_mov_b64 %[mB], %[hpB]\n" \
-    "15:\n\t" \
-    HV \
-    "s_mov_b64 exec, %[mA]\n\t" \
-    SZL5_V_ISSUE(A) \
-    "s_mov_b64 exec, %[mB]\n\t" \
-    SZL5_V_ISSUE(B) \
-    "s_mov_b64 exec, %[mA]\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    SZL_V_FINISH(A) \
-    "s_mov_b64 exec, %[mB]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    SZL_V_FINISH(B) \
-    SZL5_CNT2(n0, m) \
-    "s_cmp_ge_u32 %[n0], %[vkeep]\n\t" \
-    "s_cbranch_scc1 15b\n\t" \
-    HC \
-    SZL5_C_ISSUE(A) \
-    SZL5_C_ISSUE(B) \
-    "s_waitcnt lgkmcnt(3)\n\t" \
-    SZL5_C_FINISH(A) \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    SZL5_C_FINISH(B) \
-    "s_branch 10b\n" \
-    "19:\n\t" \
-    "s_mov_b64 exec, %[sv]\n\t"
-
-struct WalkCtx5 {     // WalkCtx plus the pending slot
-    int p, cl, best, left, off, mincl, cap, nice;
-    uint32_t pb, res2, resq;
-    int pcl;          // LDS data index of the candidate in the pending slot (being compared, `off` bytes known equal)
-};
-
-template <bool DBG>
-__global__ __launch_bounds__(B2_THREADS) void k_match5(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
-                                                       const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                       MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth, int qkeep, int vkeep, int qmin) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const TileDev tile = tiles[blockIdx.x];
-    const SegDev seg = segs[tile.seg];
-    uint32_t *sdata32 = (uint32_t *)smem;                          // B2_DATA_BYTES
-    uint16_t *slink = (uint16_t *)(smem + B2_DATA_BYTES);          // B2_LINKS entries
-    int *s_counter = (int *)(smem + B2_DATA_BYTES + B2_LINKS * 2);
-    const uint8_t *d = in + seg.buf_off;
-    const uint16_t *lk = link + seg.buf_off;
-    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
-    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
-    const int64_t t0 = tile.start;
-    const int tlen = tile.len;
-    const int64_t dlo = t0 - B_HIST; // buffer position of LDS data byte 0 (may be negative)
-    const int64_t seg_end = seg.look_end; // lookahead end
-    b2_stage_window(sdata32, slink, d, lk, dlo, seg_end, t0, tlen);
-    if (threadIdx.x == 0) *s_counter = 0;
-    __syncthreads();
-
-    const uint8_t *sdata8 = smem;
-    const uint32_t dbase = (uint32_t)(uintptr_t)(lds_u8 *)smem;
-    const uint32_t lbase = dbase + (uint32_t)B2_DATA_BYTES;
-    const uint32_t pbase = dbase + (uint32_t)B_HIST;
-    const int64_t base_lo = base_of2((int64_t)seg.abs0 + t0), base_hi = base_of2((int64_t)seg.abs0 + t0 + tlen - 1);
-    const int64_t sw64 = base_lo == base_hi ? (int64_t)1 << 30 : (base_lo + 65273) - (int64_t)seg.abs0 - t0; // first tile position on base_hi
-    const int sw = sw64 > (int64_t)B_TILE ? B_TILE : (int)sw64;
-    const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo);
-    const int64_t rem0_64 = seg_end - t0;
-    const int rem0 = rem0_64 > (int64_t)(1 << 24) ? (1 << 24) : (int)rem0_64;
-    const int lane = threadIdx.x & 63;
-    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);       // see k_match4
-    const int bhist = B_HIST;
-    int wnext = 0, wend = 0;
-    bool exhausted = false;
-
-    WalkCtx5 A, B;
-    A.p = 0; A.cl = B_HIST; A.best = 2; A.left = 0; A.off = 0; A.mincl = 0; A.cap = MAX_MATCH; A.nice = P.nice; A.pb = 0; A.res2 = 0; A.resq = 0; A.pcl = B_HIST;
-    B = A;
-    uint64_t qA = 0, hpA = 0, blA = 0, dA = 0, psA = 0, qB = 0, hpB = 0, blB = 0, dB = 0, psB = 0;
-    unsigned long long c_fvis = 0, c_flanes = 0, c_eng = 0, c_kq = 0, c_kql = 0, c_kv = 0, c_kvl = 0, c_kc = 0, c_kcl = 0;
-
-    // FETCH for one context: retire its finished walks, start new ones on its free lanes.  The first candidate of a new walk
-    // goes straight into the pending slot (it shares the position's 3-byte hash: the scan_end test at offset 2 all but always
-    // passes) and the walk starts at the second.
-    auto fetch = [&](WalkCtx5 &C, uint64_t &q, uint64_t &hp, uint64_t &bl, uint64_t &dm, uint64_t &ps) {
-        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; }
-        dm = 0;
-        if (exhausted) return;
-        const uint64_t idle = ~(q | hp | bl);
-        const int ni = __builtin_popcountll(idle);
-        if (ni == 0) return;
-        if (wnext >= wend) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(s_counter, 512);
-            base = __builtin_amdgcn_readfirstlane(base);
-            wnext = base < tlen ? base : tlen;
-            wend = base + 512 < tlen ? base + 512 : tlen;
-            if (wnext >= wend) { exhausted = true; return; }
-        }
-        const int rank = __builtin_popcountll(idle & lanemask_lt);
-        if (DBG) { c_fvis++; c_flanes += (wend - wnext) < ni ? (wend - wnext) : ni; }
-        bool started = false, walking = false;
-        if (__builtin_amdgcn_inverse_ballot_w64(idle) && wnext + rank < wend) {
-            const int p = wnext + rank;
-            C.p = p;
-            const int rem = rem0 - p;                                   // lookahead (clamped high)
-            C.res2 = 0; C.resq = 0;
-            bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
-            if (ok) {
-                const int pl = p + B_HIST;
-                const int l0 = (int)slink[pl];                           // hashHead (:782)
-                const int basem = p >= sw ? basem_hi : basem_lo;        // LDS index of window index 1 (:450-461)
-                const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem; // strstart - hashHead <= MAX_DIST (:788)
-                const int c = pl - l0;
-                ok = c >= firstmin;                                      // l0 == 0xFFFF (none) fails this too
-                if (ok) {
-                    C.pcl = c; C.off = 0;
-                    C.mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
-                    C.cap = rem < MAX_MATCH ? rem : MAX_MATCH;            // scanMax :479
-                    C.nice = rem < P.nice ? rem : P.nice;                 // :485
-                    C.best = 2;
-                    C.pb = ((uint32_t)sdata8[pl + 2] << 8) | sdata8[pl + 1];   // scan_end, scan_end1 for best_len 2
-                    started = true;
-                    const int nxt = c - (int)slink[c];                   // the walk itself starts at the second candidate
-                    C.cl = nxt;
-                    C.left = P.max_chain - 2;
-                    walking = nxt >= C.mincl && P.max_chain > 1;
-                }
-            }
-            if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
-        }
-        const uint64_t sm = __ballot(started);
-        hp |= sm;
-        q |= __ballot(walking);
-        if (P.max_chain - 1 >= SNAPLEFT) ps |= sm; else ps &= ~sm;
-        wnext = wnext + ni < wend ? wnext + ni : wend;
-    };
-
-    for (;;) {
-        fetch(A, qA, hpA, blA, dA, psA);
-        fetch(B, qB, hpB, blB, dB, psB);
-        if ((qA | hpA | qB | hpB) == 0) { if (exhausted) break; else continue; }   // bl implies hp
-        const uint32_t busy_exit = exhausted ? 0u : (uint32_t)(128 - fth);
-        if (DBG) c_eng++;
-        uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
-        uint64_t mA, mB, scA, scB, sc, cm, sv;
-        uint32_t n0, n1, n2;
-#define SZL5_OUTS \
-            [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb), \
-            [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq), [pclA] "+&v"(A.pcl), \
-            [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb), \
-            [res2B] "+&v"(B.res2), [resqB] "+&v"(B.resq), [pclB] "+&v"(B.pcl), \
-            [qA] "+&s"(qA), [hpA] "+&s"(hpA), [blA] "+&s"(blA), [dA] "+&s"(dA), [psA] "+&s"(psA), \
-            [qB] "+&s"(qB), [hpB] "+&s"(hpB), [blB] "+&s"(blB), [dB] "+&s"(dB), [psB] "+&s"(psB), \
-            [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A), \
-            [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B), \
-            [mA] "=&s"(mA), [mB] "=&s"(mB), [scA] "=&s"(scA), [scB] "=&s"(scB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), \
-            [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2)
-#define SZL5_INS \
-            [minclA] "v"(A.mincl), [capA] "v"(A.cap), [niceA] "v"(A.nice), [minclB] "v"(B.mincl), [capB] "v"(B.cap), [niceB] "v"(B.nice), \
-            [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(pbase), [dbm1] "s"(dbase - 1u), [pbm1] "s"(pbase - 1u), [bhist] "s"(bhist), [snap] "s"(SNAPLEFT), \
-            [bexit] "s"(busy_exit), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep), [qmin] "s"(qmin)
-        if (DBG) {
-            uint32_t kq = 0, kql = 0, kv = 0, kvl = 0, kc = 0, kcl = 0;
-            asm volatile(SZL5_BODY(
-                    "s_add_u32 %[kq], %[kq], 1\n\t" "s_bcnt1_i32_b64 %[n2], %[mA]\n\t" "s_add_u32 %[kql], %[kql], %[n2]\n\t"
-                    "s_bcnt1_i32_b64 %[n2], %[mB]\n\t" "s_add_u32 %[kql], %[kql], %[n2]\n\t",
-                    "s_add_u32 %[kv], %[kv], 1\n\t" "s_bcnt1_i32_b64 %[n2], %[mA]\n\t" "s_add_u32 %[kvl], %[kvl], %[n2]\n\t"
-                    "s_bcnt1_i32_b64 %[n2], %[mB]\n\t" "s_add_u32 %[kvl], %[kvl], %[n2]\n\t",
-                    "s_add_u32 %[kc], %[kc], 1\n\t" "s_andn2_b64 %[cm], %[hpA], %[mA]\n\t" "s_bcnt1_i32_b64 %[n2], %[cm]\n\t" "s_add_u32 %[kcl], %[kcl], %[n2]\n\t"
-                    "s_andn2_b64 %[cm], %[hpB], %[mB]\n\t" "s_bcnt1_i32_b64 %[n2], %[cm]\n\t" "s_add_u32 %[kcl], %[kcl], %[n2]\n\t")
-                : SZL5_OUTS, [kq] "+&s"(kq), [kql] "+&s"(kql), [kv] "+&s"(kv), [kvl] "+&s"(kvl), [kc] "+&s"(kc), [kcl] "+&s"(kcl)
-                : SZL5_INS
-                : "vcc", "scc", "memory");
-            c_kq += kq; c_kql += kql; c_kv += kv; c_kvl += kvl; c_kc += kc; c_kcl += kcl;
-        } else {
-            asm volatile(SZL5_BODY("", "", "") : SZL5_OUTS : SZL5_INS : "vcc", "scc", "memory");
-        }
-#undef SZL5_OUTS
-#undef SZL5_INS
-    }
-    if (DBG && dbg && lane == 0) {
-        atomicAdd(dbg + 14, c_fvis); atomicAdd(dbg + 15, c_flanes); atomicAdd(dbg + 8, c_eng);
-        atomicAdd(dbg + 16, c_kq); atomicAdd(dbg + 17, c_kql); atomicAdd(dbg + 18, c_kv); atomicAdd(dbg + 19, c_kvl); atomicAdd(dbg + 20, c_kc); atomicAdd(dbg + 21, c_kcl);
-    }
-}
-
 static bool lds_attr_needed2(std::atomic<uint64_t> &mask, uint64_t &bit) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -864,12 +530,10 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
     // thresholds count CONTEXTS (two per lane, 128 per wavefront)
-    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 12), qkeep = knob("SZL_QKEEP", 48), vkeep = knob("SZL_VKEEP", 4); // swept: profiles/r02/lab_s6_k_match4_sweep.log
+    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 8), qkeep = knob("SZL_QKEEP", 48), vkeep = knob("SZL_VKEEP", 4); // swept: profiles/r02/lab_s6_k_match4_sweep.log, lab_s15_two_byte_filter.log
     auto attr = [&](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); };
     if (lds_attr_needed2(attr_mask, attr_bit)) {
-        hipError_t e = attr((const void *)k_match5<false>);
-        if (e == hipSuccess) e = attr((const void *)k_match5<true>);
-        if (e == hipSuccess) e = attr((const void *)k_match4<false>);
+        hipError_t e = attr((const void *)k_match4<false>);
         if (e == hipSuccess) e = attr((const void *)k_match4<true>);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
@@ -881,13 +545,7 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     if (vth < 1) vth = 1;
     if (qkeep < 1) qkeep = 1;
     if (vkeep < 1) vkeep = 1;
-    if (ntiles > 0 && knob("SZL_MATCH_KERNEL", 2) == 3) {
-        const dim3 g(ntiles), b(B2_THREADS);
-        int f5 = knob("SZL_FTH5", 32), v5 = knob("SZL_VTH5", 40), qk5 = knob("SZL_QKEEP5", 64), vk5 = knob("SZL_VKEEP5", 4), qm5 = knob("SZL_QMIN5", 24);
-        f5 = f5 < 1 ? 1 : (f5 > 128 ? 128 : f5); v5 = v5 < 1 ? 1 : v5; qk5 = qk5 < 1 ? 1 : qk5; vk5 = vk5 < 1 ? 1 : vk5; qm5 = qm5 < 1 ? 1 : qm5;
-        if (want_dbg) hipLaunchKernelGGL((k_match5<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, f5, v5, qk5, vk5, qm5);
-        else hipLaunchKernelGGL((k_match5<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, f5, v5, qk5, vk5, qm5);
-    } else if (ntiles > 0) {
+    if (ntiles > 0) {
         const dim3 g(ntiles), b(B2_THREADS);
         if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
         else hipLaunchKernelGGL((k_match4<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
