@@ -461,6 +461,15 @@ struct szl_deflater {
     uint32_t carry_bits = 0; uint8_t carry_byte = 0;
     uint32_t adler = 1;             // running Adler32.Value of everything compressed so far
     uint32_t dict_adler = 0;        // Adler-32 of the preset dictionary (SETDICT state)
+    // SetLevel / SetStrategy while input is pending (same compression function): the parameters the first pending byte is
+    // parsed with, and the changes after it as (absolute input position, level, strategy).  `engine_seen` = TotalIn the last
+    // time the reference's engine would have run (a Deflate() call that drained the input, or a flush): its DeflateSlow /
+    // DeflateFast loop stops at the first iteration start within MIN_LOOKAHEAD - 1 = 261 bytes of that point
+    // (C/DeflaterEngine.cs:681,:759), and the new parameters apply to every iteration from there on (:304-361).
+    int base_level = 6, base_strategy = 0;
+    struct Sw { uint64_t abs_pos; int level, strategy; };
+    std::vector<Sw> switches;
+    int64_t engine_seen = 0;
     szl_engine *eng = nullptr;
     DevBuf d_in, d_out;
     std::vector<uint8_t> h_out;
@@ -472,6 +481,7 @@ static void deflater_clear(szl_deflater *d) {
     d->hist.clear(); d->hist_flags.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
     d->chunks.clear(); d->chunks_drained = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
     d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
+    d->switches.clear(); d->engine_seen = 0; d->base_level = d->level; d->base_strategy = d->strategy;
 }
 
 szl_deflater *szl_deflater_create(int level, int nowrap) {
@@ -492,25 +502,32 @@ void szl_deflater_destroy(szl_deflater *d) {
     delete d;
 }
 int szl_deflater_reset(szl_deflater *d) { if (!d) return SZL_E_ARG; deflater_clear(d); return 0; }
+static int lvl_kind(int lv) { return lv == 0 ? 0 : (lv < 5 ? 1 : 2); }   // DEFLATE_STORED / DEFLATE_FAST / DEFLATE_SLOW (C/DeflaterConstants.cs:146)
+// a parameter change while bytes are pending: it takes effect where the reference's engine stands
+static int pend_switch(szl_deflater *d, int level, int strategy) {
+    if (d->switches.size() >= (size_t)SEG_MAX_SWITCH) { set_error("more than %d SetLevel/SetStrategy calls between two flushes are not supported", (int)SEG_MAX_SWITCH); return SZL_E_UNSUPPORTED; }
+    const int64_t at = d->engine_seen > (MIN_LOOKAHEAD - 1) ? d->engine_seen - (MIN_LOOKAHEAD - 1) : 0;
+    d->switches.push_back(szl_deflater::Sw{(uint64_t)at, level, strategy});
+    return 0;
+}
 int szl_deflater_set_level(szl_deflater *d, int level) {
     if (!d) return SZL_E_ARG;
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) return SZL_E_ARG;
-    if (level == d->level) return 0;
-    // DEFLATE_SLOW -> DEFLATE_SLOW only changes the tuning for positions not yet parsed (C/DeflaterEngine.cs:304-361);
-    // that is reproducible only when nothing is buffered.
-    if (!d->pend.empty()) { set_error("SetLevel with unprocessed input is not supported"); return SZL_E_UNSUPPORTED; }
-    // stored / fast / slow keep different hash-chain contents (level 0 inserts nothing, 1-4 skip long matches, :319-329,:697):
-    // only a fresh stream may change the compression function
-    auto kind = [](int lv) { return lv == 0 ? 0 : (lv < 5 ? 1 : 2); };
-    if (kind(level) != kind(d->level) && d->total_in != 0) { set_error("switching between DeflateStored / DeflateFast / DeflateSlow levels mid-stream is not supported"); return SZL_E_UNSUPPORTED; }
+    if (level == d->level) return 0;                       // C/Deflater.cs:357
+    // stored / fast / slow keep different hash-chain contents (level 0 inserts nothing, 1-4 skip long matches, :319-329,:697)
+    // and the reference closes a block at the switch: only a fresh stream may change the compression function here
+    if (lvl_kind(level) != lvl_kind(d->level) && d->total_in != 0) { set_error("switching between DeflateStored / DeflateFast / DeflateSlow levels mid-stream is not supported"); return SZL_E_UNSUPPORTED; }
+    if (!d->pend.empty() && level != 0) { int rc = pend_switch(d, level, d->strategy); if (rc) return rc; }
+    else if (d->pend.empty()) d->base_level = level;
     d->level = level;
     return 0;
 }
 int szl_deflater_get_level(const szl_deflater *d) { return d ? d->level : SZL_E_ARG; }
 int szl_deflater_set_strategy(szl_deflater *d, int s) {
     if (!d || s < 0 || s > 2) return SZL_E_ARG;
-    if (s != d->strategy && !d->pend.empty()) { set_error("SetStrategy with unprocessed input is not supported"); return SZL_E_UNSUPPORTED; }
+    if (s != d->strategy && !d->pend.empty() && d->level != 0) { int rc = pend_switch(d, d->level, s); if (rc) return rc; }
+    else if (d->pend.empty()) d->base_strategy = s;
     d->strategy = s;
     return 0;
 }
@@ -601,7 +618,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     if (d->level == 0) return run_segment_stored(d, finish);
     d->chunks.clear(); d->chunks_drained = 0;
     LevelParams P;
-    int rc = level_params(d->level, d->strategy, &P);
+    int rc = level_params(d->switches.empty() ? d->level : d->base_level, d->switches.empty() ? d->strategy : d->base_strategy, &P);
     if (rc) return rc;
     const uint64_t H = d->hist.size(), n = d->pend.size();
     const uint64_t in_total = H + n;
@@ -621,6 +638,17 @@ static int run_segment(szl_deflater *d, bool finish) {
     s.finish = finish ? 1 : 0;
     s.flags = finish ? ((d->nowrap ? 0u : (uint32_t)SEG_ZLIB_TRAILER)) : (uint32_t)SEG_SYNC_PAD;
     s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = 0;
+    {   // parameter changes inside the pending bytes -> buffer positions
+        const int64_t pend_abs = d->total_in - (int64_t)n;       // absolute input position of the first pending byte
+        for (const auto &w : d->switches) {
+            LevelParams Pk;
+            if ((rc = level_params(w.level, w.strategy, &Pk))) return rc;
+            if (Pk.fast != P.fast) { set_error("internal: compression function changed inside a segment"); return SZL_E_STATE; }
+            int64_t rel = (int64_t)w.abs_pos - pend_abs;
+            if (rel < 0) rel = 0;
+            s.sw_pos[s.sw_cnt] = (int64_t)H + rel; s.sw_P[s.sw_cnt] = Pk; s.sw_cnt++;
+        }
+    }
     std::vector<SegOut> res;
     Engine &E = d->eng->e;
     E.fast_hist_in.clear(); E.fast_want_tail = false;
@@ -660,6 +688,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     d->hist_abs = d->hist_abs + H + n - keep;
     d->hist.swap(nh);
     d->pend.clear();
+    d->switches.clear(); d->base_level = d->level; d->base_strategy = d->strategy; d->engine_seen = d->total_in;
     d->bounds.erase(std::remove_if(d->bounds.begin(), d->bounds.end(), [&](uint64_t b) { return b <= d->hist_abs; }), d->bounds.end());
     return 0;
 }
@@ -683,7 +712,7 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Defla
         if (k) { memcpy(out, d->outq.data() + d->outpos, k); d->outpos += k; out += k; length -= (int)k; d->total_out += (int64_t)k; }
         if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }
         if (length == 0 || d->state == FINISHED_STATE) break;
-        if (d->state == BUSY_STATE) { d->chunks_drained = d->chunks.size(); break; } // "We need more input now" :482-484 (the engine has seen every chunk)
+        if (d->state == BUSY_STATE) { d->chunks_drained = d->chunks.size(); d->engine_seen = d->total_in; break; } // "We need more input now" :482-484 (the engine has seen every chunk)
         int rc;
         if (d->state == FLUSHING_STATE) { if ((rc = run_segment(d, false))) return rc; d->state = BUSY_STATE; }
         else if (d->state == FINISHING_STATE) { if ((rc = run_segment(d, true))) return rc; d->state = FINISHED_STATE; }

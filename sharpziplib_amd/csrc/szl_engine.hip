@@ -164,6 +164,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (nzero > 0x7FFFFFFFull) { set_error("batch too large"); return SZL_E_ARG; }
     const bool fast = P.fast != 0;             // DeflateFast: one wavefront per segment instead of stages B and C
     bool lazy = false;                         // stage B ran in its on-demand form
+    bool has_switch = false;                   // some segment changes LevelParams inside (SegDev.sw_*)
     std::vector<uint64_t> fast_blk_off;        // (its block slots are laid out here, not by a device scan)
     if (fast) fast_blk_off.resize(nseg + 1);
     for (uint32_t i = 0; i < nseg; i++) {
@@ -190,8 +191,20 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         if (n > 0)
             for (int64_t a = e0; a < s.seg_end; a += (int64_t)span_len)
                 spans.push_back(SpanDev{i, 0, a, std::min<int64_t>(a + (int64_t)span_len, s.seg_end)});
-        for (int64_t a = s.seg_start; a < s.seg_end; a += B_TILE)
-            tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(B_TILE, s.seg_end - a), 0});
+        if (s.sw_cnt == 0) {
+            for (int64_t a = s.seg_start; a < s.seg_end; a += B_TILE)
+                tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(B_TILE, s.seg_end - a), 0});
+        } else { // SetLevel / SetStrategy inside the segment: tiles end at the switch positions, each searched with its own parameters
+            if (s.sw_cnt > SEG_MAX_SWITCH) { set_error("too many parameter changes in one segment"); return SZL_E_UNSUPPORTED; }
+            has_switch = true;
+            int64_t lo = s.seg_start;
+            for (uint32_t k = 0; k <= s.sw_cnt; k++) {
+                int64_t hi = k < s.sw_cnt ? std::min<int64_t>(std::max<int64_t>(s.sw_pos[k], lo), s.seg_end) : s.seg_end;
+                for (int64_t a = lo; a < hi; a += B_TILE)
+                    tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(B_TILE, hi - a), (int32_t)k});
+                lo = hi;
+            }
+        }
         s.range_off = nranges;
         s.range_cnt = (uint32_t)((n + C_RANGE - 1) / C_RANGE);
         nranges += s.range_cnt;
@@ -204,6 +217,10 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     chunk_off[nseg] = nchunks;
     if (fast) fast_blk_off[nseg] = blk_slots;
     ntiles = tiles.size();
+    if (has_switch) {
+        if (nseg != 1) { set_error("parameter changes inside a segment are a single-stream feature"); return SZL_E_UNSUPPORTED; }
+        std::stable_sort(tiles.begin(), tiles.end(), [](const TileDev &a, const TileDev &b) { return a.pad2 < b.pad2; });
+    }
     if (blk_slots > 0xFFFFFFF0ull || spans.size() > 0x7FFFFFFFull || ntiles > 0x7FFFFFFFull) { set_error("batch too large"); return SZL_E_ARG; }
 
     // ---------------- workspace
@@ -293,7 +310,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     // The second evaluates far fewer positions on repetitive data but each evaluation costs ~3x more, so a pilot on a
     // sample of tiles measures the evaluated fraction first (results are identical either way).
     static const int match_mode_env = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 2; // 0 full, 1 on demand, 2 pilot
-    const int match_mode = match_mode_override >= 0 ? match_mode_override : match_mode_env;
+    const int match_mode = has_switch ? 0 : (match_mode_override >= 0 ? match_mode_override : match_mode_env);
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25; // break-even was 0.36-0.40 against k_match; the full search is 1.4-1.55x faster now
     last_pilot_frac = -1.0;
     bool b_event = false; // ev[7]: start of the stage-B search proper (after the pilot)
@@ -318,7 +335,18 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         }
     }
     if (!b_event) HIPCHK(hipEventRecord(ev[7], st));
-    if (!lazy) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
+    if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
+    if (has_switch) { // tiles are grouped by parameter set: group 0 = the call's P, group k = sw_P[k-1] of the (single) switching segment
+        size_t a = 0;
+        while (a < tiles.size()) {
+            size_t b = a;
+            while (b < tiles.size() && tiles[b].pad2 == tiles[a].pad2) b++;
+            LevelParams Pk = P;
+            if (tiles[a].pad2 > 0) Pk = segs[tiles[a].seg].sw_P[tiles[a].pad2 - 1];
+            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p + a, (int)(b - a), (const uint16_t *)link.p, mt, Pk, dcnt, st));
+            a = b;
+        }
+    }
     HIPCHK(hipEventRecord(ev[3], st));
     // C: parse
     const bool emit_copy = emit_copy_enabled(); // the speculative walk keeps its tokens; emission copies them (szl_kernels_parse.hip)

@@ -15,11 +15,13 @@
 
 namespace szl {
 
-enum : int { WSIZE = 32768, MAX_DIST = 32506, MAX_MATCH = 258, MIN_MATCH = 3, TOO_FAR = 4096, BLOCK_TOKENS = 16384 };
+enum : int { WSIZE = 32768, MAX_DIST = 32506, MAX_MATCH = 258, MIN_MATCH = 3, TOO_FAR = 4096, BLOCK_TOKENS = 16384,
+              MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1 /* C/DeflaterConstants.cs:104 */ };
 enum : int { LIT_NUM = 286, DIST_NUM = 30, BL_NUM = 19 };
 
 // fast != 0: DeflateFast (levels 1-4): max_lazy is the longest match whose interior is still inserted (:697)
 struct LevelParams { int good, nice, max_chain, strategy, max_lazy, fast; };
+enum : int { SEG_MAX_SWITCH = 4 };   // parameter changes inside one segment (more: SZL_E_UNSUPPORTED)
 
 // Stage-B output: two u32 arrays (len | dist<<16) indexed like the input buffer.
 struct MTab {
@@ -49,6 +51,15 @@ struct SegDev {
                            // DeflateFast: of its "inserted" bitmap (bit q = buffer position q)
     uint32_t adler_init;   // running Adler32.Value before this segment's bytes (zlib framing)
     uint32_t crc_init;     // running Crc32.Value before this segment's bytes
+    // SetLevel / SetStrategy while input is pending (C/DeflaterEngine.cs:304-361, DEFLATE_SLOW -> DEFLATE_SLOW): an iteration of
+    // DeflateSlow that STARTS at buffer position x >= sw_pos[k] runs with sw_P[k] (the last such k) instead of the call's
+    // LevelParams — the search at x (stage B) and the lazy decision at x (stage C) alike.  The engine stops at the first
+    // iteration start within MIN_LOOKAHEAD - 1 of the input it has, so "every iteration start >= that threshold" is exactly
+    // "every iteration after the call".
+    uint32_t sw_cnt;
+    uint32_t sw_pad;
+    int64_t sw_pos[SEG_MAX_SWITCH];
+    LevelParams sw_P[SEG_MAX_SWITCH];
     int64_t look_end;      // buffer position one past the last byte the ENGINE HAS SEEN (lookahead, FillWindow :379-394).  Equals
                            // seg_end except for the windows of a long stream (Engine::deflate_windowed): there seg_end only ends
                            // the window's parse ranges, while matches and the insert rule look on to the true end of the input.
@@ -56,7 +67,7 @@ struct SegDev {
 enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4, SEG_ZLIB_HEADER = 8, SEG_GZIP = 16 };
 
 struct SpanDev { uint32_t seg; uint32_t pad; int64_t start, end; };          // stage A: emit links for [start,end)
-struct TileDev { uint32_t seg; uint32_t pad; int64_t start; int32_t len; int32_t pad2; }; // stage B tile
+struct TileDev { uint32_t seg; uint32_t pad; int64_t start; int32_t len; int32_t pad2; }; // stage B tile (pad2: index + 1 into the segment's sw_P, 0 = the call's parameters; host side only)
 
 enum : int { B_TILE = 16384, B_HIST = 32512, B_TAIL = 264 };
 enum : int { C_RANGE = 4096 };

@@ -126,9 +126,15 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
     int64_t base = base_ge((int64_t)s.abs0 + x); // FillWindow runs when input arrives (:371)
     uint64_t ntok = 0;
     bool refilled = true; // FillWindow ran just before this iteration (segment start, or right after a block flush)
-    const bool search = P.strategy != 2; // HuffmanOnly :686
+    LevelParams Pc = P;                   // parameters of the running iteration (SetLevel / SetStrategy inside the segment: SegDev.sw_*)
+    bool search = Pc.strategy != 2;       // HuffmanOnly :686
 
     while (x < seg_end) {
+        if (s.sw_cnt) {
+            Pc = P;
+            for (uint32_t k = 0; k < s.sw_cnt; k++) if (x >= s.sw_pos[k]) Pc = s.sw_P[k];
+            search = Pc.strategy != 2;
+        }
         // ---- window slide (:680 strict; FillWindow :371 non-strict)
         {
             const int64_t idx = (int64_t)s.abs0 + x + 1 - base;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
             const int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0; // :480
             const int64_t basem = base - (int64_t)s.abs0;                            // buffer position of window index 0
             const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
-            const int nice = rem < (int64_t)P.nice ? (int)rem : P.nice;
+            const int nice = rem < (int64_t)Pc.nice ? (int)rem : Pc.nice;
             // One LDS round trip per chain hop: the hop's link, its inserted bit and its bytes (lane i: bytes 4i..4i+3,
             // compared against the position's own bytes fetched once) are requested together.
             const uint32_t off = 4u * (uint32_t)lane;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
             int lnk = rfl((int)S.link[(uint32_t)x & (F_LINKS - 1)]);
             int64_t c = x;
             bool first = true;   // still looking for hashHead, the newest INSERTED position of this hash (:686)
-            int budget = P.max_chain;
+            int budget = Pc.max_chain;
             for (;;) {
                 if (lnk == 0) break;
                 c -= lnk;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
         int64_t nx;
         if (best >= MIN_MATCH) {
             tok = (bdist << 16) | best;
-            const int ins = ((int)best <= P.max_lazy && rem - (int64_t)best >= MIN_MATCH) ? 1 : 0; // :697
+            const int ins = ((int)best <= Pc.max_lazy && rem - (int64_t)best >= MIN_MATCH) ? 1 : 0; // :697
             if (ins) flag_set(x, x + best, 1);
             else { // (two calls: the bits of x and of the interior can share a word, and flag_set gives each lane one word)
                 flag_set(x, x + 1, 1);

@@ -29,6 +29,15 @@ struct ParseCtx {
     int64_t tab_end;       // match-table entries exist for positions < tab_end
     int64_t abs0;
     LevelParams P;
+    const SegDev *sg;      // the segment in device memory (parameter switches, read only when nsw != 0)
+    uint32_t nsw;
+    // parameters in force for the DeflateSlow iteration that starts at buffer position x
+    __device__ __forceinline__ LevelParams par(int64_t x) const {
+        if (nsw == 0) return P;
+        LevelParams r = P;
+        for (uint32_t k = 0; k < nsw; k++) if (x >= sg->sw_pos[k]) r = sg->sw_P[k];
+        return r;
+    }
 };
 
 // FindLongestMatch entered with matchLen = L >= niceLength' (C/DeflaterEngine.cs:474-612): the first
@@ -46,7 +55,7 @@ __device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long
     const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
     if (L >= cap) return 0;
     const int64_t minc = p - (MAX_DIST - 1) > basem ? p - (MAX_DIST - 1) : basem;
-    int budget = c.P.max_chain >> 2;
+    int budget = c.par(p).max_chain >> 2;
     for (;;) {
         int l = 0;
         if (c.d[cand + L] == c.d[p + L]) { // quick reject :505
@@ -68,8 +77,9 @@ __device__ uint32_t slow_walk(const ParseCtx &c, int64_t p, int L, unsigned long
 __device__ void eval_global(const ParseCtx &c, int64_t p, uint32_t &m2, uint32_t &mq, unsigned long long *count) {
     if (count) atomicAdd(count, 1ull);
     m2 = 0; mq = 0;
+    const LevelParams Px = c.par(p);
     const int64_t rem = c.look_end - p;
-    if (rem < MIN_MATCH || c.P.strategy == 2) return;       // :780, HuffmanOnly :786
+    if (rem < MIN_MATCH || Px.strategy == 2) return;       // :780, HuffmanOnly :786
     const uint32_t l0 = c.lk[p];
     if (l0 == 0) return;
     const int64_t basem = base_of_c(c.abs0 + p) - c.abs0;
@@ -77,10 +87,10 @@ __device__ void eval_global(const ParseCtx &c, int64_t p, uint32_t &m2, uint32_t
     const int64_t firstmin = p - MAX_DIST > basem ? p - MAX_DIST : basem; // :788, :450-461
     if (cand < firstmin) return;
     const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
-    const int nice = rem < (int64_t)c.P.nice ? (int)rem : c.P.nice;
+    const int nice = rem < (int64_t)Px.nice ? (int)rem : Px.nice;
     const int64_t minc = p - (MAX_DIST - 1) > basem ? p - (MAX_DIST - 1) : basem; // :609
-    const int snapleft = c.P.max_chain - (c.P.max_chain >> 2);
-    int best = 2, left = c.P.max_chain;
+    const int snapleft = Px.max_chain - (Px.max_chain >> 2);
+    int best = 2, left = Px.max_chain;
     for (;;) {
         int l = 0;
         if (c.d[cand + best] == c.d[p + best]) { // quick reject :505
@@ -115,12 +125,13 @@ struct GlobalAcc {
 template <typename A>
 __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, const A &acc, int64_t &x, int &L, int &D, int64_t *tpos,
                                                bool want_lit, unsigned long long *fallbacks) {
+    const LevelParams Px = c.par(x);   // the parameters this iteration runs with (SetLevel / SetStrategy in mid-segment)
     uint32_t e2 = acc.m2(x), eq = 0;
     const bool unset = e2 == M_UNSET;
     if (unset) eval_global(c, x, e2, eq, fallbacks ? fallbacks + 6 : nullptr);
     if (L == 0) {
         int len = (int)(e2 & 0xFFFF), dist = (int)(e2 >> 16);
-        if (len != 0 && len <= 5 && (c.P.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
+        if (len != 0 && len <= 5 && (Px.strategy == 1 || (len == MIN_MATCH && dist > TOO_FAR))) len = 0; // :794-797
         if (len == 0) { // literal step :830-839 (tallied by the next iteration / final flush :752)
             uint32_t t = want_lit ? acc.lit(x) : 0u;
             *tpos = x;
@@ -137,12 +148,12 @@ __device__ __forceinline__ uint32_t parse_step(const ParseCtx &c, const A &acc, 
     if (rem >= MIN_MATCH) {
         const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
         if (L < cap) {
-            const int nice = rem < (int64_t)c.P.nice ? (int)rem : c.P.nice;
+            const int nice = rem < (int64_t)Px.nice ? (int)rem : Px.nice;
             uint32_t cand;
-            if (L < c.P.good) cand = e2;
+            if (L < Px.good) cand = e2;
             else if (L < nice) cand = unset ? eq : acc.mq(x);              // chainLength >>= 2 (:495)
             else cand = slow_walk(c, x, L, fallbacks);
-            if ((int)(cand & 0xFFFF) > L && !(c.P.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
+            if ((int)(cand & 0xFFFF) > L && !(Px.strategy == 1 && (cand & 0xFFFF) <= 5)) better = cand;
         }
     }
     if (better) { // previous position becomes a literal (:830-835)
@@ -177,10 +188,10 @@ __device__ __forceinline__ uint32_t find_seg(const SegDev *segs, uint32_t nseg, 
 }
 
 __device__ __forceinline__ ParseCtx make_ctx(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev &s,
-                                             LevelParams P) {
+                                             LevelParams P, const SegDev *sg) {
     ParseCtx c;
     c.d = in + s.buf_off; c.lk = link + s.buf_off; c.m2 = mtab.m2 + s.buf_off; c.mq = mtab.mq + s.buf_off;
-    c.seg_end = s.seg_end; c.look_end = s.look_end; c.abs0 = (int64_t)s.abs0; c.P = P;
+    c.seg_end = s.seg_end; c.look_end = s.look_end; c.abs0 = (int64_t)s.abs0; c.P = P; c.sg = sg; c.nsw = s.sw_cnt;
     // windows of a long stream keep a short tail of (unset) table entries past their parse end for the walk that crosses it
     c.tab_end = s.look_end > s.seg_end ? (s.seg_end + (int64_t)C_WIN_HALO < s.look_end ? s.seg_end + (int64_t)C_WIN_HALO : s.look_end) : s.seg_end;
     return c;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t 
     if (r >= nranges) return;
     uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     uint64_t lr = r - s.range_off;
     int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *
     uint64_t lr = r - s.range_off;
     bad_slot[r] = 0xFFFFFFFFu;
     if (lr == 0) return; // first range of a segment: entry = range start, speculative parse is the true one
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
     const int64_t entry = ranges[r - 1].exit_spec;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_
     if (si >= nseg) return;
     const SegDev s = segs[si];
     if (s.range_cnt < 2) return;
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const int lane = threadIdx.x;
     RangeDev *R = ranges + s.range_off;
     // Invariant: ranges [0, k) are final.  Range k is final iff its assumed entry == exit_true of k-1.
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_
     const uint64_t r = bad_range[slot];
     const uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
     const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t 
     if (si >= nseg) return;
     const SegDev s = segs[si];
     if (s.range_cnt < 2) return;
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const int lane = threadIdx.x;
     RangeDev *R = ranges + s.range_off;
     const uint32_t *slots = bad_slot + s.range_off;
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t 
     if (r >= nranges) return;
     uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     uint64_t lr = r - s.range_off;
     int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
     const uint64_t r = mine ? r0 : nranges - 1;
     const uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
     const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(64) void k_emit_win(const uint8_t *in, const uint16
     const uint64_t r = active ? r0 : nranges - 1;
     const uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
     const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(64) void k_emit_copy(const uint8_t *in, const uint1
     const uint64_t r = mine ? r0 : nranges - 1;
     const uint32_t si = find_seg(segs, nseg, r);
     const SegDev s = segs[si];
-    ParseCtx c = make_ctx(in, link, mtab, s, P);
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
     const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
     const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;

@@ -1,0 +1,135 @@
+"""SetLevel / SetStrategy in mid-stream (run with -m gpu): the streaming Deflater against the oracle's on random switch points.
+
+Reference: C/Deflater.cs:349-395 (SetLevel, SetStrategy) and C/DeflaterEngine.cs:304-361 (DeflaterEngine.SetLevel): within
+one compression function (levels 1-4 DeflateFast, 5-9 DeflateSlow) a call only replaces goodLength / max_lazy / niceLength /
+max_chain (and the strategy) for the iterations the engine has not run yet — and, once the caller has drained Deflate()
+until it returns 0, the engine stands where its loop stopped for want of lookahead: the first iteration start less than
+MIN_LOOKAHEAD = 262 bytes before the end of the input it was given.  The device parses a segment only at Flush()/Finish(),
+so it reproduces that position from the call history (a caller that changes the level while compressed bytes are still
+waiting in the reference's pending buffer gets the position of the drained pattern: DESIGN §7).
+Bit-exact, tolerance 0.
+"""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from sharpziplib_amd import corpus as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _drain(d, o, got, ref, buf):
+    while True:
+        k = d.Deflate(buf)
+        if k <= 0:
+            break
+        got += buf[:k].tobytes()
+    while True:
+        b = o.deflate(8192)
+        if not b:
+            break
+        ref += b
+
+
+def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_deflate_p=0.2, max_calls_per_segment=4):
+    from sharpziplib_amd.deflater import Deflater
+    rng = np.random.default_rng(seed)
+    data = np.concatenate([C.generate("enwik", seed, 0, total // 2), C.generate("logs", seed + 1, 0, total - total // 2)])
+    level = int(rng.choice(levels))
+    d, o = Deflater(level, True), O.Deflater(level, True)
+    got, ref = bytearray(), bytearray()
+    buf = np.zeros(8192, np.uint8)
+    pos, calls = 0, 0
+    log = []
+
+    def maybe_switch():
+        nonlocal calls
+        if calls >= max_calls_per_segment:
+            return
+        r = rng.random()
+        if r < 0.45:
+            lv = int(rng.choice(levels))
+            d.SetLevel(lv); o.set_level(lv)
+            if lv != d_level[0]:
+                calls += 1
+            d_level[0] = lv
+            log.append(("level", pos, lv))
+        elif r < 0.6 and len(strategies) > 1:
+            st = int(rng.choice(strategies))
+            if st != d_strat[0]:
+                calls += 1
+            d.SetStrategy(st); o.set_strategy(st)
+            d_strat[0] = st
+            log.append(("strategy", pos, st))
+
+    d_level, d_strat = [level], [0]
+    while pos < data.size:
+        n = int(rng.choice([1, 3, 100, 261, 262, 263, 700, 5000, 40000, 70000]))
+        c = data[pos:pos + n]
+        pos += c.size
+        d.SetInput(c); o.set_input(c)
+        if rng.random() < call_before_deflate_p:
+            maybe_switch()                         # the engine has not seen this chunk yet
+        assert d.Deflate(buf) == 0 and d.IsNeedingInput
+        while True:                                # drain until Deflate() returns 0: only then has the reference's engine run
+            b = o.deflate(8192)                    # as far as its lookahead allows (it pauses after every block while output
+            if not b:                              # is pending, C/DeflaterEngine.cs:126-139; IsNeedingInput alone says nothing
+                break                              # about that) — the position the device assumes, see DESIGN §7
+            ref += b
+        assert o.needs_input
+        maybe_switch()                             # the engine stopped within 261 bytes of the end of this chunk
+        if rng.random() < flush_p:
+            d.Flush(); o.flush()
+            _drain(d, o, got, ref, buf)
+            calls = 0
+            assert bytes(got) == bytes(ref), (seed, pos, log[-6:])
+    d.Finish(); o.finish()
+    while not d.IsFinished:
+        k = d.Deflate(buf)
+        assert k > 0
+        got += buf[:k].tobytes()
+    while not o.finished:
+        ref += o.deflate(8192)
+    assert bytes(got) == bytes(ref), (seed, log[-8:])
+    assert d.TotalIn == o.total_in == data.size
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_slow_levels_random_switch_points(seed):
+    _run([5, 6, 7, 8, 9], seed)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_slow_levels_with_strategy_changes(seed):
+    _run([5, 6, 9], seed, strategies=(0, 1, 2))
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_fast_levels_random_switch_points(seed):
+    _run([1, 2, 3, 4], seed, strategies=(0, 2))
+
+
+def test_switch_without_any_flush():
+    """one segment from the first byte to Finish(), four parameter changes inside"""
+    _run([5, 6, 8, 9], 31, total=900000, flush_p=0.0, max_calls_per_segment=4)
+
+
+def test_too_many_switches_is_reported_not_guessed():
+    from sharpziplib_amd.deflater import Deflater, NotSupportedOnDevice
+    d = Deflater(6, True)
+    buf = np.zeros(4096, np.uint8)
+    data = C.generate("enwik", 3, 0, 50000)
+    d.SetInput(data); d.Deflate(buf)
+    for lv in (7, 8, 9, 5):
+        d.SetLevel(lv)
+    with pytest.raises(NotSupportedOnDevice):
+        d.SetLevel(6)
+
+
+def test_compression_function_change_is_still_refused():
+    from sharpziplib_amd.deflater import Deflater, NotSupportedOnDevice
+    d = Deflater(6, True)
+    buf = np.zeros(4096, np.uint8)
+    d.SetInput(C.generate("enwik", 4, 0, 5000)); d.Deflate(buf)
+    with pytest.raises(NotSupportedOnDevice):
+        d.SetLevel(3)
