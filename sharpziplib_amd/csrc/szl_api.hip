@@ -470,6 +470,7 @@ struct szl_deflater {
     struct Sw { uint64_t abs_pos; int level, strategy; };
     std::vector<Sw> switches;
     int64_t engine_seen = 0;
+    bool hist_has_gaps = false;     // the history holds positions a DeflateFast level did not insert (beyond the segment-end rule)
     szl_engine *eng = nullptr;
     DevBuf d_in, d_out;
     std::vector<uint8_t> h_out;
@@ -481,7 +482,7 @@ static void deflater_clear(szl_deflater *d) {
     d->hist.clear(); d->hist_flags.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
     d->chunks.clear(); d->chunks_drained = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
     d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
-    d->switches.clear(); d->engine_seen = 0; d->base_level = d->level; d->base_strategy = d->strategy;
+    d->switches.clear(); d->engine_seen = 0; d->base_level = d->level; d->base_strategy = d->strategy; d->hist_has_gaps = false;
 }
 
 szl_deflater *szl_deflater_create(int level, int nowrap) {
@@ -517,7 +518,16 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
     if (level == d->level) return 0;                       // C/Deflater.cs:357
     // stored / fast / slow keep different hash-chain contents (level 0 inserts nothing, 1-4 skip long matches, :319-329,:697)
     // and the reference closes a block at the switch: only a fresh stream may change the compression function here
-    if (lvl_kind(level) != lvl_kind(d->level) && d->total_in != 0) { set_error("switching between DeflateStored / DeflateFast / DeflateSlow levels mid-stream is not supported"); return SZL_E_UNSUPPORTED; }
+    // and the reference closes a block at the switch.  DeflateFast <-> DeflateSlow is supported where that block is empty: right
+    // after a flush (nothing pending), the new function then finds exactly the chains the old one left (`hist_flags`).
+    if (lvl_kind(level) != lvl_kind(d->level) && d->total_in != 0) {
+        const bool fast_slow = lvl_kind(level) != 0 && lvl_kind(d->level) != 0;
+        if (!fast_slow || !d->pend.empty() || d->engine_seen != d->total_in) {
+            set_error(fast_slow ? "switching between DeflateFast and DeflateSlow levels is supported right after Flush() only"
+                                : "switching to or from level 0 (DeflateStored) mid-stream is not supported");
+            return SZL_E_UNSUPPORTED;
+        }
+    }
     if (!d->pend.empty() && level != 0) { int rc = pend_switch(d, level, d->strategy); if (rc) return rc; }
     else if (d->pend.empty()) d->base_level = level;
     d->level = level;
@@ -653,6 +663,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     Engine &E = d->eng->e;
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = true; }
+    else if (d->hist_has_gaps && H) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); }   // stage A must skip what DeflateFast skipped
     rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, d->nowrap ? 0u : 2u, res, nullptr);
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (rc) return rc;
@@ -684,7 +695,22 @@ static int run_segment(szl_deflater *d, bool finish) {
             if (p >= 0 && (size_t)(p >> 5) < E.fast_tail_bits.size() && ((E.fast_tail_bits[(size_t)(p >> 5)] >> (p & 31)) & 1u)) nf[q >> 5] |= 1u << (q & 31);
         }
         d->hist_flags.swap(nf);
-    } else d->hist_flags.clear();
+        d->hist_has_gaps = true;
+    } else { // DeflateSlow inserts every position that has three bytes of lookahead (:780): all but the last two of the segment
+        std::vector<uint32_t> nf((keep + 31) / 32, 0u);
+        const uint64_t first = H + n - keep;
+        bool gaps = false;
+        for (uint64_t q = 0; q < keep; q++) {
+            const uint64_t bp = first + q;                 // buffer position before the slide
+            bool ins;
+            if (bp < H) ins = !d->hist_flags.empty() && (size_t)(bp >> 5) < d->hist_flags.size() ? ((d->hist_flags[(size_t)(bp >> 5)] >> (bp & 31)) & 1u) != 0 : true;
+            else ins = bp + 3 <= H + n;
+            if (ins) nf[q >> 5] |= 1u << (q & 31);
+            else if (bp < H) gaps = true;
+        }
+        if (d->hist_has_gaps) d->hist_has_gaps = gaps;   // fast-era bytes have left the history
+        d->hist_flags.swap(nf);
+    }
     d->hist_abs = d->hist_abs + H + n - keep;
     d->hist.swap(nh);
     d->pend.clear();

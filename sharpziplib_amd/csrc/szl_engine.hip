@@ -14,7 +14,7 @@ namespace szl {
 
 // ---- launch wrappers implemented in the kernel translation units
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans, int nspans,
-                  uint16_t *link, hipStream_t st);
+                  uint16_t *link, const uint32_t *hflags, hipStream_t st);
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
@@ -114,7 +114,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &hist_flags_dev})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -283,7 +283,16 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     }
     HIPCHK(hipEventRecord(ev[1], st));
     // A: hash links
-    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, st);
+    const uint32_t *d_hflags = nullptr;
+    if (!fast && !fast_hist_in.empty() && nseg == 1 && segs[0].seg_start > 0) {
+        // the history holds bytes a DeflateFast level compressed (SetLevel 1-4 -> 5-9 at a flush): only the positions it
+        // inserted are in the hash chains (C/DeflaterEngine.cs:697-712); bit q = buffer position q
+        std::vector<uint32_t> hf(fast_hist_in);
+        hf.resize(((size_t)segs[0].seg_start + 31) / 32 + 1, 0u);
+        if ((rc = upload(hist_flags_dev, hf, st))) return rc;
+        d_hflags = (const uint32_t *)hist_flags_dev.p;
+    }
+    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, d_hflags, st);
     HIPCHK(hipEventRecord(ev[2], st));
     if (fast) {
         // B+C for DeflateFast: sequential greedy parse, one wavefront per segment (szl_kernels_fast.hip)
@@ -552,7 +561,7 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         HIPCHK(hipMemsetAsync(counters.p, 0, 8, st));             // counter 0: ranges of THIS window that never merged
         HIPCHK(hipEventRecord(ev[1], st));
         // the launch wrappers index segs[span.seg] / segs[tile.seg]: entry 1 of d_segs is the window
-        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, st);
+        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, nullptr, st);
         HIPCHK(hipEventRecord(ev[2], st));
         if (wi == 0 && match_mode == 2 && ntiles >= 64) {          // the pilot (see deflate()): once, on the first window
             const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8));

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
 // ============================================================================================
 __global__ __launch_bounds__(A_THREADS) void k_links2(const uint8_t *__restrict__ in, uint64_t in_total,
                                                       const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
-                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link) {
+                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link,
+                                                      const uint32_t *__restrict__ hflags) {
     __shared__ uint16_t head[32768];
     __shared__ uint32_t cnt[2][A_WAVES * 16];  // [owner*16 + wave] = positions of that wave's slice owned by `owner`
     __shared__ uint32_t list[2][A_THREADS];    // (position in chunk) << 16 | bucket (11 bits), grouped by owner
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(A_THREADS) void k_links2(const uint8_t *__restrict_
             while (j < nb && (int64_t)b[j] <= q) j++;
             ins = ins && j < nb && (int64_t)b[j] - q >= 3;
         }
+        if (hflags && ins && q < seg.seg_start) ins = (hflags[q >> 5] >> (q & 31)) & 1u; // history a DeflateFast level left: only inserted positions
         uint32_t owner = 16, bucket = 0;
         if (ins) {
             uint32_t w = wcur;
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(64) void k_probe_xchg_order(int rounds, int *ok_out
 
 __global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict__ in, uint64_t in_total,
                                                       const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
-                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link) {
+                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link,
+                                                      const uint32_t *__restrict__ hflags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem3[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // LDS byte addresses for the hand-written part (the compiler turns volatile accesses through generic pointers into
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict_
                 while (j < nb && (int64_t)b[j] <= q) j++;
                 ins = ins && j < nb && (int64_t)b[j] - q >= 3;
             }
+            if (hflags && ins && q < seg.seg_start) ins = (hflags[q >> 5] >> (q & 31)) & 1u; // history a DeflateFast level left: only inserted positions
             uint32_t h = 0;
             if (ins) {
                 uint32_t w = wcur;
@@ -965,8 +969,9 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
     }
 }
 
+// hflags (optional, single streaming segment): bit q = buffer position q of the history was inserted into the hash chains
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
-                  int nspans, uint16_t *link, hipStream_t st) {
+                  int nspans, uint16_t *link, const uint32_t *hflags, hipStream_t st) {
     if (nspans <= 0) return;
     const int which = knob("SZL_LINKS", 3);   // 3 = pipelined (ticket) form, 2 = bucketed by owner wavefront, 1 = first form
     static std::atomic<uint64_t> probe_done{0}, probe_ok{0};   // per device: does ds_wrxchg serve the lanes in ascending order?
@@ -984,9 +989,9 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
         probe_done.fetch_or(dev_bit, std::memory_order_release);
     }
     if (which == 3 && (probe_ok.load(std::memory_order_acquire) & dev_bit)) {
-        hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link);
-    } else if (which == 1) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
-    else hipLaunchKernelGGL(k_links2, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
+        hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link, hflags);
+    } else if (which == 1 && !hflags) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
+    else hipLaunchKernelGGL(k_links2, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link, hflags);
 }
 
 int match_lds_bytes() { return B_LDS_BYTES; }

@@ -209,11 +209,11 @@ def test_deflater_state_errors():
     out = np.zeros(64, np.uint8)
     n = d.Deflate(out)
     assert out[:n].tobytes() == O.deflate(b"abc", 6) and d.IsFinished
-    d = Deflater(1, True)     # DeflateFast -> DeflateSlow mid-stream changes what the hash chains hold: not reproducible here
+    d = Deflater(1, True)     # to or from DeflateStored mid-stream: not reproduced here (tests/test_gpu_setlevel.py has what is)
     d.SetInput(b"abcabcabc"); d.Flush()
     d.Deflate(out)
     with pytest.raises(NotSupportedOnDevice):
-        d.SetLevel(6)
+        d.SetLevel(0)
 
 
 def test_streaming_random_chunks_and_flushes():

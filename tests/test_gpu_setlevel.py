@@ -31,7 +31,8 @@ def _drain(d, o, got, ref, buf):
         ref += b
 
 
-def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_deflate_p=0.2, max_calls_per_segment=4):
+def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_deflate_p=0.2, max_calls_per_segment=4,
+         cross_kind_at_flush=False):
     from sharpziplib_amd.deflater import Deflater
     rng = np.random.default_rng(seed)
     data = np.concatenate([C.generate("enwik", seed, 0, total // 2), C.generate("logs", seed + 1, 0, total - total // 2)])
@@ -48,7 +49,7 @@ def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_
             return
         r = rng.random()
         if r < 0.45:
-            lv = int(rng.choice(levels))
+            lv = int(rng.choice([l for l in levels if (l < 5) == (d_level[0] < 5)]))   # the same compression function
             d.SetLevel(lv); o.set_level(lv)
             if lv != d_level[0]:
                 calls += 1
@@ -83,6 +84,11 @@ def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_
             _drain(d, o, got, ref, buf)
             calls = 0
             assert bytes(got) == bytes(ref), (seed, pos, log[-6:])
+            if cross_kind_at_flush and rng.random() < 0.6:      # DeflateFast <-> DeflateSlow: right after a flush
+                lv = int(rng.choice(levels))
+                d.SetLevel(lv); o.set_level(lv)
+                d_level[0] = lv
+                log.append(("level@flush", pos, lv))
     d.Finish(); o.finish()
     while not d.IsFinished:
         k = d.Deflate(buf)
@@ -109,6 +115,13 @@ def test_fast_levels_random_switch_points(seed):
     _run([1, 2, 3, 4], seed, strategies=(0, 2))
 
 
+@pytest.mark.parametrize("seed", [41, 42, 43, 44, 45, 46])
+def test_fast_and_slow_levels_alternate_at_flushes(seed):
+    """SetLevel across DeflateFast / DeflateSlow right after Flush(): the new function walks the hash chains the old one left —
+    DeflateFast does not insert the inside of long matches (C/DeflaterEngine.cs:697-712), DeflateSlow inserts everything."""
+    _run([1, 2, 3, 4, 5, 6, 7, 9], seed, flush_p=0.4, cross_kind_at_flush=True)
+
+
 def test_switch_without_any_flush():
     """one segment from the first byte to Finish(), four parameter changes inside"""
     _run([5, 6, 8, 9], 31, total=900000, flush_p=0.0, max_calls_per_segment=4)
@@ -126,10 +139,16 @@ def test_too_many_switches_is_reported_not_guessed():
         d.SetLevel(6)
 
 
-def test_compression_function_change_is_still_refused():
+def test_compression_function_change_with_pending_bytes_is_refused():
     from sharpziplib_amd.deflater import Deflater, NotSupportedOnDevice
     d = Deflater(6, True)
     buf = np.zeros(4096, np.uint8)
     d.SetInput(C.generate("enwik", 4, 0, 5000)); d.Deflate(buf)
     with pytest.raises(NotSupportedOnDevice):
-        d.SetLevel(3)
+        d.SetLevel(3)                  # DeflateSlow -> DeflateFast with bytes pending: the reference closes a block mid-segment
+    d.Flush()
+    while d.Deflate(buf) > 0:
+        pass
+    with pytest.raises(NotSupportedOnDevice):
+        d.SetLevel(0)                  # DeflateStored mid-stream
+    d.SetLevel(3)                      # right after a flush: fine
