@@ -57,7 +57,7 @@ struct SegDev {
     // iteration start within MIN_LOOKAHEAD - 1 of the input it has, so "every iteration start >= that threshold" is exactly
     // "every iteration after the call".
     uint32_t sw_cnt;
-    uint32_t sw_pad;
+    uint32_t range_len;  // positions per stage-C range (C_RANGE; shorter for small calls: the ranges are walked serially, latency counts there)
     int64_t sw_pos[SEG_MAX_SWITCH];
     LevelParams sw_P[SEG_MAX_SWITCH];
     int64_t look_end;      // buffer position one past the last byte the ENGINE HAS SEEN (lookahead, FillWindow :379-394).  Equals

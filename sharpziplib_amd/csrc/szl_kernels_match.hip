@@ -979,7 +979,7 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
     if (which == 3 && lds_attr_needed(probe_done, dev_bit)) {
         int *d_ok = nullptr, h_ok = 0;
         if (hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess) {
-            hipLaunchKernelGGL(k_probe_xchg_order, dim3(1), dim3(64), 0, st, 4096, d_ok);
+            hipLaunchKernelGGL(k_probe_xchg_order, dim3(1), dim3(64), 0, st, 512, d_ok);
             if (hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) h_ok = 0;
             (void)hipFree(d_ok);
         }

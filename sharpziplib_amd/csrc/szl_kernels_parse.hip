@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t 
     const SegDev s = segs[si];
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     uint64_t lr = r - s.range_off;
-    int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     // each range owns whole words of its segment's bitmap (C_RANGE is a multiple of 32): plain stores, no atomics
     uint32_t *vis = visited + s.vis_word_off;
     int64_t x = rs;
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *
     bad_slot[r] = 0xFFFFFFFFu;
     if (lr == 0) return; // first range of a segment: entry = range start, speculative parse is the true one
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
-    int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     const int64_t entry = ranges[r - 1].exit_spec;
     uint32_t merged, count;
     int64_t ex;
@@ -318,8 +318,8 @@ __global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_
             if (m == 0) break;
             int l = __builtin_ctzll(m);
             if (lane == l) { // redo this range from the true exit of its predecessor
-                int64_t rs = s.seg_start + (int64_t)k * C_RANGE;
-                int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+                int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
+                int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
                 const int64_t entry = R[k - 1].exit_true;
                 uint32_t merged, count;
                 int64_t ex;
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_
     const SegDev s = segs[si];
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
-    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    const int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     int64_t x = rs + j, tp;
     uint32_t count = 0;
     if (x < s.seg_end) {
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t 
         if (lane == 0) {
             for (uint32_t i = 0; i < nk; i++) {
                 const uint32_t k = k0 + i;
-                const int64_t rs = s.seg_start + (int64_t)k * C_RANGE;
-                const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+                const int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
+                const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
                 const int64_t e = prev_exit;
                 if (e == s_entry[i]) { prev_exit = s_exit[i]; continue; }           // the assumption of k_fix holds
                 s_entry[i] = e;
@@ -423,11 +423,11 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if ((uint32_t)lane < nk && s_chg[lane]) {
             const uint32_t k = k0 + lane;
-            const int64_t rs = s.seg_start + (int64_t)k * C_RANGE;
+            const int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
             uint32_t cnt = s_cnt[lane], mrg = s_mrg[lane];
             if (s_chg[lane] == 1) {
                 const int64_t j = s_entry[lane] - rs;
-                cnt = s_entry[lane] >= (rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end) ? 0u : cnmap[(uint64_t)s_slot[lane] * X_W + j];
+                cnt = s_entry[lane] >= (rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end) ? 0u : cnmap[(uint64_t)s_slot[lane] * X_W + j];
                 mrg = 0;
             }
             R[k].entry = s_entry[lane]; R[k].exit_true = s_exit[lane]; R[k].true_count = cnt; R[k].merged = mrg;
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t 
     const SegDev s = segs[si];
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     uint64_t lr = r - s.range_off;
-    int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     int64_t x = lr == 0 ? rs : ranges[r].entry;
     int L = 0, D = 0;
     uint64_t ti = range_tok[r];
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
     const SegDev s = segs[si];
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
-    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    const int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     uint32_t *vis = visited + s.vis_word_off;
     int64_t x = rs;
     int L = 0, D = 0;
@@ -639,8 +639,8 @@ __global__ __launch_bounds__(64) void k_emit_win(const uint8_t *in, const uint16
     const SegDev s = segs[si];
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
-    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    const int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     int64_t x = lr == 0 ? rs : ranges[r].entry;
     int L = 0, D = 0;
     uint64_t ti = range_tok[r];
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(64) void k_emit_copy(const uint8_t *in, const uint1
     const SegDev s = segs[si];
     ParseCtx c = make_ctx(in, link, mtab, s, P, segs + si);
     const uint64_t lr = r - s.range_off;
-    const int64_t rs = s.seg_start + (int64_t)lr * C_RANGE;
-    const int64_t re = rs + C_RANGE < s.seg_end ? rs + C_RANGE : s.seg_end;
+    const int64_t rs = s.seg_start + (int64_t)lr * (int64_t)s.range_len;
+    const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     const uint32_t *vis = visited + s.vis_word_off;
     const RangeDev rd = ranges[r];
     uint64_t ti = range_tok[r];

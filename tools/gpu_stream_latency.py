@@ -1,0 +1,49 @@
+"""Streaming-API latency (GPU box): the ZipOutputStream pattern — one Deflater.Reset() + SetInput + Finish() + Deflate() drain
+per small entry (S/Zip/ZipOutputStream.cs:494,582-640) — against the same entries as ONE batched call.
+Usage: python tools/gpu_stream_latency.py [--entries 2000] [--kib 64] [--level 6]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from sharpziplib_amd import corpus
+from sharpziplib_amd.deflater import Deflater
+from sharpziplib_amd.batch import Engine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--entries", type=int, default=2000)
+ap.add_argument("--kib", type=int, default=64)
+ap.add_argument("--level", type=int, default=6)
+a = ap.parse_args()
+n = a.kib << 10
+data = corpus.generate("enwik", 5, 0, n * a.entries)
+d = Deflater(a.level, True)
+buf = np.zeros(n + 4096, np.uint8)
+outs = []
+def one(i):
+    d.Reset()
+    d.SetInput(data[i * n:(i + 1) * n])
+    d.Finish()
+    tot = 0
+    while not d.IsFinished:
+        k = d.Deflate(buf)
+        tot += k
+    return tot
+for i in range(20):
+    one(i)                                    # warm-up (allocations, code objects)
+t0 = time.perf_counter()
+tot = 0
+for i in range(a.entries):
+    tot += one(i)
+t1 = time.perf_counter()
+ms = (t1 - t0) * 1e3 / a.entries
+print("streaming object: %d entries of %d KiB, level %d: %.3f ms per entry = %.1f MiB/s (ratio %.3f)" % (
+    a.entries, a.kib, a.level, ms, a.kib / 1024.0 / (ms / 1e3), tot / (n * a.entries)), flush=True)
+eng = Engine()
+bufs = [data[i * n:(i + 1) * n] for i in range(a.entries)]
+eng.deflate(bufs[:64], level=a.level)
+t0 = time.perf_counter()
+res = eng.deflate(bufs, level=a.level)
+t1 = time.perf_counter()
+print("one batched call (host buffers in and out): %.3f ms per entry = %.1f MiB/s" % (
+    (t1 - t0) * 1e3 / a.entries, a.entries * a.kib / 1024.0 / (t1 - t0)), flush=True)
+assert sum(len(r.data) for r in res) == tot
