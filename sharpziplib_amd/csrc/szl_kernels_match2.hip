@@ -72,6 +72,8 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
     "ds_read_u8 %[t1" #X "], %[t1" #X "] offset:1\n\t"
 // t0 = prev[] hop, t2 / t1 = the candidate's bytes at best_len - 1 / best_len (scan_end1, scan_end: :505-506).  Testing both
 // sends 40 % fewer candidates to VERIFY on text than scan_end alone (3.55 -> 2.15 per position; 18.3 -> 5.7 on logs at level 9).
+// Two byte reads on purpose: ONE ds_read_u16 at the (odd or even) byte address was measured at 103 instead of 64 ms per GiB
+// (profiles/r02/lab_s21_unaligned_u16.log) — every LDS access that is not naturally aligned is replayed, not only 32-bit ones.
 // The lanes that stay advance in place; a lane that leaves because the bytes match keeps `cl` (the candidate to compare).
 #define SZL_Q_FINISH(X) \
     "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 8, %[t2" #X "]\n\t" \
