@@ -214,8 +214,13 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
+    // (each long member costs a handful of host round trips: with many of them in one call the batch already fills the device
+    // with one wavefront per stream, and that form has no per-stream host work at all)
+    size_t n_long = 0;
+    for (size_t i = 0; i < n_all; i++) n_long += streams[i].in_len >= par_min ? 1 : 0;
+    const bool use_par = n_long > 0 && n_long <= (size_t)std::max(1, knob("SZL_INF_PAR_MAX_STREAMS", 32));
     for (size_t i = 0; i < n_all; i++) {
-        if (streams[i].in_len >= par_min) {
+        if (use_par && streams[i].in_len >= par_min) {
             (void)hipEventRecord(e->e.ev[0], st);
             rc = inflate_member_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams[i], !nowrap, st, &par_res[i]);
             if (rc < 0) return rc;
