@@ -3,6 +3,8 @@
 // TotalIn/TotalOut :862/:848, Adler :823, Reset :188.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -17,9 +19,10 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
 void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st);
-void launch_find_blocks(const uint8_t *in, uint64_t in_len, uint64_t chunk_bytes, uint32_t nchunks, uint64_t *start_bit, hipStream_t st);
-void launch_resolve_wins(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, uint8_t *wins, hipStream_t st);
-void launch_convert(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, const uint8_t *wins, uint8_t *out, uint64_t total, hipStream_t st);
+void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st);
+void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st);
+void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint8_t *wins, uint8_t *out_base, const ParMember *mem, uint32_t nmem,
+                    uint32_t nblocks, hipStream_t st);
 }
 struct szl_engine { Engine e; };
 
@@ -74,124 +77,217 @@ done:
 // the one checked against the reference — or a negative szl_status for device failures.
 struct ParResult { uint64_t out_written, consumed; uint32_t adler_read; };
 
-static int inflate_member_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_out, const szl_stream &s, bool zlib, hipStream_t st, ParResult *res) {
-    const uint64_t chunk_bytes = (uint64_t)std::max(16, knob("SZL_INF_CHUNK_KIB", 128)) * 1024;
-    if (s.in_len < 4 * chunk_bytes || s.in_len >= (1ull << 60)) return 0;
-    const uint8_t *in = d_in + s.in_off;
-    uint64_t first_bit = 0;
-    if (zlib) { // C/Inflater.cs:211-249; a preset dictionary or a bad header is the sequential decoder's business
-        uint8_t h[2];
-        HIPCHK(hipMemcpyAsync(E.pin, in, 2, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
-        memcpy(h, E.pin, 2);
-        const uint32_t hv = ((uint32_t)h[0] << 8) | h[1];
-        if (hv % 31 != 0 || (hv & 0x0f00) != (8u << 8) || (hv & 0x0020)) return 0;
-        first_bit = 16;
-    }
-    const uint32_t nchunks = (uint32_t)std::min<uint64_t>((s.in_len + chunk_bytes - 1) / chunk_bytes, 1u << 20);
-    int rc;
-    if ((rc = E.inf_misc.ensure((uint64_t)nchunks * 8 + 64))) return rc;
-    uint64_t *d_start = (uint64_t *)E.inf_misc.p;
-    launch_find_blocks(in, s.in_len, chunk_bytes, nchunks, d_start, st);
-    std::vector<uint64_t> starts(nchunks);
-    HIPCHK(hipMemcpyAsync(starts.data(), d_start, (uint64_t)nchunks * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint64_t> sb;            // start bits of the jobs, ascending
-    sb.push_back(first_bit);
-    for (uint32_t c = 1; c < nchunks; c++) if (starts[c] != ~0ull && starts[c] > sb.back()) sb.push_back(starts[c]);
-    if (sb.size() < 4) return 0;
-
+// Several members at once: the passes of all of them share their launches and their host round trips (a call with 128
+// members of a few MiB each would otherwise pay ~6 round trips per member, or — through the one-wavefront decoder — run
+// on 128 wavefronts).  `cand` = indices of the candidate streams; taken[i] / res[i] are set for the streams decoded here.
+static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_out, const szl_stream *streams, const std::vector<size_t> &cand,
+                                    bool zlib, hipStream_t st, std::vector<char> &taken, std::vector<ParResult> &res) {
     struct Cnt { uint64_t end_bit, out; int status; };
+    struct PS {
+        size_t si;                       // index into streams
+        uint64_t chunk_bytes, first_bit;
+        uint32_t nchunks; uint64_t start_off;   // its slice of the candidate-start array
+        std::vector<uint64_t> sb;        // start bits of its jobs, ascending
+        std::vector<Cnt> cnt; std::vector<char> have;
+        bool alive = true, ok = false;
+        std::vector<uint64_t> ooff; uint64_t total = 0, end_byte = 0; uint32_t adler_read = 0;
+        uint64_t sym_off = 0, win_off = 0, ooff_off = 0;   // offsets (elements / bytes) into the shared staging buffers
+    };
+    std::vector<PS> ps;
+    const bool dbg = knob("SZL_DEBUG", 0) != 0;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(st); const double t = now(); fprintf(stderr, "[szl] inflate par: %-28s %8.2f ms\n", what, t - t_prev); t_prev = t; } };
+    const uint64_t chunk_max = (uint64_t)std::max(16, knob("SZL_INF_CHUNK_KIB", 128)) * 1024;
+    uint64_t nstart_total = 0;
+    for (size_t ci : cand) {
+        const szl_stream &s = streams[ci];
+        PS p; p.si = ci;
+        uint64_t cb = s.in_len / 32;                              // short members get smaller chunks: at least ~32 of them
+        cb = std::min<uint64_t>(std::max<uint64_t>(cb & ~1023ull, 16384), chunk_max);
+        p.chunk_bytes = cb;
+        if (s.in_len < 8 * cb || s.in_len >= (1ull << 60)) continue;
+        p.nchunks = (uint32_t)std::min<uint64_t>((s.in_len + cb - 1) / cb, 1u << 20);
+        p.first_bit = 0; p.start_off = nstart_total; nstart_total += p.nchunks;
+        ps.push_back(std::move(p));
+    }
+    if (ps.empty()) return 0;
+    int rc;
+    if (zlib) { // C/Inflater.cs:211-249; a preset dictionary or a bad header is the sequential decoder's business
+        std::vector<uint8_t> hdr(2 * ps.size());
+        for (size_t k = 0; k < ps.size(); k++) HIPCHK(hipMemcpyAsync(hdr.data() + 2 * k, d_in + streams[ps[k].si].in_off, 2, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t k = 0; k < ps.size(); k++) {
+            const uint32_t hv = ((uint32_t)hdr[2 * k] << 8) | hdr[2 * k + 1];
+            if (hv % 31 != 0 || (hv & 0x0f00) != (8u << 8) || (hv & 0x0020)) ps[k].alive = false;
+            ps[k].first_bit = 16;
+        }
+    }
+    // ---- 1. candidate starts: one finder job per chunk (chunk 0 starts at the member's first block)
+    std::vector<FindJob> fj(nstart_total, FindJob{0, 0, 0, 0});
+    for (auto &p : ps) {
+        if (!p.alive) continue;
+        for (uint32_t c = 1; c < p.nchunks; c++)
+            fj[p.start_off + c] = FindJob{streams[p.si].in_off, streams[p.si].in_len, (uint64_t)c * p.chunk_bytes * 8, (uint64_t)(c + 1) * p.chunk_bytes * 8};
+    }
+    if (nstart_total > 0x7FFFFFFFull) return SZL_E_ARG;
+    if ((rc = E.inf_misc.ensure(nstart_total * 8 + 64)) || (rc = E.inf_jobs.ensure(nstart_total * sizeof(FindJob)))) return rc;
+    uint64_t *d_start = (uint64_t *)E.inf_misc.p;
+    HIPCHK(hipMemcpyAsync(E.inf_jobs.p, fj.data(), nstart_total * sizeof(FindJob), hipMemcpyHostToDevice, st));
+    launch_find_blocks(d_in, (const FindJob *)E.inf_jobs.p, (uint32_t)nstart_total, d_start, st);   // (jobs with an empty range report "none")
+    std::vector<uint64_t> starts(nstart_total);
+    HIPCHK(hipMemcpyAsync(starts.data(), d_start, nstart_total * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+    lap("find block starts");
+    for (auto &p : ps) {
+        if (!p.alive) continue;
+        p.sb.push_back(p.first_bit);
+        for (uint32_t c = 1; c < p.nchunks; c++) { const uint64_t v = starts[p.start_off + c]; if (v != ~0ull && v > p.sb.back()) p.sb.push_back(v); }
+        if (p.sb.size() < 4) { p.alive = false; continue; }
+        p.cnt.assign(p.sb.size(), Cnt{}); p.have.assign(p.sb.size(), 0);
+    }
+    // one launch of a pass over (stream, job) pairs
+    struct Ref { uint32_t k, j; };
     std::vector<InfJob> jobs;
-    std::vector<Cnt> cnt;                // count-pass result per job, keyed like sb
-    std::vector<char> have;
-    auto run_pass = [&](int pass, const std::vector<uint32_t> &which, uint16_t *sym, const std::vector<uint64_t> *ooff) -> int {
-        const uint32_t n = (uint32_t)which.size();
+    auto run_pass = [&](int pass, const std::vector<Ref> &which, uint16_t *sym) -> int {
+        const size_t n = which.size();
+        if (!n) return 0;
+        if (n > 0x7FFFFFFFull) return SZL_E_ARG;
         jobs.assign(n, InfJob{});
-        for (uint32_t k = 0; k < n; k++) {
-            const uint32_t j = which[k];
-            InfJob &jb = jobs[k];
-            jb.in_off = 0; jb.in_len = s.in_len; jb.out_cap = ~0ull >> 2;
-            jb.start_bit = sb[j]; jb.stop_bit = j + 1 < sb.size() ? sb[j + 1] : ~0ull;
-            jb.sym_out = sym ? sym + (*ooff)[j] : nullptr;
+        for (size_t q = 0; q < n; q++) {
+            const PS &p = ps[which[q].k]; const uint32_t j = which[q].j;
+            InfJob &jb = jobs[q];
+            jb.in_off = streams[p.si].in_off; jb.in_len = streams[p.si].in_len; jb.out_cap = ~0ull >> 2;
+            jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : ~0ull;
+            jb.sym_out = sym ? sym + p.sym_off + p.ooff[j] : nullptr;
         }
         int r;
-        if ((r = E.inf_jobs.ensure((uint64_t)n * sizeof(InfJob))) || (r = E.inf_states.ensure((uint64_t)n * sizeof(InfState)))) return r;
-        HIPCHK(hipMemcpyAsync(E.inf_jobs.p, jobs.data(), (uint64_t)n * sizeof(InfJob), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemsetAsync(E.inf_states.p, 0, (uint64_t)n * sizeof(InfState), st));
-        launch_inflate_chunks(in, (InfJob *)E.inf_jobs.p, (InfState *)E.inf_states.p, n, pass, st);
-        HIPCHK(hipMemcpyAsync(jobs.data(), E.inf_jobs.p, (uint64_t)n * sizeof(InfJob), hipMemcpyDeviceToHost, st));
+        if ((r = E.inf_jobs.ensure(n * sizeof(InfJob))) || (r = E.inf_states.ensure(n * sizeof(InfState)))) return r;
+        HIPCHK(hipMemcpyAsync(E.inf_jobs.p, jobs.data(), n * sizeof(InfJob), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(E.inf_states.p, 0, n * sizeof(InfState), st));
+        launch_inflate_chunks(d_in, (InfJob *)E.inf_jobs.p, (InfState *)E.inf_states.p, (uint32_t)n, pass, st);
+        HIPCHK(hipMemcpyAsync(jobs.data(), E.inf_jobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         return 0;
     };
-
-    // ---- count pass + chain repair
-    cnt.assign(sb.size(), Cnt{});
-    have.assign(sb.size(), 0);
-    bool ok = false;
-    for (int iter = 0; iter < 6 && !ok; iter++) {
-        std::vector<uint32_t> which;
-        for (uint32_t j = 0; j < sb.size(); j++) if (!have[j]) which.push_back(j);
-        if (!which.empty()) {
-            if ((rc = run_pass(1, which, nullptr, nullptr))) return rc;
-            for (uint32_t k = 0; k < which.size(); k++) { cnt[which[k]] = Cnt{jobs[k].end_bit, jobs[k].out_written, jobs[k].status}; have[which[k]] = 1; }
+    // ---- 2. count pass + chain repair (per member; the launches are shared)
+    for (int iter = 0; iter < 6; iter++) {
+        std::vector<Ref> which;
+        for (uint32_t k = 0; k < ps.size(); k++) {
+            PS &p = ps[k];
+            if (!p.alive || p.ok) continue;
+            for (uint32_t j = 0; j < p.sb.size(); j++) if (!p.have[j]) which.push_back(Ref{k, j});
         }
-        // walk the chain from job 0; keep the starts it visits
-        std::vector<uint64_t> nsb; std::vector<Cnt> ncnt; std::vector<char> nhave;
-        uint32_t j = 0;
-        ok = true;
-        for (;;) {
-            nsb.push_back(sb[j]); ncnt.push_back(cnt[j]); nhave.push_back(1);
-            const Cnt &c = cnt[j];
-            if (c.status == INF_FINISHED) break;                   // the member's last block ended inside this job
-            if (c.status != INF_CHUNK_END) return 0;               // an error on the chain is a real error of the stream
-            uint32_t m = j + 1;
-            while (m < sb.size() && sb[m] < c.end_bit) m++;        // starts the real decode ran over: false candidates
-            if (m < sb.size() && sb[m] == c.end_bit) { j = m; continue; }
-            // nobody starts where this job ended: a new job starts there (its stop is the next candidate), counted next round.
-            // The job that ended there ran with a different stop before, but a decode that stops at the first block boundary
-            // >= stop also stops there for any stop in (previous boundary, end_bit] — its count stays valid.
-            ok = false;
-            nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
-            for (; m < sb.size(); m++) { nsb.push_back(sb[m]); ncnt.push_back(cnt[m]); nhave.push_back(have[m]); }
-            break;
+        if ((rc = run_pass(1, which, nullptr))) return rc;
+        for (size_t q = 0; q < which.size(); q++) {
+            PS &p = ps[which[q].k];
+            p.cnt[which[q].j] = Cnt{jobs[q].end_bit, jobs[q].out_written, jobs[q].status}; p.have[which[q].j] = 1;
         }
-        if (!ok) {
-            // jobs in front of a changed stop must be recounted unless they ended on the chain already (those are kept above)
-            sb.swap(nsb); cnt.swap(ncnt); have.swap(nhave);
-            continue;
+        bool pending = false;
+        for (auto &p : ps) {
+            if (!p.alive || p.ok) continue;
+            // walk the chain from job 0; keep the starts it visits
+            std::vector<uint64_t> nsb; std::vector<Cnt> ncnt; std::vector<char> nhave;
+            uint32_t j = 0;
+            bool ok = true;
+            for (;;) {
+                nsb.push_back(p.sb[j]); ncnt.push_back(p.cnt[j]); nhave.push_back(1);
+                const Cnt &c = p.cnt[j];
+                if (c.status == INF_FINISHED) break;               // the member's last block ended inside this job
+                if (c.status != INF_CHUNK_END) { p.alive = false; break; }   // an error on the chain is a real error of the stream
+                uint32_t m = j + 1;
+                while (m < p.sb.size() && p.sb[m] < c.end_bit) m++;  // starts the real decode ran over: false candidates
+                if (m < p.sb.size() && p.sb[m] == c.end_bit) { j = m; continue; }
+                // nobody starts where this job ended: a new job starts there, counted next round.  (The job that ended there
+                // ran with an earlier stop, but a decode that stops at the first block boundary >= stop also stops there for
+                // any stop in (previous boundary, end_bit]: its count stays valid.)
+                ok = false;
+                nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
+                for (; m < p.sb.size(); m++) { nsb.push_back(p.sb[m]); ncnt.push_back(p.cnt[m]); nhave.push_back(p.have[m]); }
+                break;
+            }
+            if (!p.alive) continue;
+            p.sb.swap(nsb); p.cnt.swap(ncnt); p.have.swap(nhave);
+            if (ok) p.ok = true; else pending = true;
         }
-        sb.swap(nsb); cnt.swap(ncnt); have.swap(nhave);
+        if (dbg) fprintf(stderr, "[szl] inflate par: count pass %d over %zu jobs\n", iter, which.size());
+        if (!pending) break;
     }
-    if (!ok) return 0;
-    const uint32_t nj = (uint32_t)sb.size();
-    if (cnt[nj - 1].status != INF_FINISHED) return 0;              // truncated member: NEED_INPUT semantics belong to the sequential path
-    std::vector<uint64_t> ooff(nj + 1);
-    uint64_t total = 0;
-    for (uint32_t j = 0; j < nj; j++) { ooff[j] = total; total += cnt[j].out; }
-    ooff[nj] = total;
-    if (total > s.out_cap) return 0;                               // SZL_E_OUTPUT_TOO_SMALL with the bytes that fit: sequential path
-    uint64_t end_byte = (cnt[nj - 1].end_bit + 7) >> 3;
-    uint32_t adler_read = 0;
+    lap("count passes");
+    // ---- layout of what was proven
+    uint64_t sym_total = 0, win_total = 0, ooff_total = 0, njobs_total = 0;
+    std::vector<uint32_t> good;
+    for (uint32_t k = 0; k < ps.size(); k++) {
+        PS &p = ps[k];
+        if (!p.alive || !p.ok) continue;
+        const uint32_t nj = (uint32_t)p.sb.size();
+        if (p.cnt[nj - 1].status != INF_FINISHED) continue;        // truncated member: NEED_INPUT semantics belong to the sequential path
+        p.ooff.assign(nj + 1, 0);
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < nj; j++) { p.ooff[j] = total; total += p.cnt[j].out; }
+        p.ooff[nj] = total; p.total = total;
+        if (total > streams[p.si].out_cap) continue;               // SZL_E_OUTPUT_TOO_SMALL with the bytes that fit: sequential path
+        p.end_byte = (p.cnt[nj - 1].end_bit + 7) >> 3;
+        if (zlib && p.end_byte + 4 > streams[p.si].in_len) continue;
+        p.sym_off = sym_total; sym_total += total + 64;
+        p.win_off = win_total; win_total += (uint64_t)(nj + 1) * 32768;
+        p.ooff_off = ooff_total; ooff_total += nj + 1;
+        njobs_total += nj;
+        good.push_back(k);
+    }
+    if (good.empty()) return 0;
     if (zlib) {
-        if (end_byte + 4 > s.in_len) return 0;
-        HIPCHK(hipMemcpyAsync(E.pin, in + end_byte, 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
-        adler_read = ((uint32_t)E.pin[0] << 24) | ((uint32_t)E.pin[1] << 16) | ((uint32_t)E.pin[2] << 8) | E.pin[3];
-        end_byte += 4;
+        std::vector<uint8_t> tr(4 * good.size());
+        for (size_t g = 0; g < good.size(); g++) { const PS &p = ps[good[g]]; HIPCHK(hipMemcpyAsync(tr.data() + 4 * g, d_in + streams[p.si].in_off + p.end_byte, 4, hipMemcpyDeviceToHost, st)); }
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t g = 0; g < good.size(); g++) {
+            PS &p = ps[good[g]];
+            p.adler_read = ((uint32_t)tr[4 * g] << 24) | ((uint32_t)tr[4 * g + 1] << 16) | ((uint32_t)tr[4 * g + 2] << 8) | tr[4 * g + 3];
+            p.end_byte += 4;
+        }
     }
-    // ---- symbol pass, windows, bytes
-    if ((rc = E.inf_sym.ensure(total * 2 + 64)) || (rc = E.inf_wins.ensure((uint64_t)(nj + 1) * 32768)) ||
-        (rc = E.inf_misc.ensure((uint64_t)(nj + 1) * 8))) return rc;
-    std::vector<uint32_t> all(nj);
-    for (uint32_t j = 0; j < nj; j++) all[j] = j;
-    if ((rc = run_pass(2, all, (uint16_t *)E.inf_sym.p, &ooff))) return rc;
-    for (uint32_t j = 0; j < nj; j++)
-        if (jobs[j].end_bit != cnt[j].end_bit || jobs[j].out_written != cnt[j].out) { set_error("parallel inflate: pass 2 disagrees with pass 1 at job %u", j); return SZL_E_STATE; }
-    HIPCHK(hipMemcpyAsync(E.inf_misc.p, ooff.data(), (uint64_t)(nj + 1) * 8, hipMemcpyHostToDevice, st));
-    launch_resolve_wins((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, nj, (uint8_t *)E.inf_wins.p, st);
-    launch_convert((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, nj, (const uint8_t *)E.inf_wins.p, d_out + s.out_off, total, st);
+    // ---- 3. symbol pass, 4. windows and bytes
+    if ((rc = E.inf_sym.ensure(sym_total * 2 + 64)) || (rc = E.inf_wins.ensure(win_total)) || (rc = E.inf_misc.ensure(ooff_total * 8 + 64))) return rc;
+    std::vector<Ref> all;
+    all.reserve(njobs_total);
+    std::vector<uint64_t> ooff_all(ooff_total);
+    for (uint32_t k : good) {
+        const PS &p = ps[k];
+        for (uint32_t j = 0; j < p.sb.size(); j++) all.push_back(Ref{k, j});
+        std::copy(p.ooff.begin(), p.ooff.end(), ooff_all.begin() + p.ooff_off);
+    }
+    if ((rc = run_pass(2, all, (uint16_t *)E.inf_sym.p))) return rc;
+    lap("symbol pass");
+    for (size_t q = 0; q < all.size(); q++) {
+        const PS &p = ps[all[q].k];
+        if (jobs[q].end_bit != p.cnt[all[q].j].end_bit || jobs[q].out_written != p.cnt[all[q].j].out) {
+            set_error("parallel inflate: pass 2 disagrees with pass 1 (stream %zu, job %u)", p.si, all[q].j); return SZL_E_STATE;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(E.inf_misc.p, ooff_all.data(), ooff_total * 8, hipMemcpyHostToDevice, st));
+    std::vector<ParMember> mem(good.size());
+    uint64_t nblk = 0;
+    for (size_t g = 0; g < good.size(); g++) {
+        const PS &p = ps[good[g]];
+        mem[g] = ParMember{p.sym_off, p.ooff_off, p.win_off, streams[p.si].out_off, p.total, (uint32_t)p.sb.size(), (uint32_t)nblk};
+        nblk += (p.total + 16383) / 16384;
+    }
+    if (nblk > 0x7FFFFFFFull) return SZL_E_ARG;
+    if ((rc = E.inf_states.ensure(mem.size() * sizeof(ParMember)))) return rc;
+    HIPCHK(hipMemcpyAsync(E.inf_states.p, mem.data(), mem.size() * sizeof(ParMember), hipMemcpyHostToDevice, st));
+    launch_resolve_wins((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, (uint8_t *)E.inf_wins.p, (const ParMember *)E.inf_states.p,
+                        (uint32_t)mem.size(), st);
+    launch_convert((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, (const uint8_t *)E.inf_wins.p, d_out, (const ParMember *)E.inf_states.p,
+                   (uint32_t)mem.size(), (uint32_t)nblk, st);
     HIPCHK(hipStreamSynchronize(st));
-    res->out_written = total; res->consumed = end_byte; res->adler_read = adler_read;
-    E.last_par_jobs = nj;
-    return 1;
+    lap("windows + bytes");
+    if (dbg) fprintf(stderr, "[szl] inflate par: %zu of %zu candidate members decoded with %llu chunk jobs\n", good.size(), cand.size(), (unsigned long long)njobs_total);
+    for (uint32_t k : good) {
+        const PS &p = ps[k];
+        taken[p.si] = 1;
+        res[p.si] = ParResult{p.total, p.end_byte, p.adler_read};
+    }
+    E.last_par_jobs = (uint32_t)std::min<uint64_t>(njobs_total, 0xFFFFFFFFull);
+    return 0;
 }
 
 extern "C" {
@@ -209,29 +305,39 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     e->e.timing.inflate_ms = 0;
     e->e.last_par_jobs = 0;
 
-    // long members first: each is decoded by many wavefronts (inflate_member_parallel); whatever it does not take joins the batch
-    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", 2048)) * 1024;
+    // Long members are decoded by many wavefronts each (inflate_members_parallel); whatever that does not take joins the batch of
+    // one wavefront per stream.  With thousands of streams in a call that batch fills the device by itself and has no
+    // per-stream host work at all, so the chunked form is used while the call would leave wavefront slots empty.
+    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", 512)) * 1024;
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
-    // (each long member costs a handful of host round trips: with many of them in one call the batch already fills the device
-    // with one wavefront per stream, and that form has no per-stream host work at all)
-    size_t n_long = 0;
-    for (size_t i = 0; i < n_all; i++) n_long += streams[i].in_len >= par_min ? 1 : 0;
-    const bool use_par = n_long > 0 && n_long <= (size_t)std::max(1, knob("SZL_INF_PAR_MAX_STREAMS", 32));
-    for (size_t i = 0; i < n_all; i++) {
-        if (use_par && streams[i].in_len >= par_min) {
+    if (n_all <= (size_t)std::max(1, knob("SZL_INF_PAR_MAX_STREAMS", 1024))) {
+        // groups of at most ~4 GiB of compressed input keep the 2-byte-per-output-byte staging bounded
+        std::vector<size_t> cand;
+        uint64_t grp = 0;
+        auto flush_group = [&]() -> int {
+            if (cand.empty()) return 0;
+            e->e.last_par_jobs = 0;
             (void)hipEventRecord(e->e.ev[0], st);
-            rc = inflate_member_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams[i], !nowrap, st, &par_res[i]);
-            if (rc < 0) return rc;
-            if (rc == 1) {
-                (void)hipEventRecord(e->e.ev[1], st); (void)hipEventSynchronize(e->e.ev[1]);
-                float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
-                par_done[i] = 1; continue;
-            }
+            const int r = inflate_members_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams, cand, !nowrap, st, par_done, par_res);
+            (void)hipEventRecord(e->e.ev[1], st); (void)hipEventSynchronize(e->e.ev[1]);
+            float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
+            cand.clear(); grp = 0;
+            return r;
+        };
+        uint32_t par_jobs = 0;
+        for (size_t i = 0; i < n_all; i++) {
+            if (streams[i].in_len < par_min) continue;
+            if (grp + streams[i].in_len > (4ull << 30) && !cand.empty()) { if ((rc = flush_group()) < 0) return rc; par_jobs += e->e.last_par_jobs; }
+            cand.push_back(i); grp += streams[i].in_len;
         }
-        idx.push_back(i);
+        const bool had = !cand.empty();
+        if ((rc = flush_group()) < 0) return rc;
+        if (had) par_jobs += e->e.last_par_jobs;
+        e->e.last_par_jobs = par_jobs;
     }
+    for (size_t i = 0; i < n_all; i++) if (!par_done[i]) idx.push_back(i);
     const size_t n = idx.size();
     std::vector<InfJob> jobs(n);
     std::vector<InfState> states(n);

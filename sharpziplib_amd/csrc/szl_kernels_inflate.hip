@@ -123,13 +123,15 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
 template <bool SHORTWIN, int PMODE>
 __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
+    // (a 4096-entry window for the 16-bit symbol pass — the byte form's LDS footprint — was measured: 128 members of 4 MiB 58 -> 49 ms,
+    // but one 256 MiB member 74 -> 93 ms: more matches reach behind the window and are read from the symbol staging)
     constexpr int WIN = SHORTWIN ? I_WIN_SHORT : I_WIN;
     constexpr uint64_t I_WMASK = WIN - 1;
     // SHORTWIN: bytes older than FAR_DIST are read from the output region; everything older than ROOM is flushed there first
     constexpr uint32_t FAR_DIST = WIN - 512;
-    constexpr uint64_t ROOM = SHORTWIN ? 4096 : (uint64_t)(I_WIN - 300);
+    constexpr uint64_t ROOM = SHORTWIN ? (uint64_t)WIN / 2 : (uint64_t)(I_WIN - 300);
     constexpr uint64_t FLUSH_AT = SHORTWIN ? 1024 : 16384;
-    constexpr uint32_t ROUND_MAX = SHORTWIN ? 2048 : 64u * MAX_MATCH_I; // output bytes one parallel round may queue
+    constexpr uint32_t ROUND_MAX = SHORTWIN ? (uint32_t)WIN / 4 : 64u * MAX_MATCH_I; // output bytes one parallel round may queue
     using WT = typename std::conditional<PMODE == 2, uint16_t, uint8_t>::type;
     __shared__ InfLds<WIN, WT> S;
     const uint32_t ji = blockIdx.x;

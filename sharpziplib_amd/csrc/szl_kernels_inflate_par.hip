@@ -93,16 +93,18 @@ __device__ bool header_ok(const uint8_t *in, uint64_t in_len, uint64_t p, uint8_
     return true;
 }
 
-// One wavefront per chunk c >= 1: first valid dynamic header at a bit offset in [c*chunk_bytes*8, (c+1)*chunk_bytes*8).
-__global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ in, uint64_t in_len, uint64_t chunk_bytes, uint32_t nchunks,
+// One wavefront per finder job: first valid dynamic header at a bit offset in [lo_bit, hi_bit) of the job's member.
+__global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ in_base, const FindJob *__restrict__ fjobs, uint32_t njobs,
                                                     uint64_t *__restrict__ start_bit) {
     __shared__ uint8_t s_lens[320];
     __shared__ uint16_t s_mlut[128];
-    const uint32_t c = blockIdx.x + 1;
-    if (c >= nchunks) return;
+    if (blockIdx.x >= njobs) return;
+    const FindJob fj = fjobs[blockIdx.x];
+    const uint8_t *in = in_base + fj.in_off;
+    const uint64_t in_len = fj.in_len;
     const int lane = threadIdx.x;
-    const uint64_t lo = (uint64_t)c * chunk_bytes * 8;
-    uint64_t hi = lo + chunk_bytes * 8;
+    const uint64_t lo = fj.lo_bit;
+    uint64_t hi = fj.hi_bit;
     if (hi + 128 > in_len * 8) hi = in_len * 8 > 128 ? in_len * 8 - 128 : 0;
     uint64_t found = ~0ull;
     for (uint64_t base = lo; base < hi && found == ~0ull; base += 64) {
@@ -128,14 +130,19 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
             if (ok) { found = base + (uint64_t)l; break; }
         }
     }
-    if (lane == 0) start_bit[c] = found;
+    if (lane == 0) start_bit[blockIdx.x] = found;
 }
 
-// Front to back over the jobs: W_j = the 32 KiB of output that end where job j's output ends, as bytes.
-// wins[(j + 1) * 32768 ..] = W_j ; wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).
-__global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ out_off /* njobs + 1 */,
-                                                       uint32_t njobs, uint8_t *__restrict__ wins) {
+// Front to back over the jobs of one member (one workgroup per member): W_j = the 32 KiB of output that end where job j's
+// output ends, as bytes.  wins[(j + 1) * 32768 ..] = W_j ; wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).
+__global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym_all, const uint64_t *__restrict__ ooff_all,
+                                                       uint8_t *__restrict__ wins_all, const ParMember *__restrict__ mem) {
     __shared__ uint8_t s_w[2][32768];
+    const ParMember m = mem[blockIdx.x];
+    const uint16_t *sym = sym_all + m.sym_off;
+    const uint64_t *out_off = ooff_all + m.ooff_off;
+    uint8_t *wins = wins_all + m.win_off;
+    const uint32_t njobs = m.njobs;
     const int tid = threadIdx.x;
     for (int i = tid; i < 32768; i += 1024) { s_w[0][i] = 0; wins[i] = 0; }
     __syncthreads();
@@ -160,10 +167,20 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
     }
 }
 
-// symbols -> bytes; one workgroup per 16 KiB of output
-__global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ out_off, uint32_t njobs,
-                                                 const uint8_t *__restrict__ wins, uint8_t *__restrict__ out, uint64_t total) {
-    const uint64_t b0 = (uint64_t)blockIdx.x * 16384;
+// symbols -> bytes; one workgroup per 16 KiB of a member's output (blk0 = the member's first workgroup)
+__global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym_all, const uint64_t *__restrict__ ooff_all,
+                                                 const uint8_t *__restrict__ wins_all, uint8_t *__restrict__ out_base,
+                                                 const ParMember *__restrict__ mem, uint32_t nmem) {
+    uint32_t a = 0, z = nmem;                                      // last member with blk0 <= blockIdx.x
+    while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if (mem[mid].blk0 <= blockIdx.x) a = mid; else z = mid; }
+    const ParMember m = mem[a];
+    const uint16_t *sym = sym_all + m.sym_off;
+    const uint64_t *out_off = ooff_all + m.ooff_off;
+    const uint8_t *wins = wins_all + m.win_off;
+    uint8_t *out = out_base + m.out_off;
+    const uint32_t njobs = m.njobs;
+    const uint64_t total = m.total;
+    const uint64_t b0 = (uint64_t)(blockIdx.x - m.blk0) * 16384;
     if (b0 >= total) return;
     const uint64_t b1 = b0 + 16384 < total ? b0 + 16384 : total;
     uint32_t lo = 0, hi = njobs;                                   // last job with out_off <= b0
@@ -176,14 +193,15 @@ __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sy
     }
 }
 
-void launch_find_blocks(const uint8_t *in, uint64_t in_len, uint64_t chunk_bytes, uint32_t nchunks, uint64_t *start_bit, hipStream_t st) {
-    if (nchunks > 1) hipLaunchKernelGGL(k_find_blocks, dim3(nchunks - 1), dim3(64), 0, st, in, in_len, chunk_bytes, nchunks, start_bit);
+void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st) {
+    if (njobs) hipLaunchKernelGGL(k_find_blocks, dim3(njobs), dim3(64), 0, st, in_base, fjobs, njobs, start_bit);
 }
-void launch_resolve_wins(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, uint8_t *wins, hipStream_t st) {
-    hipLaunchKernelGGL(k_resolve_wins, dim3(1), dim3(1024), 0, st, sym, out_off, njobs, wins);
+void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st) {
+    if (nmem) hipLaunchKernelGGL(k_resolve_wins, dim3(nmem), dim3(1024), 0, st, sym, ooff, wins, mem);
 }
-void launch_convert(const uint16_t *sym, const uint64_t *out_off, uint32_t njobs, const uint8_t *wins, uint8_t *out, uint64_t total, hipStream_t st) {
-    if (total) hipLaunchKernelGGL(k_convert, dim3((unsigned)((total + 16383) / 16384)), dim3(256), 0, st, sym, out_off, njobs, wins, out, total);
+void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint8_t *wins, uint8_t *out_base, const ParMember *mem, uint32_t nmem,
+                    uint32_t nblocks, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_convert, dim3(nblocks), dim3(256), 0, st, sym, ooff, wins, out_base, mem, nmem);
 }
 
 } // namespace szl
