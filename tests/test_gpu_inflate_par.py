@@ -157,6 +157,31 @@ def test_mixed_batch(eng):
         assert r.status == 0 and r.data == w.tobytes() and consumed == len(s) and r.crc32 == zlib.crc32(w.tobytes())
 
 
+def test_several_long_members_in_one_call(eng):
+    """the passes of all long members of a call share their launches; a broken one among them falls back alone"""
+    rng = np.random.default_rng(4)
+    datas = [C.generate(("enwik", "logs", "dickens")[i % 3], 700 + i, 0, int(rng.integers(2 << 20, 5 << 20))) for i in range(9)]
+    streams = [zlib.compress(d.tobytes(), 6) if i % 2 else zlib.compress(d.tobytes(), 9) for i, d in enumerate(datas)]
+    bad = bytearray(streams[4]); bad[len(bad) // 2] ^= 0x10
+    streams[4] = bytes(bad)
+    smalls = [zlib.compress(C.generate("enwik", 900 + i, 0, 20000).tobytes(), 6) for i in range(5)]
+    all_streams = streams[:3] + smalls[:2] + streams[3:] + smalls[2:]
+    caps = [len(zlib.decompress(s)) if s is not streams[4] else datas[4].size for s in all_streams]
+    _knobs(16, 64)
+    par = eng.inflate(all_streams, caps, nowrap=False, crc32=True)
+    jobs = _par_jobs(eng)
+    _knobs(16, 1 << 22)
+    seq = eng.inflate(all_streams, caps, nowrap=False, crc32=True)
+    assert jobs >= 8 * 8
+    for a, b in zip(par, seq):
+        _same(a, b)
+    for (r, consumed), s in zip(par, all_streams):
+        if s is streams[4]:
+            assert r.status != 0
+        else:
+            assert r.status == 0 and r.data == zlib.decompress(s) and consumed == len(s)
+
+
 def test_default_knobs_256mib_member(eng):
     """library defaults on a member of the size they are meant for; the device's own level-6 stream"""
     from sharpziplib_amd import _lib
