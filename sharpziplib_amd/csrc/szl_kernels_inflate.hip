@@ -50,6 +50,7 @@ struct InfLds {
     uint8_t lens[320];
     uint16_t codes[320];
     uint32_t queue[64];
+    uint16_t toff[64 + 2];  // output offset of each queued token inside the round (apply step)
 };
 
 // Build decode tables from code lengths lens[0..n) (all lanes). pb = primary bits.
@@ -522,6 +523,40 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
             uint64_t mm = __ballot(lane < ntok && dist != 0);
             int done_upto = 0; // lanes < done_upto have been applied
             if (PMODE == 1) mm = 0;   // count pass: only the lengths matter
+            // Fast form for the usual round (text: ~9 tokens, ~50 bytes): if no match of the round reads a byte the round itself
+            // produces (distance >= offset in the round + length; that also rules out overlapping copies), every output byte
+            // is a pure function of the window BEFORE the round, so the lanes take one byte each instead of one match at a time:
+            // byte b -> its token (binary search over the tokens' offsets) -> literal, window[p - dist + k] or, behind the short
+            // window, the flushed output.  Chunks of 64 bytes go in ascending order, so a ring slot is overwritten only after
+            // every reader of the position it held (at most WIN - 512 back) is through.
+            if (mm && SHORTWIN && !__any(lane < ntok && dist != 0 && dist < (incl - mylen) + mylen)) {
+                const uint32_t rtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (lane < ntok) S.toff[lane] = (uint16_t)(incl - mylen);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                for (uint32_t b0 = 0; b0 < rtot; b0 += 64) {
+                    const uint32_t b = b0 + lane;
+                    const bool act = b < rtot;
+                    uint32_t lo = 0, hi = ntok;                     // last token with toff <= b
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)S.toff[mid] <= b) lo = mid; else hi = mid; }
+                    const uint32_t tv = S.queue[lo];
+                    const uint32_t k = b - (uint32_t)S.toff[lo];
+                    const uint32_t d2 = tv >> 16;
+                    WT val = (WT)(uint8_t)tv;
+                    if (act && d2 != 0) {
+                        const uint64_t p = outpos + (uint32_t)S.toff[lo];
+                        if (d2 > FAR_DIST) {
+                            const int64_t sp = (int64_t)(p - out_start) - (int64_t)d2 + (int64_t)k;
+                            if (PMODE == 2) val = sp >= 0 ? (WT)__atomic_load_n(job.sym_out + sp, __ATOMIC_RELAXED) : (WT)(0x8000u | (uint32_t)(32768 + sp));
+                            else val = sp >= 0 ? (WT)__atomic_load_n(out + sp, __ATOMIC_RELAXED) : (WT)0;
+                        } else val = S.win[(p - d2 + k) & I_WMASK];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (act) S.win[(outpos + b) & I_WMASK] = val;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+                mm = 0;
+                done_upto = 64;   // literals are written too
+            }
             while (mm) { // matches in stream order; CS/OutputWindow.cs:63-92: out[p+k] = out[p-dist+(k mod dist)]
                 const int l = __builtin_ctzll(mm);
                 mm &= mm - 1;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
 // output ends, as bytes.  wins[(j + 1) * 32768 ..] = W_j ; wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).
 __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym_all, const uint64_t *__restrict__ ooff_all,
                                                        uint8_t *__restrict__ wins_all, const ParMember *__restrict__ mem) {
-    __shared__ uint8_t s_w[2][32768];
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[2][32768];
     const ParMember m = mem[blockIdx.x];
     const uint16_t *sym = sym_all + m.sym_off;
     const uint64_t *out_off = ooff_all + m.ooff_off;
@@ -152,17 +152,30 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
         const uint64_t len = o1 - o0;
         const uint8_t *prev = s_w[cur];
         uint8_t *next = s_w[cur ^ 1];
-        uint8_t *dst = wins + (uint64_t)(j + 1) * 32768;
-        for (int t = tid; t < 32768; t += 1024) {
-            uint8_t b;
-            if ((uint64_t)(32768 - t) <= len) {                    // position o1 - 32768 + t lies inside job j's output
-                const uint32_t sv = sym[o1 - 32768 + (uint64_t)t];
-                b = sv < 0x8000u ? (uint8_t)sv : prev[sv & 0x7FFF];
-            } else b = prev[(uint64_t)t + len];                    // still the previous window, shifted by this job's output
-            next[t] = b;
-            dst[t] = b;
+        if (len >= 32768) {   // the usual job: its last 32 KiB are all its own symbols — 32 independent loads per thread in flight
+            const uint16_t *src = sym + (o1 - 32768) + tid;
+            uint32_t sv[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) sv[k] = src[1024 * k];
+#pragma unroll
+            for (int k = 0; k < 32; k++) next[tid + 1024 * k] = sv[k] < 0x8000u ? (uint8_t)sv[k] : prev[sv[k] & 0x7FFF];
+        } else {
+            for (int t = tid; t < 32768; t += 1024) {
+                uint8_t b;
+                if ((uint64_t)(32768 - t) <= len) {                // position o1 - 32768 + t lies inside job j's output
+                    const uint32_t sv = sym[o1 - 32768 + (uint64_t)t];
+                    b = sv < 0x8000u ? (uint8_t)sv : prev[sv & 0x7FFF];
+                } else b = prev[(uint64_t)t + len];                // still the previous window, shifted by this job's output
+                next[t] = b;
+            }
         }
         __syncthreads();
+        {   // the finished window goes out 32 bytes per thread (the next job only reads it: no second barrier needed)
+            const uint4 *w4 = (const uint4 *)next;
+            uint4 *d4 = (uint4 *)(wins + (uint64_t)(j + 1) * 32768);
+            d4[tid] = w4[tid];
+            d4[tid + 1024] = w4[tid + 1024];
+        }
         cur ^= 1;
     }
 }
