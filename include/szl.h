@@ -31,7 +31,7 @@ typedef enum szl_status {
     SZL_E_STATE = -2,          /* InvalidOperationException ("Finish() already called" C/Deflater.cs:333-336, "Old input was not completely processed" C/DeflaterEngine.cs:163-166, "Dictionary is not needed" C/Inflater.cs:580) */
     SZL_E_DEVICE = -3,         /* HIP error / no gfx950 device: surfaces as SharpZipBaseException */
     SZL_E_NOMEM = -4,
-    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not reproducible by a segment-at-a-time backend (SetLevel / SetStrategy mid-stream) */
+    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not reproduced here (SetLevel to or from level 0 mid-stream, across DeflateFast / DeflateSlow with bytes pending, more than four changes between two flushes) */
     SZL_E_OUTPUT_TOO_SMALL = -6,
     /* Inflater errors == the SharpZipBaseException messages of C/Inflater.cs */
     SZL_E_HEADER_CHECKSUM = -16,   /* "Header checksum illegal"            C/Inflater.cs:224 */
@@ -165,7 +165,7 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
 int szl_engine_debug_match_mode(szl_engine *e, int mode);
 
 /* Experiment / parity knob: sets a named tuning value for this process (the same names are read from the environment as a
- * fallback): SZL_MATCH_KERNEL, SZL_NCTX, SZL_FTH2, SZL_VTH2, SZL_QKEEP, SZL_VKEEP, SZL_DEBUG, ...  Results never depend on them.  value INT_MIN forgets the name again. */
+ * fallback): SZL_MATCH_KERNEL, SZL_LINKS, SZL_FTH2, SZL_VTH2, SZL_QKEEP, SZL_VKEEP, SZL_DEBUG, ...  Results never depend on them.  value INT_MIN forgets the name again. */
 int szl_debug_set(const char *name, int value);
 
 /* Parity tap: device bytes held by the engine's per-position side arrays at the peak of the last deflate call.  A single stream
@@ -173,8 +173,9 @@ int szl_debug_set(const char *name, int value);
 uint64_t szl_engine_debug_workspace(const szl_engine *e);
 
 /* Parity tap: number of chunk jobs the last szl_inflate_batch_* call decoded single members with (0: every stream went through
- * the one-wavefront-per-stream decoder).  A member of SZL_INF_PAR_MIN_KIB (default 2048) compressed KiB or more is decoded by
- * one wavefront per SZL_INF_CHUNK_KIB (default 128) of compressed bytes. */
+ * the one-wavefront-per-stream decoder).  In calls of up to SZL_INF_PAR_MAX_STREAMS (default 1024) streams, every member of
+ * SZL_INF_PAR_MIN_KIB (default 512) compressed KiB or more is decoded by one wavefront per chunk of 1/32 of its compressed
+ * bytes (16 KiB .. SZL_INF_CHUNK_KIB, default 128). */
 uint32_t szl_engine_debug_par_jobs(const szl_engine *e);
 
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
