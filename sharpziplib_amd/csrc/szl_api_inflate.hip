@@ -20,9 +20,9 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
 size_t checksum_partial_bytes();
 void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st);
 void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st);
-void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st);
-void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint8_t *wins, uint8_t *out_base, const ParMember *mem, uint32_t nmem,
-                    uint32_t nblocks, hipStream_t st);
+void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st);
+void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, const uint8_t *wins, uint8_t *out_base, const ParMember *mem,
+                    uint32_t nmem, uint32_t nblocks, hipStream_t st);
 }
 struct szl_engine { Engine e; };
 
@@ -80,8 +80,14 @@ struct ParResult { uint64_t out_written, consumed; uint32_t adler_read; };
 // Several members at once: the passes of all of them share their launches and their host round trips (a call with 128
 // members of a few MiB each would otherwise pay ~6 round trips per member, or — through the one-wavefront decoder — run
 // on 128 wavefronts).  `cand` = indices of the candidate streams; taken[i] / res[i] are set for the streams decoded here.
+//
+// single_pass: skip the count pass.  Every job decodes straight into a staging region of its own, sized from the caller's
+// output capacity (1.5 x the member's average expansion + 64 Ki symbols); the chain is verified on the bit positions the
+// symbol pass reports, and the output offsets follow from its lengths.  A job that overruns its region, or a chain that
+// needs repair, sends the member to `retry` (the caller runs those through the two-pass form).
 static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_out, const szl_stream *streams, const std::vector<size_t> &cand,
-                                    bool zlib, hipStream_t st, std::vector<char> &taken, std::vector<ParResult> &res) {
+                                    bool zlib, bool single_pass, hipStream_t st, std::vector<char> &taken, std::vector<ParResult> &res,
+                                    std::vector<size_t> *retry) {
     struct Cnt { uint64_t end_bit, out; int status; };
     struct PS {
         size_t si;                       // index into streams
@@ -89,9 +95,11 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         uint32_t nchunks; uint64_t start_off;   // its slice of the candidate-start array
         std::vector<uint64_t> sb;        // start bits of its jobs, ascending
         std::vector<Cnt> cnt; std::vector<char> have;
+        std::vector<uint64_t> reg;       // single pass: staging region (first symbol) of each job
+        uint64_t reg_cap = 0;            //              and its size in symbols
         bool alive = true, ok = false;
-        std::vector<uint64_t> ooff; uint64_t total = 0, end_byte = 0; uint32_t adler_read = 0;
-        uint64_t sym_off = 0, win_off = 0, ooff_off = 0;   // offsets (elements / bytes) into the shared staging buffers
+        std::vector<uint64_t> ooff, jbase; uint64_t total = 0, end_byte = 0; uint32_t adler_read = 0;
+        uint64_t win_off = 0, ooff_off = 0;   // offsets (bytes / elements) into the shared buffers
     };
     std::vector<PS> ps;
     const bool dbg = knob("SZL_DEBUG", 0) != 0;
@@ -138,27 +146,42 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     std::vector<uint64_t> starts(nstart_total);
     HIPCHK(hipMemcpyAsync(starts.data(), d_start, nstart_total * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
     lap("find block starts");
+    uint64_t reg_total = 0;              // single pass: symbols of staging handed out so far
     for (auto &p : ps) {
         if (!p.alive) continue;
         p.sb.push_back(p.first_bit);
         for (uint32_t c = 1; c < p.nchunks; c++) { const uint64_t v = starts[p.start_off + c]; if (v != ~0ull && v > p.sb.back()) p.sb.push_back(v); }
         if (p.sb.size() < 4) { p.alive = false; continue; }
         p.cnt.assign(p.sb.size(), Cnt{}); p.have.assign(p.sb.size(), 0);
+        if (single_pass) {
+            const szl_stream &s = streams[p.si];
+            const double expand = (double)s.out_cap / (double)s.in_len;
+            p.reg_cap = (uint64_t)(1.5 * expand * (double)p.chunk_bytes) + 65536;
+            p.reg.resize(p.sb.size());
+            for (auto &r : p.reg) { r = reg_total; reg_total += p.reg_cap; }
+        }
     }
+    if (single_pass && reg_total * 2 > (16ull << 30)) { // a capacity far above the real size would ask for too much staging: count first
+        if (retry) for (auto &p : ps) if (p.alive) retry->push_back(p.si);
+        return 0;
+    }
+    if (single_pass && (rc = E.inf_sym.ensure(reg_total * 2 + 64))) return rc;
     // one launch of a pass over (stream, job) pairs
     struct Ref { uint32_t k, j; };
     std::vector<InfJob> jobs;
-    auto run_pass = [&](int pass, const std::vector<Ref> &which, uint16_t *sym) -> int {
+    auto run_pass = [&](int pass, const std::vector<Ref> &which) -> int {
         const size_t n = which.size();
         if (!n) return 0;
         if (n > 0x7FFFFFFFull) return SZL_E_ARG;
         jobs.assign(n, InfJob{});
+        uint16_t *sym = (uint16_t *)E.inf_sym.p;
         for (size_t q = 0; q < n; q++) {
             const PS &p = ps[which[q].k]; const uint32_t j = which[q].j;
             InfJob &jb = jobs[q];
-            jb.in_off = streams[p.si].in_off; jb.in_len = streams[p.si].in_len; jb.out_cap = ~0ull >> 2;
+            jb.in_off = streams[p.si].in_off; jb.in_len = streams[p.si].in_len;
             jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : ~0ull;
-            jb.sym_out = sym ? sym + p.sym_off + p.ooff[j] : nullptr;
+            if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.reg_cap; }
+            else { jb.sym_out = pass == 2 ? sym + p.jbase[j] : nullptr; jb.out_cap = ~0ull >> 2; }
         }
         int r;
         if ((r = E.inf_jobs.ensure(n * sizeof(InfJob))) || (r = E.inf_states.ensure(n * sizeof(InfState)))) return r;
@@ -169,15 +192,15 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         HIPCHK(hipStreamSynchronize(st));
         return 0;
     };
-    // ---- 2. count pass + chain repair (per member; the launches are shared)
-    for (int iter = 0; iter < 6; iter++) {
+    // ---- 2. first pass over every job (count, or symbols straight away) + chain check / repair (per member; the launches are shared)
+    for (int iter = 0; iter < (single_pass ? 1 : 6); iter++) {
         std::vector<Ref> which;
         for (uint32_t k = 0; k < ps.size(); k++) {
             PS &p = ps[k];
             if (!p.alive || p.ok) continue;
             for (uint32_t j = 0; j < p.sb.size(); j++) if (!p.have[j]) which.push_back(Ref{k, j});
         }
-        if ((rc = run_pass(1, which, nullptr))) return rc;
+        if ((rc = run_pass(single_pass ? 2 : 1, which))) return rc;
         for (size_t q = 0; q < which.size(); q++) {
             PS &p = ps[which[q].k];
             p.cnt[which[q].j] = Cnt{jobs[q].end_bit, jobs[q].out_written, jobs[q].status}; p.have[which[q].j] = 1;
@@ -186,14 +209,19 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         for (auto &p : ps) {
             if (!p.alive || p.ok) continue;
             // walk the chain from job 0; keep the starts it visits
-            std::vector<uint64_t> nsb; std::vector<Cnt> ncnt; std::vector<char> nhave;
+            std::vector<uint64_t> nsb, nreg; std::vector<Cnt> ncnt; std::vector<char> nhave;
             uint32_t j = 0;
             bool ok = true;
             for (;;) {
                 nsb.push_back(p.sb[j]); ncnt.push_back(p.cnt[j]); nhave.push_back(1);
+                if (single_pass) nreg.push_back(p.reg[j]);
                 const Cnt &c = p.cnt[j];
                 if (c.status == INF_FINISHED) break;               // the member's last block ended inside this job
-                if (c.status != INF_CHUNK_END) { p.alive = false; break; }   // an error on the chain is a real error of the stream
+                if (c.status != INF_CHUNK_END) {                   // an error on the chain is a real error of the stream —
+                    p.alive = false;                               // or, in the single pass, a staging region that was too small
+                    if (single_pass && c.status == INF_OUTPUT_FULL && retry) retry->push_back(p.si);
+                    break;
+                }
                 uint32_t m = j + 1;
                 while (m < p.sb.size() && p.sb[m] < c.end_bit) m++;  // starts the real decode ran over: false candidates
                 if (m < p.sb.size() && p.sb[m] == c.end_bit) { j = m; continue; }
@@ -201,18 +229,20 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 // ran with an earlier stop, but a decode that stops at the first block boundary >= stop also stops there for
                 // any stop in (previous boundary, end_bit]: its count stays valid.)
                 ok = false;
+                if (single_pass) { p.alive = false; if (retry) retry->push_back(p.si); break; }
                 nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
                 for (; m < p.sb.size(); m++) { nsb.push_back(p.sb[m]); ncnt.push_back(p.cnt[m]); nhave.push_back(p.have[m]); }
                 break;
             }
             if (!p.alive) continue;
             p.sb.swap(nsb); p.cnt.swap(ncnt); p.have.swap(nhave);
+            if (single_pass) p.reg.swap(nreg);
             if (ok) p.ok = true; else pending = true;
         }
-        if (dbg) fprintf(stderr, "[szl] inflate par: count pass %d over %zu jobs\n", iter, which.size());
+        if (dbg) fprintf(stderr, "[szl] inflate par: %s pass %d over %zu jobs\n", single_pass ? "symbol" : "count", iter, which.size());
         if (!pending) break;
     }
-    lap("count passes");
+    lap(single_pass ? "symbol pass (single)" : "count passes");
     // ---- layout of what was proven
     uint64_t sym_total = 0, win_total = 0, ooff_total = 0, njobs_total = 0;
     std::vector<uint32_t> good;
@@ -221,14 +251,15 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         if (!p.alive || !p.ok) continue;
         const uint32_t nj = (uint32_t)p.sb.size();
         if (p.cnt[nj - 1].status != INF_FINISHED) continue;        // truncated member: NEED_INPUT semantics belong to the sequential path
-        p.ooff.assign(nj + 1, 0);
+        p.ooff.assign(nj + 1, 0); p.jbase.assign(nj + 1, 0);
         uint64_t total = 0;
         for (uint32_t j = 0; j < nj; j++) { p.ooff[j] = total; total += p.cnt[j].out; }
         p.ooff[nj] = total; p.total = total;
         if (total > streams[p.si].out_cap) continue;               // SZL_E_OUTPUT_TOO_SMALL with the bytes that fit: sequential path
         p.end_byte = (p.cnt[nj - 1].end_bit + 7) >> 3;
         if (zlib && p.end_byte + 4 > streams[p.si].in_len) continue;
-        p.sym_off = sym_total; sym_total += total + 64;
+        if (single_pass) for (uint32_t j = 0; j < nj; j++) p.jbase[j] = p.reg[j];
+        else { for (uint32_t j = 0; j < nj; j++) p.jbase[j] = sym_total + p.ooff[j]; sym_total += total + 64; }
         p.win_off = win_total; win_total += (uint64_t)(nj + 1) * 32768;
         p.ooff_off = ooff_total; ooff_total += nj + 1;
         njobs_total += nj;
@@ -245,48 +276,52 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             p.end_byte += 4;
         }
     }
-    // ---- 3. symbol pass, 4. windows and bytes
-    if ((rc = E.inf_sym.ensure(sym_total * 2 + 64)) || (rc = E.inf_wins.ensure(win_total)) || (rc = E.inf_misc.ensure(ooff_total * 8 + 64))) return rc;
-    std::vector<Ref> all;
-    all.reserve(njobs_total);
-    std::vector<uint64_t> ooff_all(ooff_total);
+    // ---- 3. symbol pass (two-pass form), 4. windows and bytes
+    if ((!single_pass && (rc = E.inf_sym.ensure(sym_total * 2 + 64))) || (rc = E.inf_wins.ensure(win_total)) || (rc = E.inf_misc.ensure(2 * ooff_total * 8 + 64))) return rc;
+    std::vector<uint64_t> ooff_all(2 * ooff_total);                // output offsets, then staging offsets
     for (uint32_t k : good) {
         const PS &p = ps[k];
-        for (uint32_t j = 0; j < p.sb.size(); j++) all.push_back(Ref{k, j});
         std::copy(p.ooff.begin(), p.ooff.end(), ooff_all.begin() + p.ooff_off);
+        std::copy(p.jbase.begin(), p.jbase.end(), ooff_all.begin() + ooff_total + p.ooff_off);
     }
-    if ((rc = run_pass(2, all, (uint16_t *)E.inf_sym.p))) return rc;
-    lap("symbol pass");
-    for (size_t q = 0; q < all.size(); q++) {
-        const PS &p = ps[all[q].k];
-        if (jobs[q].end_bit != p.cnt[all[q].j].end_bit || jobs[q].out_written != p.cnt[all[q].j].out) {
-            set_error("parallel inflate: pass 2 disagrees with pass 1 (stream %zu, job %u)", p.si, all[q].j); return SZL_E_STATE;
+    if (!single_pass) {
+        std::vector<Ref> all;
+        all.reserve(njobs_total);
+        for (uint32_t k : good) for (uint32_t j = 0; j < ps[k].sb.size(); j++) all.push_back(Ref{k, j});
+        if ((rc = run_pass(2, all))) return rc;
+        lap("symbol pass");
+        for (size_t q = 0; q < all.size(); q++) {
+            const PS &p = ps[all[q].k];
+            if (jobs[q].end_bit != p.cnt[all[q].j].end_bit || jobs[q].out_written != p.cnt[all[q].j].out) {
+                set_error("parallel inflate: pass 2 disagrees with pass 1 (stream %zu, job %u)", p.si, all[q].j); return SZL_E_STATE;
+            }
         }
     }
-    HIPCHK(hipMemcpyAsync(E.inf_misc.p, ooff_all.data(), ooff_total * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(E.inf_misc.p, ooff_all.data(), 2 * ooff_total * 8, hipMemcpyHostToDevice, st));
     std::vector<ParMember> mem(good.size());
     uint64_t nblk = 0;
     for (size_t g = 0; g < good.size(); g++) {
         const PS &p = ps[good[g]];
-        mem[g] = ParMember{p.sym_off, p.ooff_off, p.win_off, streams[p.si].out_off, p.total, (uint32_t)p.sb.size(), (uint32_t)nblk};
+        mem[g] = ParMember{p.ooff_off, p.win_off, streams[p.si].out_off, p.total, (uint32_t)p.sb.size(), (uint32_t)nblk};
         nblk += (p.total + 16383) / 16384;
     }
     if (nblk > 0x7FFFFFFFull) return SZL_E_ARG;
     if ((rc = E.inf_states.ensure(mem.size() * sizeof(ParMember)))) return rc;
     HIPCHK(hipMemcpyAsync(E.inf_states.p, mem.data(), mem.size() * sizeof(ParMember), hipMemcpyHostToDevice, st));
-    launch_resolve_wins((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, (uint8_t *)E.inf_wins.p, (const ParMember *)E.inf_states.p,
-                        (uint32_t)mem.size(), st);
-    launch_convert((const uint16_t *)E.inf_sym.p, (const uint64_t *)E.inf_misc.p, (const uint8_t *)E.inf_wins.p, d_out, (const ParMember *)E.inf_states.p,
+    const uint64_t *d_ooff = (const uint64_t *)E.inf_misc.p, *d_jbase = d_ooff + ooff_total;
+    launch_resolve_wins((const uint16_t *)E.inf_sym.p, d_ooff, d_jbase, (uint8_t *)E.inf_wins.p, (const ParMember *)E.inf_states.p, (uint32_t)mem.size(), st);
+    launch_convert((const uint16_t *)E.inf_sym.p, d_ooff, d_jbase, (const uint8_t *)E.inf_wins.p, d_out, (const ParMember *)E.inf_states.p,
                    (uint32_t)mem.size(), (uint32_t)nblk, st);
     HIPCHK(hipStreamSynchronize(st));
     lap("windows + bytes");
-    if (dbg) fprintf(stderr, "[szl] inflate par: %zu of %zu candidate members decoded with %llu chunk jobs\n", good.size(), cand.size(), (unsigned long long)njobs_total);
+    if (dbg) fprintf(stderr, "[szl] inflate par: %zu of %zu candidate members decoded with %llu chunk jobs (%s)\n", good.size(), cand.size(),
+                     (unsigned long long)njobs_total, single_pass ? "single pass" : "count + symbol pass");
     for (uint32_t k : good) {
         const PS &p = ps[k];
         taken[p.si] = 1;
         res[p.si] = ParResult{p.total, p.end_byte, p.adler_read};
     }
-    E.last_par_jobs = (uint32_t)std::min<uint64_t>(njobs_total, 0xFFFFFFFFull);
+    E.last_par_jobs += (uint32_t)std::min<uint64_t>(njobs_total, 0xFFFFFFFFull);
     return 0;
 }
 
@@ -316,26 +351,25 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
         // groups of at most ~4 GiB of compressed input keep the 2-byte-per-output-byte staging bounded
         std::vector<size_t> cand;
         uint64_t grp = 0;
+        const bool single = knob("SZL_INF_SINGLE_PASS", 1) != 0;
         auto flush_group = [&]() -> int {
             if (cand.empty()) return 0;
-            e->e.last_par_jobs = 0;
             (void)hipEventRecord(e->e.ev[0], st);
-            const int r = inflate_members_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams, cand, !nowrap, st, par_done, par_res);
+            std::vector<size_t> retry;
+            int r = inflate_members_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams, cand, !nowrap, single, st, par_done, par_res, &retry);
+            if (r >= 0 && single && !retry.empty())   // a staging region was too small, or a chain needed repair: count first, then decode
+                r = inflate_members_parallel(e->e, (const uint8_t *)d_in, (uint8_t *)d_out, streams, retry, !nowrap, false, st, par_done, par_res, nullptr);
             (void)hipEventRecord(e->e.ev[1], st); (void)hipEventSynchronize(e->e.ev[1]);
             float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
             cand.clear(); grp = 0;
             return r;
         };
-        uint32_t par_jobs = 0;
         for (size_t i = 0; i < n_all; i++) {
             if (streams[i].in_len < par_min) continue;
-            if (grp + streams[i].in_len > (4ull << 30) && !cand.empty()) { if ((rc = flush_group()) < 0) return rc; par_jobs += e->e.last_par_jobs; }
+            if (grp + streams[i].in_len > (4ull << 30) && !cand.empty()) { if ((rc = flush_group()) < 0) return rc; }
             cand.push_back(i); grp += streams[i].in_len;
         }
-        const bool had = !cand.empty();
         if ((rc = flush_group()) < 0) return rc;
-        if (had) par_jobs += e->e.last_par_jobs;
-        e->e.last_par_jobs = par_jobs;
     }
     for (size_t i = 0; i < n_all; i++) if (!par_done[i]) idx.push_back(i);
     const size_t n = idx.size();

@@ -45,8 +45,7 @@ struct InfState {
 // chunk-parallel decode of whole members (szl_kernels_inflate_par.hip)
 struct FindJob { uint64_t in_off, in_len, lo_bit, hi_bit; };     // look for a block header of the member at in_off in [lo_bit, hi_bit)
 struct ParMember {                                               // one member being assembled from its chunk jobs
-    uint64_t sym_off;   // first symbol of the member in the symbol staging (elements)
-    uint64_t ooff_off;  // first of its njobs + 1 output offsets
+    uint64_t ooff_off;  // first of its njobs + 1 output offsets (and of its jobs' staging offsets)
     uint64_t win_off;   // its (njobs + 1) windows of 32 KiB (bytes)
     uint64_t out_off;   // arena offset of its output region
     uint64_t total;     // output bytes

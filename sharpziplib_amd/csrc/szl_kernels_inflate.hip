@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
     uint32_t lnum = st->lnum, dnum = st->dnum;
     const uint32_t pend_len = 0, pend_dist = 0; // a token that does not fit is simply not consumed
     const uint64_t out_start = outpos;             // stream position of out[0] for this call
-    const uint64_t out_limit = PMODE ? ~0ull >> 1 : outpos + job.out_cap;
+    const uint64_t out_limit = PMODE == 1 ? ~0ull >> 1 : outpos + job.out_cap;   // (symbol pass: the job's staging region)
     uint64_t flushed = outpos;
     int status = INF_RUNNING;
 

@@ -135,12 +135,13 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
 
 // Front to back over the jobs of one member (one workgroup per member): W_j = the 32 KiB of output that end where job j's
 // output ends, as bytes.  wins[(j + 1) * 32768 ..] = W_j ; wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).
-__global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym_all, const uint64_t *__restrict__ ooff_all,
-                                                       uint8_t *__restrict__ wins_all, const ParMember *__restrict__ mem) {
+__global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,
+                                                       const uint64_t *__restrict__ jbase_all, uint8_t *__restrict__ wins_all,
+                                                       const ParMember *__restrict__ mem) {
     __shared__ __attribute__((aligned(16))) uint8_t s_w[2][32768];
     const ParMember m = mem[blockIdx.x];
-    const uint16_t *sym = sym_all + m.sym_off;
     const uint64_t *out_off = ooff_all + m.ooff_off;
+    const uint64_t *jbase = jbase_all + m.ooff_off;   // first symbol of job j in the staging (the jobs' regions need not be adjacent)
     uint8_t *wins = wins_all + m.win_off;
     const uint32_t njobs = m.njobs;
     const int tid = threadIdx.x;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
         const uint8_t *prev = s_w[cur];
         uint8_t *next = s_w[cur ^ 1];
         if (len >= 32768) {   // the usual job: its last 32 KiB are all its own symbols — 32 independent loads per thread in flight
-            const uint16_t *src = sym + (o1 - 32768) + tid;
+            const uint16_t *src = sym + jbase[j] + (len - 32768) + tid;
             uint32_t sv[32];
 #pragma unroll
             for (int k = 0; k < 32; k++) sv[k] = src[1024 * k];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
             for (int t = tid; t < 32768; t += 1024) {
                 uint8_t b;
                 if ((uint64_t)(32768 - t) <= len) {                // position o1 - 32768 + t lies inside job j's output
-                    const uint32_t sv = sym[o1 - 32768 + (uint64_t)t];
+                    const uint32_t sv = sym[jbase[j] + (len - 32768 + (uint64_t)t)];
                     b = sv < 0x8000u ? (uint8_t)sv : prev[sv & 0x7FFF];
                 } else b = prev[(uint64_t)t + len];                // still the previous window, shifted by this job's output
                 next[t] = b;
@@ -181,14 +182,14 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
 }
 
 // symbols -> bytes; one workgroup per 16 KiB of a member's output (blk0 = the member's first workgroup)
-__global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym_all, const uint64_t *__restrict__ ooff_all,
-                                                 const uint8_t *__restrict__ wins_all, uint8_t *__restrict__ out_base,
-                                                 const ParMember *__restrict__ mem, uint32_t nmem) {
+__global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,
+                                                 const uint64_t *__restrict__ jbase_all, const uint8_t *__restrict__ wins_all,
+                                                 uint8_t *__restrict__ out_base, const ParMember *__restrict__ mem, uint32_t nmem) {
     uint32_t a = 0, z = nmem;                                      // last member with blk0 <= blockIdx.x
     while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if (mem[mid].blk0 <= blockIdx.x) a = mid; else z = mid; }
     const ParMember m = mem[a];
-    const uint16_t *sym = sym_all + m.sym_off;
     const uint64_t *out_off = ooff_all + m.ooff_off;
+    const uint64_t *jbase = jbase_all + m.ooff_off;
     const uint8_t *wins = wins_all + m.win_off;
     uint8_t *out = out_base + m.out_off;
     const uint32_t njobs = m.njobs;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sy
     uint32_t j = lo;
     for (uint64_t q = b0 + threadIdx.x; q < b1; q += 256) {
         while (j + 1 < njobs && out_off[j + 1] <= q) j++;
-        const uint32_t sv = sym[q];
+        const uint32_t sv = sym[jbase[j] + (q - out_off[j])];
         out[q] = sv < 0x8000u ? (uint8_t)sv : wins[(uint64_t)j * 32768 + (sv & 0x7FFF)];   // window in front of job j = W_{j-1}
     }
 }
@@ -209,12 +210,12 @@ __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sy
 void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st) {
     if (njobs) hipLaunchKernelGGL(k_find_blocks, dim3(njobs), dim3(64), 0, st, in_base, fjobs, njobs, start_bit);
 }
-void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st) {
-    if (nmem) hipLaunchKernelGGL(k_resolve_wins, dim3(nmem), dim3(1024), 0, st, sym, ooff, wins, mem);
+void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st) {
+    if (nmem) hipLaunchKernelGGL(k_resolve_wins, dim3(nmem), dim3(1024), 0, st, sym, ooff, jbase, wins, mem);
 }
-void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint8_t *wins, uint8_t *out_base, const ParMember *mem, uint32_t nmem,
-                    uint32_t nblocks, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_convert, dim3(nblocks), dim3(256), 0, st, sym, ooff, wins, out_base, mem, nmem);
+void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, const uint8_t *wins, uint8_t *out_base, const ParMember *mem,
+                    uint32_t nmem, uint32_t nblocks, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_convert, dim3(nblocks), dim3(256), 0, st, sym, ooff, jbase, wins, out_base, mem, nmem);
 }
 
 } // namespace szl

@@ -157,6 +157,28 @@ def test_mixed_batch(eng):
         assert r.status == 0 and r.data == w.tobytes() and consumed == len(s) and r.crc32 == zlib.crc32(w.tobytes())
 
 
+@pytest.mark.parametrize("single", [0, 1])
+def test_single_pass_and_count_first_forms_agree(eng, single):
+    """The decoder normally skips the count pass and sizes every job's staging region from the caller's capacity; a member whose
+    expansion varies wildly (random bytes next to long runs) overruns a region and is redone count-first.  Both forms, same bytes."""
+    from sharpziplib_amd import _lib
+    parts = []
+    for i in range(6):
+        parts.append(C.random_bytes(700000, seed=50 + i))
+        parts.append(np.full(6 << 20, 65 + i, np.uint8))
+        parts.append(C.generate("logs", 60 + i, 0, 900000))
+    data = np.concatenate(parts)
+    stream = zlib.compress(data.tobytes(), 6)[2:-4]
+    _lib.lib().szl_debug_set(b"SZL_INF_SINGLE_PASS", single)
+    try:
+        rp, rs, jobs = _both(eng, stream, data.size)
+    finally:
+        _lib.lib().szl_debug_set(b"SZL_INF_SINGLE_PASS", -2147483648)
+    assert jobs >= 8
+    _same(rp, rs)
+    assert rp[0].status == 0 and rp[0].data == data.tobytes()
+
+
 def test_several_long_members_in_one_call(eng):
     """the passes of all long members of a call share their launches; a broken one among them falls back alone"""
     rng = np.random.default_rng(4)
