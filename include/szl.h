@@ -138,7 +138,11 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
 /* Several devices of one node behind the same call (SURVEY §8e "shard per GPU": ZipOutputStream entries S/Zip/ZipOutputStream.cs:494,
  * gzip members S/GZip/GzipInputStream.cs:353-357): the streams are cut into n_dev contiguous groups of about equal input bytes and
  * group g is compressed on devices[g] by its own host thread and engine; only a group's own bytes travel to its device.  Results
- * are identical to the single-device calls (every stream is independent).  The same ordinal may appear more than once. */
+ * are identical to the single-device calls (every stream is independent).  The same ordinal may appear more than once.
+ * ONE stream (n_streams == 1, levels 5-9, at least SZL_PART_MIN_KIB = 64 MiB per device) is not left to a single device: it is
+ * cut into n_dev position ranges, each device runs the match search and the parse of its range (one Deflater lifetime,
+ * S/GZip/GzipOutputStream.cs:87, has no other parallel form), the host checks that each range's parse is entered where the
+ * previous one leaves it, and devices[0] builds the blocks from all tokens.  Same bytes as one device. */
 int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  int level, int strategy, unsigned flags);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,

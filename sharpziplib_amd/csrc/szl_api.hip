@@ -372,8 +372,144 @@ static int multi_run(bool inflate, const int *devices, int n_dev, const void *h_
     for (int g = 0; g < n_dev; g++) if (rcs[g]) { set_error("device %d (group %d): %s", devices[g], g, errs[g].c_str()); return rcs[g]; }
     return 0;
 }
+// ---------------------------------------------------------------------------------------------
+// ONE stream over several engines / devices (levels 5-9): exact position-range partition.
+//   * The stream is cut into n_dev contiguous parts at multiples of the stage-B tile.  Part g runs stages A, B and C on
+//     devices[g] with the window pipeline (Engine::PartRun): it needs nothing but its bytes, 64 KiB of history and a few KiB of
+//     lookahead.  What it cannot know is the iteration on which the true parse enters it — so it parses a warm-up stretch in
+//     front of the part from an assumed clean state and drops those tokens.  Two parses that are clean at the same position are
+//     identical from there on: the entry the warm-up arrives at is the true one iff the previous part's parse leaves on it.
+//   * The host checks exit(g-1) == entry(g) for every g and re-runs a part with the right entry where that fails (data whose
+//     parses never re-synchronise: long runs of one byte).  No other exchange between the parts.
+//   * The tokens of all parts are gathered on devices[0] (hipMemcpyPeer), which also holds the whole input, and stage D — block
+//     positions from the tokens' own lengths, Huffman trees, bit packing, checksums, framing — runs there once.
+// Same bytes as one engine produces (tests/test_gpu_multi.py runs two and three engines on one device against it and the oracle).
+static int stream_multi_run(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *stream, int level, int strategy, unsigned flags) {
+    LevelParams P;
+    int rc = level_params(level, strategy, &P);
+    if (rc) return rc;
+    std::vector<SegDev> segs; std::vector<uint64_t> bnds_unused; uint64_t in_total0, out_total0;
+    if ((rc = build_batch(stream, 1, flags, level, segs, bnds_unused, &in_total0, &out_total0))) return rc;
+    const SegDev whole = segs[0];                       // buf_off = in_off, seg [0, N)
+    const int64_t N = (int64_t)stream->in_len;
+    const uint8_t *src = (const uint8_t *)h_in + stream->in_off;
+    const uint64_t window = std::max<uint64_t>((uint64_t)szl::knob("SZL_WINDOW_KIB", 256 * 1024) * 1024 / B_TILE * B_TILE, B_TILE);
+    const int64_t WARM = (int64_t)std::max(64, szl::knob("SZL_PART_WARM_KIB", 256)) * 1024;
+    const int64_t LOOK = C_WIN_HALO + 1024 + MAX_MATCH + 64;      // bytes a part sees beyond its end (halo of the last window + hand-over slack)
+    std::vector<int64_t> cut(n_dev + 1);
+    for (int g = 0; g <= n_dev; g++) cut[g] = g == n_dev ? N : (int64_t)((uint64_t)N * (uint64_t)g / (uint64_t)n_dev / B_TILE * B_TILE);
+    { std::lock_guard<std::mutex> lk(g_multi_mu); if ((int)g_multi_slots.size() < n_dev) g_multi_slots.resize(n_dev); }
+    struct PartOut { int rc = 0; std::string err; int64_t entry = 0, exit = 0; uint64_t ntok = 0; int64_t b0 = 0; };
+    std::vector<PartOut> po(n_dev);
+    auto run_part = [&](int g, int64_t force_entry) {
+        PartOut &o = po[g];
+        o.rc = 0;
+        if (hipSetDevice(devices[g]) != hipSuccess) { o.rc = SZL_E_DEVICE; o.err = "hipSetDevice failed"; return; }
+        MultiSlot &slot = g_multi_slots[g];
+        if (slot.eng && slot.device != devices[g]) { szl_engine_destroy(slot.eng); slot.eng = nullptr; }
+        if (!slot.eng) { slot.eng = szl_engine_create(); slot.device = devices[g]; }
+        if (!slot.eng) { o.rc = SZL_E_DEVICE; o.err = last_error(); return; }
+        Engine &E = slot.eng->e;
+        // bytes of this part: 64 KiB of history in front of the warm-up, a little lookahead behind the part; engine 0 takes all
+        // of the stream (stage D and the checksums need it)
+        const int64_t first = cut[g], pend = cut[g + 1];
+        const int64_t warm_from = g == 0 ? -1 : std::max<int64_t>(0, first - WARM) / B_TILE * B_TILE;
+        const int64_t b0 = g == 0 ? 0 : std::max<int64_t>(0, (force_entry >= 0 ? std::min(force_entry, first) : warm_from) - 65536);
+        const int64_t b1 = g == 0 ? N : std::min<int64_t>(N, pend + LOOK);
+        o.b0 = b0;
+        const uint64_t nb = (uint64_t)(b1 - b0);
+        int r;
+        if ((r = E.stage_in.ensure(nb + 64))) { o.rc = r; o.err = last_error(); return; }
+        if (force_entry < 0 || g != 0)   // (engine 0 keeps its copy across a re-run)
+            if (nb && hipMemcpy(E.stage_in.p, src + b0, nb, hipMemcpyHostToDevice) != hipSuccess) { o.rc = SZL_E_DEVICE; o.err = "H2D failed"; return; }
+        SegDev sg{};
+        sg.buf_off = 0; sg.abs0 = (uint64_t)b0;               // window bases follow the absolute position (C/DeflaterEngine.cs:371,:771)
+        sg.seg_start = (g == 0 ? 0 : (warm_from >= 0 ? warm_from : first)) - b0; sg.seg_end = b1 - b0;
+        sg.bnd_off = 0; sg.bnd_cnt = 1;
+        // the only boundary that matters is the true end of the stream (InsertString needs three bytes, :780): a part that does not
+        // see it has none within reach
+        std::vector<uint64_t> bnds{(uint64_t)(b1 == N ? N - b0 : (b1 - b0) + 64)};
+        sg.finish = whole.finish; sg.flags = 0; sg.out_off = 0; sg.out_cap = 0; sg.start_bit = 0; sg.adler_init = 1; sg.crc_init = 0;
+        E.part = Engine::PartRun{};
+        E.part.active = true; E.part.first = first - b0; E.part.parse_end = pend - b0;
+        E.part.warm_from = (g == 0 || force_entry >= 0) ? -1 : warm_from - b0;
+        E.part.force_entry = force_entry >= 0 ? force_entry - b0 : -1;
+        if (E.part.force_entry >= 0) sg.seg_start = std::min<int64_t>(sg.seg_start, E.part.force_entry);
+        std::vector<SegOut> res;
+        r = E.deflate_windowed((const uint8_t *)E.stage_in.p, nb, nullptr, 0, sg, bnds, P, 0, res, nullptr, window);
+        const Engine::PartRun pr = E.part;
+        E.part = Engine::PartRun{};
+        if (r == SZL_E_STATE && force_entry < 0 && g != 0) { o.entry = -1; o.exit = -1; o.ntok = 0; return; }   // the warm-up found no clean hand-over: decided in the chain below
+        if (r) { o.rc = r; o.err = last_error(); return; }
+        o.entry = pr.entry + b0; o.exit = pr.exit + b0; o.ntok = pr.tok_count;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int g = 1; g < n_dev; g++) th.emplace_back(run_part, g, (int64_t)-1);
+        run_part(0, -1);
+        for (auto &t : th) t.join();
+    }
+    for (int g = 0; g < n_dev; g++) if (po[g].rc) { (void)hipSetDevice(g_device); set_error("part %d on device %d: %s", g, devices[g], po[g].err.c_str()); return po[g].rc; }
+    // ---- the chain of hand-overs
+    int reruns = 0;
+    for (int g = 1; g < n_dev; g++) {
+        if (po[g].entry == po[g - 1].exit) continue;
+        run_part(g, po[g - 1].exit);                     // (sequential: its exit decides about the next part)
+        reruns++;
+        if (po[g].rc) { (void)hipSetDevice(g_device); set_error("part %d on device %d (re-run): %s", g, devices[g], po[g].err.c_str()); return po[g].rc; }
+        if (po[g].entry != po[g - 1].exit) { (void)hipSetDevice(g_device); set_error("part %d: forced entry not honoured", g); return SZL_E_STATE; }
+    }
+    if (szl::knob("SZL_DEBUG", 0)) {
+        fprintf(stderr, "[szl] one stream on %d engines: %d part(s) re-run;", n_dev, reruns);
+        for (int g = 0; g < n_dev; g++) fprintf(stderr, " [%lld,%lld) %llu tok", (long long)po[g].entry, (long long)po[g].exit, (unsigned long long)po[g].ntok);
+        fprintf(stderr, "\n");
+    }
+    // ---- gather the tokens on engine 0 and finish there
+    if (hipSetDevice(devices[0]) != hipSuccess) return SZL_E_DEVICE;
+    Engine &E0 = g_multi_slots[0].eng->e;
+    uint64_t ntok = 0;
+    for (int g = 0; g < n_dev; g++) ntok += po[g].ntok;
+    {   // tokens of part 0 are in place; make room behind them (the buffer may move)
+        DevBuf nt;
+        if ((rc = nt.ensure((ntok + 16) * 4))) return rc;
+        uint64_t at = 0;
+        for (int g = 0; g < n_dev; g++) {
+            const Engine &Eg = g_multi_slots[g].eng->e;
+            if (po[g].ntok && hipMemcpyPeer((uint32_t *)nt.p + at, devices[0], Eg.tokens.p, devices[g], po[g].ntok * 4) != hipSuccess) {
+                nt.release(); (void)hipSetDevice(g_device); set_error("token gather from device %d failed", devices[g]); return SZL_E_DEVICE;
+            }
+            at += po[g].ntok;
+        }
+        E0.tokens.release();
+        E0.tokens = nt;                                  // (DevBuf is a plain pointer + capacity; E0 owns it from here)
+    }
+    SegDev fin = whole;
+    fin.buf_off = 0;                                     // engine 0's copy of the stream starts at its buffer's first byte
+    if ((rc = E0.stage_out.ensure(stream->out_cap + 64))) return rc;
+    fin.out_off = 0;
+    std::vector<SegOut> res;
+    const unsigned want = ((flags & (SZL_F_CRC32 | SZL_F_GZIP)) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !(flags & (SZL_F_NOWRAP | SZL_F_GZIP))) ? 2u : 0u);
+    rc = E0.finish_tokens((const uint8_t *)E0.stage_in.p, (uint64_t)N, (uint8_t *)E0.stage_out.p, fin, ntok, want, res, nullptr);
+    if (rc) { (void)hipSetDevice(g_device); return rc; }
+    stream->out_len = res[0].out_bytes; stream->crc32 = res[0].crc32; stream->adler32 = res[0].adler32;
+    stream->status = res[0].out_bytes <= stream->out_cap ? 0 : SZL_E_OUTPUT_TOO_SMALL;
+    if (stream->status == 0 && stream->out_len &&
+        hipMemcpy((uint8_t *)h_out + stream->out_off, E0.stage_out.p, stream->out_len, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(g_device); set_error("D2H failed"); return SZL_E_DEVICE; }
+    (void)hipSetDevice(g_device);
+    return 0;
+}
+
 int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  int level, int strategy, unsigned flags) {
+    // one long stream at a DeflateSlow level: exact position-range partition over the devices (stream_multi_run); otherwise by stream
+    const int lv = level == -1 ? 6 : level;
+    if (n_streams == 1 && streams && n_dev > 1 && devices && lv >= 5 && lv <= 9 && strategy >= 0 && strategy <= 2 &&
+        streams[0].in_len >= (uint64_t)std::max(1, szl::knob("SZL_PART_MIN_KIB", 64 * 1024)) * 1024 * (uint64_t)n_dev) {
+        int ndev_avail = 0;
+        if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
+        for (int g = 0; g < n_dev; g++) if (devices[g] < 0 || devices[g] >= ndev_avail) { set_error("device ordinal %d out of range", devices[g]); return SZL_E_ARG; }
+        return stream_multi_run(devices, n_dev, h_in, h_out, &streams[0], lv, strategy, flags);
+    }
     return multi_run(false, devices, n_dev, h_in, h_out, streams, n_streams, level, strategy, flags);
 }
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,

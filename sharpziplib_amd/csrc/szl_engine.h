@@ -37,6 +37,24 @@ class Engine {
     int deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
                          const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st,
                          uint64_t window);
+    // One stream over several engines (szl_api.hip, stream_multi_run): an engine runs stages A-C of a *part* [first, parse_end) of
+    // the stream with deflate_windowed and keeps the tokens; stage D then runs once, on one engine, over all parts' tokens
+    // (finish_tokens).  A part that does not start the stream does not know the iteration the true parse enters it on: it
+    // parses a warm-up stretch [warm_from, first) from an assumed clean state first and drops those tokens — two parses that are
+    // clean at the same position are identical from there on, so the entry it arrives at (`entry`) is the true one iff the
+    // previous part's parse leaves on it (`exit`); the caller checks that and re-runs a part with force_entry otherwise.
+    struct PartRun {
+        bool active = false;
+        int64_t first = 0, parse_end = 0;      // buffer positions
+        int64_t warm_from = -1;                // >= 0: warm-up from here
+        int64_t force_entry = -1;              // >= 0: start exactly here (no warm-up)
+        int64_t entry = 0, exit = 0;           // [out] the part's tokens cover [entry, exit)
+        uint64_t tok_count = 0;                // [out]
+    } part;
+    // Stage D (and the checksums) of one stream whose tokens[0 .. tok_total) are in `tokens`: block positions are recomputed
+    // from the tokens themselves.
+    int finish_tokens(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, SegDev seg, uint64_t tok_total, unsigned want_ck,
+                      std::vector<SegOut> &results, hipStream_t st);
     // progress of an overlapped host->device copy of the input arena (szl_deflate_batch_host): the engine waits until the bytes a
     // window needs have arrived.  nullptr: everything is resident.
     const volatile uint64_t *in_ready = nullptr;

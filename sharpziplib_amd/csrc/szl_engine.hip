@@ -17,6 +17,8 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
                   uint16_t *link, const uint32_t *hflags, hipStream_t st);
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
+void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
+                            hipStream_t st);
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
                              const uint16_t *link, MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st);
 void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
@@ -476,6 +478,10 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
     const int64_t S0 = seg.seg_start, N = seg.seg_end;           // the real segment [S0, N) inside its stream buffer
     const uint64_t n = (uint64_t)(N - S0);
     seg.look_end = N; seg.range_off = 0; seg.vis_word_off = 0; seg.range_len = C_RANGE;
+    // part of a stream (PartRun): ranges end at NP, not at the end of the bytes the engine sees; no stage D here
+    const bool is_part = part.active;
+    const int64_t NP = is_part ? part.parse_end : N;
+    const bool final_part = NP >= N;
     int rc;
     // ---- whole-stream tables and buffers
     const uint64_t blk_slots = n / BLOCK_TOKENS + 1;
@@ -499,11 +505,12 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         const uint64_t need = seg.buf_off + upto;
         while (*in_ready < (need < in_total ? need : in_total)) std::this_thread::yield();
     };
-    launch_zero_regions(dseg_real, 1, (const uint64_t *)d_zoff.p, zero_off[1], d_out, st);
+    if (!is_part) launch_zero_regions(dseg_real, 1, (const uint64_t *)d_zoff.p, zero_off[1], d_out, st);
     HIPCHK(hipMemsetAsync(d_so.p, 0, 2 * sizeof(SegOut), st));
     HIPCHK(hipMemsetAsync(counters.p, 0, 256, st));
-    const bool forked = want_ck && !in_ready;                      // (with an overlapped copy the checksums run at the end, when all bytes are there)
-    if (forked) {
+    const bool forked = want_ck && !in_ready && !is_part;          // (with an overlapped copy the checksums run at the end, when all bytes are there)
+    if (is_part) {
+    } else if (forked) {
         if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         if (!ev_fork) HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         if (!ev_join) HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -529,11 +536,20 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
     uint64_t tok_base = 0, total_unmerged = 0, peak = 0;
     float ms_links = 0, ms_match = 0, ms_parse = 0, ms_pilot = 0;
     int64_t e = S0;                                                // clean iteration the next window starts on
-    for (uint32_t wi = 0; e < N || (wi == 0 && n == 0); wi++) {
+    bool warming = false;
+    if (is_part) {
+        if (part.force_entry >= 0) e = part.force_entry;
+        else if (part.warm_from >= 0) { e = part.warm_from; warming = true; }
+        else e = part.first;
+        part.entry = e;
+    }
+    for (uint32_t wi = 0; e < NP || (wi == 0 && n == 0); wi++) {
         int64_t wend = e + (int64_t)window;
-        if (N - wend < (int64_t)(window / 4)) wend = N;            // no sliver at the end
-        const bool last = wend >= N;
-        if (last) wend = N;
+        if (NP - wend < (int64_t)(window / 4)) wend = NP;          // no sliver at the end
+        if (warming) wend = part.first;                            // the warm-up stretch is a window of its own
+        const bool part_end = wend >= NP;                          // the part's last window (not the stream's, unless final_part)
+        const bool last = part_end && final_part;
+        if (part_end) wend = NP;
         const int64_t hi = last ? N : std::min<int64_t>(N, wend + C_WIN_HALO);   // links / table entries exist for [.., hi)
         const int64_t lo = std::max<int64_t>(0, e - WSIZE);                      // links from here (stage B stages 32512 of history)
         wait_input((uint64_t)std::min<int64_t>(N, hi + MAX_MATCH + 8));
@@ -568,7 +584,7 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         // the launch wrappers index segs[span.seg] / segs[tile.seg]: entry 1 of d_segs is the window
         launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, nullptr, st);
         HIPCHK(hipEventRecord(ev[2], st));
-        if (wi == 0 && match_mode == 2 && ntiles >= 64) {          // the pilot (see deflate()): once, on the first window
+        if (wi == 0 && match_mode == 2 && ntiles >= 64 && !warming) { // the pilot (see deflate()): once, on the first window
             const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8));
             uint64_t sampled = 0;
             for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
@@ -632,10 +648,19 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         for (DevBuf *bb : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &bsp, &blp, &spec_tok, &bad_slot, &bad_range, &ckparts}) ws += bb->cap;
         peak = std::max(peak, ws);
         tok_base = tok_after;
-        if (last) break;
+        if (last) { if (is_part) part.exit = N; break; }
         e = lastr.exit_true;                                       // >= wend: the next window starts here, on a clean iteration
         if (e < wend || e > wend + 1024) { set_error("window hand-over out of range"); return SZL_E_STATE; }
+        if (warming) { warming = false; tok_base = 0; part.entry = e; continue; }   // the warm-up's tokens are dropped
+        if (part_end) { part.exit = e; break; }                    // the next part's parse is entered here
         if (e >= N) { set_error("window hand-over reached the end of the stream"); return SZL_E_STATE; } // (the last window absorbs slivers)
+    }
+    if (is_part) {
+        part.tok_count = tok_base;
+        timing.links_ms = ms_links; timing.match_ms = ms_match; timing.parse_ms = ms_parse; timing.pilot_ms = ms_pilot;
+        timing.in_bytes = (uint64_t)(part.exit - part.entry); timing.ranges_unmerged = total_unmerged; timing.tokens = tok_base;
+        last_workspace_bytes = peak;
+        return 0;
     }
     // ---- stage D over the whole token stream (as in deflate())
     SegOut whole{};
@@ -669,6 +694,57 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
     timing.out_bytes = results[0].out_bytes; timing.tokens = results[0].tok_count; timing.blocks = results[0].blk_count;
     last_lazy = lazy; last_in_total = in_total; last_blk_slots = blk_slots; last_nranges = 0; last_mt_stride = 0;
     last_workspace_bytes = peak;
+    return 0;
+}
+
+// Stage D of a stream whose tokens were produced elsewhere (PartRun): everything deflate_windowed does outside its window loop.
+int Engine::finish_tokens(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, SegDev seg, uint64_t tok_total, unsigned want_ck,
+                          std::vector<SegOut> &results, hipStream_t st) {
+    for (auto &e : ev) if (!e) HIPCHK(hipEventCreate(&e));
+    const int64_t S0 = seg.seg_start, N = seg.seg_end;
+    const uint64_t n = (uint64_t)(N - S0);
+    seg.look_end = N; seg.range_off = 0; seg.vis_word_off = 0; seg.range_len = C_RANGE;
+    int rc;
+    const uint64_t blk_slots = n / BLOCK_TOKENS + 1;
+    const uint64_t nchunks = (n + 4095) / 4096;
+    std::vector<uint64_t> chunk_off{0, nchunks}, zero_off{0, (seg.out_cap + (uint64_t)zero_piece_bytes() - 1) / (uint64_t)zero_piece_bytes()};
+    std::vector<uint64_t> fixed_blk_off{0, blk_slots};
+    if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc))) || (rc = d_so.ensure(2 * sizeof(SegOut))) || (rc = blk_counts.ensure(16)) ||
+        (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(256)) ||
+        (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes())) || (rc = cubtmp.ensure((blk_slots + 1) * 12 + 256)) ||
+        (rc = upload(ckoff, chunk_off, st)) || (rc = upload(d_zoff, zero_off, st)) || (rc = upload(blk_off, fixed_blk_off, st)) ||
+        (rc = d_segs.ensure(2 * sizeof(SegDev))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(d_segs.p, &seg, sizeof seg, hipMemcpyHostToDevice, st));
+    const SegDev *dseg_real = (const SegDev *)d_segs.p;
+    SegOut *dso = (SegOut *)d_so.p;
+    HIPCHK(hipEventRecord(ev[0], st));
+    launch_zero_regions(dseg_real, 1, (const uint64_t *)d_zoff.p, zero_off[1], d_out, st);
+    HIPCHK(hipMemsetAsync(d_so.p, 0, 2 * sizeof(SegOut), st));
+    SegOut whole{};
+    whole.tok_first = 0; whole.tok_count = tok_total;
+    HIPCHK(hipMemcpyAsync((char *)dso, &whole, offsetof(SegOut, blk_first), hipMemcpyHostToDevice, st));
+    launch_checksums(d_in, dseg_real, 1, (const uint64_t *)ckoff.p, want_ck ? nchunks : 0, ckparts.p, dso, want_ck, st);
+    launch_block_positions((const uint32_t *)tokens.p, tok_total, S0, (uint64_t *)cubtmp.p, (uint32_t *)((uint64_t *)cubtmp.p + blk_slots + 1),
+                           (int64_t *)bsp.p, (int64_t *)blp.p, st);
+    HIPCHK(hipEventRecord(ev[4], st));
+    launch_seg_blocks(dseg_real, 1, (const uint32_t *)tokens.p, (const uint64_t *)blk_off.p, dso, 0, st);
+    launch_block_build(dseg_real, 1, dso, (const uint64_t *)blk_off.p, (const uint32_t *)tokens.p, (const int64_t *)bsp.p, (const int64_t *)blp.p,
+                       (BlockDesc *)descs.p, (uint32_t)blk_slots, 0, st);
+    launch_block_scan(dseg_real, 1, dso, (BlockDesc *)descs.p, st);
+    HIPCHK(hipEventRecord(ev[5], st));
+    launch_block_encode(d_in, d_out, dseg_real, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);
+    launch_seg_finish(dseg_real, 1, dso, d_out, st);
+    HIPCHK(hipEventRecord(ev[6], st));
+    HIPCHK(hipGetLastError());
+    results.assign(1, SegOut{});
+    HIPCHK(hipMemcpyAsync(results.data(), d_so.p, sizeof(SegOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float d1 = 0, d2 = 0;
+    (void)hipEventElapsedTime(&d1, ev[4], ev[5]); (void)hipEventElapsedTime(&d2, ev[5], ev[6]);
+    timing.blocks_ms = d1; timing.encode_ms = d2;
+    timing.in_bytes = n; timing.out_bytes = results[0].out_bytes; timing.tokens = results[0].tok_count; timing.blocks = results[0].blk_count;
+    last_in_total = in_total; last_blk_slots = blk_slots;
     return 0;
 }
 

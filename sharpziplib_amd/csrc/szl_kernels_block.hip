@@ -689,4 +689,38 @@ void launch_seg_finish(const SegDev *segs, uint32_t nseg, SegOut *so, uint8_t *o
     hipLaunchKernelGGL(k_seg_finish, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, so, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block positions from the tokens alone (one stream assembled from the tokens of several engines, Engine::finish_tokens): the
+// parse kernels normally note where every 16384-token block starts and where its last token starts while they emit; both are
+// prefix sums of token lengths (literal 1, match len).
+__global__ __launch_bounds__(256) void k_block_tok_sums(const uint32_t *__restrict__ tokens, uint64_t ntok, uint64_t *__restrict__ sums,
+                                                        uint32_t *__restrict__ lastlen) {
+    __shared__ uint64_t part[256];
+    const uint64_t b = blockIdx.x;
+    const uint64_t t0 = b * BLOCK_TOKENS, t1 = t0 + BLOCK_TOKENS < ntok ? t0 + BLOCK_TOKENS : ntok;
+    uint64_t acc = 0;
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += 256) { const uint32_t t = tokens[i]; acc += (t >> 16) ? (t & 0xFFFFu) : 1u; }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        sums[b] = part[0];
+        const uint32_t t = t1 > t0 ? tokens[t1 - 1] : 0u;
+        lastlen[b] = t1 > t0 ? ((t >> 16) ? (t & 0xFFFFu) : 1u) : 0u;
+    }
+}
+__global__ void k_block_positions(const uint64_t *__restrict__ sums, const uint32_t *__restrict__ lastlen, uint64_t nblk, int64_t seg_start,
+                                  int64_t *__restrict__ bsp, int64_t *__restrict__ blp) {
+    if (blockIdx.x || threadIdx.x) return;
+    int64_t pos = seg_start;
+    for (uint64_t b = 0; b < nblk; b++) { bsp[b] = pos; blp[b] = pos + (int64_t)sums[b] - (int64_t)lastlen[b]; pos += (int64_t)sums[b]; }
+}
+void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
+                            hipStream_t st) {
+    const uint64_t nblk = (ntok + BLOCK_TOKENS - 1) / BLOCK_TOKENS;
+    if (!nblk) return;
+    hipLaunchKernelGGL(k_block_tok_sums, dim3((unsigned)nblk), dim3(256), 0, st, tokens, ntok, sums, lastlen);
+    hipLaunchKernelGGL(k_block_positions, dim3(1), dim3(1), 0, st, sums, lastlen, nblk, seg_start, bsp, blp);
+}
+
 } // namespace szl

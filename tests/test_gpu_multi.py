@@ -50,3 +50,63 @@ def test_bad_device_ordinal_is_an_argument_error():
     from sharpziplib_amd.batch import deflate_multi
     with pytest.raises(_lib.SzlError):
         deflate_multi([b"abc"], [0, 99])
+
+
+# ---- ONE stream over several engines (stream_multi_run in csrc/szl_api.hip): exact position-range partition -------------------
+def _knob(name, value):
+    from sharpziplib_amd import _lib
+    _lib.lib().szl_debug_set(name.encode(), value)
+
+
+@pytest.fixture()
+def small_parts():
+    """parts of a few MiB and windows of 1 MiB, so that a modest stream already has several windows per part"""
+    _knob("SZL_PART_MIN_KIB", 1024); _knob("SZL_WINDOW_KIB", 1024); _knob("SZL_PART_WARM_KIB", 64)
+    yield
+    for k in ("SZL_PART_MIN_KIB", "SZL_WINDOW_KIB", "SZL_PART_WARM_KIB"):
+        _knob(k, -2147483648)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 5])
+@pytest.mark.parametrize("kind,level", [("enwik", 6), ("logs", 9), ("dickens", 5)])
+def test_one_stream_over_several_engines_equals_oracle(small_parts, devices, kind, level):
+    from sharpziplib_amd.batch import deflate_multi
+    data = C.generate(kind, 0x5EED, 0, 20 << 20)
+    (r,) = deflate_multi([data], devices, level=level, crc32=True)
+    assert r.status == 0 and r.crc32 == O.crc32(data)
+    assert r.data == O.deflate(data, level)
+
+
+def test_one_stream_with_zlib_framing_and_strategies(small_parts):
+    import zlib
+    from sharpziplib_amd.batch import deflate_multi
+    data = C.generate("enwik", 77, 0, 12 << 20)
+    (r,) = deflate_multi([data], [0, 0, 0], level=6, nowrap=False)
+    assert r.status == 0 and zlib.decompress(r.data) == data.tobytes() and r.adler32 == zlib.adler32(data.tobytes())
+    assert r.data[2:-4] == O.deflate(data, 6)
+    for strategy in (1, 2):
+        (r,) = deflate_multi([data], [0, 0], level=6, strategy=strategy)
+        assert r.data == O.deflate(data, 6, strategy=strategy)
+
+
+def test_one_stream_whose_parses_never_resynchronise(small_parts):
+    """long runs of one byte: a warm-up from an assumed clean state does not land on the true parse, the hand-over check fails
+    and the part is run again from the previous part's exit — same bytes in the end"""
+    from sharpziplib_amd.batch import deflate_multi
+    data = np.concatenate([np.zeros(7 << 20, np.uint8), C.generate("logs", 5, 0, 3 << 20), np.full(6 << 20, 0x55, np.uint8),
+                           C.period10(2 << 20) if hasattr(C, "period10") else np.zeros(2 << 20, np.uint8)])
+    (r,) = deflate_multi([data], [0, 0, 0, 0], level=6, crc32=True)
+    assert r.status == 0 and r.data == O.deflate(data, 6)
+
+
+def test_one_long_stream_default_knobs():
+    """library defaults (256 MiB windows, 256 KiB warm-up): 192 MiB over two engines against the single-engine call"""
+    import hashlib
+    from sharpziplib_amd.batch import Engine, deflate_multi
+    data = C.generate("enwik", 0xE9, 0, 192 << 20)
+    (r,) = deflate_multi([data], [0, 0], level=6, crc32=True)
+    eng = Engine()
+    (one,) = eng.deflate([data], level=6, crc32=True)
+    eng.close()
+    assert r.status == 0 and r.crc32 == one.crc32
+    assert hashlib.sha256(r.data).hexdigest() == hashlib.sha256(one.data).hexdigest()
