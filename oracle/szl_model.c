@@ -178,6 +178,19 @@ size_t szm_parse(const uint8_t *d, size_t seg_start, size_t seg_end, const uint1
     return nt;
 }
 
+/* First clean iteration at or after `at_least` of the parse that starts, clean, at `from` (hand-over between the parts of one
+ * stream on several engines, and between the windows of a long stream: DESIGN §3, §6). */
+size_t szm_first_node(const uint8_t *d, size_t seg_end, const uint16_t *link, const uint32_t *m2, const uint32_t *mq,
+                      const szm_params *P, size_t from, size_t at_least) {
+    size_t p = from;
+    node_t nd;
+    while (p < seg_end && p < at_least) {
+        node_eval(d, p, seg_end, link, m2, mq, P, &nd, NULL);
+        p = nd.next;
+    }
+    return p;
+}
+
 size_t szm_parse_ranges(const uint8_t *d, size_t seg_start, size_t seg_end, const uint16_t *link, const uint32_t *m2,
                         const uint32_t *mq, const szm_params *P, size_t R, uint32_t *tok, uint64_t *stats) {
     size_t n = seg_end - seg_start;

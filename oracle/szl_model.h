@@ -50,6 +50,9 @@ size_t szm_parse_ranges(const uint8_t *d, size_t seg_start, size_t seg_end, cons
 
 /* Block table for a segment's token stream (DeflaterEngine.cs:841-852, :750-768):
  * fills first_token[]/ntok[]/last[] ; returns number of blocks. `finish` = segment ended by Finish(). */
+/* first clean iteration >= at_least of the parse that starts clean at `from` */
+size_t szm_first_node(const uint8_t *d, size_t seg_end, const uint16_t *link, const uint32_t *m2, const uint32_t *mq,
+                      const szm_params *P, size_t from, size_t at_least);
 size_t szm_block_table(const uint32_t *tok, size_t ntok, int finish, int64_t *first_token, int32_t *count, int32_t *last);
 
 /* base_of(s): window base in effect for an iteration starting at absolute position s (App. A.2). */

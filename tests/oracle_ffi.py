@@ -79,6 +79,7 @@ def lib():
         ("szm_fast_parse", sz, [vp, sz, sz, vp, vp, vp, vp]),
         ("szm_fast_parse_fixpoint", sz, [vp, sz, sz, vp, vp, sz, vp, vp, vp]),
         ("szm_parse_needed", sz, [vp, sz, sz, vp, vp, vp, vp, vp]),
+        ("szm_first_node", sz, [vp, sz, vp, vp, vp, vp, sz, sz]),
         ("szm_lazy_eval_set", sz, [vp, sz, sz, vp, vp, vp, vp, sz, sz, vp]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
@@ -314,6 +315,11 @@ class Model:
                                         self.m2.ctypes.data, self.mq.ctypes.data, ctypes.byref(self.P), R,
                                         tok.ctypes.data, stats.ctypes.data)
         return tok[:k].copy(), stats
+
+    def first_node(self, start, at_least):
+        """first clean iteration >= at_least of the parse that starts, clean, at `start`"""
+        return int(self.L.szm_first_node(self._dpad.ctypes.data, self.n, self.link.ctypes.data, self.m2.ctypes.data, self.mq.ctypes.data,
+                                         ctypes.byref(self.P), start, at_least))
 
     def block_table(self, tok, finish=True):
         nb_cap = tok.size // 16384 + 4

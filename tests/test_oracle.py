@@ -272,3 +272,44 @@ def test_mutated_streams_do_not_break_the_oracle():
             assert delivered == out1, name
         else:
             assert out1 == b"" and (n == n1 or {n, n1} <= {-100, -102, -103}), (name, n, n1)
+
+
+def test_part_hand_over_arithmetic_of_one_stream_on_several_engines():
+    """CPU model of csrc/szl_api.hip::stream_multi_run (DESIGN §6): a part parses a warm-up stretch from an assumed clean state;
+    the clean iteration it reaches at its first position is the true parse's iff the previous part leaves on it; the parts'
+    tokens then concatenate to the stream's, and block positions follow from the tokens' own lengths."""
+    tile, warm = 16384, 65536
+    for kind, level in (("enwik", 6), ("logs", 9), ("dickens", 5)):
+        data = C.generate(kind, 0xBEEF, 0, 900000)
+        m = O.Model(data, level)
+        T, _ = m.parse()
+        lens = np.where((T >> 16) != 0, T & 0xFFFF, 1).astype(np.int64)
+        starts = np.concatenate([[0], np.cumsum(lens)])                     # input position of every token (+ the end)
+        assert starts[-1] == data.size
+        for nparts in (2, 3, 5):
+            cuts = [data.size * g // nparts // tile * tile for g in range(nparts)] + [data.size]
+            toks, prev_exit = [], 0
+            for g in range(nparts):
+                first, pend = cuts[g], cuts[g + 1]
+                entry = 0 if g == 0 else m.first_node(max(0, first - warm) // tile * tile, first)   # what the warm-up arrives at
+                true_entry = m.first_node(0, first)                          # where the stream's own parse enters the part
+                assert entry == true_entry == prev_exit, (kind, nparts, g)
+                exit_ = data.size if pend == data.size else m.first_node(entry, pend)
+                part, _ = m.parse(entry, data.size)                          # clean at `entry`: the same tokens as the stream's from there on
+                k = int(np.searchsorted(starts, exit_)) - int(np.searchsorted(starts, entry))
+                assert starts[np.searchsorted(starts, entry)] == entry and starts[np.searchsorted(starts, exit_)] == exit_
+                toks.append(part[:k])
+                prev_exit = exit_
+            allt = np.concatenate(toks)
+            assert np.array_equal(allt, T), (kind, nparts)
+        # block positions from the tokens alone (k_block_tok_sums / k_block_positions): start of block b, start of its last token
+        first_tok, cnt, _ = m.block_table(T)
+        for b in range(len(first_tok)):
+            t0 = b * 16384
+            assert first_tok[b] == t0
+            bsp = int(starts[t0]); blp = int(starts[t0 + cnt[b] - 1]) if cnt[b] else bsp
+            assert bsp == lens[:t0].sum() and blp == bsp + lens[t0:t0 + cnt[b]].sum() - (lens[t0 + cnt[b] - 1] if cnt[b] else 0)
+    # runs of one byte: a warm-up does not land on the true parse — the check the host makes must see that
+    z = np.zeros(400000, np.uint8)
+    m = O.Model(z, 6)
+    assert m.first_node(65536, 131072) != m.first_node(0, 131072)
