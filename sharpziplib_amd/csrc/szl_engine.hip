@@ -160,7 +160,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     // Stage C walks each range serially (one lane per range): a small call gets shorter ranges, i.e. more lanes and shorter
     // walks — the latency of ONE 64 KiB entry through the streaming object is dominated by that walk otherwise (2.1 of 3.2 ms)
     uint32_t range_len = C_RANGE;
-    while (range_len > 256 && total_emit / range_len < 1024) range_len >>= 1;
+    if (knob("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)knob("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
+    else while (range_len > 256 && total_emit / range_len < 65536) range_len >>= 1;   // (≈64 Ki ranges fill the device: 256 CUs x 64 lanes x a few waves)
     std::vector<SpanDev> spans;
     std::vector<TileDev> tiles;
     std::vector<uint64_t> chunk_off(nseg + 1), zero_off(nseg + 1);
