@@ -162,6 +162,9 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     uint32_t range_len = C_RANGE;
     if (knob("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)knob("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
     else while (range_len > 256 && total_emit / range_len < 65536) range_len >>= 1;   // (≈64 Ki ranges fill the device: 256 CUs x 64 lanes x a few waves)
+    // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
+    int64_t tile_len = B_TILE;
+    while (tile_len > 2048 && total_emit / (uint64_t)tile_len < 128) tile_len >>= 1;
     std::vector<SpanDev> spans;
     std::vector<TileDev> tiles;
     std::vector<uint64_t> chunk_off(nseg + 1), zero_off(nseg + 1);
@@ -199,8 +202,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
             for (int64_t a = e0; a < s.seg_end; a += (int64_t)span_len)
                 spans.push_back(SpanDev{i, 0, a, std::min<int64_t>(a + (int64_t)span_len, s.seg_end)});
         if (s.sw_cnt == 0) {
-            for (int64_t a = s.seg_start; a < s.seg_end; a += B_TILE)
-                tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(B_TILE, s.seg_end - a), 0});
+            for (int64_t a = s.seg_start; a < s.seg_end; a += tile_len)
+                tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(tile_len, s.seg_end - a), 0});
         } else { // SetLevel / SetStrategy inside the segment: tiles end at the switch positions, each searched with its own parameters
             if (s.sw_cnt > SEG_MAX_SWITCH) { set_error("too many parameter changes in one segment"); return SZL_E_UNSUPPORTED; }
             has_switch = true;
