@@ -896,24 +896,29 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
 size_t checksum_partial_bytes();
 }
 
+// Workspaces of the host-buffer checksum helpers, kept per thread and device (Deflater.Adler with pending data and the stream
+// mirrors call these once per Write: five hipMalloc/hipFree pairs per call were most of their cost).
+struct CkCache { int dev = -1; DevBuf din, dseg, doff, dparts, dso; };
 static int checksum_host(unsigned want, uint32_t value, const void *data, size_t n, uint32_t *out) {
     if (!out || (!data && n)) return SZL_E_ARG;
     if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
-    DevBuf din, dseg, doff, dparts, dso;
+    static thread_local CkCache C;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (C.dev != dev) { C.din.release(); C.dseg.release(); C.doff.release(); C.dparts.release(); C.dso.release(); C.dev = dev; }
     int rc = 0;
     SegDev s{}; s.seg_start = 0; s.seg_end = (int64_t)n; s.adler_init = value; s.crc_init = value;
     uint64_t off[2] = {0, (n + 4095) / 4096};
     SegOut so{};
-    if ((rc = din.ensure(n + 64)) || (rc = dseg.ensure(sizeof s)) || (rc = doff.ensure(sizeof off)) ||
-        (rc = dparts.ensure((off[1] + 1) * checksum_partial_bytes())) || (rc = dso.ensure(sizeof so))) goto done;
-    if ((n && hipMemcpy(din.p, data, n, hipMemcpyHostToDevice) != hipSuccess) || hipMemcpy(dseg.p, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(doff.p, off, sizeof off, hipMemcpyHostToDevice) != hipSuccess) { rc = SZL_E_DEVICE; goto done; }
-    launch_checksums((const uint8_t *)din.p, (const SegDev *)dseg.p, 1, (const uint64_t *)doff.p, off[1], dparts.p, (SegOut *)dso.p, want, nullptr);
-    if (hipMemcpy(&so, dso.p, sizeof so, hipMemcpyDeviceToHost) != hipSuccess) { rc = SZL_E_DEVICE; goto done; }
+    if ((rc = C.din.ensure(n + 64)) || (rc = C.dseg.ensure(sizeof s)) || (rc = C.doff.ensure(sizeof off)) ||
+        (rc = C.dparts.ensure((off[1] + 1) * checksum_partial_bytes())) || (rc = C.dso.ensure(sizeof so))) return rc;
+    if ((n && hipMemcpy(C.din.p, data, n, hipMemcpyHostToDevice) != hipSuccess) || hipMemcpy(C.dseg.p, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(C.doff.p, off, sizeof off, hipMemcpyHostToDevice) != hipSuccess) return SZL_E_DEVICE;
+    launch_checksums((const uint8_t *)C.din.p, (const SegDev *)C.dseg.p, 1, (const uint64_t *)C.doff.p, off[1], C.dparts.p, (SegOut *)C.dso.p, want, nullptr);
+    if (hipMemcpy(&so, C.dso.p, sizeof so, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
     *out = (want & 1) ? so.crc32 : so.adler32;
-done:
-    din.release(); dseg.release(); doff.release(); dparts.release(); dso.release();
-    return rc;
+    if (C.din.cap > (64u << 20)) C.din.release();        // (do not sit on a large input copy)
+    return 0;
 }
 extern "C" int szl_crc32(uint32_t value, const void *p, size_t n, uint32_t *out) { return checksum_host(1, value, p, n, out); }
 extern "C" int szl_adler32(uint32_t value, const void *p, size_t n, uint32_t *out) { return checksum_host(2, value, p, n, out); }

@@ -22,8 +22,9 @@
 //   * QUICK tests the two bytes the reference tests first (scan_end and scan_end1, :505-506) instead of one: 40 % fewer
 //     candidates reach VERIFY on text, 3x fewer on logs at level 9 (no gain on text — a third LDS read per step pays for it —
 //     but 271 -> 238 ms per GiB of logs).
-// Result: 24.6 VALU + 21.5 SALU per position, 89.9 -> 64 ms per GiB of text at level 6, 475 -> 238 ms per GiB of logs at
-// level 9 (full search), bit-identical tables.
+// Result: 89.9 -> 64 ms per GiB of text at level 6 (20.1 VALU + 15.7 SALU + 6.0 LDS per position), 55 ms after the tile's positions
+// went out in slices of 128 instead of 512 and the thresholds were swept again (VERIFY as soon as two contexts wait);
+// 475 -> 201 ms per GiB of logs at level 9 (full search), bit-identical tables.
 //
 // Built, measured and dropped again this round (sources in the history, logs under profiles/r02): four contexts per lane
 // (lab_s11: 99 ms per GiB — every issue slot is paid per context whatever its lane count); a run-ahead engine in which a
@@ -205,7 +206,7 @@ __device__ __forceinline__ void b2_stage_window(uint32_t *sdata32, uint16_t *sli
 template <bool DBG>
 __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                        const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                       MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth, int qkeep, int vkeep) {
+                                                       MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth, int qkeep, int vkeep, int slice) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const TileDev tile = tiles[blockIdx.x];
     const SegDev seg = segs[tile.seg];
@@ -267,10 +268,10 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
         if (ni == 0) return;
         if (wnext >= wend) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(s_counter, 512);
+            if (lane == 0) base = atomicAdd(s_counter, slice);
             base = __builtin_amdgcn_readfirstlane(base);
             wnext = base < tlen ? base : tlen;
-            wend = base + 512 < tlen ? base + 512 : tlen;
+            wend = base + slice < tlen ? base + slice : tlen;
             if (wnext >= wend) { exhausted = true; return; }
         }
         const int rank = __builtin_popcountll(idle & lanemask_lt);
@@ -532,7 +533,7 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
     // thresholds count CONTEXTS (two per lane, 128 per wavefront)
-    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 8), qkeep = knob("SZL_QKEEP", 48), vkeep = knob("SZL_VKEEP", 4); // swept: profiles/r02/lab_s6_k_match4_sweep.log, lab_s15_two_byte_filter.log
+    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2); // swept: profiles/r02/lab_s6_k_match4_sweep.log, lab_s15_two_byte_filter.log, lab_s37_slice_and_thresholds.log
     auto attr = [&](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); };
     if (lds_attr_needed2(attr_mask, attr_bit)) {
         hipError_t e = attr((const void *)k_match4<false>);
@@ -547,10 +548,12 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     if (vth < 1) vth = 1;
     if (qkeep < 1) qkeep = 1;
     if (vkeep < 1) vkeep = 1;
+    int slice = knob("SZL_SLICE", 128);   // tile positions a wavefront takes from the tile counter at a time (512: 63.5, 128: 61.6 ms per GiB — a shorter tail per tile)
+    slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B2_THREADS);
-        if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
-        else hipLaunchKernelGGL((k_match4<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep);
+        if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
+        else hipLaunchKernelGGL((k_match4<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
     }
     return hipGetLastError();
 }
