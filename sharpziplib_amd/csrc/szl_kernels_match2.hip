@@ -373,10 +373,15 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
                 SZL_Q_CLASSIFY(A)
                 SZL_Q_CLASSIFY(B)
                 "s_branch 10b\n"
-                // ---- VERIFY phase
+                // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
+                // side's instructions are issued)
                 "14:\n\t"
                 "s_mov_b64 %[mA], %[vA]\n\t"
-                "s_mov_b64 %[mB], %[vB]\n"
+                "s_mov_b64 %[mB], %[vB]\n\t"
+                "s_cmp_eq_u64 %[vB], 0\n\t"
+                "s_cbranch_scc1 16f\n\t"
+                "s_cmp_eq_u64 %[vA], 0\n\t"
+                "s_cbranch_scc1 17f\n"
                 "15:\n\t"
                 "s_add_u32 %[kv], %[kv], 1\n\t"
                 "s_bcnt1_i32_b64 %[n2], %[mA]\n\t"
@@ -406,6 +411,26 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
                 "s_bcnt1_i32_b64 %[n2], %[cm]\n\t"
                 "s_add_u32 %[kcl], %[kcl], %[n2]\n\t"
                 SZL_V_COMPLETE(A)
+                SZL_V_COMPLETE(B)
+                "s_branch 10b\n"
+                "16:\n\t"                                          // only context A has candidates to compare
+                "s_mov_b64 exec, %[mA]\n\t"
+                SZL_V_ISSUE(A)
+                "s_waitcnt lgkmcnt(0)\n\t"
+                SZL_V_FINISH(A)
+                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+                "s_cbranch_scc1 16b\n\t"
+                SZL_V_COMPLETE(A)
+                "s_branch 10b\n"
+                "17:\n\t"                                          // only context B
+                "s_mov_b64 exec, %[mB]\n\t"
+                SZL_V_ISSUE(B)
+                "s_waitcnt lgkmcnt(0)\n\t"
+                SZL_V_FINISH(B)
+                "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
+                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+                "s_cbranch_scc1 17b\n\t"
                 SZL_V_COMPLETE(B)
                 "s_branch 10b\n"
                 "19:\n\t"
@@ -475,10 +500,15 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
                 SZL_Q_CLASSIFY(A)
                 SZL_Q_CLASSIFY(B)
                 "s_branch 10b\n"
-                // ---- VERIFY phase
+                // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
+                // side's instructions are issued)
                 "14:\n\t"
                 "s_mov_b64 %[mA], %[vA]\n\t"
-                "s_mov_b64 %[mB], %[vB]\n"
+                "s_mov_b64 %[mB], %[vB]\n\t"
+                "s_cmp_eq_u64 %[vB], 0\n\t"
+                "s_cbranch_scc1 16f\n\t"
+                "s_cmp_eq_u64 %[vA], 0\n\t"
+                "s_cbranch_scc1 17f\n"
                 "15:\n\t"
                 "s_mov_b64 exec, %[mA]\n\t"
                 SZL_V_ISSUE(A)
@@ -496,6 +526,26 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
                 "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
                 "s_cbranch_scc1 15b\n\t"
                 SZL_V_COMPLETE(A)
+                SZL_V_COMPLETE(B)
+                "s_branch 10b\n"
+                "16:\n\t"                                          // only context A has candidates to compare
+                "s_mov_b64 exec, %[mA]\n\t"
+                SZL_V_ISSUE(A)
+                "s_waitcnt lgkmcnt(0)\n\t"
+                SZL_V_FINISH(A)
+                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+                "s_cbranch_scc1 16b\n\t"
+                SZL_V_COMPLETE(A)
+                "s_branch 10b\n"
+                "17:\n\t"                                          // only context B
+                "s_mov_b64 exec, %[mB]\n\t"
+                SZL_V_ISSUE(B)
+                "s_waitcnt lgkmcnt(0)\n\t"
+                SZL_V_FINISH(B)
+                "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
+                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+                "s_cbranch_scc1 17b\n\t"
                 SZL_V_COMPLETE(B)
                 "s_branch 10b\n"
                 "19:\n\t"
