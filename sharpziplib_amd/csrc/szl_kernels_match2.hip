@@ -84,6 +84,14 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
     "v_subrev_co_u32 %[left" #X "], vcc, 1, %[left" #X "]\n\t" \
     "s_andn2_b64 exec, exec, vcc\n\t" \
     "s_mov_b64 %[m" #X "], exec\n\t"
+// the same for the last step of an iteration: exec is not used again before it is reloaded
+#define SZL_Q_FINISH_LAST(X) \
+    "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 8, %[t2" #X "]\n\t" \
+    "v_cmpx_ne_u32 vcc, %[pb" #X "], %[t1" #X "]\n\t" \
+    "v_sub_u32 %[cl" #X "], %[cl" #X "], %[t0" #X "]\n\t" \
+    "v_cmpx_ge_i32 vcc, %[cl" #X "], %[mincl" #X "]\n\t" \
+    "v_subrev_co_u32 %[left" #X "], vcc, 1, %[left" #X "]\n\t" \
+    "s_andn2_b64 %[m" #X "], exec, vcc\n\t"
 // leavers of context X: lanes of q that are no longer in m; the byte read last says which way (a match wins over the chain end)
 #define SZL_Q_CLASSIFY(X) \
     "s_andn2_b64 exec, %[q" #X "], %[m" #X "]\n\t" \
@@ -361,10 +369,10 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
                 SZL_Q_ISSUE(B)
                 "s_mov_b64 exec, %[mA]\n\t"
                 "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH(A)
+                SZL_Q_FINISH_LAST(A)
                 "s_mov_b64 exec, %[mB]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_Q_FINISH(B)
+                SZL_Q_FINISH_LAST(B)
                 "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
                 "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
                 "s_add_u32 %[n0], %[n0], %[n1]\n\t"
@@ -488,10 +496,10 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
                 SZL_Q_ISSUE(B)
                 "s_mov_b64 exec, %[mA]\n\t"
                 "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH(A)
+                SZL_Q_FINISH_LAST(A)
                 "s_mov_b64 exec, %[mB]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_Q_FINISH(B)
+                SZL_Q_FINISH_LAST(B)
                 "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
                 "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
                 "s_add_u32 %[n0], %[n0], %[n1]\n\t"
