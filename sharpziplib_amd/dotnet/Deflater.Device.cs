@@ -47,6 +47,26 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		[DllImport(Lib)] internal static extern long szl_inflater_total_out(IntPtr s);
 		[DllImport(Lib)] internal static extern uint szl_inflater_adler(IntPtr s);
 
+		// batch entry points (include/szl.h): the feed for ZipOutputStream.PutNextPassthroughEntry (INTEGRATION.md §3) and for
+		// multi-member gzip; the *_multi_* forms spread the streams — or the position ranges of ONE long stream — over several GPUs
+		[StructLayout(LayoutKind.Sequential)]
+		internal struct SzlStream
+		{
+			public ulong in_off, in_len, out_off, out_cap, out_len;
+			public uint crc32, adler32;
+			public int status;
+			public uint reserved;
+			public ulong in_consumed;
+		}
+		internal const uint F_NOWRAP = 1, F_CRC32 = 2, F_ADLER32 = 4, F_SYNC_FLUSH_BEFORE_FINISH = 8, F_GZIP = 16;
+		[DllImport(Lib)] internal static extern ulong szl_deflate_bound(ulong inLen);
+		[DllImport(Lib)] internal static extern IntPtr szl_engine_create();
+		[DllImport(Lib)] internal static extern void szl_engine_destroy(IntPtr e);
+		[DllImport(Lib)] internal static extern unsafe int szl_deflate_batch_host(IntPtr e, byte* input, byte* output, SzlStream* streams, UIntPtr n, int level, int strategy, uint flags);
+		[DllImport(Lib)] internal static extern unsafe int szl_inflate_batch_host(IntPtr e, byte* input, byte* output, SzlStream* streams, UIntPtr n, uint flags);
+		[DllImport(Lib)] internal static extern unsafe int szl_deflate_batch_multi_host(int* devices, int nDev, byte* input, byte* output, SzlStream* streams, UIntPtr n, int level, int strategy, uint flags);
+		[DllImport(Lib)] internal static extern unsafe int szl_inflate_batch_multi_host(int* devices, int nDev, byte* input, byte* output, SzlStream* streams, UIntPtr n, uint flags);
+
 		// szl_status -> the exception the reference throws at the same place
 		internal static Exception Map(int status, string what)
 		{
