@@ -112,6 +112,95 @@ void szm_match_tables(const uint8_t *d, size_t seg_start, size_t seg_end, const 
     }
 }
 
+/* --- chain compression (not in the product yet) -------------------------------------------------------------------
+ * Once best_len >= 3 only a candidate that shares the position's first FOUR bytes can be strictly longer, and those candidates
+ * form a sub-chain of the 3-byte-hash chain.  link4[q] = distance to the previous inserted position with q's four bytes (0 = none
+ * within the window), skip4[q] = how many elements of the hash chain that hop passes; a walk that jumps along link4 and charges
+ * skip4 against the chain budget examines exactly the candidates of the full walk that could matter, at the same chain indices —
+ * so the limit test, the budget (max_chain, :609) and the quarter-budget snapshot (:495) stay exact.  While best_len is still 2
+ * (the first candidates were hash collisions) the full chain is walked.  szm_match_tables_c4 must equal szm_match_tables. */
+void szm_links4(const uint8_t *d, size_t n, const uint16_t *link, uint16_t *link4, uint16_t *skip4) {
+    for (size_t q = 0; q < n; q++) {
+        link4[q] = 0; skip4[q] = 0;
+        if (q + 4 > n || link[q] == 0) continue;
+        size_t c = q; uint32_t hops = 0;
+        for (;;) {
+            uint32_t l = link[c];
+            if (l == 0) break;
+            c -= l; hops++;
+            if (q - c > 32767 || hops > 65535) break;
+            if (memcmp(d + c, d + q, 4) == 0) { link4[q] = (uint16_t)(q - c); skip4[q] = (uint16_t)hops; break; }
+        }
+    }
+}
+
+static uint32_t flm_walk_c4(const uint8_t *d, size_t n, size_t p, size_t seg_end, const uint16_t *link, const uint16_t *link4,
+                            const uint16_t *skip4, const szm_params *P, int budget, int snap_at, uint32_t *snap, uint64_t *steps) {
+    if (snap) *snap = 0;
+    size_t rem = seg_end - p;
+    if (rem < MIN_MATCH) return 0;
+    if (P->strategy == 2) return 0;
+    uint32_t l0 = link[p];
+    if (l0 == 0) return 0;
+    int64_t base = szm_base_of((int64_t)p);
+    int64_t idx_p = (int64_t)p + 1 - base;
+    int64_t c = (int64_t)p - l0;
+    if ((int64_t)p - c > MAX_DIST) return 0;
+    if (c + 1 - base < 1) return 0;
+    int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    int nice = rem < (size_t)P->nice ? (int)rem : P->nice;
+    int best = 2;
+    if (best >= cap) return 0;
+    int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0;
+    const int has4 = p + 4 <= n;                          /* the position has four bytes to share */
+    uint32_t res = 0;
+    int64_t k = 1;                                        /* index of candidate c in the position's hash chain */
+    for (;;) {
+        if (steps) (*steps)++;
+        int L = lcp_cap(d, (size_t)c, p, cap);
+        if (L > best) {
+            best = L;
+            res = (uint32_t)L | ((uint32_t)((int64_t)p - c) << 16);
+            if (best >= nice) { if (snap && snap_at > 0 && k <= snap_at) *snap = res; return res; }
+        }
+        if (snap && k == snap_at) *snap = res;            /* the quarter-budget walk ends with this candidate */
+        /* next candidate that can matter, and its chain index */
+        int64_t c2, k2;
+        if (best == 2 || !has4) {
+            uint32_t l = link[c];
+            if (l == 0) break;
+            c2 = c - l; k2 = k + 1;
+        } else if ((size_t)c + 4 <= n && memcmp(d + c, d + p, 4) == 0) {
+            if (link4[c] == 0) break;
+            c2 = c - link4[c]; k2 = k + skip4[c];
+        } else {                                          /* c is not on the sub-chain: its first element below c, counted from p */
+            int64_t y = (int64_t)p, acc = 0;
+            int ended = 0;
+            do {
+                if (link4[y] == 0) { ended = 1; break; }
+                acc += skip4[y]; y -= link4[y];
+            } while (y >= c);
+            if (ended) break;
+            c2 = y; k2 = acc;
+        }
+        if (snap && k < snap_at && k2 > snap_at) *snap = res;    /* the quarter-budget walk ends between the two */
+        if (c2 + 1 - base <= limit_idx) break;
+        if (k2 > budget) break;
+        c = c2; k = k2;
+    }
+    if (snap && snap_at > 0 && k < snap_at) *snap = res;
+    return res;
+}
+
+void szm_match_tables_c4(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, const uint16_t *link4,
+                         const uint16_t *skip4, const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps) {
+    for (size_t p = seg_start; p < seg_end; p++) {
+        uint32_t snap = 0;
+        m2[p] = flm_walk_c4(d, n, p, seg_end, link, link4, skip4, P, P->max_chain, P->max_chain >> 2, &snap, steps);
+        mq[p] = snap;
+    }
+}
+
 /* --- the parse as a functional graph ------------------------------------------------------
  * A "clean" iteration is one entered with matchLen == 2 (after a match was emitted, :826-827, or
  * after a literal step with no match pending).  From a clean iteration at p everything up to the

@@ -50,6 +50,11 @@ size_t szm_parse_ranges(const uint8_t *d, size_t seg_start, size_t seg_end, cons
 
 /* Block table for a segment's token stream (DeflaterEngine.cs:841-852, :750-768):
  * fills first_token[]/ntok[]/last[] ; returns number of blocks. `finish` = segment ended by Finish(). */
+/* chain compression: links between positions that share four bytes + the hash-chain hops each one passes; the
+ * compressed walk must give the tables of szm_match_tables.  steps (optional) counts the candidates it examines. */
+void szm_links4(const uint8_t *d, size_t n, const uint16_t *link, uint16_t *link4, uint16_t *skip4);
+void szm_match_tables_c4(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, const uint16_t *link4,
+                         const uint16_t *skip4, const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps);
 /* first clean iteration >= at_least of the parse that starts clean at `from` */
 size_t szm_first_node(const uint8_t *d, size_t seg_end, const uint16_t *link, const uint32_t *m2, const uint32_t *mq,
                       const szm_params *P, size_t from, size_t at_least);

@@ -80,6 +80,7 @@ def lib():
         ("szm_fast_parse_fixpoint", sz, [vp, sz, sz, vp, vp, sz, vp, vp, vp]),
         ("szm_parse_needed", sz, [vp, sz, sz, vp, vp, vp, vp, vp]),
         ("szm_first_node", sz, [vp, sz, vp, vp, vp, vp, sz, sz]),
+        ("szm_links4", None, [vp, sz, vp, vp, vp]), ("szm_match_tables_c4", None, [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
         ("szm_lazy_eval_set", sz, [vp, sz, sz, vp, vp, vp, vp, sz, sz, vp]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
@@ -315,6 +316,19 @@ class Model:
                                         self.m2.ctypes.data, self.mq.ctypes.data, ctypes.byref(self.P), R,
                                         tok.ctypes.data, stats.ctypes.data)
         return tok[:k].copy(), stats
+
+    def match_tables_c4(self):
+        """(m2, mq, candidates examined) of the chain-compressed walk (link4 + skip4); must equal self.m2 / self.mq"""
+        l4 = np.zeros(self.n + 8, np.uint16); s4 = np.zeros(self.n + 8, np.uint16)
+        self.L.szm_links4(self._dpad.ctypes.data, self.n, self.link.ctypes.data, l4.ctypes.data, s4.ctypes.data)
+        m2 = np.zeros(self.n + 8, np.uint32); mq = np.zeros(self.n + 8, np.uint32)
+        steps = np.zeros(1, np.uint64)
+        s = 0
+        for e in self.seg_ends:
+            self.L.szm_match_tables_c4(self._dpad.ctypes.data, self.n, s, int(e), self.link.ctypes.data, l4.ctypes.data, s4.ctypes.data,
+                                       ctypes.byref(self.P), m2.ctypes.data, mq.ctypes.data, steps.ctypes.data)
+            s = int(e)
+        return m2, mq, int(steps[0])
 
     def first_node(self, start, at_least):
         """first clean iteration >= at_least of the parse that starts, clean, at `start`"""

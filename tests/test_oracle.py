@@ -313,3 +313,19 @@ def test_part_hand_over_arithmetic_of_one_stream_on_several_engines():
     z = np.zeros(400000, np.uint8)
     m = O.Model(z, 6)
     assert m.first_node(65536, 131072) != m.first_node(0, 131072)
+
+
+def test_chain_compressed_walk_gives_the_same_match_tables():
+    """DESIGN §8 (next step for stage B): jumping along links between positions that share FOUR bytes, and charging the hash-chain
+    hops each jump passes against max_chain, must reproduce FindLongestMatch exactly — M2 and the quarter-budget Mq alike."""
+    rng = np.random.default_rng(17)
+    cases = [("enwik", C.generate("enwik", 5, 0, 400000)), ("logs", C.generate("logs", 6, 0, 300000)),
+             ("dickens", C.generate("dickens", 7, 0, 300000)), ("four_symbol", rng.integers(0, 4, 120000).astype(np.uint8) + 65),
+             ("runs", np.repeat(rng.integers(0, 256, 3000).astype(np.uint8), rng.integers(1, 80, 3000))),
+             ("random", C.random_bytes(100000, seed=9)), ("period10", (np.arange(90000) % 10).astype(np.uint8))]
+    for name, data in cases:
+        for level in (5, 6, 8):
+            m = O.Model(data, level, seg_ends=[data.size // 3, data.size])        # a segment boundary in the middle as well
+            m2, mq, steps = m.match_tables_c4()
+            assert np.array_equal(m2[:data.size], m.m2[:data.size]), (name, level, "M2")
+            assert np.array_equal(mq[:data.size], m.mq[:data.size]), (name, level, "Mq")
