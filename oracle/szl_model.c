@@ -201,6 +201,121 @@ void szm_match_tables_c4(const uint8_t *d, size_t n, size_t seg_start, size_t se
     }
 }
 
+/* The same walk in the shape the device kernel runs it (csrc/szl_kernels_match3.hip, k_match6): only link4 / skip4 (saturating at
+ * 255: the form is used for max_chain <= 128) are at hand for the chain walk; the 3-byte link is read once, for the first
+ * candidate; while best_len is still 2 after it, a slow routine walks the 3-byte chain (global memory on the device) until
+ * best_len >= 3 and then re-enters the four-byte sub-chain at its first element below the candidate it stands on. */
+static uint32_t flm_walk_k6(const uint8_t *d, size_t n, size_t p, size_t seg_end, const uint16_t *link, const uint16_t *link4,
+                            const uint8_t *skip8, const szm_params *P, uint32_t *snap, uint64_t *steps) {
+    *snap = 0;
+    const int max_chain = P->max_chain, snap_at = P->max_chain >> 2;
+    size_t rem = seg_end - p;
+    if (rem < MIN_MATCH || P->strategy == 2) return 0;
+    uint32_t l3 = link[p];
+    if (l3 == 0) return 0;
+    int64_t base = szm_base_of((int64_t)p);
+    int64_t idx_p = (int64_t)p + 1 - base;
+    int64_t c1 = (int64_t)p - l3;
+    if ((int64_t)p - c1 > MAX_DIST) return 0;
+    if (c1 + 1 - base < 1) return 0;
+    int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    int nice = rem < (size_t)P->nice ? (int)rem : P->nice;
+    int best = 2;
+    if (best >= cap) return 0;
+    int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0;
+    const int has4 = p + 4 <= n;
+    uint32_t res = 0, resq = 0;
+    /* FETCH: the first candidate goes to VERIFY; the chain position is the candidate itself if it is on the four-byte sub-chain,
+     * else the position p (virtual: nothing of the budget is spent yet, the hop from p accounts for c1 as well) */
+    int64_t vcl = c1, cl;
+    int left;                                            /* max_chain - (chain index of cl) */
+    if (has4 && link4[p] != 0 && link4[p] == l3) { cl = c1; left = max_chain - 1; }
+    else { cl = (int64_t)p; left = max_chain; }
+    int first = 1;
+    for (;;) {
+        /* VERIFY + COMPLETE of vcl */
+        if (steps) (*steps)++;
+        int L = lcp_cap(d, (size_t)vcl, p, cap);
+        if (L > best) {
+            best = L;
+            res = (uint32_t)L | ((uint32_t)((int64_t)p - vcl) << 16);
+            if ((first ? max_chain - 1 : left) >= max_chain - snap_at) resq = res;    /* chain index <= snap_at */
+            if (best >= nice) { *snap = resq; return res; }
+        }
+        if (best == 2 || !has4) {
+            /* SLOW: the 3-byte chain from the candidate just examined */
+            int64_t cur3 = vcl;
+            int k3 = first ? 1 : max_chain - left;
+            int done = 0;
+            for (;;) {
+                uint32_t l = link[cur3];
+                if (l == 0) { done = 1; break; }
+                int64_t nx = cur3 - l;
+                if (nx + 1 - base <= limit_idx) { done = 1; break; }
+                if (k3 + 1 > max_chain) { done = 1; break; }
+                cur3 = nx; k3++;
+                if (steps) (*steps)++;
+                int L2 = lcp_cap(d, (size_t)cur3, p, cap);
+                if (L2 > best) {
+                    best = L2;
+                    res = (uint32_t)L2 | ((uint32_t)((int64_t)p - cur3) << 16);
+                    if (k3 <= snap_at) resq = res;
+                    if (best >= nice) { *snap = resq; return res; }
+                }
+                if (best >= 3 && has4) break;
+            }
+            if (done) break;
+            /* re-enter the sub-chain: its first element below cur3, with its chain index */
+            int64_t y = (int64_t)p; int acc = 0, ended = 0;
+            do {
+                if (link4[y] == 0) { ended = 1; break; }
+                acc += skip8[y]; y -= link4[y];
+                if (acc > max_chain) { ended = 1; break; }       /* (saturated hop counts only ever end the walk) */
+            } while (y >= cur3);
+            if (ended) break;
+            if (y + 1 - base <= limit_idx) break;
+            cl = y; left = max_chain - acc;
+            first = 0;
+        } else {
+            first = 0;
+            /* advance along the sub-chain from cl */
+            if (link4[cl] == 0) break;
+            int64_t nx = cl - link4[cl];
+            left -= skip8[cl];
+            if (left < 0) break;
+            if (nx + 1 - base <= limit_idx) break;
+            cl = nx;
+        }
+        /* QUICK: test candidates until one passes the scan_end / scan_end1 filter */
+        for (;;) {
+            if (d[cl + best] == d[p + best] && d[cl + best - 1] == d[p + best - 1]) break;
+            if (steps) (*steps)++;
+            if (link4[cl] == 0) { cl = -1; break; }
+            int64_t nx = cl - link4[cl];
+            left -= skip8[cl];
+            if (left < 0) { cl = -1; break; }
+            if (nx + 1 - base <= limit_idx) { cl = -1; break; }
+            cl = nx;
+        }
+        if (cl < 0) break;
+        vcl = cl;
+    }
+    *snap = resq;
+    return res;
+}
+
+void szm_match_tables_k6(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, const uint16_t *link4,
+                         const uint16_t *skip4, const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps) {
+    uint8_t *sk = (uint8_t *)malloc(n + 8);
+    for (size_t i = 0; i < n; i++) sk[i] = skip4[i] > 255 ? 255 : (uint8_t)skip4[i];
+    for (size_t p = seg_start; p < seg_end; p++) {
+        uint32_t snap = 0;
+        m2[p] = flm_walk_k6(d, n, p, seg_end, link, link4, sk, P, &snap, steps);
+        mq[p] = snap;
+    }
+    free(sk);
+}
+
 /* --- the parse as a functional graph ------------------------------------------------------
  * A "clean" iteration is one entered with matchLen == 2 (after a match was emitted, :826-827, or
  * after a literal step with no match pending).  From a clean iteration at p everything up to the

@@ -55,6 +55,9 @@ size_t szm_parse_ranges(const uint8_t *d, size_t seg_start, size_t seg_end, cons
 void szm_links4(const uint8_t *d, size_t n, const uint16_t *link, uint16_t *link4, uint16_t *skip4);
 void szm_match_tables_c4(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, const uint16_t *link4,
                          const uint16_t *skip4, const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps);
+/* the compressed walk in the shape of the device kernel (hop counts saturating at 255, slow routine while best_len is 2) */
+void szm_match_tables_k6(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, const uint16_t *link4,
+                         const uint16_t *skip4, const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps);
 /* first clean iteration >= at_least of the parse that starts clean at `from` */
 size_t szm_first_node(const uint8_t *d, size_t seg_end, const uint16_t *link, const uint32_t *m2, const uint32_t *mq,
                       const szm_params *P, size_t from, size_t at_least);

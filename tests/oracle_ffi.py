@@ -81,6 +81,7 @@ def lib():
         ("szm_parse_needed", sz, [vp, sz, sz, vp, vp, vp, vp, vp]),
         ("szm_first_node", sz, [vp, sz, vp, vp, vp, vp, sz, sz]),
         ("szm_links4", None, [vp, sz, vp, vp, vp]), ("szm_match_tables_c4", None, [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
+        ("szm_match_tables_k6", None, [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
         ("szm_lazy_eval_set", sz, [vp, sz, sz, vp, vp, vp, vp, sz, sz, vp]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
@@ -317,7 +318,7 @@ class Model:
                                         tok.ctypes.data, stats.ctypes.data)
         return tok[:k].copy(), stats
 
-    def match_tables_c4(self):
+    def match_tables_c4(self, kernel_shape=False):
         """(m2, mq, candidates examined) of the chain-compressed walk (link4 + skip4); must equal self.m2 / self.mq"""
         l4 = np.zeros(self.n + 8, np.uint16); s4 = np.zeros(self.n + 8, np.uint16)
         self.L.szm_links4(self._dpad.ctypes.data, self.n, self.link.ctypes.data, l4.ctypes.data, s4.ctypes.data)
@@ -325,7 +326,7 @@ class Model:
         steps = np.zeros(1, np.uint64)
         s = 0
         for e in self.seg_ends:
-            self.L.szm_match_tables_c4(self._dpad.ctypes.data, self.n, s, int(e), self.link.ctypes.data, l4.ctypes.data, s4.ctypes.data,
+            (self.L.szm_match_tables_k6 if kernel_shape else self.L.szm_match_tables_c4)(self._dpad.ctypes.data, self.n, s, int(e), self.link.ctypes.data, l4.ctypes.data, s4.ctypes.data,
                                        ctypes.byref(self.P), m2.ctypes.data, mq.ctypes.data, steps.ctypes.data)
             s = int(e)
         return m2, mq, int(steps[0])

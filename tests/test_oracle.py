@@ -329,3 +329,7 @@ def test_chain_compressed_walk_gives_the_same_match_tables():
             m2, mq, steps = m.match_tables_c4()
             assert np.array_equal(m2[:data.size], m.m2[:data.size]), (name, level, "M2")
             assert np.array_equal(mq[:data.size], m.mq[:data.size]), (name, level, "Mq")
+            if level <= 6:    # the kernel-shaped form (hop counts in a byte) is meant for max_chain <= 128
+                k2, kq, ksteps = m.match_tables_c4(kernel_shape=True)
+                assert np.array_equal(k2[:data.size], m.m2[:data.size]), (name, level, "M2 kernel shape")
+                assert np.array_equal(kq[:data.size], m.mq[:data.size]), (name, level, "Mq kernel shape")
