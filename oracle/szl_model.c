@@ -316,6 +316,100 @@ void szm_match_tables_k6(const uint8_t *d, size_t n, size_t seg_start, size_t se
     free(sk);
 }
 
+/* The same without a slow routine (device form k_match6).  While best_len is 2 a candidate changes the walk's state only if its
+ * first three bytes equal the position's (a hash collision just uses up budget), so the first candidate that matters is the first
+ * chain element with the same three bytes: e3 (distance e3d, chain index e3h), found by the pass that builds link4.  The walk
+ * compares e3 and then follows the four-byte sub-chain: from e3 itself if it is its first element, else from p. */
+void szm_links4e(const uint8_t *d, size_t n, const uint16_t *link, uint16_t *link4, uint8_t *skip8, uint16_t *e3d, uint8_t *e3h, int dist_cap) {
+    for (size_t q = 0; q < n; q++) {
+        link4[q] = 0; skip8[q] = 0; e3d[q] = 0; e3h[q] = 0;
+        if (q + 3 > n || link[q] == 0) continue;
+        const int has4 = q + 4 <= n;
+        size_t c = q;
+        for (uint32_t hops = 1; hops <= 255; hops++) {
+            uint32_t l = link[c];
+            if (l == 0) break;
+            c -= l;
+            if (q - c > (size_t)dist_cap) break;
+            if (memcmp(d + c, d + q, 3) != 0) continue;
+            if (e3d[q] == 0) { e3d[q] = (uint16_t)(q - c); e3h[q] = (uint8_t)hops; }
+            if (!has4) break;
+            if (d[c + 3] == d[q + 3]) { link4[q] = (uint16_t)(q - c); skip8[q] = (uint8_t)hops; break; }
+        }
+    }
+}
+
+static uint32_t flm_walk_k7(const uint8_t *d, size_t p, size_t seg_end, const uint16_t *link, const uint16_t *link4, const uint8_t *skip8,
+                            const uint16_t *e3d, const uint8_t *e3h, const szm_params *P, uint32_t *snap, uint64_t *steps) {
+    *snap = 0;
+    const int max_chain = P->max_chain, snap_at = P->max_chain >> 2;
+    size_t rem = seg_end - p;
+    if (rem < MIN_MATCH || P->strategy == 2) return 0;
+    uint32_t l3 = link[p];
+    if (l3 == 0) return 0;
+    int64_t base = szm_base_of((int64_t)p);
+    int64_t idx_p = (int64_t)p + 1 - base;
+    int64_t c1 = (int64_t)p - l3;
+    if ((int64_t)p - c1 > MAX_DIST) return 0;                 /* :788 */
+    if (c1 + 1 - base < 1) return 0;
+    int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH;
+    int nice = rem < (size_t)P->nice ? (int)rem : P->nice;
+    int64_t limit_idx = idx_p - MAX_DIST > 0 ? idx_p - MAX_DIST : 0;
+    /* FETCH */
+    if (e3d[p] == 0 || e3h[p] > max_chain) return 0;
+    int64_t vcl = (int64_t)p - e3d[p];
+    if (e3d[p] != l3 && vcl + 1 - base <= limit_idx) return 0;  /* :609 for every candidate but the first */
+    int best = 2;
+    int64_t cl; int left = max_chain - e3h[p], kadj;
+    if (link4[p] == e3d[p]) { cl = vcl; kadj = 0; } else { cl = (int64_t)p; kadj = e3h[p]; }
+    uint32_t res = 0, resq = 0;
+    for (;;) {
+        if (steps) (*steps)++;
+        int L = lcp_cap(d, (size_t)vcl, p, cap);
+        if (L > best) {
+            best = L;
+            res = (uint32_t)L | ((uint32_t)((int64_t)p - vcl) << 16);
+            if (left >= max_chain - snap_at) resq = res;
+            if (best >= nice) break;
+        }
+        /* advance along the sub-chain from cl */
+        if (link4[cl] == 0) break;
+        int64_t nx = cl - link4[cl];
+        if (nx + 1 - base <= limit_idx) break;
+        left += kadj; kadj = 0;
+        left -= skip8[cl];
+        if (left < 0) break;
+        cl = nx;
+        for (;;) { /* QUICK */
+            if (d[cl + best] == d[p + best] && d[cl + best - 1] == d[p + best - 1]) break;
+            if (steps) (*steps)++;
+            if (link4[cl] == 0) { cl = -1; break; }
+            nx = cl - link4[cl];
+            if (nx + 1 - base <= limit_idx) { cl = -1; break; }
+            left -= skip8[cl];
+            if (left < 0) { cl = -1; break; }
+            cl = nx;
+        }
+        if (cl < 0) break;
+        vcl = cl;
+    }
+    *snap = resq;
+    return res;
+}
+
+void szm_match_tables_k7(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, int dist_cap,
+                         const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps) {
+    uint16_t *l4 = (uint16_t *)malloc((n + 8) * 2), *e3d = (uint16_t *)malloc((n + 8) * 2);
+    uint8_t *s8 = (uint8_t *)malloc(n + 8), *e3h = (uint8_t *)malloc(n + 8);
+    szm_links4e(d, n, link, l4, s8, e3d, e3h, dist_cap);
+    for (size_t p = seg_start; p < seg_end; p++) {
+        uint32_t snap = 0;
+        m2[p] = flm_walk_k7(d, p, seg_end, link, l4, s8, e3d, e3h, P, &snap, steps);
+        mq[p] = snap;
+    }
+    free(l4); free(e3d); free(s8); free(e3h);
+}
+
 /* --- the parse as a functional graph ------------------------------------------------------
  * A "clean" iteration is one entered with matchLen == 2 (after a match was emitted, :826-827, or
  * after a literal step with no match pending).  From a clean iteration at p everything up to the

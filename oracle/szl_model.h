@@ -58,6 +58,10 @@ void szm_match_tables_c4(const uint8_t *d, size_t n, size_t seg_start, size_t se
 /* the compressed walk in the shape of the device kernel (hop counts saturating at 255, slow routine while best_len is 2) */
 void szm_match_tables_k6(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, const uint16_t *link4,
                          const uint16_t *skip4, const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps);
+/* the same without the slow routine: the first candidate is the first chain element with the same three bytes (device form) */
+void szm_links4e(const uint8_t *d, size_t n, const uint16_t *link, uint16_t *link4, uint8_t *skip8, uint16_t *e3d, uint8_t *e3h, int dist_cap);
+void szm_match_tables_k7(const uint8_t *d, size_t n, size_t seg_start, size_t seg_end, const uint16_t *link, int dist_cap,
+                         const szm_params *P, uint32_t *m2, uint32_t *mq, uint64_t *steps);
 /* first clean iteration >= at_least of the parse that starts clean at `from` */
 size_t szm_first_node(const uint8_t *d, size_t seg_end, const uint16_t *link, const uint32_t *m2, const uint32_t *mq,
                       const szm_params *P, size_t from, size_t at_least);

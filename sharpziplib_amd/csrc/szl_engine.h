@@ -78,7 +78,7 @@ class Engine {
     std::vector<uint32_t> fast_hist_in, fast_tail_bits;
     bool fast_want_tail = false;
     int64_t fast_tail_start = 0;
-    DevBuf link, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_so, blk_counts, blk_off,
+    DevBuf link, link4, skip4, e3dist, e3hops, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_stripes, d_so, blk_counts, blk_off,
         bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored, spec_tok, d_zoff,
         inf_sym, inf_wins, inf_jobs, inf_states, inf_misc, hist_flags_dev;   // parallel decode of one member (szl_api_inflate.hip)
     hipEvent_t ev[8];

@@ -17,6 +17,21 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
                   uint16_t *link, const uint32_t *hflags, hipStream_t st);
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
+void launch_links4(const uint8_t *in, const uint16_t *link, int64_t lo, int64_t hi, int64_t n_end, uint16_t *link4, uint8_t *skip4, uint16_t *e3d,
+                   uint8_t *e3h, hipStream_t st);
+int match3_tile();
+// SZL_MATCH_KERNEL=3: the full search of stage B walks four-byte sub-chains (szl_kernels_match3.hip); hop counts are bytes there
+hipError_t launch_match_slide(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
+                              unsigned long long *dbg, hipStream_t st);
+// SZL_MATCH_KERNEL=4: the full search runs over stripes with a sliding window (k_match7, szl_kernels_match2.hip).  `emit` = positions searched.
+static int64_t slide_stripe_len(uint64_t emit, int64_t tile_len) {
+    const uint64_t min_stripes = (uint64_t)std::max(1, knob("SZL_STRIPE_MIN", 512));   // (1: tests — long stripes on small inputs)
+    if ((knob("SZL_MATCH_KERNEL", 2) != 4 && knob("SZL_MATCH_KERNEL", 2) != 5) || (tile_len < B_TILE && min_stripes > 1)) return 0;
+    int64_t len = (int64_t)std::max(16, knob("SZL_STRIPE_KIB", 256)) << 10;
+    while (len > B_TILE && emit / (uint64_t)len < min_stripes) len >>= 1;
+    return len;
+}
+static bool use_match3(const LevelParams &P) { return knob("SZL_MATCH_KERNEL", 2) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
 void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
                             hipStream_t st);
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
@@ -163,10 +178,14 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (knob("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)knob("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
     else while (range_len > 256 && total_emit / range_len < 65536) range_len >>= 1;   // (≈64 Ki ranges fill the device: 256 CUs x 64 lanes x a few waves)
     // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
-    int64_t tile_len = B_TILE;
+    bool m3 = !P.fast && use_match3(P);
+    for (auto &s : segs) if (s.sw_cnt) m3 = false;
+    int64_t tile_len = m3 ? match3_tile() : B_TILE;
+    if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
     while (tile_len > 2048 && total_emit / (uint64_t)tile_len < 128) tile_len >>= 1;
+    const int64_t stripe_len = (!P.fast && !m3) ? slide_stripe_len(total_emit, tile_len) : 0;
     std::vector<SpanDev> spans;
-    std::vector<TileDev> tiles;
+    std::vector<TileDev> tiles, stripes;
     std::vector<uint64_t> chunk_off(nseg + 1), zero_off(nseg + 1);
     uint64_t nzero = 0;
     for (uint32_t i = 0; i < nseg; i++) { zero_off[i] = nzero; nzero += (segs[i].out_cap + (uint64_t)zero_piece_bytes() - 1) / (uint64_t)zero_piece_bytes(); }
@@ -204,6 +223,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         if (s.sw_cnt == 0) {
             for (int64_t a = s.seg_start; a < s.seg_end; a += tile_len)
                 tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(tile_len, s.seg_end - a), 0});
+            for (int64_t a = s.seg_start; stripe_len && a < s.seg_end; a += stripe_len)
+                stripes.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(stripe_len, s.seg_end - a), 0});
         } else { // SetLevel / SetStrategy inside the segment: tiles end at the switch positions, each searched with its own parameters
             if (s.sw_cnt > SEG_MAX_SWITCH) { set_error("too many parameter changes in one segment"); return SZL_E_UNSUPPORTED; }
             has_switch = true;
@@ -260,6 +281,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if ((rc = upload(d_bnds, bnds, st))) return rc;
     if ((rc = upload(d_spans, spans, st))) return rc;
     if ((rc = upload(d_tiles, tiles, st))) return rc;
+    const bool slide = stripe_len > 0 && !has_switch && !stripes.empty();
+    if (slide && (rc = upload(d_stripes, stripes, st))) return rc;
     if ((rc = upload(ckoff, chunk_off, st))) return rc;
     if ((rc = upload(d_zoff, zero_off, st))) return rc;
     size_t cub_bytes1 = 0, cub_bytes2 = 0;
@@ -355,7 +378,17 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         }
     }
     if (!b_event) HIPCHK(hipEventRecord(ev[7], st));
-    if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
+    if (!lazy && m3) {
+        if ((rc = link4.ensure(in_total * 2 + 64)) || (rc = skip4.ensure(in_total + 64)) || (rc = e3dist.ensure(in_total * 2 + 64)) ||
+            (rc = e3hops.ensure(in_total + 64))) return rc;
+        launch_links4(d_in, (const uint16_t *)link.p, 0, (int64_t)in_total, (int64_t)in_total, (uint16_t *)link4.p, (uint8_t *)skip4.p,
+                      (uint16_t *)e3dist.p, (uint8_t *)e3hops.p, st);
+        MTab mt3 = mt;
+        mt3.link4 = (const uint16_t *)link4.p; mt3.skip4 = (const uint8_t *)skip4.p;
+        mt3.e3d = (const uint16_t *)e3dist.p; mt3.e3h = (const uint8_t *)e3hops.p;
+        HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt3, P, dcnt, st));
+    } else if (!lazy && slide) HIPCHK(launch_match_slide(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+    else if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     if (has_switch) { // tiles are grouped by parameter set: group 0 = the call's P, group k = sw_P[k-1] of the (single) switching segment
         size_t a = 0;
         while (a < tiles.size()) {
@@ -437,6 +470,9 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     timing.fallback_walks = hc[1];
     last_evaluated = hc[6]; last_eval_fallbacks = hc[7]; last_lazy = lazy;
     if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] match: quick wave-steps %llu (avg lanes %.1f), verify wave-steps %llu (avg lanes %.1f), positions %llu\n", hc[2], hc[2] ? (double)hc[3] / hc[2] : 0.0, hc[5], hc[5] ? (double)hc[4] / hc[5] : 0.0, (unsigned long long)seg_bytes);
+    if (knob("SZL_DEBUG", 0) && hc[22])   // k_match8 (ring): per-wave loop statistics
+        fprintf(stderr, "[szl] match8: engine calls %llu (busy contexts at entry %.1f) | starving %llu | chunks staged %llu, staging refused %llu, lock busy %llu | idle sleeps %llu\n",
+                hc[22], (double)hc[28] / hc[22], hc[23], hc[27], hc[24], hc[25], hc[26]);
     if (knob("SZL_DEBUG", 0) && hc[16]) { // k_match4 (two-context engine): loop iterations of each phase and the contexts (of 128) that took part
         const double np = (double)seg_bytes;
         fprintf(stderr, "[szl] match4: engine calls %llu | fetch visits %llu lanes/visit %.1f | QUICK iterations %llu contexts/iter %.1f (x2 steps) | VERIFY iterations %llu contexts/iter %.1f | "
@@ -570,8 +606,15 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         span_len = std::min<uint64_t>(std::max<uint64_t>(span_len, 1u << 17), 1u << 22);
         span_len = (span_len + 63) & ~63ull;
         for (int64_t a = lo; a < hi; a += (int64_t)span_len) spans.push_back(SpanDev{1, 0, a, std::min<int64_t>(a + (int64_t)span_len, hi)});
-        for (int64_t a = e; a < wend; a += B_TILE) tiles.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(B_TILE, wend - a), 0});
+        const bool m3 = use_match3(P);
+        int64_t tile_len = m3 ? match3_tile() : B_TILE;
+        if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+        for (int64_t a = e; a < wend; a += tile_len) tiles.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(tile_len, wend - a), 0});
         const uint64_t ntiles = tiles.size();
+        std::vector<TileDev> stripes;
+        const int64_t stripe_len = m3 ? 0 : slide_stripe_len((uint64_t)(wend - e), tile_len);
+        for (int64_t a = e; stripe_len && a < wend; a += stripe_len) stripes.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(stripe_len, wend - a), 0});
+        if (!stripes.empty() && (rc = upload(d_stripes, stripes, st))) return rc;
         // side arrays of this window, addressed with the stream's own indices (pointer minus the window's first index)
         const uint64_t nlink = (uint64_t)(hi - lo), ntab = (uint64_t)(hi - e);
         const size_t mt_stride = (ntab + 63) & ~(size_t)63;
@@ -604,7 +647,18 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
             HIPCHK(hipMemsetAsync(mtab.p, 0xFF, mt_stride * 4, st)); // M_UNSET
             HIPCHK(launch_match_lazy(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, 0, 1, lk, mt, P, dcnt, st));
         } else {
-            HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mt, P, dcnt, st));
+            MTab mtw = mt;
+            if (m3) {   // four-byte links of the window: [lo, wend) is all a tile's LDS window holds
+                if ((rc = link4.ensure(nlink * 2 + 64)) || (rc = skip4.ensure(nlink + 64)) || (rc = e3dist.ensure(nlink * 2 + 64)) ||
+                    (rc = e3hops.ensure(nlink + 64))) return rc;
+                const uint64_t bias = seg.buf_off + (uint64_t)lo;
+                uint16_t *l4 = (uint16_t *)link4.p - bias, *ed = (uint16_t *)e3dist.p - bias;
+                uint8_t *s4 = (uint8_t *)skip4.p - bias, *eh = (uint8_t *)e3hops.p - bias;
+                launch_links4(d_in, lk, (int64_t)seg.buf_off + lo, (int64_t)seg.buf_off + wend, (int64_t)seg.buf_off + N, l4, s4, ed, eh, st);
+                mtw.link4 = l4; mtw.skip4 = s4; mtw.e3d = ed; mtw.e3h = eh;
+            }
+            if (!stripes.empty()) HIPCHK(launch_match_slide(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
+            else HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mtw, P, dcnt, st));
             if (!last) HIPCHK(hipMemsetAsync((uint32_t *)mtab.p + wn, 0xFF, (size_t)(hi - wend) * 4, st)); // the tail past the parse end: evaluated on demand
         }
         HIPCHK(hipEventRecord(ev[3], st));

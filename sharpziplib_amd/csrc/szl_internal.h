@@ -27,6 +27,10 @@ enum : int { SEG_MAX_SWITCH = 4 };   // parameter changes inside one segment (mo
 struct MTab {
     uint32_t *m2;
     uint32_t *mq;
+    const uint16_t *link4 = nullptr;   // chain compression (szl_kernels_match3.hip): set => stage B may use k_match6
+    const uint8_t *skip4 = nullptr;
+    const uint16_t *e3d = nullptr;     // first chain element with the same three bytes: distance, chain index
+    const uint8_t *e3h = nullptr;
 };
 
 enum : uint32_t { M_UNSET = 0xFFFFFFFFu }; // M2 entry of a position no stage-B walker evaluated (valid entries have len <= 258)

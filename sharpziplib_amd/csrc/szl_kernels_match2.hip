@@ -578,6 +578,702 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
     }
 }
 
+
+// ---- k_match7: the same engine over a STRIPE of consecutive positions with a window that slides ---------------------------------
+// What a 16 Ki tile costs k_match4 beyond its walks (profiles/r02/lab_s46_tile_length.log: 52.5 / 69.8 / 101.7 ms per GiB with 16 / 8 /
+// 4 Ki tiles, i.e. 67 us per tile, a third of the kernel): every tile stages 48 Ki positions to search 16 Ki, and ends with the
+// workgroup waiting for its longest walks (a full-budget walk is 128 dependent steps, ~40 us) with most lanes idle.  Here a
+// workgroup owns a stripe and moves the window along it SZ7_SHIFT positions at a time: the bytes and links that stay are moved
+// down inside LDS, only the new ones come from memory (a third of the traffic), and walks of positions that are still inside
+// the window after the move (tile index >= SZ7_SHIFT) simply go on — cl, p and mincl are window indices, so they move with it.
+// The wait at a move is only for positions below SZ7_SHIFT, which were handed out at least a quarter of a window ago.
+
+__device__ __forceinline__ void b7_stage(uint32_t *sdata32, uint16_t *slink, const uint8_t *d, const uint16_t *lk, int64_t dlo, int64_t seg_end,
+                                         int64_t link_end, int i0d, int i0l) {
+    for (int i = i0d + threadIdx.x; i < B2_DATA_BYTES / 4; i += B2_THREADS) {
+        int64_t pos = dlo + 4 * (int64_t)i;
+        uint32_t w = 0;
+        if (pos >= 0 && pos + 4 <= seg_end) w = load_u32_unaligned2(d + pos);
+        else {
+            for (int k = 0; k < 4; k++) {
+                int64_t pk = pos + k;
+                if (pk >= 0 && pk < seg_end) w |= (uint32_t)d[pk] << (8 * k);
+            }
+        }
+        sdata32[i] = w;
+    }
+    for (int i = i0l + threadIdx.x; i < B2_LINKS / 2; i += B2_THREADS) {
+        int64_t pos = dlo + 2 * (int64_t)i;
+        uint32_t w = 0;
+        if (pos >= 0 && pos < link_end) w |= lk[pos];
+        if (pos + 1 >= 0 && pos + 1 < link_end) w |= (uint32_t)lk[pos + 1] << 16;
+        if ((w & 0xFFFFu) == 0) w |= 0xFFFFu;
+        if ((w >> 16) == 0) w |= 0xFFFF0000u;
+        ((uint32_t *)slink)[i] = w;
+    }
+}
+
+template <int SZ7_SHIFT>
+__global__ __launch_bounds__(B2_THREADS) void k_match7(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
+                                                       const TileDev *__restrict__ stripes, const uint16_t *__restrict__ link,
+                                                       MTab mtab, LevelParams P, int fth, int vth, int qkeep, int vkeep, int slice) {
+    static_assert(SZ7_SHIFT % 16 == 0 && SZ7_SHIFT >= 1024 && B_TILE - SZ7_SHIFT >= 1024, "window move");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const TileDev stripe = stripes[blockIdx.x];
+    const SegDev seg = segs[stripe.seg];
+    uint32_t *sdata32 = (uint32_t *)smem;
+    uint16_t *slink = (uint16_t *)(smem + B2_DATA_BYTES);
+    int *s_counter = (int *)(smem + B2_DATA_BYTES + B2_LINKS * 2);
+    const uint8_t *d = in + seg.buf_off;
+    const uint16_t *lk = link + seg.buf_off;
+    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
+    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
+    const int64_t seg_end = seg.look_end;
+    const int64_t stripe_end = stripe.start + stripe.len;       // links are needed (and exist) up to here
+    const int nwin = stripe.len <= B_TILE ? 1 : 1 + (stripe.len - B_TILE + SZ7_SHIFT - 1) / SZ7_SHIFT;
+
+    int64_t t0 = stripe.start;                                   // stream position of tile index 0 of the window
+    b7_stage(sdata32, slink, d, lk, t0 - B_HIST, seg_end, stripe_end, 0, 0);
+    if (threadIdx.x == 0) *s_counter = 0;
+    __syncthreads();
+
+    const uint8_t *sdata8 = smem;
+    const uint32_t dbase = (uint32_t)(uintptr_t)(lds_u8 *)smem;
+    const uint32_t lbase = dbase + (uint32_t)B2_DATA_BYTES;
+    const uint32_t pbase = dbase + (uint32_t)B_HIST;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);
+    const int bhist = B_HIST;
+
+    WalkCtx A, B;
+    A.p = 0; A.cl = B_HIST; A.best = 2; A.left = 0; A.off = 0; A.mincl = 0; A.cap = MAX_MATCH; A.nice = P.nice; A.pb = 0; A.res2 = 0; A.resq = 0;
+    B = A;
+    uint64_t qA = 0, vA = 0, dA = 0, qB = 0, vB = 0, dB = 0;
+
+    for (int win = 0;; win++) {
+        // ---- this window: tile indices [0, tlen) are stream positions t0 + index; [0, first) were handed out before the move
+        const int64_t left64 = stripe_end - t0;
+        const int tlen = left64 < (int64_t)B_TILE ? (int)left64 : (int)B_TILE;
+        const bool last_win = win == nwin - 1;
+        const int must_finish = last_win ? 0x7FFFFFFF : (int)SZ7_SHIFT;   // walks of tile indices below this end before the window moves
+        const int64_t dlo = t0 - B_HIST;
+        const int64_t base_lo = base_of2((int64_t)seg.abs0 + t0), base_hi = base_of2((int64_t)seg.abs0 + t0 + tlen - 1);
+        const int64_t sw64 = base_lo == base_hi ? (int64_t)1 << 30 : (base_lo + 65273) - (int64_t)seg.abs0 - t0;
+        const int sw = sw64 > (int64_t)B_TILE ? B_TILE : (int)sw64;
+        const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo);
+        const int64_t rem0_64 = seg_end - t0;
+        const int rem0 = rem0_64 > (int64_t)(1 << 24) ? (1 << 24) : (int)rem0_64;
+        int wnext = 0, wend = 0;
+        bool exhausted = false;
+
+        auto fetch = [&](WalkCtx &C, uint64_t &q, uint64_t &v, uint64_t &dm) {
+            if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; }
+            dm = 0;
+            if (exhausted) return;
+            const uint64_t idle = ~(q | v);
+            const int ni = __builtin_popcountll(idle);
+            if (ni == 0) return;
+            if (wnext >= wend) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(s_counter, slice);
+                base = __builtin_amdgcn_readfirstlane(base);
+                wnext = base < tlen ? base : tlen;
+                wend = base + slice < tlen ? base + slice : tlen;
+                if (wnext >= wend) { exhausted = true; return; }
+            }
+            const int rank = __builtin_popcountll(idle & lanemask_lt);
+            bool toverify = false;
+            if (__builtin_amdgcn_inverse_ballot_w64(idle) && wnext + rank < wend) {
+                const int p = wnext + rank;
+                C.p = p;
+                const int rem = rem0 - p;
+                C.res2 = 0; C.resq = 0;
+                bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
+                if (ok) {
+                    const int pl = p + B_HIST;
+                    const int l0 = (int)slink[pl];                           // hashHead (:782)
+                    const int basem = p >= sw ? basem_hi : basem_lo;
+                    const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem; // strstart - hashHead <= MAX_DIST (:788)
+                    const int c = pl - l0;
+                    ok = c >= firstmin;
+                    if (ok) {
+                        C.cl = c;
+                        C.mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
+                        C.cap = rem < MAX_MATCH ? rem : MAX_MATCH;
+                        C.nice = rem < P.nice ? rem : P.nice;
+                        C.best = 2; C.left = P.max_chain - 1;
+                        C.pb = ((uint32_t)sdata8[pl + 2] << 8) | sdata8[pl + 1];
+                        C.off = 0;
+                        toverify = true;
+                    }
+                }
+                if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
+            }
+            v |= __ballot(toverify);
+            wnext = wnext + ni < wend ? wnext + ni : wend;
+        };
+
+        for (;;) {
+            fetch(A, qA, vA, dA);
+            fetch(B, qB, vB, dB);
+            // once every position of the window is handed out, only the walks that must finish before the move keep the wave here
+            const uint64_t oldA = exhausted ? __ballot(A.p < must_finish) : ~0ull, oldB = exhausted ? __ballot(B.p < must_finish) : ~0ull;
+            if ((((qA | vA) & oldA) | ((qB | vB) & oldB)) == 0) { if (exhausted) break; else continue; }
+            const uint32_t busy_exit = exhausted ? 0u : (uint32_t)(128 - fth);
+        uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
+        uint64_t mA, mB, sc, cm, sv;
+        uint32_t n0, n1, n2;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n"
+            "10:\n\t"                                           // ---- census
+            "s_or_b64 %[sc], %[qA], %[vA]\n\t"
+            "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
+            "s_and_b64 %[cm], %[sc], %[oA]\n\t"
+            "s_or_b64 %[sc], %[qB], %[vB]\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
+            "s_and_b64 %[sc], %[sc], %[oB]\n\t"
+            "s_or_b64 %[cm], %[cm], %[sc]\n\t"
+            "s_cmp_eq_u64 %[cm], 0\n\t"                        // no walk left that must finish before the window moves
+            "s_cbranch_scc1 19f\n\t"
+            "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
+            "s_cmp_le_u32 %[n0], %[bexit]\n\t"
+            "s_cbranch_scc1 19f\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
+            "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
+            "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
+            "s_cmp_ge_u32 %[n1], %[vth]\n\t"
+            "s_cbranch_scc1 14f\n\t"
+            "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
+            "s_cbranch_scc1 14f\n"
+            // ---- QUICK phase
+            "s_mov_b64 %[mA], %[qA]\n\t"
+            "s_mov_b64 %[mB], %[qB]\n"
+            "11:\n\t"
+            "s_mov_b64 exec, %[mA]\n\t"
+            SZL_Q_ISSUE(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            SZL_Q_ISSUE(B)
+            "s_mov_b64 exec, %[mA]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            SZL_Q_FINISH(A)
+            SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
+            "s_mov_b64 exec, %[mB]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            SZL_Q_FINISH(B)
+            SZL_Q_ISSUE(B)
+            "s_mov_b64 exec, %[mA]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            SZL_Q_FINISH_LAST(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_Q_FINISH_LAST(B)
+            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
+            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
+            "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
+            "s_cbranch_scc1 11b\n\t"
+            SZL_Q_CLASSIFY(A)
+            SZL_Q_CLASSIFY(B)
+            "s_branch 10b\n"
+            // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
+            // side's instructions are issued)
+            "14:\n\t"
+            "s_mov_b64 %[mA], %[vA]\n\t"
+            "s_mov_b64 %[mB], %[vB]\n\t"
+            "s_cmp_eq_u64 %[vB], 0\n\t"
+            "s_cbranch_scc1 16f\n\t"
+            "s_cmp_eq_u64 %[vA], 0\n\t"
+            "s_cbranch_scc1 17f\n"
+            "15:\n\t"
+            "s_mov_b64 exec, %[mA]\n\t"
+            SZL_V_ISSUE(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            SZL_V_ISSUE(B)
+            "s_mov_b64 exec, %[mA]\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            SZL_V_FINISH(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_V_FINISH(B)
+            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
+            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
+            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+            "s_cbranch_scc1 15b\n\t"
+            SZL_V_COMPLETE(A)
+            SZL_V_COMPLETE(B)
+            "s_branch 10b\n"
+            "16:\n\t"                                          // only context A has candidates to compare
+            "s_mov_b64 exec, %[mA]\n\t"
+            SZL_V_ISSUE(A)
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_V_FINISH(A)
+            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+            "s_cbranch_scc1 16b\n\t"
+            SZL_V_COMPLETE(A)
+            "s_branch 10b\n"
+            "17:\n\t"                                          // only context B
+            "s_mov_b64 exec, %[mB]\n\t"
+            SZL_V_ISSUE(B)
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_V_FINISH(B)
+            "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
+            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+            "s_cbranch_scc1 17b\n\t"
+            SZL_V_COMPLETE(B)
+            "s_branch 10b\n"
+            "19:\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
+              [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
+              [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
+              [res2B] "+&v"(B.res2), [resqB] "+&v"(B.resq),
+              [qA] "+&s"(qA), [vA] "+&s"(vA), [dA] "+&s"(dA), [qB] "+&s"(qB), [vB] "+&s"(vB), [dB] "+&s"(dB),
+              [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A),
+              [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B),
+              [mA] "=&s"(mA), [mB] "=&s"(mB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2)
+            : [minclA] "v"(A.mincl), [capA] "v"(A.cap), [niceA] "v"(A.nice), [minclB] "v"(B.mincl), [capB] "v"(B.cap), [niceB] "v"(B.nice),
+              [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(pbase), [dbm1] "s"(dbase - 1u), [pbm1] "s"(pbase - 1u), [bhist] "s"(bhist), [snap] "s"(SNAPLEFT),
+              [bexit] "s"(busy_exit), [oA] "s"(oldA), [oB] "s"(oldB), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep)
+            : "vcc", "scc", "memory");
+        }
+        if (last_win) break;
+        // ---- move the window: every walk that reads below tile index SZ7_SHIFT is over in this wave; wait for the other waves
+        __syncthreads();
+        {
+            enum : int { ND = (B2_DATA_BYTES - SZ7_SHIFT) / 16, NL = (B2_LINKS - SZ7_SHIFT) * 2 / 16, NPER = (ND + NL + B2_THREADS - 1) / B2_THREADS };
+            static_assert((B2_DATA_BYTES - SZ7_SHIFT) % 16 == 0 && ((B2_LINKS - SZ7_SHIFT) * 2) % 16 == 0 && B2_DATA_BYTES % 16 == 0 && (B2_LINKS * 2) % 16 == 0, "16-byte moves");
+            // (one uint4 view of both arrays: the links start at entry LB; every thread moves NPER entries through registers)
+            enum : int { LB = B2_DATA_BYTES / 16, LASTSRC = LB + B2_LINKS * 2 / 16 - 1 };
+            uint4 *s4 = (uint4 *)smem;
+            static_assert(NPER <= 9, "the move below is written out for nine entries per thread");
+            auto src_of = [&](int k) { const int idx = (int)threadIdx.x + k * B2_THREADS;
+                                       const int src = idx < ND ? idx + SZ7_SHIFT / 16 : idx - ND + LB + SZ7_SHIFT * 2 / 16; return src < LASTSRC ? src : LASTSRC; };
+            auto put = [&](int k, const uint4 &v) { const int idx = (int)threadIdx.x + k * B2_THREADS;
+                                                    if (idx < ND + NL) s4[idx < ND ? idx : idx - ND + LB] = v; };
+            const uint4 r0 = s4[src_of(0)], r1 = s4[src_of(1)], r2 = s4[src_of(2)], r3 = s4[src_of(3)], r4 = s4[src_of(4)], r5 = s4[src_of(5)], r6 = s4[src_of(6)],
+                        r7 = s4[src_of(7)], r8 = s4[src_of(8)];
+            __syncthreads();
+            put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5); put(6, r6); put(7, r7); put(8, r8);
+        }
+        t0 += SZ7_SHIFT;
+        A.p -= SZ7_SHIFT; A.cl -= SZ7_SHIFT; A.mincl -= SZ7_SHIFT;
+        B.p -= SZ7_SHIFT; B.cl -= SZ7_SHIFT; B.mincl -= SZ7_SHIFT;
+        b7_stage(sdata32, slink, d, lk, t0 - B_HIST, seg_end, stripe_end, (B2_DATA_BYTES - SZ7_SHIFT) / 4, (B2_LINKS - SZ7_SHIFT) / 2);
+        if (threadIdx.x == 0) *s_counter = B_TILE - SZ7_SHIFT;          // the positions below were handed out before the move
+        __syncthreads();
+    }
+}
+
+
+// ---- k_match8: the same engine fed from a RING ----------------------------------------------------------------------------------
+// What k_match7 showed (profiles/r02/lab_s47_*, lab_s48_*): moving the window costs as much as a new tile — ~20 us per move however
+// far it moves — because a move is a barrier, and a wave that waits at a barrier has its walks paused while its free lanes cannot
+// be refilled.  Here nothing stops: bytes and links live in a ring of R8_W positions (ring address = position mod R8_W), waves take
+// slices of positions from one counter as long as the ring holds their lookahead, and whichever wave finds the ring running low
+// stages the next R8_C positions over the oldest ones — allowed as soon as no walk can still reach them, which the waves publish as
+// their lowest position in flight.  Ring addresses cost the chain step three more VALU instructions (the hop wraps; the limit
+// test becomes a test of the accumulated distance), and save the distance computation when a match is recorded.
+enum : int { R8_W = 53248, R8_C = 2048, R8_NCH = R8_W / R8_C, R8_PAD = 288, R8_H = 32768 };
+enum : int { R8_LINK_OFF = R8_W + R8_PAD, R8_CTL_OFF = R8_LINK_OFF + R8_W * 2, R8_LDS_BYTES = R8_CTL_OFF + 128 };
+static_assert(R8_W % R8_C == 0 && R8_LINK_OFF % 16 == 0 && R8_LDS_BYTES <= 160 * 1024 && R8_H >= B_HIST && R8_PAD >= B_TAIL + 16, "ring layout");
+enum : int { R8_COUNTER = 0, R8_STAGED = 1, R8_LOCK = 2, R8_SLOT0 = 4 };
+
+#define SZL8_Q_FINISH_(X, TAIL) \
+    "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 8, %[t2" #X "]\n\t" \
+    "v_cmpx_ne_u32 vcc, %[pb" #X "], %[t1" #X "]\n\t" \
+    "v_add_u32 %[dist" #X "], %[dist" #X "], %[t0" #X "]\n\t"              /* distance of the next candidate ("no link" is 0xFFFF) */ \
+    "v_cmpx_le_u32 vcc, %[dist" #X "], %[maxd" #X "]\n\t"                   /* curMatch > limit (:609) */ \
+    "v_sub_u32 %[cl" #X "], %[cl" #X "], %[t0" #X "]\n\t" \
+    "v_add_u32 %[t2" #X "], %[ringw], %[cl" #X "]\n\t"                       /* below ring address 0: wraps */ \
+    "v_min_u32 %[cl" #X "], %[cl" #X "], %[t2" #X "]\n\t" \
+    "v_subrev_co_u32 %[left" #X "], vcc, 1, %[left" #X "]\n\t" \
+    TAIL
+#define SZL8_Q_FINISH(X) SZL8_Q_FINISH_(X, "s_andn2_b64 exec, exec, vcc\n\t" "s_mov_b64 %[m" #X "], exec\n\t")
+#define SZL8_Q_FINISH_LAST(X) SZL8_Q_FINISH_(X, "s_andn2_b64 %[m" #X "], exec, vcc\n\t")
+#define SZL8_V_COMPLETE(X) \
+    "s_andn2_b64 %[cm], %[v" #X "], %[m" #X "]\n\t" \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "v_lshl_add_u32 %[t0" #X "], %[cl" #X "], 1, %[lbase]\n\t" \
+    "ds_read_u16 %[t0" #X "], %[t0" #X "]\n\t"                              /* prev[] hop of this candidate */ \
+    "v_min_i32 %[t2" #X "], %[off" #X "], %[cap" #X "]\n\t"                /* L */ \
+    "v_cmp_gt_i32 %[sc], %[t2" #X "], %[best" #X "]\n\t" \
+    "s_mov_b64 exec, %[sc]\n\t" \
+    "v_mov_b32 %[best" #X "], %[t2" #X "]\n\t" \
+    "v_lshl_or_b32 %[res2" #X "], %[dist" #X "], 16, %[t2" #X "]\n\t" \
+    "v_cmp_ge_i32 vcc, %[left" #X "], %[snap]\n\t"                           /* seen by the quarter-budget walk too (:495) */ \
+    "v_cndmask_b32 %[resq" #X "], %[resq" #X "], %[res2" #X "], vcc\n\t" \
+    "v_add3_u32 %[t1" #X "], %[p" #X "], %[t2" #X "], %[pbm1]\n\t" \
+    "ds_read_u8 %[t3" #X "], %[t1" #X "]\n\t" \
+    "ds_read_u8 %[t1" #X "], %[t1" #X "] offset:1\n\t" \
+    "v_cmp_ge_i32 %[sc], %[t2" #X "], %[nice" #X "]\n\t"                   /* >= niceLength: stop (:603) */ \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_lshl_or_b32 %[pb" #X "], %[t1" #X "], 8, %[t3" #X "]\n\t" \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "v_add_u32 %[dist" #X "], %[dist" #X "], %[t0" #X "]\n\t" \
+    "v_cmp_gt_u32 vcc, %[dist" #X "], %[maxd" #X "]\n\t" \
+    "s_or_b64 %[sc], %[sc], vcc\n\t" \
+    "v_cmp_eq_u32 vcc, 0, %[left" #X "]\n\t" \
+    "s_or_b64 %[sc], %[sc], vcc\n\t"                                         /* sc = lanes whose walk ends here */ \
+    "v_mov_b32 %[off" #X "], 0\n\t" \
+    "s_or_b64 %[d" #X "], %[d" #X "], %[sc]\n\t" \
+    "s_andn2_b64 exec, %[cm], %[sc]\n\t" \
+    "v_sub_u32 %[cl" #X "], %[cl" #X "], %[t0" #X "]\n\t" \
+    "v_add_u32 %[t1" #X "], %[ringw], %[cl" #X "]\n\t" \
+    "v_min_u32 %[cl" #X "], %[cl" #X "], %[t1" #X "]\n\t" \
+    "v_add_u32 %[left" #X "], -1, %[left" #X "]\n\t" \
+    "s_or_b64 %[q" #X "], %[q" #X "], exec\n\t" \
+    "s_mov_b64 %[v" #X "], %[m" #X "]\n\t"
+
+struct WalkCtx8 {
+    int p;            // ring address of the position being searched
+    int pg;           // the same position counted from the stripe's origin
+    int cl;           // ring address of the current candidate
+    uint32_t dist;    // its distance from the position
+    uint32_t maxd;    // largest distance a chain candidate may have (:609)
+    int best, left, off, cap, nice;
+    uint32_t pb, res2, resq;
+};
+
+// stage positions [k * R8_C, (k + 1) * R8_C) (counted from `origin`) into their place in the ring; threads tid of nthreads
+__device__ __forceinline__ void r8_stage_chunk(uint8_t *smem, const uint8_t *d, const uint16_t *lk, int64_t origin, int k, int64_t seg_end, int64_t link_end,
+                                               int tid, int nthreads) {
+    uint32_t *sdata32 = (uint32_t *)smem;
+    uint32_t *slink32 = (uint32_t *)(smem + R8_LINK_OFF);
+    const int ra0 = (k % R8_NCH) * R8_C;
+    const int64_t pos0 = origin + (int64_t)k * R8_C;
+    if (nthreads == 64 && pos0 >= 0 && pos0 + R8_C <= seg_end && pos0 + R8_C <= link_end) {
+        // one wave, chunk inside the stream (the steady state): all six 16-byte loads of a lane are in flight together — a chunk
+        // has to arrive faster than the workgroup searches one (~17 us), and one wave stages at a time
+        static_assert(R8_C == 2048 && R8_W % 16 == 0 && (R8_LINK_OFF % 16) == 0, "two data and four link loads per lane");
+        auto ld16 = [](const void *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; };
+        auto fix = [](uint32_t w) { if ((w & 0xFFFFu) == 0) w |= 0xFFFFu; if ((w >> 16) == 0) w |= 0xFFFF0000u; return w; };
+        const uint8_t *dp = d + pos0;
+        const uint8_t *lp = (const uint8_t *)(lk + pos0);
+        const uint4 d0 = ld16(dp + tid * 16), d1 = ld16(dp + (tid + 64) * 16);
+        uint4 l0 = ld16(lp + tid * 16), l1 = ld16(lp + (tid + 64) * 16), l2 = ld16(lp + (tid + 128) * 16), l3 = ld16(lp + (tid + 192) * 16);
+        uint4 *sd4 = (uint4 *)smem, *sl4 = (uint4 *)(smem + R8_LINK_OFF);
+        sd4[(ra0 >> 4) + tid] = d0; sd4[(ra0 >> 4) + tid + 64] = d1;
+        if (ra0 == 0 && tid * 16 < R8_PAD) sd4[(R8_W >> 4) + tid] = d0;       // (R8_PAD <= 1024: within the first load)
+        l0.x = fix(l0.x); l0.y = fix(l0.y); l0.z = fix(l0.z); l0.w = fix(l0.w);
+        l1.x = fix(l1.x); l1.y = fix(l1.y); l1.z = fix(l1.z); l1.w = fix(l1.w);
+        l2.x = fix(l2.x); l2.y = fix(l2.y); l2.z = fix(l2.z); l2.w = fix(l2.w);
+        l3.x = fix(l3.x); l3.y = fix(l3.y); l3.z = fix(l3.z); l3.w = fix(l3.w);
+        sl4[(ra0 >> 3) + tid] = l0; sl4[(ra0 >> 3) + tid + 64] = l1; sl4[(ra0 >> 3) + tid + 128] = l2; sl4[(ra0 >> 3) + tid + 192] = l3;
+        return;
+    }
+    for (int i = tid; i < R8_C / 4; i += nthreads) {
+        const int64_t pos = pos0 + 4 * (int64_t)i;
+        uint32_t w = 0;
+        if (pos >= 0 && pos + 4 <= seg_end) w = load_u32_unaligned2(d + pos);
+        else for (int b = 0; b < 4; b++) { const int64_t pk = pos + b; if (pk >= 0 && pk < seg_end) w |= (uint32_t)d[pk] << (8 * b); }
+        sdata32[(ra0 >> 2) + i] = w;
+        if (ra0 == 0 && 4 * i < R8_PAD) sdata32[(R8_W >> 2) + i] = w;      // the bytes after the ring's end are those at its start
+    }
+    for (int i = tid; i < R8_C / 2; i += nthreads) {
+        const int64_t pos = pos0 + 2 * (int64_t)i;
+        uint32_t w = 0;
+        if (pos >= 0 && pos < link_end) w |= lk[pos];
+        if (pos + 1 >= 0 && pos + 1 < link_end) w |= (uint32_t)lk[pos + 1] << 16;
+        if ((w & 0xFFFFu) == 0) w |= 0xFFFFu;
+        if ((w >> 16) == 0) w |= 0xFFFF0000u;
+        slink32[(ra0 >> 1) + i] = w;
+    }
+}
+
+__global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
+                                                       const TileDev *__restrict__ stripes, const uint16_t *__restrict__ link,
+                                                       MTab mtab, LevelParams P, int fth, int vth, int qkeep, int vkeep, int slice, int lowwater, unsigned long long *dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const TileDev stripe = stripes[blockIdx.x];
+    const SegDev seg = segs[stripe.seg];
+    const uint16_t *slink = (const uint16_t *)(smem + R8_LINK_OFF);
+    volatile int *ctl = (volatile int *)(smem + R8_CTL_OFF);
+    int *ctl_a = (int *)(smem + R8_CTL_OFF);
+    const uint8_t *d = in + seg.buf_off;
+    const uint16_t *lk = link + seg.buf_off;
+    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
+    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
+    const int64_t seg_end = seg.look_end;
+    const int64_t stripe_end = stripe.start + stripe.len;
+    const int64_t origin = stripe.start - R8_H;                 // stream position of ring position 0 (may be negative)
+    const int xo_end = R8_H + stripe.len;                       // positions are counted from the origin ("xo") from here on
+    const int NC = (xo_end + R8_PAD + R8_C - 1) / R8_C;         // chunks the stripe needs in all
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const int n0 = NC < R8_NCH ? NC : (int)R8_NCH;
+        for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, B2_THREADS);
+        if (threadIdx.x == 0) { ctl[R8_COUNTER] = R8_H; ctl[R8_STAGED] = n0; ctl[R8_LOCK] = 0; }
+        if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = R8_H;
+    }
+    __syncthreads();
+
+    const uint8_t *sdata8 = smem;
+    const uint32_t dbase = (uint32_t)(uintptr_t)(lds_u8 *)smem;
+    const uint32_t lbase = dbase + (uint32_t)R8_LINK_OFF;
+    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);
+    const int INF = 0x7FFFFFFF;
+
+    WalkCtx8 A, B;
+    A.p = 0; A.pg = 0; A.cl = 0; A.dist = 0; A.maxd = 0; A.best = 2; A.left = 0; A.off = 0; A.cap = MAX_MATCH; A.nice = P.nice; A.pb = 0; A.res2 = 0; A.resq = 0;
+    B = A;
+    uint64_t qA = 0, vA = 0, dA = 0, qB = 0, vB = 0, dB = 0;
+    int wnext = 0, wend = 0;          // the wave's reservation (xo)
+    int myslot = R8_H;                // what ctl[R8_SLOT0 + wave] holds: a lower bound of every position this wave still works on
+    bool done_all = false;            // the counter passed the stripe's end
+    unsigned c_iter = 0, c_starve = 0, c_blocked = 0, c_lockfail = 0, c_sleep = 0, c_staged = 0, c_busy = 0;   // (lab counters, per wave)
+
+    auto wave_min = [&](int v) { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; };
+    auto retire = [&](WalkCtx8 &C, uint64_t &dm) {
+        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[origin + C.pg] = C.res2; mtq[origin + C.pg] = C.resq; }
+        dm = 0;
+    };
+    // start walks on the free lanes of a context with the positions [wnext, lim)
+    auto assign = [&](WalkCtx8 &C, uint64_t &q, uint64_t &v, int lim) {
+        if (wnext >= lim) return;
+        const uint64_t idle = ~(q | v);
+        const int ni = __builtin_popcountll(idle);
+        if (ni == 0) return;
+        const int rank = __builtin_popcountll(idle & lanemask_lt);
+        const int rabase = wnext % (int)R8_W;
+        bool toverify = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(idle) && wnext + rank < lim) {
+            const int pxo = wnext + rank;
+            int ra = rabase + rank;
+            ra = ra >= (int)R8_W ? ra - (int)R8_W : ra;
+            C.pg = pxo; C.p = ra;
+            const int64_t pos = origin + pxo;
+            const int64_t rem64 = seg_end - pos;
+            const int rem = rem64 > (int64_t)(1 << 24) ? (1 << 24) : (int)rem64;
+            C.res2 = 0; C.resq = 0;
+            bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
+            if (ok) {
+                const uint32_t l0 = slink[ra];                           // hashHead (:782) as a distance; none = 0xFFFF
+                const int64_t s_abs = (int64_t)seg.abs0 + pos;
+                const int64_t room64 = s_abs - base_of2(s_abs);         // distance to window index 0 (entries below were clamped by a slide, :450-461)
+                const uint32_t room = room64 > (int64_t)(1 << 20) ? (1u << 20) : (uint32_t)room64;
+                ok = l0 <= (room < (uint32_t)MAX_DIST ? room : (uint32_t)MAX_DIST);   // strstart - hashHead <= MAX_DIST (:788)
+                if (ok) {
+                    int c = ra - (int)l0;
+                    C.cl = c < 0 ? c + (int)R8_W : c;
+                    C.dist = l0;
+                    C.maxd = room < (uint32_t)(MAX_DIST - 1) ? room : (uint32_t)(MAX_DIST - 1);   // curMatch > limit (:609)
+                    C.cap = rem < MAX_MATCH ? rem : MAX_MATCH;
+                    C.nice = rem < P.nice ? rem : P.nice;
+                    C.best = 2; C.left = P.max_chain - 1;
+                    C.pb = ((uint32_t)sdata8[ra + 2] << 8) | sdata8[ra + 1];
+                    C.off = 0;
+                    toverify = true;
+                }
+            }
+            if (!ok) { mt2[pos] = 0u; mtq[pos] = 0u; }
+        }
+        v |= __ballot(toverify);
+        wnext = wnext + ni < lim ? wnext + ni : lim;
+    };
+
+    for (;;) {
+        retire(A, dA);
+        retire(B, dB);
+        const int nidle = 128 - __builtin_popcountll(qA | vA) - __builtin_popcountll(qB | vB);
+        if (wnext >= wend && !done_all && nidle > 0) {                  // a new reservation
+            int base = 0, c0 = 0;
+            if (lane == 0) c0 = ctl[R8_COUNTER];
+            c0 = __builtin_amdgcn_readfirstlane(c0);
+            if (myslot > c0) {        // (a wave with nothing in flight: whatever it takes next is at or above the counter — say so BEFORE taking it)
+                myslot = c0;
+                if (lane == 0) ctl[R8_SLOT0 + wave] = c0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+            if (lane == 0) base = atomicAdd(&ctl_a[R8_COUNTER], slice);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= xo_end) done_all = true;
+            else { wnext = base; wend = base + slice < xo_end ? base + slice : xo_end; }
+        }
+        int st = 0, cnt = 0;
+        if (lane == 0) { st = ctl[R8_STAGED]; cnt = ctl[R8_COUNTER]; }
+        st = __builtin_amdgcn_readfirstlane(st); cnt = __builtin_amdgcn_readfirstlane(cnt);
+        int avail = st == NC ? xo_end : st * (int)R8_C - (int)R8_PAD;
+        if (st < NC && (avail - cnt < lowwater || (wnext < wend && wnext >= avail))) {
+            // keep the ring ahead of the counter: one wave at a time stages the next chunk, over the oldest one
+            int got = 0;
+            if (lane == 0) got = atomicCAS(&ctl_a[R8_LOCK], 0, 1) == 0;
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (!got) c_lockfail++;
+            if (got) {
+                int st2 = 0, c1 = 0;
+                if (lane == 0) { st2 = ctl[R8_STAGED]; c1 = ctl[R8_COUNTER]; }           // the counter BEFORE the slots (see the reservation above)
+                st2 = __builtin_amdgcn_readfirstlane(st2); c1 = __builtin_amdgcn_readfirstlane(c1);
+                if (st2 < NC) {
+                    int mn = lane < 16 ? ctl[R8_SLOT0 + lane] : INF;
+                    mn = wave_min(mn);
+                    mn = mn < c1 ? mn : c1;
+                    // chunk k goes over chunk k - R8_NCH: no walk may reach below position (k - R8_NCH + 1) * R8_C any more
+                    int k = st2;
+                    while (k < NC && k < st2 + 3 && mn >= (k - (int)R8_NCH + 1) * (int)R8_C + (int)B_HIST) {
+                        r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, lane, 64);
+                        k++;
+                    }
+                    if (k > st2) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) ctl[R8_STAGED] = k;
+                        c_staged += (unsigned)(k - st2);
+                    } else c_blocked++;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) { atomicExch(&ctl_a[R8_LOCK], 0); st = ctl[R8_STAGED]; }
+                st = __builtin_amdgcn_readfirstlane(st);
+                avail = st == NC ? xo_end : st * (int)R8_C - (int)R8_PAD;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int lim = wend < avail ? wend : avail;
+        assign(A, qA, vA, lim);
+        assign(B, qB, vB, lim);
+        {   // publish the lowest position this wave still works on
+            const bool actA = __builtin_amdgcn_inverse_ballot_w64(qA | vA), actB = __builtin_amdgcn_inverse_ballot_w64(qB | vB);
+            int mn = actA ? A.pg : INF;
+            mn = actB && B.pg < mn ? B.pg : mn;
+            mn = wave_min(mn);
+            if (wnext < wend && wnext < mn) mn = wnext;
+            if (mn != myslot) { myslot = mn; if (lane == 0) ctl[R8_SLOT0 + wave] = mn; }
+        }
+        const uint32_t busy = (uint32_t)(__builtin_popcountll(qA | vA) + __builtin_popcountll(qB | vB));
+        if (busy == 0) {
+            if (done_all && wnext >= wend) break;
+            c_sleep++;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        // run until `fth` contexts are free again; without positions to give them (the ring is not ahead, or the stripe is handed out)
+        // until 16 more walks are over, resp. all of them
+        const bool handed_out = done_all && wnext >= wend;
+        const bool starving = wnext >= lim && !handed_out;
+        c_iter++; c_busy += busy; if (starving) c_starve++;
+        const uint32_t busy_exit = (uint32_t)__builtin_amdgcn_readfirstlane((int)(handed_out ? 0u : (starving ? (busy > 16u ? busy - 16u : 0u) : (uint32_t)(128 - fth))));
+        uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
+        uint64_t mA, mB, sc, cm, sv;
+        uint32_t n0, n1, n2;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n"
+            "10:\n\t"                                           // ---- census
+            "s_or_b64 %[sc], %[qA], %[vA]\n\t"
+            "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
+            "s_or_b64 %[sc], %[qB], %[vB]\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
+            "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
+            "s_cmp_le_u32 %[n0], %[bexit]\n\t"
+            "s_cbranch_scc1 19f\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
+            "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
+            "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
+            "s_cmp_ge_u32 %[n1], %[vth]\n\t"
+            "s_cbranch_scc1 14f\n\t"
+            "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
+            "s_cbranch_scc1 14f\n"
+            // ---- QUICK phase
+            "s_mov_b64 %[mA], %[qA]\n\t"
+            "s_mov_b64 %[mB], %[qB]\n"
+            "11:\n\t"
+            "s_mov_b64 exec, %[mA]\n\t"
+            SZL_Q_ISSUE(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            SZL_Q_ISSUE(B)
+            "s_mov_b64 exec, %[mA]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            SZL8_Q_FINISH(A)
+            SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
+            "s_mov_b64 exec, %[mB]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            SZL8_Q_FINISH(B)
+            SZL_Q_ISSUE(B)
+            "s_mov_b64 exec, %[mA]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            SZL8_Q_FINISH_LAST(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL8_Q_FINISH_LAST(B)
+            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
+            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
+            "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
+            "s_cbranch_scc1 11b\n\t"
+            SZL_Q_CLASSIFY(A)
+            SZL_Q_CLASSIFY(B)
+            "s_branch 10b\n"
+            // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
+            // side's instructions are issued)
+            "14:\n\t"
+            "s_mov_b64 %[mA], %[vA]\n\t"
+            "s_mov_b64 %[mB], %[vB]\n\t"
+            "s_cmp_eq_u64 %[vB], 0\n\t"
+            "s_cbranch_scc1 16f\n\t"
+            "s_cmp_eq_u64 %[vA], 0\n\t"
+            "s_cbranch_scc1 17f\n"
+            "15:\n\t"
+            "s_mov_b64 exec, %[mA]\n\t"
+            SZL_V_ISSUE(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            SZL_V_ISSUE(B)
+            "s_mov_b64 exec, %[mA]\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            SZL_V_FINISH(A)
+            "s_mov_b64 exec, %[mB]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_V_FINISH(B)
+            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
+            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
+            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+            "s_cbranch_scc1 15b\n\t"
+            SZL8_V_COMPLETE(A)
+            SZL8_V_COMPLETE(B)
+            "s_branch 10b\n"
+            "16:\n\t"                                          // only context A has candidates to compare
+            "s_mov_b64 exec, %[mA]\n\t"
+            SZL_V_ISSUE(A)
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_V_FINISH(A)
+            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
+            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+            "s_cbranch_scc1 16b\n\t"
+            SZL8_V_COMPLETE(A)
+            "s_branch 10b\n"
+            "17:\n\t"                                          // only context B
+            "s_mov_b64 exec, %[mB]\n\t"
+            SZL_V_ISSUE(B)
+            "s_waitcnt lgkmcnt(0)\n\t"
+            SZL_V_FINISH(B)
+            "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
+            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
+            "s_cbranch_scc1 17b\n\t"
+            SZL8_V_COMPLETE(B)
+            "s_branch 10b\n"
+            "19:\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [distA] "+&v"(A.dist), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
+              [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
+              [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [distB] "+&v"(B.dist), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
+              [res2B] "+&v"(B.res2), [resqB] "+&v"(B.resq),
+              [qA] "+&s"(qA), [vA] "+&s"(vA), [dA] "+&s"(dA), [qB] "+&s"(qB), [vB] "+&s"(vB), [dB] "+&s"(dB),
+              [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A),
+              [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B),
+              [mA] "=&s"(mA), [mB] "=&s"(mB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2)
+            : [maxdA] "v"(A.maxd), [capA] "v"(A.cap), [niceA] "v"(A.nice), [maxdB] "v"(B.maxd), [capB] "v"(B.cap), [niceB] "v"(B.nice),
+              [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(dbase), [dbm1] "s"(dbase - 1u), [pbm1] "s"(dbase - 1u), [snap] "s"(SNAPLEFT),
+              [bexit] "s"(busy_exit), [ringw] "s"((uint32_t)R8_W), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep)
+            : "vcc", "scc", "memory");
+    }
+    if (dbg && lane == 0) {
+        atomicAdd(dbg + 22, (unsigned long long)c_iter); atomicAdd(dbg + 23, (unsigned long long)c_starve); atomicAdd(dbg + 24, (unsigned long long)c_blocked);
+        atomicAdd(dbg + 25, (unsigned long long)c_lockfail); atomicAdd(dbg + 26, (unsigned long long)c_sleep); atomicAdd(dbg + 27, (unsigned long long)c_staged);
+        atomicAdd(dbg + 28, (unsigned long long)c_busy);
+    }
+}
+
 static bool lds_attr_needed2(std::atomic<uint64_t> &mask, uint64_t &bit) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -612,6 +1308,48 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
         const dim3 g(ntiles), b(B2_THREADS);
         if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
         else hipLaunchKernelGGL((k_match4<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
+    }
+    return hipGetLastError();
+}
+
+// stripes: TileDev entries whose len may exceed B_TILE (the engine cuts them)
+hipError_t launch_match_slide(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
+                              unsigned long long *dbg, hipStream_t st) {
+    static std::atomic<uint64_t> attr_mask{0};
+    uint64_t attr_bit = 0;
+    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2), slice = knob("SZL_SLICE", 128);
+    if (lds_attr_needed2(attr_mask, attr_bit)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_match7<12288>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match7<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match7<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match7<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_mask.fetch_or(attr_bit, std::memory_order_release);
+    }
+    if (knob("SZL_MATCH_KERNEL", 2) == 5) {
+        static std::atomic<uint64_t> attr_mask8{0};
+        uint64_t bit8 = 0;
+        if (lds_attr_needed2(attr_mask8, bit8)) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_match8, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_mask8.fetch_or(bit8, std::memory_order_release);
+        }
+        int lowwater = knob("SZL_LOWWATER", 6144);
+        lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
+        if (slice > 1024) slice = 1024;
+        if (nstripes > 0)
+            hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, knob("SZL_DEBUG", 0) ? dbg : nullptr);
+        return hipGetLastError();
+    }
+    const int shift = knob("SZL_SHIFT", 12288);   // positions the window moves at a time
+    fth = fth < 1 ? 1 : (fth > 128 ? 128 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; vkeep = vkeep < 1 ? 1 : vkeep;
+    slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
+    if (nstripes > 0) {
+        const dim3 g(nstripes), b(B2_THREADS);
+        if (shift >= 12288) hipLaunchKernelGGL(k_match7<12288>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
+        else if (shift >= 8192) hipLaunchKernelGGL(k_match7<8192>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
+        else if (shift >= 4096) hipLaunchKernelGGL(k_match7<4096>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
+        else hipLaunchKernelGGL(k_match7<2048>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
     }
     return hipGetLastError();
 }

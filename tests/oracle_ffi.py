@@ -82,6 +82,7 @@ def lib():
         ("szm_first_node", sz, [vp, sz, vp, vp, vp, vp, sz, sz]),
         ("szm_links4", None, [vp, sz, vp, vp, vp]), ("szm_match_tables_c4", None, [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
         ("szm_match_tables_k6", None, [vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp]),
+        ("szm_match_tables_k7", None, [vp, sz, sz, sz, vp, ctypes.c_int, vp, vp, vp, vp]),
         ("szm_lazy_eval_set", sz, [vp, sz, sz, vp, vp, vp, vp, sz, sz, vp]),
     ]:
         f = getattr(L, name); f.restype = res; f.argtypes = args
@@ -328,6 +329,17 @@ class Model:
         for e in self.seg_ends:
             (self.L.szm_match_tables_k6 if kernel_shape else self.L.szm_match_tables_c4)(self._dpad.ctypes.data, self.n, s, int(e), self.link.ctypes.data, l4.ctypes.data, s4.ctypes.data,
                                        ctypes.byref(self.P), m2.ctypes.data, mq.ctypes.data, steps.ctypes.data)
+            s = int(e)
+        return m2, mq, int(steps[0])
+
+    def match_tables_k7(self, dist_cap=32512):
+        """(m2, mq, candidates examined) of the device form of the compressed walk (no slow routine); must equal self.m2 / self.mq"""
+        m2 = np.zeros(self.n + 8, np.uint32); mq = np.zeros(self.n + 8, np.uint32)
+        steps = np.zeros(1, np.uint64)
+        s = 0
+        for e in self.seg_ends:
+            self.L.szm_match_tables_k7(self._dpad.ctypes.data, self.n, s, int(e), self.link.ctypes.data, dist_cap, ctypes.byref(self.P),
+                                       m2.ctypes.data, mq.ctypes.data, steps.ctypes.data)
             s = int(e)
         return m2, mq, int(steps[0])
 

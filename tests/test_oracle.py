@@ -333,3 +333,9 @@ def test_chain_compressed_walk_gives_the_same_match_tables():
                 k2, kq, ksteps = m.match_tables_c4(kernel_shape=True)
                 assert np.array_equal(k2[:data.size], m.m2[:data.size]), (name, level, "M2 kernel shape")
                 assert np.array_equal(kq[:data.size], m.mq[:data.size]), (name, level, "Mq kernel shape")
+                # the device form: no slow routine (first candidate = first chain element with the same THREE bytes), links no
+                # farther than a stage-B window's history
+                j2, jq, jsteps = m.match_tables_k7(dist_cap=32512)
+                assert np.array_equal(j2[:data.size], m.m2[:data.size]), (name, level, "M2 device form")
+                assert np.array_equal(jq[:data.size], m.mq[:data.size]), (name, level, "Mq device form")
+                assert jsteps <= ksteps
