@@ -21,12 +21,23 @@ void launch_links4(const uint8_t *in, const uint16_t *link, int64_t lo, int64_t 
                    uint8_t *e3h, hipStream_t st);
 int match3_tile();
 // SZL_MATCH_KERNEL=3: the full search of stage B walks four-byte sub-chains (szl_kernels_match3.hip); hop counts are bytes there
-hipError_t launch_match_slide(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
-                              unsigned long long *dbg, hipStream_t st);
-// SZL_MATCH_KERNEL=4: the full search runs over stripes with a sliding window (k_match7, szl_kernels_match2.hip).  `emit` = positions searched.
-static int64_t slide_stripe_len(uint64_t emit, int64_t tile_len) {
+hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
+                             unsigned long long *dbg, hipStream_t st);
+int match2_tile();
+// The full search of stage B has a work list of its own: k_match4 (SZL_MATCH_KERNEL=2, the default) takes tiles as long as its LDS window
+// allows — longer than the B_TILE the other forms of stage B are built for; the ring form (=4, lab) takes stripes of any length.
+// `emit` = positions searched, `tile_len` = what the call's size made of B_TILE.  0: use the common tile list.
+static int64_t full_search_len(uint64_t emit, int64_t tile_len) {
+    const int which = knob("SZL_MATCH_KERNEL", 2);
+    if (which == 2) {
+        int64_t len = match2_tile();
+        if (knob("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+        while (len > 2048 && emit / (uint64_t)len < 128) len >>= 1;     // a small call gets shorter tiles (see tile_len)
+        return len;
+    }
+    if (which != 4) return 0;
     const uint64_t min_stripes = (uint64_t)std::max(1, knob("SZL_STRIPE_MIN", 512));   // (1: tests — long stripes on small inputs)
-    if ((knob("SZL_MATCH_KERNEL", 2) != 4 && knob("SZL_MATCH_KERNEL", 2) != 5) || (tile_len < B_TILE && min_stripes > 1)) return 0;
+    if (tile_len < B_TILE && min_stripes > 1) return 0;
     int64_t len = (int64_t)std::max(16, knob("SZL_STRIPE_KIB", 256)) << 10;
     while (len > B_TILE && emit / (uint64_t)len < min_stripes) len >>= 1;
     return len;
@@ -183,7 +194,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     int64_t tile_len = m3 ? match3_tile() : B_TILE;
     if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
     while (tile_len > 2048 && total_emit / (uint64_t)tile_len < 128) tile_len >>= 1;
-    const int64_t stripe_len = (!P.fast && !m3) ? slide_stripe_len(total_emit, tile_len) : 0;
+    const int64_t stripe_len = (!P.fast && !m3) ? full_search_len(total_emit, tile_len) : 0;
     std::vector<SpanDev> spans;
     std::vector<TileDev> tiles, stripes;
     std::vector<uint64_t> chunk_off(nseg + 1), zero_off(nseg + 1);
@@ -281,8 +292,8 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if ((rc = upload(d_bnds, bnds, st))) return rc;
     if ((rc = upload(d_spans, spans, st))) return rc;
     if ((rc = upload(d_tiles, tiles, st))) return rc;
-    const bool slide = stripe_len > 0 && !has_switch && !stripes.empty();
-    if (slide && (rc = upload(d_stripes, stripes, st))) return rc;
+    const bool own_list = stripe_len > 0 && !has_switch && !stripes.empty();   // the full search's own work list
+    if (own_list && (rc = upload(d_stripes, stripes, st))) return rc;
     if ((rc = upload(ckoff, chunk_off, st))) return rc;
     if ((rc = upload(d_zoff, zero_off, st))) return rc;
     size_t cub_bytes1 = 0, cub_bytes2 = 0;
@@ -387,7 +398,10 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         mt3.link4 = (const uint16_t *)link4.p; mt3.skip4 = (const uint8_t *)skip4.p;
         mt3.e3d = (const uint16_t *)e3dist.p; mt3.e3h = (const uint8_t *)e3hops.p;
         HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt3, P, dcnt, st));
-    } else if (!lazy && slide) HIPCHK(launch_match_slide(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+    } else if (!lazy && own_list) {
+        if (knob("SZL_MATCH_KERNEL", 2) == 4) HIPCHK(launch_match_ring(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+        else HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+    }
     else if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     if (has_switch) { // tiles are grouped by parameter set: group 0 = the call's P, group k = sw_P[k-1] of the (single) switching segment
         size_t a = 0;
@@ -612,7 +626,7 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         for (int64_t a = e; a < wend; a += tile_len) tiles.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(tile_len, wend - a), 0});
         const uint64_t ntiles = tiles.size();
         std::vector<TileDev> stripes;
-        const int64_t stripe_len = m3 ? 0 : slide_stripe_len((uint64_t)(wend - e), tile_len);
+        const int64_t stripe_len = m3 ? 0 : full_search_len((uint64_t)(wend - e), tile_len);
         for (int64_t a = e; stripe_len && a < wend; a += stripe_len) stripes.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(stripe_len, wend - a), 0});
         if (!stripes.empty() && (rc = upload(d_stripes, stripes, st))) return rc;
         // side arrays of this window, addressed with the stream's own indices (pointer minus the window's first index)
@@ -657,7 +671,8 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
                 launch_links4(d_in, lk, (int64_t)seg.buf_off + lo, (int64_t)seg.buf_off + wend, (int64_t)seg.buf_off + N, l4, s4, ed, eh, st);
                 mtw.link4 = l4; mtw.skip4 = s4; mtw.e3d = ed; mtw.e3h = eh;
             }
-            if (!stripes.empty()) HIPCHK(launch_match_slide(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
+            if (!stripes.empty() && knob("SZL_MATCH_KERNEL", 2) == 4) HIPCHK(launch_match_ring(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
+            else if (!stripes.empty()) HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
             else HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mtw, P, dcnt, st));
             if (!last) HIPCHK(hipMemsetAsync((uint32_t *)mtab.p + wn, 0xFF, (size_t)(hi - wend) * 4, st)); // the tail past the parse end: evaluated on demand
         }

@@ -48,9 +48,12 @@ __device__ __forceinline__ int64_t base_of2(int64_t s_abs) { // window base of a
 }
 __device__ __forceinline__ uint32_t load_u32_unaligned2(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-enum : int { B2_THREADS = 1024 };
-enum : int { B2_DATA_BYTES = B_HIST + B_TILE + B_TAIL + 8, B2_LINKS = B_HIST + B_TILE };
+// A tile costs ~67 us beyond its walks (staging of the history, and the wait for the longest walks at its end: profiles/r02/
+// lab_s46_tile_length.log), so the tile is as long as the LDS of a CU allows: 3 bytes per position of history + tile.
+enum : int { B2_THREADS = 1024, B2_TILE = 21504 };
+enum : int { B2_DATA_BYTES = B_HIST + B2_TILE + B_TAIL + 8, B2_LINKS = B_HIST + B2_TILE };
 enum : int { B2_LDS_BYTES = B2_DATA_BYTES + B2_LINKS * 2 + 16 };
+static_assert(B2_LDS_BYTES <= 160 * 1024 && B2_DATA_BYTES % 16 == 0 && B2_TILE % 64 == 0, "the window must fit the CU's LDS");
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
 
     const int64_t base_lo = base_of2((int64_t)seg.abs0 + t0), base_hi = base_of2((int64_t)seg.abs0 + t0 + tlen - 1);
     const int64_t sw64 = base_lo == base_hi ? (int64_t)1 << 30 : (base_lo + 65273) - (int64_t)seg.abs0 - t0; // first tile position on base_hi
-    const int sw = sw64 > (int64_t)B_TILE ? B_TILE : (int)sw64;
+    const int sw = sw64 > (int64_t)B2_TILE ? B2_TILE : (int)sw64;
     const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo);
     // lookahead at tile position 0, clamped (only its value below 258 matters): rem(p) = rem0 - p
     const int64_t rem0_64 = seg_end - t0;
@@ -579,303 +582,21 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
 }
 
 
-// ---- k_match7: the same engine over a STRIPE of consecutive positions with a window that slides ---------------------------------
-// What a 16 Ki tile costs k_match4 beyond its walks (profiles/r02/lab_s46_tile_length.log: 52.5 / 69.8 / 101.7 ms per GiB with 16 / 8 /
-// 4 Ki tiles, i.e. 67 us per tile, a third of the kernel): every tile stages 48 Ki positions to search 16 Ki, and ends with the
-// workgroup waiting for its longest walks (a full-budget walk is 128 dependent steps, ~40 us) with most lanes idle.  Here a
-// workgroup owns a stripe and moves the window along it SZ7_SHIFT positions at a time: the bytes and links that stay are moved
-// down inside LDS, only the new ones come from memory (a third of the traffic), and walks of positions that are still inside
-// the window after the move (tile index >= SZ7_SHIFT) simply go on — cl, p and mincl are window indices, so they move with it.
-// The wait at a move is only for positions below SZ7_SHIFT, which were handed out at least a quarter of a window ago.
-
-__device__ __forceinline__ void b7_stage(uint32_t *sdata32, uint16_t *slink, const uint8_t *d, const uint16_t *lk, int64_t dlo, int64_t seg_end,
-                                         int64_t link_end, int i0d, int i0l) {
-    for (int i = i0d + threadIdx.x; i < B2_DATA_BYTES / 4; i += B2_THREADS) {
-        int64_t pos = dlo + 4 * (int64_t)i;
-        uint32_t w = 0;
-        if (pos >= 0 && pos + 4 <= seg_end) w = load_u32_unaligned2(d + pos);
-        else {
-            for (int k = 0; k < 4; k++) {
-                int64_t pk = pos + k;
-                if (pk >= 0 && pk < seg_end) w |= (uint32_t)d[pk] << (8 * k);
-            }
-        }
-        sdata32[i] = w;
-    }
-    for (int i = i0l + threadIdx.x; i < B2_LINKS / 2; i += B2_THREADS) {
-        int64_t pos = dlo + 2 * (int64_t)i;
-        uint32_t w = 0;
-        if (pos >= 0 && pos < link_end) w |= lk[pos];
-        if (pos + 1 >= 0 && pos + 1 < link_end) w |= (uint32_t)lk[pos + 1] << 16;
-        if ((w & 0xFFFFu) == 0) w |= 0xFFFFu;
-        if ((w >> 16) == 0) w |= 0xFFFF0000u;
-        ((uint32_t *)slink)[i] = w;
-    }
-}
-
-template <int SZ7_SHIFT>
-__global__ __launch_bounds__(B2_THREADS) void k_match7(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
-                                                       const TileDev *__restrict__ stripes, const uint16_t *__restrict__ link,
-                                                       MTab mtab, LevelParams P, int fth, int vth, int qkeep, int vkeep, int slice) {
-    static_assert(SZ7_SHIFT % 16 == 0 && SZ7_SHIFT >= 1024 && B_TILE - SZ7_SHIFT >= 1024, "window move");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const TileDev stripe = stripes[blockIdx.x];
-    const SegDev seg = segs[stripe.seg];
-    uint32_t *sdata32 = (uint32_t *)smem;
-    uint16_t *slink = (uint16_t *)(smem + B2_DATA_BYTES);
-    int *s_counter = (int *)(smem + B2_DATA_BYTES + B2_LINKS * 2);
-    const uint8_t *d = in + seg.buf_off;
-    const uint16_t *lk = link + seg.buf_off;
-    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
-    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
-    const int64_t seg_end = seg.look_end;
-    const int64_t stripe_end = stripe.start + stripe.len;       // links are needed (and exist) up to here
-    const int nwin = stripe.len <= B_TILE ? 1 : 1 + (stripe.len - B_TILE + SZ7_SHIFT - 1) / SZ7_SHIFT;
-
-    int64_t t0 = stripe.start;                                   // stream position of tile index 0 of the window
-    b7_stage(sdata32, slink, d, lk, t0 - B_HIST, seg_end, stripe_end, 0, 0);
-    if (threadIdx.x == 0) *s_counter = 0;
-    __syncthreads();
-
-    const uint8_t *sdata8 = smem;
-    const uint32_t dbase = (uint32_t)(uintptr_t)(lds_u8 *)smem;
-    const uint32_t lbase = dbase + (uint32_t)B2_DATA_BYTES;
-    const uint32_t pbase = dbase + (uint32_t)B_HIST;
-    const int lane = threadIdx.x & 63;
-    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);
-    const int bhist = B_HIST;
-
-    WalkCtx A, B;
-    A.p = 0; A.cl = B_HIST; A.best = 2; A.left = 0; A.off = 0; A.mincl = 0; A.cap = MAX_MATCH; A.nice = P.nice; A.pb = 0; A.res2 = 0; A.resq = 0;
-    B = A;
-    uint64_t qA = 0, vA = 0, dA = 0, qB = 0, vB = 0, dB = 0;
-
-    for (int win = 0;; win++) {
-        // ---- this window: tile indices [0, tlen) are stream positions t0 + index; [0, first) were handed out before the move
-        const int64_t left64 = stripe_end - t0;
-        const int tlen = left64 < (int64_t)B_TILE ? (int)left64 : (int)B_TILE;
-        const bool last_win = win == nwin - 1;
-        const int must_finish = last_win ? 0x7FFFFFFF : (int)SZ7_SHIFT;   // walks of tile indices below this end before the window moves
-        const int64_t dlo = t0 - B_HIST;
-        const int64_t base_lo = base_of2((int64_t)seg.abs0 + t0), base_hi = base_of2((int64_t)seg.abs0 + t0 + tlen - 1);
-        const int64_t sw64 = base_lo == base_hi ? (int64_t)1 << 30 : (base_lo + 65273) - (int64_t)seg.abs0 - t0;
-        const int sw = sw64 > (int64_t)B_TILE ? B_TILE : (int)sw64;
-        const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo);
-        const int64_t rem0_64 = seg_end - t0;
-        const int rem0 = rem0_64 > (int64_t)(1 << 24) ? (1 << 24) : (int)rem0_64;
-        int wnext = 0, wend = 0;
-        bool exhausted = false;
-
-        auto fetch = [&](WalkCtx &C, uint64_t &q, uint64_t &v, uint64_t &dm) {
-            if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; }
-            dm = 0;
-            if (exhausted) return;
-            const uint64_t idle = ~(q | v);
-            const int ni = __builtin_popcountll(idle);
-            if (ni == 0) return;
-            if (wnext >= wend) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(s_counter, slice);
-                base = __builtin_amdgcn_readfirstlane(base);
-                wnext = base < tlen ? base : tlen;
-                wend = base + slice < tlen ? base + slice : tlen;
-                if (wnext >= wend) { exhausted = true; return; }
-            }
-            const int rank = __builtin_popcountll(idle & lanemask_lt);
-            bool toverify = false;
-            if (__builtin_amdgcn_inverse_ballot_w64(idle) && wnext + rank < wend) {
-                const int p = wnext + rank;
-                C.p = p;
-                const int rem = rem0 - p;
-                C.res2 = 0; C.resq = 0;
-                bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
-                if (ok) {
-                    const int pl = p + B_HIST;
-                    const int l0 = (int)slink[pl];                           // hashHead (:782)
-                    const int basem = p >= sw ? basem_hi : basem_lo;
-                    const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem; // strstart - hashHead <= MAX_DIST (:788)
-                    const int c = pl - l0;
-                    ok = c >= firstmin;
-                    if (ok) {
-                        C.cl = c;
-                        C.mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem; // curMatch > limit (:609)
-                        C.cap = rem < MAX_MATCH ? rem : MAX_MATCH;
-                        C.nice = rem < P.nice ? rem : P.nice;
-                        C.best = 2; C.left = P.max_chain - 1;
-                        C.pb = ((uint32_t)sdata8[pl + 2] << 8) | sdata8[pl + 1];
-                        C.off = 0;
-                        toverify = true;
-                    }
-                }
-                if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
-            }
-            v |= __ballot(toverify);
-            wnext = wnext + ni < wend ? wnext + ni : wend;
-        };
-
-        for (;;) {
-            fetch(A, qA, vA, dA);
-            fetch(B, qB, vB, dB);
-            // once every position of the window is handed out, only the walks that must finish before the move keep the wave here
-            const uint64_t oldA = exhausted ? __ballot(A.p < must_finish) : ~0ull, oldB = exhausted ? __ballot(B.p < must_finish) : ~0ull;
-            if ((((qA | vA) & oldA) | ((qB | vB) & oldB)) == 0) { if (exhausted) break; else continue; }
-            const uint32_t busy_exit = exhausted ? 0u : (uint32_t)(128 - fth);
-        uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
-        uint64_t mA, mB, sc, cm, sv;
-        uint32_t n0, n1, n2;
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n"
-            "10:\n\t"                                           // ---- census
-            "s_or_b64 %[sc], %[qA], %[vA]\n\t"
-            "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
-            "s_and_b64 %[cm], %[sc], %[oA]\n\t"
-            "s_or_b64 %[sc], %[qB], %[vB]\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
-            "s_and_b64 %[sc], %[sc], %[oB]\n\t"
-            "s_or_b64 %[cm], %[cm], %[sc]\n\t"
-            "s_cmp_eq_u64 %[cm], 0\n\t"                        // no walk left that must finish before the window moves
-            "s_cbranch_scc1 19f\n\t"
-            "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
-            "s_cmp_le_u32 %[n0], %[bexit]\n\t"
-            "s_cbranch_scc1 19f\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
-            "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
-            "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
-            "s_cmp_ge_u32 %[n1], %[vth]\n\t"
-            "s_cbranch_scc1 14f\n\t"
-            "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
-            "s_cbranch_scc1 14f\n"
-            // ---- QUICK phase
-            "s_mov_b64 %[mA], %[qA]\n\t"
-            "s_mov_b64 %[mB], %[qB]\n"
-            "11:\n\t"
-            "s_mov_b64 exec, %[mA]\n\t"
-            SZL_Q_ISSUE(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            SZL_Q_ISSUE(B)
-            "s_mov_b64 exec, %[mA]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            SZL_Q_FINISH(A)
-            SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
-            "s_mov_b64 exec, %[mB]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            SZL_Q_FINISH(B)
-            SZL_Q_ISSUE(B)
-            "s_mov_b64 exec, %[mA]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            SZL_Q_FINISH_LAST(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_Q_FINISH_LAST(B)
-            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-            "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
-            "s_cbranch_scc1 11b\n\t"
-            SZL_Q_CLASSIFY(A)
-            SZL_Q_CLASSIFY(B)
-            "s_branch 10b\n"
-            // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
-            // side's instructions are issued)
-            "14:\n\t"
-            "s_mov_b64 %[mA], %[vA]\n\t"
-            "s_mov_b64 %[mB], %[vB]\n\t"
-            "s_cmp_eq_u64 %[vB], 0\n\t"
-            "s_cbranch_scc1 16f\n\t"
-            "s_cmp_eq_u64 %[vA], 0\n\t"
-            "s_cbranch_scc1 17f\n"
-            "15:\n\t"
-            "s_mov_b64 exec, %[mA]\n\t"
-            SZL_V_ISSUE(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            SZL_V_ISSUE(B)
-            "s_mov_b64 exec, %[mA]\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            SZL_V_FINISH(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_V_FINISH(B)
-            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-            "s_cbranch_scc1 15b\n\t"
-            SZL_V_COMPLETE(A)
-            SZL_V_COMPLETE(B)
-            "s_branch 10b\n"
-            "16:\n\t"                                          // only context A has candidates to compare
-            "s_mov_b64 exec, %[mA]\n\t"
-            SZL_V_ISSUE(A)
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_V_FINISH(A)
-            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-            "s_cbranch_scc1 16b\n\t"
-            SZL_V_COMPLETE(A)
-            "s_branch 10b\n"
-            "17:\n\t"                                          // only context B
-            "s_mov_b64 exec, %[mB]\n\t"
-            SZL_V_ISSUE(B)
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_V_FINISH(B)
-            "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
-            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-            "s_cbranch_scc1 17b\n\t"
-            SZL_V_COMPLETE(B)
-            "s_branch 10b\n"
-            "19:\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
-              [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
-              [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
-              [res2B] "+&v"(B.res2), [resqB] "+&v"(B.resq),
-              [qA] "+&s"(qA), [vA] "+&s"(vA), [dA] "+&s"(dA), [qB] "+&s"(qB), [vB] "+&s"(vB), [dB] "+&s"(dB),
-              [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A),
-              [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B),
-              [mA] "=&s"(mA), [mB] "=&s"(mB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2)
-            : [minclA] "v"(A.mincl), [capA] "v"(A.cap), [niceA] "v"(A.nice), [minclB] "v"(B.mincl), [capB] "v"(B.cap), [niceB] "v"(B.nice),
-              [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(pbase), [dbm1] "s"(dbase - 1u), [pbm1] "s"(pbase - 1u), [bhist] "s"(bhist), [snap] "s"(SNAPLEFT),
-              [bexit] "s"(busy_exit), [oA] "s"(oldA), [oB] "s"(oldB), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep)
-            : "vcc", "scc", "memory");
-        }
-        if (last_win) break;
-        // ---- move the window: every walk that reads below tile index SZ7_SHIFT is over in this wave; wait for the other waves
-        __syncthreads();
-        {
-            enum : int { ND = (B2_DATA_BYTES - SZ7_SHIFT) / 16, NL = (B2_LINKS - SZ7_SHIFT) * 2 / 16, NPER = (ND + NL + B2_THREADS - 1) / B2_THREADS };
-            static_assert((B2_DATA_BYTES - SZ7_SHIFT) % 16 == 0 && ((B2_LINKS - SZ7_SHIFT) * 2) % 16 == 0 && B2_DATA_BYTES % 16 == 0 && (B2_LINKS * 2) % 16 == 0, "16-byte moves");
-            // (one uint4 view of both arrays: the links start at entry LB; every thread moves NPER entries through registers)
-            enum : int { LB = B2_DATA_BYTES / 16, LASTSRC = LB + B2_LINKS * 2 / 16 - 1 };
-            uint4 *s4 = (uint4 *)smem;
-            static_assert(NPER <= 9, "the move below is written out for nine entries per thread");
-            auto src_of = [&](int k) { const int idx = (int)threadIdx.x + k * B2_THREADS;
-                                       const int src = idx < ND ? idx + SZ7_SHIFT / 16 : idx - ND + LB + SZ7_SHIFT * 2 / 16; return src < LASTSRC ? src : LASTSRC; };
-            auto put = [&](int k, const uint4 &v) { const int idx = (int)threadIdx.x + k * B2_THREADS;
-                                                    if (idx < ND + NL) s4[idx < ND ? idx : idx - ND + LB] = v; };
-            const uint4 r0 = s4[src_of(0)], r1 = s4[src_of(1)], r2 = s4[src_of(2)], r3 = s4[src_of(3)], r4 = s4[src_of(4)], r5 = s4[src_of(5)], r6 = s4[src_of(6)],
-                        r7 = s4[src_of(7)], r8 = s4[src_of(8)];
-            __syncthreads();
-            put(0, r0); put(1, r1); put(2, r2); put(3, r3); put(4, r4); put(5, r5); put(6, r6); put(7, r7); put(8, r8);
-        }
-        t0 += SZ7_SHIFT;
-        A.p -= SZ7_SHIFT; A.cl -= SZ7_SHIFT; A.mincl -= SZ7_SHIFT;
-        B.p -= SZ7_SHIFT; B.cl -= SZ7_SHIFT; B.mincl -= SZ7_SHIFT;
-        b7_stage(sdata32, slink, d, lk, t0 - B_HIST, seg_end, stripe_end, (B2_DATA_BYTES - SZ7_SHIFT) / 4, (B2_LINKS - SZ7_SHIFT) / 2);
-        if (threadIdx.x == 0) *s_counter = B_TILE - SZ7_SHIFT;          // the positions below were handed out before the move
-        __syncthreads();
-    }
-}
-
-
 // ---- k_match8: the same engine fed from a RING ----------------------------------------------------------------------------------
-// What k_match7 showed (profiles/r02/lab_s47_*, lab_s48_*): moving the window costs as much as a new tile — ~20 us per move however
-// far it moves — because a move is a barrier, and a wave that waits at a barrier has its walks paused while its free lanes cannot
-// be refilled.  Here nothing stops: bytes and links live in a ring of R8_W positions (ring address = position mod R8_W), waves take
+// A tile costs k_match4 ~67 us beyond its walks (profiles/r02/lab_s46_tile_length.log: 52.5 / 69.8 / 101.7 ms per GiB with 16 / 8 / 4 Ki
+// tiles): it stages 48 Ki positions to search 16 Ki, and it ends with the workgroup waiting for its longest walks with most lanes
+// idle.  A first attempt kept the window and moved it along a stripe behind a barrier, walks in flight moving with it (k_match7, in
+// the history; lab_s47_*, lab_s48_*): a move cost as much as a new tile — ~20 us however far it moved — because a wave that waits
+// at a barrier has its walks paused while its free lanes cannot be refilled.  Here nothing stops: bytes and links live in a ring of R8_W positions (ring address = position mod R8_W), waves take
 // slices of positions from one counter as long as the ring holds their lookahead, and whichever wave finds the ring running low
 // stages the next R8_C positions over the oldest ones — allowed as soon as no walk can still reach them, which the waves publish as
 // their lowest position in flight.  Ring addresses cost the chain step three more VALU instructions (the hop wraps; the limit
 // test becomes a test of the accumulated distance), and save the distance computation when a match is recorded.
+// Measured (lab_s49_ring_k_match8.log): bit-exact, 55.0 ms per GiB against k_match4's 53.0.  The loop counters say why: 43 % of the
+// engine calls run without positions to hand out and staging is refused 19 times per chunk staged — the ring holds 32.5 Ki positions
+// of history plus 20 Ki, and the slowest walk in flight (a full chain: ~100 us, 12 Ki positions of progress for the workgroup) pins
+// its history, so the lead the ring can build is what a tile had.  The limit is LDS per workgroup, not the tiling.  Lab form
+// (SZL_MATCH_KERNEL=4), kept because it removes the 3x staging traffic (9.6 -> 3.3 GB per GiB) should that ever matter.
 enum : int { R8_W = 53248, R8_C = 2048, R8_NCH = R8_W / R8_C, R8_PAD = 288, R8_H = 32768 };
 enum : int { R8_LINK_OFF = R8_W + R8_PAD, R8_CTL_OFF = R8_LINK_OFF + R8_W * 2, R8_LDS_BYTES = R8_CTL_OFF + 128 };
 static_assert(R8_W % R8_C == 0 && R8_LINK_OFF % 16 == 0 && R8_LDS_BYTES <= 160 * 1024 && R8_H >= B_HIST && R8_PAD >= B_TAIL + 16, "ring layout");
@@ -1312,46 +1033,27 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     return hipGetLastError();
 }
 
-// stripes: TileDev entries whose len may exceed B_TILE (the engine cuts them)
-hipError_t launch_match_slide(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
-                              unsigned long long *dbg, hipStream_t st) {
+// stripes: TileDev entries of any length (the engine cuts them)
+hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
+                             unsigned long long *dbg, hipStream_t st) {
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2), slice = knob("SZL_SLICE", 128);
     if (lds_attr_needed2(attr_mask, attr_bit)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_match7<12288>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match7<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match7<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match7<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_match8, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
-    if (knob("SZL_MATCH_KERNEL", 2) == 5) {
-        static std::atomic<uint64_t> attr_mask8{0};
-        uint64_t bit8 = 0;
-        if (lds_attr_needed2(attr_mask8, bit8)) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_match8, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
-            if (e != hipSuccess) return e;
-            attr_mask8.fetch_or(bit8, std::memory_order_release);
-        }
-        int lowwater = knob("SZL_LOWWATER", 6144);
-        lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
-        if (slice > 1024) slice = 1024;
-        if (nstripes > 0)
-            hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, knob("SZL_DEBUG", 0) ? dbg : nullptr);
-        return hipGetLastError();
-    }
-    const int shift = knob("SZL_SHIFT", 12288);   // positions the window moves at a time
     fth = fth < 1 ? 1 : (fth > 128 ? 128 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; vkeep = vkeep < 1 ? 1 : vkeep;
-    slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
-    if (nstripes > 0) {
-        const dim3 g(nstripes), b(B2_THREADS);
-        if (shift >= 12288) hipLaunchKernelGGL(k_match7<12288>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
-        else if (shift >= 8192) hipLaunchKernelGGL(k_match7<8192>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
-        else if (shift >= 4096) hipLaunchKernelGGL(k_match7<4096>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
-        else hipLaunchKernelGGL(k_match7<2048>, g, b, B2_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice);
-    }
+    slice = slice < 64 ? 64 : (slice > 1024 ? 1024 : slice);
+    int lowwater = knob("SZL_LOWWATER", 6144);
+    lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
+    if (nstripes > 0)
+        hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater,
+                           knob("SZL_DEBUG", 0) ? dbg : nullptr);
     return hipGetLastError();
 }
+
+int match2_tile() { return B2_TILE; }
 
 } // namespace szl

@@ -1,0 +1,96 @@
+"""The forms of the full stage-B search must all produce the reference's match tables, i.e. the oracle's bytes:
+  * k_match4 with its own tile length (default; the tile is as long as LDS allows, longer than the tiles of the on-demand form),
+  * chain compression (SZL_MATCH_KERNEL=3, lab: k_links4t + k_match6 — four-byte sub-chains, hop counts charged to max_chain),
+  * the ring-fed engine (SZL_MATCH_KERNEL=4, lab: k_match8 — positions and links in a ring, staged chunk by chunk while walks run).
+Reference: FindLongestMatch, C/DeflaterEngine.cs:474-612."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from sharpziplib_amd import corpus as C
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [b"SZL_MATCH_KERNEL", b"SZL_STRIPE_MIN", b"SZL_STRIPE_KIB", b"SZL_TILE_LEN", b"SZL_WINDOW_KIB", b"SZL_WINDOW_FROM_KIB"]
+
+
+@pytest.fixture()
+def knobs():
+    from sharpziplib_amd import _lib
+    L = _lib.lib()
+
+    def set_(**kv):
+        for k, v in kv.items():
+            L.szl_debug_set(k.encode(), int(v))
+    yield set_
+    for k in KNOBS:
+        L.szl_debug_set(k, -2147483648)       # forget
+
+
+def _streams():
+    rng = np.random.default_rng(23)
+    return [C.generate("enwik", 0xE9, 0, 1500000), C.generate("logs", 0x106, 0, 900000), C.generate("dickens", 0xD1CE, 0, 700000),
+            C.four_symbol(300000), C.period10(200000), C.zeros(150000), C.random_bytes(120000, seed=3), C.mixed(1200000, seed=5),
+            np.repeat(rng.integers(0, 256, 4000).astype(np.uint8), rng.integers(1, 90, 4000)), np.zeros(0, np.uint8), C.random_bytes(5, seed=1)]
+
+
+@pytest.mark.parametrize("form", ["tiles", "chain", "ring", "ring_long_stripes"])
+@pytest.mark.parametrize("level", [5, 6, 9])
+def test_full_search_forms_are_bit_exact(knobs, form, level):
+    from sharpziplib_amd.batch import Engine
+    if form == "chain":
+        knobs(SZL_MATCH_KERNEL=3)                       # (levels above 6 — max_chain > 128 — fall back to k_match4 by design)
+    elif form == "ring":
+        knobs(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=64)
+    elif form == "ring_long_stripes":
+        knobs(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=4096)
+    data = _streams()
+    eng = Engine()
+    try:
+        eng.debug_match_mode(0)                         # the full search, whatever the pilot would choose
+        res = eng.deflate(data, level=level)
+        for d, r in zip(data, res):
+            assert r.status == 0 and r.data == O.deflate(d, level), (form, level, d.size)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("form", ["tiles", "chain", "ring"])
+def test_full_search_forms_in_the_window_pipeline(knobs, form):
+    """a long stream goes through stage B window by window: links of a window start at its first position"""
+    from sharpziplib_amd.batch import Engine
+    knobs(SZL_WINDOW_KIB=192, SZL_WINDOW_FROM_KIB=0)
+    if form == "chain":
+        knobs(SZL_MATCH_KERNEL=3)
+    elif form == "ring":
+        knobs(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=128)
+    data = C.generate("enwik", 5, 0, 2200000)
+    eng = Engine()
+    try:
+        eng.debug_match_mode(0)
+        for level in (6, 5):
+            r = eng.deflate([data], level=level)[0]
+            assert r.status == 0 and r.data == O.deflate(data, level), (form, level)
+    finally:
+        eng.close()
+
+
+def test_streaming_deflater_through_the_lab_forms(knobs):
+    """segments with history (the streaming object's calls): candidates reach into bytes of earlier calls"""
+    import io
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.streams import DeflaterOutputStream
+    data = C.generate("enwik", 11, 0, 700000)
+    ref, tin, tout = O.stream_deflate(data, 6, True, chunk=150000, flush_every=None)
+    for kernel in (3, 4):
+        knobs(SZL_MATCH_KERNEL=kernel, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=64)
+        d = Deflater(6, True)
+        ms = io.BytesIO()
+        s = DeflaterOutputStream(ms, d, 4096)
+        s.IsStreamOwner = False
+        for pos in range(0, data.size, 150000):
+            c = data[pos:pos + 150000]
+            s.Write(c, 0, c.size)
+        s.Finish()
+        assert ms.getvalue() == ref, kernel
+        assert d.TotalIn == tin and d.TotalOut == tout
