@@ -1,4 +1,5 @@
-// szl_kernels_match3.hip — stage B with chain compression (k_links4 + k_match6); selected with SZL_MATCH_KERNEL=3.
+// szl_kernels_match3.hip — stage B with chain compression (k_links4t + k_match6).  A LAB FORM, selected with SZL_MATCH_KERNEL=3 for
+// levels 5-6: bit-exact (tests/test_gpu_stage_b_forms.py), but slower than k_match4 — see "Measured" below and DESIGN §4.2.
 //
 // Reference being restated: FindLongestMatch, C/DeflaterEngine.cs:474-612 — same M2 / Mq tables as k_match4.
 //
@@ -12,7 +13,10 @@
 // with the same three bytes (e3: distance and chain index per position, found by k_links4 on its way); the sub-chain is entered
 // at e3 if e3 is its first element, else from the position itself.  oracle/szl_model.c::flm_walk_k7 is this control flow on the
 // CPU, checked against the plain walk on every data class.  34.1 -> 16.4 candidates per position on text.
-// Price: a fourth byte per position in LDS, i.e. 8 KiB tiles (twice the staging of k_match4's 16 KiB tiles).
+// Price: a fourth byte per position in LDS, i.e. 8 Ki tiles where k_match4 has 21 Ki.
+// Measured (profiles/r02/lab_s45_chain_compression_k_match6.log, 256 MiB of text, level 6): k_match6 58.7 ms per GiB + k_links4t 35 ms,
+// against 53 ms for k_match4 with 16 Ki tiles.  Half the candidates is not half the time: a tile costs ~67 us beyond its walks
+// (lab_s46_tile_length.log) and there are twice as many, and fetch / first compare / result stores per position stay.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
