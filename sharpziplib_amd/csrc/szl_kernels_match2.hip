@@ -170,6 +170,130 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
     "s_or_b64 %[q" #X "], %[q" #X "], exec\n\t" \
     "s_mov_b64 %[v" #X "], %[m" #X "]\n\t"
 
+// The engine's instruction text, shared by k_match4 (plain and with lab counters) and k_match8.  QFIN / QFINL / VCOMP name the
+// QUICK-step and COMPLETE macros of the kernel (window indices or ring addresses); KQ / KV / KC are empty or the lab counters.
+#define SZL_ENGINE_TEXT(QFIN, QFINL, VCOMP, KQ, KV, KC) \
+    "s_mov_b64 %[sv], exec\n" \
+    "10:\n\t"                                           /* ---- census */ \
+    "s_or_b64 %[sc], %[qA], %[vA]\n\t" \
+    "s_bcnt1_i32_b64 %[n0], %[sc]\n\t" \
+    "s_or_b64 %[sc], %[qB], %[vB]\n\t" \
+    "s_bcnt1_i32_b64 %[n1], %[sc]\n\t" \
+    "s_add_u32 %[n0], %[n0], %[n1]\n\t"               /* busy contexts */ \
+    "s_cmp_le_u32 %[n0], %[bexit]\n\t" \
+    "s_cbranch_scc1 19f\n\t" \
+    "s_bcnt1_i32_b64 %[n1], %[vA]\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[vB]\n\t" \
+    "s_add_u32 %[n1], %[n1], %[n2]\n\t"               /* contexts waiting for VERIFY */ \
+    "s_cmp_ge_u32 %[n1], %[vth]\n\t" \
+    "s_cbranch_scc1 14f\n\t" \
+    "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    /* nothing in QUICK */ \
+    "s_cbranch_scc1 14f\n" \
+    /* ---- QUICK phase */ \
+    "s_mov_b64 %[mA], %[qA]\n\t" \
+    "s_mov_b64 %[mB], %[qB]\n" \
+    "11:\n\t" \
+    KQ \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    SZL_Q_ISSUE(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    SZL_Q_ISSUE(B) \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    QFIN(A) \
+    SZL_Q_ISSUE(A)                               /* A's next step is in flight while B finishes */ \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    QFIN(B) \
+    SZL_Q_ISSUE(B) \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    QFINL(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    QFINL(B) \
+    "s_bcnt1_i32_b64 %[n0], %[mA]\n\t" \
+    "s_bcnt1_i32_b64 %[n1], %[mB]\n\t" \
+    "s_add_u32 %[n0], %[n0], %[n1]\n\t" \
+    "s_cmp_ge_u32 %[n0], %[qkeep]\n\t" \
+    "s_cbranch_scc1 11b\n\t" \
+    SZL_Q_CLASSIFY(A) \
+    SZL_Q_CLASSIFY(B) \
+    "s_branch 10b\n" \
+    /* ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other side's */ \
+    /* instructions are issued) */ \
+    "14:\n\t" \
+    "s_mov_b64 %[mA], %[vA]\n\t" \
+    "s_mov_b64 %[mB], %[vB]\n\t" \
+    "s_cmp_eq_u64 %[vB], 0\n\t" \
+    "s_cbranch_scc1 16f\n\t" \
+    "s_cmp_eq_u64 %[vA], 0\n\t" \
+    "s_cbranch_scc1 17f\n" \
+    "15:\n\t" \
+    KV \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    SZL_V_ISSUE(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    SZL_V_ISSUE(B) \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    "s_waitcnt lgkmcnt(6)\n\t" \
+    SZL_V_FINISH(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL_V_FINISH(B) \
+    "s_bcnt1_i32_b64 %[n0], %[mA]\n\t" \
+    "s_bcnt1_i32_b64 %[n1], %[mB]\n\t" \
+    "s_add_u32 %[n0], %[n0], %[n1]\n\t" \
+    "s_cmp_ge_u32 %[n0], %[vkeep]\n\t" \
+    "s_cbranch_scc1 15b\n\t" \
+    KC \
+    VCOMP(A) \
+    VCOMP(B) \
+    "s_branch 10b\n" \
+    "16:\n\t"                                          /* only context A has candidates to compare */ \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    SZL_V_ISSUE(A) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL_V_FINISH(A) \
+    "s_bcnt1_i32_b64 %[n0], %[mA]\n\t" \
+    "s_cmp_ge_u32 %[n0], %[vkeep]\n\t" \
+    "s_cbranch_scc1 16b\n\t" \
+    VCOMP(A) \
+    "s_branch 10b\n" \
+    "17:\n\t"                                          /* only context B */ \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    SZL_V_ISSUE(B) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL_V_FINISH(B) \
+    "s_bcnt1_i32_b64 %[n0], %[mB]\n\t" \
+    "s_cmp_ge_u32 %[n0], %[vkeep]\n\t" \
+    "s_cbranch_scc1 17b\n\t" \
+    VCOMP(B) \
+    "s_branch 10b\n" \
+    "19:\n\t" \
+    "s_mov_b64 exec, %[sv]\n\t"
+// lab counters of the phases: loop iterations and the contexts that took part
+#define SZL_ENGINE_KQ \
+    "s_add_u32 %[kq], %[kq], 1\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[mA]\n\t" \
+    "s_add_u32 %[kql], %[kql], %[n2]\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[mB]\n\t" \
+    "s_add_u32 %[kql], %[kql], %[n2]\n\t"
+#define SZL_ENGINE_KV \
+    "s_add_u32 %[kv], %[kv], 1\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[mA]\n\t" \
+    "s_add_u32 %[kvl], %[kvl], %[n2]\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[mB]\n\t" \
+    "s_add_u32 %[kvl], %[kvl], %[n2]\n\t"
+#define SZL_ENGINE_KC \
+    "s_add_u32 %[kc], %[kc], 1\n\t" \
+    "s_andn2_b64 %[cm], %[vA], %[mA]\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[cm]\n\t" \
+    "s_add_u32 %[kcl], %[kcl], %[n2]\n\t" \
+    "s_andn2_b64 %[cm], %[vB], %[mB]\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[cm]\n\t" \
+    "s_add_u32 %[kcl], %[kcl], %[n2]\n\t"
+
 struct WalkCtx {      // one FindLongestMatch walk in flight (all of it in registers)
     int p;            // tile position being searched
     int cl;           // LDS data index of the current candidate (curMatch)
@@ -333,119 +457,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
             uint64_t mA, mB, sc, cm, sv;
             uint32_t n0, n1, n2;
             asm volatile(
-                "s_mov_b64 %[sv], exec\n"
-                "10:\n\t"                                           // ---- census
-                "s_or_b64 %[sc], %[qA], %[vA]\n\t"
-                "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
-                "s_or_b64 %[sc], %[qB], %[vB]\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
-                "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
-                "s_cmp_le_u32 %[n0], %[bexit]\n\t"
-                "s_cbranch_scc1 19f\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
-                "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
-                "s_cmp_ge_u32 %[n1], %[vth]\n\t"
-                "s_cbranch_scc1 14f\n\t"
-                "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
-                "s_cbranch_scc1 14f\n"
-                // ---- QUICK phase
-                "s_mov_b64 %[mA], %[qA]\n\t"
-                "s_mov_b64 %[mB], %[qB]\n"
-                "11:\n\t"
-                "s_add_u32 %[kq], %[kq], 1\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[mA]\n\t"
-                "s_add_u32 %[kql], %[kql], %[n2]\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
-                "s_add_u32 %[kql], %[kql], %[n2]\n\t"
-                "s_mov_b64 exec, %[mA]\n\t"
-                SZL_Q_ISSUE(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                SZL_Q_ISSUE(B)
-                "s_mov_b64 exec, %[mA]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH(A)
-                SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
-                "s_mov_b64 exec, %[mB]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH(B)
-                SZL_Q_ISSUE(B)
-                "s_mov_b64 exec, %[mA]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH_LAST(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_Q_FINISH_LAST(B)
-                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-                "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-                "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
-                "s_cbranch_scc1 11b\n\t"
-                SZL_Q_CLASSIFY(A)
-                SZL_Q_CLASSIFY(B)
-                "s_branch 10b\n"
-                // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
-                // side's instructions are issued)
-                "14:\n\t"
-                "s_mov_b64 %[mA], %[vA]\n\t"
-                "s_mov_b64 %[mB], %[vB]\n\t"
-                "s_cmp_eq_u64 %[vB], 0\n\t"
-                "s_cbranch_scc1 16f\n\t"
-                "s_cmp_eq_u64 %[vA], 0\n\t"
-                "s_cbranch_scc1 17f\n"
-                "15:\n\t"
-                "s_add_u32 %[kv], %[kv], 1\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[mA]\n\t"
-                "s_add_u32 %[kvl], %[kvl], %[n2]\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
-                "s_add_u32 %[kvl], %[kvl], %[n2]\n\t"
-                "s_mov_b64 exec, %[mA]\n\t"
-                SZL_V_ISSUE(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                SZL_V_ISSUE(B)
-                "s_mov_b64 exec, %[mA]\n\t"
-                "s_waitcnt lgkmcnt(6)\n\t"
-                SZL_V_FINISH(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_V_FINISH(B)
-                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-                "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-                "s_cbranch_scc1 15b\n\t"
-                "s_add_u32 %[kc], %[kc], 1\n\t"
-                "s_andn2_b64 %[cm], %[vA], %[mA]\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[cm]\n\t"
-                "s_add_u32 %[kcl], %[kcl], %[n2]\n\t"
-                "s_andn2_b64 %[cm], %[vB], %[mB]\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[cm]\n\t"
-                "s_add_u32 %[kcl], %[kcl], %[n2]\n\t"
-                SZL_V_COMPLETE(A)
-                SZL_V_COMPLETE(B)
-                "s_branch 10b\n"
-                "16:\n\t"                                          // only context A has candidates to compare
-                "s_mov_b64 exec, %[mA]\n\t"
-                SZL_V_ISSUE(A)
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_V_FINISH(A)
-                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-                "s_cbranch_scc1 16b\n\t"
-                SZL_V_COMPLETE(A)
-                "s_branch 10b\n"
-                "17:\n\t"                                          // only context B
-                "s_mov_b64 exec, %[mB]\n\t"
-                SZL_V_ISSUE(B)
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_V_FINISH(B)
-                "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
-                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-                "s_cbranch_scc1 17b\n\t"
-                SZL_V_COMPLETE(B)
-                "s_branch 10b\n"
-                "19:\n\t"
-                "s_mov_b64 exec, %[sv]\n\t"
+                SZL_ENGINE_TEXT(SZL_Q_FINISH, SZL_Q_FINISH_LAST, SZL_V_COMPLETE, SZL_ENGINE_KQ, SZL_ENGINE_KV, SZL_ENGINE_KC)
                 : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
                   [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
                   [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
@@ -465,102 +477,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict
             uint64_t mA, mB, sc, cm, sv;
             uint32_t n0, n1, n2;
             asm volatile(
-                "s_mov_b64 %[sv], exec\n"
-                "10:\n\t"                                           // ---- census
-                "s_or_b64 %[sc], %[qA], %[vA]\n\t"
-                "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
-                "s_or_b64 %[sc], %[qB], %[vB]\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
-                "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
-                "s_cmp_le_u32 %[n0], %[bexit]\n\t"
-                "s_cbranch_scc1 19f\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
-                "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
-                "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
-                "s_cmp_ge_u32 %[n1], %[vth]\n\t"
-                "s_cbranch_scc1 14f\n\t"
-                "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
-                "s_cbranch_scc1 14f\n"
-                // ---- QUICK phase
-                "s_mov_b64 %[mA], %[qA]\n\t"
-                "s_mov_b64 %[mB], %[qB]\n"
-                "11:\n\t"
-                "s_mov_b64 exec, %[mA]\n\t"
-                SZL_Q_ISSUE(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                SZL_Q_ISSUE(B)
-                "s_mov_b64 exec, %[mA]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH(A)
-                SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
-                "s_mov_b64 exec, %[mB]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH(B)
-                SZL_Q_ISSUE(B)
-                "s_mov_b64 exec, %[mA]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                SZL_Q_FINISH_LAST(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_Q_FINISH_LAST(B)
-                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-                "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-                "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
-                "s_cbranch_scc1 11b\n\t"
-                SZL_Q_CLASSIFY(A)
-                SZL_Q_CLASSIFY(B)
-                "s_branch 10b\n"
-                // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
-                // side's instructions are issued)
-                "14:\n\t"
-                "s_mov_b64 %[mA], %[vA]\n\t"
-                "s_mov_b64 %[mB], %[vB]\n\t"
-                "s_cmp_eq_u64 %[vB], 0\n\t"
-                "s_cbranch_scc1 16f\n\t"
-                "s_cmp_eq_u64 %[vA], 0\n\t"
-                "s_cbranch_scc1 17f\n"
-                "15:\n\t"
-                "s_mov_b64 exec, %[mA]\n\t"
-                SZL_V_ISSUE(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                SZL_V_ISSUE(B)
-                "s_mov_b64 exec, %[mA]\n\t"
-                "s_waitcnt lgkmcnt(6)\n\t"
-                SZL_V_FINISH(A)
-                "s_mov_b64 exec, %[mB]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_V_FINISH(B)
-                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-                "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-                "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-                "s_cbranch_scc1 15b\n\t"
-                SZL_V_COMPLETE(A)
-                SZL_V_COMPLETE(B)
-                "s_branch 10b\n"
-                "16:\n\t"                                          // only context A has candidates to compare
-                "s_mov_b64 exec, %[mA]\n\t"
-                SZL_V_ISSUE(A)
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_V_FINISH(A)
-                "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-                "s_cbranch_scc1 16b\n\t"
-                SZL_V_COMPLETE(A)
-                "s_branch 10b\n"
-                "17:\n\t"                                          // only context B
-                "s_mov_b64 exec, %[mB]\n\t"
-                SZL_V_ISSUE(B)
-                "s_waitcnt lgkmcnt(0)\n\t"
-                SZL_V_FINISH(B)
-                "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
-                "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-                "s_cbranch_scc1 17b\n\t"
-                SZL_V_COMPLETE(B)
-                "s_branch 10b\n"
-                "19:\n\t"
-                "s_mov_b64 exec, %[sv]\n\t"
+                SZL_ENGINE_TEXT(SZL_Q_FINISH, SZL_Q_FINISH_LAST, SZL_V_COMPLETE, "", "", "")
                 : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
                   [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
                   [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
@@ -879,102 +796,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
         uint64_t mA, mB, sc, cm, sv;
         uint32_t n0, n1, n2;
         asm volatile(
-            "s_mov_b64 %[sv], exec\n"
-            "10:\n\t"                                           // ---- census
-            "s_or_b64 %[sc], %[qA], %[vA]\n\t"
-            "s_bcnt1_i32_b64 %[n0], %[sc]\n\t"
-            "s_or_b64 %[sc], %[qB], %[vB]\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[sc]\n\t"
-            "s_add_u32 %[n0], %[n0], %[n1]\n\t"               // busy contexts
-            "s_cmp_le_u32 %[n0], %[bexit]\n\t"
-            "s_cbranch_scc1 19f\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[vA]\n\t"
-            "s_bcnt1_i32_b64 %[n2], %[vB]\n\t"
-            "s_add_u32 %[n1], %[n1], %[n2]\n\t"               // contexts waiting for VERIFY
-            "s_cmp_ge_u32 %[n1], %[vth]\n\t"
-            "s_cbranch_scc1 14f\n\t"
-            "s_cmp_eq_u32 %[n0], %[n1]\n\t"                    // nothing in QUICK
-            "s_cbranch_scc1 14f\n"
-            // ---- QUICK phase
-            "s_mov_b64 %[mA], %[qA]\n\t"
-            "s_mov_b64 %[mB], %[qB]\n"
-            "11:\n\t"
-            "s_mov_b64 exec, %[mA]\n\t"
-            SZL_Q_ISSUE(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            SZL_Q_ISSUE(B)
-            "s_mov_b64 exec, %[mA]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            SZL8_Q_FINISH(A)
-            SZL_Q_ISSUE(A)                               // A's next step is in flight while B finishes
-            "s_mov_b64 exec, %[mB]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            SZL8_Q_FINISH(B)
-            SZL_Q_ISSUE(B)
-            "s_mov_b64 exec, %[mA]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            SZL8_Q_FINISH_LAST(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL8_Q_FINISH_LAST(B)
-            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-            "s_cmp_ge_u32 %[n0], %[qkeep]\n\t"
-            "s_cbranch_scc1 11b\n\t"
-            SZL_Q_CLASSIFY(A)
-            SZL_Q_CLASSIFY(B)
-            "s_branch 10b\n"
-            // ---- VERIFY phase (with VERIFY running as soon as two contexts wait, one side is often empty: then only the other
-            // side's instructions are issued)
-            "14:\n\t"
-            "s_mov_b64 %[mA], %[vA]\n\t"
-            "s_mov_b64 %[mB], %[vB]\n\t"
-            "s_cmp_eq_u64 %[vB], 0\n\t"
-            "s_cbranch_scc1 16f\n\t"
-            "s_cmp_eq_u64 %[vA], 0\n\t"
-            "s_cbranch_scc1 17f\n"
-            "15:\n\t"
-            "s_mov_b64 exec, %[mA]\n\t"
-            SZL_V_ISSUE(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            SZL_V_ISSUE(B)
-            "s_mov_b64 exec, %[mA]\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            SZL_V_FINISH(A)
-            "s_mov_b64 exec, %[mB]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_V_FINISH(B)
-            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-            "s_bcnt1_i32_b64 %[n1], %[mB]\n\t"
-            "s_add_u32 %[n0], %[n0], %[n1]\n\t"
-            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-            "s_cbranch_scc1 15b\n\t"
-            SZL8_V_COMPLETE(A)
-            SZL8_V_COMPLETE(B)
-            "s_branch 10b\n"
-            "16:\n\t"                                          // only context A has candidates to compare
-            "s_mov_b64 exec, %[mA]\n\t"
-            SZL_V_ISSUE(A)
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_V_FINISH(A)
-            "s_bcnt1_i32_b64 %[n0], %[mA]\n\t"
-            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-            "s_cbranch_scc1 16b\n\t"
-            SZL8_V_COMPLETE(A)
-            "s_branch 10b\n"
-            "17:\n\t"                                          // only context B
-            "s_mov_b64 exec, %[mB]\n\t"
-            SZL_V_ISSUE(B)
-            "s_waitcnt lgkmcnt(0)\n\t"
-            SZL_V_FINISH(B)
-            "s_bcnt1_i32_b64 %[n0], %[mB]\n\t"
-            "s_cmp_ge_u32 %[n0], %[vkeep]\n\t"
-            "s_cbranch_scc1 17b\n\t"
-            SZL8_V_COMPLETE(B)
-            "s_branch 10b\n"
-            "19:\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
+            SZL_ENGINE_TEXT(SZL8_Q_FINISH, SZL8_Q_FINISH_LAST, SZL8_V_COMPLETE, "", "", "")
             : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [distA] "+&v"(A.dist), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
               [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
               [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [distB] "+&v"(B.dist), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
