@@ -338,166 +338,12 @@ __device__ __forceinline__ void b2_stage_window(uint32_t *sdata32, uint16_t *sli
     }
 }
 
-template <bool DBG>
-__global__ __launch_bounds__(B2_THREADS) void k_match4(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
-                                                       const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
-                                                       MTab mtab, LevelParams P, unsigned long long *dbg, int fth, int vth, int qkeep, int vkeep, int slice) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const TileDev tile = tiles[blockIdx.x];
-    const SegDev seg = segs[tile.seg];
-    uint32_t *sdata32 = (uint32_t *)smem;                          // B2_DATA_BYTES
-    uint16_t *slink = (uint16_t *)(smem + B2_DATA_BYTES);          // B2_LINKS entries
-    int *s_counter = (int *)(smem + B2_DATA_BYTES + B2_LINKS * 2);
-    const uint8_t *d = in + seg.buf_off;
-    const uint16_t *lk = link + seg.buf_off;
-    uint32_t *__restrict__ mt2 = mtab.m2 + seg.buf_off;
-    uint32_t *__restrict__ mtq = mtab.mq + seg.buf_off;
-    const int64_t t0 = tile.start;
-    const int tlen = tile.len;
-    const int64_t dlo = t0 - B_HIST; // buffer position of LDS data byte 0 (may be negative)
-    const int64_t seg_end = seg.look_end; // lookahead end
-
-    b2_stage_window(sdata32, slink, d, lk, dlo, seg_end, t0, tlen);
-    if (threadIdx.x == 0) *s_counter = 0;
-    __syncthreads();
-    if (DBG && fth < 0) { // timing experiment (lab only): staging + one coalesced pass of result stores, no search
-        for (int i = threadIdx.x; i < tlen; i += B2_THREADS) { mt2[t0 + i] = sdata32[i & 1023] == 0xDEADBEEFu && slink[i] == 0x1234 ? 3u : 0u; mtq[t0 + i] = 0; }
-        return;
-    }
-
-    const uint8_t *sdata8 = smem;
-    // LDS byte offsets of the two arrays for the hand-written loops
-    const uint32_t dbase = (uint32_t)(uintptr_t)(lds_u8 *)smem;
-    const uint32_t lbase = dbase + (uint32_t)B2_DATA_BYTES;
-    const uint32_t pbase = dbase + (uint32_t)B_HIST;
-
-    const int64_t base_lo = base_of2((int64_t)seg.abs0 + t0), base_hi = base_of2((int64_t)seg.abs0 + t0 + tlen - 1);
-    const int64_t sw64 = base_lo == base_hi ? (int64_t)1 << 30 : (base_lo + 65273) - (int64_t)seg.abs0 - t0; // first tile position on base_hi
-    const int sw = sw64 > (int64_t)B2_TILE ? B2_TILE : (int)sw64;
-    const int basem_lo = (int)(base_lo - (int64_t)seg.abs0 - dlo), basem_hi = (int)(base_hi - (int64_t)seg.abs0 - dlo);
-    // lookahead at tile position 0, clamped (only its value below 258 matters): rem(p) = rem0 - p
-    const int64_t rem0_64 = seg_end - t0;
-    const int rem0 = rem0_64 > (int64_t)(1 << 24) ? (1 << 24) : (int)rem0_64;
-    const int lane = threadIdx.x & 63;
-    const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // The quarter-budget walk (:495) has seen a candidate iff the reference's chainLength was > max_chain - (max_chain >> 2)
-    // when it was examined, i.e. left >= that value (left = chainLength - 1).
-    const int SNAPLEFT = P.max_chain - (P.max_chain >> 2);
-    const int bhist = B_HIST;
-    int wnext = 0, wend = 0;       // wave-uniform slice of tile positions being handed out
-    bool exhausted = false;
-
-    WalkCtx A, B;
-    A.p = 0; A.cl = B_HIST; A.best = 2; A.left = 0; A.off = 0; A.mincl = 0; A.cap = MAX_MATCH; A.nice = P.nice; A.pb = 0; A.res2 = 0; A.resq = 0;
-    B = A;
-    uint64_t qA = 0, vA = 0, dA = 0, qB = 0, vB = 0, dB = 0;   // state masks (wave-uniform)
-    unsigned long long c_fvis = 0, c_flanes = 0, c_eng = 0, c_kq = 0, c_kql = 0, c_kv = 0, c_kvl = 0, c_kc = 0, c_kcl = 0;
-
-    // FETCH for one context: retire its finished walks, start new ones on its free lanes
-    auto fetch = [&](WalkCtx &C, uint64_t &q, uint64_t &v, uint64_t &dm) {
-        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; }
-        dm = 0;
-        if (exhausted) return;
-        const uint64_t idle = ~(q | v);
-        const int ni = __builtin_popcountll(idle);
-        if (ni == 0) return;
-        if (wnext >= wend) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(s_counter, slice);
-            base = __builtin_amdgcn_readfirstlane(base);
-            wnext = base < tlen ? base : tlen;
-            wend = base + slice < tlen ? base + slice : tlen;
-            if (wnext >= wend) { exhausted = true; return; }
-        }
-        const int rank = __builtin_popcountll(idle & lanemask_lt);
-        if (DBG) { c_fvis++; c_flanes += (wend - wnext) < ni ? (wend - wnext) : ni; }
-        bool toverify = false;
-        if (__builtin_amdgcn_inverse_ballot_w64(idle) && wnext + rank < wend) {
-            const int p = wnext + rank;
-            C.p = p;
-            const int rem = rem0 - p;                                   // lookahead (clamped high)
-            C.res2 = 0; C.resq = 0;
-            bool ok = rem >= MIN_MATCH && P.strategy != 2;              // :780, HuffmanOnly :786
-            if (ok) {
-                const int pl = p + B_HIST;
-                const int l0 = (int)slink[pl];                           // hashHead (:782)
-                const int basem = p >= sw ? basem_hi : basem_lo;        // LDS index of window index 1 (entries below were clamped by a slide, :450-461)
-                const int firstmin = pl - MAX_DIST > basem ? pl - MAX_DIST : basem; // first candidate: strstart - hashHead <= MAX_DIST (:788)
-                const int c = pl - l0;
-                ok = c >= firstmin;                                      // l0 == 0xFFFF (none) fails this too
-                if (ok) {
-                    C.cl = c;
-                    C.mincl = pl - (MAX_DIST - 1) > basem ? pl - (MAX_DIST - 1) : basem; // chain: curMatch > limit (:609)
-                    C.cap = rem < MAX_MATCH ? rem : MAX_MATCH;            // scanMax :479
-                    C.nice = rem < P.nice ? rem : P.nice;                 // :485
-                    C.best = 2; C.left = P.max_chain - 1;
-                    C.pb = ((uint32_t)sdata8[pl + 2] << 8) | sdata8[pl + 1];   // scan_end, scan_end1 for best_len 2
-                    // the first candidate shares the position's 3-byte hash, so the scan_end test at offset 2 (:505) all but
-                    // always passes: compare it right away instead of spending a chain step on that test
-                    C.off = 0;
-                    toverify = true;
-                }
-            }
-            if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
-        }
-        v |= __ballot(toverify);
-        wnext = wnext + ni < wend ? wnext + ni : wend;
-    };
-
-    for (;;) {
-        fetch(A, qA, vA, dA);
-        fetch(B, qB, vB, dB);
-        if ((qA | vA | qB | vB) == 0) { if (exhausted) break; else continue; }
-        // run until at least `fth` contexts are free again (after the last batch: until all of them are)
-        const uint32_t busy_exit = exhausted ? 0u : (uint32_t)(128 - fth);
-        if (DBG) c_eng++;
-        if (DBG) {   // the same engine with per-phase counters (lab)
-            uint32_t kq = 0, kql = 0, kv = 0, kvl = 0, kc = 0, kcl = 0;
-            uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
-            uint64_t mA, mB, sc, cm, sv;
-            uint32_t n0, n1, n2;
-            asm volatile(
-                SZL_ENGINE_TEXT(SZL_Q_FINISH, SZL_Q_FINISH_LAST, SZL_V_COMPLETE, SZL_ENGINE_KQ, SZL_ENGINE_KV, SZL_ENGINE_KC)
-                : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
-                  [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
-                  [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
-                  [res2B] "+&v"(B.res2), [resqB] "+&v"(B.resq),
-                  [qA] "+&s"(qA), [vA] "+&s"(vA), [dA] "+&s"(dA), [qB] "+&s"(qB), [vB] "+&s"(vB), [dB] "+&s"(dB),
-                  [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A),
-                  [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B),
-                  [mA] "=&s"(mA), [mB] "=&s"(mB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2),
-                  [kq] "+&s"(kq), [kql] "+&s"(kql), [kv] "+&s"(kv), [kvl] "+&s"(kvl), [kc] "+&s"(kc), [kcl] "+&s"(kcl)
-                : [minclA] "v"(A.mincl), [capA] "v"(A.cap), [niceA] "v"(A.nice), [minclB] "v"(B.mincl), [capB] "v"(B.cap), [niceB] "v"(B.nice),
-                  [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(pbase), [dbm1] "s"(dbase - 1u), [pbm1] "s"(pbase - 1u), [bhist] "s"(bhist), [snap] "s"(SNAPLEFT),
-                  [bexit] "s"(busy_exit), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep)
-                : "vcc", "scc", "memory");
-            c_kq += kq; c_kql += kql; c_kv += kv; c_kvl += kvl; c_kc += kc; c_kcl += kcl;
-        } else {
-            uint32_t t0A, t1A, t2A, t3A, t4A, t5A, t6A, t7A, t0B, t1B, t2B, t3B, t4B, t5B, t6B, t7B;
-            uint64_t mA, mB, sc, cm, sv;
-            uint32_t n0, n1, n2;
-            asm volatile(
-                SZL_ENGINE_TEXT(SZL_Q_FINISH, SZL_Q_FINISH_LAST, SZL_V_COMPLETE, "", "", "")
-                : [pA] "+&v"(A.p), [clA] "+&v"(A.cl), [bestA] "+&v"(A.best), [leftA] "+&v"(A.left), [offA] "+&v"(A.off), [pbA] "+&v"(A.pb),
-                  [res2A] "+&v"(A.res2), [resqA] "+&v"(A.resq),
-                  [pB] "+&v"(B.p), [clB] "+&v"(B.cl), [bestB] "+&v"(B.best), [leftB] "+&v"(B.left), [offB] "+&v"(B.off), [pbB] "+&v"(B.pb),
-                  [res2B] "+&v"(B.res2), [resqB] "+&v"(B.resq),
-                  [qA] "+&s"(qA), [vA] "+&s"(vA), [dA] "+&s"(dA), [qB] "+&s"(qB), [vB] "+&s"(vB), [dB] "+&s"(dB),
-                  [t0A] "=&v"(t0A), [t1A] "=&v"(t1A), [t2A] "=&v"(t2A), [t3A] "=&v"(t3A), [t4A] "=&v"(t4A), [t5A] "=&v"(t5A), [t6A] "=&v"(t6A), [t7A] "=&v"(t7A),
-                  [t0B] "=&v"(t0B), [t1B] "=&v"(t1B), [t2B] "=&v"(t2B), [t3B] "=&v"(t3B), [t4B] "=&v"(t4B), [t5B] "=&v"(t5B), [t6B] "=&v"(t6B), [t7B] "=&v"(t7B),
-                  [mA] "=&s"(mA), [mB] "=&s"(mB), [sc] "=&s"(sc), [cm] "=&s"(cm), [sv] "=&s"(sv), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2)
-                : [minclA] "v"(A.mincl), [capA] "v"(A.cap), [niceA] "v"(A.nice), [minclB] "v"(B.mincl), [capB] "v"(B.cap), [niceB] "v"(B.nice),
-                  [lbase] "s"(lbase), [dbase] "s"(dbase), [pbase] "s"(pbase), [dbm1] "s"(dbase - 1u), [pbm1] "s"(pbase - 1u), [bhist] "s"(bhist), [snap] "s"(SNAPLEFT),
-                  [bexit] "s"(busy_exit), [vth] "s"(vth), [qkeep] "s"(qkeep), [vkeep] "s"(vkeep)
-                : "vcc", "scc", "memory");
-        }
-    }
-    if (DBG && dbg && lane == 0) {
-        atomicAdd(dbg + 14, c_fvis); atomicAdd(dbg + 15, c_flanes); atomicAdd(dbg + 8, c_eng);
-        atomicAdd(dbg + 16, c_kq); atomicAdd(dbg + 17, c_kql); atomicAdd(dbg + 18, c_kv); atomicAdd(dbg + 19, c_kvl); atomicAdd(dbg + 20, c_kc); atomicAdd(dbg + 21, c_kcl);
-    }
-}
-
+#define SZL_M4_ORD 0
+#include "szl_match4_body.inc"
+#undef SZL_M4_ORD
+#define SZL_M4_ORD 1
+#include "szl_match4_body.inc"
+#undef SZL_M4_ORD
 
 // ---- k_match8: the same engine fed from a RING ----------------------------------------------------------------------------------
 // A tile costs k_match4 ~67 us beyond its walks (profiles/r02/lab_s46_tile_length.log: 52.5 / 69.8 / 101.7 ms per GiB with 16 / 8 / 4 Ki
@@ -847,6 +693,18 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     if (vkeep < 1) vkeep = 1;
     int slice = knob("SZL_SLICE", 128);   // tile positions a wavefront takes from the tile counter at a time (512: 63.5, 128: 61.6 ms per GiB — a shorter tail per tile)
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
+    if (ntiles > 0 && knob("SZL_ORDERED", 0) == 1 && !want_dbg) {   // (lab: two-pass order of a tile's positions; not yet run on a device)
+        static std::atomic<uint64_t> attr_mask_o{0};
+        uint64_t bit_o = 0;
+        if (lds_attr_needed2(attr_mask_o, bit_o)) {
+            hipError_t e = attr((const void *)k_match4o);
+            if (e != hipSuccess) return e;
+            attr_mask_o.fetch_or(bit_o, std::memory_order_release);
+        }
+        int order_th = knob("SZL_ORDER_TH", 4096);
+        hipLaunchKernelGGL(k_match4o, dim3(ntiles), dim3(B2_THREADS), B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, fth, vth, qkeep, vkeep, slice, order_th);
+        return hipGetLastError();
+    }
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B2_THREADS);
         if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
