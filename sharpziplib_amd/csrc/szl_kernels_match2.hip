@@ -307,9 +307,10 @@ struct WalkCtx {      // one FindLongestMatch walk in flight (all of it in regis
 };
 
 // Stage the window of one tile into LDS: the bytes of history + tile + lookahead tail, and the links of history + tile.
+// (NT: threads of the workgroup; the lab kernels can be launched with fewer than B2_THREADS and pass blockDim.x)
 __device__ __forceinline__ void b2_stage_window(uint32_t *sdata32, uint16_t *slink, const uint8_t *d, const uint16_t *lk, int64_t dlo,
-                                                int64_t seg_end, int64_t t0, int tlen) {
-    for (int i = threadIdx.x; i < B2_DATA_BYTES / 4; i += B2_THREADS) {
+                                                int64_t seg_end, int64_t t0, int tlen, const int NT = B2_THREADS) {
+    for (int i = threadIdx.x; i < B2_DATA_BYTES / 4; i += NT) {
         int64_t pos = dlo + 4 * (int64_t)i;
         uint32_t w = 0;
         if (pos >= 0 && pos + 4 <= seg_end) w = load_u32_unaligned2(d + pos);
@@ -321,7 +322,7 @@ __device__ __forceinline__ void b2_stage_window(uint32_t *sdata32, uint16_t *sli
         }
         sdata32[i] = w;
     }
-    for (int i = threadIdx.x; i < B2_LINKS / 2; i += B2_THREADS) {
+    for (int i = threadIdx.x; i < B2_LINKS / 2; i += NT) {
         int64_t pos = dlo + 2 * (int64_t)i;
         uint32_t w = 0;
         if (pos >= 0 && pos + 2 <= t0 + tlen) {
@@ -488,9 +489,9 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     {
         const int n0 = NC < R8_NCH ? NC : (int)R8_NCH;
-        for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, B2_THREADS);
+        for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, (int)blockDim.x);
         if (threadIdx.x == 0) { ctl[R8_COUNTER] = R8_H; ctl[R8_STAGED] = n0; ctl[R8_LOCK] = 0; }
-        if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = R8_H;
+        if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = threadIdx.x < (blockDim.x >> 6) ? (int)R8_H : 0x7FFFFFFF;   // (SZL_RING_WAVES: fewer waves)
     }
     __syncthreads();
 
@@ -702,7 +703,9 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
             attr_mask_o.fetch_or(bit_o, std::memory_order_release);
         }
         int order_th = knob("SZL_ORDER_TH", 4096);
-        hipLaunchKernelGGL(k_match4o, dim3(ntiles), dim3(B2_THREADS), B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, fth, vth, qkeep, vkeep, slice, order_th);
+        int waves = knob("SZL_M4_WAVES", 16);   // (lab)
+        waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+        hipLaunchKernelGGL(k_match4o, dim3(ntiles), dim3(64 * waves), B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, fth, vth, qkeep, vkeep, slice, order_th);
         return hipGetLastError();
     }
     if (ntiles > 0) {
@@ -728,8 +731,10 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
     slice = slice < 64 ? 64 : (slice > 1024 ? 1024 : slice);
     int lowwater = knob("SZL_LOWWATER", 6144);
     lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
+    int waves = knob("SZL_RING_WAVES", 16);   // (lab: fewer walks in flight end sooner and pin the ring's history for a shorter time)
+    waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
     if (nstripes > 0)
-        hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater,
+        hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(64 * waves), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater,
                            knob("SZL_DEBUG", 0) ? dbg : nullptr);
     return hipGetLastError();
 }
