@@ -468,6 +468,8 @@ __device__ __forceinline__ void r8_stage_chunk(uint8_t *smem, const uint8_t *d, 
     }
 }
 
+// FLEX: launched with fewer than B2_THREADS threads (lab, SZL_RING_WAVES); the 16-wave form keeps its constants
+template <bool FLEX>
 __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                        const TileDev *__restrict__ stripes, const uint16_t *__restrict__ link,
                                                        MTab mtab, LevelParams P, int fth, int vth, int qkeep, int vkeep, int slice, int lowwater, unsigned long long *dbg) {
@@ -489,9 +491,11 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     {
         const int n0 = NC < R8_NCH ? NC : (int)R8_NCH;
-        for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, (int)blockDim.x);
+        if (FLEX) for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, (int)blockDim.x);
+        else for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, B2_THREADS);
         if (threadIdx.x == 0) { ctl[R8_COUNTER] = R8_H; ctl[R8_STAGED] = n0; ctl[R8_LOCK] = 0; }
-        if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = threadIdx.x < (blockDim.x >> 6) ? (int)R8_H : 0x7FFFFFFF;   // (SZL_RING_WAVES: fewer waves)
+        if (FLEX) { if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = threadIdx.x < (blockDim.x >> 6) ? (int)R8_H : 0x7FFFFFFF; }   // (waves that do not exist hold nothing back)
+        else if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = R8_H;
     }
     __syncthreads();
 
@@ -723,7 +727,8 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
     uint64_t attr_bit = 0;
     int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2), slice = knob("SZL_SLICE", 128);
     if (lds_attr_needed2(attr_mask, attr_bit)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_match8, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_match8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
@@ -733,9 +738,11 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
     lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
     int waves = knob("SZL_RING_WAVES", 16);   // (lab: fewer walks in flight end sooner and pin the ring's history for a shorter time)
     waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
-    if (nstripes > 0)
-        hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(64 * waves), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater,
-                           knob("SZL_DEBUG", 0) ? dbg : nullptr);
+    unsigned long long *dbg8 = knob("SZL_DEBUG", 0) ? dbg : nullptr;
+    if (nstripes > 0 && waves == 16)
+        hipLaunchKernelGGL(k_match8<false>, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, dbg8);
+    else if (nstripes > 0)
+        hipLaunchKernelGGL(k_match8<true>, dim3(nstripes), dim3(64 * waves), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, dbg8);
     return hipGetLastError();
 }
 
