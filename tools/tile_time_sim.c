@@ -23,7 +23,7 @@ typedef struct { int mode, p, cl, best, left, off; } Ctx;
 
 static uint8_t *d; static uint16_t *lk; static size_t n;
 static int max_chain = 128, nice = 128;
-static int RING = 0, SPAN = 18400, TILE = 16384, ORDER = 0, TH = 4096, FTH = 32, VTH = 2, QKEEP = 64, VKEEP = 2, SLICE = 128, QKEEP_TAIL = -1;
+static int QSTEPS = 3, RING = 0, SPAN = 18400, TILE = 16384, ORDER = 0, TH = 4096, FTH = 32, VTH = 2, QKEEP = 64, VKEEP = 2, SLICE = 128, QKEEP_TAIL = -1;
 /* issue cost / latency of the engine's steps, in cycles */
 static double C_CENSUS = 40, C_QITER = 190, L_QITER = 360, C_CLASSIFY = 50, C_VITER = 150, L_VITER = 140, C_COMPLETE = 210, L_COMPLETE = 240,
               C_FETCH = 330, L_FETCH = 420, C_FETCH_ORD = 130, C_STAGE_US = 21, SCALE = 1.0, GHZ = 2.4;
@@ -87,7 +87,7 @@ int main(int argc, char **argv) {
         char *eq = strchr(argv[i], '='); if (!eq) continue; *eq = 0;
         double v = atof(eq + 1); const char *k = argv[i];
 #define P(name, var) if (!strcmp(k, name)) { var = v; continue; }
-        P("WAVES", WAVES) P("RING", RING) P("SPAN", SPAN) P("TILE", TILE) P("ORDER", ORDER) P("TH", TH) P("FTH", FTH) P("VTH", VTH) P("QKEEP", QKEEP) P("VKEEP", VKEEP) P("SLICE", SLICE) P("QKEEP_TAIL", QKEEP_TAIL)
+        P("QSTEPS", QSTEPS) P("WAVES", WAVES) P("RING", RING) P("SPAN", SPAN) P("TILE", TILE) P("ORDER", ORDER) P("TH", TH) P("FTH", FTH) P("VTH", VTH) P("QKEEP", QKEEP) P("VKEEP", VKEEP) P("SLICE", SLICE) P("QKEEP_TAIL", QKEEP_TAIL)
         P("CHAIN", max_chain) P("NICE", nice) P("SCALE", SCALE) P("C_QITER", C_QITER) P("L_QITER", L_QITER) P("C_VITER", C_VITER) P("L_VITER", L_VITER)
         P("C_COMPLETE", C_COMPLETE) P("L_COMPLETE", L_COMPLETE) P("C_FETCH", C_FETCH) P("L_FETCH", L_FETCH) P("C_CENSUS", C_CENSUS) P("C_FETCH_ORD", C_FETCH_ORD)
         fprintf(stderr, "unknown key %s\n", k); return 2;
@@ -168,8 +168,8 @@ int main(int argc, char **argv) {
             } else {
                 int qk = X->exhausted && QKEEP_TAIL >= 0 ? QKEEP_TAIL : QKEEP;
                 for (;;) {
-                    for (int s = 0; s < 3; s++) for (int i = 0; i < NCTX; i++) if (X->c[i].mode == QUICK) { quick_step(&X->c[i]); steps_q++; }
-                    cost += C_QITER; lat += L_QITER;
+                    for (int s = 0; s < QSTEPS; s++) for (int i = 0; i < NCTX; i++) if (X->c[i].mode == QUICK) { quick_step(&X->c[i]); steps_q++; }
+                    cost += 16 + (C_QITER - 16) * QSTEPS / 3.0; lat += L_QITER * QSTEPS / 3.0;   /* (a fixed loop overhead + per-step instructions) */
                     int still = 0;
                     for (int i = 0; i < NCTX; i++) still += X->c[i].mode == QUICK;
                     if (still < qk || still == 0) break;
