@@ -24,11 +24,33 @@ int match3_tile();
 hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
                              unsigned long long *dbg, hipStream_t st);
 int match2_tile();
+// SZL_MATCH_KERNEL=5: the full search in bucket order (szl_kernels_match5.hip): tiles of up to match5_tile() positions, a scratch slot per resident workgroup
+hipError_t launch_match5(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const TileDev *tiles, int ntiles,
+                         MTab mtab, LevelParams P, uint8_t *scratch, int nslots, unsigned long long *dbg, hipStream_t st);
+size_t match5_scratch_bytes(int nslots);
+int match5_tile();
+static int match5_slots() {   // one workgroup per CU is resident (its LDS): one scratch slot per CU
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+}
+// which form of the full search a call uses: SZL_MATCH_KERNEL, with 5 (bucket order) only where it applies — DeflateSlow with a chain budget
+// of 4 or more, and no history whose insertions a DeflateFast level decided (`hist_flags`: only the link pass knows those)
+static int match_form(const LevelParams &P, bool hist_flags) {
+    const int which = knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT);
+    if (which == 5 && (P.fast || P.strategy == 2 || P.max_chain < 4 || hist_flags)) return 2;
+    return which;
+}
 // The full search of stage B has a work list of its own: k_match4 (SZL_MATCH_KERNEL=2, the default) takes tiles as long as its LDS window
 // allows — longer than the B_TILE the other forms of stage B are built for; the ring form (=4, lab) takes stripes of any length.
 // `emit` = positions searched, `tile_len` = what the call's size made of B_TILE.  0: use the common tile list.
-static int64_t full_search_len(uint64_t emit, int64_t tile_len) {
-    const int which = knob("SZL_MATCH_KERNEL", 2);
+static int64_t full_search_len(uint64_t emit, int64_t tile_len, int which) {
+    if (which == 5) {
+        int64_t len = match5_tile();
+        if (knob("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+        while (len > 8192 && emit / (uint64_t)len < 128) len >>= 1;     // a small call gets shorter tiles: more workgroups (a tile's sort has a fixed cost: not below 8 Ki)
+        return len;
+    }
     if (which == 2) {
         int64_t len = match2_tile();
         if (knob("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
@@ -42,7 +64,7 @@ static int64_t full_search_len(uint64_t emit, int64_t tile_len) {
     while (len > B_TILE && emit / (uint64_t)len < min_stripes) len >>= 1;
     return len;
 }
-static bool use_match3(const LevelParams &P) { return knob("SZL_MATCH_KERNEL", 2) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
+static bool use_match3(const LevelParams &P) { return knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
 void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
                             hipStream_t st);
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
@@ -194,7 +216,9 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     int64_t tile_len = m3 ? match3_tile() : B_TILE;
     if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
     while (tile_len > 2048 && total_emit / (uint64_t)tile_len < 128) tile_len >>= 1;
-    const int64_t stripe_len = (!P.fast && !m3) ? full_search_len(total_emit, tile_len) : 0;
+    const bool hist_flags = !P.fast && !fast_hist_in.empty() && nseg == 1 && segs[0].seg_start > 0;
+    const int form = match_form(P, hist_flags);
+    const int64_t stripe_len = (!P.fast && !m3) ? full_search_len(total_emit, tile_len, form) : 0;
     std::vector<SpanDev> spans;
     std::vector<TileDev> tiles, stripes;
     std::vector<uint64_t> chunk_off(nseg + 1), zero_off(nseg + 1);
@@ -237,7 +261,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
             // (tiles: equal parts, so that a 64 KiB entry is 4 x 16384 and not 3 x 21504 + 1024 — a sliver still costs a tile's fixed
             // time: 50000 such entries 212.6 -> 174.9 ms in stage B, profiles/r02/config3_tile_balance.log)
             int64_t part = stripe_len;
-            if (part && knob("SZL_MATCH_KERNEL", 2) == 2 && s.seg_end > s.seg_start) {
+            if (part && (form == 2 || form == 5) && s.seg_end > s.seg_start) {
                 const int64_t nt = (s.seg_end - s.seg_start + part - 1) / part;
                 part = std::min<int64_t>(part, ((s.seg_end - s.seg_start + nt - 1) / nt + 63) & ~(int64_t)63);
             }
@@ -406,7 +430,12 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         mt3.e3d = (const uint16_t *)e3dist.p; mt3.e3h = (const uint8_t *)e3hops.p;
         HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt3, P, dcnt, st));
     } else if (!lazy && own_list) {
-        if (knob("SZL_MATCH_KERNEL", 2) == 4) HIPCHK(launch_match_ring(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+        if (form == 4) HIPCHK(launch_match_ring(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+        else if (form == 5) {
+            const int nslots = match5_slots();
+            if ((rc = m5_scratch.ensure(match5_scratch_bytes(nslots)))) return rc;
+            HIPCHK(launch_match5(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const TileDev *)d_stripes.p, (int)stripes.size(), mt, P, (uint8_t *)m5_scratch.p, nslots, dcnt, st));
+        }
         else HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
     }
     else if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
@@ -494,7 +523,20 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (knob("SZL_DEBUG", 0) && hc[22])   // k_match8 (ring): per-wave loop statistics
         fprintf(stderr, "[szl] match8: engine calls %llu (busy contexts at entry %.1f) | starving %llu | chunks staged %llu, staging refused %llu, lock busy %llu | idle sleeps %llu\n",
                 hc[22], (double)hc[28] / hc[22], hc[23], hc[27], hc[24], hc[25], hc[26]);
-    if (knob("SZL_DEBUG", 0) && hc[16]) { // k_match4 (two-context engine): loop iterations of each phase and the contexts (of 128) that took part
+    if (knob("SZL_DEBUG", 0) && hc[31])   // k_match5 (bucket order): lockstep wave-steps and the lanes that took part
+        fprintf(stderr, "[szl] k_match5: %.2f candidates per position, %.1f %% of the lane-steps do work, %.3f byte comparisons and %.3f best_len updates per position\n",
+                (double)hc[30] / (double)seg_bytes, 100.0 * (double)hc[30] / (64.0 * (double)hc[31]), (double)hc[29] / (double)seg_bytes, (double)hc[28] / (double)seg_bytes);
+    if (knob("SZL_DEBUG", 0) && hc[31]) { // (wall_clock64 runs at 100 MHz)
+        const double tot = (double)(hc[9] + hc[10] + hc[11] + hc[12] + hc[13]);
+        fprintf(stderr, "[szl] k_match5 phases (share of the workgroups' time): clear+histogram %.1f %%, scan %.1f %%, scatter %.1f %%, window bytes %.1f %%, search %.1f %%\n",
+                100.0 * hc[9] / tot, 100.0 * hc[10] / tot, 100.0 * hc[11] / tot, 100.0 * hc[12] / tot, 100.0 * hc[13] / tot);
+    }
+    if (knob("SZL_DEBUG", 0) && hc[31]) {
+        const double tot = (double)(hc[17] + hc[18] + hc[19] + hc[20] + hc[21]);
+        fprintf(stderr, "[szl] k_match5 search (share of the waves' cycles): slice setup + staging %.1f %%, candidate counts %.1f %%, pass 1 %.1f %%, pass 2 %.1f %%, settle + store + restage %.1f %%\n",
+                100.0 * hc[17] / tot, 100.0 * hc[18] / tot, 100.0 * hc[19] / tot, 100.0 * hc[20] / tot, 100.0 * hc[21] / tot);
+    }
+    if (knob("SZL_DEBUG", 0) && hc[16] && !hc[31]) { // k_match4 (two-context engine): loop iterations of each phase and the contexts (of 128) that took part
         const double np = (double)seg_bytes;
         fprintf(stderr, "[szl] match4: engine calls %llu | fetch visits %llu lanes/visit %.1f | QUICK iterations %llu contexts/iter %.1f (x2 steps) | VERIFY iterations %llu contexts/iter %.1f | "
                         "COMPLETE passes %llu contexts/pass %.1f | per position: quick ctx-steps %.2f verify ctx-steps %.2f completes %.2f\n",
@@ -633,7 +675,8 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         for (int64_t a = e; a < wend; a += tile_len) tiles.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(tile_len, wend - a), 0});
         const uint64_t ntiles = tiles.size();
         std::vector<TileDev> stripes;
-        const int64_t stripe_len = m3 ? 0 : full_search_len((uint64_t)(wend - e), tile_len);
+        const int form = match_form(P, false);
+        const int64_t stripe_len = m3 ? 0 : full_search_len((uint64_t)(wend - e), tile_len, form);
         for (int64_t a = e; stripe_len && a < wend; a += stripe_len) stripes.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(stripe_len, wend - a), 0});
         if (!stripes.empty() && (rc = upload(d_stripes, stripes, st))) return rc;
         // side arrays of this window, addressed with the stream's own indices (pointer minus the window's first index)
@@ -678,7 +721,12 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
                 launch_links4(d_in, lk, (int64_t)seg.buf_off + lo, (int64_t)seg.buf_off + wend, (int64_t)seg.buf_off + N, l4, s4, ed, eh, st);
                 mtw.link4 = l4; mtw.skip4 = s4; mtw.e3d = ed; mtw.e3h = eh;
             }
-            if (!stripes.empty() && knob("SZL_MATCH_KERNEL", 2) == 4) HIPCHK(launch_match_ring(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
+            if (!stripes.empty() && form == 4) HIPCHK(launch_match_ring(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
+            else if (!stripes.empty() && form == 5) {
+                const int nslots = match5_slots();
+                if ((rc = m5_scratch.ensure(match5_scratch_bytes(nslots)))) return rc;
+                HIPCHK(launch_match5(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const TileDev *)d_stripes.p, (int)stripes.size(), mtw, P, (uint8_t *)m5_scratch.p, nslots, dcnt, st));
+            }
             else if (!stripes.empty()) HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
             else HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mtw, P, dcnt, st));
             if (!last) HIPCHK(hipMemsetAsync((uint32_t *)mtab.p + wn, 0xFF, (size_t)(hi - wend) * 4, st)); // the tail past the parse end: evaluated on demand

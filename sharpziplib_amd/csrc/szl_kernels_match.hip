@@ -1006,7 +1006,7 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
     // SZL_MATCH_KERNEL: 4 = ring-fed engine (lab; launch_match_ring, the engine calls it), 3 = chain compression (lab; szl_kernels_match3.hip,
     // the engine passes the four-byte links in mtab), 2 = two positions in flight per lane (szl_kernels_match2.hip, default), 1 = k_match below
-    const int which = knob("SZL_MATCH_KERNEL", 2);
+    const int which = knob("SZL_MATCH_KERNEL", 2);   // (5, the bucket-order form, has its own launch: what reaches this one with 5 set is work it does not take)
     if (mtab.link4) return launch_match3(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // the engine set the call up for k_match6
     if (which >= 2) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
