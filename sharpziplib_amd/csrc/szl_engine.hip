@@ -528,13 +528,15 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
                 (double)hc[30] / (double)seg_bytes, 100.0 * (double)hc[30] / (64.0 * (double)hc[31]), (double)hc[29] / (double)seg_bytes, (double)hc[28] / (double)seg_bytes);
     if (knob("SZL_DEBUG", 0) && hc[31]) { // (wall_clock64 runs at 100 MHz)
         const double tot = (double)(hc[9] + hc[10] + hc[11] + hc[12] + hc[13]);
-        fprintf(stderr, "[szl] k_match5 phases (share of the workgroups' time): clear+histogram %.1f %%, scan %.1f %%, scatter %.1f %%, window bytes %.1f %%, search %.1f %%\n",
-                100.0 * hc[9] / tot, 100.0 * hc[10] / tot, 100.0 * hc[11] / tot, 100.0 * hc[12] / tot, 100.0 * hc[13] / tot);
+        const double u = 1e-5 / (double)match5_slots();   // ticks of 10 ns summed over the workgroups -> ms per workgroup
+        fprintf(stderr, "[szl] k_match5 phases (ms per workgroup): clear+histogram %.2f, scan %.2f, scatter %.2f, window bytes %.2f, search %.2f (sum %.2f)\n",
+                u * hc[9], u * hc[10], u * hc[11], u * hc[12], u * hc[13], u * tot);
     }
     if (knob("SZL_DEBUG", 0) && hc[31]) {
         const double tot = (double)(hc[17] + hc[18] + hc[19] + hc[20] + hc[21]);
-        fprintf(stderr, "[szl] k_match5 search (share of the waves' cycles): slice setup + staging %.1f %%, candidate counts %.1f %%, pass 1 %.1f %%, pass 2 %.1f %%, settle + store + restage %.1f %%\n",
-                100.0 * hc[17] / tot, 100.0 * hc[18] / tot, 100.0 * hc[19] / tot, 100.0 * hc[20] / tot, 100.0 * hc[21] / tot);
+        const double u = 1e-5 / (16.0 * (double)match5_slots());
+        fprintf(stderr, "[szl] k_match5 search (ms per wave): slice setup + staging %.2f, candidate counts %.2f, pass 1 %.2f, pass 2 %.2f, settle + store + restage %.2f (sum %.2f)\n",
+                u * hc[17], u * hc[18], u * hc[19], u * hc[20], u * hc[21], u * tot);
     }
     if (knob("SZL_DEBUG", 0) && hc[16] && !hc[31]) { // k_match4 (two-context engine): loop iterations of each phase and the contexts (of 128) that took part
         const double np = (double)seg_bytes;

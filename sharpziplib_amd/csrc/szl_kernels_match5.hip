@@ -43,17 +43,19 @@ int knob(const char *name, int dflt);
 enum : int { B5_THREADS = 1024, B5_WAVES = 16, B5_TMAX = 65536, B5_WMAX = B_HIST + B5_TMAX };
 // LDS.  Sort phase: the 32768 bucket counters, then (above everything the search phase touches) the bucket-start bitmap and the control
 // words.  Search phase: the window's bytes, then one private area per wavefront — 192 staged entries of S, the queue of candidates
-// that need the window's bytes (13-bit lane | step pairs) and 64 + 64 result slots.
+// that need the window's bytes (candidate position << 13 | lane << 7 | step), 64 + 64 result slots and the positions' own data.
 enum : int { B5_CNT_BYTES = 32768 * 4 };
-enum : int { B5_DATA_BYTES = (B5_WMAX + B_TAIL + 8 + 15) & ~15, B5_STG_ENTRIES = 192, B5_QCAP = 320 };
-enum : int { B5_WV_STG = 0, B5_WV_QUEUE = B5_STG_ENTRIES * 8, B5_WV_SLOT2 = B5_WV_QUEUE + B5_QCAP * 2, B5_WV_SLOTQ = B5_WV_SLOT2 + 256, B5_WV_BYTES = B5_WV_SLOTQ + 256 };
+enum : int { B5_DATA_BYTES = (B5_WMAX + B_TAIL + 8 + 15) & ~15, B5_STG_ENTRIES = 192, B5_QCAP = 192 };
+enum : int { B5_WV_STG = 0, B5_WV_QUEUE = B5_STG_ENTRIES * 8, B5_WV_SLOT2 = B5_WV_QUEUE + B5_QCAP * 4, B5_WV_SLOTQ = B5_WV_SLOT2 + 256, B5_WV_PINFO = B5_WV_SLOTQ + 256, B5_WV_BYTES = B5_WV_PINFO + 256 };
 enum : int { B5_WV_OFF = B5_DATA_BYTES, B5_BITMAP_WORDS = (B5_WMAX + 63) / 64 + 4,
               B5_BITMAP_OFF = (B5_WV_OFF + B5_WAVES * B5_WV_BYTES > B5_CNT_BYTES ? B5_WV_OFF + B5_WAVES * B5_WV_BYTES : B5_CNT_BYTES),
               B5_CTL_OFF = B5_BITMAP_OFF + B5_BITMAP_WORDS * 8, B5_LDS_BYTES = B5_CTL_OFF + 64 };
 static_assert(B5_WV_BYTES % 16 == 0 && B5_BITMAP_OFF % 8 == 0, "alignment of the per-wave areas");
 static_assert(B5_LDS_BYTES <= 160 * 1024 && B5_WMAX < (1 << 17), "window: 17-bit positions, one CU's LDS");
 enum : int { B5_CTL_TICKET = 0, B5_CTL_NS = 1, B5_CTL_SLICE = 2, B5_CTL_TILE = 3 };
-enum : size_t { B5_SLOT_BYTES = ((size_t)B5_WMAX * 8 + 4095) & ~(size_t)4095 };
+// per-workgroup scratch: S (sorted entries), RES (the results, in S order) and RANK (S index of every window position)
+enum : size_t { B5_S_BYTES = ((size_t)B5_WMAX * 8 + 4095) & ~(size_t)4095, B5_RANK_BYTES = ((size_t)B5_WMAX * 4 + 4095) & ~(size_t)4095,
+                B5_SLOT_BYTES = 2 * B5_S_BYTES + B5_RANK_BYTES };
 enum : int { B5_U = 4 };   // 64-position slices per ticket
 
 typedef __attribute__((address_space(3))) uint8_t b5_lds_u8;
@@ -62,6 +64,17 @@ __device__ __forceinline__ int64_t base_of5(int64_t s_abs) { // window base of a
     int64_t idx = s_abs + 1;
     if (idx <= 65273) return 0;
     return ((idx - 65273 + 32767) >> 15) << 15;
+}
+// maximum over the wavefront without the LDS (DPP row shifts and broadcasts); the result is wave-uniform
+__device__ __forceinline__ int wave_max_i32(int x) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); x = t > x ? t : x;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); x = t > x ? t : x;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); x = t > x ? t : x;   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); x = t > x ? t : x;   // row_shr:8  (lane 15 of every row: the row's maximum)
+    t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); x = t > x ? t : x;   // row_bcast:15 into rows 1 and 3
+    t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); x = t > x ? t : x;   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
 }
 __device__ __forceinline__ uint32_t ffbl_m1(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }   // 0xFFFFFFFF for 0
 
@@ -103,68 +116,72 @@ __device__ __forceinline__ uint2 entry_of(uint64_t w, uint32_t rel) {
     return e;
 }
 
-// The byte pass of k_match5: up to 64 queued candidates (lane of the position << 7 | step), oldest first.  All 46 content bits of
-// such a candidate agree with the position's, so their common prefix is 7 or more: test the two bytes at the position's running best
-// (scan_end / scan_end1, :505-506), compare the window's bytes from offset 7 on, and raise the position's slot with an LDS atomic
-// max — key = length (capped at niceLength) << 22 | (127 - step) << 15 | distance: the first longest candidate wins whatever the
-// order inside a batch, and a length another candidate of the SAME batch reached never hides an earlier equal one (the slot a
-// candidate is tested against only holds candidates of earlier batches, i.e. of lower steps).
-// All loads of a candidate are issued together: pair -> {position, lookahead, entry, slot} -> {filter bytes, 16 bytes of each side}.
-__device__ __noinline__ void b5_byte_pass(const uint8_t *smem, const uint2 *stg, const uint16_t *queue, uint32_t *slot2, uint32_t *slotq,
-                                          int nb, int prel, int cap, int pnice, int snapk, unsigned long long *cnt) {
+// The byte pass of k_match5: up to 64 queued candidates (window position of the candidate << 13 | lane of the position << 7 |
+// step), oldest first.  All 46 content bits of such a candidate agree with the position's, so their common prefix is 7 or more:
+// test the two bytes at the position's running best (scan_end / scan_end1, :505-506), compare the window's bytes from offset 7 on,
+// and raise the position's slot with an LDS atomic max — key = length (capped at niceLength) << 22 | (127 - step) << 15 | distance:
+// the first longest candidate wins whatever the order inside a batch, and the length a slot holds when a candidate is tested comes
+// from earlier batches only, i.e. from lower steps (a later equal candidate never hides an earlier one).
+// The LDS pipe is what this pass costs: one read for the pair, two for the position's data and slot, the two scan_end bytes of each
+// side only when the running best is 8 or more, and the bytes themselves only for the candidates that pass.
+__device__ __noinline__ void b5_byte_pass(const uint8_t *smem, const uint32_t *queue, uint32_t *slot2, uint32_t *slotq, const uint32_t *pinfo,
+                                          int nb, int pnice, int snapk, unsigned long long *cnt) {
     const int lane = threadIdx.x & 63;
     const uint8_t *sdata8 = smem;
     const uint32_t *sdata32 = (const uint32_t *)smem;
     const bool v = lane < nb;
-    const uint32_t pr = v ? (uint32_t)queue[lane] : 0u;
-    const int pl = (int)(pr >> 7), kk = (int)(pr & 127u);
-    const int pp = __builtin_amdgcn_ds_bpermute(pl << 2, prel), pc = __builtin_amdgcn_ds_bpermute(pl << 2, cap);
-    const uint32_t ey = stg[pl + 127 - kk].y, key0 = slot2[pl];
+    const uint32_t pr = v ? queue[lane] : 0u;
+    const int pl = (int)((pr >> 7) & 63u), kk = (int)(pr & 127u), crel = (int)(pr >> 13);
+    const uint32_t info = pinfo[pl], key0 = slot2[pl];
+    const int pp = (int)(info & 0x1FFFFu), pc = (int)(info >> 17);
     const int pn = pc < pnice ? pc : pnice;
-    const int crel = (int)(ey >> 15), b2 = (int)(key0 >> 22);
-    // the two scan_end bytes of both sides, and 16 bytes of both sides from offset 7 (five aligned dwords each)
-    const int fo = b2 >= 8 ? b2 : 8;
-    const uint32_t fc = ((uint32_t)sdata8[crel + fo] << 8) | sdata8[crel + fo - 1], fp = ((uint32_t)sdata8[pp + fo] << 8) | sdata8[pp + fo - 1];
-    const int ca = crel + 7, pa = pp + 7;
-    const uint32_t *cw = sdata32 + (ca >> 2), *pw = sdata32 + (pa >> 2);
-    const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
-    const uint32_t p0 = pw[0], p1 = pw[1], p2 = pw[2], p3 = pw[3], p4 = pw[4];
+    const int b2 = (int)(key0 >> 22);
     bool go = v && b2 < pn;                                  // (a position that has reached niceLength takes nothing more, :603)
-    if (b2 >= 8) go = go && fc == fp;
-    const uint32_t cs = (uint32_t)ca & 3u, ps = (uint32_t)pa & 3u;
-    const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, cs) ^ __builtin_amdgcn_alignbyte(p1, p0, ps);
-    const uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, cs) ^ __builtin_amdgcn_alignbyte(p2, p1, ps);
-    const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, cs) ^ __builtin_amdgcn_alignbyte(p3, p2, ps);
-    const uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, cs) ^ __builtin_amdgcn_alignbyte(p4, p3, ps);
-    int L;
-    if (x0) L = 7 + (int)(__builtin_ctz(x0) >> 3);
-    else if (x1) L = 11 + (int)(__builtin_ctz(x1) >> 3);
-    else if (x2) L = 15 + (int)(__builtin_ctz(x2) >> 3);
-    else if (x3) L = 19 + (int)(__builtin_ctz(x3) >> 3);
-    else L = 23;
-    if (go && L == 23) {                                     // longer than 16 bytes past offset 7: the rest in a loop (rare on text)
-        while (L < pc) {
-            const int i0 = crel + L, i1 = pp + L;
-            const uint32_t a0 = sdata32[i0 >> 2], a1 = sdata32[(i0 >> 2) + 1], q0 = sdata32[i1 >> 2], q1 = sdata32[(i1 >> 2) + 1];
-            const uint32_t x = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i0 & 3)) ^ __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)(i1 & 3));
-            if (x) { L += (int)(__builtin_ctz(x) >> 3); break; }
-            L += 4;
+    if (go && b2 >= 8) {
+        const uint32_t fc = ((uint32_t)sdata8[crel + b2] << 8) | sdata8[crel + b2 - 1], fp = ((uint32_t)sdata8[pp + b2] << 8) | sdata8[pp + b2 - 1];
+        go = fc == fp;
+    }
+    if (go) {
+        const int ca = crel + 7, pa = pp + 7;
+        const uint32_t *cw = sdata32 + (ca >> 2), *pw = sdata32 + (pa >> 2);
+        const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
+        const uint32_t p0 = pw[0], p1 = pw[1], p2 = pw[2], p3 = pw[3], p4 = pw[4];
+        const uint32_t cs = (uint32_t)ca & 3u, ps = (uint32_t)pa & 3u;
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, cs) ^ __builtin_amdgcn_alignbyte(p1, p0, ps);
+        const uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, cs) ^ __builtin_amdgcn_alignbyte(p2, p1, ps);
+        const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, cs) ^ __builtin_amdgcn_alignbyte(p3, p2, ps);
+        const uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, cs) ^ __builtin_amdgcn_alignbyte(p4, p3, ps);
+        int L;
+        if (x0) L = 7 + (int)(__builtin_ctz(x0) >> 3);
+        else if (x1) L = 11 + (int)(__builtin_ctz(x1) >> 3);
+        else if (x2) L = 15 + (int)(__builtin_ctz(x2) >> 3);
+        else if (x3) L = 19 + (int)(__builtin_ctz(x3) >> 3);
+        else {                                               // longer than 16 bytes past offset 7: the rest in a loop (rare on text)
+            L = 23;
+            while (L < pc) {
+                const int i0 = crel + L, i1 = pp + L;
+                const uint32_t a0 = sdata32[i0 >> 2], a1 = sdata32[(i0 >> 2) + 1], q0 = sdata32[i1 >> 2], q1 = sdata32[(i1 >> 2) + 1];
+                const uint32_t x = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i0 & 3)) ^ __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)(i1 & 3));
+                if (x) { L += (int)(__builtin_ctz(x) >> 3); break; }
+                L += 4;
+            }
         }
+        if (L > pc) L = pc;
+        if (L > b2) {
+            const uint32_t key = ((uint32_t)(L < pn ? L : pn) << 22) | ((uint32_t)(127 - kk) << 15) | (uint32_t)(pp - crel);
+            atomicMax(&slot2[pl], key);
+            if (kk < snapk) atomicMax(&slotq[pl], key);
+            if (cnt) cnt[1]++;
+        }
+        if (cnt) cnt[0]++;
     }
-    if (L > pc) L = pc;
-    if (go && L > b2) {
-        const uint32_t key = ((uint32_t)(L < pn ? L : pn) << 22) | ((uint32_t)(127 - kk) << 15) | (uint32_t)(pp - crel);
-        atomicMax(&slot2[pl], key);
-        if (kk < snapk) atomicMax(&slotq[pl], key);
-    }
-    if (cnt) { cnt[0] += go ? 1ull : 0ull; cnt[1] += (go && L > b2) ? 1ull : 0ull; }
 }
 
 template <bool DBG>
 __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict__ in, uint64_t in_total, const SegDev *__restrict__ segs,
                                                        const uint64_t *__restrict__ bnds, const TileDev *__restrict__ tiles, int ntiles,
                                                        MTab mtab, LevelParams P, uint8_t *__restrict__ scratch, unsigned int *__restrict__ tile_counter,
-                                                       unsigned long long *dbg) {
+                                                       unsigned long long *dbg, int lab) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *s_cnt = (uint32_t *)smem;
     unsigned long long *s_bitmap = (unsigned long long *)(smem + B5_BITMAP_OFF);
@@ -173,11 +190,13 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint2 *S = (uint2 *)(scratch + (size_t)blockIdx.x * B5_SLOT_BYTES);
+    uint2 *RES = (uint2 *)(scratch + (size_t)blockIdx.x * B5_SLOT_BYTES + B5_S_BYTES);
+    uint32_t *RANK = (uint32_t *)(scratch + (size_t)blockIdx.x * B5_SLOT_BYTES + 2 * B5_S_BYTES);
     const uint32_t cnt_a = (uint32_t)(uintptr_t)(b5_lds_u8 *)smem;
     const uint32_t turn_a = cnt_a + (uint32_t)B5_CTL_OFF + 4u * B5_CTL_TICKET;
     unsigned long long c_steps = 0, c_slots = 0, c_ext = 0, c_upd = 0, bp_cnt[2] = {0, 0};
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, wk[6] = {0, 0, 0, 0, 0, 0}, wk0 = 0;   // (lab) clock ticks per phase, thread 0 of each workgroup
-#define B5_WTICK(n) do { if (DBG) { const unsigned long long now_ = clock64(); wk[n] += now_ - wk0; wk0 = now_; } } while (0)
+#define B5_WTICK(n) do { if (DBG) { const unsigned long long now_ = wall_clock64(); wk[n] += now_ - wk0; wk0 = now_; } } while (0)
 #define B5_TICK(n) do { if (DBG && threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); tk[n] += now_ - tk0; tk0 = now_; } } while (0)
 
     for (;;) {
@@ -318,13 +337,18 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
 #pragma unroll
                 for (int u = 0; u < B5_U; u++) {
                     const uint32_t basev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lead[u] << 2), (int)old[u]);
-                    if ((m_ins[u] >> lane) & 1) S[basev + rank[u]] = ent[u];
+                    const bool insd = (m_ins[u] >> lane) & 1;
+                    if (insd) S[basev + rank[u]] = ent[u];
+                    const int rel = 64 * (B5_U * t + u) + lane;
+                    if (rel < wlen) RANK[rel] = insd ? basev + rank[u] : 0xFFFFFFFFu;   // (a position that is not inserted has no entry: empty tables, :780)
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // S is written and read by this workgroup only (one CU, one vector L1): workgroup scope.  (Agent scope writes back and invalidates
+        // the XCD's L2 — for all the workgroups that share it — once per tile: measured, it made every S read a miss.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         B5_TICK(2);
         // ---- B1: the window's bytes (+ the lookahead tail) into LDS
@@ -349,9 +373,7 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
             const uint32_t *sdata32 = (const uint32_t *)smem;
             uint8_t *wv = smem + B5_WV_OFF + wave * B5_WV_BYTES;
             uint2 *stg = (uint2 *)(wv + B5_WV_STG);
-            uint16_t *queue = (uint16_t *)(wv + B5_WV_QUEUE);
             uint32_t *slot2 = (uint32_t *)(wv + B5_WV_SLOT2), *slotq = (uint32_t *)(wv + B5_WV_SLOTQ);
-            uint32_t *mt2 = mtab.m2 + seg.buf_off + w0, *mtq = mtab.mq + seg.buf_off + w0;
             const int64_t A = (int64_t)seg.abs0 + w0;          // absolute stream position of window position 0
             const int64_t rem0 = seg.look_end - w0;             // lookahead at window position 0
             const int SNAP = P.max_chain >> 2;
@@ -378,24 +400,27 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
                 else return INT_MAX;
                 return (128 + lane) - j;
             };
+            // the entries of a slice (own + the 128 in front) are loaded one slice ahead: a global load is ~2 us away
+            auto grab = [&]() -> int {
+                int sl = 0;
+                if (lane == 0) sl = atomicAdd(&s_ctl_a[B5_CTL_SLICE], 64);
+                return __builtin_amdgcn_readfirstlane(sl);
+            };
+            auto ldS = [&](int j) -> uint2 { return (j >= 0 && j < ns) ? S[j] : make_uint2(0, 0); };
+            int nslice = grab();
+            uint2 nOwn = ldS(nslice + lane), nP0 = ldS(nslice - 128 + lane), nP1 = ldS(nslice - 64 + lane);
             for (;;) {
-                if (DBG) wk0 = clock64();
-                int slice = 0;
-                if (lane == 0) slice = atomicAdd(&s_ctl_a[B5_CTL_SLICE], 64);
-                slice = __builtin_amdgcn_readfirstlane(slice);
+                if (DBG) wk0 = wall_clock64();
+                const int slice = nslice;
                 if (slice >= ns) break;
                 const int i = slice + lane;
-                uint2 own = make_uint2(0, 0);
-                if (i < ns) own = S[i];
+                const uint2 own = nOwn, pre0 = nP0, pre1 = nP1;
+                nslice = grab();
+                nOwn = ldS(nslice + lane); nP0 = ldS(nslice - 128 + lane); nP1 = ldS(nslice - 64 + lane);
                 const int prel = (int)(own.y >> 15);
                 const bool mine = i < ns && prel >= hoff;        // this lane's entry is a position of the tile
-                if (!__any(mine)) continue;
-                {   // stage S[slice-128 .. slice+63]
-                    const int j0 = slice - 128 + lane, j1 = slice - 64 + lane;
-                    stg[lane] = j0 >= 0 ? S[j0] : make_uint2(0, 0);
-                    stg[64 + lane] = j1 >= 0 ? S[j1] : make_uint2(0, 0);
-                    stg[128 + lane] = own;
-                }
+                if (!__any(mine) || (lab & 16)) continue;
+                stg[lane] = pre0; stg[64 + lane] = pre1; stg[128 + lane] = own;   // stage S[slice-128 .. slice+63]
                 wave_sync();
                 int nav = avail_in(slice - 128);                 // candidates of my bucket in front of me (INT_MAX: 128 or more)
                 const int rem = (int)(rem0 - prel > (int64_t)(1 << 24) ? (int64_t)(1 << 24) : rem0 - prel);
@@ -425,22 +450,28 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
                         nact = lim > 128 ? 128 : lim;
                     }
                     int count = 0;
-                    {   // the staged positions descend with kk: binary search for the first one below mincl
-                        int lo = 0, hi = nact;
+                    {   // the staged positions descend with kk: how many of my nact candidates are at or above mincl?  Three rounds of
+                        // independent probes (16-, 4-, 1-spaced) instead of a binary search: an LDS round trip is ~400 cycles under load
+                        const uint2 *top = stg + lane + 127;
+                        int c1 = 0;
 #pragma unroll
-                        for (int it = 0; it < 8; it++) {
-                            const int mid = (lo + hi) >> 1;
-                            const uint32_t ey = stg[lane + 127 - (mid < 127 ? mid : 127)].y;
-                            const bool ok = ey >= mincs;
-                            if (lo < hi) { if (ok) lo = mid + 1; else hi = mid; }
-                        }
-                        count = lo;
-                        if (chunk == 0 && count == 0 && nact > 0 && (int)(stg[lane + 127].y >> 15) >= firstmin) count = 1;   // a first candidate at exactly MAX_DIST (:788 vs :609)
+                        for (int j = 0; j < 8; j++) { const int kk = 16 * j + 15; c1 += (kk < nact && top[-kk].y >= mincs) ? 1 : 0; }
+                        const int b1 = 16 * c1;                  // every candidate below b1 is in range; b1 + 15 is not (or does not exist)
+                        int c2 = 0;
+#pragma unroll
+                        for (int j = 0; j < 3; j++) { const int kk = b1 + 4 * j + 3; c2 += (kk < nact && top[-(kk < 127 ? kk : 127)].y >= mincs) ? 1 : 0; }
+                        const int b2s = b1 + 4 * c2;
+                        int c3 = 0;
+#pragma unroll
+                        for (int j = 0; j < 3; j++) { const int kk = b2s + j; c3 += (kk < nact && top[-(kk < 127 ? kk : 127)].y >= mincs) ? 1 : 0; }
+                        count = b2s + c3;
+                        if (count > nact) count = nact;
+                        if (lab & 8) count = nact;
+                        if (chunk == 0 && count == 0 && nact > 0 && (int)(top[0].y >> 15) >= firstmin) count = 1;   // a first candidate at exactly MAX_DIST (:788 vs :609)
                     }
                     const bool ends_here = count < 128 || kbase + 128 >= kmax;   // my walk ends inside this chunk
-                    int kw = count;
-                    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(kw, o); kw = v > kw ? v : kw; }
-                    kw = __builtin_amdgcn_readfirstlane(kw);
+                    int kw = wave_max_i32(count);
+                    if (lab & 2) kw = kw < 2 ? kw : 2;          // (lab: timing without the candidate loop; results are wrong)
                     if (kw == 0) break;
                     if (DBG) { c_slots += (unsigned long long)kw; c_steps += (unsigned long long)count; }
                     const int snapk = SNAP - kbase;              // the quarter-budget snapshot falls in front of this chunk's candidate `snapk`
@@ -449,61 +480,66 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
                     slot2[lane] = (uint32_t)bestL << 22;
                     slotq[lane] = (uint32_t)bestL << 22;
                     B5_WTICK(1);
-                    // ---- pass 1, lockstep and branch-free: the first differing content bit t of every candidate; running maximum of
-                    // (length class, nearest first); the lanes whose candidate agrees on all 46 content bits (length >= 7) are recorded
-                    // per step — lane kk of (balA, balB) receives the ballot of step kk resp. 64 + kk
+                    // ---- pass 1, lockstep: the first differing content bit t of every candidate; running maximum of (length class, nearest
+                    // first); a candidate that agrees on all 46 content bits (length >= 7) is queued for the byte pass by its lane, in step
+                    // order; 64 queued candidates are one byte pass
                     uint32_t best = 0, bestq = 0;
-                    uint32_t balA0 = 0, balA1 = 0, balB0 = 0, balB1 = 0;
-                    for (int k0 = 0; k0 < kw; k0 += 4) {
-                        const uint2 *sp = stg + lane + 127 - k0;
-                        const uint2 ee[4] = {sp[0], sp[-1], sp[-2], sp[-3]};       // (k0 + 3 <= 127)
+                    int qlen = 0;
+                    uint32_t *queue = (uint32_t *)(wv + B5_WV_QUEUE), *pinfo = (uint32_t *)(wv + B5_WV_PINFO);
+                    pinfo[lane] = (uint32_t)prel | ((uint32_t)cap << 17);
+                    const uint2 *top = stg + lane + 127;
+                    uint2 cur[8], nxt[8];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int kk = k0 + j;
-                            if (kk == snapk) bestq = best;
-                            const uint32_t xl = ee[j].x ^ mylo, xh = ee[j].y ^ myhi;
-                            const uint32_t tl = ffbl_m1(xl), th = ffbl_m1(xh) + 32u;
-                            uint32_t t = tl < th ? tl : th;
-                            t = kk < count ? t : 0u;
-                            const uint32_t K = (((t + 7u) & ~7u) << 4) | (uint32_t)(127 - kk);
-                            best = K > best ? K : best;
-                            const uint64_t bal = __ballot(t == 46u);
-                            const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
-                            const bool me = lane == (kk & 63);   // (v_writelane cannot take the value and the lane from two scalar registers on gfx9)
-                            if (kk < 64) { balA0 = me ? blo : balA0; balA1 = me ? bhi : balA1; }
-                            else { balB0 = me ? blo : balB0; balB1 = me ? bhi : balB1; }
+                    for (int j = 0; j < 8; j++) cur[j] = top[-j];
+                    for (int k0 = 0; k0 < kw; k0 += 8) {
+                        {   // the next eight entries are in flight while these eight are looked at
+                            const int kn = k0 + 8 < 120 ? k0 + 8 : 120;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) nxt[j] = top[-(kn + j)];
                         }
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {
+                            uint32_t tt[2];
+#pragma unroll
+                            for (int j = 0; j < 2; j++) {
+                                const int kk = k0 + 2 * h + j;
+                                if (kk == snapk) bestq = best;
+                                const uint32_t xl = cur[2 * h + j].x ^ mylo, xh = cur[2 * h + j].y ^ myhi;
+                                const uint32_t tl = ffbl_m1(xl), th = ffbl_m1(xh) + 32u;
+                                uint32_t t = tl < th ? tl : th;
+                                t = kk < count ? t : 0u;
+                                tt[j] = t;
+                                const uint32_t K = (((t + 7u) & ~7u) << 4) | (uint32_t)(127 - kk);
+                                best = K > best ? K : best;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 2; j++) {
+                                const bool f = tt[j] == 46u;
+                                const uint64_t bal = __ballot(f);
+                                if (bal) {
+                                    if (f) queue[qlen + __builtin_popcountll(bal & lanemask_lt)] = ((cur[2 * h + j].y >> 15) << 13) | ((uint32_t)lane << 7) | (uint32_t)(k0 + 2 * h + j);
+                                    qlen += __builtin_popcountll(bal);
+                                }
+                            }
+                            while (qlen >= 64) {
+                                wave_sync();
+                                if (!(lab & 1)) b5_byte_pass(smem, queue, slot2, slotq, pinfo, 64, P.nice, snapk, DBG ? bp_cnt : nullptr);
+                                const int r = qlen - 64;                              // (< 128: two steps were appended)
+                                const uint32_t mv0 = queue[64 + lane], mv1 = queue[128 + lane < B5_QCAP ? 128 + lane : 0];
+                                wave_sync();
+                                if (lane < r) queue[lane] = mv0;
+                                if (64 + lane < r) queue[64 + lane] = mv1;
+                                qlen = r;
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) cur[j] = nxt[j];
                     }
                     if (snapk >= kw) bestq = best;               // (the snapshot lies behind this chunk's last candidate: all of them count)
                     B5_WTICK(2);
-                    // ---- the recorded candidates, flattened in step order (lane kk writes the pairs of step kk), 64 at a time
-                    for (int half = 0; half < 2; half++) {
-                        if (64 * half >= kw) break;
-                        const uint64_t mymask = half ? (((uint64_t)balB1 << 32) | balB0) : (((uint64_t)balA1 << 32) | balA0);
-                        const int np = __builtin_popcountll(mymask);
-                        int incl = np;                           // inclusive prefix over the steps (lanes)
-                        for (int o = 1; o < 64; o <<= 1) { const int vv = __shfl_up(incl, o); if (lane >= o) incl += vv; }
-                        const int total = __builtin_amdgcn_readlane(incl, 63);
-                        int done = 0;                            // pairs already processed
-                        while (done < total) {
-                            // the steps whose pairs fit the queue: prefix - done <= B5_QCAP (at least one step: a step has at most 64 pairs)
-                            const uint64_t fits = __ballot(incl - done <= B5_QCAP && incl > done);
-                            const int off = incl - np - done;    // my first pair's place
-                            if ((fits >> lane) & 1) {
-                                uint64_t mk = mymask;
-                                int o = off < 0 ? 0 : off;       // (a step that was partly... never: steps are taken whole)
-                                while (mk) { const int bpos = __builtin_ctzll(mk); mk &= mk - 1; queue[o++] = (uint16_t)((bpos << 7) | (64 * half + lane)); }
-                            }
-                            const int upto = __builtin_popcountll(fits) ? 63 - __builtin_clzll(fits) : 0;
-                            const int seg_total = __builtin_amdgcn_readlane(incl, upto) - done;
-                            wave_sync();
-                            for (int q0 = 0; q0 < seg_total; q0 += 64) {
-                                b5_byte_pass(smem, stg, queue + q0, slot2, slotq, seg_total - q0 < 64 ? seg_total - q0 : 64, prel, cap, P.nice, snapk, DBG ? bp_cnt : nullptr);
-                                wave_sync();
-                            }
-                            done += seg_total;
-                        }
-                    }
+                    wave_sync();
+                    if (qlen > 0 && !(lab & 1)) b5_byte_pass(smem, queue, slot2, slotq, pinfo, qlen, P.nice, snapk, DBG ? bp_cnt : nullptr);
+                    wave_sync();
                     B5_WTICK(3);
                     // ---- this chunk's winner: the longer of the two passes' bests, the nearer one among equals
                     auto settle = [&](uint32_t bK, uint32_t key, int &Lout, uint32_t &rout) {
@@ -576,24 +612,27 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
                         if (SNAP == 0) resq = 0;
                     }
                 }
-                if (mine) { mt2[prel] = res2; mtq[prel] = resq; }
+                if (mine && !(lab & 4)) RES[i] = make_uint2(res2, resq);     // coalesced; the tile's tables are written in position order below
                 B5_WTICK(4);
             }
         }
         __syncthreads();
         B5_TICK(4);
-        // ---- B3: tile positions that are not inserted have no entry: their tables are empty (:780)
-        {
-            for (int bi = 0; bi < nb; bi++) {
-                const int64_t bb = (int64_t)b[bi];
-                if (bb <= t0) continue;
-                if (bb - 2 >= t1) break;
-                if (threadIdx.x < 2) {
-                    const int64_t q = bb - 2 + threadIdx.x;
-                    if (q >= t0 && q < t1 && q >= 0) { mtab.m2[seg.buf_off + q] = 0u; mtab.mq[seg.buf_off + q] = 0u; }
-                }
+        // ---- B3: the tile's tables in position order.  In S order a wavefront's 64 results belong to 64 positions all over the tile:
+        // written straight to the tables they are 4-byte stores scattered over 512 KiB per workgroup — more open cache lines than the
+        // L2 can merge, 25 ms per GiB (profiles/r03/lab_m5_knockout.log).  RES is written coalesced instead and gathered here through
+        // RANK (a workgroup's 0.8 MiB of RES is read back while it is still in the L2).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!(lab & 4)) {
+            uint32_t *m2o = mtab.m2 + seg.buf_off + w0, *mqo = mtab.mq + seg.buf_off + w0;
+            for (int rel = hoff + (int)threadIdx.x; rel < wlen; rel += B5_THREADS) {
+                const uint32_t r = RANK[rel];
+                uint2 v = make_uint2(0, 0);
+                if (r != 0xFFFFFFFFu) v = RES[r];
+                m2o[rel] = v.x; mqo[rel] = v.y;
             }
-            if (nb == 0) for (int64_t q = t0 + threadIdx.x; q < t1; q += B5_THREADS) { mtab.m2[seg.buf_off + q] = 0u; mtab.mq[seg.buf_off + q] = 0u; }
         }
     }
     if (DBG && dbg && threadIdx.x == 0) for (int i = 0; i < 5; i++) atomicAdd(dbg + 9 + i, tk[i]);
@@ -623,8 +662,8 @@ hipError_t launch_match5(const uint8_t *in, uint64_t in_total, const SegDev *seg
     hipError_t e = hipMemsetAsync(counter, 0, 4, st);
     if (e != hipSuccess) return e;
     const int grid = ntiles < nslots ? ntiles : nslots;
-    if (knob("SZL_DEBUG", 0)) hipLaunchKernelGGL((k_match5<true>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg);
-    else hipLaunchKernelGGL((k_match5<false>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg);
+    if (knob("SZL_DEBUG", 0)) hipLaunchKernelGGL((k_match5<true>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg, knob("SZL_B5_LAB", 0));
+    else hipLaunchKernelGGL((k_match5<false>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg, knob("SZL_B5_LAB", 0));
     return hipGetLastError();
 }
 
