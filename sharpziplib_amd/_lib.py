@@ -7,7 +7,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.path.join(CSRC, "libszl_amd.so")
+SO_LAB = os.path.join(CSRC, "libszl_amd_lab.so")   # the same + the laboratory forms of stage B (csrc/Makefile); tests only
 _lib = None
+_lab = None
 
 
 class Stream(ctypes.Structure):
@@ -35,12 +37,25 @@ def build(force=False):
 
 def lib():
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(SO):
-        raise RuntimeError("libszl_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
-                           "sharpziplib_amd has no CPU fallback")
-    L = ctypes.CDLL(SO)
+    if _lib is None:
+        _lib = _load(SO)
+    return _lib
+
+
+def lab_lib():
+    """The laboratory build (measured alternatives of stage B that lost: chain compression, the ring, the bucket-order search).
+    tests/test_gpu_stage_b_forms.py swaps it in for the product library to keep those forms bit-exact; nothing else loads it."""
+    global _lab
+    if _lab is None:
+        _lab = _load(SO_LAB)
+    return _lab
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError("%s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "sharpziplib_amd has no CPU fallback" % os.path.basename(path))
+    L = ctypes.CDLL(path)
     vp, sz, i32, i64, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
     sig = {
         "szl_strerror": (ctypes.c_char_p, [i32]), "szl_last_error": (ctypes.c_char_p, []),
@@ -79,7 +94,6 @@ def lib():
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
-    _lib = L
     return L
 
 

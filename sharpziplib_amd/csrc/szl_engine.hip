@@ -17,18 +17,33 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
                   uint16_t *link, const uint32_t *hflags, hipStream_t st);
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
+#if SZL_LAB   // laboratory forms of the full search (libszl_amd_lab.so only; Makefile)
 void launch_links4(const uint8_t *in, const uint16_t *link, int64_t lo, int64_t hi, int64_t n_end, uint16_t *link4, uint8_t *skip4, uint16_t *e3d,
                    uint8_t *e3h, hipStream_t st);
 int match3_tile();
+#else
+static void launch_links4(const uint8_t *, const uint16_t *, int64_t, int64_t, int64_t, uint16_t *, uint8_t *, uint16_t *, uint8_t *, hipStream_t) {}
+static int match3_tile() { return B_TILE; }
+#endif
 // SZL_MATCH_KERNEL=3: the full search of stage B walks four-byte sub-chains (szl_kernels_match3.hip); hop counts are bytes there
+#if SZL_LAB
 hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
                              unsigned long long *dbg, hipStream_t st);
+#else
+static hipError_t launch_match_ring(const uint8_t *, const SegDev *, const TileDev *, int, const uint16_t *, MTab, LevelParams, unsigned long long *, hipStream_t) { return hipErrorNotSupported; }
+#endif
 int match2_tile();
 // SZL_MATCH_KERNEL=5: the full search in bucket order (szl_kernels_match5.hip): tiles of up to match5_tile() positions, a scratch slot per resident workgroup
+#if SZL_LAB
 hipError_t launch_match5(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const TileDev *tiles, int ntiles,
                          MTab mtab, LevelParams P, uint8_t *scratch, int nslots, unsigned long long *dbg, hipStream_t st);
 size_t match5_scratch_bytes(int nslots);
 int match5_tile();
+#else
+static hipError_t launch_match5(const uint8_t *, uint64_t, const SegDev *, const uint64_t *, const TileDev *, int, MTab, LevelParams, uint8_t *, int, unsigned long long *, hipStream_t) { return hipErrorNotSupported; }
+static size_t match5_scratch_bytes(int) { return 0; }
+static int match5_tile() { return B_TILE; }
+#endif
 static int match5_slots() {   // one workgroup per CU is resident (its LDS): one scratch slot per CU
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -37,6 +52,9 @@ static int match5_slots() {   // one workgroup per CU is resident (its LDS): one
 // which form of the full search a call uses: SZL_MATCH_KERNEL, with 5 (bucket order) only where it applies — DeflateSlow with a chain budget
 // of 4 or more, and no history whose insertions a DeflateFast level decided (`hist_flags`: only the link pass knows those)
 static int match_form(const LevelParams &P, bool hist_flags) {
+#if !SZL_LAB
+    return 2;   // the product library holds one form of the full search: k_match4
+#endif
     const int which = knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT);
     if (which == 5 && (P.fast || P.strategy == 2 || P.max_chain < 4 || hist_flags)) return 2;
     return which;
@@ -64,7 +82,7 @@ static int64_t full_search_len(uint64_t emit, int64_t tile_len, int which) {
     while (len > B_TILE && emit / (uint64_t)len < min_stripes) len >>= 1;
     return len;
 }
-static bool use_match3(const LevelParams &P) { return knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
+static bool use_match3(const LevelParams &P) { return SZL_LAB && knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
 void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
                             hipStream_t st);
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,

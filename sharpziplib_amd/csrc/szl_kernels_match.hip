@@ -48,6 +48,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 // ============================================================================================
 enum : int { A_THREADS = 1024, A_WAVES = 16 };
 
+#if SZL_LAB   // the first form (lab library only)
 __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__ in, uint64_t in_total,
                                                      const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
                                                      const SpanDev *__restrict__ spans, uint16_t *__restrict__ link) {
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(A_THREADS) void k_links(const uint8_t *__restrict__
         }
     }
 }
+
+#endif
 
 // ============================================================================================
 // Stage A, compacted form (default).  Same partition of the head table, but instead of every wavefront scanning
@@ -483,6 +486,7 @@ enum : int { B_THREADS = 1024 };
 enum : int { B_DATA_BYTES = B_HIST + B_TILE + B_TAIL + 8, B_LINKS = B_HIST + B_TILE };
 enum : int { B_LDS_BYTES = B_DATA_BYTES + B_LINKS * 2 + 16 };
 
+#if SZL_LAB   // the first form of the full search (lab library only; the product runs k_match4, szl_kernels_match2.hip)
 template <bool DBG>
 __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                      const TileDev *__restrict__ tiles, const uint16_t *__restrict__ link,
@@ -681,6 +685,8 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
         if (lane == 0) { atomicAdd(dbg + 3, ql); atomicAdd(dbg + 4, vl); }
     }
 }
+
+#endif
 
 // ============================================================================================
 // Stage B, on-demand form: k_match_lazy.
@@ -990,8 +996,12 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
     }
     if (which == 3 && (probe_ok.load(std::memory_order_acquire) & dev_bit)) {
         hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link, hflags);
-    } else if (which == 1 && !hflags) hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link);
-    else hipLaunchKernelGGL(k_links2, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link, hflags);
+        return;
+    }
+#if SZL_LAB
+    if (which == 1 && !hflags) { hipLaunchKernelGGL(k_links, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link); return; }
+#endif
+    hipLaunchKernelGGL(k_links2, dim3(nspans), dim3(A_THREADS), 0, st, in, in_total, segs, bnds, spans, link, hflags);
 }
 
 int match_lds_bytes() { return B_LDS_BYTES; }
@@ -999,14 +1009,19 @@ int match_lds_bytes() { return B_LDS_BYTES; }
 hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                          MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st);
 
+#if SZL_LAB
 hipError_t launch_match3(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab, LevelParams P,
                          unsigned long long *dbg, hipStream_t st);
+#endif
 
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                         MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
-    // SZL_MATCH_KERNEL: 4 = ring-fed engine (lab; launch_match_ring, the engine calls it), 3 = chain compression (lab; szl_kernels_match3.hip,
-    // the engine passes the four-byte links in mtab), 2 = two positions in flight per lane (szl_kernels_match2.hip, default), 1 = k_match below
-    const int which = knob("SZL_MATCH_KERNEL", 2);   // (5, the bucket-order form, has its own launch: what reaches this one with 5 set is work it does not take)
+#if !SZL_LAB
+    return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // k_match4 (szl_kernels_match2.hip)
+#else
+    // SZL_MATCH_KERNEL (lab library): 5 = bucket order and 4 = ring-fed engine (own launches: the engine calls them), 3 = chain compression
+    // (szl_kernels_match3.hip, the engine passes the four-byte links in mtab), 2 = k_match4 (default), 1 = k_match below
+    const int which = knob("SZL_MATCH_KERNEL", 2);
     if (mtab.link4) return launch_match3(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // the engine set the call up for k_match6
     if (which >= 2) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
@@ -1025,6 +1040,7 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
         else hipLaunchKernelGGL(k_match<false>, dim3(ntiles), dim3(B_THREADS), B_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth);
     }
     return hipGetLastError();
+#endif
 }
 
 // On-demand stage B over the tiles tile_first, tile_first + tile_step, ... (count of them = nblocks).

@@ -339,13 +339,9 @@ __device__ __forceinline__ void b2_stage_window(uint32_t *sdata32, uint16_t *sli
     }
 }
 
-#define SZL_M4_ORD 0
 #include "szl_match4_body.inc"
-#undef SZL_M4_ORD
-#define SZL_M4_ORD 1
-#include "szl_match4_body.inc"
-#undef SZL_M4_ORD
 
+#if SZL_LAB   // (lab library only)
 // ---- k_match8: the same engine fed from a RING ----------------------------------------------------------------------------------
 // A tile costs k_match4 ~67 us beyond its walks (profiles/r02/lab_s46_tile_length.log: 52.5 / 69.8 / 101.7 ms per GiB with 16 / 8 / 4 Ki
 // tiles): it stages 48 Ki positions to search 16 Ki, and it ends with the workgroup waiting for its longest walks with most lanes
@@ -468,8 +464,6 @@ __device__ __forceinline__ void r8_stage_chunk(uint8_t *smem, const uint8_t *d, 
     }
 }
 
-// FLEX: launched with fewer than B2_THREADS threads (lab, SZL_RING_WAVES); the 16-wave form keeps its constants
-template <bool FLEX>
 __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs,
                                                        const TileDev *__restrict__ stripes, const uint16_t *__restrict__ link,
                                                        MTab mtab, LevelParams P, int fth, int vth, int qkeep, int vkeep, int slice, int lowwater, unsigned long long *dbg) {
@@ -491,11 +485,9 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     {
         const int n0 = NC < R8_NCH ? NC : (int)R8_NCH;
-        if (FLEX) for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, (int)blockDim.x);
-        else for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, B2_THREADS);
+        for (int k = 0; k < n0; k++) r8_stage_chunk(smem, d, lk, origin, k, seg_end, stripe_end, threadIdx.x, B2_THREADS);
         if (threadIdx.x == 0) { ctl[R8_COUNTER] = R8_H; ctl[R8_STAGED] = n0; ctl[R8_LOCK] = 0; }
-        if (FLEX) { if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = threadIdx.x < (blockDim.x >> 6) ? (int)R8_H : 0x7FFFFFFF; }   // (waves that do not exist hold nothing back)
-        else if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = R8_H;
+        if (threadIdx.x < 16) ctl[R8_SLOT0 + threadIdx.x] = R8_H;
     }
     __syncthreads();
 
@@ -668,6 +660,8 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
     }
 }
 
+#endif   // SZL_LAB
+
 static bool lds_attr_needed2(std::atomic<uint64_t> &mask, uint64_t &bit) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -698,20 +692,6 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     if (vkeep < 1) vkeep = 1;
     int slice = knob("SZL_SLICE", 128);   // tile positions a wavefront takes from the tile counter at a time (512: 63.5, 128: 61.6 ms per GiB — a shorter tail per tile)
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
-    if (ntiles > 0 && knob("SZL_ORDERED", 0) == 1 && !want_dbg) {   // (lab: two-pass order of a tile's positions; not yet run on a device)
-        static std::atomic<uint64_t> attr_mask_o{0};
-        uint64_t bit_o = 0;
-        if (lds_attr_needed2(attr_mask_o, bit_o)) {
-            hipError_t e = attr((const void *)k_match4o);
-            if (e != hipSuccess) return e;
-            attr_mask_o.fetch_or(bit_o, std::memory_order_release);
-        }
-        int order_th = knob("SZL_ORDER_TH", 4096);
-        int waves = knob("SZL_M4_WAVES", 16);   // (lab)
-        waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
-        hipLaunchKernelGGL(k_match4o, dim3(ntiles), dim3(64 * waves), B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, fth, vth, qkeep, vkeep, slice, order_th);
-        return hipGetLastError();
-    }
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B2_THREADS);
         if (want_dbg) hipLaunchKernelGGL((k_match4<true>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
@@ -720,6 +700,7 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
     return hipGetLastError();
 }
 
+#if SZL_LAB
 // stripes: TileDev entries of any length (the engine cuts them)
 hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDev *stripes, int nstripes, const uint16_t *link, MTab mtab, LevelParams P,
                              unsigned long long *dbg, hipStream_t st) {
@@ -727,8 +708,7 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
     uint64_t attr_bit = 0;
     int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2), slice = knob("SZL_SLICE", 128);
     if (lds_attr_needed2(attr_mask, attr_bit)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_match8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_match8, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
@@ -736,15 +716,15 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
     slice = slice < 64 ? 64 : (slice > 1024 ? 1024 : slice);
     int lowwater = knob("SZL_LOWWATER", 6144);
     lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
-    int waves = knob("SZL_RING_WAVES", 16);   // (lab: fewer walks in flight end sooner and pin the ring's history for a shorter time)
-    waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+    // (fewer than 16 waves per workgroup — the timing model's suggestion, DESIGN §8 of round 2 — measured: 12 / 10 / 8 / 6 waves take 57.6 / 62.3 /
+    // 68.3 / 84.2 ms per GiB against 54.9 with 16, profiles/r03/lab_r3a_ring_waves_256.log; the variant was removed)
     unsigned long long *dbg8 = knob("SZL_DEBUG", 0) ? dbg : nullptr;
-    if (nstripes > 0 && waves == 16)
-        hipLaunchKernelGGL(k_match8<false>, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, dbg8);
-    else if (nstripes > 0)
-        hipLaunchKernelGGL(k_match8<true>, dim3(nstripes), dim3(64 * waves), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, dbg8);
+    if (nstripes > 0)
+        hipLaunchKernelGGL(k_match8, dim3(nstripes), dim3(B2_THREADS), R8_LDS_BYTES, st, in, segs, stripes, link, mtab, P, fth, vth, qkeep, vkeep, slice, lowwater, dbg8);
     return hipGetLastError();
 }
+
+#endif
 
 int match2_tile() { return B2_TILE; }
 

@@ -1,7 +1,10 @@
 """The forms of the full stage-B search must all produce the reference's match tables, i.e. the oracle's bytes:
-  * k_match4 with its own tile length (default; the tile is as long as LDS allows, longer than the tiles of the on-demand form),
-  * chain compression (SZL_MATCH_KERNEL=3, lab: k_links4t + k_match6 — four-byte sub-chains, hop counts charged to max_chain),
-  * the ring-fed engine (SZL_MATCH_KERNEL=4, lab: k_match8 — positions and links in a ring, staged chunk by chunk while walks run).
+  * k_match4 with its own tile length (the product; the tile is as long as LDS allows, longer than the tiles of the on-demand form),
+and, in the LABORATORY library only (csrc/libszl_amd_lab.so — measured alternatives that lost; the product library does not contain them):
+  * chain compression (SZL_MATCH_KERNEL=3: k_links4t + k_match6 — four-byte sub-chains, hop counts charged to max_chain),
+  * the ring-fed engine (SZL_MATCH_KERNEL=4: k_match8 — positions and links in a ring, staged chunk by chunk while walks run),
+  * the bucket-order search (SZL_MATCH_KERNEL=5: k_match5 — every tile's window sorted by (hash, position), lockstep walks over the
+    sorted array, no prev[] links; round 3).
 Reference: FindLongestMatch, C/DeflaterEngine.cs:474-612."""
 import numpy as np
 import pytest
@@ -15,9 +18,11 @@ KNOBS = [b"SZL_MATCH_KERNEL", b"SZL_STRIPE_MIN", b"SZL_STRIPE_KIB", b"SZL_TILE_L
 
 
 @pytest.fixture()
-def knobs():
+def knobs(monkeypatch):
+    """Every object of this module's tests is created on the laboratory library (swapped in for the product one)."""
     from sharpziplib_amd import _lib
-    L = _lib.lib()
+    L = _lib.lab_lib()
+    monkeypatch.setattr(_lib, "_lib", L)
 
     def set_(**kv):
         for k, v in kv.items():
@@ -27,6 +32,26 @@ def knobs():
         L.szl_debug_set(k, -2147483648)       # forget
 
 
+def test_the_product_library_holds_one_form_of_the_full_search():
+    """SZL_MATCH_KERNEL is a laboratory switch: the shipped library ignores it (and still produces the reference's bytes)."""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    L = _lib.lib()
+    data = [C.generate("enwik", 0xE9, 0, 600000)]
+    want = O.deflate(data[0], 6)
+    try:
+        for k in (2, 3, 4, 5):
+            L.szl_debug_set(b"SZL_MATCH_KERNEL", k)
+            eng = Engine()
+            try:
+                eng.debug_match_mode(0)
+                assert eng.deflate(data, level=6)[0].data == want, k
+            finally:
+                eng.close()
+    finally:
+        L.szl_debug_set(b"SZL_MATCH_KERNEL", -2147483648)
+
+
 def _streams():
     rng = np.random.default_rng(23)
     return [C.generate("enwik", 0xE9, 0, 1500000), C.generate("logs", 0x106, 0, 900000), C.generate("dickens", 0xD1CE, 0, 700000),
@@ -34,7 +59,7 @@ def _streams():
             np.repeat(rng.integers(0, 256, 4000).astype(np.uint8), rng.integers(1, 90, 4000)), np.zeros(0, np.uint8), C.random_bytes(5, seed=1)]
 
 
-@pytest.mark.parametrize("form", ["tiles", "chain", "ring", "ring_long_stripes"])
+@pytest.mark.parametrize("form", ["tiles", "chain", "ring", "ring_long_stripes", "bucket", "bucket_short_tiles"])
 @pytest.mark.parametrize("level", [5, 6, 9])
 def test_full_search_forms_are_bit_exact(knobs, form, level):
     from sharpziplib_amd.batch import Engine
@@ -44,6 +69,12 @@ def test_full_search_forms_are_bit_exact(knobs, form, level):
         knobs(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=64)
     elif form == "ring_long_stripes":
         knobs(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=4096)
+    elif form == "bucket":
+        knobs(SZL_MATCH_KERNEL=5)
+    elif form == "bucket_short_tiles":
+        knobs(SZL_MATCH_KERNEL=5, SZL_TILE_LEN=12288)     # (several tiles per stream: windows with history, window-base changes inside a tile)
+    else:
+        knobs(SZL_MATCH_KERNEL=2)
     data = _streams()
     eng = Engine()
     try:
@@ -55,7 +86,7 @@ def test_full_search_forms_are_bit_exact(knobs, form, level):
         eng.close()
 
 
-@pytest.mark.parametrize("form", ["tiles", "chain", "ring"])
+@pytest.mark.parametrize("form", ["tiles", "chain", "ring", "bucket"])
 def test_full_search_forms_in_the_window_pipeline(knobs, form):
     """a long stream goes through stage B window by window: links of a window start at its first position"""
     from sharpziplib_amd.batch import Engine
@@ -64,6 +95,8 @@ def test_full_search_forms_in_the_window_pipeline(knobs, form):
         knobs(SZL_MATCH_KERNEL=3)
     elif form == "ring":
         knobs(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=128)
+    elif form == "bucket":
+        knobs(SZL_MATCH_KERNEL=5)
     data = C.generate("enwik", 5, 0, 2200000)
     eng = Engine()
     try:
@@ -82,7 +115,7 @@ def test_streaming_deflater_through_the_lab_forms(knobs):
     from sharpziplib_amd.streams import DeflaterOutputStream
     data = C.generate("enwik", 11, 0, 700000)
     ref, tin, tout = O.stream_deflate(data, 6, True, chunk=150000, flush_every=None)
-    for kernel in (3, 4):
+    for kernel in (3, 4, 5):
         knobs(SZL_MATCH_KERNEL=kernel, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=64)
         d = Deflater(6, True)
         ms = io.BytesIO()

@@ -17,9 +17,11 @@ ap.add_argument("--level", type=int, default=6)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--oracle", action="store_true")
 ap.add_argument("--debug", action="store_true")
+ap.add_argument("--product", action="store_true", help="the product library (one form of the full search) instead of the laboratory build")
 ap.add_argument("cfgs", nargs="*")
 a = ap.parse_args()
-L = _lib.lib()
+L = _lib.lib() if a.product else _lib.lab_lib()
+_lib._lib = L                        # (everything below, Engine included, runs on that library)
 n = a.mib << 20
 seed = {"enwik": 0xE9, "logs": 0x106, "dickens": 0xD1CE}[a.kind]
 host = corpus.generate(a.kind, seed, 0, n)
