@@ -140,9 +140,13 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
  * group g is compressed on devices[g] by its own host thread and engine; only a group's own bytes travel to its device.  Results
  * are identical to the single-device calls (every stream is independent).  The same ordinal may appear more than once.
  * ONE stream (n_streams == 1, levels 5-9, at least SZL_PART_MIN_KIB = 64 MiB per device) is not left to a single device: it is
- * cut into n_dev position ranges, each device runs the match search and the parse of its range (one Deflater lifetime,
- * S/GZip/GzipOutputStream.cs:87, has no other parallel form), the host checks that each range's parse is entered where the
- * previous one leaves it, and devices[0] builds the blocks from all tokens.  Same bytes as one device. */
+ * cut into position ranges (SZL_PART_UNITS = 4 per device) that the devices take one after the other as they become free — a
+ * device with cheaper bytes takes more of them — each device runs the match search and the parse of its ranges (one Deflater
+ * lifetime, S/GZip/GzipOutputStream.cs:87, has no other parallel form), the host checks that each range's parse is entered
+ * where the previous one leaves it, and devices[0] collects the tokens while later ranges still run (peer copies where the
+ * devices reach each other, through the host otherwise) and builds the blocks.  Same bytes as one device.
+ * These two entry points take no engine handle: their engines live in a process-wide pool and the calls SERIALISE on it
+ * (a second caller waits for the first). */
 int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  int level, int strategy, unsigned flags);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,

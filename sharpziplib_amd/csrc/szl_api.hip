@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <deque>
+#include <condition_variable>
+#include <atomic>
 #include <new>
 #include <string>
 #include <thread>
@@ -316,8 +319,11 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
 // thread with its own engine (kept for the next call), staging only the bytes of its group.  No data-path collective: the
 // groups never exchange anything.  One stream is never split.
 struct MultiSlot { szl_engine *eng = nullptr; int device = -1; };
+// The engines of the multi-device entry points are kept from call to call in this process-wide pool (slot g = group g).  The
+// entry points take no handle, so they SERIALISE: g_multi_mu is held for the whole call (include/szl.h says so), and the pool is
+// a deque — growing it never moves an engine another thread holds a reference to.
 static std::mutex g_multi_mu;
-static std::vector<MultiSlot> g_multi_slots;
+static std::deque<MultiSlot> g_multi_slots;
 
 static int multi_run(bool inflate, const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n,
                      int level, int strategy, unsigned flags) {
@@ -335,7 +341,8 @@ static int multi_run(bool inflate, const int *devices, int n_dev, const void *h_
       for (size_t i = 0; i < n && g < n_dev; i++) { acc += streams[i].in_len + 1; while (g < n_dev && acc * (uint64_t)n_dev >= total * (uint64_t)g) cut[g++] = i + 1; } }
     for (int g = 1; g <= n_dev; g++) if (cut[g] < cut[g - 1]) cut[g] = cut[g - 1];
     cut[n_dev] = n;
-    { std::lock_guard<std::mutex> lk(g_multi_mu); if ((int)g_multi_slots.size() < n_dev) g_multi_slots.resize(n_dev); }
+    std::lock_guard<std::mutex> multi_lock(g_multi_mu);          // one multi-device call at a time
+    if ((int)g_multi_slots.size() < n_dev) g_multi_slots.resize(n_dev);
     std::vector<int> rcs(n_dev, 0);
     std::vector<std::string> errs(n_dev);
     auto work = [&](int g) {
@@ -373,17 +380,22 @@ static int multi_run(bool inflate, const int *devices, int n_dev, const void *h_
     return 0;
 }
 // ---------------------------------------------------------------------------------------------
-// ONE stream over several engines / devices (levels 5-9): exact position-range partition.
-//   * The stream is cut into n_dev contiguous parts at multiples of the stage-B tile.  Part g runs stages A, B and C on
-//     devices[g] with the window pipeline (Engine::PartRun): it needs nothing but its bytes, 64 KiB of history and a few KiB of
-//     lookahead.  What it cannot know is the iteration on which the true parse enters it — so it parses a warm-up stretch in
-//     front of the part from an assumed clean state and drops those tokens.  Two parses that are clean at the same position are
-//     identical from there on: the entry the warm-up arrives at is the true one iff the previous part's parse leaves on it.
-//   * The host checks exit(g-1) == entry(g) for every g and re-runs a part with the right entry where that fails (data whose
-//     parses never re-synchronise: long runs of one byte).  No other exchange between the parts.
-//   * The tokens of all parts are gathered on devices[0] (hipMemcpyPeer), which also holds the whole input, and stage D — block
-//     positions from the tokens' own lengths, Huffman trees, bit packing, checksums, framing — runs there once.
-// Same bytes as one engine produces (tests/test_gpu_multi.py runs two and three engines on one device against it and the oracle).
+// ONE stream over several engines / devices (levels 5-9): exact position-range partition, dynamically balanced.
+//   * The stream is cut into UNITS at multiples of the stage-B tile — SZL_PART_UNITS (4) per device — and every device takes the
+//     next unit when it is free: a device that gets cheap bytes (or is faster) simply takes more units, so the parts balance by
+//     measured cost without an estimate, and without a collective (the devices never exchange input; all engines live in this
+//     process).  A unit runs stages A, B and C with the window pipeline (Engine::PartRun): it needs nothing but its bytes, 64 KiB
+//     of history and a few KiB of lookahead.
+//   * What a unit cannot know is the iteration on which the true parse enters it — so it parses a warm-up stretch in front of
+//     itself from an assumed clean state and drops those tokens.  Two parses that are clean at the same position are identical
+//     from there on: the entry the warm-up arrives at is the true one iff the previous unit's parse leaves on it.  The host checks
+//     exit(u-1) == entry(u) in unit order and re-runs a unit with the right entry where that fails (data whose parses never
+//     re-synchronise: long runs of one byte).  No other coupling between the units.
+//   * The tokens are gathered on devices[0] — which also holds the whole input — WHILE later units still run: as soon as units
+//     0..u are done their offsets are known, and unit u's tokens travel on a stream of their own (peer copy where the devices can
+//     reach each other, through a host buffer otherwise).  Stage D — block positions from the tokens' own lengths, Huffman trees,
+//     bit packing, checksums, framing — then runs there once.
+// Same bytes as one engine produces (tests/test_gpu_multi.py: several engines on one or more devices against it and the oracle).
 static int stream_multi_run(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *stream, int level, int strategy, unsigned flags) {
     LevelParams P;
     int rc = level_params(level, strategy, &P);
@@ -395,94 +407,160 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     const uint8_t *src = (const uint8_t *)h_in + stream->in_off;
     const uint64_t window = std::max<uint64_t>((uint64_t)szl::knob("SZL_WINDOW_KIB", 256 * 1024) * 1024 / B_TILE * B_TILE, B_TILE);
     const int64_t WARM = (int64_t)std::max(64, szl::knob("SZL_PART_WARM_KIB", 256)) * 1024;
-    const int64_t LOOK = C_WIN_HALO + 1024 + MAX_MATCH + 64;      // bytes a part sees beyond its end (halo of the last window + hand-over slack)
-    std::vector<int64_t> cut(n_dev + 1);
-    for (int g = 0; g <= n_dev; g++) cut[g] = g == n_dev ? N : (int64_t)((uint64_t)N * (uint64_t)g / (uint64_t)n_dev / B_TILE * B_TILE);
-    { std::lock_guard<std::mutex> lk(g_multi_mu); if ((int)g_multi_slots.size() < n_dev) g_multi_slots.resize(n_dev); }
-    struct PartOut { int rc = 0; std::string err; int64_t entry = 0, exit = 0; uint64_t ntok = 0; int64_t b0 = 0; };
-    std::vector<PartOut> po(n_dev);
-    auto run_part = [&](int g, int64_t force_entry) {
-        PartOut &o = po[g];
-        o.rc = 0;
-        if (hipSetDevice(devices[g]) != hipSuccess) { o.rc = SZL_E_DEVICE; o.err = "hipSetDevice failed"; return; }
-        MultiSlot &slot = g_multi_slots[g];
-        if (slot.eng && slot.device != devices[g]) { szl_engine_destroy(slot.eng); slot.eng = nullptr; }
-        if (!slot.eng) { slot.eng = szl_engine_create(); slot.device = devices[g]; }
-        if (!slot.eng) { o.rc = SZL_E_DEVICE; o.err = last_error(); return; }
-        Engine &E = slot.eng->e;
-        // bytes of this part: 64 KiB of history in front of the warm-up, a little lookahead behind the part; engine 0 takes all
-        // of the stream (stage D and the checksums need it)
-        const int64_t first = cut[g], pend = cut[g + 1];
-        const int64_t warm_from = g == 0 ? -1 : std::max<int64_t>(0, first - WARM) / B_TILE * B_TILE;
-        const int64_t b0 = g == 0 ? 0 : std::max<int64_t>(0, (force_entry >= 0 ? std::min(force_entry, first) : warm_from) - 65536);
+    const int64_t LOOK = C_WIN_HALO + 1024 + MAX_MATCH + 64;      // bytes a unit sees beyond its end (halo of the last window + hand-over slack)
+    int n_units = n_dev * std::max(1, szl::knob("SZL_PART_UNITS", 4));
+    {   // a unit pays a warm-up stretch: not shorter than 16 times that (and never fewer units than devices)
+        const int64_t min_unit = std::max<int64_t>(16 * WARM, (int64_t)B_TILE);
+        while (n_units > n_dev && N / n_units < min_unit) n_units--;
+    }
+    std::vector<int64_t> cut(n_units + 1);
+    for (int u = 0; u <= n_units; u++) cut[u] = u == n_units ? N : (int64_t)((uint64_t)N * (uint64_t)u / (uint64_t)n_units / B_TILE * B_TILE);
+    std::lock_guard<std::mutex> multi_lock(g_multi_mu);          // one multi-device call at a time
+    if ((int)g_multi_slots.size() < n_dev) g_multi_slots.resize(n_dev);
+    struct Unit { int rc = 0; std::string err; int64_t entry = 0, exit = 0; uint64_t ntok = 0; int slot = -1; DevBuf toks; bool done = false; };
+    std::vector<Unit> un(n_units);
+    std::mutex mu; std::condition_variable cv;
+    std::atomic<int> next_unit{0};
+    std::vector<int> slot_rc(n_dev, 0);
+    std::vector<std::string> slot_err(n_dev);
+    auto free_units = [&]() { for (auto &x : un) if (x.toks.p) { if (x.slot >= 0) (void)hipSetDevice(devices[x.slot]); x.toks.release(); } (void)hipSetDevice(g_device); };
+
+    // one unit on slot g's engine (the calling thread has made devices[g] current and the engine exists)
+    auto run_unit = [&](int g, int u, int64_t force_entry) {
+        Unit &o = un[u];
+        o.rc = 0; o.slot = g;
+        Engine &E = g_multi_slots[g].eng->e;
+        const int64_t first = cut[u], pend = cut[u + 1];
+        const int64_t warm_from = u == 0 ? -1 : std::max<int64_t>(0, first - WARM) / B_TILE * B_TILE;
+        // bytes of this unit: 64 KiB of history in front of the warm-up, a little lookahead behind the unit; engine 0 holds the
+        // whole stream (stage D and the checksums need it) and runs its units on that copy
+        const int64_t b0 = g == 0 ? 0 : (u == 0 ? 0 : std::max<int64_t>(0, (force_entry >= 0 ? std::min(force_entry, first) : warm_from) - 65536));
         const int64_t b1 = g == 0 ? N : std::min<int64_t>(N, pend + LOOK);
-        o.b0 = b0;
         const uint64_t nb = (uint64_t)(b1 - b0);
         int r;
-        if ((r = E.stage_in.ensure(nb + 64))) { o.rc = r; o.err = last_error(); return; }
-        if (force_entry < 0 || g != 0)   // (engine 0 keeps its copy across a re-run)
+        if (g != 0) {
+            if ((r = E.stage_in.ensure(nb + 64))) { o.rc = r; o.err = last_error(); return; }
             if (nb && hipMemcpy(E.stage_in.p, src + b0, nb, hipMemcpyHostToDevice) != hipSuccess) { o.rc = SZL_E_DEVICE; o.err = "H2D failed"; return; }
+        }
         SegDev sg{};
         sg.buf_off = 0; sg.abs0 = (uint64_t)b0;               // window bases follow the absolute position (C/DeflaterEngine.cs:371,:771)
-        sg.seg_start = (g == 0 ? 0 : (warm_from >= 0 ? warm_from : first)) - b0; sg.seg_end = b1 - b0;
+        sg.seg_start = (u == 0 ? 0 : (warm_from >= 0 ? warm_from : first)) - b0; sg.seg_end = b1 - b0;
         sg.bnd_off = 0; sg.bnd_cnt = 1;
-        // the only boundary that matters is the true end of the stream (InsertString needs three bytes, :780): a part that does not
+        // the only boundary that matters is the true end of the stream (InsertString needs three bytes, :780): a unit that does not
         // see it has none within reach
         std::vector<uint64_t> bnds{(uint64_t)(b1 == N ? N - b0 : (b1 - b0) + 64)};
         sg.finish = whole.finish; sg.flags = 0; sg.out_off = 0; sg.out_cap = 0; sg.start_bit = 0; sg.adler_init = 1; sg.crc_init = 0;
         E.part = Engine::PartRun{};
         E.part.active = true; E.part.first = first - b0; E.part.parse_end = pend - b0;
-        E.part.warm_from = (g == 0 || force_entry >= 0) ? -1 : warm_from - b0;
+        E.part.warm_from = (u == 0 || force_entry >= 0) ? -1 : warm_from - b0;
         E.part.force_entry = force_entry >= 0 ? force_entry - b0 : -1;
         if (E.part.force_entry >= 0) sg.seg_start = std::min<int64_t>(sg.seg_start, E.part.force_entry);
         std::vector<SegOut> res;
         r = E.deflate_windowed((const uint8_t *)E.stage_in.p, nb, nullptr, 0, sg, bnds, P, 0, res, nullptr, window);
         const Engine::PartRun pr = E.part;
         E.part = Engine::PartRun{};
-        if (r == SZL_E_STATE && force_entry < 0 && g != 0) { o.entry = -1; o.exit = -1; o.ntok = 0; return; }   // the warm-up found no clean hand-over: decided in the chain below
+        if (r == SZL_E_STATE && force_entry < 0 && u != 0) { o.entry = -1; o.exit = -1; o.ntok = 0; return; }   // the warm-up found no clean hand-over: decided in the chain below
         if (r) { o.rc = r; o.err = last_error(); return; }
         o.entry = pr.entry + b0; o.exit = pr.exit + b0; o.ntok = pr.tok_count;
+        // the unit's tokens leave the engine's buffer (its next unit overwrites it)
+        if ((r = o.toks.ensure((o.ntok + 16) * 4))) { o.rc = r; o.err = last_error(); return; }
+        if (o.ntok && (hipMemcpy(o.toks.p, E.tokens.p, o.ntok * 4, hipMemcpyDeviceToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {   // (the gather reads them on another stream)
+            o.rc = SZL_E_DEVICE; o.err = "token copy failed"; return;
+        }
     };
-    {
-        std::vector<std::thread> th;
-        for (int g = 1; g < n_dev; g++) th.emplace_back(run_part, g, (int64_t)-1);
-        run_part(0, -1);
-        for (auto &t : th) t.join();
-    }
-    for (int g = 0; g < n_dev; g++) if (po[g].rc) { (void)hipSetDevice(g_device); set_error("part %d on device %d: %s", g, devices[g], po[g].err.c_str()); return po[g].rc; }
-    // ---- the chain of hand-overs
+    auto worker = [&](int g) {
+        auto fail = [&](int r, const std::string &e) { slot_rc[g] = r; slot_err[g] = e; std::lock_guard<std::mutex> lk(mu); cv.notify_all(); };
+        if (hipSetDevice(devices[g]) != hipSuccess) { fail(SZL_E_DEVICE, "hipSetDevice failed"); return; }
+        MultiSlot &slot = g_multi_slots[g];
+        if (slot.eng && slot.device != devices[g]) { szl_engine_destroy(slot.eng); slot.eng = nullptr; }
+        if (!slot.eng) { slot.eng = szl_engine_create(); slot.device = devices[g]; }
+        if (!slot.eng) { fail(SZL_E_DEVICE, last_error()); return; }
+        if (g == 0) {   // engine 0 holds the whole stream
+            Engine &E = slot.eng->e;
+            int r = E.stage_in.ensure((uint64_t)N + 64);
+            if (r) { fail(r, last_error()); return; }
+            if (N && hipMemcpy(E.stage_in.p, src, (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { fail(SZL_E_DEVICE, "H2D failed"); return; }
+        }
+        for (;;) {
+            const int u = next_unit.fetch_add(1);
+            if (u >= n_units) break;
+            run_unit(g, u, -1);
+            { std::lock_guard<std::mutex> lk(mu); un[u].done = true; }
+            cv.notify_all();
+            if (un[u].rc) break;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_dev; g++) th.emplace_back(worker, g);
+
+    // ---- the main thread: hand-over chain and token gather, in unit order, while the workers run
+    if (hipSetDevice(devices[0]) != hipSuccess) { for (auto &t : th) t.join(); return SZL_E_DEVICE; }
+    DevBuf nt;                                           // the stream's tokens on device 0 (a token covers at least one byte)
+    hipStream_t gst = nullptr;
+    std::vector<uint8_t> bounce;                         // devices that cannot reach device 0: through the host
+    int fatal = 0; std::string fatal_msg;
+    auto set_fatal = [&](int r, const std::string &m) { if (!fatal) { fatal = r; fatal_msg = m; } };
+    if ((rc = nt.ensure(((uint64_t)N + 16) * 4))) set_fatal(rc, last_error());
+    if (!fatal && hipStreamCreateWithFlags(&gst, hipStreamNonBlocking) != hipSuccess) set_fatal(SZL_E_DEVICE, "stream for the token gather");
+    uint64_t at = 0;
     int reruns = 0;
-    for (int g = 1; g < n_dev; g++) {
-        if (po[g].entry == po[g - 1].exit) continue;
-        run_part(g, po[g - 1].exit);                     // (sequential: its exit decides about the next part)
-        reruns++;
-        if (po[g].rc) { (void)hipSetDevice(g_device); set_error("part %d on device %d (re-run): %s", g, devices[g], po[g].err.c_str()); return po[g].rc; }
-        if (po[g].entry != po[g - 1].exit) { (void)hipSetDevice(g_device); set_error("part %d: forced entry not honoured", g); return SZL_E_STATE; }
+    bool workers_joined = false;
+    auto join_workers = [&]() { if (!workers_joined) { for (auto &t : th) t.join(); workers_joined = true; (void)hipSetDevice(devices[0]); } };
+    auto gather = [&](int u) -> bool {
+        Unit &x = un[u];
+        if (!x.ntok) return true;
+        const int sd = devices[x.slot];
+        int can = 1;
+        if (sd != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], sd) != hipSuccess) can = 0;
+        if (sd == devices[0] || can) {
+            if (hipMemcpyPeerAsync((uint32_t *)nt.p + at, devices[0], x.toks.p, sd, x.ntok * 4, gst) != hipSuccess) return false;
+        } else {
+            bounce.resize(x.ntok * 4);
+            if (hipSetDevice(sd) != hipSuccess || hipMemcpy(bounce.data(), x.toks.p, x.ntok * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            if (hipSetDevice(devices[0]) != hipSuccess || hipMemcpy((uint32_t *)nt.p + at, bounce.data(), x.ntok * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+        }
+        at += x.ntok;
+        return true;
+    };
+    for (int u = 0; u < n_units && !fatal; u++) {
+        if (!workers_joined) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { if (un[u].done) return true; for (int g = 0; g < n_dev; g++) if (slot_rc[g]) return true; return false; });
+            if (!un[u].done) { lk.unlock(); join_workers(); }
+        }
+        for (int g = 0; g < n_dev && !fatal; g++) if (slot_rc[g]) set_fatal(slot_rc[g], "device " + std::to_string(devices[g]) + ": " + slot_err[g]);
+        if (fatal) break;
+        if (!un[u].done) { set_fatal(SZL_E_STATE, "a unit was never run"); break; }
+        if (un[u].rc) { set_fatal(un[u].rc, "unit " + std::to_string(u) + " on device " + std::to_string(devices[un[u].slot]) + ": " + un[u].err); break; }
+        if (u > 0 && un[u].entry != un[u - 1].exit) {
+            // the warm-up did not arrive on the iteration the true parse enters this unit on: run it again from the right one, on
+            // engine 0 (it holds the whole stream) once the workers are through — rare, and sequential by nature (its exit decides
+            // about the next unit)
+            join_workers();
+            if (un[u].toks.p) { (void)hipSetDevice(devices[un[u].slot]); un[u].toks.release(); (void)hipSetDevice(devices[0]); }
+            run_unit(0, u, un[u - 1].exit);
+            reruns++;
+            if (un[u].rc) { set_fatal(un[u].rc, "unit " + std::to_string(u) + " (re-run): " + un[u].err); break; }
+            if (un[u].entry != un[u - 1].exit) { set_fatal(SZL_E_STATE, "unit " + std::to_string(u) + ": forced entry not honoured"); break; }
+        }
+        if (!gather(u)) set_fatal(SZL_E_DEVICE, "token gather from device " + std::to_string(devices[un[u].slot]) + " failed");
     }
-    if (szl::knob("SZL_DEBUG", 0)) {
-        fprintf(stderr, "[szl] one stream on %d engines: %d part(s) re-run;", n_dev, reruns);
-        for (int g = 0; g < n_dev; g++) fprintf(stderr, " [%lld,%lld) %llu tok", (long long)po[g].entry, (long long)po[g].exit, (unsigned long long)po[g].ntok);
+    join_workers();
+    if (!fatal && gst && hipStreamSynchronize(gst) != hipSuccess) set_fatal(SZL_E_DEVICE, "token gather failed");
+    if (gst) (void)hipStreamDestroy(gst);
+    if (szl::knob("SZL_DEBUG", 0) && !fatal) {
+        fprintf(stderr, "[szl] one stream on %d engines, %d units: %d re-run;", n_dev, n_units, reruns);
+        for (int u = 0; u < n_units; u++) fprintf(stderr, " [%lld,%lld)@%d", (long long)un[u].entry, (long long)un[u].exit, un[u].slot);
         fprintf(stderr, "\n");
     }
-    // ---- gather the tokens on engine 0 and finish there
+    free_units();
+    if (fatal) { (void)hipSetDevice(devices[0]); nt.release(); (void)hipSetDevice(g_device); set_error("%s", fatal_msg.c_str()); return fatal; }
+    // ---- finish on engine 0
     if (hipSetDevice(devices[0]) != hipSuccess) return SZL_E_DEVICE;
     Engine &E0 = g_multi_slots[0].eng->e;
-    uint64_t ntok = 0;
-    for (int g = 0; g < n_dev; g++) ntok += po[g].ntok;
-    {   // tokens of part 0 are in place; make room behind them (the buffer may move)
-        DevBuf nt;
-        if ((rc = nt.ensure((ntok + 16) * 4))) return rc;
-        uint64_t at = 0;
-        for (int g = 0; g < n_dev; g++) {
-            const Engine &Eg = g_multi_slots[g].eng->e;
-            if (po[g].ntok && hipMemcpyPeer((uint32_t *)nt.p + at, devices[0], Eg.tokens.p, devices[g], po[g].ntok * 4) != hipSuccess) {
-                nt.release(); (void)hipSetDevice(g_device); set_error("token gather from device %d failed", devices[g]); return SZL_E_DEVICE;
-            }
-            at += po[g].ntok;
-        }
-        E0.tokens.release();
-        E0.tokens = nt;                                  // (DevBuf is a plain pointer + capacity; E0 owns it from here)
-    }
+    const uint64_t ntok = at;
+    E0.tokens.release();
+    E0.tokens = nt;                                      // (DevBuf is a plain pointer + capacity; E0 owns it from here)
     SegDev fin = whole;
     fin.buf_off = 0;                                     // engine 0's copy of the stream starts at its buffer's first byte
     if ((rc = E0.stage_out.ensure(stream->out_cap + 64))) return rc;

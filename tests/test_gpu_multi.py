@@ -1,7 +1,8 @@
-"""Several devices behind the C ABI (szl_deflate_batch_multi_host / szl_inflate_batch_multi_host).  The GPU box
-of the test run has ONE MI355X, so the device list names it several times: every group still gets its own host thread,
-engine and staging — the code path of an 8-GPU node with the ordinals replaced.  Results must equal the single-device call's
-and the oracle's for every stream."""
+"""Several devices behind the C ABI (szl_deflate_batch_multi_host / szl_inflate_batch_multi_host).  Device lists
+are written as SLOT counts: `_devs(n)` names n distinct ordinals when the box has them and wraps around otherwise — on a box
+with ONE MI355X every slot is ordinal 0, and each group / unit still gets its own host thread, engine and staging (the code
+path of an 8-GPU node with the ordinals replaced; peer copies degenerate to device-to-device copies).  Results must equal the
+single-device call's and the oracle's for every stream."""
 import numpy as np
 import pytest
 
@@ -9,6 +10,12 @@ import oracle_ffi as O
 from sharpziplib_amd import corpus as C
 
 pytestmark = pytest.mark.gpu
+
+
+def _devs(n):
+    from sharpziplib_amd import _lib
+    have = max(1, int(_lib.lib().szl_device_count()))
+    return [i % have for i in range(n)]
 
 
 def _bufs(n, seed):
@@ -20,9 +27,10 @@ def _bufs(n, seed):
     return out
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 8])
-def test_deflate_multi_equals_oracle(devices):
+@pytest.mark.parametrize("ndev", [1, 2, 3, 8])
+def test_deflate_multi_equals_oracle(ndev):
     from sharpziplib_amd.batch import deflate_multi
+    devices = _devs(ndev)
     bufs = _bufs(37, 7) + [C.generate("enwik", 9, 0, 3 << 20)]           # one big stream skews the byte balance
     res = deflate_multi(bufs, devices, level=6, crc32=True)
     for b, r in zip(bufs, res):
@@ -32,15 +40,15 @@ def test_deflate_multi_equals_oracle(devices):
 def test_fewer_streams_than_devices_and_empty_streams():
     from sharpziplib_amd.batch import deflate_multi
     bufs = [C.generate("dickens", 3, 0, 5000), np.zeros(0, np.uint8)]
-    res = deflate_multi(bufs, [0] * 8, level=9)
+    res = deflate_multi(bufs, _devs(8), level=9)
     assert [r.data for r in res] == [O.deflate(b, 9) for b in bufs]
 
 
 def test_inflate_multi_roundtrip():
     from sharpziplib_amd.batch import deflate_multi, inflate_multi
     bufs = _bufs(50, 11)
-    comp = [r.data for r in deflate_multi(bufs, [0, 0, 0, 0], level=6)]
-    back = inflate_multi(comp, [b.size for b in bufs], [0, 0, 0], crc32=True)
+    comp = [r.data for r in deflate_multi(bufs, _devs(4), level=6)]
+    back = inflate_multi(comp, [b.size for b in bufs], _devs(3), crc32=True)
     for b, c, (r, consumed) in zip(bufs, comp, back):
         assert r.status == 0 and r.data == b.tobytes() and consumed == len(c) and r.crc32 == O.crc32(b)
 
@@ -67,10 +75,11 @@ def small_parts():
         _knob(k, -2147483648)
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 5])
+@pytest.mark.parametrize("ndev", [2, 3, 5])
 @pytest.mark.parametrize("kind,level", [("enwik", 6), ("logs", 9), ("dickens", 5)])
-def test_one_stream_over_several_engines_equals_oracle(small_parts, devices, kind, level):
+def test_one_stream_over_several_engines_equals_oracle(small_parts, ndev, kind, level):
     from sharpziplib_amd.batch import deflate_multi
+    devices = _devs(ndev)
     data = C.generate(kind, 0x5EED, 0, 20 << 20)
     (r,) = deflate_multi([data], devices, level=level, crc32=True)
     assert r.status == 0 and r.crc32 == O.crc32(data)
@@ -81,11 +90,11 @@ def test_one_stream_with_zlib_framing_and_strategies(small_parts):
     import zlib
     from sharpziplib_amd.batch import deflate_multi
     data = C.generate("enwik", 77, 0, 12 << 20)
-    (r,) = deflate_multi([data], [0, 0, 0], level=6, nowrap=False)
+    (r,) = deflate_multi([data], _devs(3), level=6, nowrap=False)
     assert r.status == 0 and zlib.decompress(r.data) == data.tobytes() and r.adler32 == zlib.adler32(data.tobytes())
     assert r.data[2:-4] == O.deflate(data, 6)
     for strategy in (1, 2):
-        (r,) = deflate_multi([data], [0, 0], level=6, strategy=strategy)
+        (r,) = deflate_multi([data], _devs(2), level=6, strategy=strategy)
         assert r.data == O.deflate(data, 6, strategy=strategy)
 
 
@@ -95,8 +104,35 @@ def test_one_stream_whose_parses_never_resynchronise(small_parts):
     from sharpziplib_amd.batch import deflate_multi
     data = np.concatenate([np.zeros(7 << 20, np.uint8), C.generate("logs", 5, 0, 3 << 20), np.full(6 << 20, 0x55, np.uint8),
                            C.period10(2 << 20) if hasattr(C, "period10") else np.zeros(2 << 20, np.uint8)])
-    (r,) = deflate_multi([data], [0, 0, 0, 0], level=6, crc32=True)
+    (r,) = deflate_multi([data], _devs(4), level=6, crc32=True)
     assert r.status == 0 and r.data == O.deflate(data, 6)
+
+
+def test_units_are_taken_dynamically(small_parts):
+    """more units than engines (SZL_PART_UNITS): an engine takes the next unit when it is free; the tokens are gathered in unit
+    order while later units run — same bytes whatever the number of units, two concurrent callers serialise"""
+    import threading
+    from sharpziplib_amd.batch import deflate_multi
+    data = np.concatenate([C.generate("logs", 3, 0, 9 << 20), C.generate("enwik", 4, 0, 9 << 20), np.zeros(3 << 20, np.uint8),
+                           C.generate("dickens", 5, 0, 6 << 20)])     # parts of very different cost per byte
+    want = O.deflate(data, 6)
+    for units in (1, 3, 6):
+        _knob("SZL_PART_UNITS", units)
+        try:
+            (r,) = deflate_multi([data], _devs(3), level=6, crc32=True)
+        finally:
+            _knob("SZL_PART_UNITS", -2147483648)
+        assert r.status == 0 and r.data == want and r.crc32 == O.crc32(data), units
+    got = [None, None]
+
+    def call(i):
+        got[i] = deflate_multi([data], _devs(2 + i), level=6)[0].data
+    th = [threading.Thread(target=call, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got[0] == want and got[1] == want
 
 
 def test_one_long_stream_default_knobs():
@@ -104,7 +140,7 @@ def test_one_long_stream_default_knobs():
     import hashlib
     from sharpziplib_amd.batch import Engine, deflate_multi
     data = C.generate("enwik", 0xE9, 0, 192 << 20)
-    (r,) = deflate_multi([data], [0, 0], level=6, crc32=True)
+    (r,) = deflate_multi([data], _devs(2), level=6, crc32=True)
     eng = Engine()
     (one,) = eng.deflate([data], level=6, crc32=True)
     eng.close()
