@@ -74,6 +74,11 @@ class Engine:
         _lib.check(self._L.szl_deflate_batch_device(self._h, d_in_ptr, d_out_ptr, streams, len(streams), level, strategy, flags, hip_stream),
                    "szl_deflate_batch_device")
 
+    def inflate_device(self, d_in_ptr, d_out_ptr, streams, flags=_lib.F_NOWRAP, hip_stream=0):
+        """Device-resident inflate of independent streams (szl_inflate_batch_device): per stream status / out_len / in_consumed."""
+        _lib.check(self._L.szl_inflate_batch_device(self._h, d_in_ptr, d_out_ptr, streams, len(streams), flags, hip_stream),
+                   "szl_inflate_batch_device")
+
     def timing(self):
         t = _lib.Timing()
         self._L.szl_engine_last_timing(self._h, ctypes.byref(t))

@@ -48,3 +48,62 @@ def max_over_ranks(value, dist=None, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- shard rebalance (BASELINE configs[4]: "RCCL shard rebalance") -------------------------------------------------------------
+# Ranks start with unequal work: the streams a rank holds (zip entries, gzip members, pieces of a log) differ in cost per byte —
+# level 9 on repetitive logs takes 3-4x the stage-B time of prose.  The plan keeps the global stream order and cuts
+# it into `world` contiguous runs of about equal COST; streams that change owner travel in one all-to-all of bytes (RCCL over xGMI
+# with the "nccl" backend, gloo in the CPU tests).  Nothing else is exchanged: every stream is still compressed where it lands.
+
+
+def rebalance_plan(costs_per_rank):
+    """costs_per_rank[r] = cost of every stream rank r holds, in global order.  Returns owner[g] for every global stream index g:
+    contiguous runs, run r ends where the running cost passes r+1 shares of the total."""
+    flat = [c for row in costs_per_rank for c in row]
+    world = len(costs_per_rank)
+    total = float(sum(flat))
+    owner, acc, r = [], 0.0, 0
+    for i, c in enumerate(flat):
+        # a stream goes to the run its midpoint falls into (keeps runs contiguous and never leaves a later rank empty-handed
+        # when streams remain)
+        mid = acc + c / 2.0
+        while r < world - 1 and total > 0 and mid >= total * (r + 1) / world:
+            r += 1
+        r = min(r, world - 1)
+        owner.append(r)
+        acc += c
+    return owner
+
+
+def rebalance(streams, costs, dist=None, device=None):
+    """streams: this rank's byte buffers (1-D uint8 torch tensors on `device`), costs: their estimated costs.
+    Returns [(global_index, tensor)] this rank owns after the exchange, in global order."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(enumerate(streams))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    meta = [None] * world
+    dist.all_gather_object(meta, ([int(s.numel()) for s in streams], [float(c) for c in costs]))
+    owner = rebalance_plan([m[1] for m in meta])
+    first = [0]
+    for m in meta:
+        first.append(first[-1] + len(m[0]))
+    sizes = [n for m in meta for n in m[0]]
+    # what I send to each rank / receive from each rank (whole streams, global order inside every pair)
+    send_idx = [[g for g in range(first[rank], first[rank + 1]) if owner[g] == r] for r in range(world)]
+    recv_idx = [[g for g in range(first[r], first[r + 1]) if owner[g] == rank] for r in range(world)]
+    in_split = [sum(sizes[g] for g in idx) for idx in send_idx]
+    out_split = [sum(sizes[g] for g in idx) for idx in recv_idx]
+    dev = device if device is not None else (streams[0].device if streams else "cpu")
+    parts = [streams[g - first[rank]] for idx in send_idx for g in idx]
+    send = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=dev)
+    recv = torch.empty(sum(out_split), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split)
+    out, pos = [], 0
+    for idx in recv_idx:
+        for g in idx:
+            out.append((g, recv[pos:pos + sizes[g]]))
+            pos += sizes[g]
+    out.sort(key=lambda t: t[0])
+    return out

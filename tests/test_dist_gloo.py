@@ -88,3 +88,64 @@ def test_shard_helpers():
     assert shard.shard_bytes(10 << 20, 0, 8) == (0, 2 << 20) and shard.shard_bytes(10 << 20, 7, 8) == (9 << 20, 10 << 20)
     offs, joint = shard.member_offsets([[3, 4], [5]])
     assert offs == [[0, 3], [7]] and joint == 12
+
+
+# ---- shard rebalance (sharpziplib_amd/shard.py: the RCCL all-to-all of BASELINE configs[4], gloo here) ---------------------------
+def _rebalance_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from sharpziplib_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 holds six streams, the first two of them expensive; rank 1 holds two cheap ones
+        rng = np.random.default_rng(100 + rank)
+        sizes = [5000, 7000, 300, 200, 100, 50] if rank == 0 else [400, 600]
+        costs = [9.0, 9.0, 1.0, 1.0, 1.0, 1.0] if rank == 0 else [1.0, 1.0]
+        streams = [torch.from_numpy(rng.integers(0, 256, n).astype(np.uint8)) for n in sizes]
+        mine = shard.rebalance(streams, costs, dist)
+        q.put((rank, [(g, bytes(t.numpy().tobytes())) for g, t in mine], [bytes(t.numpy().tobytes()) for t in streams]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rebalance_moves_whole_streams_by_cost():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rebalance_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, own0, orig0), (_, own1, orig1) = res
+    everything = orig0 + orig1                               # global order: rank 0's streams, then rank 1's
+    # every stream has exactly one owner afterwards, bytes unchanged, global order kept on each rank
+    got = dict(own0 + own1)
+    assert sorted(got) == list(range(8)) and all(got[g] == everything[g] for g in range(8))
+    assert [g for g, _ in own0] == sorted(g for g, _ in own0) and [g for g, _ in own1] == sorted(g for g, _ in own1)
+    # total cost 24, share 12: the second expensive stream straddles the cut with its larger half beyond it -> loads 9 / 15
+    # (keeping both on rank 0 would be 18 / 6)
+    assert [g for g, _ in own0] == [0] and [g for g, _ in own1] == [1, 2, 3, 4, 5, 6, 7]
+
+
+def test_rebalance_plan_properties():
+    sys.path.insert(0, ROOT)
+    from sharpziplib_amd import shard
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        for trial in range(20):
+            rows = [list(rng.uniform(0.1, 10.0, int(rng.integers(0, 12)))) for _ in range(world)]
+            owner = shard.rebalance_plan(rows)
+            n = sum(len(r) for r in rows)
+            assert len(owner) == n and all(0 <= o < world for o in owner) and owner == sorted(owner)   # contiguous runs in rank order
+            if n:
+                flat = [c for r in rows for c in r]
+                loads = [sum(c for c, o in zip(flat, owner) if o == r) for r in range(world)]
+                assert max(loads) <= sum(flat) / world + max(flat)          # no rank is more than one stream above its share
+    assert shard.rebalance_plan([[], []]) == []
