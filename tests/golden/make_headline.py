@@ -25,12 +25,19 @@ CASES = {
     "cfg5_logs_512m_l9": ("logs", 0x106, 0, 512 << 20, 9, 0),       # configs[4] at 1/8 size: level 9, max chains, repetitive logs
     "cfg3_4096x64k_l6": ("dickens", 0x21B0, 0, 4096 * 65536, 6, 65536),  # configs[2] at 4096 entries: many small independent streams
     "off4g_enwik_8m_l6": ("enwik", 0xE9, 7 << 20, 8 << 20, 6, 0),   # the stream placed above 2^32 in the arenas (64-bit offsets)
+    "cfg5_logs_2g_l9": ("logs", 0x106, 0, 2 << 30, 9, 0),           # configs[4] at half size: 2 GiB takes the library's default window pipeline
+    "cfg1_dickens_64m_l6": ("dickens", 0xD1CE, 0, 64 << 20, 6, 0),  # configs[0]: raw Deflater level 6 on 64 MiB of prose
 }
 
 
 def main():
     out = {"_comment": "sha256 of oracle raw-deflate outputs for the headline configs; see make_headline.py", "cases": {}}
+    path = os.path.join(HERE, "headline_golden.json")
+    if os.path.exists(path) and "--all" not in sys.argv:      # keep what is there, add what is new
+        out["cases"] = json.load(open(path))["cases"]
     for name, (kind, seed, off, n, level, entry) in CASES.items():
+        if name in out["cases"]:
+            continue
         t = time.time()
         data = C.generate(kind, seed, off, n)
         if entry:

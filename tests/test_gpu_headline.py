@@ -148,3 +148,94 @@ def test_arena_offsets_above_4gib(eng):
     finally:
         d_in.free()
         d_out.free()
+
+
+# ---- the other BASELINE configs at (or near) full size, in the driver-run suite -------------------------------------------------
+def test_config1_dickens_64mib_level6_bit_exact(eng):
+    """configs[0]: raw Deflater level 6 on 64 MiB of prose — against the oracle itself and its frozen hash."""
+    c, data = _case_input("cfg1_dickens_64m_l6")
+    got, crc = _one_stream(eng, data, c["level"])
+    assert got.size == c["out_len"] and hashlib.sha256(got.tobytes()).hexdigest() == c["out_sha256"] and crc == c["crc32"]
+    assert got.tobytes() == O.deflate(data, c["level"])
+
+
+def test_config5_2gib_level9_logs_through_the_default_window_pipeline(eng):
+    """configs[4] at half size: 2 GiB is where the library switches to the window pipeline by itself (SZL_WINDOW_FROM_KIB default;
+    side arrays for one 256 MiB window instead of ~20 bytes per input byte) — sha256 of the oracle's output, frozen."""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    c, data = _case_input("cfg5_logs_2g_l9")
+    fresh = Engine()                                   # (its side arrays are what this call needs: the module's engine keeps the 1 GiB one-piece arrays)
+    try:
+        got, crc = _one_stream(fresh, data, c["level"])
+        assert got.size == c["out_len"]
+        assert hashlib.sha256(got.tobytes()).hexdigest() == c["out_sha256"], "2 GiB, level 9, window pipeline: output differs from the oracle's"
+        assert crc == c["crc32"]
+        ws = int(_lib.lib().szl_engine_debug_workspace(fresh._h))
+        assert 0 < ws < 6 * data.size, ws             # (the one-piece run would hold ~20 bytes per input byte)
+    finally:
+        fresh.close()
+
+
+def _device_roundtrip(eng, data, sizes, level=6, check_consumed=True):
+    """deflate `sizes`-long streams cut from data on the device, inflate them back on the device with the library's default knobs,
+    compare on the host; returns (deflate device ms, inflate device ms, compressed bytes)"""
+    import hip_ffi as H
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    n = int(sum(sizes))
+    st, in_total, out_total = Engine.layout(list(sizes))
+    d_in, d_out, d_back = H.DevBuf(n + 64), H.DevBuf(out_total + 64), H.DevBuf(n + 4 * len(sizes) + 64)
+    try:
+        d_in.upload(0, data[:n])
+        eng.deflate_device(d_in.addr, d_out.addr, st, level=level, flags=_lib.F_NOWRAP | _lib.F_CRC32)
+        t_def = eng.timing()["total_ms"]
+        assert all(s.status == 0 for s in st)
+        ist = (_lib.Stream * len(sizes))()
+        oo = 0
+        for i, (s, cap) in enumerate(zip(st, sizes)):
+            ist[i].in_off, ist[i].in_len, ist[i].out_off, ist[i].out_cap = s.out_off, s.out_len, oo, cap
+            oo += (cap + 3) & ~3
+        eng.inflate_device(d_out.addr, d_back.addr, ist, flags=_lib.F_NOWRAP | _lib.F_CRC32)
+        t_inf = eng.timing()["inflate_ms"]
+        for s, t in zip(ist, st):
+            assert s.status == 0 and s.out_len == t.in_len and s.crc32 == t.crc32
+            if check_consumed:
+                assert s.in_consumed == t.out_len
+        oo = 0
+        for i, cap in enumerate(sizes):
+            got = d_back.download(oo, cap)
+            assert np.array_equal(got, data[st[i].in_off:st[i].in_off + cap]), i
+            oo += (cap + 3) & ~3
+        return t_def, t_inf, sum(int(s.out_len) for s in st)
+    finally:
+        d_in.free(); d_out.free(); d_back.free()
+
+
+def test_config4i_inflate_the_1gib_member(eng):
+    """configs[3](i): InflaterInputStream over ONE 1 GiB member, default knobs (chunk-parallel decoder): the member is the device
+    Deflater's own output for the headline stream (its sha256 is pinned above); bytes == corpus, in_consumed exact, CRC-32."""
+    c, data = _case_input("cfg2_enwik_1g_l6")
+    t_def, t_inf, comp = _device_roundtrip(eng, data, [data.size], level=6)
+    assert comp == c["out_len"]
+    assert eng._L.szl_engine_debug_par_jobs(eng._h) > 1      # the member was decoded by many wavefronts, not one
+
+
+def test_config4ii_inflate_512_members_of_4mib(eng):
+    """configs[3](ii): a .gz of many members — 2 GiB as 512 x 4 MiB members in ONE call."""
+    data = C.generate("enwik", 0xEA, 0, 512 * (4 << 20))
+    _device_roundtrip(eng, data, [4 << 20] * 512, level=6)
+
+
+def test_config3_50000_entries_round_trip(eng):
+    """configs[2] at half its entry count (the other half is the second GPU's shard): 50000 x 64 KiB entries in one call, every
+    entry back through the device Inflater; a spread of entries against the oracle."""
+    import hip_ffi as H  # noqa: F401
+    n3, esz = 50000, 65536
+    data = C.generate("enwik", 0x21B0, 0, n3 * esz)
+    _device_roundtrip(eng, data, [esz] * n3, level=6)
+    from sharpziplib_amd.batch import Engine
+    res = eng.deflate([data[i * esz:(i + 1) * esz] for i in (0, 17, 25000, n3 - 1)], level=6, crc32=True)
+    for i, r in zip((0, 17, 25000, n3 - 1), res):
+        d = data[i * esz:(i + 1) * esz]
+        assert r.data == O.deflate(d, 6) and r.crc32 == O.crc32(d)
