@@ -273,10 +273,8 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
     if ((rc = e->e.stage_out.ensure(out_total + 64))) return rc;
     // One long stream that will go through the window pipeline: the input is copied by a second host thread, 32 MiB at a time
     // on its own stream, while the engine already works on the windows that have arrived (Engine::in_ready).
-    const uint64_t window = (uint64_t)szl::knob("SZL_WINDOW_KIB", 256 * 1024) * 1024;
     const int lv = level == -1 ? 6 : level;
-    if (n_streams == 1 && lv >= 5 && window >= (uint64_t)B_TILE && streams[0].in_len > window + window / 4 &&
-        streams[0].in_len >= (uint64_t)szl::knob("SZL_WINDOW_FROM_KIB", 2048 * 1024) * 1024 && szl::knob("SZL_H2D_OVERLAP", 1)) {
+    if (Engine::uses_window_pipeline(n_streams, lv >= 5, n_streams == 1 ? streams[0].in_len : 0, nullptr) && szl::knob("SZL_H2D_OVERLAP", 1)) {
         volatile uint64_t ready = 0;
         int copy_rc = 0, dev = 0;
         (void)hipGetDevice(&dev);

@@ -161,11 +161,20 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             for (auto &r : p.reg) { r = reg_total; reg_total += p.reg_cap; }
         }
     }
-    if (single_pass && reg_total * 2 > (16ull << 30)) { // a capacity far above the real size would ask for too much staging: count first
-        if (retry) for (auto &p : ps) if (p.alive) retry->push_back(p.si);
-        return 0;
+    // Staging is sized from the CALLER's out_cap (an upper bound he chose, possibly an untrusted ISIZE trailer): a generous capacity must
+    // not turn into gigabytes of device memory, let alone fail the batch.  Above a budget — 64 symbols per compressed byte plus slack, 8 GiB
+    // at most — or when the allocation itself fails, the members go through the count-first form, which needs no such estimate.
+    if (single_pass) {
+        uint64_t in_sum = 0;
+        for (auto &p : ps) if (p.alive) in_sum += streams[p.si].in_len;
+        const uint64_t budget = std::min<uint64_t>(8ull << 30, 2 * (64 * in_sum + (uint64_t)ps.size() * 65536 * 40));
+        bool fits = reg_total * 2 <= budget;
+        if (fits && E.inf_sym.ensure(reg_total * 2 + 64)) { fits = false; set_error(""); }   // (out of memory here is not an error of the call)
+        if (!fits) {
+            if (retry) for (auto &p : ps) if (p.alive) retry->push_back(p.si);
+            return 0;
+        }
     }
-    if (single_pass && (rc = E.inf_sym.ensure(reg_total * 2 + 64))) return rc;
     // one launch of a pass over (stream, job) pairs
     struct Ref { uint32_t k, j; };
     std::vector<InfJob> jobs;

@@ -32,6 +32,7 @@ class Engine {
     int deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
                 const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st);
 
+    static bool uses_window_pipeline(size_t n_segments, bool deflate_slow, uint64_t stream_len, uint64_t *window_out);   // (see szl_engine.hip)
     // One long stream (a single segment, levels 5-9) as a software pipeline of windows: stages A-C run window by window on
     // side arrays sized for ONE window — the parse of a window starts at the clean iteration the previous one ended on — and
     // stage D runs once over the whole token stream.  Output is bit-identical to deflate()'s (tests force tiny windows).

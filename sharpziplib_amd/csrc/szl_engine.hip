@@ -198,6 +198,18 @@ template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipS
     return 0;
 }
 
+// THE decision "this call goes through the window pipeline" — Engine::deflate takes it, and szl_deflate_batch_host asks the same
+// function before it starts the overlapped host->device copy (only deflate_windowed waits for Engine::in_ready: two copies of
+// the predicate that drift apart would let the one-piece form read bytes that have not arrived).
+// (from SZL_WINDOW_FROM_KIB of input on — 2 GiB by default: below that the 19 B per byte of the one-pass form fit easily and it is
+// ~10 % faster, profiles/r02/bench_windowed_vs_monolithic.txt; 0 = as soon as the stream is longer than a window)
+bool Engine::uses_window_pipeline(size_t n_segments, bool deflate_slow, uint64_t stream_len, uint64_t *window_out) {
+    const uint64_t window = (uint64_t)knob("SZL_WINDOW_KIB", 256 * 1024) * 1024;
+    const uint64_t from = (uint64_t)knob("SZL_WINDOW_FROM_KIB", 2048 * 1024) * 1024;
+    if (window_out) *window_out = window / B_TILE * B_TILE;
+    return n_segments == 1 && deflate_slow && window >= (uint64_t)B_TILE && stream_len > window + window / 4 && stream_len >= from;
+}
+
 int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
                     const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st) {
     const uint32_t nseg = (uint32_t)segs.size();
@@ -205,13 +217,9 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if (nseg == 0) return 0;
     for (auto &s : segs) if (s.look_end < s.seg_end) s.look_end = s.seg_end;
     {   // a single long stream at a DeflateSlow level goes through the window pipeline (workspace of one window, not of the stream)
-        // (from SZL_WINDOW_FROM_KIB of input on — 2 GiB by default: below that the 19 B per byte of the one-pass form fit easily and
-        // it is ~10 % faster, profiles/r02/bench_windowed_vs_monolithic.txt; 0 = as soon as the stream is longer than a window)
-        const uint64_t window = (uint64_t)knob("SZL_WINDOW_KIB", 256 * 1024) * 1024;
-        const uint64_t from = (uint64_t)knob("SZL_WINDOW_FROM_KIB", 2048 * 1024) * 1024;
-        const uint64_t slen = (uint64_t)(segs[0].seg_end - segs[0].seg_start);
-        if (nseg == 1 && !P.fast && window >= (uint64_t)B_TILE && slen > window + window / 4 && slen >= from)
-            return deflate_windowed(d_in, in_total, d_out, out_total, segs[0], bnds, P, want_ck, results, st, window / B_TILE * B_TILE);
+        uint64_t window = 0;
+        if (uses_window_pipeline(nseg, !P.fast, (uint64_t)(segs[0].seg_end - segs[0].seg_start), &window))
+            return deflate_windowed(d_in, in_total, d_out, out_total, segs[0], bnds, P, want_ck, results, st, window);
     }
     memset(&timing, 0, sizeof timing);
     for (auto &e : ev) if (!e) HIPCHK(hipEventCreate(&e));

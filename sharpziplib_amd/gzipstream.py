@@ -280,15 +280,35 @@ def parse_member_header(buf, pos=0):
         raise GZipException("Reserved flag bits in GZIP header != 0")
     p = pos + 10
     name = None
+
+    def need(k):                                   # the streaming reader raises EOFError on a truncated header (ReadHeader :203-291)
+        if len(b) - p < k:
+            raise EOFError("EOS reading GZIP header")
+
+    def cstring():                                 # a zero-terminated field: searched 64 KiB at a time, never by copying the member
+        q = p
+        while True:
+            chunk = bytes(b[q:q + 65536])
+            if not chunk:
+                raise EOFError("EOS reading GZIP header")
+            k = chunk.find(b"\0")
+            if k >= 0:
+                return q + k
+            q += len(chunk)
     if flags & FEXTRA:
-        p += 2 + (b[p] | (b[p + 1] << 8))
+        need(2)
+        xlen = b[p] | (b[p + 1] << 8)
+        p += 2
+        need(xlen)
+        p += xlen
     if flags & FNAME:
-        e = bytes(b[p:]).index(b"\0") + p
+        e = cstring()
         name = bytes(b[p:min(e, p + 1024)]).decode("latin-1")
         p = e + 1
     if flags & FCOMMENT:
-        p = bytes(b[p:]).index(b"\0") + p + 1
+        p = cstring() + 1
     if flags & FHCRC:
+        need(2)
         v = (b[p] << 8) | b[p + 1]
         if v != (_crc32(0, bytes(b[pos:p])) & 0xFFFF):
             raise GZipException("Header CRC value mismatch")
@@ -299,7 +319,8 @@ def parse_member_header(buf, pos=0):
 def read_members(members, sizes=None, engine=None):
     """Reader fast path for independent members (one per buffer, e.g. the parts of a multi-member archive whose offsets are
     known): headers on the host, ALL members through one szl_inflate_batch_host call with CRC-32 on device, trailers checked
-    like ReadFooter.  `sizes[i]` bounds member i's output; default: ISIZE of its trailer (valid below 4 GiB).
+    like ReadFooter.  `sizes[i]` bounds member i's output; default: ISIZE of its trailer (valid below 4 GiB), clamped to what
+    its compressed bytes can expand to.
     Returns [(data, file name)]."""
     from .batch import Engine
     eng = engine or Engine()
@@ -308,7 +329,8 @@ def read_members(members, sizes=None, engine=None):
         start, name = parse_member_header(m)
         bodies.append(np.frombuffer(m, dtype=np.uint8)[start:])
         names.append(name)
-        caps.append(sizes[i] if sizes else int.from_bytes(bytes(m[-4:]), "little"))
+        # default bound: the trailer's ISIZE — untrusted, so never more than DEFLATE can expand the member's bytes to (1032:1)
+        caps.append(sizes[i] if sizes else min(int.from_bytes(bytes(m[-4:]), "little"), 1032 * (len(m) - start) + 1024))
     res = eng.inflate(bodies, caps, nowrap=True, crc32=True)
     out = []
     for i, ((r, consumed), body) in enumerate(zip(res, bodies)):
