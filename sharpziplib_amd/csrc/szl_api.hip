@@ -605,9 +605,18 @@ int szl_engine_debug_fetch(szl_engine *e, uint16_t *link, uint32_t *m2, uint32_t
             if (mq) memset(mq, 0, n * 4);
             m2 = mq = nullptr;
         }
+        // the device keeps packed entries (szl_internal.h): the tap hands out what they mean — M2 and Mq as len | dist<<16
         const uint32_t *dm = (const uint32_t *)E.mtab.p;
-        if (m2 && hipMemcpy(m2, dm, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
-        if (mq && hipMemcpy(mq, dm + E.last_mt_stride, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+        if (m2 || mq) {
+            std::vector<uint32_t> pk(n), side(mq ? n : 0);
+            if (hipMemcpy(pk.data(), dm, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+            if (mq && hipMemcpy(side.data(), dm + E.last_mt_stride, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t e = pk[i];
+                if (m2) m2[i] = e == M_UNSET ? e : mt_m2(e);
+                if (mq) mq[i] = e == M_UNSET ? e : (mt_code(e) == 0u ? mt_m2(e) : (mt_code(e) == 1u ? 0u : side[i]));
+            }
+        }
     }
     size_t nt = std::min<size_t>(tok_cap, (size_t)E.timing.tokens);
     if (tokens && nt && hipMemcpy(tokens, E.tokens.p, nt * 4, hipMemcpyDeviceToHost) != hipSuccess) return SZL_E_DEVICE;

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
         if ((ni >= F_THRESH && !exhausted) || (nq == 0 && nv == 0)) {
             // ---------------- FETCH: retire finished positions and hand out new ones
             if (mode == DONE) {
-                { mt2[t0 + p] = res2; mtq[t0 + p] = resq; }
+                { const uint32_t e_ = mt_pack(res2, resq); mt2[t0 + p] = e_; if (e_ >> 25) mtq[t0 + p] = resq; }
                 mode = NEED;
             }
             if (!exhausted) {
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
                             mode = QUICK;
                         }
                     }
-                    if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
+                    if (!ok) mt2[t0 + p] = 0u;
                 }
                 wnext = wnext + ni < wend ? wnext + ni : wend;
             }
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
                 const int s_p = __shfl_down(p, 1);
                 const bool ready = head && mode == DONE && (s_mode == DONE || s_mode == NEED);
                 const bool h_ready = __shfl((int)ready, lane & ~1) != 0;
-                if (h_ready && mode == DONE) { mt2[t0 + p] = res2; mtq[t0 + p] = resq; }
+                if (h_ready && mode == DONE) { const uint32_t e_ = mt_pack(res2, resq); mt2[t0 + p] = e_; if (e_ >> 25) mtq[t0 + p] = resq; }
                 if (ready) {
                     const int x = p;
                     nx = consume(x, res2, resq, wL);
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
                 }
                 if (h_ready) mode = NEED;
             } else if (mode == DONE) {
-                mt2[t0 + p] = res2; mtq[t0 + p] = resq;
+                const uint32_t e_ = mt_pack(res2, resq); mt2[t0 + p] = e_; if (e_ >> 25) mtq[t0 + p] = resq;
                 nx = consume(p, res2, resq, wL);
                 mode = NEED;
                 if (nx >= tlen) { nx = -1; wL = 0; } // the walker leaves the tile (its continuation belongs to the next tile's walkers)

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
 
     auto wave_min = [&](int v) { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; };
     auto retire = [&](WalkCtx8 &C, uint64_t &dm) {
-        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[origin + C.pg] = C.res2; mtq[origin + C.pg] = C.resq; }
+        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { const uint32_t e = mt_pack(C.res2, C.resq); mt2[origin + C.pg] = e; if (e >> 25) mtq[origin + C.pg] = C.resq; }
         dm = 0;
     };
     // start walks on the free lanes of a context with the positions [wnext, lim)
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
                     toverify = true;
                 }
             }
-            if (!ok) { mt2[pos] = 0u; mtq[pos] = 0u; }
+            if (!ok) mt2[pos] = 0u;
         }
         v |= __ballot(toverify);
         wnext = wnext + ni < lim ? wnext + ni : lim;

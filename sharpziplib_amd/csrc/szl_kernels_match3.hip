@@ -355,7 +355,7 @@ __global__ __launch_bounds__(B6_THREADS) void k_match6(const uint8_t *__restrict
 
     // FETCH: the first candidate compared is e3 (see the head of the file); hashHead itself only decides whether there is a search.
     auto fetch = [&](WalkCtx6 &C, uint64_t &q, uint64_t &v, uint64_t &dm) {
-        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { mt2[t0 + C.p] = C.res2; mtq[t0 + C.p] = C.resq; }
+        if (__builtin_amdgcn_inverse_ballot_w64(dm)) { const uint32_t e = mt_pack(C.res2, C.resq); mt2[t0 + C.p] = e; if (e >> 25) mtq[t0 + C.p] = C.resq; }
         dm = 0;
         if (exhausted) return;
         const uint64_t idle = ~(q | v);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(B6_THREADS) void k_match6(const uint8_t *__restrict
                     toverify = true;
                 }
             }
-            if (!ok) { mt2[t0 + p] = 0u; mtq[t0 + p] = 0u; }
+            if (!ok) mt2[t0 + p] = 0u;
         }
         v |= __ballot(toverify);
         wnext = wnext + ni < wend ? wnext + ni : wend;

@@ -631,7 +631,9 @@ __global__ __launch_bounds__(B5_THREADS) void k_match5(const uint8_t *__restrict
                 const uint32_t r = RANK[rel];
                 uint2 v = make_uint2(0, 0);
                 if (r != 0xFFFFFFFFu) v = RES[r];
-                m2o[rel] = v.x; mqo[rel] = v.y;
+                const uint32_t e = mt_pack(v.x, v.y);
+                m2o[rel] = e;
+                if (e >> 25) mqo[rel] = v.y;
             }
         }
     }

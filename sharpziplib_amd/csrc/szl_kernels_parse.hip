@@ -117,8 +117,9 @@ __device__ void eval_global(const ParseCtx &c, int64_t p, uint32_t &m2, uint32_t
 // staged in LDS (WinAcc, k_spec_win / k_emit_win).
 struct GlobalAcc {
     const uint32_t *m2p, *mqp; const uint8_t *dp;
-    __device__ __forceinline__ uint32_t m2(int64_t x) const { return m2p[x]; }
-    __device__ __forceinline__ uint32_t mq(int64_t x) const { return mqp[x]; }
+    // (entries are packed, szl_internal.h: M2 in the word itself, Mq by its code — the same, empty, or in the mq array)
+    __device__ __forceinline__ uint32_t m2(int64_t x) const { const uint32_t e = m2p[x]; return e == M_UNSET ? e : mt_m2(e); }
+    __device__ __forceinline__ uint32_t mq(int64_t x) const { const uint32_t e = m2p[x]; const uint32_t k = mt_code(e); return k == 0u ? mt_m2(e) : (k == 1u ? 0u : mqp[x]); }
     __device__ __forceinline__ uint32_t lit(int64_t x) const { return dp[x]; }
 };
 
@@ -503,9 +504,9 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t 
 template <int W> struct WinCfg { enum : int { STRIDE = W + 1, BSTRIDE = W + 8 }; };
 
 struct WinAcc {
-    const uint32_t *m2p, *mqp; const uint8_t *bp; int64_t w0; // bp[0] is the byte at w0-1
-    __device__ __forceinline__ uint32_t m2(int64_t x) const { return m2p[(int)(x - w0)]; }
-    __device__ __forceinline__ uint32_t mq(int64_t x) const { return mqp[(int)(x - w0)]; }
+    const uint32_t *m2p, *mqg; const uint8_t *bp; int64_t w0; // m2p: the staged window of packed entries; mqg: the GLOBAL mq array (read only where an entry says so); bp[0] is the byte at w0-1
+    __device__ __forceinline__ uint32_t m2(int64_t x) const { const uint32_t e = m2p[(int)(x - w0)]; return e == M_UNSET ? e : mt_m2(e); }
+    __device__ __forceinline__ uint32_t mq(int64_t x) const { const uint32_t e = m2p[(int)(x - w0)]; const uint32_t k = mt_code(e); return k == 0u ? mt_m2(e) : (k == 1u ? 0u : mqg[x]); }
     __device__ __forceinline__ uint32_t lit(int64_t x) const { return bp[(int)(x - w0) + 1]; }
 };
 
@@ -521,24 +522,22 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 
 // Stage the window [x, x+W) of every active lane: one load instruction covers 64/W windows.
 template <int W, bool WITH_BYTES>
-__device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool active, int lane, uint32_t *sm2, uint32_t *smq, uint8_t *sb) {
+__device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool active, int lane, uint32_t *sm2, uint8_t *sb) {
     constexpr int PER = 64 / W;          // windows per load instruction
     constexpr int STRIDE = WinCfg<W>::STRIDE, BSTRIDE = WinCfg<W>::BSTRIDE;
     const int64_t navail = active ? c.tab_end - x : 0; // entries valid from x on
-    const int64_t pm_l = (int64_t)(c.m2 + x), pq_l = (int64_t)(c.mq + x), pd_l = (int64_t)(c.d + x) - 1;
+    const int64_t pm_l = (int64_t)(c.m2 + x), pd_l = (int64_t)(c.d + x) - 1;
     const int sub = lane / W, i = lane % W;
     constexpr int BATCH = 8;
     for (int kb = 0; kb < W; kb += BATCH) { // W instructions per array, BATCH of them in flight
-        uint32_t v[BATCH], q[BATCH], bv[BATCH], be[BATCH];
+        uint32_t v[BATCH], bv[BATCH], be[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
             const int j = (kb + u) * PER + sub;
             const int64_t nv = shfl64(navail, j);
             const uint32_t *pm = (const uint32_t *)shfl64(pm_l, j);
-            const uint32_t *pq = (const uint32_t *)shfl64(pq_l, j);
             const bool ok = (int64_t)i < nv;
             v[u] = ok ? pm[i] : 0u;
-            q[u] = ok ? pq[i] : 0u;
             if (WITH_BYTES) {
                 const uint8_t *pd = (const uint8_t *)shfl64(pd_l, j);
                 const int64_t xj = shfl64(x, j);
@@ -550,7 +549,6 @@ __device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool ac
         for (int u = 0; u < BATCH; u++) {
             const int j = (kb + u) * PER + sub;
             sm2[j * STRIDE + i] = v[u];
-            smq[j * STRIDE + i] = q[u];
             if (WITH_BYTES) {
                 sb[j * BSTRIDE + i] = (uint8_t)bv[u];
                 if (i == 0) sb[j * BSTRIDE + W] = (uint8_t)be[u];
@@ -565,7 +563,6 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
                                                  uint32_t *visited, unsigned long long *counters, uint32_t *spec_tok) {
     constexpr int STRIDE = WinCfg<W>::STRIDE;
     __shared__ uint32_t sm2[64 * STRIDE];
-    __shared__ uint32_t smq[64 * STRIDE];
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * 64 + lane;
     const bool mine = r0 < nranges;
@@ -586,10 +583,10 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
     uint32_t acc = 0;
     if (x >= re) active = false;
     while (__any(active)) {
-        win_refill<W, false>(c, x, active, lane, sm2, smq, nullptr);
+        win_refill<W, false>(c, x, active, lane, sm2, nullptr);
         __syncthreads();
         uint32_t *win = sm2 + lane * STRIDE;
-        const WinAcc wa{win, smq + lane * STRIDE, nullptr, x};
+        const WinAcc wa{win, c.mq, nullptr, x};
         const int64_t wend = x + W;
         int nt = 0;
         while (active && x < wend) {
@@ -629,7 +626,6 @@ __global__ __launch_bounds__(64) void k_emit_win(const uint8_t *in, const uint16
                                                  const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos) {
     constexpr int STRIDE = WinCfg<W>::STRIDE, BSTRIDE = WinCfg<W>::BSTRIDE;
     __shared__ uint32_t sm2[64 * STRIDE];
-    __shared__ uint32_t smq[64 * STRIDE];
     __shared__ uint8_t sb[64 * BSTRIDE];
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * 64 + lane;
@@ -649,10 +645,10 @@ __global__ __launch_bounds__(64) void k_emit_win(const uint8_t *in, const uint16
     int64_t tp;
     if (x >= re) active = false;
     while (__any(active)) {
-        win_refill<W, true>(c, x, active, lane, sm2, smq, sb);
+        win_refill<W, true>(c, x, active, lane, sm2, sb);
         __syncthreads();
         uint32_t *win = sm2 + lane * STRIDE;
-        const WinAcc wa{win, smq + lane * STRIDE, sb + lane * BSTRIDE, x};
+        const WinAcc wa{win, c.mq, sb + lane * BSTRIDE, x};
         const int64_t wend = x + W;
         int nt = 0;
         while (active && x < wend) {
