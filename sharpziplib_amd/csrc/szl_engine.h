@@ -45,6 +45,11 @@ class Engine {
     // parses a warm-up stretch [warm_from, first) from an assumed clean state first and drops those tokens — two parses that are
     // clean at the same position are identical from there on, so the entry it arrives at (`entry`) is the true one iff the
     // previous part's parse leaves on it (`exit`); the caller checks that and re-runs a part with force_entry otherwise.
+    int deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
+                     const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st);
+    int deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
+                              const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st,
+                              uint64_t window);
     struct PartRun {
         bool active = false;
         int64_t first = 0, parse_end = 0;      // buffer positions

@@ -14,7 +14,16 @@ namespace szl {
 
 // ---- launch wrappers implemented in the kernel translation units
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans, int nspans,
-                  uint16_t *link, const uint32_t *hflags, hipStream_t st);
+                  uint16_t *link, const uint32_t *hflags, unsigned long long *guard_flag, uint64_t span_bytes, hipStream_t st);
+void links_distrust_ticket_form();
+enum : int { CNT_WORDS = 64, CNT_LINKS_GUARD = 32 };   // counters: 64 x u64; [32] = links the per-call guard found wrong (szl_kernels_match.hip)
+enum : int { SZL_I_RETRY_LINKS = -1000 };             // internal: run the call again (the ticket form of stage A is distrusted from now on)
+static int links_guard_tripped() {
+    links_distrust_ticket_form();
+    fprintf(stderr, "[szl] stage A: the per-call guard found a link k_links3 got wrong (LDS exchange order under load); this process uses the "
+                    "bucketed form (k_links2) from now on and the call is run again\n");
+    return SZL_I_RETRY_LINKS;
+}
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
 #if SZL_LAB   // laboratory forms of the full search (libszl_amd_lab.so only; Makefile)
@@ -212,6 +221,22 @@ bool Engine::uses_window_pipeline(size_t n_segments, bool deflate_slow, uint64_t
 
 int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
                     const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st) {
+    const std::vector<SegDev> segs0 = segs;
+    int rc = deflate_impl(d_in, in_total, d_out, out_total, segs, bnds, P, want_ck, results, st);
+    if (rc == SZL_I_RETRY_LINKS) { segs = segs0; rc = deflate_impl(d_in, in_total, d_out, out_total, segs, bnds, P, want_ck, results, st); }
+    return rc == SZL_I_RETRY_LINKS ? SZL_E_STATE : rc;
+}
+int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
+                             const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st,
+                             uint64_t window) {
+    const PartRun part0 = part;
+    int rc = deflate_windowed_impl(d_in, in_total, d_out, out_total, seg, bnds, P, want_ck, results, st, window);
+    if (rc == SZL_I_RETRY_LINKS) { part = part0; rc = deflate_windowed_impl(d_in, in_total, d_out, out_total, seg, bnds, P, want_ck, results, st, window); }
+    return rc == SZL_I_RETRY_LINKS ? SZL_E_STATE : rc;
+}
+
+int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, std::vector<SegDev> &segs,
+                         const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st) {
     const uint32_t nseg = (uint32_t)segs.size();
     results.assign(nseg, SegOut{});
     if (nseg == 0) return 0;
@@ -343,7 +368,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     if ((rc = blk_off.ensure((nseg + 2) * 8))) return rc;
     if ((rc = bsp.ensure((blk_slots + 1) * 8))) return rc;
     if ((rc = blp.ensure((blk_slots + 1) * 8))) return rc;
-    if ((rc = counters.ensure(256))) return rc;
+    if ((rc = counters.ensure(CNT_WORDS * 8))) return rc;
     if (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) return rc;
     if ((rc = upload(d_segs, segs, st))) return rc;
     if ((rc = upload(d_bnds, bnds, st))) return rc;
@@ -365,7 +390,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipEventRecord(ev[0], st));
     launch_zero_regions(dsegs, nseg, (const uint64_t *)d_zoff.p, nzero, d_out, st); // only the streams' own regions (szl.h)
     HIPCHK(hipMemsetAsync(visited.p, 0, (vis_words + 4) * 4, st));
-    HIPCHK(hipMemsetAsync(counters.p, 0, 256, st));
+    HIPCHK(hipMemsetAsync(counters.p, 0, CNT_WORDS * 8, st));
     HIPCHK(hipMemsetAsync(d_so.p, 0, nseg * sizeof(SegOut), st));
     HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
     HIPCHK(hipMemsetAsync(blk_counts.p, 0, (nseg + 2) * 4, st));
@@ -394,7 +419,7 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
         if ((rc = upload(hist_flags_dev, hf, st))) return rc;
         d_hflags = (const uint32_t *)hist_flags_dev.p;
     }
-    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, d_hflags, st);
+    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, d_hflags, dcnt + CNT_LINKS_GUARD, total_emit, st);
     HIPCHK(hipEventRecord(ev[2], st));
     if (fast) {
         // B+C for DeflateFast: sequential greedy parse, one wavefront per segment (szl_kernels_fast.hip)
@@ -525,9 +550,10 @@ int Engine::deflate(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint
     HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results.data(), d_so.p, nseg * sizeof(SegOut), hipMemcpyDeviceToHost, st));
-    unsigned long long hc[32] = {0};
+    unsigned long long hc[CNT_LINKS_GUARD + 1] = {0};
     HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (hc[CNT_LINKS_GUARD]) return links_guard_tripped();
 
     float ms[6] = {0};
     for (int i = 0; i < 6; i++) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
@@ -599,7 +625,7 @@ static int grow_preserve(DevBuf &b, size_t need, size_t used, hipStream_t st) { 
     return 0;
 }
 
-int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
+int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out, uint64_t out_total, SegDev seg,
                              const std::vector<uint64_t> &bnds, LevelParams P, unsigned want_ck, std::vector<SegOut> &results, hipStream_t st,
                              uint64_t window) {
     (void)out_total;
@@ -620,7 +646,7 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
     std::vector<uint64_t> chunk_off{0, nchunks}, zero_off{0, (seg.out_cap + (uint64_t)zero_piece_bytes() - 1) / (uint64_t)zero_piece_bytes()};
     std::vector<uint64_t> fixed_blk_off{0, blk_slots};
     if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc))) || (rc = d_so.ensure(2 * sizeof(SegOut))) || (rc = blk_counts.ensure(16)) ||
-        (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(256)) ||
+        (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(CNT_WORDS * 8)) ||
         (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) ||
         (rc = upload(d_bnds, bnds, st)) || (rc = upload(ckoff, chunk_off, st)) || (rc = upload(d_zoff, zero_off, st)) || (rc = upload(blk_off, fixed_blk_off, st)))
         return rc;
@@ -638,7 +664,7 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
     };
     if (!is_part) launch_zero_regions(dseg_real, 1, (const uint64_t *)d_zoff.p, zero_off[1], d_out, st);
     HIPCHK(hipMemsetAsync(d_so.p, 0, 2 * sizeof(SegOut), st));
-    HIPCHK(hipMemsetAsync(counters.p, 0, 256, st));
+    HIPCHK(hipMemsetAsync(counters.p, 0, CNT_WORDS * 8, st));
     const bool forked = want_ck && !in_ready && !is_part;          // (with an overlapped copy the checksums run at the end, when all bytes are there)
     if (is_part) {
     } else if (forked) {
@@ -721,7 +747,7 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         HIPCHK(hipMemsetAsync(counters.p, 0, 8, st));             // counter 0: ranges of THIS window that never merged
         HIPCHK(hipEventRecord(ev[1], st));
         // the launch wrappers index segs[span.seg] / segs[tile.seg]: entry 1 of d_segs is the window
-        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, nullptr, st);
+        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, nullptr, dcnt + CNT_LINKS_GUARD, (uint64_t)(hi - lo), st);
         HIPCHK(hipEventRecord(ev[2], st));
         if (wi == 0 && match_mode == 2 && ntiles >= 64 && !warming) { // the pilot (see deflate()): once, on the first window
             const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8));
@@ -764,7 +790,9 @@ int Engine::deflate_windowed(const uint8_t *d_in, uint64_t in_total, uint8_t *d_
         launch_spec(d_in, lk, mt, dseg_win, 1, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, stok, st);
         launch_fix(d_in, lk, mt, dseg_win, 1, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
         HIPCHK(hipMemcpyAsync(pin, counters.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(pin + 8, (unsigned long long *)counters.p + CNT_LINKS_GUARD, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (*(volatile unsigned long long *)(pin + 8)) return links_guard_tripped();      // (the window's links: see launch_links)
         const unsigned long long nbad = *(volatile unsigned long long *)pin;
         total_unmerged += nbad;
         if (nbad > 0 && lazy) HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mt, P, dcnt, st));
@@ -866,7 +894,7 @@ int Engine::finish_tokens(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out
     std::vector<uint64_t> chunk_off{0, nchunks}, zero_off{0, (seg.out_cap + (uint64_t)zero_piece_bytes() - 1) / (uint64_t)zero_piece_bytes()};
     std::vector<uint64_t> fixed_blk_off{0, blk_slots};
     if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc))) || (rc = d_so.ensure(2 * sizeof(SegOut))) || (rc = blk_counts.ensure(16)) ||
-        (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(256)) ||
+        (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(CNT_WORDS * 8)) ||
         (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes())) || (rc = cubtmp.ensure((blk_slots + 1) * 12 + 256)) ||
         (rc = upload(ckoff, chunk_off, st)) || (rc = upload(d_zoff, zero_off, st)) || (rc = upload(blk_off, fixed_blk_off, st)) ||
         (rc = d_segs.ensure(2 * sizeof(SegDev))))

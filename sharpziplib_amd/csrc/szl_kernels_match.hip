@@ -318,20 +318,23 @@ enum : int { A3_U = 4 };   // 64-position slices per ticket: a ticket covers 256
 
 typedef __attribute__((address_space(3))) uint8_t a3_lds_u8;
 
-// One wavefront, `rounds` patterns: lane l exchanges (l + 1) into slot[pat(l)]; ok unless some lane got something else than
-// "the lane below with my slot" or a slot does not end up holding its highest lane.
-__global__ __launch_bounds__(64) void k_probe_xchg_order(int rounds, int *ok_out) {
-    __shared__ uint32_t slot[64];
-    const int lane = threadIdx.x;
+// `rounds` patterns: lane l exchanges (l + 1) into slot[pat(l)]; ok unless some lane got something else than "the lane below with my
+// slot" or a slot does not end up holding its highest lane.  The probe runs the way k_links3 does: SIXTEEN wavefronts of one
+// workgroup exchange into the same LDS at the same time (each into its own 64 slots, so that every wave can check what it received) —
+// an idle LDS unit serving one wave in lane order proves nothing about a busy one.
+__global__ __launch_bounds__(A_THREADS) void k_probe_xchg_order(int rounds, int *ok_out) {
+    __shared__ uint32_t slots[A_WAVES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *slot = slots + wave * 64;
     const uint32_t base = (uint32_t)(uintptr_t)(a3_lds_u8 *)slot;
     int ok = 1;
-    uint32_t rng = 0x9E3779B9u * (uint32_t)(lane + 1);
+    uint32_t rng = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1);
     for (int r = 0; r < rounds; r++) {
         slot[lane] = 0;
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         rng = rng * 1664525u + 1013904223u;
         uint32_t h;
-        switch (r & 7) {
+        switch ((r + wave) & 7) {                                  // (the waves run different patterns at the same time)
             case 0: h = 0; break;                                  // every lane the same slot
             case 1: h = (uint32_t)lane >> 1; break;                // neighbours in pairs
             case 2: h = (uint32_t)lane & 1; break;                 // two interleaved chains
@@ -353,8 +356,51 @@ __global__ __launch_bounds__(64) void k_probe_xchg_order(int rounds, int *ok_out
         if (got != want || slot[h] != last) ok = 0;
         __builtin_amdgcn_wave_barrier();
     }
-    const int all = __builtin_popcountll(__ballot(ok != 0)) == 64;
-    if (lane == 0) *ok_out = all;
+    const int all = __syncthreads_and(ok != 0);
+    if (threadIdx.x == 0) *ok_out = all;
+}
+
+// The guard of every call: the probe above is evidence, not a guarantee, and the product's tolerance is 0.  One wavefront per
+// SAMPLED position recomputes that position's link from first principles — scan backwards for the nearest inserted position with
+// the same hash, 64 candidates per step — and raises *flag if k_links3 stored something else.  The engine reads the flag with the
+// counters it reads anyway, distrusts the ticket form from then on (k_links2 needs no ordering assumption) and runs the call again.
+__global__ __launch_bounds__(64) void k_links_guard(const uint8_t *__restrict__ in, uint64_t in_total, const SegDev *__restrict__ segs,
+                                                    const uint64_t *__restrict__ bnds, const SpanDev *__restrict__ spans, int nspans,
+                                                    const uint16_t *__restrict__ link, const uint32_t *__restrict__ hflags,
+                                                    unsigned long long *flag) {
+    const int lane = threadIdx.x;
+    const uint32_t sidx = blockIdx.x;
+    const SpanDev span = spans[(uint32_t)(((uint64_t)sidx * 2654435761u) >> 7) % (uint32_t)nspans];
+    const SegDev seg = segs[span.seg];
+    const uint8_t *d = in + seg.buf_off;
+    const uint64_t avail = in_total - seg.buf_off;
+    const uint64_t *b = bnds + seg.bnd_off;
+    const int nb = (int)seg.bnd_cnt;
+    if (nb > 64 || span.end <= span.start) return;                // (a stream flushed hundreds of times inside one window: not sampled)
+    const int64_t q = span.start + (int64_t)((((uint64_t)sidx + 1) * 0x9E3779B97F4A7C15ull) >> 20) % (span.end - span.start);
+    auto inserted = [&](int64_t x) -> bool {                      // InsertString ran at x: three bytes of lookahead in front of the next boundary
+        if (x < 0) return false;
+        int j = 0;
+        while (j < nb && (int64_t)b[j] <= x) j++;
+        if (j >= nb || (int64_t)b[j] - x < 3) return false;
+        if (hflags && x < seg.seg_start) return (hflags[x >> 5] >> (x & 31)) & 1u;
+        return true;
+    };
+    auto hash_at = [&](int64_t x) -> uint32_t {
+        if ((uint64_t)x + 3 > avail) return 0xFFFFFFFFu;
+        return (((uint32_t)d[x] << 10) ^ ((uint32_t)d[x + 1] << 5) ^ d[x + 2]) & 0x7FFFu;
+    };
+    uint32_t want = 0;
+    if (inserted(q)) {
+        const uint32_t hq = hash_at(q);
+        for (int64_t base = 1; base <= 32767; base += 64) {
+            const int64_t dist = base + lane, x = q - dist;
+            const bool hit = dist <= 32767 && x >= 0 && inserted(x) && hash_at(x) == hq;
+            const uint64_t m = __ballot(hit);
+            if (m) { want = (uint32_t)(base + __builtin_ctzll(m)); break; }
+        }
+    }
+    if (lane == 0 && (uint32_t)link[seg.buf_off + q] != want) atomicAdd(flag, 1ull);
 }
 
 __global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict__ in, uint64_t in_total,
@@ -976,16 +1022,21 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
 }
 
 // hflags (optional, single streaming segment): bit q = buffer position q of the history was inserted into the hash chains
+static std::atomic<int> g_links3_distrusted{0};   // the guard caught k_links3 storing a wrong link: this process uses k_links2 from then on
+void links_distrust_ticket_form() { g_links3_distrusted.store(1, std::memory_order_release); }
+bool links_ticket_form_distrusted() { return g_links3_distrusted.load(std::memory_order_acquire) != 0; }
+
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
-                  int nspans, uint16_t *link, const uint32_t *hflags, hipStream_t st) {
+                  int nspans, uint16_t *link, const uint32_t *hflags, unsigned long long *guard_flag, uint64_t span_bytes, hipStream_t st) {
     if (nspans <= 0) return;
-    const int which = knob("SZL_LINKS", 3);   // 3 = pipelined (ticket) form, 2 = bucketed by owner wavefront, 1 = first form
+    int which = knob("SZL_LINKS", 3);   // 3 = pipelined (ticket) form, 2 = bucketed by owner wavefront, 1 = first form
+    if (which == 3 && links_ticket_form_distrusted()) which = 2;
     static std::atomic<uint64_t> probe_done{0}, probe_ok{0};   // per device: does ds_wrxchg serve the lanes in ascending order?
     uint64_t dev_bit = 0;
     if (which == 3 && lds_attr_needed(probe_done, dev_bit)) {
         int *d_ok = nullptr, h_ok = 0;
         if (hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess) {
-            hipLaunchKernelGGL(k_probe_xchg_order, dim3(1), dim3(64), 0, st, 512, d_ok);
+            hipLaunchKernelGGL(k_probe_xchg_order, dim3(1), dim3(A_THREADS), 0, st, 512, d_ok);
             if (hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) h_ok = 0;
             (void)hipFree(d_ok);
         }
@@ -996,6 +1047,13 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
     }
     if (which == 3 && (probe_ok.load(std::memory_order_acquire) & dev_bit)) {
         hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link, hflags);
+        if (guard_flag && knob("SZL_LINKS_GUARD", 1)) {           // one sampled position per 4 MiB, 8..256 of them
+            const int lab_break = knob("SZL_LINKS_GUARD_TEST", 0);   // (tests: pretend a mismatch, to exercise the fallback)
+            uint64_t ns = span_bytes >> 22;
+            ns = ns < 8 ? 8 : (ns > 256 ? 256 : ns);
+            hipLaunchKernelGGL(k_links_guard, dim3((unsigned)ns), dim3(64), 0, st, in, in_total, segs, bnds, spans, nspans, (const uint16_t *)link, hflags, guard_flag);
+            if (lab_break) (void)hipMemsetAsync(guard_flag, 1, 1, st);
+        }
         return;
     }
 #if SZL_LAB
