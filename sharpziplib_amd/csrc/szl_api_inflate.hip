@@ -482,12 +482,21 @@ struct szl_inflater {
     uint32_t adler = 1;            // Adler-32 of the bytes handed out so far (zlib mode), excluding `unsummed`
     std::vector<uint8_t> unsummed; // handed-out bytes not yet folded into `adler` (folded on the device, lazily)
     uint32_t adler_dec = 1;        // Adler-32 of everything decoded so far
+    size_t hin_pos = 0;            // bytes at the front of hin that are consumed already (dropped in bulk, not per step)
     DevBuf d_in, d_out, d_win, d_job, d_state;
     static constexpr size_t OUT_CHUNK = 256 * 1024;
+    // One step = one upload, one launch, two small downloads: job, state and the input prefix travel as ONE block through pinned
+    // host memory (`h_ctl` -> `d_ctl`: [InfJob | InfState | input]), the decoded bytes come back through a pinned buffer.
+    // (Before: three synchronous pageable copies up, three down and an erase at the front of the input vector per Inflate() call
+    // that ran dry — InflaterInputStream.Fill gives 4 KiB at a time, CS/InflaterInputStream.cs:115,658.)
+    static constexpr size_t IN_STEP = OUT_CHUNK + (64u << 10);
+    static constexpr size_t CTL_HDR = (sizeof(InfJob) + sizeof(InfState) + 63) & ~(size_t)63;
+    uint8_t *h_ctl = nullptr, *h_out = nullptr;
+    DevBuf d_ctl;
 };
 
 static void inflater_clear(szl_inflater *s) {
-    s->hin.clear(); s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0;
+    s->hin.clear(); s->hin_pos = 0; s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0;
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
     s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
@@ -503,7 +512,9 @@ szl_inflater *szl_inflater_create(int no_header) {
 }
 void szl_inflater_destroy(szl_inflater *s) {
     if (!s) return;
-    s->d_in.release(); s->d_out.release(); s->d_win.release(); s->d_job.release(); s->d_state.release();
+    s->d_in.release(); s->d_out.release(); s->d_win.release(); s->d_job.release(); s->d_state.release(); s->d_ctl.release();
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_out) (void)hipHostFree(s->h_out);
     delete s;
 }
 int szl_inflater_reset(szl_inflater *s) { if (!s) return SZL_E_ARG; inflater_clear(s); return 0; }
@@ -519,7 +530,7 @@ int szl_inflater_remaining_input(const szl_inflater *s) { // C/Inflater.cs:878
 int szl_inflater_needs_input(const szl_inflater *s) { // :783 — all given input was taken by the decoder
     if (!s) return 0;
     if (s->dec_status == INF_FINISHED) return szl_inflater_remaining_input(s) == 0;
-    if (s->dec_status == INF_NEED_DICT) return s->hin.size() * 8 <= s->st.bitpos;
+    if (s->dec_status == INF_NEED_DICT) return (s->hin.size() - s->hin_pos) * 8 <= s->st.bitpos;
     return s->dec_status == INF_NEED_INPUT && !s->fresh_input;
 }
 int szl_inflater_needs_dictionary(const szl_inflater *s) { return s && s->dec_status == INF_NEED_DICT; } // :794
@@ -563,28 +574,33 @@ int szl_inflater_set_dictionary(szl_inflater *s, const uint8_t *p, int n) { // :
     if (len && hipMemcpy((uint8_t *)s->d_win.p + (32768 - len), p + (n - len), (size_t)len, hipMemcpyHostToDevice) != hipSuccess) return SZL_E_DEVICE;
     s->have_dict = true;
     s->dec_status = INF_NEED_INPUT;
-    s->fresh_input = !s->hin.empty(); // the bytes after the DICTID are still waiting
+    s->fresh_input = s->hin.size() > s->hin_pos; // the bytes after the DICTID are still waiting
     return 0;
 }
 
 // Run the decoder once over the input given so far.
 static int inflater_step(szl_inflater *s) {
     int rc;
-    const size_t nin = s->hin.size();
-    if ((rc = s->d_in.ensure(nin + 64)) || (rc = s->d_out.ensure(szl_inflater::OUT_CHUNK + 64)) || (rc = s->d_win.ensure(32768)) ||
-        (rc = s->d_job.ensure(sizeof(InfJob))) || (rc = s->d_state.ensure(sizeof(InfState)))) return rc;
+    const size_t nin = s->hin.size() - s->hin_pos;
+    if ((rc = s->d_ctl.ensure(szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64)) || (rc = s->d_out.ensure(szl_inflater::OUT_CHUNK + 64)) ||
+        (rc = s->d_win.ensure(32768))) return rc;
+    if (!s->h_ctl && hipHostMalloc((void **)&s->h_ctl, szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
+    if (!s->h_out && hipHostMalloc((void **)&s->h_out, szl_inflater::OUT_CHUNK + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
     // One step produces at most OUT_CHUNK bytes, so it cannot need more than about that much input (stored data is 1:1):
     // upload a bounded prefix instead of the whole unconsumed input every step (a large SetInput would cost O(n^2) H2D).
-    const size_t nup = std::min<size_t>(nin, szl_inflater::OUT_CHUNK + (64u << 10));
+    const size_t nup = std::min<size_t>(nin, szl_inflater::IN_STEP);
     InfJob j{};
     j.in_off = 0; j.in_len = nup; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
     j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1; j.load_window = s->have_dict ? 1 : 0;
-    if (nup) HIPCHK(hipMemcpy(s->d_in.p, s->hin.data(), nup, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->d_job.p, &j, sizeof j, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->d_state.p, &s->st, sizeof s->st, hipMemcpyHostToDevice));
-    launch_inflate((const uint8_t *)s->d_in.p, (uint8_t *)s->d_out.p, (InfJob *)s->d_job.p, (InfState *)s->d_state.p, 1, false, nullptr);
-    HIPCHK(hipMemcpy(&j, s->d_job.p, sizeof j, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&s->st, s->d_state.p, sizeof s->st, hipMemcpyDeviceToHost));
+    InfJob *hj = (InfJob *)s->h_ctl; InfState *hs = (InfState *)(s->h_ctl + sizeof(InfJob));
+    uint8_t *dctl = (uint8_t *)s->d_ctl.p;
+    *hj = j; *hs = s->st;
+    if (nup) memcpy(s->h_ctl + szl_inflater::CTL_HDR, s->hin.data() + s->hin_pos, nup);
+    HIPCHK(hipMemcpyAsync(dctl, s->h_ctl, szl_inflater::CTL_HDR + nup, hipMemcpyHostToDevice, nullptr));
+    launch_inflate(dctl + szl_inflater::CTL_HDR, (uint8_t *)s->d_out.p, (InfJob *)dctl, (InfState *)(dctl + sizeof(InfJob)), 1, false, nullptr);
+    HIPCHK(hipMemcpyAsync(s->h_ctl, dctl, sizeof(InfJob) + sizeof(InfState), hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    j = *hj; s->st = *hs;
     s->fresh_input = false;
     // A corrupt token stops the decoder, but everything it decoded before that point is still delivered (the reference hands
     // those bytes out over earlier Inflate() calls and throws only when it reaches the bad token): record the error, keep the
@@ -596,7 +612,9 @@ static int inflater_step(szl_inflater *s) {
         size_t old = s->pend.size();
         if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
         s->pend.resize(old + j.out_written);
-        HIPCHK(hipMemcpy(s->pend.data() + old, s->d_out.p, j.out_written, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(s->h_out, s->d_out.p, j.out_written, hipMemcpyDeviceToHost, nullptr));
+        HIPCHK(hipStreamSynchronize(nullptr));
+        memcpy(s->pend.data() + old, s->h_out, j.out_written);
         if (!s->no_header) { // running Adler-32 of the decoded bytes, on the device (K/Adler32.cs)
             std::vector<std::pair<uint64_t, uint64_t>> regs{{0, j.out_written}};
             std::vector<std::pair<uint32_t, uint32_t>> init{{0u, s->adler_dec}}, out;
@@ -606,14 +624,17 @@ static int inflater_step(szl_inflater *s) {
     }
     if (s->err) return 0;
     if (s->dec_status == INF_FINISHED && !s->no_header && s->st.adler_read != s->adler_dec) { s->err = SZL_E_ADLER_MISMATCH; return 0; }
-    // drop the consumed whole dwords of input; keep bitpos relative to the new base
+    // drop the consumed whole dwords of input (an offset into the vector; the vector itself is compacted once half of it is dead);
+    // keep bitpos relative to the new base
     uint64_t drop = (s->st.bitpos >> 3) & ~3ull;
     if (s->st.mode == INF_M_ZHEADER) drop = 0;
-    if (drop > s->hin.size()) drop = s->hin.size() & ~3ull;
+    if (drop > nin) drop = nin & ~3ull;
     if (drop) {
-        s->hin.erase(s->hin.begin(), s->hin.begin() + (ptrdiff_t)drop);
+        s->hin_pos += (size_t)drop;
         s->in_base += drop;
         s->st.bitpos -= 8 * drop;
+        if (s->hin_pos == s->hin.size()) { s->hin.clear(); s->hin_pos = 0; }
+        else if (s->hin_pos > (1u << 20) && s->hin_pos * 2 > s->hin.size()) { s->hin.erase(s->hin.begin(), s->hin.begin() + (ptrdiff_t)s->hin_pos); s->hin_pos = 0; }
     }
     return 0;
 }

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--entries", type=int, default=2000)
 ap.add_argument("--kib", type=int, default=64)
 ap.add_argument("--level", type=int, default=6)
+ap.add_argument("--inflate-mib", type=int, default=32)
 a = ap.parse_args()
 n = a.kib << 10
 data = corpus.generate("enwik", 5, 0, n * a.entries)
@@ -47,3 +48,28 @@ t1 = time.perf_counter()
 print("one batched call (host buffers in and out): %.3f ms per entry = %.1f MiB/s" % (
     (t1 - t0) * 1e3 / a.entries, a.entries * a.kib / 1024.0 / (t1 - t0)), flush=True)
 assert sum(len(r.data) for r in res) == tot
+
+
+# ---- the unchanged-host read path: InflaterInputStream (CS/InflaterInputStream.cs:115,486,658) — Fill() gives the Inflater its
+# input 4 KiB at a time (the default buffer) or 64 KiB (a caller who passes bufferSize), Read() asks for 4 KiB of output at a time
+import io
+from sharpziplib_amd.inflater import Inflater
+from sharpziplib_amd.streams import InflaterInputStream
+m = a.inflate_mib << 20
+plain = corpus.generate("enwik", 6, 0, m)
+comp = Engine().deflate([plain], level=6)[0].data
+for bufsz, readsz in ((4096, 4096), (65536, 65536), (65536, 1 << 20)):
+    src = io.BytesIO(comp)
+    st = InflaterInputStream(src, Inflater(True), bufsz)
+    out = bytearray(readsz)
+    t0 = time.perf_counter()
+    got = 0
+    h = 0
+    while True:
+        k = st.Read(out, 0, readsz)
+        if k <= 0:
+            break
+        got += k
+    dt = time.perf_counter() - t0
+    assert got == m
+    print("InflaterInputStream, %d B input buffer, Read(%d): %.1f MiB/s of output (%d MiB member)" % (bufsz, readsz, m / 2 ** 20 / dt, a.inflate_mib), flush=True)
