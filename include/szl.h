@@ -31,7 +31,7 @@ typedef enum szl_status {
     SZL_E_STATE = -2,          /* InvalidOperationException ("Finish() already called" C/Deflater.cs:333-336, "Old input was not completely processed" C/DeflaterEngine.cs:163-166, "Dictionary is not needed" C/Inflater.cs:580) */
     SZL_E_DEVICE = -3,         /* HIP error / no gfx950 device: surfaces as SharpZipBaseException */
     SZL_E_NOMEM = -4,
-    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not reproduced here (SetLevel to or from level 0 mid-stream, across DeflateFast / DeflateSlow with bytes pending, more than four changes between two flushes) */
+    SZL_E_UNSUPPORTED = -5,    /* API-legal in the reference but not reproduced here */
     SZL_E_OUTPUT_TOO_SMALL = -6,
     /* Inflater errors == the SharpZipBaseException messages of C/Inflater.cs */
     SZL_E_HEADER_CHECKSUM = -16,   /* "Header checksum illegal"            C/Inflater.cs:224 */
@@ -45,9 +45,12 @@ typedef enum szl_status {
     SZL_E_DYN_HEADER = -24,        /* ValueOutOfRange/StreamDecodingException C/InflaterDynHeader.cs:50-52,83,106,114 */
     SZL_E_UNEXPECTED_EOF = -25,    /* batch inflate only: input exhausted before the final block (CS/InflaterInputStream.cs:494) */
     SZL_E_WINDOW_FULL = -26,       /* CS/OutputWindow.cs:37,66 */
-    SZL_E_CODE_OVERSUBSCRIBED = -27 /* over-subscribed code lengths in a dynamic header: the reference's InflaterHuffmanTree.BuildTree
+    SZL_E_CODE_OVERSUBSCRIBED = -27,/* over-subscribed code lengths in a dynamic header: the reference's InflaterHuffmanTree.BuildTree
                                        throws IndexOutOfRangeException out of DeflaterHuffman.BitReverse (C/InflaterHuffmanTree.cs:133-166,
                                        C/DeflaterHuffman.cs:924-930); the shim rethrows that type */
+    SZL_E_INDEX = -28              /* IndexOutOfRangeException out of DeflaterEngine.UpdateHash (C/DeflaterEngine.cs:409): SetLevel from level 0 to a
+                                       coded level while DeflateStored stands at one of the last two bytes of a full window reads
+                                       window[strstart + 1] past the array — the reference throws there, and so does this */
 } szl_status;
 
 const char *szl_strerror(int status);

@@ -43,6 +43,7 @@ const char *szl_strerror(int st) {
     case SZL_E_UNEXPECTED_EOF: return "Unexpected EOF";
     case SZL_E_WINDOW_FULL: return "Window full";
     case SZL_E_CODE_OVERSUBSCRIBED: return "Index was outside the bounds of the array (over-subscribed code lengths)";
+    case SZL_E_INDEX: return "Index was outside the bounds of the array";
     default: return "unknown status";
     }
 }
@@ -195,8 +196,8 @@ int region_checksums(const uint8_t *base, const std::vector<std::pair<uint64_t, 
 }
 // Level 0 batch: every stream == new Deflater(0, nowrap); SetInput(all, in <= 1 GiB pieces); [Flush();] Finish()
 static int deflate_batch_stored(szl_engine *e, const uint8_t *d_in, uint8_t *d_out, szl_stream *streams, size_t n, unsigned flags, hipStream_t st) {
-    if (flags & SZL_F_GZIP) { set_error("SZL_F_GZIP needs level 5-9"); return SZL_E_UNSUPPORTED; }
-    const bool nowrap = flags & SZL_F_NOWRAP;
+    const bool gzip = flags & SZL_F_GZIP;              // GZipOutputStream: a raw deflate stream inside the RFC 1952 member (:315-375)
+    const bool nowrap = (flags & SZL_F_NOWRAP) || gzip;
     std::vector<StoredBlk> sb;
     std::vector<std::pair<uint64_t, uint64_t>> regs(n);
     for (size_t i = 0; i < n; i++) {
@@ -207,21 +208,28 @@ static int deflate_batch_stored(szl_engine *e, const uint8_t *d_in, uint8_t *d_o
         L0State st0; std::vector<L0Blk> blks;
         if (flags & SZL_F_SYNC_FLUSH_BEFORE_FINISH) { l0_replay(st0, chunks, chunks.size(), true, false, blks); l0_replay(st0, {}, 0, false, true, blks); }
         else l0_replay(st0, chunks, chunks.size(), false, true, blks);
-        uint64_t o = s.out_off + (nowrap ? 0 : 2);
+        uint64_t o = s.out_off + (gzip ? 10 : (nowrap ? 0 : 2));
         for (auto &b : blks) { sb.push_back(StoredBlk{s.in_off + b.abs_off, o, b.len, b.last}); o += 5 + (uint64_t)b.len; }
-        s.out_len = o - s.out_off + (nowrap ? 0 : 4);
+        s.out_len = o - s.out_off + (gzip ? 8 : (nowrap ? 0 : 4));
         s.status = s.out_len <= s.out_cap ? 0 : SZL_E_OUTPUT_TOO_SMALL;
         if (s.status) { set_error("stream %zu: out_cap too small for level 0", i); return SZL_E_OUTPUT_TOO_SMALL; }
         regs[i] = {s.in_off, s.in_len};
     }
     int rc = e->e.deflate_stored(d_in, d_out, sb, 0, 0, 0, 0, 1, nullptr, nullptr, st);
     if (rc) return rc;
-    unsigned want = ((flags & SZL_F_CRC32) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !nowrap) ? 2u : 0u);
+    unsigned want = (((flags & SZL_F_CRC32) || gzip) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !nowrap) ? 2u : 0u);
     std::vector<std::pair<uint32_t, uint32_t>> cks(n, {0u, 1u});
     if (want && (rc = szl::region_checksums(d_in, regs, want, cks, nullptr, st))) return rc;
     for (size_t i = 0; i < n; i++) {
         streams[i].crc32 = cks[i].first; streams[i].adler32 = cks[i].second;
-        if (!nowrap) { // zlib header (level_flags = 3 for level 0: (0-1)>>1 < 0 -> 3, C/Deflater.cs:440-444) and Adler trailer
+        if (gzip) {    // ID1 ID2 CM FLG MTIME XFL OS ... CRC32 ISIZE (little endian), as k_finish writes them for the coded levels
+            const uint32_t t = streams[i].reserved, c = cks[i].first, isz = (uint32_t)(streams[i].in_len & 0xffffffffu);
+            uint8_t hb[10] = {0x1F, 0x8B, 8, 0, (uint8_t)t, (uint8_t)(t >> 8), (uint8_t)(t >> 16), (uint8_t)(t >> 24), 0, 255};
+            uint8_t tb[8] = {(uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24), (uint8_t)isz, (uint8_t)(isz >> 8), (uint8_t)(isz >> 16), (uint8_t)(isz >> 24)};
+            if (hipMemcpyAsync(d_out + streams[i].out_off, hb, 10, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_out + streams[i].out_off + streams[i].out_len - 8, tb, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return SZL_E_DEVICE;
+        } else if (!nowrap) { // zlib header (level_flags = 3 for level 0: (0-1)>>1 < 0 -> 3, C/Deflater.cs:440-444) and Adler trailer
             int hdr = zlib_header(0);
             uint8_t hb[2] = {(uint8_t)(hdr >> 8), (uint8_t)hdr};
             uint32_t a = cks[i].second;
@@ -724,10 +732,10 @@ void szl_deflater_destroy(szl_deflater *d) {
     delete d;
 }
 int szl_deflater_reset(szl_deflater *d) { if (!d) return SZL_E_ARG; deflater_clear(d); return 0; }
+static int function_switch(szl_deflater *d, int level);
 static int lvl_kind(int lv) { return lv == 0 ? 0 : (lv < 5 ? 1 : 2); }   // DEFLATE_STORED / DEFLATE_FAST / DEFLATE_SLOW (C/DeflaterConstants.cs:146)
 // a parameter change while bytes are pending: it takes effect where the reference's engine stands
 static int pend_switch(szl_deflater *d, int level, int strategy) {
-    if (d->switches.size() >= (size_t)SEG_MAX_SWITCH) { set_error("more than %d SetLevel/SetStrategy calls between two flushes are not supported", (int)SEG_MAX_SWITCH); return SZL_E_UNSUPPORTED; }
     const int64_t at = d->engine_seen > (MIN_LOOKAHEAD - 1) ? d->engine_seen - (MIN_LOOKAHEAD - 1) : 0;
     d->switches.push_back(szl_deflater::Sw{(uint64_t)at, level, strategy});
     return 0;
@@ -737,17 +745,15 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) return SZL_E_ARG;
     if (level == d->level) return 0;                       // C/Deflater.cs:357
-    // stored / fast / slow keep different hash-chain contents (level 0 inserts nothing, 1-4 skip long matches, :319-329,:697)
-    // and the reference closes a block at the switch: only a fresh stream may change the compression function here
-    // and the reference closes a block at the switch.  DeflateFast <-> DeflateSlow is supported where that block is empty: right
-    // after a flush (nothing pending), the new function then finds exactly the chains the old one left (`hist_flags`).
+    // Another compression function (DeflateStored / DeflateFast / DeflateSlow, C/DeflaterConstants.cs:146): the reference flushes a block
+    // with the OLD function where its engine stands and continues with the new one (C/DeflaterEngine.cs:319-359) — with bytes pending,
+    // to or from level 0, any number of times.  The three functions leave different hash chains behind (level 0 inserts nothing,
+    // 1-4 skip the inside of long matches, :697): the per-byte "inserted" flags of the history carry that over.
     if (lvl_kind(level) != lvl_kind(d->level) && d->total_in != 0) {
-        const bool fast_slow = lvl_kind(level) != 0 && lvl_kind(d->level) != 0;
-        if (!fast_slow || !d->pend.empty() || d->engine_seen != d->total_in) {
-            set_error(fast_slow ? "switching between DeflateFast and DeflateSlow levels is supported right after Flush() only"
-                                : "switching to or from level 0 (DeflateStored) mid-stream is not supported");
-            return SZL_E_UNSUPPORTED;
-        }
+        int rc = function_switch(d, level);
+        if (rc) return rc;
+        d->level = level; d->base_level = level; d->base_strategy = d->strategy;
+        return 0;
     }
     if (!d->pend.empty() && level != 0) { int rc = pend_switch(d, level, d->strategy); if (rc) return rc; }
     else if (d->pend.empty()) d->base_level = level;
@@ -809,15 +815,9 @@ uint32_t szl_deflater_adler(const szl_deflater *d) {
 }
 
 // Compress the pending bytes as one segment on the device and append the produced bytes to outq.
-static int run_segment_stored(szl_deflater *d, bool finish) {
-    std::vector<L0Blk> blks;
-    const uint64_t fed0 = d->l0.fed;
-    l0_replay(d->l0, d->chunks, d->chunks_drained, !finish, finish, blks);
-    // Bytes the engine really took in.  Normally all of them; the reference stops early when Finish() precedes the first
-    // Deflate() on > 64 KiB of level-0 input (DeflateStored marks the block final while input remains, :630-631) — the Adler-32
-    // trailer then only covers what FillWindow copied (:389), and so does ours.
-    const uint64_t fed_now = d->l0.fed - fed0;
-    d->chunks.clear(); d->chunks_drained = 0;
+// Level 0: render the stored blocks `blks` (absolute positions; all inside the pending bytes) and queue their bytes.
+// fed_now: bytes of the pending data FillWindow took in (what the running Adler-32 covers).
+static int stored_emit(szl_deflater *d, const std::vector<L0Blk> &blks, uint64_t fed_now, bool finish) {
     // absolute positions count the preset dictionary (if any) as a prefix of the stream
     const uint64_t n = d->pend.size(), pend_abs = (uint64_t)d->total_in - n + d->l0_dict;
     std::vector<StoredBlk> sb(blks.size());
@@ -834,14 +834,66 @@ static int run_segment_stored(szl_deflater *d, bool finish) {
     rc = d->eng->e.deflate_stored((const uint8_t *)d->d_in.p, (uint8_t *)d->d_out.p, sb, d->nowrap ? 0u : 2u, 0, fed_now < n ? fed_now : n, 0, d->adler, nullptr, &adler, nullptr);
     if (rc) return rc;
     if (!d->nowrap) d->adler = adler;
-    const size_t old = d->outq.size();
+    // A stored block after a compressed era starts inside a byte: its three header bits follow the carried bits, then the stream is
+    // byte aligned (FlushStoredBlock: WriteBits(3) + AlignToByte, C/DeflaterHuffman.cs:766-779, C/PendingBuffer.cs:143-155)
+    size_t old = d->outq.size();
+    if (d->carry_bits && !sb.empty()) {
+        const uint32_t c = d->carry_bits;
+        d->outq.push_back((uint8_t)(d->carry_byte | ((sb[0].last ? 1u : 0u) << c)));
+        if (c + 3 > 8) d->outq.push_back(0);
+        d->carry_bits = 0; d->carry_byte = 0;
+        old = d->outq.size() - 1;                         // the block's own first byte (device: the header at bit 0) is replaced by the above
+        d->outq.resize(old + out_total + (finish && !d->nowrap ? 4 : 0));
+        const uint8_t keep = d->outq[old];
+        if (out_total && hipMemcpy(d->outq.data() + old, d->d_out.p, out_total, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+        d->outq[old] = keep;
+    } else {
     d->outq.resize(old + out_total + (finish && !d->nowrap ? 4 : 0));
     if (out_total && hipMemcpy(d->outq.data() + old, d->d_out.p, out_total, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    }
     if (finish && !d->nowrap) { // C/Deflater.cs:510-515
         uint8_t *t = d->outq.data() + old + out_total;
         t[0] = (uint8_t)(d->adler >> 24); t[1] = (uint8_t)(d->adler >> 16); t[2] = (uint8_t)(d->adler >> 8); t[3] = (uint8_t)d->adler;
     }
-    d->pend.clear();
+    return 0;
+}
+enum { TAIL0 = WSIZE + MAX_DIST /* 65274: an engine that stands at this window index or further slides first (:371) */ };
+static int64_t base_of_host(int64_t wp) { int64_t idx = wp + 1; if (idx < TAIL0) return 0; return ((idx - (TAIL0 - 1) + 32767) >> 15) << 15; }   // DESIGN App. A.2
+
+// the bytes of `pend` in front of position X_rel become history (flags: which of them are in the hash chains), the rest stays pending
+static void advance_history(szl_deflater *d, uint64_t X_rel, const std::vector<uint32_t> *new_flags /* bit q = pend position q; null = none inserted */, bool all_inserted) {
+    const uint64_t H = d->hist.size();
+    const uint64_t keep = std::min<uint64_t>(H + X_rel, 65536);
+    const uint64_t first = H + X_rel - keep;                       // buffer position (hist + pend) of the first byte kept
+    std::vector<uint8_t> nh; nh.reserve(keep);
+    std::vector<uint32_t> nf((keep + 31) / 32, 0u);
+    bool gaps = false;
+    for (uint64_t q = 0; q < keep; q++) {
+        const uint64_t bp = first + q;
+        bool ins;
+        if (bp < H) { nh.push_back(d->hist[bp]); ins = d->hist_flags.empty() ? true : ((size_t)(bp >> 5) < d->hist_flags.size() && ((d->hist_flags[(size_t)(bp >> 5)] >> (bp & 31)) & 1u)); }
+        else { const uint64_t pq = bp - H; nh.push_back(d->pend[pq]); ins = all_inserted ? true : (new_flags && (size_t)(pq >> 5) < new_flags->size() && (((*new_flags)[(size_t)(pq >> 5)] >> (pq & 31)) & 1u)); }
+        if (ins) nf[q >> 5] |= 1u << (q & 31); else gaps = true;
+    }
+    d->hist_abs = d->hist_abs + first;
+    d->hist.swap(nh); d->hist_flags.swap(nf); d->hist_has_gaps = gaps;
+    d->pend.erase(d->pend.begin(), d->pend.begin() + (ptrdiff_t)X_rel);
+    d->bounds.erase(std::remove_if(d->bounds.begin(), d->bounds.end(), [&](uint64_t b) { return b <= d->hist_abs; }), d->bounds.end());
+}
+static int run_segment_stored(szl_deflater *d, bool finish) {
+    std::vector<L0Blk> blks;
+    const int64_t wp0 = d->total_in - (int64_t)d->pend.size() + (int64_t)d->l0_dict;
+    l0_replay(d->l0, d->chunks, d->chunks_drained, !finish, finish, blks);
+    // Bytes the engine really took in.  Normally all of them; the reference stops early when Finish() precedes the first
+    // Deflate() on > 64 KiB of level-0 input (DeflateStored marks the block final while input remains, :630-631) — the Adler-32
+    // trailer then only covers what FillWindow copied (:389), and so does ours.
+    const int64_t fed_end = (int64_t)(d->l0.strstart + d->l0.lookahead) - 1 + d->l0.base;
+    const uint64_t fed_now = fed_end > wp0 ? (uint64_t)(fed_end - wp0) : 0;
+    d->chunks.clear(); d->chunks_drained = 0;
+    int rc = stored_emit(d, blks, fed_now, finish);
+    if (rc) return rc;
+    advance_history(d, d->pend.size(), nullptr, false);   // stored bytes are in the window, but in no hash chain
+    d->engine_seen = d->total_in;
     return 0;
 }
 
@@ -869,6 +921,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     s.finish = finish ? 1 : 0;
     s.flags = finish ? ((d->nowrap ? 0u : (uint32_t)SEG_ZLIB_TRAILER)) : (uint32_t)SEG_SYNC_PAD;
     s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = 0;
+    std::vector<int64_t> sw_pos; std::vector<LevelParams> sw_P;
     {   // parameter changes inside the pending bytes -> buffer positions
         const int64_t pend_abs = d->total_in - (int64_t)n;       // absolute input position of the first pending byte
         for (const auto &w : d->switches) {
@@ -877,16 +930,17 @@ static int run_segment(szl_deflater *d, bool finish) {
             if (Pk.fast != P.fast) { set_error("internal: compression function changed inside a segment"); return SZL_E_STATE; }
             int64_t rel = (int64_t)w.abs_pos - pend_abs;
             if (rel < 0) rel = 0;
-            s.sw_pos[s.sw_cnt] = (int64_t)H + rel; s.sw_P[s.sw_cnt] = Pk; s.sw_cnt++;
+            sw_pos.push_back((int64_t)H + rel); sw_P.push_back(Pk);
         }
     }
     std::vector<SegOut> res;
     Engine &E = d->eng->e;
+    E.sw_pos_in = sw_pos; E.sw_P_in = sw_P;
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = true; }
     else if (d->hist_has_gaps && H) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); }   // stage A must skip what DeflateFast skipped
     rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, d->nowrap ? 0u : 2u, res, nullptr);
-    E.fast_hist_in.clear(); E.fast_want_tail = false;
+    E.fast_hist_in.clear(); E.fast_want_tail = false; E.sw_pos_in.clear(); E.sw_P_in.clear();
     if (rc) return rc;
     const uint64_t end_bit = res[0].end_bit;
     const uint64_t bytes = (end_bit + 7) >> 3;
@@ -940,6 +994,134 @@ static int run_segment(szl_deflater *d, bool finish) {
     return 0;
 }
 
+// ---- SetLevel to another compression function in mid-stream (C/DeflaterEngine.cs:304-361) ----------------------------------------
+// Where does the reference's engine stand when the call arrives?  It has SEEN `engine_seen` bytes of input (everything up to the
+// last Deflate() call that drained it; later SetInput bytes still sit in the Deflater's input buffer).  DeflateStored consumes all
+// it sees; DeflateFast / DeflateSlow stop at the first iteration start with less than MIN_LOOKAHEAD bytes in front of it
+// (`while (lookahead >= MIN_LOOKAHEAD || flush)`, :681,:759).  The pending bytes in front of that point are compressed now — with
+// the old function, as a block that is flushed without the sync padding of a Flush() — and the rest stays pending for the new one.
+// DeflateFast / DeflateSlow -> another function: run the bytes the engine has seen through the device with SEG_SWITCH_CUT
+static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out) {
+    *x_rel_out = 0;
+    const int64_t pend_abs = d->total_in - (int64_t)d->pend.size();
+    const int64_t T_abs = d->engine_seen - (int64_t)(MIN_LOOKAHEAD - 1);   // first position whose iteration did not run
+    if (seen == 0 || T_abs <= pend_abs) return 0;                          // the engine stands where the pending bytes begin: no block to flush
+    LevelParams P;
+    int rc = level_params(d->switches.empty() ? d->level : d->base_level, d->switches.empty() ? d->strategy : d->base_strategy, &P);
+    if (rc) return rc;
+    const uint64_t H = d->hist.size(), n = seen;
+    const uint64_t in_total = H + n;
+    const uint64_t cap = (szl_deflate_bound(n) + 16 + 3) & ~3ull;
+    if ((rc = d->d_in.ensure(in_total + 64)) || (rc = d->d_out.ensure(cap + 64))) return rc;
+    if (H && hipMemcpy(d->d_in.p, d->hist.data(), H, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    if (hipMemcpy((uint8_t *)d->d_in.p + H, d->pend.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    std::vector<SegDev> segs(1);
+    std::vector<uint64_t> bnds;
+    for (uint64_t b : d->bounds) if (b > d->hist_abs) bnds.push_back(b - d->hist_abs);
+    bnds.push_back(H + n);
+    SegDev &s = segs[0];
+    s = SegDev{};
+    s.buf_off = 0; s.abs0 = d->hist_abs; s.seg_start = (int64_t)H; s.seg_end = (int64_t)(H + n);
+    s.bnd_off = 0; s.bnd_cnt = (uint32_t)bnds.size();
+    s.finish = 0; s.flags = (uint32_t)SEG_SWITCH_CUT; s.cut_pos = (int64_t)H + (T_abs - pend_abs);
+    s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = 1; s.crc_init = 0;
+    Engine &E = d->eng->e;
+    E.sw_pos_in.clear(); E.sw_P_in.clear();
+    for (const auto &w : d->switches) {     // parameter changes of the old function inside these bytes
+        LevelParams Pk;
+        if ((rc = level_params(w.level, w.strategy, &Pk))) return rc;
+        if (Pk.fast != P.fast) { set_error("internal: compression function changed inside a segment"); return SZL_E_STATE; }
+        int64_t rel = (int64_t)w.abs_pos - pend_abs;
+        if (rel < 0) rel = 0;
+        E.sw_pos_in.push_back((int64_t)H + rel); E.sw_P_in.push_back(Pk);
+    }
+    E.fast_hist_in.clear(); E.fast_want_tail = false;
+    if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = true; }
+    else if (d->hist_has_gaps && H) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); }
+    std::vector<SegOut> res;
+    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, 0u, res, nullptr);
+    E.fast_hist_in.clear(); E.fast_want_tail = false; E.sw_pos_in.clear(); E.sw_P_in.clear();
+    if (rc) return rc;
+    const int64_t X = res[0].cut_x;
+    if (X < (int64_t)H || X > (int64_t)(H + n)) { set_error("internal: the switch cut landed outside the pending bytes"); return SZL_E_STATE; }
+    const uint64_t X_rel = (uint64_t)(X - (int64_t)H);
+    // the block(s) in front of the cut: whole bytes go out, the partial byte is carried (no padding: FlushBlock(.., false))
+    const uint64_t end_bit = res[0].end_bit;
+    const uint64_t bytes = (end_bit + 7) >> 3;
+    d->h_out.resize(bytes + 1);
+    if (bytes && hipMemcpy(d->h_out.data(), d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    if (d->carry_bits && bytes) d->h_out[0] |= d->carry_byte;
+    const uint64_t whole = end_bit >> 3;
+    d->outq.insert(d->outq.end(), d->h_out.begin(), d->h_out.begin() + whole);
+    d->carry_bits = (uint32_t)(end_bit & 7);
+    d->carry_byte = d->carry_bits ? d->h_out[whole] : 0;
+    if (!d->nowrap && X_rel) { uint32_t a = d->adler; if ((rc = szl_adler32(d->adler, d->pend.data(), (size_t)X_rel, &a))) return rc; d->adler = a; }
+    // history: DeflateSlow inserted every position in front of the cut (each had MIN_LOOKAHEAD bytes in front of it); DeflateFast the
+    // ones its flags say
+    std::vector<uint32_t> ff;
+    if (P.fast) {
+        ff.assign((X_rel + 31) / 32, 0u);
+        for (uint64_t q = 0; q < X_rel; q++) {
+            const int64_t p = (int64_t)(H + q) - E.fast_tail_start;
+            if (p >= 0 && (size_t)(p >> 5) < E.fast_tail_bits.size() && ((E.fast_tail_bits[(size_t)(p >> 5)] >> (p & 31)) & 1u)) ff[q >> 5] |= 1u << (q & 31);
+        }
+    }
+    advance_history(d, X_rel, P.fast ? &ff : nullptr, !P.fast);
+    *x_rel_out = X_rel;
+    return 0;
+}
+
+static int function_switch(szl_deflater *d, int level) {
+    const int old_kind = lvl_kind(d->level), new_kind = lvl_kind(level);
+    const int64_t pend_abs = d->total_in - (int64_t)d->pend.size();
+    uint64_t seen = d->engine_seen > pend_abs ? (uint64_t)(d->engine_seen - pend_abs) : 0;
+    if (seen > d->pend.size()) seen = d->pend.size();
+    int rc;
+    const size_t ndr = std::min(d->chunks_drained, d->chunks.size());
+    std::vector<uint64_t> unseen_chunks(d->chunks.begin() + (ptrdiff_t)ndr, d->chunks.end());
+    uint64_t look = 0;                                 // bytes the engine keeps in front of it (its lookahead)
+    if (old_kind == 0) {
+        // DeflateStored has consumed what it was given (everything, normally): FlushStoredBlock(blockStart .. strstart, false)
+        // if that is not empty, then UpdateHash() (:327-333)
+        std::vector<L0Blk> blks;
+        const int64_t wp0 = pend_abs + (int64_t)d->l0_dict;
+        for (size_t i = 0; i < ndr; i++) {
+            uint64_t avail = d->chunks[i];
+            while (l0_engine_deflate(d->l0, avail, false, false, blks)) { }
+        }
+        if (d->l0.strstart > d->l0.blockStart) {
+            blks.push_back(L0Blk{(uint64_t)(d->l0.blockStart - 1 + d->l0.base), (uint32_t)(d->l0.strstart - d->l0.blockStart), 0u});
+            d->l0.blockStart = d->l0.strstart;
+        }
+        const int64_t X_w = (int64_t)d->l0.strstart - 1 + d->l0.base;
+        const uint64_t X_rel = X_w > wp0 ? (uint64_t)(X_w - wp0) : 0;
+        if (X_rel > d->pend.size()) { set_error("internal: level-0 replay ran past the pending bytes"); return SZL_E_STATE; }
+        // ins_h = window[strstart] << 5 ^ window[strstart + 1] (:409).  The value itself never matters — FillWindow() calls UpdateHash()
+        // again as soon as three bytes of lookahead are there (:396-399) and InsertString() needs as many — but the READ does: with
+        // DeflateStored at one of the last two indices of a full window it is past the array, and the reference throws.
+        if ((int64_t)d->l0.strstart + 1 >= 2 * WSIZE) { set_error("SetLevel: the reference's UpdateHash() reads past its window array here (IndexOutOfRangeException, C/DeflaterEngine.cs:409)"); return SZL_E_INDEX; }
+        if (!blks.empty()) { if ((rc = stored_emit(d, blks, X_rel, false))) return rc; }
+        look = (uint64_t)d->l0.lookahead;
+        advance_history(d, X_rel, nullptr, false);      // stored bytes are in the window but in no hash chain
+    } else {
+        uint64_t X_rel = 0;
+        if ((rc = cut_coded(d, seen, &X_rel))) return rc;
+        look = seen - X_rel;
+    }
+    d->switches.clear();
+    d->chunks = unseen_chunks; d->chunks_drained = 0;
+    if (new_kind == 0) {
+        // DeflateStored continues in the engine's window: strstart at the cut, `look` bytes of lookahead already there
+        const int64_t X_w = (d->total_in - (int64_t)d->pend.size()) + (int64_t)d->l0_dict;
+        d->l0 = L0State{};
+        d->l0.base = base_of_host(X_w);
+        d->l0.strstart = d->l0.blockStart = (int)(X_w + 1 - d->l0.base);
+        d->l0.lookahead = (int)look;
+        d->l0.fed = (uint64_t)d->engine_seen;
+    }
+    return 0;
+}
+
 int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Deflater.cs:427
     if (!d || length < 0 || (!out && length)) return SZL_E_ARG;
     if (d->state == CLOSED_STATE) return SZL_E_STATE;
@@ -959,7 +1141,14 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Defla
         if (k) { memcpy(out, d->outq.data() + d->outpos, k); d->outpos += k; out += k; length -= (int)k; d->total_out += (int64_t)k; }
         if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }
         if (length == 0 || d->state == FINISHED_STATE) break;
-        if (d->state == BUSY_STATE) { d->chunks_drained = d->chunks.size(); d->engine_seen = d->total_in; break; } // "We need more input now" :482-484 (the engine has seen every chunk)
+        if (d->state == BUSY_STATE) {                    // "We need more input now" :482-484 (the engine has seen every chunk)
+            d->chunks_drained = d->chunks.size(); d->engine_seen = d->total_in;
+            if (d->level == 0 && d->l0.lookahead > 0) {  // DeflateStored takes the lookahead a coded function left in the window (:621-623)
+                uint64_t none = 0; std::vector<L0Blk> nb;
+                while (l0_engine_deflate(d->l0, none, false, false, nb)) { }
+            }
+            break;
+        }
         int rc;
         if (d->state == FLUSHING_STATE) { if ((rc = run_segment(d, false))) return rc; d->state = BUSY_STATE; }
         else if (d->state == FINISHING_STATE) { if ((rc = run_segment(d, true))) return rc; d->state = FINISHED_STATE; }

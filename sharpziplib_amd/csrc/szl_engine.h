@@ -82,12 +82,16 @@ class Engine {
     int match_mode_override = -1; // debug tap: -1 = SZL_MATCH_MODE / default (2 = pilot), 0 full, 1 on demand
     // DeflateFast, single-segment calls (streaming Deflater): "inserted" bits of the buffer's history in (bit q = buffer
     // position q), and of the last 32 Ki positions out (bit 0 of fast_tail_bits = position fast_tail_start).
+    // SetLevel / SetStrategy inside the (single) segment of a call: an iteration that starts at buffer position >= sw_pos_in[k] runs with
+    // sw_P_in[k] (the last such k).  Set by the caller before deflate(), any number of entries; cleared by the caller.
+    std::vector<int64_t> sw_pos_in;
+    std::vector<LevelParams> sw_P_in;
     std::vector<uint32_t> fast_hist_in, fast_tail_bits;
     bool fast_want_tail = false;
     int64_t fast_tail_start = 0;
     DevBuf link, link4, skip4, e3dist, e3hops, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_stripes, d_so, blk_counts, blk_off,
         bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored, spec_tok, d_zoff,
-        inf_sym, inf_wins, inf_jobs, inf_states, inf_misc, hist_flags_dev, m5_scratch;   // parallel decode of one member (szl_api_inflate.hip)
+        inf_sym, inf_wins, inf_jobs, inf_states, inf_misc, hist_flags_dev, m5_scratch, d_sw_pos, d_sw_P;   // parallel decode of one member (szl_api_inflate.hip)
     hipEvent_t ev[8];
     // checksum kernels run beside stages A-C on this stream (they only share the input bytes)
     hipStream_t side = nullptr;

@@ -99,6 +99,7 @@ hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDe
 void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, RangeDev *ranges, uint32_t *visited, unsigned long long *counters, uint32_t *spec_tok, hipStream_t st);
 bool emit_copy_enabled();
+void launch_switch_cut(const uint8_t *in, const SegDev *segs, uint32_t *tokens, SegOut *so, const uint64_t *blk_off, const int64_t *bsp, int64_t *blp, hipStream_t st);
 void launch_emit_copy(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                       LevelParams P, const RangeDev *ranges, const uint32_t *visited, const uint32_t *spec_tok,
                       const uint64_t *range_tok, const SegOut *so, uint32_t *tokens, const uint64_t *blk_off, int64_t *blk_start_pos,
@@ -191,7 +192,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &hist_flags_dev})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -243,7 +244,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     for (auto &s : segs) if (s.look_end < s.seg_end) s.look_end = s.seg_end;
     {   // a single long stream at a DeflateSlow level goes through the window pipeline (workspace of one window, not of the stream)
         uint64_t window = 0;
-        if (uses_window_pipeline(nseg, !P.fast, (uint64_t)(segs[0].seg_end - segs[0].seg_start), &window))
+        if (!(segs[0].flags & SEG_SWITCH_CUT) && sw_pos_in.empty() && uses_window_pipeline(nseg, !P.fast, (uint64_t)(segs[0].seg_end - segs[0].seg_start), &window))
             return deflate_windowed(d_in, in_total, d_out, out_total, segs[0], bnds, P, want_ck, results, st, window);
     }
     memset(&timing, 0, sizeof timing);
@@ -263,7 +264,11 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     else while (range_len > 256 && total_emit / range_len < 65536) range_len >>= 1;   // (≈64 Ki ranges fill the device: 256 CUs x 64 lanes x a few waves)
     // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
     bool m3 = !P.fast && use_match3(P);
-    for (auto &s : segs) if (s.sw_cnt) m3 = false;
+    if (!sw_pos_in.empty()) {   // SetLevel / SetStrategy inside the (single) segment: any number of changes, carried in device arrays
+        if (nseg != 1 || sw_pos_in.size() != sw_P_in.size()) { set_error("parameter changes inside a segment are a single-stream feature"); return SZL_E_UNSUPPORTED; }
+        segs[0].sw_cnt = (uint32_t)sw_pos_in.size();
+        m3 = false;
+    } else for (auto &s : segs) { s.sw_cnt = 0; s.sw_pos = nullptr; s.sw_P = nullptr; }
     int64_t tile_len = m3 ? match3_tile() : B_TILE;
     if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
     while (tile_len > 2048 && total_emit / (uint64_t)tile_len < 128) tile_len >>= 1;
@@ -319,11 +324,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             for (int64_t a = s.seg_start; part && a < s.seg_end; a += part)
                 stripes.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(part, s.seg_end - a), 0});
         } else { // SetLevel / SetStrategy inside the segment: tiles end at the switch positions, each searched with its own parameters
-            if (s.sw_cnt > SEG_MAX_SWITCH) { set_error("too many parameter changes in one segment"); return SZL_E_UNSUPPORTED; }
             has_switch = true;
             int64_t lo = s.seg_start;
             for (uint32_t k = 0; k <= s.sw_cnt; k++) {
-                int64_t hi = k < s.sw_cnt ? std::min<int64_t>(std::max<int64_t>(s.sw_pos[k], lo), s.seg_end) : s.seg_end;
+                int64_t hi = k < s.sw_cnt ? std::min<int64_t>(std::max<int64_t>(sw_pos_in[k], lo), s.seg_end) : s.seg_end;
                 for (int64_t a = lo; a < hi; a += B_TILE)
                     tiles.push_back(TileDev{i, 0, a, (int32_t)std::min<int64_t>(B_TILE, hi - a), (int32_t)k});
                 lo = hi;
@@ -370,6 +374,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     if ((rc = blp.ensure((blk_slots + 1) * 8))) return rc;
     if ((rc = counters.ensure(CNT_WORDS * 8))) return rc;
     if (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) return rc;
+    if (!sw_pos_in.empty()) {
+        if ((rc = upload(d_sw_pos, sw_pos_in, st)) || (rc = upload(d_sw_P, sw_P_in, st))) return rc;
+        segs[0].sw_pos = (const int64_t *)d_sw_pos.p; segs[0].sw_P = (const LevelParams *)d_sw_P.p;
+    }
     if ((rc = upload(d_segs, segs, st))) return rc;
     if ((rc = upload(d_bnds, bnds, st))) return rc;
     if ((rc = upload(d_spans, spans, st))) return rc;
@@ -496,7 +504,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             size_t b = a;
             while (b < tiles.size() && tiles[b].pad2 == tiles[a].pad2) b++;
             LevelParams Pk = P;
-            if (tiles[a].pad2 > 0) Pk = segs[tiles[a].seg].sw_P[tiles[a].pad2 - 1];
+            if (tiles[a].pad2 > 0) Pk = sw_P_in[(size_t)tiles[a].pad2 - 1];
             HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p + a, (int)(b - a), (const uint16_t *)link.p, mt, Pk, dcnt, st));
             a = b;
         }
@@ -538,6 +546,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
                 (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
     HIPCHK(hipEventRecord(ev[4], st));
     }
+    // a segment that ends where the reference's engine stands at a SetLevel to another function (SEG_SWITCH_CUT): DeflateFast cut itself
+    // (k_fast); DeflateSlow's token stream is cut here
+    if (!fast && nseg == 1 && (segs[0].flags & SEG_SWITCH_CUT))
+        launch_switch_cut(d_in, dsegs, (uint32_t *)tokens.p, dso, (const uint64_t *)blk_off.p, (const int64_t *)bsp.p, (int64_t *)blp.p, st);
     // D: blocks
     launch_seg_blocks(dsegs, nseg, (const uint32_t *)tokens.p, (const uint64_t *)blk_off.p, dso, fast ? 1 : 0, st);
     launch_block_build(dsegs, nseg, dso, (const uint64_t *)blk_off.p, (const uint32_t *)tokens.p, (const int64_t *)bsp.p, (const int64_t *)blp.p,

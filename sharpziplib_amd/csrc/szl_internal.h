@@ -21,7 +21,6 @@ enum : int { LIT_NUM = 286, DIST_NUM = 30, BL_NUM = 19 };
 
 // fast != 0: DeflateFast (levels 1-4): max_lazy is the longest match whose interior is still inserted (:697)
 struct LevelParams { int good, nice, max_chain, strategy, max_lazy, fast; };
-enum : int { SEG_MAX_SWITCH = 4 };   // parameter changes inside one segment (more: SZL_E_UNSUPPORTED)
 
 // Stage-B output, indexed like the input buffer.  The parse reads ~4 bytes per position of it and is HBM-bound on exactly that
 // (k_spec_win, round-2 VERDICT), so an entry is ONE packed word in `m2`:
@@ -76,15 +75,21 @@ struct SegDev {
     // LevelParams — the search at x (stage B) and the lazy decision at x (stage C) alike.  The engine stops at the first
     // iteration start within MIN_LOOKAHEAD - 1 of the input it has, so "every iteration start >= that threshold" is exactly
     // "every iteration after the call".
-    uint32_t sw_cnt;
+    uint32_t sw_cnt;     // entries of sw_pos / sw_P (device arrays of the call, any number; the engine uploads them: Engine::sw_pos_in / sw_P_in)
     uint32_t range_len;  // positions per stage-C range (C_RANGE; shorter for small calls: the ranges are walked serially, latency counts there)
-    int64_t sw_pos[SEG_MAX_SWITCH];
-    LevelParams sw_P[SEG_MAX_SWITCH];
+    const int64_t *sw_pos;
+    const LevelParams *sw_P;
+    // SEG_SWITCH_CUT (SetLevel across compression functions with bytes pending, C/DeflaterEngine.cs:319-359): the reference flushes a
+    // block where its engine STANDS and continues with the other function.  The engine stands at the first iteration start at or
+    // behind cut_pos (it stopped for want of lookahead: `while (lookahead >= MIN_LOOKAHEAD || flush)`, :681,:759); the segment's
+    // tokens end there (a DeflateSlow iteration with a match pending drops the match and tallies its first byte, :338-341), the
+    // last block is flushed without sync padding, and SegOut.cut_x says where the next function starts.
+    int64_t cut_pos;
     int64_t look_end;      // buffer position one past the last byte the ENGINE HAS SEEN (lookahead, FillWindow :379-394).  Equals
                            // seg_end except for the windows of a long stream (Engine::deflate_windowed): there seg_end only ends
                            // the window's parse ranges, while matches and the insert rule look on to the true end of the input.
 };
-enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4, SEG_ZLIB_HEADER = 8, SEG_GZIP = 16 };
+enum : uint32_t { SEG_SYNC_PAD = 1, SEG_EXTRA_FINAL_EMPTY = 2, SEG_ZLIB_TRAILER = 4, SEG_ZLIB_HEADER = 8, SEG_GZIP = 16, SEG_SWITCH_CUT = 32 };
 
 struct SpanDev { uint32_t seg; uint32_t pad; int64_t start, end; };          // stage A: emit links for [start,end)
 struct TileDev { uint32_t seg; uint32_t pad; int64_t start; int32_t len; int32_t pad2; }; // stage B tile (pad2: index + 1 into the segment's sw_P, 0 = the call's parameters; host side only)
@@ -112,6 +117,7 @@ struct SegOut {          // per-segment results written by the device
     uint64_t end_bit;    // bit offset (inside out region) after the last block / trailer
     uint64_t out_bytes;  // bytes of output (incl. a trailing partial byte)
     uint32_t crc32, adler32;
+    int64_t cut_x;       // SEG_SWITCH_CUT: buffer position the segment's tokens end at (the next function's first iteration)
 };
 
 struct StoredBlk { uint64_t in_off; uint64_t out_off; uint32_t len; uint32_t last; }; // level 0: one stored block

@@ -46,7 +46,8 @@ __global__ void k_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *
     const uint64_t T = so[si].tok_count;
     uint64_t full = T / BLOCK_TOKENS, rem = T % BLOCK_TOKENS;
     uint64_t nb = full;
-    if (rem > 0 || T == 0) nb++;
+    if (segs[si].flags & SEG_SWITCH_CUT) { if (rem > 0) nb++; }   // FlushBlock only `if (strstart > blockStart)` (C/DeflaterEngine.cs:336,:345): no empty block, no sync block
+    else if (rem > 0 || T == 0) nb++;
     else if (fast) { if (!segs[si].finish) nb++; } // DeflateFast: the full block was the last one iff finishing (:729); a flush adds an empty block (:664)
     else if ((tokens[so[si].tok_first + T - 1] >> 16) != 0 && !segs[si].finish) nb++; // sync flush right after a full block
     so[si].blk_first = (uint32_t)blk_off[si];
@@ -315,8 +316,9 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     if ((tid & 63) == 0) { atomicAdd(&s_sums[0], a); atomicAdd(&s_sums[1], st); atomicAdd(&s_sums[2], abl); }
     __syncthreads();
 
-    const int64_t in_start = ntok > 0 ? blk_start_pos[gb] : s.seg_end;
-    int64_t in_next = s.seg_end;
+    const int64_t seg_stop = (s.flags & SEG_SWITCH_CUT) ? so[si].cut_x : s.seg_end;   // (a cut segment's last block ends where the engine stands)
+    const int64_t in_start = ntok > 0 ? blk_start_pos[gb] : seg_stop;
+    int64_t in_next = seg_stop;
     if (lb + 1 < so[si].blk_count && T > tdone + BLOCK_TOKENS) in_next = blk_start_pos[gb + 1];
     const int in_len = (int)(in_next - in_start);
 

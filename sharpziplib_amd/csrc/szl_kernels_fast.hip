@@ -129,7 +129,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
     LevelParams Pc = P;                   // parameters of the running iteration (SetLevel / SetStrategy inside the segment: SegDev.sw_*)
     bool search = Pc.strategy != 2;       // HuffmanOnly :686
 
+    const bool cut = (s.flags & SEG_SWITCH_CUT) != 0;   // SetLevel to another compression function: the engine stands at the first iteration start >= cut_pos (:681)
     while (x < seg_end) {
+        if (cut && x >= s.cut_pos) break;
         if (s.sw_cnt) {
             Pc = P;
             for (uint32_t k = 0; k < s.sw_cnt; k++) if (x >= s.sw_pos[k]) Pc = s.sw_P[k];
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
         else if (!s.finish) blk_base[b0 + ntok / BLOCK_TOKENS] = base;
         so[si].tok_first = tok_base;
         so[si].tok_count = ntok;
+        so[si].cut_x = x;                 // (SEG_SWITCH_CUT: where the next function starts)
     }
     // inserted bits of the last 32 Ki positions -> global (history of the next segment of this stream)
     __syncthreads();

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict_
             if (ins) {
                 uint32_t w = wcur;
                 if ((uint64_t)q + 4 > avail) w = (uint32_t)d[q] | ((uint32_t)d[q + 1] << 8) | ((uint32_t)d[q + 2] << 16);
-                const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
+                    const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF;
                 h = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFF; // :404,:420
             }
             haddr[u] = head_a + 4u * h; m_ins[u] = __ballot(ins);

@@ -35,7 +35,8 @@ struct ParseCtx {
     __device__ __forceinline__ LevelParams par(int64_t x) const {
         if (nsw == 0) return P;
         LevelParams r = P;
-        for (uint32_t k = 0; k < nsw; k++) if (x >= sg->sw_pos[k]) r = sg->sw_P[k];
+        const int64_t *sp = sg->sw_pos; const LevelParams *sP = sg->sw_P;
+        for (uint32_t k = 0; k < nsw; k++) if (x >= sp[k]) r = sP[k];
         return r;
     }
 };
@@ -831,6 +832,76 @@ void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDe
     if (cw == 8) { hipLaunchKernelGGL(k_emit_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos); return; }
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos, counters);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// SetLevel to another compression function while DeflateSlow has bytes pending (C/DeflaterEngine.cs:338-351).  The segment was
+// parsed as if nothing happened; the reference's engine, however, STANDS at the first iteration start at or behind cut_pos (its loop
+// stopped for want of lookahead) when the call arrives.  In terms of the token stream: iteration starts are the token starts plus,
+// for every match token, the position after its first byte (the lazy look).  So the cut lands on the first token start >= cut_pos —
+// unless the token in front of it is a match that starts at cut_pos - 1: then the engine stands on that match's lazy look with the
+// match pending, SetLevel tallies its first byte as a literal and drops the match (`if (prevAvailable) TallyLit`, :340), and the
+// next function starts one byte behind the match start.  (Iterations in front of the cut had MIN_LOOKAHEAD bytes to look at: what
+// follows the cut never influenced them.)  One wavefront, segment 0.
+__global__ __launch_bounds__(64) void k_switch_cut(const uint8_t *in, const SegDev *segs, uint32_t *tokens, SegOut *so, const uint64_t *blk_off,
+                                                   const int64_t *blk_start_pos, int64_t *blk_lasttok_pos) {
+    const int lane = threadIdx.x;
+    const SegDev s = segs[0];
+    const uint8_t *d = in + s.buf_off;
+    const int64_t T = s.cut_pos;
+    const uint64_t ntok = so[0].tok_count, tf = so[0].tok_first, b0 = blk_off[0];
+    uint64_t keep = 0;           // tokens that stay
+    int64_t X = s.seg_start;     // where the next function starts
+    int64_t last_pos = -1;       // start of the last token that stays (for the block's stored-offset rule)
+    bool patch = false;
+    if (ntok > 0 && blk_start_pos[b0] < T) {
+        const uint64_t nblk = (ntok + BLOCK_TOKENS - 1) / BLOCK_TOKENS;
+        uint64_t lo = 0, hi = nblk - 1;                          // last block whose first token starts below T
+        while (lo < hi) { const uint64_t mid = (lo + hi + 1) >> 1; if (blk_start_pos[b0 + mid] < T) lo = mid; else hi = mid - 1; }
+        const uint64_t kb = lo;
+        const uint64_t base_i = kb * BLOCK_TOKENS, cnt = ntok - base_i < (uint64_t)BLOCK_TOKENS ? ntok - base_i : (uint64_t)BLOCK_TOKENS;
+        int64_t pos = blk_start_pos[b0 + kb];                    // start of token base_i
+        uint64_t ci = base_i + cnt;                              // first token of the block that starts at or behind T (none: the next block's first)
+        int64_t cstart = 0, pstart = -1; uint32_t ptok = 0;      // its start; start and value of the token in front of it
+        bool found = false;
+        for (uint64_t i0 = 0; i0 < cnt && !found; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            const uint32_t t = i < cnt ? tokens[tf + base_i + i] : 0u;
+            const int len = i < cnt ? ((t >> 16) ? (int)(t & 0xFFFF) : 1) : 0;
+            int incl = len;
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            const int64_t start = pos + (int64_t)(incl - len);
+            const uint64_t m = __ballot(i < cnt && start >= T);
+            if (m) {
+                const int l = __builtin_ctzll(m);
+                found = true;
+                ci = base_i + i0 + (uint64_t)l;
+                cstart = shfl64(start, l);
+                if (l > 0) { pstart = shfl64(start, l - 1); ptok = (uint32_t)__shfl((int)t, l - 1); }
+                // (l == 0: the token in front is the previous round's last one — kept in pstart / ptok below)
+            } else {
+                pstart = shfl64(start, 63 < (int)(cnt - i0) - 1 ? 63 : (int)(cnt - i0) - 1);
+                ptok = (uint32_t)__shfl((int)t, 63 < (int)(cnt - i0) - 1 ? 63 : (int)(cnt - i0) - 1);
+                pos += (int64_t)__shfl(incl, 63);
+            }
+        }
+        if (!found) cstart = pos;                                // behind the block's last token: the next block's first token (or the segment's end)
+        keep = ci; X = cstart; last_pos = pstart;
+        if (ci > 0 && (ptok >> 16) != 0 && pstart + 1 >= T) {    // the engine stands on the lazy look of that match
+            patch = true;
+            X = pstart + 1;
+        }
+        if (lane == 0) {
+            if (patch) tokens[tf + ci - 1] = (uint32_t)d[pstart];
+            if (keep > 0) blk_lasttok_pos[b0 + (keep - 1) / BLOCK_TOKENS] = last_pos;
+        }
+    }   // (else: the first iteration start is already at or behind cut_pos — nothing was parsed, X = seg_start)
+    if (lane == 0) { so[0].tok_count = keep; so[0].cut_x = X; }
+}
+
+void launch_switch_cut(const uint8_t *in, const SegDev *segs, uint32_t *tokens, SegOut *so, const uint64_t *blk_off, const int64_t *bsp, int64_t *blp, hipStream_t st) {
+    hipLaunchKernelGGL(k_switch_cut, dim3(1), dim3(64), 0, st, in, segs, tokens, so, blk_off, bsp, blp);
 }
 
 } // namespace szl

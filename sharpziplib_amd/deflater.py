@@ -32,7 +32,7 @@ def _raise(status, where):
         raise InvalidOperation(msg)
     if status == -5:
         raise NotSupportedOnDevice(msg)
-    if status == -27:
+    if status in (-27, -28):
         raise IndexError(msg)  # IndexOutOfRangeException out of InflaterHuffmanTree.BuildTree (over-subscribed code lengths)
     raise SharpZipBaseException(msg)
 

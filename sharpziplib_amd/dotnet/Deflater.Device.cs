@@ -78,6 +78,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 				case -2: return new InvalidOperationException(detail ?? msg);             // SZL_E_STATE
 				case -5: return new NotSupportedException(detail ?? msg);                 // SZL_E_UNSUPPORTED
 				case -24: return new StreamDecodingException(msg);                         // SZL_E_DYN_HEADER
+				case -28:                                                                  // SZL_E_INDEX (UpdateHash past the window array)
 				case -27: return new IndexOutOfRangeException(msg);                        // SZL_E_CODE_OVERSUBSCRIBED (what BuildTree throws there)
 				default: return new SharpZipBaseException(msg + (detail != null ? ": " + detail : "")); // incl. -3 device errors
 			}

@@ -200,7 +200,7 @@ def test_streaming_chunks_flushes_and_reset():
 
 
 def test_deflater_state_errors():
-    from sharpziplib_amd.deflater import Deflater, InvalidOperation, NotSupportedOnDevice
+    from sharpziplib_amd.deflater import Deflater, InvalidOperation
     d = Deflater(6, True)
     d.SetInput(b"abc")
     d.Finish()
@@ -209,11 +209,14 @@ def test_deflater_state_errors():
     out = np.zeros(64, np.uint8)
     n = d.Deflate(out)
     assert out[:n].tobytes() == O.deflate(b"abc", 6) and d.IsFinished
-    d = Deflater(1, True)     # to or from DeflateStored mid-stream: not reproduced here (tests/test_gpu_setlevel.py has what is)
-    d.SetInput(b"abcabcabc"); d.Flush()
-    d.Deflate(out)
-    with pytest.raises(NotSupportedOnDevice):
-        d.SetLevel(0)
+    d, o = Deflater(1, True), O.Deflater(1, True)   # to DeflateStored mid-stream (tests/test_gpu_setlevel.py has the random patterns)
+    d.SetInput(b"abcabcabc"); d.Flush(); o.set_input(b"abcabcabc"); o.flush()
+    n = d.Deflate(out)
+    assert out[:n].tobytes() == o.deflate(64)
+    d.SetLevel(0); o.set_level(0)
+    d.SetInput(b"xyzxyz"); d.Finish(); o.set_input(b"xyzxyz"); o.finish()
+    n = d.Deflate(out)
+    assert out[:n].tobytes() == o.deflate(64) and d.IsFinished
 
 
 def test_streaming_random_chunks_and_flushes():
@@ -347,12 +350,13 @@ def test_gzip_members_on_device(eng):
     import struct
     datas = [C.generate("enwik", 0xE9, 0, 300000), np.zeros(0, np.uint8), C.random_bytes(70000)]
     mtime = 1_700_000_000
-    res = eng.deflate(datas, level=6, gzip_mtime=mtime)
-    for d, r in zip(datas, res):
-        raw = O.deflate(d, 6)
-        want = bytes([0x1F, 0x8B, 8, 0]) + struct.pack("<I", mtime) + bytes([0, 255]) + raw + struct.pack("<II", O.crc32(d), d.size & 0xFFFFFFFF)
-        assert r.data == want
-        assert gzip.decompress(r.data) == d.tobytes()
+    for level in (6, 2, 0):     # DeflateSlow, DeflateFast, DeflateStored
+        res = eng.deflate(datas, level=level, gzip_mtime=mtime)
+        for d, r in zip(datas, res):
+            raw = O.deflate(d, level)
+            want = bytes([0x1F, 0x8B, 8, 0]) + struct.pack("<I", mtime) + bytes([0, 255]) + raw + struct.pack("<II", O.crc32(d), d.size & 0xFFFFFFFF)
+            assert r.status == 0 and r.data == want, level
+            assert gzip.decompress(r.data) == d.tobytes()
     # concatenated members form a multi-member .gz (what GZipInputStream reads, S/GZip/GzipInputStream.cs:109-153)
     assert gzip.decompress(b"".join(r.data for r in res)) == b"".join(d.tobytes() for d in datas)
 

@@ -31,8 +31,10 @@ def _drain(d, o, got, ref, buf):
         ref += b
 
 
-def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_deflate_p=0.2, max_calls_per_segment=4,
-         cross_kind_at_flush=False):
+def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_deflate_p=0.2, max_calls_per_segment=None,
+         cross_kind_at_flush=False, cross_p=0.0, chunk_sizes=(1, 3, 100, 261, 262, 263, 700, 5000, 40000, 70000), stats=None):
+    """cross_p: share of the SetLevel calls that may pick ANY of `levels` — another compression function (DeflateStored /
+    DeflateFast / DeflateSlow) with bytes pending: the reference flushes a block with the old function where its engine stands."""
     from sharpziplib_amd.deflater import Deflater
     rng = np.random.default_rng(seed)
     data = np.concatenate([C.generate("enwik", seed, 0, total // 2), C.generate("logs", seed + 1, 0, total - total // 2)])
@@ -42,17 +44,30 @@ def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_
     buf = np.zeros(8192, np.uint8)
     pos, calls = 0, 0
     log = []
+    kind = lambda lv: 0 if lv == 0 else (1 if lv < 5 else 2)
 
     def maybe_switch():
         nonlocal calls
-        if calls >= max_calls_per_segment:
-            return
+        if max_calls_per_segment is not None and calls >= max_calls_per_segment:
+            return True
         r = rng.random()
         if r < 0.45:
-            lv = int(rng.choice([l for l in levels if (l < 5) == (d_level[0] < 5)]))   # the same compression function
-            d.SetLevel(lv); o.set_level(lv)
+            if rng.random() < cross_p:
+                lv = int(rng.choice(levels))
+            else:
+                lv = int(rng.choice([l for l in levels if kind(l) == kind(d_level[0])]))   # the same compression function
+            try:
+                d.SetLevel(lv)
+            except IndexError:          # UpdateHash() past the window array: the reference throws IndexOutOfRangeException there
+                if stats is not None:
+                    stats["index"] = stats.get("index", 0) + 1
+                return False
+            o.set_level(lv)
             if lv != d_level[0]:
                 calls += 1
+                if stats is not None and kind(lv) != kind(d_level[0]):
+                    k = "%d>%d" % (kind(d_level[0]), kind(lv))
+                    stats[k] = stats.get(k, 0) + 1
             d_level[0] = lv
             log.append(("level", pos, lv))
         elif r < 0.6 and len(strategies) > 1:
@@ -62,31 +77,48 @@ def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_
             d.SetStrategy(st); o.set_strategy(st)
             d_strat[0] = st
             log.append(("strategy", pos, st))
+        return True
+
+    def drain_both():
+        while True:                                # drain until Deflate() returns 0: only then has the reference's engine run
+            k = d.Deflate(buf)                     # as far as its lookahead allows (it pauses after every block while output
+            if k <= 0:                             # is pending, C/DeflaterEngine.cs:126-139; IsNeedingInput alone says nothing
+                break                              # about that) — the position the device assumes, see DESIGN §7
+            got.extend(buf[:k].tobytes())
+        while True:
+            b = o.deflate(8192)
+            if not b:
+                break
+            ref.extend(b)
 
     d_level, d_strat = [level], [0]
     while pos < data.size:
-        n = int(rng.choice([1, 3, 100, 261, 262, 263, 700, 5000, 40000, 70000]))
+        n = int(rng.choice(chunk_sizes))
         c = data[pos:pos + n]
         pos += c.size
         d.SetInput(c); o.set_input(c)
         if rng.random() < call_before_deflate_p:
-            maybe_switch()                         # the engine has not seen this chunk yet
-        assert d.Deflate(buf) == 0 and d.IsNeedingInput
-        while True:                                # drain until Deflate() returns 0: only then has the reference's engine run
-            b = o.deflate(8192)                    # as far as its lookahead allows (it pauses after every block while output
-            if not b:                              # is pending, C/DeflaterEngine.cs:126-139; IsNeedingInput alone says nothing
-                break                              # about that) — the position the device assumes, see DESIGN §7
-            ref += b
-        assert o.needs_input
-        maybe_switch()                             # the engine stopped within 261 bytes of the end of this chunk
+            if not maybe_switch():                 # the engine has not seen this chunk yet
+                return
+        drain_both()
+        assert d.IsNeedingInput and o.needs_input
+        if not maybe_switch():                     # the engine stopped within 261 bytes of the end of this chunk
+            return
+        if rng.random() < 0.5:
+            drain_both()                           # the block a function change flushed (the next Deflate() call hands it out anyway)
+            assert bytes(ref).startswith(bytes(got)) or bytes(got).startswith(bytes(ref)), (seed, pos, log[-6:])
         if rng.random() < flush_p:
             d.Flush(); o.flush()
-            _drain(d, o, got, ref, buf)
+            drain_both()
             calls = 0
             assert bytes(got) == bytes(ref), (seed, pos, log[-6:])
-            if cross_kind_at_flush and rng.random() < 0.6:      # DeflateFast <-> DeflateSlow: right after a flush
+            if cross_kind_at_flush and rng.random() < 0.6:      # another function right after a flush
                 lv = int(rng.choice(levels))
-                d.SetLevel(lv); o.set_level(lv)
+                try:
+                    d.SetLevel(lv)
+                except IndexError:
+                    return
+                o.set_level(lv)
                 d_level[0] = lv
                 log.append(("level@flush", pos, lv))
     d.Finish(); o.finish()
@@ -127,28 +159,43 @@ def test_switch_without_any_flush():
     _run([5, 6, 8, 9], 31, total=900000, flush_p=0.0, max_calls_per_segment=4)
 
 
-def test_too_many_switches_is_reported_not_guessed():
-    from sharpziplib_amd.deflater import Deflater, NotSupportedOnDevice
-    d = Deflater(6, True)
+def test_many_switches_inside_one_segment():
+    """a dozen parameter changes between two flushes (the reference takes any number, C/DeflaterEngine.cs:304-361)"""
+    _run([5, 6, 7, 8, 9], 32, total=500000, flush_p=0.03, call_before_deflate_p=0.5, chunk_sizes=(100, 700, 5000, 20000))
+
+
+@pytest.mark.parametrize("seed", [51, 52, 53, 54, 55, 56, 57, 58])
+def test_fast_and_slow_levels_switch_with_bytes_pending(seed):
+    """DeflateFast <-> DeflateSlow anywhere: the old function flushes a block where its engine stands (FlushBlock(.., false),
+    C/DeflaterEngine.cs:335-353; a pending lazy match of DeflateSlow is dropped and its first byte tallied), the new one goes on
+    from there on the hash chains the old one left."""
+    _run([1, 2, 3, 4, 5, 6, 7, 9], seed, cross_p=0.7, total=400000)
+
+
+@pytest.mark.parametrize("seed", [61, 62, 63, 64, 65, 66, 67, 68, 69, 70])
+def test_all_three_functions_switch_with_bytes_pending(seed):
+    """level 0 in the mix: FlushStoredBlock of what DeflateStored consumed (:327-333; its UpdateHash() is redone by FillWindow :396),
+    stored blocks that start inside a byte after a coded block, DeflateStored taking over a coded function's lookahead."""
+    st = {}
+    _run([0, 1, 3, 4, 5, 6, 9], seed, cross_p=0.8, total=400000, stats=st)
+    print("switches", st)
+
+
+@pytest.mark.parametrize("seed", [81, 82, 83, 84])
+def test_all_three_functions_small_chunks_cross_window_bases(seed):
+    """small SetInput chunks, few flushes: chunk ends fall everywhere relative to the window base, the engine slides between them"""
+    st = {}
+    _run([0, 2, 6], seed, cross_p=0.9, total=300000, flush_p=0.02, chunk_sizes=(1, 50, 261, 262, 700, 3000, 9000), stats=st)
+    print("switches", st)
+
+
+def test_update_hash_past_the_window_array_throws_like_the_reference():
+    """DeflateStored standing at the end of a full window (strstart = 65536 after 65535 bytes): SetLevel's UpdateHash() reads
+    window[strstart] past the array (C/DeflaterEngine.cs:332,:409) — IndexOutOfRangeException in the reference, IndexError here."""
+    from sharpziplib_amd.deflater import Deflater
+    d = Deflater(0, True)
     buf = np.zeros(4096, np.uint8)
-    data = C.generate("enwik", 3, 0, 50000)
-    d.SetInput(data); d.Deflate(buf)
-    for lv in (7, 8, 9, 5):
-        d.SetLevel(lv)
-    with pytest.raises(NotSupportedOnDevice):
+    d.SetInput(C.generate("enwik", 5, 0, 65535))
+    assert d.Deflate(buf) == 0
+    with pytest.raises(IndexError):
         d.SetLevel(6)
-
-
-def test_compression_function_change_with_pending_bytes_is_refused():
-    from sharpziplib_amd.deflater import Deflater, NotSupportedOnDevice
-    d = Deflater(6, True)
-    buf = np.zeros(4096, np.uint8)
-    d.SetInput(C.generate("enwik", 4, 0, 5000)); d.Deflate(buf)
-    with pytest.raises(NotSupportedOnDevice):
-        d.SetLevel(3)                  # DeflateSlow -> DeflateFast with bytes pending: the reference closes a block mid-segment
-    d.Flush()
-    while d.Deflate(buf) > 0:
-        pass
-    with pytest.raises(NotSupportedOnDevice):
-        d.SetLevel(0)                  # DeflateStored mid-stream
-    d.SetLevel(3)                      # right after a flush: fine
