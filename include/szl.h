@@ -50,7 +50,8 @@ typedef enum szl_status {
                                        C/DeflaterHuffman.cs:924-930); the shim rethrows that type */
     SZL_E_INDEX = -28              /* IndexOutOfRangeException out of DeflaterEngine.UpdateHash (C/DeflaterEngine.cs:409): SetLevel from level 0 to a
                                        coded level while DeflateStored stands at one of the last two bytes of a full window reads
-                                       window[strstart + 1] past the array — the reference throws there, and so does this */
+                                       window[strstart + 1] past the array.  A caller who drains Deflate() never gets there (the last
+                                       engine call slides the window first, :371); kept as a guard, not reachable through this API */
 } szl_status;
 
 const char *szl_strerror(int status);
@@ -71,7 +72,14 @@ int szl_adler32(uint32_t value, const void *host_data, size_t n, uint32_t *out);
 typedef struct szl_deflater szl_deflater;
 
 /* Deflater(int level, bool noZlibHeaderOrFooter) C/Deflater.cs:178 ; level -1 => 6 ; returns NULL and
- * sets szl_last_error on a bad level (ArgumentOutOfRangeException :184-187) or device failure. */
+ * sets szl_last_error on a bad level (ArgumentOutOfRangeException :184-187) or device failure.
+ *
+ * Levels and speed.  5-9 (DeflateSlow) are the accelerated path: every position's match search is independent, so one stream
+ * spreads over the whole device (level 6: ~16 GiB/s per MI355X, bench.py).  0 is a copy with block headers.  1-4 (DeflateFast)
+ * are COMPATIBILITY-ONLY: bit-identical, but the dictionary of DeflateFast depends on its own output (C/DeflaterEngine.cs:697-712),
+ * which makes a stream a sequential recurrence — one wavefront per stream, ~2 MiB/s for a single stream (a CPU core does ~95)
+ * and ~0.5 GiB/s over thousands of streams in one batch call.  Level 5 is faster than that by an order of magnitude AND
+ * compresses better; pick 1-4 on the device only to reproduce bytes an existing consumer expects. */
 szl_deflater *szl_deflater_create(int level, int no_zlib_header_or_footer);
 void szl_deflater_destroy(szl_deflater *d);
 int szl_deflater_reset(szl_deflater *d);                                   /* Reset()          C/Deflater.cs:204 */

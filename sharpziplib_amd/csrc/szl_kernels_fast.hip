@@ -164,8 +164,13 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
             int64_t c = x;
             bool first = true;   // still looking for hashHead, the newest INSERTED position of this hash (:686)
             int budget = Pc.max_chain;
+            // Path compression: the inserted bits of positions behind x are final, so a run of never-inserted positions between two
+            // chain elements is walked once — the element in front of it (`from`) then links straight to the next inserted one in
+            // this wavefront's LDS copy of the links (distances < 65536: both lie inside the 32 Ki links resident here).
+            int64_t from = x;
+            bool skipped = false;
             for (;;) {
-                if (lnk == 0) break;
+                if (lnk == 0) { if (skipped && lane == 0) S.link[(uint32_t)from & (F_LINKS - 1)] = 0; break; }
                 c -= lnk;
                 if (first) {
                     if (x - c > MAX_DIST) break;              // strstart - hashHead <= MAX_DIST :687 (older hops are farther still)
@@ -175,7 +180,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
                 const uint32_t fw = S.flag[((uint32_t)c >> 5) & (F_FLAGW - 1)];
                 const uint32_t cdw = ldsdw((uint32_t)c + off);
                 lnk = rfl((int)l2);
-                if (((rfl((int)fw) >> ((uint32_t)c & 31)) & 1) == 0) continue; // never inserted: not part of the reference's chain
+                if (((rfl((int)fw) >> ((uint32_t)c & 31)) & 1) == 0) { skipped = true; continue; } // never inserted: not part of the reference's chain
+                if (skipped && lane == 0) S.link[(uint32_t)from & (F_LINKS - 1)] = (uint16_t)(from - c);
+                from = c; skipped = false;
                 first = false;
                 // length of the common prefix of c and x, capped (:505-591)
                 const uint32_t xr = cdw ^ xdw;

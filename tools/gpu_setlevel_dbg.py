@@ -84,3 +84,5 @@ run("stored>slow>stored>fast", 0, [I(5000), D, L(6), I(30000), D, L(0), I(40000)
 run("zlib stored>slow", 0, [I(5000), D, L(6), I(3000), D], nowrap=False)
 run("zlib slow>stored>fast", 6, [I(5000), D, L(0), I(3000), D, L(1), I(9000), D], nowrap=False)
 run("stored full window>slow", 0, [I(65535), D, L(6), I(3000), D])
+run("stored 65273>slow", 0, [I(65273), D, L(6), I(3000), D])
+run("stored 65272>fast", 0, [I(65272), D, L(3), I(3000), D])
