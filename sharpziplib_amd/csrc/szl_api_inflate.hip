@@ -408,6 +408,8 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
             hipStreamSynchronize(st) != hipSuccess) { cleanup(); set_error("inflate kernel/D2H failed: %s", hipGetErrorString(hipGetLastError())); return SZL_E_DEVICE; }
         cleanup();
         float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
+        if (knob("SZL_DEBUG", 0)) { uint64_t r = 0, p = 0, t = 0, ob = 0; for (auto &j : jobs) { r += j.dbg_rounds; p += j.dbg_par; t += j.dbg_partok; ob += j.out_written; }
+            fprintf(stderr, "[szl] inflate: rounds %llu parallel %llu tokens in parallel rounds %llu out bytes %llu\n", (unsigned long long)r, (unsigned long long)p, (unsigned long long)t, (unsigned long long)ob); }
     }
     std::vector<std::pair<uint32_t, uint32_t>> cks;
     if (want) {

@@ -20,7 +20,7 @@ struct InfJob {
     uint32_t zlib;       // 1: zlib framing (header at mode INF_M_ZHEADER, Adler-32 trailer)
     uint32_t keep_window;
     uint32_t load_window; // 1: restore the window even at outpos 0 (preset dictionary)
-    uint32_t pad1;
+    uint32_t dbg_rounds;  // [out] decode rounds of this call (SZL_DEBUG prints the sums)
     // chunked decode of ONE member (szl_api_inflate.hip, inflate_member_parallel): this job decodes the blocks from bit `start_bit`
     // (a block header) up to the block boundary `stop_bit` (~0: to the end of the stream); `sym_out` receives 16-bit symbols —
     // a byte, or 0x8000 | i for "byte i of the 32 KiB of output in front of this chunk", unknown until the chunks before are done
@@ -31,6 +31,8 @@ struct InfJob {
     uint64_t out_written;
     uint64_t consumed;   // ceil(bits consumed / 8)  == Inflater.TotalIn at this point
     int32_t status;
+    uint32_t dbg_par;     // [out] rounds decoded by the whole wavefront (the rest: lane 0's careful path, headers, restaging)
+    uint32_t dbg_partok;  // [out] tokens of those rounds
     uint32_t pad;
 };
 

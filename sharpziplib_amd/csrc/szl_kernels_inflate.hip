@@ -21,6 +21,9 @@
 
 namespace szl {
 
+#ifndef SZL_INF_NPO
+#define SZL_INF_NPO 4   // bit offsets every lane decodes speculatively per round (64 * NPO bits of input per round; 6 and 8 measured: +-1 %)
+#endif
 enum : int { I_WIN = 32768, I_STAGE = 1024, I_LPB = 10, I_DPB = 9, MAX_MATCH_I = 258 };
 // One-shot jobs (batch API: the whole output of a stream is one contiguous region) use the SHORT-window form: only the
 // last 8 KiB of output live in LDS and matches that reach farther back read the output region itself, which lets a CU keep
@@ -60,25 +63,52 @@ struct InfLds {
 // lengths' Kraft sum exceeds 1.  Incomplete sets are accepted like there (:116-121 commented out).
 __device__ bool build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut, int pb, uint16_t *codes, int lane) {
     for (int i = lane; i < (1 << pb); i += 64) lut[i] = 0;
-    int over = 0;
-    if (lane == 0) {
-        int cnt[16];
-        for (int l = 0; l < 16; l++) cnt[l] = 0;
-        for (int i = 0; i < n; i++) cnt[lens[i]]++;
-        cnt[0] = 0;
-        int code = 0, off = 0, kraft = 0;
-        for (int l = 1; l < 16; l++) {
-            T->first[l] = (uint16_t)code; T->count[l] = (uint16_t)cnt[l]; T->offs[l] = (uint16_t)off;
-            code = (code + cnt[l]) << 1;
-            off += cnt[l];
-            kraft += cnt[l] << (16 - l);
+    // Counts per length, first canonical code and offset of each length, and every symbol's code: all lanes, registers only.
+    // (The obvious form — lane 0 counting into cnt[lens[i]] — indexes private arrays dynamically, which puts them in scratch
+    // memory: ~1 us per dependent access, three passes over up to 286 symbols, ~1 ms per block — a third of the whole decode.)
+    uint32_t cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) cnt[l] = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const int l = i < n ? (int)lens[i] : 0;
+#pragma unroll
+        for (int L = 1; L < 16; L++) cnt[L] += (uint32_t)__builtin_popcountll(__ballot(l == L));
+    }
+    uint32_t first[16], offs[16];
+    int over;
+    {
+        uint32_t code = 0, off = 0, kraft = 0;
+#pragma unroll
+        for (int L = 1; L < 16; L++) {
+            first[L] = code & 0xFFFFu; offs[L] = off;
+            code = (code + cnt[L]) << 1;
+            off += cnt[L];
+            kraft += cnt[L] << (16 - L);
         }
         over = kraft > 65536;
-        int nxt[16], pos[16];
-        for (int l = 1; l < 16; l++) { nxt[l] = T->first[l]; pos[l] = T->offs[l]; }
-        for (int i = 0; i < n; i++) {
-            int l = lens[i];
-            if (l) { codes[i] = (uint16_t)nxt[l]++; T->sorted[pos[l]++] = (uint16_t)i; }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int L = 1; L < 16; L++) { T->first[L] = (uint16_t)first[L]; T->count[L] = (uint16_t)cnt[L]; T->offs[L] = (uint16_t)offs[L]; }
+    }
+    if (!over) {
+        uint32_t run[16];
+#pragma unroll
+        for (int L = 0; L < 16; L++) run[L] = 0;
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            const int l = i < n ? (int)lens[i] : 0;
+            uint32_t mycode = 0, mypos = 0;
+#pragma unroll
+            for (int L = 1; L < 16; L++) {
+                const uint64_t m = __ballot(l == L);
+                const uint32_t r = run[L] + (uint32_t)__builtin_popcountll(m & below);
+                if (l == L) { mycode = first[L] + r; mypos = offs[L] + r; }
+                run[L] += (uint32_t)__builtin_popcountll(m);
+            }
+            if (l) { codes[i] = (uint16_t)mycode; T->sorted[mypos] = (uint16_t)i; }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -98,6 +128,17 @@ __device__ bool build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut,
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     return true;
+}
+
+// OR over the wavefront without the LDS (DPP row shifts and broadcasts); the result is wave-uniform
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8  (lane 15 of every row: the row's OR)
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
 // decode one symbol from the low bits of `bits` (LSB-first); returns sym | len<<16, or -1 invalid
@@ -238,19 +279,22 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
     };
 
     enum { EV_NONE = 0, EV_RESTAGE, EV_TABLES, EV_STORED, EV_STOP };
-    enum { QN = 64, PAR_W = 128, PAR_BYTES = PAR_W / 8 + 24 }; // bytes the parallel round may touch from its first byte on
+    enum { QN = 64, NPO = SZL_INF_NPO, PAR_W = 64 * NPO, PAR_BYTES = PAR_W / 8 + 24 }; // offsets per lane; bits per round; bytes the parallel round may touch from its first byte on
     // Decode state (bit buffer, block mode, table sizes) is private to lane 0.  Each round lane 0 decodes up to 64
     // tokens into an LDS queue; then the whole wavefront applies them (prefix sum of lengths, literals in parallel,
     // matches in order with all lanes copying), flushes the window when half full, and services lane 0's request.
+    uint32_t dbg_rounds = 0, dbg_par = 0, dbg_partok = 0;
     while (status == INF_RUNNING) {
         int ev = EV_NONE, ea = 0, eb = 0, ntok = 0;
+        dbg_rounds++;
         // ---------------- wave-parallel round (the common case inside a Huffman block)
-        // Every lane decodes the complete token that WOULD start at two bit offsets of a 128-bit span (offset = lane,
-        // lane+64): literal/length code through the primary table, length extra bits, distance code, distance extra bits
+        // Every lane decodes the complete token that WOULD start at NPO bit offsets of a 64*NPO-bit span (offset = lane,
+        // lane+64, ...): literal/length code through the primary table, length extra bits, distance code, distance extra bits
         // (C/Inflater.cs:283-386).  Which offsets really are token starts is then a walk from offset 0 over the decoded
-        // bit counts, done with readlane (no memory traffic): one round yields ~9 tokens on text instead of lane 0
-        // crawling through them.  Anything unusual at a real token start — code longer than the primary table, end of
-        // block, an invalid code — stops the walk there and is left to the careful single-token path below.
+        // bit counts (scalar, one readlane per token, no memory traffic); the tokens at the starts are queued by all lanes
+        // at once: one round yields ~19 tokens on text instead of lane 0 crawling through them.  Anything unusual at a real
+        // token start — code longer than the primary table, end of block, an invalid code — stops the walk there and is left
+        // to the careful single-token path below.
         bool par_ok = false;   // preconditions of the parallel round held (then the careful path handles one token only)
         uint64_t par_bitpos = 0;
         {
@@ -270,9 +314,9 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                 }
             }
             if (par_ok) {
-                uint32_t tokv[2];
+                uint32_t tokv[NPO];
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++) {
+                for (int jj = 0; jj < NPO; jj++) {
                     const uint64_t bp = P + (uint32_t)(lane + 64 * jj);
                     const uint32_t so = (uint32_t)((bp >> 3) - sbase);
                     const uint32_t w0 = S.stage[so >> 2], w1 = S.stage[(so >> 2) + 1], w2 = S.stage[(so >> 2) + 2];
@@ -304,22 +348,70 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                     }
                     tokv[jj] = tk | (nbv << 10); // bits 10..15 (free: literal/length use 9 bits): bit count of the token, 0 = stop
                 }
-                uint32_t o = 0, olen = 0;
-                while (ntok < QN && o < (uint32_t)PAR_W && olen <= ROUND_MAX) {
-                    const int l = (int)(o & 63);
-                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[0], l), t1 = (uint32_t)__builtin_amdgcn_readlane((int)tokv[1], l);
-                    const uint32_t tp = o < 64 ? t0 : t1;
-                    const uint32_t nx = (tp >> 10) & 63u, tk = tp & 0xFFFF03FFu;
-                    if (nx == 0) break;
-                    if (lane == 0) S.queue[ntok] = tk;
-                    ntok++;
-                    olen += (tk >> 16) ? (tk & 0x3FF) : 1u;
-                    o += nx;
+                // Which offsets are token starts: a walk over the bit counts alone (NPO x 6 bits packed per lane, one readlane and a
+                // handful of scalar instructions per token — this serial loop was 38 % of the kernel when it also carried the tokens),
+                // recorded as one lane mask per 64 offsets.  The tokens are then queued by all lanes at once (rank = tokens before).
+                uint32_t pk[(NPO + 4) / 5] = {};                  // five 6-bit counts per register
+#pragma unroll
+                for (int jj = 0; jj < NPO; jj++) pk[jj / 5] |= ((tokv[jj] >> 10) & 63u) << (6 * (jj % 5));
+                uint64_t smask[NPO];
+                uint32_t o = 0;
+                bool stopped = false;
+#pragma unroll
+                for (int jj = 0; jj < NPO; jj++) {
+                    uint64_t m = 0;
+                    if (!stopped && o < 64u * (uint32_t)(jj + 1)) {
+                        // while (o < limit) { nx = (readlane(pk, o & 63) >> shift) & 63; if (!nx) break; m |= 1 << (o & 63); o += nx; }
+                        // — eight scalar instructions and one taken branch per token (readlane and s_bitset1 use bits 5:0 of o)
+                        uint32_t nx = 1, t;
+                        asm volatile("1%=:\n\t"
+                                     "v_readlane_b32 %[t], %[pk], %[o]\n\t"
+                                     "s_bfe_u32 %[n], %[t], %[bf]\n\t"
+                                     "s_cmp_eq_u32 %[n], 0\n\t"
+                                     "s_cbranch_scc1 2%=f\n\t"
+                                     "s_bitset1_b64 %[m], %[o]\n\t"
+                                     "s_add_u32 %[o], %[o], %[n]\n\t"
+                                     "s_cmp_lt_u32 %[o], %[lim]\n\t"
+                                     "s_cbranch_scc1 1%=b\n"
+                                     "2%=:"
+                                     : [o] "+s"(o), [m] "+s"(m), [n] "+s"(nx), [t] "=&s"(t)
+                                     : [pk] "v"(pk[jj / 5]), [bf] "s"((6u << 16) | (uint32_t)(6 * (jj % 5))), [lim] "s"(64u * (uint32_t)(jj + 1))
+                                     : "scc");
+                        stopped = nx == 0;
+                    }
+                    smask[jj] = m;
+                }
+                uint32_t before = 0;
+#pragma unroll
+                for (int jj = 0; jj < NPO; jj++) {
+                    const uint64_t m = smask[jj];
+                    if ((m >> lane) & 1ull) {
+                        const uint32_t rank = before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                        if (rank < (uint32_t)QN) {
+                            S.queue[rank] = tokv[jj] & 0xFFFF03FFu;
+                            S.toff[rank] = (uint16_t)((uint32_t)lane + 64u * (uint32_t)jj + ((tokv[jj] >> 10) & 63u));   // bit offset behind the token (apply rewrites toff)
+                        }
+                    }
+                    before += (uint32_t)__builtin_popcountll(m);
+                }
+                ntok = (int)(before < (uint32_t)QN ? before : (uint32_t)QN);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (ntok > 0) {
+                    // a round queues at most ROUND_MAX bytes (+ one token): cut behind the first token that starts past that
+                    if ((uint32_t)ntok * (uint32_t)MAX_MATCH_I > ROUND_MAX) {
+                        const uint32_t tq = lane < ntok ? S.queue[lane] : 0;
+                        const uint32_t ml = lane < ntok ? ((tq >> 16) ? (tq & 0xFFFF) : 1u) : 0u;
+                        uint32_t inc = ml;
+                        for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t y = __shfl_up(inc, sft); if (lane >= sft) inc += y; }
+                        ntok = __builtin_popcountll(__ballot(lane < ntok && inc - ml <= ROUND_MAX));
+                    }
+                    o = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.toff[ntok - 1]);
                 }
                 par_bitpos = P + o;
             }
         }
         const int npar = ntok;
+        if (npar) { dbg_par++; dbg_partok += (uint32_t)npar; }
         if (lane == 0) {
             uint64_t opos = outpos;                       // position after the queued tokens
             const uint64_t room_lim = flushed + ROOM;
@@ -536,8 +628,14 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                 for (uint32_t b0 = 0; b0 < rtot; b0 += 64) {
                     const uint32_t b = b0 + lane;
                     const bool act = b < rtot;
-                    uint32_t lo = 0, hi = ntok;                     // last token with toff <= b
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)S.toff[mid] <= b) lo = mid; else hi = mid; }
+                    // last token with toff <= b: the token starts inside this chunk as a 64-bit mask (an OR over the wavefront, no
+                    // LDS round trips — a binary search over toff[] was five dependent ones) + the tokens that start before it
+                    const uint32_t rel = (incl - mylen) - b0;
+                    const bool inchunk = lane < ntok && rel < 64u;
+                    const uint32_t mlo = wave_or_u32(inchunk && rel < 32u ? 1u << rel : 0u), mhi = wave_or_u32(inchunk && rel >= 32u ? 1u << (rel - 32u) : 0u);
+                    const uint64_t starts = ((uint64_t)mhi << 32) | mlo;
+                    const uint32_t nbefore = (uint32_t)__builtin_popcountll(__ballot(lane < ntok && (incl - mylen) < b0));
+                    const uint32_t lo = nbefore + (uint32_t)__builtin_popcountll(starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull))) - 1u;
                     const uint32_t tv = S.queue[lo];
                     const uint32_t k = b - (uint32_t)S.toff[lo];
                     const uint32_t d2 = tv >> 16;
@@ -656,6 +754,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
         jobs[ji].status = status;
         jobs[ji].consumed = (bitpos + 7) >> 3;
         jobs[ji].end_bit = bitpos;
+        jobs[ji].dbg_rounds = dbg_rounds; jobs[ji].dbg_par = dbg_par; jobs[ji].dbg_partok = dbg_partok;
     }
 }
 
