@@ -130,6 +130,17 @@ __device__ bool build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut,
     return true;
 }
 
+// inclusive prefix sum over the wavefront in registers (Hillis-Steele inside each row of 16 lanes, then the row totals):
+// __shfl_up is a ds_bpermute — six dependent LDS crossbar trips per scan, twice per round
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15: total of row 0 -> row 1, of row 2 -> row 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31: total of rows 0-1 -> rows 2 and 3
+    return x;
+}
 // OR over the wavefront without the LDS (DPP row shifts and broadcasts); the result is wave-uniform
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
     x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
@@ -243,6 +254,14 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         (void)rebuild_tables(); // a resumed block: these lengths were accepted when its header was read
     }
+    // second level of the literal/length code for the wave-parallel decode: lane l holds first | count << 16 and the offset of length l
+    uint32_t l2a = 0, l2b = 0;
+    auto load_second_level = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        l2a = lane < 16 ? ((uint32_t)S.lt.first[lane] | ((uint32_t)S.lt.count[lane] << 16)) : 0u;
+        l2b = lane < 16 ? (uint32_t)S.lt.offs[lane] : 0u;
+    };
+    load_second_level();
 
     // ---- input staging: S.stage holds input bytes [sbase, sbase + I_STAGE)
     uint64_t sbase = ~0ull;
@@ -296,6 +315,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
         // token start — code longer than the primary table, end of block, an invalid code — stops the walk there and is left
         // to the careful single-token path below.
         bool par_ok = false;   // preconditions of the parallel round held (then the careful path handles one token only)
+        uint32_t rmax = ROUND_MAX;
         uint64_t par_bitpos = 0;
         {
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
@@ -307,7 +327,10 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                 const uint64_t room_lim = flushed + ROOM;
                 const uint64_t olim = out_limit < room_lim ? out_limit : room_lim;
                 par_ok = byte0 >= sbase && byte0 + PAR_BYTES <= sbase + I_STAGE && availb >= (uint64_t)(PAR_W + 64) &&
-                         outpos + (uint64_t)ROUND_MAX + MAX_MATCH_I <= olim;
+                         outpos + (uint64_t)MAX_MATCH_I <= olim;
+                // bytes this round may queue before its last token (up to the end of the output region, not ROUND_MAX short of it:
+                // the last 2 KiB of every 64 KiB zip entry used to crawl through lane 0)
+                if (par_ok) { const uint64_t r = olim - outpos - MAX_MATCH_I; rmax = r < (uint64_t)ROUND_MAX ? (uint32_t)r : ROUND_MAX; }
                 if (!par_ok && byte0 >= sbase + 256 && byte0 + PAR_BYTES > sbase + I_STAGE && byte0 + PAR_BYTES <= job.in_len) {
                     // the staged input is nearly used up: slide it (cooperative) instead of crawling through the careful loop
                     ev = EV_RESTAGE; ea = (int)(uint32_t)byte0; eb = (int)(uint32_t)(byte0 >> 32);
@@ -322,7 +345,21 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                     const uint32_t w0 = S.stage[so >> 2], w1 = S.stage[(so >> 2) + 1], w2 = S.stage[(so >> 2) + 2];
                     const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, so & 3), hi = __builtin_amdgcn_alignbyte(w2, w1, so & 3);
                     const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (uint32_t)(bp & 7); // >= 57 stream bits from bp on
-                    const uint32_t e = S.llut[(uint32_t)bits & ((1u << I_LPB) - 1)];
+                    uint32_t e = S.llut[(uint32_t)bits & ((1u << I_LPB) - 1)];
+                    if (e == 0xFFFEu) {
+                        // a literal/length code longer than the primary table (every ~86th token on text, each used to cost a round
+                        // of its own through lane 0): the canonical second level (decode_sym) on all lanes — first code, count and
+                        // offset of the lengths I_LPB+1..15 come out of two registers (l2a, l2b), the symbol is one LDS read
+                        const uint32_t rev15 = __builtin_bitreverse32((uint32_t)bits) >> 17;
+                        uint32_t si = 0xFFFFFFFFu, sl2 = 0;
+#pragma unroll
+                        for (int l = I_LPB + 1; l <= 15; l++) {
+                            const uint32_t fa = (uint32_t)__builtin_amdgcn_readlane((int)l2a, l), of = (uint32_t)__builtin_amdgcn_readlane((int)l2b, l);
+                            const uint32_t idx = (rev15 >> (15 - l)) - (fa & 0xFFFFu);
+                            if (si == 0xFFFFFFFFu && idx < (fa >> 16)) { si = of + idx; sl2 = (uint32_t)l; }
+                        }
+                        e = si != 0xFFFFFFFFu ? (((uint32_t)S.lt.sorted[si] << 4) | sl2) : 0u;
+                    }
                     const uint32_t sl = e & 15, sym = e >> 4;
                     uint32_t nbv = 0, tk = 0;
                     if (e - 1 < 0xFFFDu) { // neither invalid (0) nor a long code (0xFFFE)
@@ -397,13 +434,12 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                 ntok = (int)(before < (uint32_t)QN ? before : (uint32_t)QN);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (ntok > 0) {
-                    // a round queues at most ROUND_MAX bytes (+ one token): cut behind the first token that starts past that
-                    if ((uint32_t)ntok * (uint32_t)MAX_MATCH_I > ROUND_MAX) {
+                    // a round queues at most rmax bytes (+ one token): cut behind the first token that starts past that
+                    if ((uint32_t)ntok * (uint32_t)MAX_MATCH_I > rmax) {
                         const uint32_t tq = lane < ntok ? S.queue[lane] : 0;
                         const uint32_t ml = lane < ntok ? ((tq >> 16) ? (tq & 0xFFFF) : 1u) : 0u;
-                        uint32_t inc = ml;
-                        for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t y = __shfl_up(inc, sft); if (lane >= sft) inc += y; }
-                        ntok = __builtin_popcountll(__ballot(lane < ntok && inc - ml <= ROUND_MAX));
+                        const uint32_t inc = wave_scan_add_u32(ml);
+                        ntok = __builtin_popcountll(__ballot(lane < ntok && inc - ml <= rmax));
                     }
                     o = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.toff[ntok - 1]);
                 }
@@ -607,8 +643,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
             const uint32_t tok = lane < ntok ? S.queue[lane] : 0;
             const uint32_t dist = tok >> 16;
             const uint32_t mylen = lane < ntok ? (dist ? (tok & 0xFFFF) : 1u) : 0u;
-            uint32_t incl = mylen;
-            for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            const uint32_t incl = wave_scan_add_u32(mylen);
             const uint64_t mypos = outpos + (incl - mylen);
             // Tokens are applied in stream order: the window is circular, so a literal written early could overwrite
             // history (32768 positions back) that an earlier far-distance match of the same round still has to read.
@@ -704,6 +739,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
         case EV_TABLES:
             btype = (uint32_t)ea & 3; lnum = ((uint32_t)ea >> 8) & 0xFFF; dnum = ((uint32_t)ea >> 20) & 0xFF;
             if (!rebuild_tables()) status = SZL_E_CODE_OVERSUBSCRIBED;
+            load_second_level();
             break;
         case EV_STORED: {
             const uint64_t n = (uint32_t)ea;
