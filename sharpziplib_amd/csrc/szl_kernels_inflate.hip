@@ -281,7 +281,9 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
         if (PMODE == 2) { for (uint64_t i = lane; i < n; i += 64) job.sym_out[flushed + i] = (uint16_t)S.win[(flushed + i) & I_WMASK]; }
         else if (PMODE == 0) { for (uint64_t i = lane; i < n; i += 64) out[flushed - out_start + i] = (uint8_t)S.win[(flushed + i) & I_WMASK]; }
         flushed = upto;
-        if (SHORTWIN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // later far matches read these bytes back
+        // later far matches of THIS wavefront read these bytes back: workgroup scope orders its own stores and loads (both go through the
+        // CU's L1, which its stores write through); agent scope would write the XCD's L2 back on every KiB and make every far read miss it
+        if (SHORTWIN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     };
 
     // bit reader (lane 0 owns bb/nb; bitpos is the stream position of bit 0 of bb)
@@ -679,8 +681,8 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                         const uint64_t p = outpos + (uint32_t)S.toff[lo];
                         if (d2 > FAR_DIST) {
                             const int64_t sp = (int64_t)(p - out_start) - (int64_t)d2 + (int64_t)k;
-                            if (PMODE == 2) val = sp >= 0 ? (WT)__atomic_load_n(job.sym_out + sp, __ATOMIC_RELAXED) : (WT)(0x8000u | (uint32_t)(32768 + sp));
-                            else val = sp >= 0 ? (WT)__atomic_load_n(out + sp, __ATOMIC_RELAXED) : (WT)0;
+                            if (PMODE == 2) val = sp >= 0 ? (WT)__hip_atomic_load(job.sym_out + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (WT)(0x8000u | (uint32_t)(32768 + sp));
+                            else val = sp >= 0 ? (WT)__hip_atomic_load(out + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (WT)0;
                         } else val = S.win[(p - d2 + k) & I_WMASK];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -706,11 +708,11 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                     if (PMODE == 2) { // symbols already flushed to sym_out, or — before the chunk — "byte 32768 + s of the preceding 32 KiB"
                         for (uint32_t k = lane; k < len; k += 64) {
                             const int64_t sp = s0 + (int64_t)k;
-                            S.win[(p + k) & I_WMASK] = sp >= 0 ? (WT)__atomic_load_n(job.sym_out + sp, __ATOMIC_RELAXED) : (WT)(0x8000u | (uint32_t)(32768 + sp));
+                            S.win[(p + k) & I_WMASK] = sp >= 0 ? (WT)__hip_atomic_load(job.sym_out + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (WT)(0x8000u | (uint32_t)(32768 + sp));
                         }
                     } else
                     for (uint32_t k = lane; k < len; k += 64)
-                        S.win[(p + k) & I_WMASK] = s0 + (int64_t)k >= 0 ? (WT)__atomic_load_n(out + (s0 + (int64_t)k), __ATOMIC_RELAXED) : (WT)0;
+                        S.win[(p + k) & I_WMASK] = s0 + (int64_t)k >= 0 ? (WT)__hip_atomic_load(out + (s0 + (int64_t)k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (WT)0;
                 } else if (d2 >= len) { // no overlap (wave-uniform test): plain copy
                     for (uint32_t k = lane; k < len; k += 64) S.win[(p + k) & I_WMASK] = S.win[(p - d2 + k) & I_WMASK];
                 } else {
