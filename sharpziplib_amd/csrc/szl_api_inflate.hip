@@ -352,7 +352,9 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     // Long members are decoded by many wavefronts each (inflate_members_parallel); whatever that does not take joins the batch of
     // one wavefront per stream.  With thousands of streams in a call that batch fills the device by itself and has no
     // per-stream host work at all, so the chunked form is used while the call would leave wavefront slots empty.
-    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", 512)) * 1024;
+    // (members of 128-512 KiB compressed: chunked only while the call has few streams — 64 x 1 MiB members 56 -> 34 ms, but 512 of them
+    // 57 -> 100 ms: their chunks are 16 KiB, and the finder / chain / resolve passes cost more than idle wavefront slots)
+    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", n_all <= 128 ? 128 : 512)) * 1024;
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
