@@ -174,7 +174,7 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
 // position reached.  2 = symbol pass: the same decode, writing 16-bit symbols to job.sym_out — a byte, or 0x8000 | i for
 // "byte i of the 32 KiB in front of this chunk" (what a back-reference reaching before the chunk reads; resolved afterwards).
 template <bool SHORTWIN, int PMODE>
-__global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
+__global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 1)) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
     // (a 4096-entry window for the 16-bit symbol pass — the byte form's LDS footprint — was measured: 128 members of 4 MiB 58 -> 49 ms,
     // but one 256 MiB member 74 -> 93 ms: more matches reach behind the window and are read from the symbol staging)
@@ -339,52 +339,79 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
                 }
             }
             if (par_ok) {
+                // Branch-free on purpose: with exec-mask regions around the rare cases the compiler keeps the NPO decodes apart, each
+                // waiting out its own three LDS round trips (170 instructions per 64 offsets, two thirds of a round's issue slots);
+                // as straight-line code they interleave.  32-bit windows throughout (v_alignbit instead of 64-bit shifts): a token
+                // is at most 15+5+15+13 = 48 bits, the length part at most 20, so the distance part fits one register.
                 uint32_t tokv[NPO];
+                const uint32_t p7 = (uint32_t)P & 7u, so0 = (uint32_t)((P >> 3) - sbase);
+                uint32_t fa2[16], of2[16];                                   // second level of the literal/length code (uniform)
+#pragma unroll
+                for (int l = I_LPB + 1; l <= 15; l++) { fa2[l] = (uint32_t)__builtin_amdgcn_readlane((int)l2a, l); of2[l] = (uint32_t)__builtin_amdgcn_readlane((int)l2b, l); }
+                // (written as phases over all NPO offsets so that each phase's LDS reads are in flight together)
+                uint32_t lo[NPO], hi[NPO], ev_[NPO], si_[NPO], sl2_[NPO], sr_[NPO], t2_[NPO], de_[NPO];
+                {
+                    uint32_t w0[NPO], w1[NPO], w2[NPO], sh[NPO];
+#pragma unroll
+                    for (int jj = 0; jj < NPO; jj++) {
+                        const uint32_t kk = p7 + (uint32_t)lane + 64u * (uint32_t)jj;     // bit offset from the byte of P
+                        const uint32_t so = so0 + (kk >> 3);
+                        sh[jj] = ((so & 3u) << 3) | (kk & 7u);
+                        w0[jj] = S.stage[so >> 2]; w1[jj] = S.stage[(so >> 2) + 1]; w2[jj] = S.stage[(so >> 2) + 2];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < NPO; jj++) {
+                        lo[jj] = __builtin_amdgcn_alignbit(w1[jj], w0[jj], sh[jj]); hi[jj] = __builtin_amdgcn_alignbit(w2[jj], w1[jj], sh[jj]); // 64 stream bits from the offset on
+                        ev_[jj] = S.llut[lo[jj] & ((1u << I_LPB) - 1)];
+                    }
+                }
 #pragma unroll
                 for (int jj = 0; jj < NPO; jj++) {
-                    const uint64_t bp = P + (uint32_t)(lane + 64 * jj);
-                    const uint32_t so = (uint32_t)((bp >> 3) - sbase);
-                    const uint32_t w0 = S.stage[so >> 2], w1 = S.stage[(so >> 2) + 1], w2 = S.stage[(so >> 2) + 2];
-                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, so & 3), hi = __builtin_amdgcn_alignbyte(w2, w1, so & 3);
-                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (uint32_t)(bp & 7); // >= 57 stream bits from bp on
-                    uint32_t e = S.llut[(uint32_t)bits & ((1u << I_LPB) - 1)];
-                    if (e == 0xFFFEu) {
-                        // a literal/length code longer than the primary table (every ~86th token on text, each used to cost a round
-                        // of its own through lane 0): the canonical second level (decode_sym) on all lanes — first code, count and
-                        // offset of the lengths I_LPB+1..15 come out of two registers (l2a, l2b), the symbol is one LDS read
-                        const uint32_t rev15 = __builtin_bitreverse32((uint32_t)bits) >> 17;
-                        uint32_t si = 0xFFFFFFFFu, sl2 = 0;
+                    // a literal/length code longer than the primary table (every ~86th token on text; each used to cost a round of its
+                    // own through lane 0): the canonical second level (decode_sym) — first code, count and offset of the lengths
+                    // I_LPB+1..15 come out of two registers (l2a, l2b), the symbol is one LDS read (made by every lane: no branch)
+                    const uint32_t rev15 = __builtin_bitreverse32(lo[jj]) >> 17;
+                    uint32_t si = 0, sl2 = 0;
 #pragma unroll
-                        for (int l = I_LPB + 1; l <= 15; l++) {
-                            const uint32_t fa = (uint32_t)__builtin_amdgcn_readlane((int)l2a, l), of = (uint32_t)__builtin_amdgcn_readlane((int)l2b, l);
-                            const uint32_t idx = (rev15 >> (15 - l)) - (fa & 0xFFFFu);
-                            if (si == 0xFFFFFFFFu && idx < (fa >> 16)) { si = of + idx; sl2 = (uint32_t)l; }
-                        }
-                        e = si != 0xFFFFFFFFu ? (((uint32_t)S.lt.sorted[si] << 4) | sl2) : 0u;
+                    for (int l = 15; l > I_LPB; l--) {                   // (descending: the shortest length that fits wins, as in decode_sym)
+                        const uint32_t idx = (rev15 >> (15 - l)) - (fa2[l] & 0xFFFFu);
+                        const bool hit = idx < (fa2[l] >> 16);
+                        si = hit ? of2[l] + idx : si; sl2 = hit ? (uint32_t)l : sl2;
                     }
-                    const uint32_t sl = e & 15, sym = e >> 4;
-                    uint32_t nbv = 0, tk = 0;
-                    if (e - 1 < 0xFFFDu) { // neither invalid (0) nor a long code (0xFFFE)
-                        if (sym < 256) { nbv = sl; tk = sym; }
-                        else if (sym > 256 && sym <= 285) {
-                            const uint32_t ls = sym - 257;
-                            const uint32_t xl = (ls < 8 || ls == 28) ? 0u : ((ls - 4) >> 2);             // CPLEXT :44-48
-                            const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << xl)); // CPLENS :39-43
-                            uint64_t tb = bits >> sl;
-                            const uint32_t len = lbase + ((uint32_t)tb & ((1u << xl) - 1));
-                            tb >>= xl;
-                            const uint32_t de = S.dlut[(uint32_t)tb & ((1u << I_DPB) - 1)];
-                            const uint32_t dl = de & 15, dsym = de >> 4;
-                            if (de - 1 < 0xFFFDu && dsym < 30) {
-                                tb >>= dl;
-                                const uint32_t xd = dsym < 4 ? 0u : ((dsym >> 1) - 1);                 // CPDEXT :62-68
-                                const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << xd); // CPDIST :50-60
-                                const uint32_t dist = dbase + ((uint32_t)tb & ((1u << xd) - 1));
-                                nbv = sl + xl + dl + xd;
-                                tk = len | (dist << 16);
-                            }
-                        }
-                    }
+                    si_[jj] = si; sl2_[jj] = sl2;
+                    uint32_t sr = S.lt.sorted[si];
+                    asm volatile("" : "+v"(sr));                           // (keeps the read out of a conditional region)
+                    sr_[jj] = sr;
+                }
+                uint32_t sl_[NPO], xl_[NPO], len_[NPO], sym_[NPO];
+                bool evalid_[NPO], islit_[NPO], islen_[NPO];
+#pragma unroll
+                for (int jj = 0; jj < NPO; jj++) {
+                    const uint32_t e2 = sl2_[jj] ? ((sr_[jj] << 4) | sl2_[jj]) : 0u;
+                    const uint32_t e = ev_[jj] == 0xFFFEu ? e2 : ev_[jj];
+                    const uint32_t sl = e & 15u, sym = e >> 4;
+                    evalid_[jj] = e - 1u < 0xFFFDu;                                                   // neither invalid (0) nor a long code
+                    islit_[jj] = sym < 256u; islen_[jj] = sym - 257u < 29u;
+                    const uint32_t ls = islen_[jj] ? sym - 257u : 0u;
+                    const uint32_t xl = (ls < 8u || ls == 28u) ? 0u : ((ls - 4u) >> 2);                 // CPLEXT :44-48
+                    const uint32_t lbase = ls < 8u ? 3u + ls : (ls == 28u ? 258u : 3u + ((4u + (ls & 3u)) << xl)); // CPLENS :39-43
+                    const uint32_t t1 = __builtin_amdgcn_alignbit(hi[jj], lo[jj], sl);                  // the bits behind the code
+                    len_[jj] = lbase + __builtin_amdgcn_ubfe(t1, 0u, xl);
+                    t2_[jj] = __builtin_amdgcn_alignbit(hi[jj], lo[jj], sl + xl);                       // ... behind the length's extra bits (<= 20)
+                    de_[jj] = S.dlut[t2_[jj] & ((1u << I_DPB) - 1)];
+                    sl_[jj] = sl; xl_[jj] = xl; sym_[jj] = sym;
+                }
+#pragma unroll
+                for (int jj = 0; jj < NPO; jj++) {
+                    const uint32_t de = de_[jj];
+                    const bool dvalid = de - 1u < 0xFFFDu && (de >> 4) < 30u;
+                    const uint32_t dl = de & 15u, dsym = dvalid ? de >> 4 : 0u;
+                    const uint32_t xd = dsym < 4u ? 0u : ((dsym >> 1) - 1u);                            // CPDEXT :62-68
+                    const uint32_t dbase = dsym < 4u ? 1u + dsym : 1u + ((2u + (dsym & 1u)) << xd);     // CPDIST :50-60
+                    const uint32_t dist = dbase + __builtin_amdgcn_ubfe(t2_[jj] >> dl, 0u, xd);
+                    const bool lit = evalid_[jj] && islit_[jj], ismatch = evalid_[jj] && islen_[jj] && dvalid;
+                    const uint32_t nbv = lit ? sl_[jj] : (ismatch ? sl_[jj] + xl_[jj] + dl + xd : 0u);
+                    const uint32_t tk = lit ? sym_[jj] : (ismatch ? (len_[jj] | (dist << 16)) : 0u);
                     tokv[jj] = tk | (nbv << 10); // bits 10..15 (free: literal/length use 9 bits): bit count of the token, 0 = stop
                 }
                 // Which offsets are token starts: a walk over the bit counts alone (NPO x 6 bits packed per lane, one readlane and a
@@ -450,19 +477,21 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : 1) void k_inflat
         }
         const int npar = ntok;
         if (npar) { dbg_par++; dbg_partok += (uint32_t)npar; }
-        if (lane == 0) {
+        if (npar > 0) { bitpos = par_bitpos; bb = 0; nb = -1; }   // adopt the parallel round's result (all lanes: only lane 0's copy counts);
+                                                                   // the bit buffer is primed when the careful path next needs it
+        if (npar == 0 && lane == 0) {                              // (after a parallel round: nothing more this round)
             uint64_t opos = outpos;                       // position after the queued tokens
             const uint64_t room_lim = flushed + ROOM;
-            if (npar > 0) { // adopt the parallel round's result: new bit position, bit buffer re-primed (possibly mid-byte)
-                bitpos = par_bitpos;
-                const uint32_t o2 = (uint32_t)((bitpos >> 3) - sbase);
-                const uint32_t w0 = S.stage[o2 >> 2], w1 = S.stage[(o2 >> 2) + 1];
-                const uint32_t sh = (uint32_t)(bitpos & 7);
-                bb = (uint64_t)(__builtin_amdgcn_alignbyte(w1, w0, o2 & 3) >> sh); nb = 32 - (int)sh;
-            }
-            const int careful_cap = npar > 0 ? npar : (par_ok ? 1 : QN); // after a parallel round: nothing more this round
+            const int careful_cap = par_ok ? 1 : QN;
             for (;;) {
                 if (ntok >= careful_cap || ev != EV_NONE) break;
+                if (nb < 0) { // a wave-parallel round moved bitpos: prime the bit buffer there (possibly mid-byte)
+                    if (!stage_ok(bitpos >> 3)) { ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break; }
+                    const uint32_t o2 = (uint32_t)((bitpos >> 3) - sbase);
+                    const uint32_t w0 = S.stage[o2 >> 2], w1 = S.stage[(o2 >> 2) + 1];
+                    const uint32_t sh = (uint32_t)(bitpos & 7);
+                    bb = (uint64_t)(__builtin_amdgcn_alignbyte(w1, w0, o2 & 3) >> sh); nb = 32 - (int)sh;
+                }
                 const uint64_t bytepos = (bitpos + nb) >> 3;
                 if (!stage_ok(bytepos)) { ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break; }
                 refill();

@@ -10,7 +10,7 @@ so = sys.argv[1][:-4]
 ref = _lib.SO
 from sharpziplib_amd import corpus as C
 from sharpziplib_amd.batch import Engine
-nm, msz = 8192, 65536
+nm, msz = (int(os.environ.get("NM", 8192)), int(os.environ.get("MSZ", 65536)))
 d = C.generate('enwik', 0xE9, 0, nm * msz)
 parts = [d[i * msz:(i + 1) * msz] for i in range(nm)]
 _lib.SO = os.path.join(_lib.CSRC, so)
