@@ -20,7 +20,8 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
 size_t checksum_partial_bytes();
 void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st);
 void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st);
-void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st);
+int launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem,
+                        const ResGroup *groups, uint32_t ngroups, const uint32_t *gfirst, bool chained, uint16_t *gmaps, uint8_t *ewins, hipStream_t st);
 void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, const uint8_t *wins, uint8_t *out_base, const ParMember *mem,
                     uint32_t nmem, uint32_t nblocks, hipStream_t st);
 }
@@ -318,7 +319,32 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     if ((rc = E.inf_states.ensure(mem.size() * sizeof(ParMember)))) return rc;
     HIPCHK(hipMemcpyAsync(E.inf_states.p, mem.data(), mem.size() * sizeof(ParMember), hipMemcpyHostToDevice, st));
     const uint64_t *d_ooff = (const uint64_t *)E.inf_misc.p, *d_jbase = d_ooff + ooff_total;
-    launch_resolve_wins((const uint16_t *)E.inf_sym.p, d_ooff, d_jbase, (uint8_t *)E.inf_wins.p, (const ParMember *)E.inf_states.p, (uint32_t)mem.size(), st);
+    {   // the window chain of every member, in groups of RES_GROUP jobs (szl_kernels_inflate_par.hip)
+        std::vector<ResGroup> groups;
+        std::vector<uint32_t> gfirst(mem.size() + 1, 0u);
+        bool chained = false;
+        for (size_t g = 0; g < mem.size(); g++) {
+            gfirst[g] = (uint32_t)groups.size();
+            const uint32_t nj = mem[g].njobs;
+            for (uint32_t j0 = 0; j0 < nj || j0 == 0; j0 += RES_GROUP) {
+                groups.push_back(ResGroup{(uint32_t)g, j0, std::min<uint32_t>(j0 + RES_GROUP, nj), j0 == 0 ? 1u : 0u, (uint64_t)groups.size()});
+                if (j0 + RES_GROUP >= nj) break;
+            }
+            if (nj > RES_GROUP) chained = true;
+        }
+        gfirst[mem.size()] = (uint32_t)groups.size();
+        const size_t tab_bytes = groups.size() * sizeof(ResGroup), gf_bytes = gfirst.size() * 4;
+        const size_t maps_off = (tab_bytes + gf_bytes + 255) & ~(size_t)255;
+        const size_t maps_bytes = chained ? groups.size() * 65536 : 0, ew_bytes = chained ? groups.size() * 32768 : 0;
+        if ((rc = E.inf_groups.ensure(maps_off + maps_bytes + ew_bytes + 64))) return rc;
+        uint8_t *gb = (uint8_t *)E.inf_groups.p;
+        HIPCHK(hipMemcpyAsync(gb, groups.data(), tab_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(gb + tab_bytes, gfirst.data(), gf_bytes, hipMemcpyHostToDevice, st));
+        if ((rc = launch_resolve_wins((const uint16_t *)E.inf_sym.p, d_ooff, d_jbase, (uint8_t *)E.inf_wins.p, (const ParMember *)E.inf_states.p, (uint32_t)mem.size(),
+                                      (const ResGroup *)gb, (uint32_t)groups.size(), (const uint32_t *)(gb + tab_bytes), chained,
+                                      (uint16_t *)(gb + maps_off), gb + maps_off + maps_bytes, st))) return rc;
+        HIPCHK(hipStreamSynchronize(st));   // (groups / gfirst are host vectors of this scope)
+    }
     launch_convert((const uint16_t *)E.inf_sym.p, d_ooff, d_jbase, (const uint8_t *)E.inf_wins.p, d_out, (const ParMember *)E.inf_states.p,
                    (uint32_t)mem.size(), (uint32_t)nblk, st);
     HIPCHK(hipStreamSynchronize(st));

@@ -192,7 +192,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);

@@ -55,4 +55,10 @@ struct ParMember {                                               // one member b
     uint32_t blk0;      // first workgroup of k_convert that belongs to it
 };
 
+// k_resolve_*: the jobs of a member in groups of RES_GROUP consecutive ones (a member of thousands of chunks is not resolved
+// front to back by ONE workgroup: every group first resolves relative to its unknown entry window, a short chain fixes the
+// entry windows, then every group resolves for real)
+enum : uint32_t { RES_GROUP = 32 };
+struct ResGroup { uint32_t mem; uint32_t j0, j1; uint32_t first; uint64_t slot; };   // member, its jobs [j0, j1), first group of the member?, index of its map / entry window
+
 } // namespace szl

@@ -12,6 +12,7 @@
 // start bit, otherwise the member is decoded by the ordinary single-wavefront path.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <atomic>
 #include "szl_internal.h"
 #include "szl_inflate.h"
 
@@ -133,43 +134,110 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     if (lane == 0) start_bit[blockIdx.x] = found;
 }
 
-// Front to back over the jobs of one member (one workgroup per member): W_j = the 32 KiB of output that end where job j's
-// output ends, as bytes.  wins[(j + 1) * 32768 ..] = W_j ; wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).
+// The windows W_j = the 32 KiB of output that end where job j's output ends, as bytes: wins[(j + 1) * 32768 ..] = W_j ;
+// wins[0 .. 32768) = W_-1 = zeros (a fresh OutputWindow, CS/OutputWindow.cs:22).  W_j follows from job j's symbols and W_j-1 — a
+// chain over the jobs.  One workgroup walking thousands of jobs front to back (a global round trip and a barrier each) was 10 of
+// the 77 ms of a 1 GiB member with the rest of the device idle, so the chain is cut into groups of RES_GROUP jobs:
+//   k_resolve_rel    every group walks its jobs with 16-bit entries — a byte, or 0x8000 | i = "byte i of the window in front of
+//                    the group" — and leaves the map M_g of its last job;
+//   k_resolve_chain  one workgroup per member: E_0 = zeros, E_g+1 = M_g applied to E_g (a few dozen steps);
+//   k_resolve_wins   every group walks its jobs again from its true entry window E_g and writes the W_j.
+// Members of at most RES_GROUP jobs are one group: k_resolve_wins alone, from zeros.
+template <typename T>
+__device__ __forceinline__ void resolve_step(const uint16_t *__restrict__ sym, uint64_t jb, uint64_t len, const T *prev, T *next, int tid) {
+    if (len >= 32768) {   // the usual job: its last 32 KiB are all its own symbols — 32 independent loads per thread in flight
+        const uint16_t *src = sym + jb + (len - 32768) + tid;
+        uint32_t sv[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) sv[k] = src[1024 * k];
+#pragma unroll
+        for (int k = 0; k < 32; k++) next[tid + 1024 * k] = sv[k] < 0x8000u ? (T)sv[k] : prev[sv[k] & 0x7FFF];
+    } else {
+        for (int t = tid; t < 32768; t += 1024) {
+            T b;
+            if ((uint64_t)(32768 - t) <= len) {                // position o1 - 32768 + t lies inside the job's output
+                const uint32_t sv = sym[jb + (len - 32768 + (uint64_t)t)];
+                b = sv < 0x8000u ? (T)sv : prev[sv & 0x7FFF];
+            } else b = prev[(uint64_t)t + len];                // still the previous window, shifted by this job's output
+            next[t] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_resolve_rel(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,
+                                                      const uint64_t *__restrict__ jbase_all, const ParMember *__restrict__ mem,
+                                                      const ResGroup *__restrict__ groups, uint16_t *__restrict__ gmaps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_rel[];
+    uint16_t *const wa = (uint16_t *)smem_rel, *const wb = (uint16_t *)smem_rel + 32768;
+    const ResGroup g = groups[blockIdx.x];
+    const ParMember m = mem[g.mem];
+    const uint64_t *out_off = ooff_all + m.ooff_off;
+    const uint64_t *jbase = jbase_all + m.ooff_off;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 32768; i += 1024) wa[i] = g.first ? (uint16_t)0 : (uint16_t)(0x8000u | (uint32_t)i);
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t j = g.j0; j < g.j1; j++) {
+        resolve_step<uint16_t>(sym, jbase[j], out_off[j + 1] - out_off[j], cur ? wb : wa, cur ? wa : wb, tid);
+        __syncthreads();
+        cur ^= 1;
+    }
+    uint4 *d4 = (uint4 *)(gmaps + g.slot * 32768);
+    const uint4 *w4 = (const uint4 *)(cur ? wb : wa);
+    for (int i = tid; i < 4096; i += 1024) d4[i] = w4[i];
+}
+
+// grid = members; groups of member blockIdx.x = [gfirst[b], gfirst[b + 1]); ewins[slot] = entry window of the group
+__global__ __launch_bounds__(1024) void k_resolve_chain(const ResGroup *__restrict__ groups, const uint32_t *__restrict__ gfirst,
+                                                        const uint16_t *__restrict__ gmaps, uint8_t *__restrict__ ewins) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_e[2][32768];
+    const uint32_t g0 = gfirst[blockIdx.x], g1 = gfirst[blockIdx.x + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 32768; i += 1024) s_e[0][i] = 0;
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t g = g0; g < g1; g++) {
+        const uint64_t slot = groups[g].slot;
+        {
+            const uint4 *w4 = (const uint4 *)s_e[cur];
+            uint4 *d4 = (uint4 *)(ewins + slot * 32768);
+            d4[tid] = w4[tid]; d4[tid + 1024] = w4[tid + 1024];
+        }
+        if (g + 1 == g1) break;
+        const uint16_t *mp = gmaps + slot * 32768;
+        uint32_t mv[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) mv[k] = mp[tid + 1024 * k];
+#pragma unroll
+        for (int k = 0; k < 32; k++) s_e[cur ^ 1][tid + 1024 * k] = mv[k] < 0x8000u ? (uint8_t)mv[k] : s_e[cur][mv[k] & 0x7FFF];
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// grid = groups; ewins == nullptr: every member is one group (entry window = zeros)
 __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,
                                                        const uint64_t *__restrict__ jbase_all, uint8_t *__restrict__ wins_all,
-                                                       const ParMember *__restrict__ mem) {
+                                                       const ParMember *__restrict__ mem, const ResGroup *__restrict__ groups,
+                                                       const uint8_t *__restrict__ ewins) {
     __shared__ __attribute__((aligned(16))) uint8_t s_w[2][32768];
-    const ParMember m = mem[blockIdx.x];
+    const ResGroup g = groups[blockIdx.x];
+    const ParMember m = mem[g.mem];
     const uint64_t *out_off = ooff_all + m.ooff_off;
     const uint64_t *jbase = jbase_all + m.ooff_off;   // first symbol of job j in the staging (the jobs' regions need not be adjacent)
     uint8_t *wins = wins_all + m.win_off;
-    const uint32_t njobs = m.njobs;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 32768; i += 1024) { s_w[0][i] = 0; wins[i] = 0; }
+    if (ewins && !g.first) {
+        const uint4 *e4 = (const uint4 *)(ewins + g.slot * 32768);
+        uint4 *w4 = (uint4 *)s_w[0];
+        w4[tid] = e4[tid]; w4[tid + 1024] = e4[tid + 1024];
+    } else for (int i = tid; i < 32768; i += 1024) s_w[0][i] = 0;
+    if (g.first) for (int i = tid; i < 32768; i += 1024) wins[i] = 0;
     __syncthreads();
     int cur = 0;
-    for (uint32_t j = 0; j < njobs; j++) {
-        const uint64_t o0 = out_off[j], o1 = out_off[j + 1];
-        const uint64_t len = o1 - o0;
-        const uint8_t *prev = s_w[cur];
+    for (uint32_t j = g.j0; j < g.j1; j++) {
         uint8_t *next = s_w[cur ^ 1];
-        if (len >= 32768) {   // the usual job: its last 32 KiB are all its own symbols — 32 independent loads per thread in flight
-            const uint16_t *src = sym + jbase[j] + (len - 32768) + tid;
-            uint32_t sv[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) sv[k] = src[1024 * k];
-#pragma unroll
-            for (int k = 0; k < 32; k++) next[tid + 1024 * k] = sv[k] < 0x8000u ? (uint8_t)sv[k] : prev[sv[k] & 0x7FFF];
-        } else {
-            for (int t = tid; t < 32768; t += 1024) {
-                uint8_t b;
-                if ((uint64_t)(32768 - t) <= len) {                // position o1 - 32768 + t lies inside job j's output
-                    const uint32_t sv = sym[jbase[j] + (len - 32768 + (uint64_t)t)];
-                    b = sv < 0x8000u ? (uint8_t)sv : prev[sv & 0x7FFF];
-                } else b = prev[(uint64_t)t + len];                // still the previous window, shifted by this job's output
-                next[t] = b;
-            }
-        }
+        resolve_step<uint8_t>(sym, jbase[j], out_off[j + 1] - out_off[j], s_w[cur], next, tid);
         __syncthreads();
         {   // the finished window goes out 32 bytes per thread (the next job only reads it: no second barrier needed)
             const uint4 *w4 = (const uint4 *)next;
@@ -210,8 +278,24 @@ __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sy
 void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st) {
     if (njobs) hipLaunchKernelGGL(k_find_blocks, dim3(njobs), dim3(64), 0, st, in_base, fjobs, njobs, start_bit);
 }
-void launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem, hipStream_t st) {
-    if (nmem) hipLaunchKernelGGL(k_resolve_wins, dim3(nmem), dim3(1024), 0, st, sym, ooff, jbase, wins, mem);
+// groups / gfirst: device copies of the group table (ngroups entries; nmem + 1 first-group indices); gmaps (ngroups x 64 KiB) and
+// ewins (ngroups x 32 KiB) are only needed when some member has more than one group (chained == true)
+int launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem,
+                        const ResGroup *groups, uint32_t ngroups, const uint32_t *gfirst, bool chained, uint16_t *gmaps, uint8_t *ewins, hipStream_t st) {
+    if (!ngroups) return 0;
+    if (chained) {
+        static std::atomic<uint64_t> attr_mask{0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void *)k_resolve_rel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return SZL_E_DEVICE;
+            attr_mask.fetch_or(bit, std::memory_order_acq_rel);
+        }
+        hipLaunchKernelGGL(k_resolve_rel, dim3(ngroups), dim3(1024), 131072, st, sym, ooff, jbase, mem, groups, gmaps);
+        hipLaunchKernelGGL(k_resolve_chain, dim3(nmem), dim3(1024), 0, st, groups, gfirst, (const uint16_t *)gmaps, ewins);
+    }
+    hipLaunchKernelGGL(k_resolve_wins, dim3(ngroups), dim3(1024), 0, st, sym, ooff, jbase, wins, mem, groups, chained ? (const uint8_t *)ewins : nullptr);
+    return 0;
 }
 void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, const uint8_t *wins, uint8_t *out_base, const ParMember *mem,
                     uint32_t nmem, uint32_t nblocks, hipStream_t st) {
