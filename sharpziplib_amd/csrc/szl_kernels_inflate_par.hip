@@ -41,27 +41,43 @@ __device__ __forceinline__ uint64_t bits_at(const uint8_t *in, uint64_t in_len, 
     return v;
 }
 
-// Full parse of a dynamic block header at bit position p (one lane).  True iff it is complete and consistent.
-__device__ bool header_ok(const uint8_t *in, uint64_t in_len, uint64_t p, uint8_t *lens /* 320 */, uint16_t *mlut /* 128 */) {
-    uint64_t bp = p;
-    uint64_t w = bits_at(in, in_len, bp);
+// Full parse of a dynamic block header (one lane).  True iff it is complete and consistent.  The header's bytes are staged in
+// LDS by the whole wavefront first (hs: 1 KiB + 16 from the byte that holds bit position p; a header is at most 563 bytes): read from
+// global memory bit by bit, with the code-length code in a dynamically indexed private array (= scratch), one attempt cost
+// ~100 us, and a chunk sees dozens of candidates that pass the cheap tests (finder of a 1 GiB member: 12.6 -> 9.2 ms).
+//   b0: bit offset of the header inside hs (0..7); left: input bits from the header's first bit to the end of the member
+__device__ bool header_ok(const uint32_t *hs, uint32_t b0, uint64_t left, uint8_t *lens /* 320 */, uint16_t *mlut /* 128 */) {
+    auto win32 = [&](uint32_t bp) -> uint32_t {                   // 32 stream bits from bit bp of the stage on
+        const uint32_t by = bp >> 3, sh = ((by & 3u) << 3) | (bp & 7u);
+        return __builtin_amdgcn_alignbit(hs[(by >> 2) + 1], hs[by >> 2], sh);
+    };
+    uint32_t rel = 0;                                             // bits consumed
+    uint32_t w = win32(b0);
     if ((w & 7) != 4) return false;                               // BFINAL = 0, BTYPE = 2 (the final block is left to its predecessor's decode)
-    const uint32_t nl = (uint32_t)((w >> 3) & 31) + 257, nd = (uint32_t)((w >> 8) & 31) + 1, nm = (uint32_t)((w >> 13) & 15) + 4;
+    const uint32_t nl = ((w >> 3) & 31) + 257, nd = ((w >> 8) & 31) + 1, nm = ((w >> 13) & 15) + 4;
     if (nl > 286 || nd > 30) return false;                        // :50-52
-    bp += 17;
-    uint8_t ml[19];
+    rel = 17;
+    const uint64_t mw = (uint64_t)win32(b0 + 17) | ((uint64_t)win32(b0 + 49) << 32);
+    constexpr int ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // C/InflaterDynHeader.cs:23-24
+    uint32_t ml[19];
+#pragma unroll
     for (int i = 0; i < 19; i++) ml[i] = 0;
-    w = bits_at(in, in_len, bp);
     int kraft = 0;
-    for (uint32_t i = 0; i < nm; i++) { const uint32_t l = (uint32_t)(w >> (3 * i)) & 7; ml[c_meta_order2[i]] = (uint8_t)l; if (l) kraft += 128 >> l; }
+#pragma unroll
+    for (int i = 0; i < 19; i++) {                                // (unrolled: ml[] is indexed by constants only and stays in registers)
+        const uint32_t l = (uint32_t)i < nm ? (uint32_t)(mw >> (3 * i)) & 7u : 0u;
+        ml[ORDER[i]] = l;
+        if (l) kraft += 128 >> l;
+    }
     if (kraft != 128) return false;                               // a complete code-length code (what every encoder writes)
-    bp += 3 * nm;
-    if (bp + 64 > in_len * 8) return false;
+    rel += 3 * nm;
+    if ((uint64_t)rel + 64 > left) return false;
     for (int i = 0; i < 128; i++) mlut[i] = 0;
     int code = 0;
     for (int l = 1; l < 8; l++) {
+#pragma unroll
         for (int i = 0; i < 19; i++) {
-            if (ml[i] != l) continue;
+            if (ml[i] != (uint32_t)l) continue;
             const uint32_t rev = (__builtin_bitreverse32((uint32_t)code++) >> (32 - l)) & ((1u << l) - 1);
             for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint16_t)((i << 4) | l);
         }
@@ -71,16 +87,16 @@ __device__ bool header_ok(const uint8_t *in, uint64_t in_len, uint64_t p, uint8_
     const uint32_t total = nl + nd;
     int kl = 0, kd = 0, ndist = 0;                                // Kraft sums in units of 2^-15
     while (idx < total) {
-        if (bp + 16 > in_len * 8) return false;
-        w = bits_at(in, in_len, bp);
-        const uint32_t e = mlut[(uint32_t)w & 127];
+        if ((uint64_t)rel + 16 > left) return false;
+        w = win32(b0 + rel);
+        const uint32_t e = mlut[w & 127];
         if (e == 0) return false;
         const uint32_t sl = e & 15, sym = e >> 4;
-        bp += sl; w >>= sl;
+        rel += sl; w >>= sl;
         uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (idx == 0) return false; val = lens[idx - 1]; rep = 3 + ((uint32_t)w & 3); bp += 2; }        // :83
-        else if (sym == 17) { val = 0; rep = 3 + ((uint32_t)w & 7); bp += 3; }
-        else if (sym == 18) { val = 0; rep = 11 + ((uint32_t)w & 127); bp += 7; }
+        if (sym == 16) { if (idx == 0) return false; val = lens[idx - 1]; rep = 3 + (w & 3); rel += 2; }        // :83
+        else if (sym == 17) { val = 0; rep = 3 + (w & 7); rel += 3; }
+        else if (sym == 18) { val = 0; rep = 11 + (w & 127); rel += 7; }
         if (idx + rep > total) return false;                       // :106
         for (uint32_t r = 0; r < rep; r++, idx++) {
             lens[idx] = (uint8_t)val;
@@ -99,6 +115,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                                                     uint64_t *__restrict__ start_bit) {
     __shared__ uint8_t s_lens[320];
     __shared__ uint16_t s_mlut[128];
+    __shared__ uint32_t s_hdr[256 + 4];
     if (blockIdx.x >= njobs) return;
     const FindJob fj = fjobs[blockIdx.x];
     const uint8_t *in = in_base + fj.in_off;
@@ -126,7 +143,18 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
             const int l = __builtin_ctzll(mm);
             mm &= mm - 1;
             int ok = 0;
-            if (lane == 0) ok = header_ok(in, in_len, base + (uint64_t)l, s_lens, s_mlut) ? 1 : 0;
+            {   // stage the candidate's bytes (whole dwords from its byte on; zeros past the end of the member)
+                const uint64_t cb = (base + (uint64_t)l) >> 3;
+                for (int i = lane; i < 256 + 4; i += 64) {
+                    const uint64_t q = cb + 4ull * (uint64_t)i;
+                    uint32_t v = 0;
+                    if (q + 4 <= in_len) __builtin_memcpy(&v, in + q, 4);
+                    else for (int kb = 0; kb < 4; kb++) if (q + kb < in_len) v |= (uint32_t)in[q + kb] << (8 * kb);
+                    s_hdr[i] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (lane == 0) ok = header_ok(s_hdr, (uint32_t)((base + (uint64_t)l) & 7), in_len * 8 - (base + (uint64_t)l), s_lens, s_mlut) ? 1 : 0;
             ok = __builtin_amdgcn_readfirstlane(ok);
             if (ok) { found = base + (uint64_t)l; break; }
         }
