@@ -14,7 +14,8 @@ namespace szl {
 
 // ---- launch wrappers implemented in the kernel translation units
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans, int nspans,
-                  uint16_t *link, const uint32_t *hflags, unsigned long long *guard_flag, uint64_t span_bytes, hipStream_t st);
+                  uint16_t *link, const uint32_t *hflags, unsigned long long *guard_flag, uint64_t span_bytes, hipStream_t st,
+                  hipStream_t guard_st, hipEvent_t guard_ev);
 void links_distrust_ticket_form();
 enum : int { CNT_WORDS = 64, CNT_LINKS_GUARD = 32 };   // counters: 64 x u64; [32] = links the per-call guard found wrong (szl_kernels_match.hip)
 enum : int { SZL_I_RETRY_LINKS = -1000 };             // internal: run the call again (the ticket form of stage A is distrusted from now on)
@@ -197,6 +198,8 @@ Engine::~Engine() {
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_guard) (void)hipEventDestroy(ev_guard);
+    if (ev_gjoin) (void)hipEventDestroy(ev_gjoin);
     if (side) (void)hipStreamDestroy(side);
     if (pin) (void)hipHostFree(pin);
 }
@@ -427,7 +430,12 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         if ((rc = upload(hist_flags_dev, hf, st))) return rc;
         d_hflags = (const uint32_t *)hist_flags_dev.p;
     }
-    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, d_hflags, dcnt + CNT_LINKS_GUARD, total_emit, st);
+    if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (!ev_guard) HIPCHK(hipEventCreateWithFlags(&ev_guard, hipEventDisableTiming));
+    if (!ev_gjoin) HIPCHK(hipEventCreateWithFlags(&ev_gjoin, hipEventDisableTiming));
+    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, d_hflags, dcnt + CNT_LINKS_GUARD, total_emit, st,
+                 side, ev_guard);
+    HIPCHK(hipEventRecord(ev_gjoin, side));      // (joined in front of the read-back of the counters)
     HIPCHK(hipEventRecord(ev[2], st));
     if (fast) {
         // B+C for DeflateFast: sequential greedy parse, one wavefront per segment (szl_kernels_fast.hip)
@@ -458,7 +466,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25; // break-even was 0.36-0.40 against k_match; the full search is 1.4-1.55x faster now
     last_pilot_frac = -1.0;
     bool b_event = false; // ev[7]: start of the stage-B search proper (after the pilot)
-    if (match_mode == 1 || (match_mode == 2 && ntiles >= 64)) { // (inputs under 1 MiB: not worth a pilot)
+    // (the pilot is one on-demand walk of a tile sample, ~0.5 ms whatever the input: more than the whole search of a few MiB — calls of
+    // 256 KiB-1 MiB spent 0.46-0.56 ms in it and 0.1-0.15 ms in the search it was to speed up)
+    const bool pilot_worth = total_emit >= ((uint64_t)std::max(1, knob("SZL_PILOT_MIN_MIB", 8)) << 20) && ntiles >= 64;
+    if (match_mode == 1 || (match_mode == 2 && pilot_worth)) {
         if (match_mode == 2) { // the pilot's own entries are overwritten by whichever form runs afterwards
             const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8)); // >= 64 sampled tiles
             const int nb = (int)((ntiles + step - 1) / step);
@@ -558,6 +569,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     HIPCHK(hipEventRecord(ev[5], st));
     launch_block_encode(d_in, d_out, dsegs, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);
     if (forked) HIPCHK(hipStreamWaitEvent(st, ev_join, 0));
+    HIPCHK(hipStreamWaitEvent(st, ev_gjoin, 0));
     launch_seg_finish(dsegs, nseg, dso, d_out, st);
     HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
@@ -759,7 +771,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         HIPCHK(hipMemsetAsync(counters.p, 0, 8, st));             // counter 0: ranges of THIS window that never merged
         HIPCHK(hipEventRecord(ev[1], st));
         // the launch wrappers index segs[span.seg] / segs[tile.seg]: entry 1 of d_segs is the window
-        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, nullptr, dcnt + CNT_LINKS_GUARD, (uint64_t)(hi - lo), st);
+        launch_links(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), lk, nullptr, dcnt + CNT_LINKS_GUARD, (uint64_t)(hi - lo), st, nullptr, nullptr);
         HIPCHK(hipEventRecord(ev[2], st));
         if (wi == 0 && match_mode == 2 && ntiles >= 64 && !warming) { // the pilot (see deflate()): once, on the first window
             const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8));

@@ -574,8 +574,10 @@ def test_on_demand_stage_b_is_bit_exact(eng, name, level):
         assert eng.deflate([data], level=level, crc32=True)[0].data == ref
         assert eng.debug_match_mode() or name in ("zeros", "p10")   # (never-merging ranges fall back to the full search)
         eng.debug_match_mode(2)
-        assert eng.deflate([data], level=level)[0].data == ref      # pilot (inputs >= 1 MiB) or full
-        if name == "logs":
+        assert eng.deflate([data], level=level)[0].data == ref      # pilot (inputs >= 8 MiB) or full
+        if name == "logs" and level == 6:
+            big = C.generate("logs", 0x106, 0, 9 << 20)
+            assert eng.deflate([big], level=level)[0].data == O.deflate(big, level)
             assert eng.debug_match_mode()                            # repetitive data: the pilot picks the on-demand form
     finally:
         eng.debug_match_mode(-1)
