@@ -41,3 +41,11 @@ for k in ('szl::k_match4<false>', 'szl::k_spec_win<16>', 'szl::k_links3'):
     print(k, tr.get(k), dict(sq.get(k, {})))
 PY
 rm -rf $O/stats $O/pmc
+# the other measured paths of the round (logs next to the headline's)
+python $R/tools/gpu_inflate_ab.py libszl_amd.so 2>&1 | grep -v "^\[szl\]" > $O/inflate_round.log
+python $R/tools/gpu_inflate_big.py 1024 2>&1 | grep -v "stage B\|links\|match_ms" >> $O/inflate_round.log
+python $R/tools/gpu_inflate_big.py 1024 logs 2>&1 | tail -1 >> $O/inflate_round.log
+python $R/tools/gpu_small_call.py 200 > $O/small_calls.log 2>&1
+python $R/tools/gpu_fast.py 4 4000 > $O/levels_1_4.log 2>&1
+python $R/tools/gpu_stream_latency.py --entries 500 > $O/stream_latency.log 2>&1
+tail -n 30 $O/inflate_round.log $O/small_calls.log $O/levels_1_4.log $O/stream_latency.log
