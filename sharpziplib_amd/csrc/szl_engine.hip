@@ -461,7 +461,11 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     // Two forms of stage B (szl_kernels_match.hip): search every position, or only the positions a parse can reach.
     // The second evaluates far fewer positions on repetitive data but each evaluation costs ~3x more, so a pilot on a
     // sample of tiles measures the evaluated fraction first (results are identical either way).
-    static const int match_mode_env = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 2; // 0 full, 1 on demand, 2 pilot
+    // Round 3: measured again on ten data classes at levels 6 and 9 (tools/gpu_forms_classes.py, profiles/r03/forms_by_class.log), the
+    // full search wins everywhere, by 1.3x (logs) to 5x (four-symbol text) — k_match4 is 1.5x the search the 0.25 threshold was set
+    // against — so the default is the full search, without the pilot (0.75 ms of the 1 GiB pass; config 5, 1 GiB of logs at level 9,
+    // 261 -> 190 ms).  The on-demand form and the pilot stay behind SZL_MATCH_MODE = 1 / 2 and the tests that force them.
+    static const int match_mode_env = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 0; // 0 full, 1 on demand, 2 pilot
     const int match_mode = has_switch ? 0 : (match_mode_override >= 0 ? match_mode_override : match_mode_env);
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25; // break-even was 0.36-0.40 against k_match; the full search is 1.4-1.55x faster now
     last_pilot_frac = -1.0;
@@ -709,7 +713,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(max_ranges + 1), st));
     if ((rc = cubtmp.ensure(cub_bytes + 256))) return rc;
 
-    const int match_mode = match_mode_override >= 0 ? match_mode_override : knob("SZL_MATCH_MODE", 2);
+    const int match_mode = match_mode_override >= 0 ? match_mode_override : knob("SZL_MATCH_MODE", 0);
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25;
     const bool emit_copy = emit_copy_enabled();
     bool lazy = match_mode == 1;
