@@ -90,7 +90,7 @@ class Engine {
     bool fast_want_tail = false;
     int64_t fast_tail_start = 0;
     DevBuf link, link4, skip4, e3dist, e3hops, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_stripes, d_so, blk_counts, blk_off,
-        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, d_stored, spec_tok, d_zoff,
+        bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, chain_buf, d_stored, spec_tok, d_zoff,
         inf_sym, inf_wins, inf_jobs, inf_states, inf_misc, inf_groups, hist_flags_dev, m5_scratch, d_sw_pos, d_sw_P;   // parallel decode of one member (szl_api_inflate.hip)
     hipEvent_t ev[8];
     // checksum kernels run beside stages A-C on this stream (they only share the input bytes)

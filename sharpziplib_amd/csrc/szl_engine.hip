@@ -113,7 +113,8 @@ void launch_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const Se
 int exitmap_width();
 void launch_exitmaps(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                      RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint64_t *bad_range, uint64_t nbad,
-                     uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st);
+                     uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st, void *chain_scratch, uint32_t range_cnt0);
+size_t exitchain_scratch_bytes(uint64_t range_cnt);
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st);
 void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts, hipStream_t st);
 void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
@@ -193,7 +194,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &chain_buf, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -544,8 +545,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             const size_t W = (size_t)exitmap_width();
             if ((rc = exmap.ensure(nbad * W * 2 + 64))) return rc;
             if ((rc = cnmap.ensure(nbad * W * 2 + 64))) return rc;
+            if (nseg == 1 && (rc = chain_buf.ensure(exitchain_scratch_bytes(segs[0].range_cnt)))) return rc;
             launch_exitmaps(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p,
-                            (const uint32_t *)bad_slot.p, (const uint64_t *)bad_range.p, nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st);
+                            (const uint32_t *)bad_slot.p, (const uint64_t *)bad_range.p, nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st,
+                            nseg == 1 ? chain_buf.p : nullptr, segs[0].range_cnt);
         }
     }
     launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
@@ -827,9 +830,9 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         if (nbad > 0 && nbad <= 48) launch_resolve(d_in, lk, mt, dseg_win, 1, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
         else if (nbad > 48) {
             const size_t W = (size_t)exitmap_width();
-            if ((rc = exmap.ensure(nbad * W * 2 + 64)) || (rc = cnmap.ensure(nbad * W * 2 + 64))) return rc;
+            if ((rc = exmap.ensure(nbad * W * 2 + 64)) || (rc = cnmap.ensure(nbad * W * 2 + 64)) || (rc = chain_buf.ensure(exitchain_scratch_bytes(nranges)))) return rc;
             launch_exitmaps(d_in, lk, mt, dseg_win, 1, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, (const uint32_t *)bad_slot.p, (const uint64_t *)bad_range.p,
-                            nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st);
+                            nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st, chain_buf.p, (uint32_t)nranges);
         }
         launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));

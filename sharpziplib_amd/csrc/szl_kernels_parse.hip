@@ -371,13 +371,86 @@ __global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_
 }
 
 enum : int { CH_RANGES = 32 };
+// The chain over the ranges of a segment: range k is entered where range k-1 was left.  Where the entry is the one k_fix assumed
+// the range's exit stands; where it is not, the exit map of the range (k_exitmap: exit as a function of the entry offset) gives it,
+// and a range without a map is walked (rare).  With all-zero or periodic input EVERY range has a map and the chain is as long as the
+// stream: 64 Ki ranges for 64 MiB, one global round trip each — 67 ms of a 70 ms call.  Hence two levels for a long segment:
+//   k_chain_maps   every chunk of CH_RANGES ranges: exit of the chunk as a function of the entry offset into it (all X_W of them,
+//                  through the chunk's maps in LDS; an entry that would need a walk is marked);
+//   k_chain_top    one wavefront: chunk to chunk through those chunk maps (a marked entry runs the chunk's ranges one by one);
+//   k_chain_apply  every chunk again, from its true entry: the ranges' records.
+struct ChainLds {
+    uint16_t ex[CH_RANGES][X_W];
+    int64_t entry[CH_RANGES], exit[CH_RANGES];
+    uint32_t slot[CH_RANGES], chg[CH_RANGES], cnt[CH_RANGES], mrg[CH_RANGES];
+};
+// stage the chunk's range records and exit maps (whole wavefront)
+__device__ __forceinline__ void chain_stage(ChainLds &S, const RangeDev *R, const uint32_t *slots, const uint16_t *exmap, uint32_t k0, uint32_t nk, int lane) {
+    if ((uint32_t)lane < nk) {
+        S.entry[lane] = R[k0 + lane].entry; S.exit[lane] = R[k0 + lane].exit_true;
+        S.slot[lane] = slots[k0 + lane]; S.chg[lane] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    {   // all loads of the chunk are issued before the first store (map by map, every map was a global round trip of its own)
+        constexpr int PER = X_W * 2 / 16, TOT = CH_RANGES * PER, NL = (TOT + 63) / 64;
+        uint4 v[NL];
+#pragma unroll
+        for (int t = 0; t < NL; t++) {
+            const int q = lane + 64 * t, i = q / PER;
+            v[t] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (q < TOT && (uint32_t)i < nk && S.slot[i] != 0xFFFFFFFFu) v[t] = ((const uint4 *)(exmap + (uint64_t)S.slot[i] * X_W))[q - i * PER];
+        }
+#pragma unroll
+        for (int t = 0; t < NL; t++) { const int q = lane + 64 * t; if (q < TOT) ((uint4 *)&S.ex[0][0])[q] = v[t]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+// the ranges [k0, k0 + nk) of segment s from the entry prev_exit on: updates their records, returns the exit of the last one
+__device__ int64_t chain_chunk(ChainLds &S, ParseCtx &c, const SegDev &s, RangeDev *R, const uint32_t *slots, const uint32_t *visited,
+                               const uint16_t *exmap, const uint16_t *cnmap, unsigned long long *counters, uint32_t k0, uint32_t nk,
+                               int64_t prev_exit, int lane) {
+    chain_stage(S, R, slots, exmap, k0, nk, lane);
+        if (lane == 0) {
+            for (uint32_t i = 0; i < nk; i++) {
+                const uint32_t k = k0 + i;
+                const int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
+                const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
+                const int64_t e = prev_exit;
+                if (e == S.entry[i]) { prev_exit = S.exit[i]; continue; }           // the assumption of k_fix holds
+                S.entry[i] = e;
+                const int64_t j = e - rs;
+                if (S.slot[i] != 0xFFFFFFFFu && j >= 0 && j < X_W && S.ex[i][j] != 65535) {
+                    prev_exit = (e >= re ? e : re + S.ex[i][j]);
+                    S.exit[i] = prev_exit; S.chg[i] = 1;
+                } else { // unexpected entry into a range without a map: walk it (rare)
+                    uint32_t merged, count; int64_t ex;
+                    fixup_range(c, visited + s.vis_word_off, s.seg_start, rs, re, e, R[k].spec_count, R[k].exit_spec, &merged, &ex, &count, counters + 1);
+                    prev_exit = ex; S.exit[i] = ex; S.cnt[i] = count; S.mrg[i] = merged; S.chg[i] = 2;
+                }
+            }
+        }
+        prev_exit = ((int64_t)__builtin_amdgcn_readfirstlane((int)(prev_exit >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)prev_exit);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if ((uint32_t)lane < nk && S.chg[lane]) {
+            const uint32_t k = k0 + lane;
+            const int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
+            uint32_t cnt = S.cnt[lane], mrg = S.mrg[lane];
+            if (S.chg[lane] == 1) {
+                const int64_t j = S.entry[lane] - rs;
+                cnt = S.entry[lane] >= (rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end) ? 0u : cnmap[(uint64_t)S.slot[lane] * X_W + j];
+                mrg = 0;
+            }
+            R[k].entry = S.entry[lane]; R[k].exit_true = S.exit[lane]; R[k].true_count = cnt; R[k].merged = mrg;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return prev_exit;
+}
+
 __global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                               uint32_t nseg, LevelParams P, RangeDev *ranges, const uint32_t *visited,
                                               const uint32_t *bad_slot, const uint16_t *exmap, const uint16_t *cnmap,
                                               unsigned long long *counters) {
-    __shared__ uint16_t s_ex[CH_RANGES][X_W];
-    __shared__ int64_t s_entry[CH_RANGES], s_exit[CH_RANGES];
-    __shared__ uint32_t s_slot[CH_RANGES], s_chg[CH_RANGES], s_cnt[CH_RANGES], s_mrg[CH_RANGES];
+    __shared__ ChainLds S;
     const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
     const SegDev s = segs[si];
@@ -389,53 +462,74 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *in, const uint16_t 
     int64_t prev_exit = R[0].exit_true;
     for (uint32_t k0 = 1; k0 < s.range_cnt; k0 += CH_RANGES) {
         const uint32_t nk = s.range_cnt - k0 < CH_RANGES ? s.range_cnt - k0 : CH_RANGES;
-        if ((uint32_t)lane < nk) {
-            s_entry[lane] = R[k0 + lane].entry; s_exit[lane] = R[k0 + lane].exit_true;
-            s_slot[lane] = slots[k0 + lane]; s_chg[lane] = 0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (uint32_t i = 0; i < nk; i++) { // stage the exit maps of the flagged ranges of this chunk (coalesced)
-            const uint32_t sl = s_slot[i];
-            if (sl == 0xFFFFFFFFu) continue;
-            const uint4 *src = (const uint4 *)(exmap + (uint64_t)sl * X_W);
-            uint4 *dst = (uint4 *)&s_ex[i][0];
-            for (int q = lane; q < X_W * 2 / 16; q += 64) dst[q] = src[q];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (lane == 0) {
-            for (uint32_t i = 0; i < nk; i++) {
-                const uint32_t k = k0 + i;
-                const int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
-                const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
-                const int64_t e = prev_exit;
-                if (e == s_entry[i]) { prev_exit = s_exit[i]; continue; }           // the assumption of k_fix holds
-                s_entry[i] = e;
-                const int64_t j = e - rs;
-                if (s_slot[i] != 0xFFFFFFFFu && j >= 0 && j < X_W && s_ex[i][j] != 65535) {
-                    prev_exit = (e >= re ? e : re + s_ex[i][j]);
-                    s_exit[i] = prev_exit; s_chg[i] = 1;
-                } else { // unexpected entry into a range without a map: walk it (rare)
-                    uint32_t merged, count; int64_t ex;
-                    fixup_range(c, visited + s.vis_word_off, s.seg_start, rs, re, e, R[k].spec_count, R[k].exit_spec, &merged, &ex, &count, counters + 1);
-                    prev_exit = ex; s_exit[i] = ex; s_cnt[i] = count; s_mrg[i] = merged; s_chg[i] = 2;
-                }
-            }
-        }
-        prev_exit = ((int64_t)__builtin_amdgcn_readfirstlane((int)(prev_exit >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)prev_exit);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if ((uint32_t)lane < nk && s_chg[lane]) {
-            const uint32_t k = k0 + lane;
-            const int64_t rs = s.seg_start + (int64_t)k * (int64_t)s.range_len;
-            uint32_t cnt = s_cnt[lane], mrg = s_mrg[lane];
-            if (s_chg[lane] == 1) {
-                const int64_t j = s_entry[lane] - rs;
-                cnt = s_entry[lane] >= (rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end) ? 0u : cnmap[(uint64_t)s_slot[lane] * X_W + j];
-                mrg = 0;
-            }
-            R[k].entry = s_entry[lane]; R[k].exit_true = s_exit[lane]; R[k].true_count = cnt; R[k].merged = mrg;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        prev_exit = chain_chunk(S, c, s, R, slots, visited, exmap, cnmap, counters, k0, nk, prev_exit, lane);
     }
+}
+
+// (single long segment) chunk map: cm[chunk * X_W + j] = exit of the chunk relative to the start of the range behind it, for the
+// entry offset j into the chunk's first range; 0xFFFFFFFF = some range of the chunk needs a walk for that entry
+__global__ __launch_bounds__(64) void k_chain_maps(const SegDev *segs, const RangeDev *ranges, const uint32_t *bad_slot, const uint16_t *exmap,
+                                                   uint32_t *cm) {
+    __shared__ ChainLds S;
+    const SegDev s = segs[0];
+    const uint32_t k0 = 1 + blockIdx.x * CH_RANGES;
+    if (k0 >= s.range_cnt) return;
+    const uint32_t nk = s.range_cnt - k0 < CH_RANGES ? s.range_cnt - k0 : CH_RANGES;
+    const int lane = threadIdx.x;
+    chain_stage(S, ranges + s.range_off, bad_slot + s.range_off, exmap, k0, nk, lane);
+    const int64_t rs0 = s.seg_start + (int64_t)k0 * (int64_t)s.range_len;
+    const int64_t rs_next = s.seg_start + (int64_t)(k0 + nk) * (int64_t)s.range_len;
+    for (int j0 = lane; j0 < X_W; j0 += 64) {
+        int64_t e = rs0 + j0;
+        bool ok = true;
+        for (uint32_t i = 0; i < nk && ok; i++) {
+            const int64_t rs = rs0 + (int64_t)i * (int64_t)s.range_len;
+            const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
+            if (e == S.entry[i]) { e = S.exit[i]; continue; }
+            const int64_t j = e - rs;
+            if (S.slot[i] != 0xFFFFFFFFu && j >= 0 && j < X_W && S.ex[i][j] != 65535) e = e >= re ? e : re + S.ex[i][j];
+            else ok = false;
+        }
+        const int64_t off = e - rs_next;
+        cm[(uint64_t)blockIdx.x * X_W + j0] = (ok && off >= -(int64_t)0x40000000 && off < (int64_t)0x40000000) ? (uint32_t)(int32_t)off : 0xFFFFFFFFu;
+    }
+}
+// one wavefront: the entry of every chunk (ein[chunk]); a chunk whose map does not cover the entry is run range by range
+__global__ __launch_bounds__(64) void k_chain_top(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, LevelParams P,
+                                                  RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint16_t *exmap,
+                                                  const uint16_t *cnmap, unsigned long long *counters, const uint32_t *cm, int64_t *ein) {
+    __shared__ ChainLds S;
+    const SegDev s = segs[0];
+    if (s.range_cnt < 2) return;
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs);
+    const int lane = threadIdx.x;
+    RangeDev *R = ranges + s.range_off;
+    const uint32_t *slots = bad_slot + s.range_off;
+    int64_t prev_exit = R[0].exit_true;
+    uint32_t ch = 0;
+    for (uint32_t k0 = 1; k0 < s.range_cnt; k0 += CH_RANGES, ch++) {
+        const uint32_t nk = s.range_cnt - k0 < CH_RANGES ? s.range_cnt - k0 : CH_RANGES;
+        if (lane == 0) ein[ch] = prev_exit;
+        const int64_t rs0 = s.seg_start + (int64_t)k0 * (int64_t)s.range_len;
+        const int64_t rs_next = s.seg_start + (int64_t)(k0 + nk) * (int64_t)s.range_len;
+        const int64_t j = prev_exit - rs0;
+        uint32_t v = 0xFFFFFFFFu;
+        if (j >= 0 && j < X_W) v = __builtin_nontemporal_load(cm + (uint64_t)ch * X_W + j);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        if (v != 0xFFFFFFFFu) prev_exit = rs_next + (int64_t)(int32_t)v;
+        else prev_exit = chain_chunk(S, c, s, R, slots, visited, exmap, cnmap, counters, k0, nk, prev_exit, lane);
+    }
+}
+__global__ __launch_bounds__(64) void k_chain_apply(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, LevelParams P,
+                                                    RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint16_t *exmap,
+                                                    const uint16_t *cnmap, unsigned long long *counters, const int64_t *ein) {
+    __shared__ ChainLds S;
+    const SegDev s = segs[0];
+    const uint32_t k0 = 1 + blockIdx.x * CH_RANGES;
+    if (k0 >= s.range_cnt) return;
+    const uint32_t nk = s.range_cnt - k0 < CH_RANGES ? s.range_cnt - k0 : CH_RANGES;
+    ParseCtx c = make_ctx(in, link, mtab, s, P, segs);
+    (void)chain_chunk(S, c, s, ranges + s.range_off, bad_slot + s.range_off, visited, exmap, cnmap, counters, k0, nk, ein[blockIdx.x], threadIdx.x);
 }
 
 // Token counts per range -> scan input
@@ -792,12 +886,25 @@ void launch_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const Se
 int exitmap_width() { return X_W; }
 void launch_exitmaps(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                      RangeDev *ranges, const uint32_t *visited, const uint32_t *bad_slot, const uint64_t *bad_range, uint64_t nbad,
-                     uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st) {
+                     uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st, void *chain_scratch, uint32_t range_cnt0) {
     if (nbad == 0) return;
     hipLaunchKernelGGL(k_exitmap, dim3((unsigned)(nbad * (X_W / 64))), dim3(64), 0, st, in, link, mtab, segs, nseg, P, bad_range, nbad,
                        exmap, cnmap, counters);
+    if (nseg == 1 && chain_scratch && range_cnt0 > 8u * CH_RANGES) {   // one long segment: the chain in two levels
+        const uint32_t nch = (range_cnt0 - 1 + CH_RANGES - 1) / CH_RANGES;
+        uint32_t *cm = (uint32_t *)chain_scratch;
+        int64_t *ein = (int64_t *)((uint8_t *)chain_scratch + (((size_t)nch * X_W * 4 + 63) & ~(size_t)63));
+        hipLaunchKernelGGL(k_chain_maps, dim3(nch), dim3(64), 0, st, segs, (const RangeDev *)ranges, bad_slot, (const uint16_t *)exmap, cm);
+        hipLaunchKernelGGL(k_chain_top, dim3(1), dim3(64), 0, st, in, link, mtab, segs, P, ranges, visited, bad_slot, (const uint16_t *)exmap, (const uint16_t *)cnmap, counters, (const uint32_t *)cm, ein);
+        hipLaunchKernelGGL(k_chain_apply, dim3(nch), dim3(64), 0, st, in, link, mtab, segs, P, ranges, visited, bad_slot, (const uint16_t *)exmap, (const uint16_t *)cnmap, counters, (const int64_t *)ein);
+        return;
+    }
     hipLaunchKernelGGL(k_chain, dim3(nseg), dim3(64), 0, st, in, link, mtab, segs, nseg, P, ranges, visited, bad_slot, exmap, cnmap,
                        counters);
+}
+size_t exitchain_scratch_bytes(uint64_t range_cnt) {
+    const uint64_t nch = (range_cnt + CH_RANGES - 1) / CH_RANGES + 1;
+    return (size_t)(((nch * X_W * 4 + 63) & ~63ull) + nch * 8 + 64);
 }
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st) {
     if (nranges == 0) return;
