@@ -298,6 +298,22 @@ __global__ __launch_bounds__(256) void k_fix(const uint8_t *in, const uint16_t *
     }
 }
 
+// A range that merged under k_fix's assumption but FOLLOWS a never-merging one will be entered somewhere else (the true exit of
+// its predecessor is only known in the chain), and without a map the chain walks it with one lane, ~100 us a time, one after the
+// other — mixed data (stretches of zeros or periodic bytes between ordinary ones) has hundreds of them.  They get a map too.
+__global__ __launch_bounds__(256) void k_flag_followers(const SegDev *segs, uint32_t nseg, uint64_t nranges, const RangeDev *ranges,
+                                                        unsigned long long *counters, uint32_t *bad_slot, uint64_t *bad_range) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nranges || r == 0) return;
+    const uint32_t si = find_seg(segs, nseg, r);
+    if (r - segs[si].range_off < 2) return;                  // (range 0 of a segment is never flagged by k_fix)
+    if (ranges[r].merged != 0 && ranges[r - 1].merged == 0 && bad_slot[r - 1] != 0xFFFFFFFFu) {
+        unsigned long long slot = atomicAdd(counters + 0, 1ull);
+        bad_slot[r] = (uint32_t)slot;
+        bad_range[slot] = r;
+    }
+}
+
 // C3: one wavefront per segment chains the ranges whose assumed entry was wrong (sequential; rare).
 __global__ __launch_bounds__(64) void k_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                                 uint32_t nseg, LevelParams P, RangeDev *ranges, const uint32_t *visited,
@@ -343,7 +359,8 @@ enum : int { X_W = 576 }; // entries per map (multiple of 64, > 513)
 
 __global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                                 uint32_t nseg, LevelParams P, const uint64_t *bad_range, uint64_t nbad,
-                                                uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters) {
+                                                uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters,
+                                                const RangeDev *ranges, const uint32_t *visited) {
     const uint64_t slot = blockIdx.x / (X_W / 64);
     const int j = (int)(blockIdx.x % (X_W / 64)) * 64 + (int)threadIdx.x;
     if (slot >= nbad) return;
@@ -356,6 +373,11 @@ __global__ __launch_bounds__(64) void k_exitmap(const uint8_t *in, const uint16_
     const int64_t re = rs + (int64_t)s.range_len < s.seg_end ? rs + (int64_t)s.range_len : s.seg_end;
     int64_t x = rs + j, tp;
     uint32_t count = 0;
+    if (ranges[r].merged != 0) {      // a follower (k_flag_followers): walk until the range's speculative path is met, as k_fix does
+        uint32_t merged = 0; int64_t ex = x;
+        if (x < s.seg_end) fixup_range(c, visited + s.vis_word_off, s.seg_start, rs, re, x, ranges[r].spec_count, ranges[r].exit_spec, &merged, &ex, &count, counters + 1);
+        x = ex;
+    } else
     if (x < s.seg_end) {
         int L = 0, D = 0;
         for (;;) {
@@ -878,6 +900,8 @@ void launch_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev
     if (nranges == 0) return;
     hipLaunchKernelGGL(k_fix, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, visited, counters, bad_slot, bad_range);
+    hipLaunchKernelGGL(k_flag_followers, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, segs, nseg, nranges, (const RangeDev *)ranges, counters,
+                       bad_slot, bad_range);
 }
 void launch_resolve(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, LevelParams P,
                     RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, hipStream_t st) {
@@ -889,7 +913,7 @@ void launch_exitmaps(const uint8_t *in, const uint16_t *link, MTab mtab, const S
                      uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st, void *chain_scratch, uint32_t range_cnt0) {
     if (nbad == 0) return;
     hipLaunchKernelGGL(k_exitmap, dim3((unsigned)(nbad * (X_W / 64))), dim3(64), 0, st, in, link, mtab, segs, nseg, P, bad_range, nbad,
-                       exmap, cnmap, counters);
+                       exmap, cnmap, counters, (const RangeDev *)ranges, visited);
     if (nseg == 1 && chain_scratch && range_cnt0 > 8u * CH_RANGES) {   // one long segment: the chain in two levels
         const uint32_t nch = (range_cnt0 - 1 + CH_RANGES - 1) / CH_RANGES;
         uint32_t *cm = (uint32_t *)chain_scratch;
