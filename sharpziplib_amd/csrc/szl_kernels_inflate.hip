@@ -176,9 +176,12 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
 template <bool SHORTWIN, int PMODE>
 __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 1)) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
-    // (a 4096-entry window for the 16-bit symbol pass — the byte form's LDS footprint — was measured: 128 members of 4 MiB 58 -> 49 ms,
-    // but one 256 MiB member 74 -> 93 ms: more matches reach behind the window and are read from the symbol staging)
-    constexpr int WIN = SHORTWIN ? I_WIN_SHORT : I_WIN;
+    // (round 2 measured the 4096-entry window slower for one long member — 74 -> 93 ms per 256 MiB — when every far read was an
+    // agent-scope load that missed the L2; round 3, with workgroup-scope far reads, it wins)
+#ifndef SZL_INF_SYMWIN
+#define SZL_INF_SYMWIN 4096   // entries of the symbol pass's LDS window: 8 KiB of 16-bit symbols, 8 chunk jobs per CU instead of 6 (1 GiB member 61.0 -> 58.1 ms, now that far reads are workgroup-scope)
+#endif
+    constexpr int WIN = SHORTWIN ? (PMODE == 2 ? SZL_INF_SYMWIN : I_WIN_SHORT) : I_WIN;
     constexpr uint64_t I_WMASK = WIN - 1;
     // SHORTWIN: bytes older than FAR_DIST are read from the output region; everything older than ROOM is flushed there first
     constexpr uint32_t FAR_DIST = WIN - 512;
