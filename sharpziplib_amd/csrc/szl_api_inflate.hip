@@ -107,7 +107,21 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(st); const double t = now(); fprintf(stderr, "[szl] inflate par: %-28s %8.2f ms\n", what, t - t_prev); t_prev = t; } };
-    const uint64_t chunk_max = (uint64_t)std::max(16, knob("SZL_INF_CHUNK_KIB", 128)) * 1024;
+    // Chunk size: the symbol pass is a fixed number of wavefront slots (8 chunk jobs per CU: 8 KiB of LDS window + tables each) times
+    // the one-wavefront decode of a chunk, so what counts is how evenly the jobs fill the slots — a 1 GiB text member: 128 KiB chunks
+    // = 3034 jobs = 1.5 rounds of the 2048 slots, 56 ms; 192 KiB = one round, 43 ms; a 1 GiB log member (70 MiB compressed): 128 KiB =
+    // a quarter of the slots, 37 ms; 64 KiB 25 ms.  So: r whole rounds of the slots with chunks of at most ~192 KiB, at least 32 KiB.
+    uint64_t chunk_max = (uint64_t)std::max(16, knob("SZL_INF_CHUNK_KIB", 128)) * 1024;
+    if (knob("SZL_INF_CHUNK_KIB", 0) == 0) {
+        uint64_t total_in = 0;
+        for (size_t ci : cand) total_in += streams[ci].in_len;
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const uint64_t slots = 8ull * (uint64_t)cus;
+        const uint64_t rounds = std::max<uint64_t>(1, (total_in + slots * (192ull << 10) - 1) / (slots * (192ull << 10)));
+        chunk_max = std::min<uint64_t>(std::max<uint64_t>((total_in / (slots * rounds) + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
+    }
     uint64_t nstart_total = 0;
     for (size_t ci : cand) {
         const szl_stream &s = streams[ci];

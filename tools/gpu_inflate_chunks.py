@@ -10,7 +10,7 @@ mb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 for kind in ('enwik', 'logs'):
     d = C.generate(kind, 0xE9, 0, mb << 20)
     comp = eng.deflate([d], level=6)[0].data
-    for kib in (128, 96, 64, 48, 32, 16):
+    for kib in (64, 96, 128, 160, 192, 256, 384):
         L.szl_debug_set(b"SZL_INF_CHUNK_KIB", kib)
         for rep in range(2):
             (r, cons), = eng.inflate([comp], [d.size])
