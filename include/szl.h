@@ -169,7 +169,8 @@ typedef struct szl_timing {
     float total_ms, checksum_ms, links_ms, match_ms, parse_ms, blocks_ms, encode_ms;
     uint64_t in_bytes, out_bytes, tokens, blocks, ranges_unmerged, fallback_walks;
     float inflate_ms;   /* last szl_inflate_batch_* call: k_inflate time (HIP events) */
-    float pilot_ms;     /* stage-B pilot (sample of tiles + read-back) that picks the search form; in total_ms, not in match_ms */
+    float pilot_ms;     /* stage-B pilot (sample of tiles + read-back) when SZL_MATCH_MODE = 2 asks for one (the default is the full search
+                           without a pilot since round 3); in total_ms, not in match_ms */
 } szl_timing;
 int szl_engine_last_timing(const szl_engine *e, szl_timing *t);
 
