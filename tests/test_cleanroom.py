@@ -144,3 +144,61 @@ def test_preset_dictionary_and_set_level():
     assert bytes(outs) == bytes(outo)
     import zlib
     assert zlib.decompress(bytes(outs), -15) == d.tobytes()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_set_level_across_compression_functions_random_patterns(seed):
+    """The call patterns tests/test_gpu_setlevel.py checks the device against the oracle on — SetLevel to another compression
+    function (stored / fast / slow) with bytes pending, any number of times, SetStrategy, Flush in between — checked here between
+    the oracle and the independent Python transliteration (C/DeflaterEngine.cs:304-361 read twice, by two restatements)."""
+    rng = np.random.default_rng(1000 + seed)
+    data = np.concatenate([C.generate("enwik", seed, 0, 45000), C.generate("logs", seed + 1, 0, 35000)])
+    level = int(rng.choice([0, 2, 6]))
+    nowrap = seed % 2 == 1
+    s, o = S.Deflater(level, nowrap), O.Deflater(level, nowrap)
+    outs, outo = bytearray(), bytearray()
+    buf = bytearray(int(rng.choice([64, 700, 4096])))
+
+    def drain():
+        while True:
+            k = s.Deflate(buf, 0, len(buf))
+            if k <= 0:
+                break
+            outs.extend(buf[:k])
+        while True:
+            b = o.deflate(len(buf))
+            if not b:
+                break
+            outo.extend(b)
+
+    pos = 0
+    while pos < data.size:
+        n = int(rng.choice([1, 3, 100, 261, 262, 263, 700, 5000, 20000]))
+        c = data[pos:pos + n]
+        pos += c.size
+        s.SetInput(c.tobytes()); o.set_input(c)
+        if rng.random() < 0.2:                      # before the engine has seen the chunk
+            lv = int(rng.choice([0, 1, 3, 4, 5, 6, 9]))
+            s.SetLevel(lv); o.set_level(lv)
+        drain()
+        r = rng.random()
+        if r < 0.5:
+            lv = int(rng.choice([0, 1, 3, 4, 5, 6, 9]))
+            s.SetLevel(lv); o.set_level(lv)
+            if rng.random() < 0.5:
+                drain()
+        elif r < 0.6:
+            st = int(rng.choice([0, 1, 2]))
+            s.SetStrategy(st); o.set_strategy(st)
+        if rng.random() < 0.15:
+            s.Flush(); o.flush()
+            drain()
+        assert bytes(outs) == bytes(outo), (seed, pos)
+    s.Finish(); o.finish()
+    while not s.IsFinished:
+        k = s.Deflate(buf, 0, len(buf)); outs.extend(buf[:k])
+    while not o.finished:
+        outo.extend(o.deflate(4096))
+    assert bytes(outs) == bytes(outo)
+    import zlib
+    assert zlib.decompress(bytes(outs), -15 if nowrap else 15) == data.tobytes()
