@@ -202,3 +202,65 @@ def test_set_level_across_compression_functions_random_patterns(seed):
     assert bytes(outs) == bytes(outo)
     import zlib
     assert zlib.decompress(bytes(outs), -15 if nowrap else 15) == data.tobytes()
+
+
+@pytest.mark.parametrize("seed", list(range(21, 61)))
+def test_random_api_programs_with_reset_and_dictionary(seed):
+    """Whole-object programs — preset dictionary (zlib framing only, C/Deflater.cs:559), Reset() between streams (S/Zip/ZipOutputStream.cs:494),
+    SetLevel / SetStrategy / Flush in mid-stream, output buffers of a few bytes to a few KiB — oracle vs the Python transliteration:
+    bytes, TotalIn, TotalOut and Adler after every stream."""
+    rng = np.random.default_rng(5000 + seed)
+    pool = np.concatenate([C.generate("dickens", seed, 0, 30000), C.generate("logs", seed, 0, 30000), C.generate("enwik", seed, 0, 30000)])
+    nowrap = bool(rng.integers(0, 2))
+    level = int(rng.choice([0, 1, 4, 5, 6, 8, 9]))
+    s, o = S.Deflater(level, nowrap), O.Deflater(level, nowrap)
+    for stream in range(3):
+        outs, outo = bytearray(), bytearray()
+        buf = bytearray(int(rng.choice([7, 100, 1000, 5000])))
+
+        def drain():
+            while True:
+                k = s.Deflate(buf, 0, len(buf))
+                if k <= 0:
+                    break
+                outs.extend(buf[:k])
+            while True:
+                b = o.deflate(len(buf))
+                if not b:
+                    break
+                outo.extend(b)
+
+        if not nowrap and rng.random() < 0.5:
+            a = int(rng.integers(0, pool.size - 9000))
+            dic = pool[a:a + int(rng.choice([2, 3, 500, 8000]))]
+            s.SetDictionary(dic.tobytes()); o.set_dictionary(dic)
+        total = int(rng.choice([0, 1, 500, 20000, 70000]))
+        a0 = int(rng.integers(0, pool.size - total)) if total < pool.size else 0
+        data = pool[a0:a0 + total]
+        pos = 0
+        while pos < data.size:
+            n = int(rng.choice([1, 2, 3, 260, 262, 5000, 33000]))
+            c = data[pos:pos + n]
+            pos += c.size
+            s.SetInput(c.tobytes()); o.set_input(c)
+            drain()
+            r = rng.random()
+            if r < 0.3:
+                lv = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]))
+                s.SetLevel(lv); o.set_level(lv)
+            elif r < 0.4:
+                st = int(rng.choice([0, 1, 2]))
+                s.SetStrategy(st); o.set_strategy(st)
+            elif r < 0.5:
+                s.Flush(); o.flush()
+                drain()
+        s.Finish(); o.finish()
+        while not s.IsFinished:
+            k = s.Deflate(buf, 0, len(buf)); outs.extend(buf[:k])
+        while not o.finished:
+            outo.extend(o.deflate(len(buf)))
+        assert bytes(outs) == bytes(outo), (seed, stream)
+        assert s.TotalIn == o.total_in == data.size and s.TotalOut == o.total_out == len(outs)
+        if not nowrap:
+            assert s.Adler == o.adler
+        s.Reset(); o.reset()
