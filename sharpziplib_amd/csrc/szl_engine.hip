@@ -581,7 +581,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results.data(), d_so.p, nseg * sizeof(SegOut), hipMemcpyDeviceToHost, st));
-    unsigned long long hc[CNT_LINKS_GUARD + 1] = {0};
+    unsigned long long hc[48] = {0};
     HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (hc[CNT_LINKS_GUARD]) return links_guard_tripped();
@@ -627,6 +627,11 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
                         "COMPLETE passes %llu contexts/pass %.1f | per position: quick ctx-steps %.2f verify ctx-steps %.2f completes %.2f\n",
                 hc[8], hc[14], hc[14] ? (double)hc[15] / hc[14] : 0.0, hc[16], (double)hc[17] / hc[16], hc[18], hc[18] ? (double)hc[19] / hc[18] : 0.0,
                 hc[20], hc[20] ? (double)hc[21] / hc[20] : 0.0, 2.0 * hc[17] / np, hc[19] / np, hc[21] / np);
+    }
+    if (knob("SZL_DEBUG", 0) && hc[43]) {   // k_match9: the tiles' timeline (wall_clock64: 10 ns ticks), averaged over the tiles
+        const double u = 0.01 / (double)hc[43];
+        fprintf(stderr, "[szl] stage B tiles: %llu, per tile: staging %.1f us, until the first wavefront runs out of positions %.1f us, from there to the last wavefront's end %.1f us\n",
+                hc[43], u * hc[40], u * hc[41], u * hc[42]);
     }
     if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] stage B %s (pilot fraction %.3f): %llu of %llu positions evaluated by walkers, %llu by the parse (eval_global), slow walks %llu, unmerged %llu\n", lazy ? "on demand" : "full", last_pilot_frac, hc[6], (unsigned long long)seg_bytes, hc[7], hc[1], hc[0]);
     for (auto &r : results) { timing.out_bytes += r.out_bytes; timing.tokens += r.tok_count; timing.blocks += r.blk_count; }

@@ -51,8 +51,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned2(const uint8_t *p) { uint
 // A tile costs ~67 us beyond its walks (staging of the history, and the wait for the longest walks at its end: profiles/r02/
 // lab_s46_tile_length.log), so the tile is as long as the LDS of a CU allows: 3 bytes per position of history + tile.
 enum : int { B2_THREADS = 1024, B2_TILE = 21504 };
+enum : int { SZL_B9_DEFAULT = 0 };   // (1 once k_match9 has been measured faster on the device)
 enum : int { B2_DATA_BYTES = B_HIST + B2_TILE + B_TAIL + 8, B2_LINKS = B_HIST + B2_TILE };
-enum : int { B2_LDS_BYTES = B2_DATA_BYTES + B2_LINKS * 2 + 16 };
+enum : int { B2_LDS_BYTES = B2_DATA_BYTES + B2_LINKS * 2 + 32 };   // (+ the tile counter and, in the debug build, two time stamps)
 static_assert(B2_LDS_BYTES <= 160 * 1024 && B2_DATA_BYTES % 16 == 0 && B2_TILE % 64 == 0, "the window must fit the CU's LDS");
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -669,8 +670,13 @@ static bool lds_attr_needed2(std::atomic<uint64_t> &mask, uint64_t &bit) {
     return (mask.load(std::memory_order_acquire) & bit) == 0;
 }
 
+hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab, LevelParams P,
+                         unsigned long long *dbg, hipStream_t st);
+
 hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                          MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
+    // SZL_B9: the all-assembly engine of szl_kernels_match9.hip (same tiles, same tables); 0 = k_match4 below
+    if (knob("SZL_B9", SZL_B9_DEFAULT) != 0) return launch_match9(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
