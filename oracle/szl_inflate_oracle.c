@@ -293,6 +293,33 @@ static int iht_get_symbol(const IHT *t, SM *input) { /* :181 */
     }
 }
 
+/* Test hooks (tests/test_reftree.py): the lookup table BuildTree leaves behind and one GetSymbol on a bit pattern of which
+ * `avail` bits exist — what the device's exact-table mode (csrc/szl_inflate_reftree.h) is checked against. */
+int szo_iht_table(const uint8_t *codeLengths, int n, int16_t *out, int cap) {
+    IHT t; t.tree = NULL; t.treeSize = 0;
+    int rc = iht_build(&t, codeLengths, n);
+    if (rc < 0) { free(t.tree); return rc; }
+    int sz = t.treeSize;
+    if (sz <= cap) memcpy(out, t.tree, (size_t)sz * sizeof(int16_t));
+    iht_free(&t);
+    return sz;
+}
+int szo_iht_symbol(const int16_t *tree, int treeSize, uint32_t bits, int avail, int *dropped) {
+    uint8_t buf[4];
+    for (int i = 0; i < 4; i++) buf[i] = (uint8_t)(bits >> (8 * i));
+    IHT t; t.tree = (int16_t *)tree; t.treeSize = treeSize;
+    SM in; sm_reset(&in);
+    /* `avail` bits: whole bytes through the window, the rest pre-loaded the way an odd SetInput leaves them */
+    int nbytes = avail >> 3, rest = avail & 7;
+    (void)rest;
+    in.window_ = buf; in.windowStart_ = 0; in.windowEnd_ = 0; in.buffer_ = avail >= 32 ? bits : (bits & ((1u << avail) - 1)); in.bitsInBuffer_ = avail;
+    (void)nbytes;
+    int before = in.bitsInBuffer_;
+    int sym = iht_get_symbol(&t, &in);
+    *dropped = before - in.bitsInBuffer_;
+    return sym;
+}
+
 /* ================================================================= InflaterDynHeader.cs
  * The C# iterator state machine (:42-120) restated as an explicit resumable state machine. */
 static const int MetaCodeLengthIndex[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};

@@ -682,12 +682,17 @@ struct szl_deflater {
     std::vector<uint64_t> bounds;   // absolute positions of earlier segment ends that still lie inside hist
     std::vector<uint8_t> pend;      // bytes given by SetInput since the last Flush()
     std::vector<uint64_t> chunks;   // SetInput sizes since the last Flush() (level 0 block cuts depend on them)
+    uint64_t chunk_base = 0;        // offset of chunks[0] inside `pend` (not 0 after a function switch: the lookahead the old function left)
     L0State l0;
     size_t chunks_drained = 0;      // chunks after which Deflate() ran while no Flush/Finish was pending
     uint64_t l0_dict = 0;           // bytes of preset dictionary in front of the stream (window positions, not TotalIn)
     std::vector<uint8_t> outq;      // compressed bytes not yet handed out
     size_t outpos = 0;
     uint32_t carry_bits = 0; uint8_t carry_byte = 0;
+    // PendingBuffer.Reset() clears bitCount but not `bits` (C/PendingBuffer.cs:43): what an unfinished stream left in the bit buffer
+    // is OR'ed into the first byte the next stream writes bit by bit (WriteBits :168-189, AlignToByte :143-155).  Survives
+    // deflater_clear(); consumed by the first segment / stored block that produces such a byte.
+    uint8_t stale = 0;
     uint32_t adler = 1;             // running Adler32.Value of everything compressed so far
     uint32_t dict_adler = 0;        // Adler-32 of the preset dictionary (SETDICT state)
     // SetLevel / SetStrategy while input is pending (same compression function): the parameters the first pending byte is
@@ -709,7 +714,7 @@ static void deflater_clear(szl_deflater *d) {
     d->state = d->nowrap ? BUSY_STATE : INIT_STATE;
     d->total_in = d->total_out = 0;
     d->hist.clear(); d->hist_flags.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
-    d->chunks.clear(); d->chunks_drained = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
+    d->chunks.clear(); d->chunks_drained = 0; d->chunk_base = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
     d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
     d->switches.clear(); d->engine_seen = 0; d->base_level = d->level; d->base_strategy = d->strategy; d->hist_has_gaps = false;
 }
@@ -731,9 +736,56 @@ void szl_deflater_destroy(szl_deflater *d) {
     szl_engine_destroy(d->eng);
     delete d;
 }
-int szl_deflater_reset(szl_deflater *d) { if (!d) return SZL_E_ARG; deflater_clear(d); return 0; }
 static int function_switch(szl_deflater *d, int level);
 static int lvl_kind(int lv) { return lv == 0 ? 0 : (lv < 5 ? 1 : 2); }   // DEFLATE_STORED / DEFLATE_FAST / DEFLATE_SLOW (C/DeflaterConstants.cs:146)
+static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out, uint64_t *end_bit_out = nullptr);
+// What PendingBuffer.bits holds when Reset() arrives (C/Deflater.cs:204-210 -> C/PendingBuffer.cs:43 leaves it): the partial byte
+// behind everything the reference has written by then.  That is the byte carried behind the last Flush() / function switch —
+// plus, if the caller went on feeding input and draining Deflate() without a flush, the FULL blocks the engine has flushed since
+// (16384 tokens each, C/DeflaterHuffman.cs:863; DeflateStored: its blocks end on a byte and AlignToByte clears `bits`).  Those
+// blocks are produced here, once, to learn the bits that follow the last of them.  (A caller that resets a finished stream — every
+// ZipOutputStream entry — has nothing pending and pays nothing.)
+static int reset_stale_bits(szl_deflater *d, uint8_t *out) {
+    uint8_t stale = d->carry_bits ? (uint8_t)(d->carry_byte & ((1u << d->carry_bits) - 1u)) : d->stale;
+    *out = stale;
+    if (d->state == FINISHED_STATE || d->pend.empty()) return 0;            // (Finish: AlignToByte has cleared `bits`; carry is 0 then)
+    const int64_t pend_abs = d->total_in - (int64_t)d->pend.size();
+    uint64_t seen = d->engine_seen > pend_abs ? (uint64_t)(d->engine_seen - pend_abs) : 0;
+    if (seen > d->pend.size()) seen = d->pend.size();
+    if (seen == 0) return 0;
+    if (lvl_kind(d->level) == 0) {
+        L0State l0 = d->l0;
+        std::vector<L0Blk> blks;
+        const size_t ndr = std::min(d->chunks_drained, d->chunks.size());
+        for (size_t i = 0; i < ndr; i++) { uint64_t avail = d->chunks[i]; while (l0_engine_deflate(l0, avail, false, false, blks)) { } }
+        if (!blks.empty()) *out = 0;
+        return 0;
+    }
+    if (seen < 16384) return 0;                                               // no full block without 16384 tokens
+    uint64_t x_rel = 0, end_bit = ~0ull;
+    int rc = cut_coded(d, seen, &x_rel, &end_bit);                            // (mutates the object: the caller clears it next)
+    if (rc) return rc;
+    if (end_bit == ~0ull) return 0;                                           // the engine stands where the pending bytes begin
+    size_t nrows = 0;
+    if ((rc = szl_engine_debug_blocks(d->eng, nullptr, 0, &nrows))) return rc;
+    std::vector<uint64_t> rows(8 * (nrows ? nrows : 1));
+    if ((rc = szl_engine_debug_blocks(d->eng, rows.data(), nrows, &nrows))) return rc;
+    int64_t last_full = -1;
+    for (size_t i = 0; i < nrows; i++) if (rows[8 * i + 2] >= 16384) last_full = (int64_t)i;
+    if (last_full < 0) return 0;
+    const uint64_t fend = (size_t)last_full + 1 < nrows ? rows[8 * (last_full + 1) + 3] : end_bit;
+    const uint32_t c = (uint32_t)(fend & 7);
+    *out = c && (fend >> 3) < d->h_out.size() ? (uint8_t)(d->h_out[fend >> 3] & ((1u << c) - 1u)) : 0;
+    return 0;
+}
+int szl_deflater_reset(szl_deflater *d) {
+    if (!d) return SZL_E_ARG;
+    uint8_t stale = 0;
+    const int rc = reset_stale_bits(d, &stale);
+    deflater_clear(d);
+    d->stale = rc ? 0 : stale;
+    return rc;
+}
 // a parameter change while bytes are pending: it takes effect where the reference's engine stands
 static int pend_switch(szl_deflater *d, int level, int strategy) {
     const int64_t at = d->engine_seen > (MIN_LOOKAHEAD - 1) ? d->engine_seen - (MIN_LOOKAHEAD - 1) : 0;
@@ -851,6 +903,7 @@ static int stored_emit(szl_deflater *d, const std::vector<L0Blk> &blks, uint64_t
     d->outq.resize(old + out_total + (finish && !d->nowrap ? 4 : 0));
     if (out_total && hipMemcpy(d->outq.data() + old, d->d_out.p, out_total, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
     }
+    if (d->stale && !sb.empty()) { d->outq[old] |= d->stale; d->stale = 0; }   // the header byte AlignToByte writes is the whole `bits` (:143-155)
     if (finish && !d->nowrap) { // C/Deflater.cs:510-515
         uint8_t *t = d->outq.data() + old + out_total;
         t[0] = (uint8_t)(d->adler >> 24); t[1] = (uint8_t)(d->adler >> 16); t[2] = (uint8_t)(d->adler >> 8); t[3] = (uint8_t)d->adler;
@@ -889,7 +942,7 @@ static int run_segment_stored(szl_deflater *d, bool finish) {
     // trailer then only covers what FillWindow copied (:389), and so does ours.
     const int64_t fed_end = (int64_t)(d->l0.strstart + d->l0.lookahead) - 1 + d->l0.base;
     const uint64_t fed_now = fed_end > wp0 ? (uint64_t)(fed_end - wp0) : 0;
-    d->chunks.clear(); d->chunks_drained = 0;
+    d->chunks.clear(); d->chunks_drained = 0; d->chunk_base = 0;
     int rc = stored_emit(d, blks, fed_now, finish);
     if (rc) return rc;
     advance_history(d, d->pend.size(), nullptr, false);   // stored bytes are in the window, but in no hash chain
@@ -897,9 +950,57 @@ static int run_segment_stored(szl_deflater *d, bool finish) {
     return 0;
 }
 
+// The parameter changes inside the pending bytes (SetLevel / SetStrategy within one compression function) as buffer positions for
+// the engine — and, for DeflateFast, the SetInput boundaries: the reference's engine stops at the first iteration start within
+// MIN_LOOKAHEAD - 1 bytes of the input it has (C/DeflaterEngine.cs:681), and the Deflate() call that brings the next chunk starts
+// with FillWindow(), which slides at window index >= 65274 where DeflateFast's own test is > 65274 (:371 vs :680).  An iteration
+// that starts exactly at index 65274 behind such a boundary therefore runs on the slid window (one candidate at distance 32506
+// becomes index 0 = "no entry").  `nbounds` boundaries: chunk_base + chunks[0] + ... (pend-relative ends of the first nbounds chunks).
+static int segment_switches(szl_deflater *d, const LevelParams &P, uint64_t H, size_t nbounds, std::vector<int64_t> &sw_pos, std::vector<LevelParams> &sw_P) {
+    struct Ev { int64_t pos; int kind; LevelParams P; };
+    std::vector<Ev> ev;
+    const int64_t pend_abs = d->total_in - (int64_t)d->pend.size();
+    int rc;
+    for (const auto &w : d->switches) {
+        LevelParams Pk;
+        if ((rc = level_params(w.level, w.strategy, &Pk))) return rc;
+        if (Pk.fast != P.fast) { set_error("internal: compression function changed inside a segment"); return SZL_E_STATE; }
+        int64_t rel = (int64_t)w.abs_pos - pend_abs;
+        if (rel < 0) rel = 0;
+        ev.push_back(Ev{(int64_t)H + rel, 0, Pk});
+    }
+    if (P.fast) {
+        uint64_t b = d->chunk_base;
+        for (size_t i = 0; i < nbounds && i < d->chunks.size(); i++) {
+            b += d->chunks[i];
+            ev.push_back(Ev{(int64_t)H + (int64_t)b - (int64_t)(MIN_LOOKAHEAD - 1), 1, P});
+        }
+    }
+    std::stable_sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &b) { return a.pos != b.pos ? a.pos < b.pos : a.kind < b.kind; });
+    LevelParams cur = P;
+    sw_pos.clear(); sw_P.clear();
+    for (auto &e : ev) {
+        if (e.kind == 0) cur = e.P;
+        LevelParams q = cur;
+        if (e.kind == 1) q.fast |= 2;
+        sw_pos.push_back(e.pos); sw_P.push_back(q);
+    }
+    return 0;
+}
+
 static int run_segment(szl_deflater *d, bool finish) {
     if (d->level == 0) return run_segment_stored(d, finish);
-    d->chunks.clear(); d->chunks_drained = 0;
+    // SetInput boundaries behind which a Deflate() call ran FillWindow() with the engine out of lookahead: all but the last chunk's
+    // end — and that one too if the caller drained Deflate() once more before Flush() / Finish()
+    const size_t fill_bounds = d->chunks.empty() ? 0 : (d->chunks_drained >= d->chunks.size() ? d->chunks.size() : d->chunks.size() - 1);
+    std::vector<int64_t> sw_pos; std::vector<LevelParams> sw_P;
+    {
+        LevelParams P0;
+        int rc0 = level_params(d->switches.empty() ? d->level : d->base_level, d->switches.empty() ? d->strategy : d->base_strategy, &P0);
+        if (rc0) return rc0;
+        if ((rc0 = segment_switches(d, P0, d->hist.size(), fill_bounds, sw_pos, sw_P))) return rc0;
+    }
+    d->chunks.clear(); d->chunks_drained = 0; d->chunk_base = 0;
     LevelParams P;
     int rc = level_params(d->switches.empty() ? d->level : d->base_level, d->switches.empty() ? d->strategy : d->base_strategy, &P);
     if (rc) return rc;
@@ -921,18 +1022,6 @@ static int run_segment(szl_deflater *d, bool finish) {
     s.finish = finish ? 1 : 0;
     s.flags = finish ? ((d->nowrap ? 0u : (uint32_t)SEG_ZLIB_TRAILER)) : (uint32_t)SEG_SYNC_PAD;
     s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = 0;
-    std::vector<int64_t> sw_pos; std::vector<LevelParams> sw_P;
-    {   // parameter changes inside the pending bytes -> buffer positions
-        const int64_t pend_abs = d->total_in - (int64_t)n;       // absolute input position of the first pending byte
-        for (const auto &w : d->switches) {
-            LevelParams Pk;
-            if ((rc = level_params(w.level, w.strategy, &Pk))) return rc;
-            if (Pk.fast != P.fast) { set_error("internal: compression function changed inside a segment"); return SZL_E_STATE; }
-            int64_t rel = (int64_t)w.abs_pos - pend_abs;
-            if (rel < 0) rel = 0;
-            sw_pos.push_back((int64_t)H + rel); sw_P.push_back(Pk);
-        }
-    }
     std::vector<SegOut> res;
     Engine &E = d->eng->e;
     E.sw_pos_in = sw_pos; E.sw_P_in = sw_P;
@@ -947,6 +1036,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     d->h_out.resize(bytes + 1);
     if (bytes && hipMemcpy(d->h_out.data(), d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
     if (d->carry_bits && bytes) d->h_out[0] |= d->carry_byte;
+    if (d->stale && bytes) { d->h_out[0] |= d->stale; d->stale = 0; }
     if (!d->nowrap) d->adler = res[0].adler32;
     uint64_t whole = finish ? bytes : (end_bit >> 3);
     d->outq.insert(d->outq.end(), d->h_out.begin(), d->h_out.begin() + whole);
@@ -1008,8 +1098,9 @@ static int run_segment(szl_deflater *d, bool finish) {
 // (`while (lookahead >= MIN_LOOKAHEAD || flush)`, :681,:759).  The pending bytes in front of that point are compressed now — with
 // the old function, as a block that is flushed without the sync padding of a Flush() — and the rest stays pending for the new one.
 // DeflateFast / DeflateSlow -> another function: run the bytes the engine has seen through the device with SEG_SWITCH_CUT
-static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out) {
+static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out, uint64_t *end_bit_out) {
     *x_rel_out = 0;
+    if (end_bit_out) *end_bit_out = ~0ull;
     const int64_t pend_abs = d->total_in - (int64_t)d->pend.size();
     const int64_t T_abs = d->engine_seen - (int64_t)(MIN_LOOKAHEAD - 1);   // first position whose iteration did not run
     if (seen == 0 || T_abs <= pend_abs) return 0;                          // the engine stands where the pending bytes begin: no block to flush
@@ -1033,14 +1124,9 @@ static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out) {
     s.finish = 0; s.flags = (uint32_t)SEG_SWITCH_CUT; s.cut_pos = (int64_t)H + (T_abs - pend_abs);
     s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = 1; s.crc_init = 0;
     Engine &E = d->eng->e;
-    E.sw_pos_in.clear(); E.sw_P_in.clear();
-    for (const auto &w : d->switches) {     // parameter changes of the old function inside these bytes
-        LevelParams Pk;
-        if ((rc = level_params(w.level, w.strategy, &Pk))) return rc;
-        if (Pk.fast != P.fast) { set_error("internal: compression function changed inside a segment"); return SZL_E_STATE; }
-        int64_t rel = (int64_t)w.abs_pos - pend_abs;
-        if (rel < 0) rel = 0;
-        E.sw_pos_in.push_back((int64_t)H + rel); E.sw_P_in.push_back(Pk);
+    {   // parameter changes of the old function inside these bytes, and (DeflateFast) the SetInput boundaries in front of the last one seen
+        const size_t ndr = std::min(d->chunks_drained, d->chunks.size());
+        if ((rc = segment_switches(d, P, H, ndr ? ndr - 1 : 0, E.sw_pos_in, E.sw_P_in))) return rc;
     }
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = true; }
@@ -1058,6 +1144,8 @@ static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out) {
     d->h_out.resize(bytes + 1);
     if (bytes && hipMemcpy(d->h_out.data(), d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
     if (d->carry_bits && bytes) d->h_out[0] |= d->carry_byte;
+    if (d->stale && bytes) { d->h_out[0] |= d->stale; d->stale = 0; }
+    if (end_bit_out) *end_bit_out = end_bit;
     const uint64_t whole = end_bit >> 3;
     d->outq.insert(d->outq.end(), d->h_out.begin(), d->h_out.begin() + whole);
     d->carry_bits = (uint32_t)(end_bit & 7);
@@ -1087,6 +1175,7 @@ static int function_switch(szl_deflater *d, int level) {
     const size_t ndr = std::min(d->chunks_drained, d->chunks.size());
     std::vector<uint64_t> unseen_chunks(d->chunks.begin() + (ptrdiff_t)ndr, d->chunks.end());
     uint64_t look = 0;                                 // bytes the engine keeps in front of it (its lookahead)
+    uint64_t seen_left = 0;                            // seen bytes that stay pending: the unseen chunks begin behind them
     if (old_kind == 0) {
         // DeflateStored has consumed what it was given (everything, normally): FlushStoredBlock(blockStart .. strstart, false)
         // if that is not empty, then UpdateHash() (:327-333)
@@ -1110,13 +1199,15 @@ static int function_switch(szl_deflater *d, int level) {
         if (!blks.empty()) { if ((rc = stored_emit(d, blks, X_rel, false))) return rc; }
         look = (uint64_t)d->l0.lookahead;
         advance_history(d, X_rel, nullptr, false);      // stored bytes are in the window but in no hash chain
+        seen_left = seen > X_rel ? seen - X_rel : 0;
     } else {
         uint64_t X_rel = 0;
         if ((rc = cut_coded(d, seen, &X_rel))) return rc;
         look = seen - X_rel;
+        seen_left = look;
     }
     d->switches.clear();
-    d->chunks = unseen_chunks; d->chunks_drained = 0;
+    d->chunks = unseen_chunks; d->chunks_drained = 0; d->chunk_base = seen_left;
     if (new_kind == 0) {
         // DeflateStored continues in the engine's window: strstart at the cut, `look` bytes of lookahead already there
         const int64_t X_w = (d->total_in - (int64_t)d->pend.size()) + (int64_t)d->l0_dict;

@@ -128,13 +128,18 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t *__restrict__ in, con
     bool refilled = true; // FillWindow ran just before this iteration (segment start, or right after a block flush)
     LevelParams Pc = P;                   // parameters of the running iteration (SetLevel / SetStrategy inside the segment: SegDev.sw_*)
     bool search = Pc.strategy != 2;       // HuffmanOnly :686
+    uint32_t swk = 0;
 
     const bool cut = (s.flags & SEG_SWITCH_CUT) != 0;   // SetLevel to another compression function: the engine stands at the first iteration start >= cut_pos (:681)
     while (x < seg_end) {
         if (cut && x >= s.cut_pos) break;
-        if (s.sw_cnt) {
-            Pc = P;
-            for (uint32_t k = 0; k < s.sw_cnt; k++) if (x >= s.sw_pos[k]) Pc = s.sw_P[k];
+        // entries of sw_pos are ascending: a cursor.  An entry whose `fast` has bit 1 set marks a SetInput boundary: the engine had run
+        // out of lookahead there (it stops at the first iteration start within MIN_LOOKAHEAD - 1 of the input it has, :681) and the
+        // next Deflate() call began with FillWindow() — whose slide test is `>=` where this loop's own is `>` (:371 vs :680)
+        while (swk < s.sw_cnt && x >= s.sw_pos[swk]) {
+            Pc = s.sw_P[swk++];
+            if (Pc.fast & 2) refilled = true;
+            Pc.fast &= 1;
             search = Pc.strategy != 2;
         }
         // ---- window slide (:680 strict; FillWindow :371 non-strict)

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned2(const uint8_t *p) { uint
 // A tile costs ~67 us beyond its walks (staging of the history, and the wait for the longest walks at its end: profiles/r02/
 // lab_s46_tile_length.log), so the tile is as long as the LDS of a CU allows: 3 bytes per position of history + tile.
 enum : int { B2_THREADS = 1024, B2_TILE = 21504 };
-enum : int { SZL_B9_DEFAULT = 0 };   // (1 once k_match9 has been measured faster on the device)
+enum : int { SZL_B9_DEFAULT = 1 };   // k_match9 (szl_kernels_match9.hip); 0 = k_match4 below
 enum : int { B2_DATA_BYTES = B_HIST + B2_TILE + B_TAIL + 8, B2_LINKS = B_HIST + B2_TILE };
 enum : int { B2_LDS_BYTES = B2_DATA_BYTES + B2_LINKS * 2 + 32 };   // (+ the tile counter and, in the debug build, two time stamps)
 static_assert(B2_LDS_BYTES <= 160 * 1024 && B2_DATA_BYTES % 16 == 0 && B2_TILE % 64 == 0, "the window must fit the CU's LDS");

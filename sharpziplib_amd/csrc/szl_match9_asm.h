@@ -53,9 +53,9 @@
 #define SZL9_Q_ISSUE(X) \
     "v_lshl_add_u32 %[t0" #X "], %[cb" #X "], 1, %[kk" #X "]\n\t" \
     "ds_read_u16 %[hop" #X "], %[t0" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"     /* prev[] hop of the candidate */ \
-    "ds_read_u8 %[t2" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_DM1) "\n\t"      /* candidate[best_len - 1] */ \
-    "ds_read_u8 %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"        /* candidate[best_len] */
-#define SZL9_Q_COMBINE(X) "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 8, %[t2" #X "]\n\t"
+    "ds_read_u8 %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_DM1) "\n\t"      /* candidate[best_len - 1] -> bits 7:0 */ \
+    "ds_read_u8_d16_hi %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_D) "\n\t" /* candidate[best_len] -> bits 23:16 (the low half stays: no combine) */
+#define SZL9_Q_COMBINE(X)
 #else
 #define SZL9_Q_ISSUE(X) \
     "v_lshl_add_u32 %[t0" #X "], %[cb" #X "], 1, %[kk" #X "]\n\t" \
@@ -185,7 +185,7 @@
     "s_or_b64 %[q" #X "], %[q" #X "], %[sc]\n" \
     "39:\n\t"
 #if SZL9_NQ == 3
-#define SZL9_PB_SET(X) "v_lshl_or_b32 %[pb" #X "], %[t1" #X "], 8, %[t3" #X "]\n\t"
+#define SZL9_PB_SET(X) "v_lshl_or_b32 %[pb" #X "], %[t1" #X "], 16, %[t3" #X "]\n\t"
 #else
 #define SZL9_PB_SET(X) "v_mov_b32 %[pb" #X "], %[t1" #X "]\n\t"
 #endif
@@ -342,7 +342,7 @@
     "s_add_i32 %[wnext], %[wnext], %[f0]\n" \
     "29:\n\t"
 #if SZL9_NQ == 3
-#define SZL9_PB_FIRST(X) "v_lshl_or_b32 %[pb" #X "], %[t4" #X "], 8, %[t3" #X "]\n\t"
+#define SZL9_PB_FIRST(X) "v_lshl_or_b32 %[pb" #X "], %[t4" #X "], 16, %[t3" #X "]\n\t"
 #else
 #define SZL9_PB_FIRST(X) "v_mov_b32 %[pb" #X "], %[t4" #X "]\n\t"
 #endif
@@ -357,6 +357,255 @@
 #else
 #define SZL9_QW1 "2"
 #endif
+
+// ---- the tail program: what a wavefront runs once the tile's positions are handed out -------------------------------------------------
+// Nothing is fetched any more, so the time to the tile's end is the longest walk's dependent chain of rounds — and a round of the
+// two-context loop costs the same ~300 instructions whether 120 or 12 walks are left (PMC / tools/sim_match9.py: a third of a tile's
+// time passes here at 4-13 % lane occupancy).  Therefore:
+//   * 40: the two-context loop without fetch, bookkeeping for it or thresholds (every round: one QUICK iteration = two chain steps,
+//     then whoever left is compared and completed);
+//   * 50: as soon as the walks of both contexts fit ONE context (<= 64), context B's walks MOVE into the free lanes of context A —
+//     rank of the walk among B's = rank of the lane among A's free ones, lane ids through 64 bytes of LDS per wavefront, the 17 state
+//     registers through ds_bpermute_b32 —
+//   * 60: and the rest of the tile runs a one-context loop: half the instructions per round.
+// Results are retired when the walks have moved (their lanes are reused) and at the end.
+#define SZL9_MOVE8(a, b, c, d, e, f, g, h) \
+    "ds_bpermute_b32 %[t0B], %[t3A], %[" a "B]\n\t" \
+    "ds_bpermute_b32 %[t1B], %[t3A], %[" b "B]\n\t" \
+    "ds_bpermute_b32 %[t2B], %[t3A], %[" c "B]\n\t" \
+    "ds_bpermute_b32 %[t3B], %[t3A], %[" d "B]\n\t" \
+    "ds_bpermute_b32 %[t4B], %[t3A], %[" e "B]\n\t" \
+    "ds_bpermute_b32 %[t5B], %[t3A], %[" f "B]\n\t" \
+    "ds_bpermute_b32 %[t6B], %[t3A], %[" g "B]\n\t" \
+    "ds_bpermute_b32 %[t7B], %[t3A], %[" h "B]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_cndmask_b32 %[" a "A], %[" a "A], %[t0B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" b "A], %[" b "A], %[t1B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" c "A], %[" c "A], %[t2B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" d "A], %[" d "A], %[t3B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" e "A], %[" e "A], %[t4B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" f "A], %[" f "A], %[t5B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" g "A], %[" g "A], %[t6B], %[sa]\n\t" \
+    "v_cndmask_b32 %[" h "A], %[" h "A], %[t7B], %[sa]\n\t"
+
+#define SZL9_TAIL \
+    "; @phase census\n" \
+    "40:\n\t" \
+    SZL9_BUSY(A, "n0") \
+    SZL9_BUSY(B, "n1") \
+    "s_add_u32 %[n2], %[n0], %[n1]\n\t" \
+    "s_cmp_eq_u32 %[n2], 0\n\t" \
+    "s_cbranch_scc1 98f\n\t" \
+    "s_cmp_eq_u32 %[n1], 0\n\t"                          /* context B is empty: the one-context loop */ \
+    "s_cbranch_scc1 60f\n\t" \
+    "s_cmp_le_i32 %[n2], %[mth]\n\t"                     /* both fit one context: move B's walks over */ \
+    "s_cbranch_scc1 50f\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[vA]\n\t" \
+    "s_bcnt1_i32_b64 %[f0], %[vB]\n\t" \
+    "s_add_u32 %[n2], %[n2], %[f0]\n\t" \
+    "s_cmp_ge_u32 %[n2], %[vtht]\n\t" \
+    "s_cbranch_scc1 44f\n\t" \
+    "s_or_b64 %[sc], %[qA], %[qB]\n\t" \
+    "s_cbranch_scc0 44f\n\t" \
+    "s_mov_b64 %[mA], %[qA]\n\t" \
+    "s_mov_b64 %[mB], %[qB]\n\t" \
+    "s_mov_b32 %[kt], %[ktail]\n" \
+    "; @phase quick\n" \
+    "41:\n\t" \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    SZL9_Q_ISSUE(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    SZL9_Q_ISSUE(B) \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    "s_waitcnt lgkmcnt(" SZL9_QW1 ")\n\t" \
+    SZL9_Q_FINISH(A) \
+    SZL9_Q_ISSUE(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    "s_waitcnt lgkmcnt(" SZL9_QW1 ")\n\t" \
+    SZL9_Q_FINISH(B) \
+    SZL9_Q_ISSUE(B) \
+    "s_mov_b64 exec, %[mA]\n\t" \
+    "s_waitcnt lgkmcnt(" SZL9_QW1 ")\n\t" \
+    SZL9_Q_FINISH_LAST(A) \
+    "s_mov_b64 exec, %[mB]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_Q_FINISH_LAST(B) \
+    "s_or_b64 %[sc], %[mA], %[mB]\n\t" \
+    "s_cbranch_scc0 42f\n\t"                              /* nobody walks any more */ \
+    "s_sub_u32 %[kt], %[kt], 1\n\t" \
+    "s_cmp_lg_u32 %[kt], 0\n\t" \
+    "s_cbranch_scc1 41b\n" \
+    "; @phase classify\n" \
+    "42:\n\t" \
+    SZL9_Q_CLASSIFY(A) \
+    SZL9_Q_CLASSIFY(B) \
+    "s_branch 40b\n" \
+    "; @phase verify1\n" \
+    "44:\n\t" \
+    "s_mov_b64 %[cA], 0\n\t" \
+    "s_mov_b64 %[cB], 0\n\t" \
+    "s_cmp_eq_u64 %[vB], 0\n\t" \
+    "s_cbranch_scc1 46f\n\t" \
+    "s_cmp_eq_u64 %[vA], 0\n\t" \
+    "s_cbranch_scc1 47f\n\t" \
+    "s_mov_b64 exec, %[vA]\n\t" \
+    SZL9_VF_ISSUE(A) \
+    "s_mov_b64 exec, %[vB]\n\t" \
+    SZL9_VF_ISSUE(B) \
+    "s_mov_b64 exec, %[vA]\n\t" \
+    "s_waitcnt lgkmcnt(5)\n\t" \
+    SZL9_VF_FINISH(A) \
+    "s_mov_b64 exec, %[vB]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_VF_FINISH(B) \
+    SZL9_AFTER_VF(A) \
+    SZL9_AFTER_VF(B) \
+    "s_branch 48f\n" \
+    "46:\n\t" \
+    "s_cmp_eq_u64 %[vA], 0\n\t" \
+    "s_cbranch_scc1 48f\n\t" \
+    "s_mov_b64 exec, %[vA]\n\t" \
+    SZL9_VF_ISSUE(A) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_VF_FINISH(A) \
+    SZL9_AFTER_VF(A) \
+    "s_branch 48f\n" \
+    "47:\n\t" \
+    "s_mov_b64 exec, %[vB]\n\t" \
+    SZL9_VF_ISSUE(B) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_VF_FINISH(B) \
+    SZL9_AFTER_VF(B) \
+    "; @phase verify2\n" \
+    "48:\n\t" \
+    "s_or_b64 %[sc], %[wA], %[wB]\n\t" \
+    "s_cbranch_scc0 49f\n" \
+    "451:\n\t" \
+    SZL9_W_STEP(A) \
+    SZL9_W_STEP(B) \
+    "s_or_b64 %[sc], %[qA], %[qB]\n\t" \
+    "s_or_b64 %[sc], %[sc], %[cA]\n\t" \
+    "s_or_b64 %[sc], %[sc], %[cB]\n\t" \
+    "s_cbranch_scc1 49f\n\t" \
+    "s_or_b64 %[sc], %[wA], %[wB]\n\t" \
+    "s_cbranch_scc1 451b\n" \
+    "; @phase complete\n" \
+    "49:\n\t" \
+    SZL9_COMPLETE(A) \
+    SZL9_COMPLETE(B) \
+    "s_branch 40b\n" \
+    /* ---- 50: context B's walks move into the free lanes of context A */ \
+    "; @phase merge\n" \
+    "50:\n\t" \
+    SZL9_RETIRE(A) \
+    SZL9_RETIRE(B) \
+    "s_or_b64 %[cm], %[qB], %[vB]\n\t" \
+    "s_or_b64 %[cm], %[cm], %[wB]\n\t"                   /* B's walks */ \
+    "s_or_b64 %[sa], %[qA], %[vA]\n\t" \
+    "s_or_b64 %[sa], %[sa], %[wA]\n\t" \
+    "s_not_b64 %[sa], %[sa]\n\t"                         /* A's free lanes */ \
+    "s_mov_b64 exec, -1\n\t" \
+    "v_mbcnt_lo_u32_b32 %[t2A], -1, 0\n\t" \
+    "v_mbcnt_hi_u32_b32 %[t2A], -1, %[t2A]\n\t"         /* lane id */ \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "v_mbcnt_lo_u32_b32 %[t0A], exec_lo, 0\n\t" \
+    "v_mbcnt_hi_u32_b32 %[t0A], exec_hi, %[t0A]\n\t"    /* rank among B's walks */ \
+    "v_add_u32 %[t0A], %[wscr], %[t0A]\n\t" \
+    "ds_write_b8 %[t0A], %[t2A]\n\t"                     /* scratch[rank] = lane */ \
+    "s_mov_b64 exec, %[sa]\n\t" \
+    "v_mbcnt_lo_u32_b32 %[t1A], exec_lo, 0\n\t" \
+    "v_mbcnt_hi_u32_b32 %[t1A], exec_hi, %[t1A]\n\t"    /* rank among A's free lanes */ \
+    "v_cmpx_gt_u32 vcc, %[n1], %[t1A]\n\t"               /* the first n1 of them receive */ \
+    "s_mov_b64 %[sa], exec\n\t" \
+    "v_add_u32 %[t1A], %[wscr], %[t1A]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "ds_read_u8 %[t3A], %[t1A]\n\t"                      /* the lane to take a walk from */ \
+    "s_mov_b64 exec, -1\n\t" \
+    "v_cndmask_b32 %[t4A], 0, 1, %[qB]\n\t"              /* the walk's phase: 1 walking, 2 first compare, 4 comparing on */ \
+    "v_cndmask_b32 %[t5A], 0, 2, %[vB]\n\t" \
+    "v_cndmask_b32 %[t6A], 0, 4, %[wB]\n\t" \
+    "v_or3_b32 %[t4A], %[t4A], %[t5A], %[t6A]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_lshlrev_b32 %[t3A], 2, %[t3A]\n\t" \
+    SZL9_MOVE8("pl", "cb", "kk", "mincb", "left", "pb", "best", "off") \
+    SZL9_MOVE8("cap", "nice", "res2", "resq", "p0", "p1", "p2", "p3") \
+    "ds_bpermute_b32 %[t0B], %[t3A], %[hopB]\n\t" \
+    "ds_bpermute_b32 %[t1B], %[t3A], %[t4A]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_cndmask_b32 %[hopA], %[hopA], %[t0B], %[sa]\n\t" \
+    "s_mov_b64 exec, %[sa]\n\t" \
+    "v_and_b32 %[t2B], 1, %[t1B]\n\t" \
+    "v_cmp_ne_u32 vcc, 0, %[t2B]\n\t" \
+    "s_or_b64 %[qA], %[qA], vcc\n\t" \
+    "v_and_b32 %[t2B], 2, %[t1B]\n\t" \
+    "v_cmp_ne_u32 vcc, 0, %[t2B]\n\t" \
+    "s_or_b64 %[vA], %[vA], vcc\n\t" \
+    "v_and_b32 %[t2B], 4, %[t1B]\n\t" \
+    "v_cmp_ne_u32 vcc, 0, %[t2B]\n\t" \
+    "s_or_b64 %[wA], %[wA], vcc\n\t" \
+    "s_mov_b64 %[qB], 0\n\t" \
+    "s_mov_b64 %[vB], 0\n\t" \
+    "s_mov_b64 %[wB], 0\n" \
+    /* ---- 60: the one-context loop */ \
+    "; @phase census\n" \
+    "60:\n\t" \
+    SZL9_BUSY(A, "n0") \
+    "s_cmp_eq_u32 %[n0], 0\n\t" \
+    "s_cbranch_scc1 98f\n\t" \
+    "s_bcnt1_i32_b64 %[n2], %[vA]\n\t" \
+    "s_cmp_ge_u32 %[n2], %[vtht]\n\t" \
+    "s_cbranch_scc1 64f\n\t" \
+    "s_cmp_eq_u64 %[qA], 0\n\t" \
+    "s_cbranch_scc1 64f\n\t" \
+    "s_mov_b64 %[mA], %[qA]\n\t" \
+    "s_mov_b32 %[kt], %[ktail1]\n\t" \
+    "s_mov_b64 exec, %[mA]\n" \
+    "; @phase quick\n" \
+    "61:\n\t" \
+    SZL9_Q_ISSUE(A) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_Q_FINISH_(A, "") \
+    "s_cbranch_execz 62f\n\t" \
+    SZL9_Q_ISSUE(A) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_Q_FINISH_(A, "") \
+    "s_cbranch_execz 62f\n\t" \
+    "s_sub_u32 %[kt], %[kt], 1\n\t" \
+    "s_cmp_lg_u32 %[kt], 0\n\t" \
+    "s_cbranch_scc1 61b\n" \
+    "; @phase classify\n" \
+    "62:\n\t" \
+    "s_mov_b64 %[mA], exec\n\t" \
+    SZL9_Q_CLASSIFY(A) \
+    "s_branch 60b\n" \
+    "; @phase verify1\n" \
+    "64:\n\t" \
+    "s_mov_b64 %[cA], 0\n\t" \
+    "s_cmp_eq_u64 %[vA], 0\n\t" \
+    "s_cbranch_scc1 68f\n\t" \
+    "s_mov_b64 exec, %[vA]\n\t" \
+    SZL9_VF_ISSUE(A) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_VF_FINISH(A) \
+    SZL9_AFTER_VF(A) \
+    "; @phase verify2\n" \
+    "68:\n\t" \
+    "s_cmp_eq_u64 %[wA], 0\n\t" \
+    "s_cbranch_scc1 69f\n" \
+    "651:\n\t" \
+    SZL9_W_STEP(A) \
+    "s_or_b64 %[sc], %[qA], %[cA]\n\t" \
+    "s_cbranch_scc1 69f\n\t" \
+    "s_cmp_lg_u64 %[wA], 0\n\t" \
+    "s_cbranch_scc1 651b\n" \
+    "; @phase complete\n" \
+    "69:\n\t" \
+    SZL9_COMPLETE(A) \
+    "s_branch 60b\n" \
+    "; @phase retire\n" \
+    "98:\n\t" \
+    SZL9_RETIRE(A) \
+    SZL9_RETIRE(B)
 
 // ---- the main loop -----------------------------------------------------------------------------------------------------------
 // thresholds (SGPR inputs): bexit = 64 - (free lanes of ONE context that make the engine stop for a fetch); vth = contexts
@@ -397,7 +646,9 @@
     "s_cbranch_scc1 99f\n\t" \
     "s_mov_b32 %[qkeep], %[qkeept]\n\t" \
     "s_mov_b32 %[vth], %[vtht]\n\t" \
-    "s_mov_b32 %[bexit], -1\n" \
+    "s_mov_b32 %[bexit], -1\n\t" \
+    "s_cmp_lg_u32 %[tailp], 0\n\t"                     /* the tail program (SZL9_TAIL below); 0: stay in this loop (laboratory) */ \
+    "s_cbranch_scc1 40f\n" \
     "5:\n" \
     "; @phase census\n" \
     "10:\n\t" \
@@ -516,5 +767,6 @@
     SZL9_COMPLETE(A) \
     SZL9_COMPLETE(B) \
     "s_branch 10b\n" \
+    SZL9_TAIL \
     "99:\n\t" \
     "s_mov_b64 exec, %[sv]\n\t"

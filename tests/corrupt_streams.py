@@ -232,6 +232,61 @@ def crafted_long_code_incomplete():
     return out
 
 
+def random_code_set(rng, n, style):
+    """n code lengths that are not over-subscribed: a random complete prefix code over some of the symbols ("complete"), then with
+    codes removed ("drop") or made longer ("longer") — incomplete, and with codes of 10+ bits the class on which the reference's
+    lookup table is not a canonical decoder (C/InflaterHuffmanTree.cs:153-163,200-203)."""
+    leaves = [1, 1]
+    while len(leaves) < n and rng.random() < 0.995:
+        k = int(rng.integers(len(leaves)))
+        if leaves[k] >= 15:
+            if all(l >= 15 for l in leaves):
+                break
+            continue
+        l = leaves.pop(k) + 1
+        leaves += [l, l]
+    lens = np.zeros(n, dtype=np.uint8)
+    idx = rng.permutation(n)[:len(leaves)]
+    lens[idx] = leaves[:len(idx)]
+    if style == "complete":
+        return lens
+    used = np.flatnonzero(lens)
+    drop = max(1, int(len(used) * (0.02 + 0.3 * rng.random())))
+    if style == "drop":
+        lens[rng.choice(used, size=min(drop, len(used) - 1), replace=False)] = 0
+    elif style == "longer":
+        for k in rng.choice(used, size=min(drop, len(used)), replace=False):
+            lens[k] = min(15, int(lens[k]) + int(rng.integers(1, 4)))
+    return lens
+
+
+def quirk_set_streams(rng, count):
+    """[(name, bytes)]: a dynamic block whose literal/length and/or distance set is a damaged random code, followed by RANDOM bits
+    (they walk all over the table: unassigned second-level slots, entries a partial prefix left in the primary table, real
+    codes) — whole, and cut short at random places (what GetSymbol does with fewer than 9 / fewer than `bitlen` bits left)."""
+    out = []
+    k = 0
+    while len(out) < count:
+        k += 1
+        hl = 257 + int(rng.integers(0, 30))
+        ll = random_code_set(rng, hl, ["drop", "longer", "longer", "complete"][k % 4])
+        if ll[256] == 0:
+            ll[256] = int(rng.integers(1, 16))
+            if int(np.sum(1 << (16 - ll[ll > 0].astype(np.int64)))) > 65536:
+                continue
+        hd = 1 + int(rng.integers(0, 30))
+        dd = random_code_set(rng, hd, ["longer", "drop", "complete", "drop"][(k // 4) % 4]) if hd > 1 else np.array([int(rng.integers(0, 3))], dtype=np.uint8)
+        w = dynamic_block([int(x) for x in ll], [int(x) for x in dd], [], last=bool(k & 1))
+        body = rng.integers(0, 256, size=int(rng.integers(4, 400)), dtype=np.uint8).tobytes()
+        head = w.done()
+        s = head + body
+        out.append(("quirkset%d" % k, s))
+        for t in range(2):
+            cut = len(head) + int(rng.integers(0, min(len(body), 40)))
+            out.append(("quirkset%d_trunc@%d" % (k, cut), s[:cut]))
+    return out[:count]
+
+
 def mutations(valid, rng, n_flip=6, n_trunc=3):
     """[(name, bytes)]: single-bit flips and truncations of each valid stream."""
     out = []

@@ -1,0 +1,105 @@
+"""Levels 1-4, the one chunk-dependent corner of DeflateFast (run with -m gpu; the oracle half also runs on the CPU).
+FillWindow() slides the window at index >= 65274 (C/DeflaterEngine.cs:371), DeflateFast's own test is > 65274 (:680).  The engine
+stops at the first iteration start within 261 bytes of the input it has; if that iteration starts exactly at window index 65274
+and the next SetInput() arrives, the Deflate() call that brings it runs FillWindow() first and the iteration sees the SLID window —
+a candidate at distance exactly 32506 is then window index 0, "no entry".  One-shot feeding never slides there.  Both orders must
+come out as the reference's.  Tolerance 0."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+
+def _data(k, seed):
+    """random bytes (an iteration starts at every position) with one planted repeat: position 65273 + 32768 k copies the 24 bytes
+    32506 in front of it"""
+    rng = np.random.default_rng(seed)
+    n = 65273 + 32768 * k + 4000
+    d = rng.integers(0, 256, size=n, dtype=np.uint8)
+    p = 65273 + 32768 * k
+    d[p:p + 24] = d[p - 32506:p - 32506 + 24]
+    return d, p
+
+
+def _oracle_chunked(d, level, cuts):
+    o = O.Deflater(level, True)
+    out = bytearray()
+    prev = 0
+    for c in list(cuts) + [len(d)]:
+        o.set_input(d[prev:c]); prev = c
+        if c == len(d):
+            o.finish()
+        while True:
+            b = o.deflate(8192)
+            if not b:
+                break
+            out += b
+    return bytes(out)
+
+
+def test_the_corner_exists_in_the_reference():
+    hit = 0
+    for level in (1, 2, 3, 4):
+        for k in (0, 1, 3):
+            d, p = _data(k, 100 + k)
+            one = O.deflate(d, level)
+            chunked = _oracle_chunked(d, level, [p + 261])       # the engine stops exactly at p
+            hit += one != chunked
+            assert _oracle_chunked(d, level, [p + 262]) == one   # one byte later: it stops at p + 1, index 65275: both rules slide
+    assert hit >= 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_device_follows_the_feeding_order(level):
+    from sharpziplib_amd.deflater import Deflater
+    buf = np.zeros(8192, np.uint8)
+    for k in (0, 1, 3):
+        d, p = _data(k, 100 + k)
+        for cuts in ([], [p + 261], [p + 260], [p + 262], [1000, p + 261], [p + 261, p + 2000], [p - 40000, p + 261 - 32768 if k else 50, p + 261]):
+            cuts = sorted(set(c for c in cuts if 0 < c < len(d)))
+            dev = Deflater(level, True)
+            got = bytearray()
+            prev = 0
+            for c in cuts + [len(d)]:
+                dev.SetInput(d[prev:c]); prev = c
+                if c == len(d):
+                    dev.Finish()
+                while True:
+                    n = dev.Deflate(buf)
+                    if n <= 0:
+                        break
+                    got += buf[:n].tobytes()
+            assert bytes(got) == _oracle_chunked(d, level, cuts), "level %d k %d cuts %s" % (level, k, cuts)
+
+
+@pytest.mark.gpu
+def test_device_corner_across_a_flush_and_a_function_switch():
+    """the boundary bookkeeping survives Flush() (chunks restart) and SetLevel across functions (the pending bytes restart at the cut)"""
+    from sharpziplib_amd.deflater import Deflater
+    buf = np.zeros(8192, np.uint8)
+    d, p = _data(1, 321)
+    for plan in ("flush", "switch"):
+        dev, o = Deflater(6 if plan == "switch" else 2, True), O.Deflater(6 if plan == "switch" else 2, True)
+        got, ref = bytearray(), bytearray()
+
+        def drain():
+            while True:
+                n = dev.Deflate(buf)
+                if n <= 0:
+                    break
+                got.extend(buf[:n].tobytes())
+            while True:
+                b = o.deflate(8192)
+                if not b:
+                    break
+                ref.extend(b)
+        dev.SetInput(d[:30000]); o.set_input(d[:30000]); drain()
+        if plan == "flush":
+            dev.Flush(); o.flush(); drain()
+        else:
+            dev.SetLevel(2); o.set_level(2); drain()
+        dev.SetInput(d[30000:p + 261]); o.set_input(d[30000:p + 261]); drain()
+        dev.SetInput(d[p + 261:]); o.set_input(d[p + 261:])
+        dev.Finish(); o.finish(); drain()
+        assert bytes(got) == bytes(ref), plan

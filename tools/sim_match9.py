@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--wth", type=int, default=2); ap.add_argument("--wkeep", type=int, default=2); ap.add_argument("--qkeep", type=int, default=64)
     ap.add_argument("--qkeept", type=int, default=128); ap.add_argument("--vtht", type=int, default=1); ap.add_argument("--ktail", type=int, default=4); ap.add_argument("--slice", type=int, default=128); ap.add_argument("--abs0", type=int, default=0)
     ap.add_argument("--notail", action="store_true"); ap.add_argument("--strategy", type=int, default=0); ap.add_argument("--quantum", type=int, default=300)
+    ap.add_argument("--tailp", type=int, default=1); ap.add_argument("--mth", type=int, default=64); ap.add_argument("--ktail1", type=int, default=1)
     ap.add_argument("--cut", type=int, default=0, help="segment ends this many bytes before the end of the generated data's last tile (lookahead clamps)")
     a = ap.parse_args()
     import oracle_ffi as O
@@ -110,7 +111,8 @@ def main():
         s = dict(qA=0, vA=0, wA=0, dA=0, mA=0, cA=0, qB=0, vB=0, wB=0, dB=0, mB=0, cB=0, sc=0, cm=0, sa=0, sv=0, n0=0, n1=0, n2=0, f0=0, f1=0, f2=0,
                  wnext=0, wend=0, exh=0, tlen=tlen, slice=a.slice, rem0=K["rem0"], sw=K["sw"] & W.M32, bmlo=K["bmlo"], bmhi=K["bmhi"],
                  nicel=P.nice, chainm2=(P.max_chain - 2) & W.M32, snapm1=(P.max_chain - (P.max_chain >> 2) - 1) & W.M32, bexit=64 - a.fth, vth=a.vth, wth=a.wth,
-                 wkeep=a.wkeep, qkeep=a.qkeep, qkeept=a.qkeept, vtht=a.vtht, ktail=a.ktail, kt=0, texh=0, stratm=0 if a.strategy == 2 else M64, mt2b=0, mtqb=0)
+                 wkeep=a.wkeep, qkeep=a.qkeep, qkeept=a.qkeept, vtht=a.vtht, ktail=a.ktail, kt=0, texh=0, stratm=0 if a.strategy == 2 else M64, mt2b=0, mtqb=0,
+                 tailp=a.tailp, mth=a.mth & W.M32, ktail1=a.ktail1, wscr=162368 + 64 * w)
         waves.append(W.Wave(prog, lds, v, s, {"mt2b": mt2, "mtqb": mtq}))
         waves[-1].tail_flag = None if a.notail else "exh"
     t = time.time()

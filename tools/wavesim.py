@@ -362,9 +362,9 @@ class Wave:
 
     def _ds(self, op, o, mods, em):
         off = mods.get("offset", 0)
-        if op in ("ds_read_u8", "ds_read_u16", "ds_read_b32", "ds_read_i8"):
+        if op in ("ds_read_u8", "ds_read_u16", "ds_read_b32", "ds_read_i8", "ds_read_u8_d16_hi", "ds_read_u16_d16_hi"):
             addr = (np.broadcast_to(self.rv(o[1]), (64,)).astype(np.int64) + off)
-            n = {"ds_read_u8": 1, "ds_read_i8": 1, "ds_read_u16": 2, "ds_read_b32": 4}[op]
+            n = {"ds_read_u8": 1, "ds_read_i8": 1, "ds_read_u16": 2, "ds_read_b32": 4, "ds_read_u8_d16_hi": 1, "ds_read_u16_d16_hi": 2}[op]
             res = np.zeros(64, dtype=np.uint64)
             a = np.where(em, addr, 0)
             if ((a < 0) | (a + n > self.lds.size)).any():
@@ -377,9 +377,35 @@ class Wave:
                 res |= self.lds[a + k].astype(np.uint64) << np.uint64(8 * k)
             dn = self._name(o[0])
             # the destination may equal the address register: the read takes its address at issue
+            if op.endswith("_d16_hi"):
+                # bits 31:16 = the zero-extended value, bits 15:0 keep what they hold — which may be a read still in flight
+                # (the LDS returns data in issue order)
+                self.v[dn] = np.where(em, (self.v[dn] & np.uint32(0xFFFF)) | (res.astype(np.uint32) << np.uint32(16)), self.v[dn])
+                self.fifo.append(dn)
+                return
             if dn in self.fifo:
                 raise SimError("pc %d: VGPR %s is already the target of an LDS read in flight" % (self.pc - 1, dn))
             self.v[dn] = np.where(em, res.astype(np.uint32), self.v[dn])
+            self.fifo.append(dn)
+            return
+        if op == "ds_write_b8":
+            addr = (np.broadcast_to(self.rv(o[0]), (64,)).astype(np.int64) + off)
+            data = np.broadcast_to(self.rv(o[1]), (64,))
+            for l in np.where(em)[0]:
+                a = int(addr[l])
+                if a < 0 or a >= self.lds.size:
+                    raise SimError("pc %d: LDS write out of range" % (self.pc - 1))
+                self.lds[a] = int(data[l]) & 0xFF
+            self.fifo.append("@write")
+            return
+        if op == "ds_bpermute_b32":       # D[lane] = S[(addr[lane] >> 2) & 63]; data of inactive source lanes reads as 0
+            addr = np.broadcast_to(self.rv(o[1]), (64,)).astype(np.int64) + off
+            data = np.where(em, np.broadcast_to(self.rv(o[2]), (64,)), 0).astype(np.uint32)
+            res = data[(addr >> 2) & 63]
+            dn = self._name(o[0])
+            if dn in self.fifo:
+                raise SimError("pc %d: VGPR %s is already the target of an LDS read in flight" % (self.pc - 1, dn))
+            self.v[dn] = np.where(em, res, self.v[dn])
             self.fifo.append(dn)
             return
         if op == "ds_write_b32":
