@@ -42,6 +42,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=384)
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--quick-configs", action="store_true", help="the other configs at the round-3 sizes (2 GiB / 25000 entries / 1 GiB) instead of BASELINE.json's")
     ap.add_argument("--stub", action="store_true", help="CPU-only plumbing test: gloo, ranks sleep instead of compressing")
     return ap.parse_args(argv)
 
@@ -69,18 +70,84 @@ def roofline(alg_bytes, ms):
     return round(ach, 2), round(ach / HBM_PEAK, 5)
 
 
-def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level):
-    """The other BASELINE configs on one GPU, inputs resident in HBM, device time from the engine's HIP events; every output is
-    checked (round trip on the device, CRC-32 against zlib, oracle bytes on samples)."""
+def gen_parallel(kind, seed, n, threads=None):
+    """the seeded corpus in parallel slices (the generator is position-addressable and releases the GIL)"""
+    import threading
+    import numpy as np
+    from sharpziplib_amd import corpus
+    threads = threads or max(1, min(32, len(os.sched_getaffinity(0))))
+    out = np.empty(n, dtype=np.uint8)
+    piece = 64 << 20
+    offs = list(range(0, n, piece))
+    lock = threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                if not offs:
+                    return
+                o = offs.pop()
+            m = min(piece, n - o)
+            out[o:o + m] = corpus.generate(kind, seed, o, m)
+    th = [threading.Thread(target=work) for _ in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out
+
+
+def zlib_member_parallel(data, chunk=16 << 20, level=6):
+    """ONE raw-deflate member produced by zlib (not by this library): chunks compressed on host threads, each closed by a sync flush
+    (the last one finished) — the block structure of a foreign encoder: zlib's block sizes and trees, empty stored blocks between"""
+    import threading
+    import zlib
+    n = len(data)
+    offs = list(range(0, n, chunk))
+    parts = [None] * len(offs)
+    lock = threading.Lock()
+    todo = list(range(len(offs)))
+
+    def work():
+        while True:
+            with lock:
+                if not todo:
+                    return
+                k = todo.pop()
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            o = offs[k]
+            b = co.compress(data[o:o + chunk].tobytes())
+            b += co.flush(zlib.Z_FINISH if k == len(offs) - 1 else zlib.Z_SYNC_FLUSH)
+            parts[k] = b
+    th = [threading.Thread(target=work) for _ in range(max(1, min(32, len(os.sched_getaffinity(0)))))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return b"".join(parts)
+
+
+def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, quick=False):
+    """The other BASELINE configs on one GPU AT THEIR STATED SIZES (quick: the round-3 sizes), inputs resident in HBM, device time
+    from the engine's HIP events; every output is checked (round trip on the device, CRC-32 against zlib, oracle bytes on samples,
+    the oracle's frozen sha256 for config 5).  Each entry stands alone: one that fails says so and the others still run."""
+    import hashlib
     import zlib
     import numpy as np
     import oracle_ffi as O
-    from sharpziplib_amd import _lib, corpus
+    from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
     out = {}
+    GiB = 1 << 30
+    flags = _lib.F_NOWRAP | _lib.F_CRC32
 
     def alloc(nbytes):
         return torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
+
+    def upload(host):
+        d = alloc(host.size)
+        d[:host.size].copy_(torch.from_numpy(host))
+        return d
 
     def inflate_table(streams, out_lens):
         ist = (_lib.Stream * len(streams))()
@@ -90,91 +157,180 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level):
             oo += (cap + 3) & ~3
         return ist, oo
 
-    # ---- config 4(i): InflaterInputStream over ONE 1 GiB member — the stream the timed region just produced
-    if n >= (64 << 20):
+    def entry(name, nbytes, comp, ms, checked, **more):
+        ach, frac = roofline(nbytes + comp, ms)
+        e = {"device_ms": round(ms, 2), "mib_s": round(nbytes / 2 ** 20 / (ms * 1e-3), 1), "achieved_gb_s": ach, "roofline_frac": frac, "checked": checked}
+        e.update(more)
+        out[name] = e
+
+    def guarded(name, fn):
+        t = time.perf_counter()
+        try:
+            fn()
+        except Exception as e:                    # (an entry that cannot run — memory on a shared box — or fails its check says so; the headline stands on its own)
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        finally:
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+        out.setdefault("_wall_s", {})[name] = round(time.perf_counter() - t, 1)
+
+    # ---- config 4(i): InflaterInputStream over ONE member — the 1 GiB stream the timed region just produced ...
+    def c4i_1g():
         ist, oo = inflate_table([type("S", (), {"out_off": 0, "out_len": out_len})()], [n])
         back = alloc(oo)
-        eng.inflate_device(d_out.data_ptr(), back.data_ptr(), ist, flags=_lib.F_NOWRAP | _lib.F_CRC32, hip_stream=hip_stream)   # (first call: allocations)
-        eng.inflate_device(d_out.data_ptr(), back.data_ptr(), ist, flags=_lib.F_NOWRAP | _lib.F_CRC32, hip_stream=hip_stream)
+        for _ in range(2):                              # (first call: allocations)
+            eng.inflate_device(d_out.data_ptr(), back.data_ptr(), ist, flags=flags, hip_stream=hip_stream)
         ms = eng.timing()["inflate_ms"]
-        ok = ist[0].status == 0 and int(ist[0].out_len) == n and int(ist[0].in_consumed) == out_len and bool(torch.equal(back[:n], d_in[:n]))
-        assert ok, "config 4(i): the device Inflater does not return the corpus from the device Deflater's member"
-        ach, frac = roofline(n + out_len, ms)
-        out["4i_inflate_one_%dMiB_member" % (n >> 20)] = {"device_ms": round(ms, 2), "mib_s": round(n / 2 ** 20 / (ms * 1e-3), 1), "achieved_gb_s": ach,
-                                                          "roofline_frac": frac, "checked": "bytes == corpus on device, in_consumed exact, CRC-32"}
-        del back
-    # ---- config 3: ZipOutputStream entries — 50000 x 64 KiB text entries, level 6 + CRC-32, one call (and back through the Inflater)
-    n3, esz = 50000, 65536
-    host3 = corpus.generate("enwik", 0x21B0, 0, n3 * esz)
-    d3 = alloc(n3 * esz)
-    d3[:n3 * esz].copy_(torch.from_numpy(host3))
-    st3, _, ot3 = Engine.layout([esz] * n3)
-    o3 = alloc(ot3)
-    flags = _lib.F_NOWRAP | _lib.F_CRC32
-    eng.deflate_device(d3.data_ptr(), o3.data_ptr(), st3, level=level, flags=flags, hip_stream=hip_stream)
-    eng.deflate_device(d3.data_ptr(), o3.data_ptr(), st3, level=level, flags=flags, hip_stream=hip_stream)
-    tm = eng.timing()
-    comp3 = sum(int(s.out_len) for s in st3)
-    for i in (0, 1, n3 // 2, n3 - 1):
-        s = st3[i]
-        got = o3[s.out_off:s.out_off + s.out_len].cpu().numpy().tobytes()
-        assert got == O.deflate(host3[i * esz:(i + 1) * esz], level) and s.crc32 == zlib.crc32(host3[i * esz:(i + 1) * esz].tobytes()), "config 3: entry %d" % i
-    ach, frac = roofline(n3 * esz + comp3, tm["total_ms"])
-    out["3_zip_%d_x_64KiB_deflate" % n3] = {"device_ms": round(tm["total_ms"], 2), "mib_s": round(n3 * esz / 2 ** 20 / (tm["total_ms"] * 1e-3), 1),
-                                            "ratio": round(comp3 / (n3 * esz), 4), "achieved_gb_s": ach, "roofline_frac": frac,
-                                            "checked": "4 entries == oracle bytes + CRC-32; all entries inflated back below"}
-    ist, oo = inflate_table(st3, [esz] * n3)
-    b3 = alloc(oo)
-    eng.inflate_device(o3.data_ptr(), b3.data_ptr(), ist, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
-    eng.inflate_device(o3.data_ptr(), b3.data_ptr(), ist, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
-    ms = eng.timing()["inflate_ms"]
-    assert all(s.status == 0 for s in ist) and bool(torch.equal(b3[:n3 * esz], d3[:n3 * esz])), "config 3: inflate round trip"
-    ach, frac = roofline(n3 * esz + comp3, ms)
-    out["3_zip_%d_x_64KiB_inflate" % n3] = {"device_ms": round(ms, 2), "mib_s": round(n3 * esz / 2 ** 20 / (ms * 1e-3), 1), "achieved_gb_s": ach,
-                                            "roofline_frac": frac, "checked": "every entry == input on device"}
-    del o3, b3
-    # ---- config 4(ii): a .gz of many members — 2 GiB as 512 x 4 MiB members (the first 2 GiB of the same bytes), inflate only
-    m4, msz = 512, 4 << 20
-    st4, _, ot4 = Engine.layout([msz] * m4)
-    o4 = alloc(ot4)
-    eng.deflate_device(d3.data_ptr(), o4.data_ptr(), st4, level=level, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
-    comp4 = sum(int(s.out_len) for s in st4)
-    ist, oo = inflate_table(st4, [msz] * m4)
-    b4 = alloc(oo)
-    eng.inflate_device(o4.data_ptr(), b4.data_ptr(), ist, flags=_lib.F_NOWRAP | _lib.F_CRC32, hip_stream=hip_stream)
-    eng.inflate_device(o4.data_ptr(), b4.data_ptr(), ist, flags=_lib.F_NOWRAP | _lib.F_CRC32, hip_stream=hip_stream)
-    ms = eng.timing()["inflate_ms"]
-    assert all(s.status == 0 and int(s.in_consumed) == int(t.out_len) for s, t in zip(ist, st4)) and bool(torch.equal(b4[:m4 * msz], d3[:m4 * msz])), "config 4(ii)"
-    ach, frac = roofline(m4 * msz + comp4, ms)
-    out["4ii_inflate_%d_x_4MiB_members" % m4] = {"device_ms": round(ms, 2), "mib_s": round(m4 * msz / 2 ** 20 / (ms * 1e-3), 1), "achieved_gb_s": ach,
-                                                 "roofline_frac": frac, "checked": "every member == input on device, in_consumed exact"}
-    del o4, b4, d3, host3
-    # ---- config 5: Deflater level 9 on repetitive logs, 1 GiB
-    n5 = 1 << 30
-    host5 = corpus.generate("logs", 0x106, 0, n5)
-    d5 = alloc(n5)
-    d5[:n5].copy_(torch.from_numpy(host5))
-    st5, _, ot5 = Engine.layout([n5])
-    o5 = alloc(ot5)
-    eng.deflate_device(d5.data_ptr(), o5.data_ptr(), st5, level=9, flags=flags, hip_stream=hip_stream)
-    eng.deflate_device(d5.data_ptr(), o5.data_ptr(), st5, level=9, flags=flags, hip_stream=hip_stream)
-    tm = eng.timing()
-    c5 = int(st5[0].out_len)
-    assert st5[0].crc32 == zlib.crc32(host5.tobytes()), "config 5: CRC-32"
-    sample = 32 << 20
-    ps, _, pot = Engine.layout([sample])
-    po = alloc(pot)
-    eng.deflate_device(d5.data_ptr(), po.data_ptr(), ps, level=9, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
-    assert po[:int(ps[0].out_len)].cpu().numpy().tobytes() == O.deflate(host5[:sample], 9), "config 5: first 32 MiB as a stream != oracle"
-    ist, oo = inflate_table(st5, [n5])
-    b5 = alloc(oo)
-    eng.inflate_device(o5.data_ptr(), b5.data_ptr(), ist, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
-    assert ist[0].status == 0 and bool(torch.equal(b5[:n5], d5[:n5])), "config 5: round trip"
-    ach, frac = roofline(n5 + c5, tm["total_ms"])
-    out["5_level9_logs_1GiB_deflate"] = {"device_ms": round(tm["total_ms"], 2), "mib_s": round(n5 / 2 ** 20 / (tm["total_ms"] * 1e-3), 1),
-                                         "ratio": round(c5 / n5, 4), "achieved_gb_s": ach, "roofline_frac": frac,
-                                         "stage_ms": {k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")},
-                                         "checked": "CRC-32 == zlib, device round trip == input, first 32 MiB as a stream == oracle bytes"}
+        assert ist[0].status == 0 and int(ist[0].out_len) == n and int(ist[0].in_consumed) == out_len and bool(torch.equal(back[:n], d_in[:n])), "device Inflater != corpus"
+        entry("4i_inflate_one_%dMiB_member" % (n >> 20), n, out_len, ms, "bytes == corpus on device, in_consumed exact, CRC-32")
+    if n >= (64 << 20):
+        guarded("4i_inflate_one_%dMiB_member" % (n >> 20), c4i_1g)
+
+    big_n = (2 if quick else 8) * GiB
+    host_big = gen_parallel("enwik", 0x21B0, big_n)
+    d_big = upload(host_big)
+
+    # ---- ... and ONE 8 GiB member (the stated size): the device Deflater's (window pipeline), back through the chunk-parallel decoder
+    def c4i_big():
+        e2 = Engine()
+        try:
+            st, _, ot = Engine.layout([big_n])
+            o = alloc(ot)
+            e2.deflate_device(d_big.data_ptr(), o.data_ptr(), st, level=level, flags=flags, hip_stream=hip_stream)
+            dms = e2.timing()["total_ms"]
+            clen = int(st[0].out_len)
+            ist, oo = inflate_table(st, [big_n])
+            back = alloc(oo)
+            for _ in range(2):
+                e2.inflate_device(o.data_ptr(), back.data_ptr(), ist, flags=flags, hip_stream=hip_stream)
+            ms = e2.timing()["inflate_ms"]
+            assert ist[0].status == 0 and int(ist[0].out_len) == big_n and int(ist[0].in_consumed) == clen and ist[0].crc32 == st[0].crc32, "status / sizes / CRC-32"
+            assert bool(torch.equal(back[:big_n], d_big[:big_n])), "8 GiB member: bytes differ"
+            entry("4i_inflate_one_%dGiB_member" % (big_n // GiB), big_n, clen, ms, "bytes == input on device, in_consumed exact, CRC-32 == the Deflater's",
+                  deflate_ms_window_pipeline=round(dms, 1), workspace_gib=round(e2._L.szl_engine_debug_workspace(e2._h) / GiB, 2))
+        finally:
+            e2.close()
+    guarded("4i_inflate_one_%dGiB_member" % (big_n // GiB), c4i_big)
+
+    # ---- config 4(ii): a .gz of many members — 8 GiB as 2048 x 4 MiB members, inflate only (deflated here in four calls)
+    def c4ii():
+        msz = 4 << 20
+        m4 = big_n // msz
+        e2 = Engine()
+        try:
+            st4, _, ot4 = Engine.layout([msz] * m4)
+            o4 = alloc(ot4)
+            per = 512
+            for a in range(0, m4, per):
+                sub = (_lib.Stream * per)()
+                for k in range(per):
+                    for f in ("in_off", "in_len", "out_off", "out_cap"):
+                        setattr(sub[k], f, getattr(st4[a + k], f))
+                e2.deflate_device(d_big.data_ptr(), o4.data_ptr(), sub, level=level, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
+                for k in range(per):
+                    st4[a + k].out_len = sub[k].out_len
+            comp4 = sum(int(s.out_len) for s in st4)
+            ist, oo = inflate_table(st4, [msz] * m4)
+            b4 = alloc(oo)
+            for _ in range(2):
+                e2.inflate_device(o4.data_ptr(), b4.data_ptr(), ist, flags=flags, hip_stream=hip_stream)
+            ms = e2.timing()["inflate_ms"]
+            assert all(s.status == 0 and int(s.in_consumed) == int(t.out_len) for s, t in zip(ist, st4)) and bool(torch.equal(b4[:m4 * msz], d_big[:m4 * msz])), "members differ"
+            entry("4ii_inflate_%d_x_4MiB_members" % m4, m4 * msz, comp4, ms, "every member == input on device, in_consumed exact")
+        finally:
+            e2.close()
+    guarded("4ii_inflate_members", c4ii)
+
+    # ---- config 3: ZipOutputStream entries — 100000 x 64 KiB text entries, level 6 + CRC-32, one call (and back through the Inflater)
+    def c3():
+        esz = 65536
+        n3 = min(25000 if quick else 100000, big_n // esz)
+        e2 = Engine()
+        try:
+            st3, _, ot3 = Engine.layout([esz] * n3)
+            o3 = alloc(ot3)
+            for _ in range(2):
+                e2.deflate_device(d_big.data_ptr(), o3.data_ptr(), st3, level=level, flags=flags, hip_stream=hip_stream)
+            tm = e2.timing()
+            comp3 = sum(int(s.out_len) for s in st3)
+            for i in (0, 1, n3 // 2, n3 - 1):
+                s = st3[i]
+                got = o3[s.out_off:s.out_off + s.out_len].cpu().numpy().tobytes()
+                assert got == O.deflate(host_big[i * esz:(i + 1) * esz], level) and s.crc32 == zlib.crc32(host_big[i * esz:(i + 1) * esz].tobytes()), "entry %d" % i
+            entry("3_zip_%d_x_64KiB_deflate" % n3, n3 * esz, comp3, tm["total_ms"], "4 entries == oracle bytes + CRC-32; all entries inflated back below",
+                  ratio=round(comp3 / (n3 * esz), 4), stage_ms={k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")})
+            ist, oo = inflate_table(st3, [esz] * n3)
+            b3 = alloc(oo)
+            for _ in range(2):
+                e2.inflate_device(o3.data_ptr(), b3.data_ptr(), ist, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
+            ms = e2.timing()["inflate_ms"]
+            assert all(s.status == 0 for s in ist) and bool(torch.equal(b3[:n3 * esz], d_big[:n3 * esz])), "inflate round trip"
+            entry("3_zip_%d_x_64KiB_inflate" % n3, n3 * esz, comp3, ms, "every entry == input on device")
+        finally:
+            e2.close()
+    guarded("3_zip_entries", c3)
+
+    # ---- a member this library did not produce: 1 GiB through zlib (sync-flushed 16 MiB pieces), default knobs, chunk-parallel decoder
+    def cz():
+        zn = GiB
+        comp = np.frombuffer(zlib_member_parallel(host_big[:zn]), dtype=np.uint8)
+        dz = upload(comp)
+        back = alloc(zn)
+        ist = (_lib.Stream * 1)()
+        ist[0].in_off, ist[0].in_len, ist[0].out_off, ist[0].out_cap = 0, comp.size, 0, zn
+        e2 = Engine()
+        try:
+            for _ in range(2):
+                e2.inflate_device(dz.data_ptr(), back.data_ptr(), ist, flags=flags, hip_stream=hip_stream)
+            ms = e2.timing()["inflate_ms"]
+            assert ist[0].status == 0 and int(ist[0].out_len) == zn and int(ist[0].in_consumed) == comp.size and bool(torch.equal(back[:zn], d_big[:zn])), "zlib member"
+            entry("4z_inflate_one_1GiB_member_made_by_zlib", zn, comp.size, ms, "bytes == input on device, in_consumed exact (zlib level 6, 64 sync-flushed pieces)",
+                  par_jobs=int(e2._L.szl_engine_debug_par_jobs(e2._h)))
+        finally:
+            e2.close()
+    guarded("4z_inflate_zlib_member", cz)
+    del d_big, host_big
+    torch.cuda.empty_cache()
+
+    # ---- config 5: Deflater level 9 on repetitive logs, 4 GiB (the window pipeline), sha256 against the oracle's frozen output
+    def c5():
+        n5 = (1 if quick else 4) * GiB
+        host5 = gen_parallel("logs", 0x106, n5)
+        d5 = upload(host5)
+        e2 = Engine()
+        try:
+            st5, _, ot5 = Engine.layout([n5])
+            o5 = alloc(ot5)
+            for _ in range(2):
+                e2.deflate_device(d5.data_ptr(), o5.data_ptr(), st5, level=9, flags=flags, hip_stream=hip_stream)
+            tm = e2.timing()
+            c5n = int(st5[0].out_len)
+            checked = []
+            gpath = os.path.join(ROOT, "tests", "golden", "headline_golden.json")
+            g = json.load(open(gpath))["cases"].get("cfg5_logs_4g_l9") if os.path.exists(gpath) else None
+            if g and n5 == g["n"]:
+                got = hashlib.sha256(o5[:c5n].cpu().numpy().tobytes()).hexdigest()
+                assert c5n == g["out_len"] and got == g["out_sha256"] and int(st5[0].crc32) == g["crc32"], "4 GiB level 9: device output != the oracle's (golden sha256)"
+                checked.append("sha256 + CRC-32 == oracle golden (tests/golden, 4 GiB)")
+            else:
+                sample = 32 << 20
+                ps, _, pot = Engine.layout([sample])
+                po = alloc(pot)
+                e2.deflate_device(d5.data_ptr(), po.data_ptr(), ps, level=9, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
+                assert po[:int(ps[0].out_len)].cpu().numpy().tobytes() == O.deflate(host5[:sample], 9), "first 32 MiB as a stream != oracle"
+                checked.append("first 32 MiB as a stream == oracle bytes")
+            ist, oo = inflate_table(st5, [n5])
+            b5 = alloc(oo)
+            e2.inflate_device(o5.data_ptr(), b5.data_ptr(), ist, flags=_lib.F_NOWRAP, hip_stream=hip_stream)
+            ims = e2.timing()["inflate_ms"]
+            assert ist[0].status == 0 and bool(torch.equal(b5[:n5], d5[:n5])), "round trip"
+            checked.append("device round trip == input")
+            entry("5_level9_logs_%dGiB_deflate" % (n5 // GiB), n5, c5n, tm["total_ms"], "; ".join(checked), ratio=round(c5n / n5, 4),
+                  stage_ms={k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")}, workspace_gib=round(e2._L.szl_engine_debug_workspace(e2._h) / GiB, 2),
+                  inflate_back_ms=round(ims, 1))
+        finally:
+            e2.close()
+    guarded("5_level9_logs", c5)
     return out
 
 
@@ -339,7 +495,7 @@ def run_weak(args, rank, local_rank, world, dist):
     if rank == 0:
         assert len(all_sizes) == world == args.gpus, "the line must report the GPUs that ran"
         value = world * n * args.steps / elapsed / 2 ** 20
-        # roofline of the dominant kernel (k_match4, stage B): algorithmic bytes per launch = input read once +
+        # roofline of the dominant kernel (k_match9, stage B): algorithmic bytes per launch = input read once +
         # output written once = n*(1+ratio), divided by the kernel's mean duration measured with
         # HIP events on the launch stream inside the timed region.
         k_ms = sum(kern_ms) / len(kern_ms)
@@ -348,13 +504,13 @@ def run_weak(args, rank, local_rank, world, dist):
         traffic = None
         # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 --pmc passes of this
         # same command (tools/gpu_traffic.sh -> profiles/rNN/*traffic_pmc.json); `traffic_source` says which file
-        tpath = next((t for t in ([os.path.join(ROOT, "profiles", r, "traffic_pmc.json") for r in ("r03", "r02")] +
+        tpath = next((t for t in ([os.path.join(ROOT, "profiles", r, "traffic_pmc.json") for r in ("r04", "r03", "r02")] +
                                   [os.path.join(ROOT, "profiles", "r01", "g_traffic_pmc.json")]) if os.path.exists(t)), "")
         if args.mib == 1024 and args.level == 6 and tpath:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units) of this same command, per launch of k_match;
             # FETCH_SIZE doubled for wide coalesced streaming reads on gfx950 (MI355X_MICROARCH.md §HBM)
             rec = json.load(open(tpath))
-            k = next((v for kk, v in rec.items() if "k_match4" in kk or "k_match<" in kk), None)   # the search proper, not the pilot (k_match_lazy)
+            k = next((v for kk, v in rec.items() if "k_match9" in kk), None)   # counters of THIS kernel only (profiles of earlier rounds hold k_match4's)
             if k:
                 traffic = int((2 * k["fetch"] + k["write"]) * 1024 / max(1, k.get("dispatches", 1)))
         line = {
@@ -366,7 +522,7 @@ def run_weak(args, rank, local_rank, world, dist):
             "config": {"workload": "configs[1]: GZip-style raw Deflater level %d + CRC-32 on one %d MiB enwik-style stream per GPU "
                                    "(seed 0xE9, shard = rank), bit-identical to the reference Deflater" % (args.level, args.mib),
                        "level": args.level, "shard_mib": args.mib, "parallelism": "stream-per-gpu x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_match4", "achieved": round(achieved, 2), "peak": HBM_PEAK, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_match9", "achieved": round(achieved, 2), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,
                          "traffic_source": (os.path.relpath(tpath, ROOT) + " (rocprofv3 PMC pass of this command; not measured in this run)") if traffic else None,
                          "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg_bytes),
@@ -397,28 +553,40 @@ def run_weak(args, rank, local_rank, world, dist):
             del p_out
             parity["checked_bytes"] += sample
             parity["how"].append("first %d MiB as its own stream: bytes == oracle run in this process" % (sample >> 20))
-            # all host cores: one independent oracle Deflater per core on disjoint 16 MiB slices (what a host-side
-            # "shard = stream" run over the same corpus could reach; the reference itself is single-threaded per Deflater)
-            import threading
-            ncore = min(os.cpu_count() or 1, max(1, n // (16 << 20)))
-            outs = [0] * ncore
-
-            def work(i):
-                outs[i] = len(O.deflate(host[i * (16 << 20):(i + 1) * (16 << 20)], args.level))
-            th = [threading.Thread(target=work, args=(i,)) for i in range(ncore)]
+            # all host cores this process may use: independent oracle Deflaters on disjoint 16 MiB slices, pthreads inside oracle/
+            # (szo_deflate_slices_mt) — what a host-side "shard = stream" run over the same corpus could reach on this box; the
+            # reference itself is single-threaded per Deflater.  `cores` = the threads that ran = the CPUs the scheduler gives this
+            # process (affinity mask and cgroup quota), not the machine's core count (`host_cores`).
+            import ctypes
+            usable = len(os.sched_getaffinity(0))
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    quota = float(q) / float(per)
+            except Exception:
+                try:
+                    q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if q > 0:
+                        quota = q / per
+                except Exception:
+                    pass
+            nthr = max(1, min(usable, int(quota + 0.5) if quota else usable, n // (16 << 20)))
+            nsl = max(nthr, min(n // (16 << 20), 2 * nthr))
+            OL = O.lib()
+            OL.szo_deflate_slices_mt.restype = ctypes.c_int64
+            OL.szo_deflate_slices_mt.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            lens = np.zeros(nsl, dtype=np.uint64)
             t2 = time.perf_counter()
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
+            tot = OL.szo_deflate_slices_mt(host.ctypes.data, 16 << 20, nsl, args.level, nthr, lens.ctypes.data)
             dt2 = time.perf_counter() - t2
-            line["cpu_baseline_all_cores"] = {"value": round(ncore * 16 / dt2, 1), "unit": "MiB/s", "cores": ncore, "kind": "port",
-                                              "sample": "%d independent 16 MiB slices, one oracle Deflater per thread" % ncore}
+            assert tot > 0
+            line["cpu_baseline_all_cores"] = {"value": round(nsl * 16 / dt2, 1), "unit": "MiB/s", "cores": nthr, "kind": "port",
+                                              "host_cores": os.cpu_count(), "usable_cpus": usable, "cpu_quota": quota,
+                                              "sample": "%d independent 16 MiB slices of the same shard, one oracle Deflater per pthread (%d threads)" % (nsl, nthr)}
         if world == 1 and not args.no_extra_configs:
             try:
-                line["configs"] = extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, args.level)
-            except AssertionError:
-                raise
+                line["configs"] = extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, args.level, quick=args.quick_configs)
             except Exception as e:                      # (e.g. not enough memory on a shared box: the headline stands on its own)
                 line["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         line["parity_checked_bytes"] = parity["checked_bytes"]

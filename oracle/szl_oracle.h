@@ -119,6 +119,8 @@ uint32_t szo_inflater_adler(const szo_inflater *s);
 int64_t szo_inflate_oneshot(const uint8_t *in, size_t n, int no_header, uint8_t *out, size_t out_cap,
                             size_t *consumed);
 /* Test aid: number of incomplete code-length sets with codes of 10+ bits built since the last reset (see iht_build). */
+/* bench infrastructure (szl_parallel.c): n_slices independent one-shot raw Deflaters on `threads` host threads */
+int64_t szo_deflate_slices_mt(const uint8_t *in, size_t slice_len, int n_slices, int level, int threads, uint64_t *out_lens);
 int szo_quirk_sets_seen(int reset);
 /* test hooks: BuildTree's table (returns treeSize or an error) and one GetSymbol with `avail` bits of input left */
 int szo_iht_table(const uint8_t *codeLengths, int n, int16_t *out, int cap);

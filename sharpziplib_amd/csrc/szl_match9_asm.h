@@ -53,9 +53,11 @@
 #define SZL9_Q_ISSUE(X) \
     "v_lshl_add_u32 %[t0" #X "], %[cb" #X "], 1, %[kk" #X "]\n\t" \
     "ds_read_u16 %[hop" #X "], %[t0" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"     /* prev[] hop of the candidate */ \
-    "ds_read_u8 %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_DM1) "\n\t"      /* candidate[best_len - 1] -> bits 7:0 */ \
-    "ds_read_u8_d16_hi %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_D) "\n\t" /* candidate[best_len] -> bits 23:16 (the low half stays: no combine) */
-#define SZL9_Q_COMBINE(X)
+    "ds_read_u8 %[t2" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_DM1) "\n\t"      /* candidate[best_len - 1] */ \
+    "ds_read_u8 %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"        /* candidate[best_len] */
+/* (ds_read_u8_d16_hi into the register the first byte is in flight to would save this instruction — measured on the device it does
+ * not keep the low half: gfx950 runs with SRAM ECC, where a d16 load writes the whole register; profiles/r04/c1_lab.log) */
+#define SZL9_Q_COMBINE(X) "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 16, %[t2" #X "]\n\t"
 #else
 #define SZL9_Q_ISSUE(X) \
     "v_lshl_add_u32 %[t0" #X "], %[cb" #X "], 1, %[kk" #X "]\n\t" \

@@ -27,6 +27,7 @@ CASES = {
     "off4g_enwik_8m_l6": ("enwik", 0xE9, 7 << 20, 8 << 20, 6, 0),   # the stream placed above 2^32 in the arenas (64-bit offsets)
     "cfg5_logs_2g_l9": ("logs", 0x106, 0, 2 << 30, 9, 0),           # configs[4] at half size: 2 GiB takes the library's default window pipeline
     "cfg1_dickens_64m_l6": ("dickens", 0xD1CE, 0, 64 << 20, 6, 0),  # configs[0]: raw Deflater level 6 on 64 MiB of prose
+    "cfg5_logs_4g_l9": ("logs", 0x106, 0, 4 << 30, 9, 0),           # configs[4] at FULL size (bench.py times it through the window pipeline)
 }
 
 
