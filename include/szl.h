@@ -222,6 +222,9 @@ int szl_inflater_remaining_input(const szl_inflater *s);                    /* R
 int64_t szl_inflater_total_in(const szl_inflater *s);                       /* TotalIn          C/Inflater.cs:862 */
 int64_t szl_inflater_total_out(const szl_inflater *s);                      /* TotalOut         C/Inflater.cs:848 */
 uint32_t szl_inflater_adler(const szl_inflater *s);                         /* Adler            C/Inflater.cs:823 */
+/* Parity / measurement tap: pieces of this streaming Inflater's input that went to the chunk-parallel decoder (a SetInput of 2 MiB or
+ * more — InflaterInputStream with a large buffer, CS/InflaterInputStream.cs:342-396 — is not decoded by one wavefront) */
+uint32_t szl_inflater_debug_bulk_calls(const szl_inflater *s);
 
 /* Batch inflate of independent raw-deflate / zlib streams (zip entries, gzip members): one
  * wavefront per stream.  streams[i].in_* = compressed bytes, out_* = region for the decompressed

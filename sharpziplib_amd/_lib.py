@@ -80,6 +80,7 @@ def _load(path):
         "szl_debug_set": (i32, [ctypes.c_char_p, i32]),
         "szl_engine_debug_workspace": (u64, [vp]),
         "szl_engine_debug_par_jobs": (ctypes.c_uint32, [vp]),
+        "szl_inflater_debug_bulk_calls": (ctypes.c_uint32, [vp]),
         "szl_debug_stored_layout": (i32, [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]),
         "szl_inflater_create": (vp, [i32]), "szl_inflater_destroy": (None, [vp]), "szl_inflater_reset": (i32, [vp]),
         "szl_inflater_set_input": (i32, [vp, vp, i32]), "szl_inflater_set_dictionary": (i32, [vp, vp, i32]),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -77,6 +78,17 @@ done:
 // input, output too small, no chain) — the caller then runs the ordinary decoder, whose status/partial-output behaviour is
 // the one checked against the reference — or a negative szl_status for device failures.
 struct ParResult { uint64_t out_written, consumed; uint32_t adler_read; };
+// A PIECE of a stream instead of whole members (the streaming Inflater, inflater_bulk below): the single candidate starts at a block
+// header at bit `first_bit` with `win0` (device, 32 KiB, oldest byte first) in front of it, and the input may end anywhere — the jobs
+// of the verified chain up to the last one that ended on a block boundary are delivered, the rest stays for a later call.
+struct ParStream {
+    uint64_t first_bit = 0;
+    const uint8_t *win0 = nullptr;
+    std::function<uint8_t *(uint64_t)> alloc_out;   // device buffer for `total` output bytes (nullptr: give up)
+    uint8_t *win_out = nullptr;                     // [out] device, 32 KiB: what lies in front of `end_bit` afterwards
+    uint64_t end_bit = 0;                           // [out] where the delivered output ends: a block header, or the end of the final block
+    bool finished = false;                          // [out] the final block was among the jobs
+};
 
 // Several members at once: the passes of all of them share their launches and their host round trips (a call with 128
 // members of a few MiB each would otherwise pay ~6 round trips per member, or — through the one-wavefront decoder — run
@@ -88,7 +100,7 @@ struct ParResult { uint64_t out_written, consumed; uint32_t adler_read; };
 // needs repair, sends the member to `retry` (the caller runs those through the two-pass form).
 static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_out, const szl_stream *streams, const std::vector<size_t> &cand,
                                     bool zlib, bool single_pass, hipStream_t st, std::vector<char> &taken, std::vector<ParResult> &res,
-                                    std::vector<size_t> *retry) {
+                                    std::vector<size_t> *retry, ParStream *sm = nullptr) {
     struct Cnt { uint64_t end_bit, out; int status; };
     struct PS {
         size_t si;                       // index into streams
@@ -98,7 +110,8 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         std::vector<Cnt> cnt; std::vector<char> have;
         std::vector<uint64_t> reg;       // single pass: staging region (first symbol) of each job
         uint64_t reg_cap = 0;            //              and its size in symbols
-        bool alive = true, ok = false;
+        bool alive = true, ok = false, truncated = false;
+        uint64_t trunc_bit = 0;          // (piece of a stream) start bit of the dropped last job
         std::vector<uint64_t> ooff, jbase; uint64_t total = 0, end_byte = 0; uint32_t adler_read = 0;
         uint64_t win_off = 0, ooff_off = 0;   // offsets (bytes / elements) into the shared buffers
     };
@@ -131,7 +144,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         p.chunk_bytes = cb;
         if (s.in_len < 8 * cb || s.in_len >= (1ull << 60)) continue;
         p.nchunks = (uint32_t)std::min<uint64_t>((s.in_len + cb - 1) / cb, 1u << 20);
-        p.first_bit = 0; p.start_off = nstart_total; nstart_total += p.nchunks;
+        p.first_bit = sm ? sm->first_bit : 0; p.start_off = nstart_total; nstart_total += p.nchunks;
         ps.push_back(std::move(p));
     }
     if (ps.empty()) return 0;
@@ -241,6 +254,13 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 if (single_pass) nreg.push_back(p.reg[j]);
                 const Cnt &c = p.cnt[j];
                 if (c.status == INF_FINISHED) break;               // the member's last block ended inside this job
+                if (sm && c.status == INF_NEED_INPUT && nsb.size() > 1) {
+                    // a piece of a stream: the input ends inside the last job's blocks — that job is left to a later call
+                    nsb.pop_back(); ncnt.pop_back(); nhave.pop_back();
+                    if (single_pass) nreg.pop_back();
+                    p.truncated = true; p.trunc_bit = p.sb[j];
+                    break;
+                }
                 if (c.status != INF_CHUNK_END) {                   // an error on the chain is a real error of the stream —
                     p.alive = false;                               // or, in the single pass, a staging region that was too small
                     if (single_pass && c.status == INF_OUTPUT_FULL && retry) retry->push_back(p.si);
@@ -274,12 +294,13 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         PS &p = ps[k];
         if (!p.alive || !p.ok) continue;
         const uint32_t nj = (uint32_t)p.sb.size();
-        if (p.cnt[nj - 1].status != INF_FINISHED) continue;        // truncated member: NEED_INPUT semantics belong to the sequential path
+        if (p.cnt[nj - 1].status != INF_FINISHED && !(sm && p.truncated && p.cnt[nj - 1].status == INF_CHUNK_END)) continue;   // truncated member: NEED_INPUT semantics belong to the sequential path
         p.ooff.assign(nj + 1, 0); p.jbase.assign(nj + 1, 0);
         uint64_t total = 0;
         for (uint32_t j = 0; j < nj; j++) { p.ooff[j] = total; total += p.cnt[j].out; }
         p.ooff[nj] = total; p.total = total;
-        if (total > streams[p.si].out_cap) continue;               // SZL_E_OUTPUT_TOO_SMALL with the bytes that fit: sequential path
+        if (!sm && total > streams[p.si].out_cap) continue;        // SZL_E_OUTPUT_TOO_SMALL with the bytes that fit: sequential path
+        if (sm) { d_out = sm->alloc_out ? sm->alloc_out(total) : nullptr; if (!d_out) continue; }
         p.end_byte = (p.cnt[nj - 1].end_bit + 7) >> 3;
         if (zlib && p.end_byte + 4 > streams[p.si].in_len) continue;
         if (single_pass) for (uint32_t j = 0; j < nj; j++) p.jbase[j] = p.reg[j];
@@ -326,7 +347,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     uint64_t nblk = 0;
     for (size_t g = 0; g < good.size(); g++) {
         const PS &p = ps[good[g]];
-        mem[g] = ParMember{p.ooff_off, p.win_off, streams[p.si].out_off, p.total, (uint32_t)p.sb.size(), (uint32_t)nblk};
+        mem[g] = ParMember{p.ooff_off, p.win_off, sm ? 0 : streams[p.si].out_off, p.total, (uint32_t)p.sb.size(), (uint32_t)nblk, sm ? sm->win0 : nullptr};
         nblk += (p.total + 16383) / 16384;
     }
     if (nblk > 0x7FFFFFFFull) return SZL_E_ARG;
@@ -369,6 +390,13 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         const PS &p = ps[k];
         taken[p.si] = 1;
         res[p.si] = ParResult{p.total, p.end_byte, p.adler_read};
+        if (sm) {
+            const uint32_t nj = (uint32_t)p.sb.size();
+            sm->finished = !p.truncated;
+            sm->end_bit = p.truncated ? p.trunc_bit : p.cnt[nj - 1].end_bit;
+            if (sm->win_out) HIPCHK(hipMemcpyAsync(sm->win_out, (const uint8_t *)E.inf_wins.p + p.win_off + (uint64_t)nj * 32768, 32768, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
     }
     E.last_par_jobs += (uint32_t)std::min<uint64_t>(njobs_total, 0xFFFFFFFFull);
     return 0;
@@ -537,6 +565,13 @@ struct szl_inflater {
     static constexpr size_t CTL_HDR = (sizeof(InfJob) + sizeof(InfState) + 63) & ~(size_t)63;
     uint8_t *h_ctl = nullptr, *h_out = nullptr;
     DevBuf d_ctl;
+    // A LONG input (InflaterInputStream with a large buffer, CS/InflaterInputStream.cs:342-396: the size is a constructor argument) goes
+    // to the chunk-parallel decoder: the one-wavefront decoder brings the stream to a block header, then everything up to the last block
+    // boundary in the input is decoded by many wavefronts at once (inflater_bulk) and waits in `pend`.
+    szl_engine *eng = nullptr;
+    DevBuf d_bulk_in, d_bulk_out, d_win_lin;
+    uint64_t bulk_skip_given = 0;  // do not try again before more input than this has been given (the last attempt found no chain)
+    uint32_t bulk_calls = 0;       // (tests / tools: how often the parallel decoder took a piece)
 };
 
 static void inflater_clear(szl_inflater *s) {
@@ -544,6 +579,7 @@ static void inflater_clear(szl_inflater *s) {
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
     s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
+    s->bulk_skip_given = 0;
 }
 
 szl_inflater *szl_inflater_create(int no_header) {
@@ -557,6 +593,8 @@ szl_inflater *szl_inflater_create(int no_header) {
 void szl_inflater_destroy(szl_inflater *s) {
     if (!s) return;
     s->d_in.release(); s->d_out.release(); s->d_win.release(); s->d_job.release(); s->d_state.release(); s->d_ctl.release();
+    s->d_bulk_in.release(); s->d_bulk_out.release(); s->d_win_lin.release();
+    if (s->eng) szl_engine_destroy(s->eng);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
     delete s;
@@ -622,10 +660,101 @@ int szl_inflater_set_dictionary(szl_inflater *s, const uint8_t *p, int n) { // :
     return 0;
 }
 
+// drop the consumed whole dwords of input (an offset into the vector; the vector itself is compacted once half of it is dead);
+// keep bitpos relative to the new base
+static void inflater_drop_consumed(szl_inflater *s) {
+    const size_t nin = s->hin.size() - s->hin_pos;
+    uint64_t drop = (s->st.bitpos >> 3) & ~3ull;
+    if (s->st.mode == INF_M_ZHEADER) drop = 0;
+    if (drop > nin) drop = nin & ~3ull;
+    if (drop) {
+        s->hin_pos += (size_t)drop;
+        s->in_base += drop;
+        s->st.bitpos -= 8 * drop;
+        if (s->hin_pos == s->hin.size()) { s->hin.clear(); s->hin_pos = 0; }
+        else if (s->hin_pos > (1u << 20) && s->hin_pos * 2 > s->hin.size()) { s->hin.erase(s->hin.begin(), s->hin.begin() + (ptrdiff_t)s->hin_pos); s->hin_pos = 0; }
+    }
+}
+
+enum : size_t { BULK_MIN_DEFAULT_KIB = 2048 };
+
+// The chunk-parallel decoder on everything the caller has given and the decoder has not consumed.  The stream stands at a block
+// header (st.mode == INF_M_HEADER, not the last block).  Returns 1 = a piece was decoded into `pend`, 0 = not taken (the caller goes
+// on with the one-wavefront decoder), < 0 = device failure.
+static int inflater_bulk(szl_inflater *s) {
+    int rc;
+    const size_t nin = s->hin.size() - s->hin_pos;
+    if (!s->eng && !(s->eng = szl_engine_create())) return SZL_E_NOMEM;
+    Engine &E = s->eng->e;
+    if ((rc = s->d_bulk_in.ensure(nin + 64)) || (rc = s->d_win_lin.ensure(2 * 32768)) || (rc = s->d_win.ensure(32768))) return rc;
+    HIPCHK(hipMemcpy(s->d_bulk_in.p, s->hin.data() + s->hin_pos, nin, hipMemcpyHostToDevice));
+    // the window the one-wavefront decoder keeps is a ring indexed by output position & 32767; the chunk jobs' windows are linear
+    // (oldest byte first): linear[i] = ring[(outpos + i) & 32767]
+    uint8_t *ring = (uint8_t *)s->d_win.p, *lin = (uint8_t *)s->d_win_lin.p, *lin_out = lin + 32768;
+    const uint32_t r0 = (uint32_t)(s->st.outpos & 32767);
+    if (s->st.outpos == 0 && !s->have_dict) HIPCHK(hipMemset(lin, 0, 32768));
+    else {
+        HIPCHK(hipMemcpy(lin, ring + r0, 32768 - r0, hipMemcpyDeviceToDevice));
+        if (r0) HIPCHK(hipMemcpy(lin + (32768 - r0), ring, r0, hipMemcpyDeviceToDevice));
+    }
+    szl_stream ps{};
+    ps.in_off = 0; ps.in_len = nin; ps.out_off = 0;
+    // staging of the single pass is sized from an expected expansion: what this stream has shown so far, generously (a piece that
+    // overruns it goes through the count-first form below)
+    const uint64_t cons = s->in_base + (s->st.bitpos >> 3);
+    double expand = cons > 65536 ? 1.5 * (double)s->st.outpos / (double)cons : 6.0;
+    if (expand < 4.0) expand = 4.0;
+    if (expand > 64.0) expand = 64.0;
+    ps.out_cap = (uint64_t)(expand * (double)nin);
+    ParStream sm;
+    sm.first_bit = s->st.bitpos; sm.win0 = lin; sm.win_out = lin_out;
+    sm.alloc_out = [&](uint64_t total) -> uint8_t * { return s->d_bulk_out.ensure(total + 64) ? nullptr : (uint8_t *)s->d_bulk_out.p; };
+    std::vector<size_t> cand{0}, retry;
+    std::vector<char> taken(1, 0);
+    std::vector<ParResult> res(1);
+    rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, cand, false, knob("SZL_INF_SINGLE_PASS", 1) != 0, nullptr, taken, res, &retry, &sm);
+    if (rc >= 0 && !taken[0] && !retry.empty()) rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, retry, false, false, nullptr, taken, res, nullptr, &sm);
+    if (rc < 0) return rc;
+    if (!taken[0] || sm.end_bit <= s->st.bitpos) return 0;
+    const uint64_t total = res[0].out_written;
+    // the decoded bytes wait in `pend` (the decoder runs ahead of the caller as in inflater_step)
+    size_t old = s->pend.size();
+    if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
+    s->pend.resize(old + total);
+    if (total) HIPCHK(hipMemcpy(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost));
+    if (!s->no_header && total) {
+        std::vector<std::pair<uint64_t, uint64_t>> regs{{0, total}};
+        std::vector<std::pair<uint32_t, uint32_t>> init{{0u, s->adler_dec}}, out;
+        if ((rc = region_checksums((const uint8_t *)s->d_bulk_out.p, regs, 2u, out, &init, nullptr))) return rc;
+        s->adler_dec = out[0].second;
+    }
+    // the state the one-wavefront decoder continues from: a block header (or, behind the final block, "last block done")
+    s->st.outpos += total;
+    s->st.bitpos = sm.end_bit;
+    s->st.mode = INF_M_HEADER; s->st.last = sm.finished ? 1u : 0u; s->st.stored_left = 0;
+    const uint32_t r1 = (uint32_t)(s->st.outpos & 32767);
+    HIPCHK(hipMemcpy(ring + r1, lin_out, 32768 - r1, hipMemcpyDeviceToDevice));
+    if (r1) HIPCHK(hipMemcpy(ring, lin_out + (32768 - r1), r1, hipMemcpyDeviceToDevice));
+    s->have_dict = true;            // (the window is to be loaded whatever the output position says)
+    s->dec_status = INF_CHUNK_END;  // "running": szl_inflater_inflate goes on with the rest of the input
+    s->bulk_calls++;
+    inflater_drop_consumed(s);
+    return 1;
+}
+
 // Run the decoder once over the input given so far.
 static int inflater_step(szl_inflater *s) {
     int rc;
     const size_t nin = s->hin.size() - s->hin_pos;
+    // a long input: bring the stream to a block header (stop_at_header), then the chunk-parallel decoder
+    const size_t bulk_min = (size_t)std::max(256, knob("SZL_INF_STREAM_BULK_KIB", (int)BULK_MIN_DEFAULT_KIB)) * 1024;
+    const bool bulk = nin >= bulk_min && s->given > s->bulk_skip_given && !s->err && s->dec_status != INF_NEED_DICT && knob("SZL_INF_STREAM_BULK", 1) != 0;
+    if (bulk && s->st.mode == INF_M_HEADER && !s->st.last && s->dec_status == INF_CHUNK_END) {
+        rc = inflater_bulk(s);
+        if (rc < 0) return rc;
+        if (rc == 1) return 0;
+        s->bulk_skip_given = s->given;     // no chain in this input (static / stored blocks only, an error ahead, ...): the ordinary decoder
+    }
     if ((rc = s->d_ctl.ensure(szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64)) || (rc = s->d_out.ensure(szl_inflater::OUT_CHUNK + 64)) ||
         (rc = s->d_win.ensure(32768))) return rc;
     if (!s->h_ctl && hipHostMalloc((void **)&s->h_ctl, szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
@@ -636,6 +765,7 @@ static int inflater_step(szl_inflater *s) {
     InfJob j{};
     j.in_off = 0; j.in_len = nup; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
     j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1; j.load_window = s->have_dict ? 1 : 0;
+    j.stop_at_header = bulk && s->given > s->bulk_skip_given && !(s->st.mode == INF_M_HEADER && s->dec_status == INF_CHUNK_END) ? 1u : 0u;
     InfJob *hj = (InfJob *)s->h_ctl; InfState *hs = (InfState *)(s->h_ctl + sizeof(InfJob));
     uint8_t *dctl = (uint8_t *)s->d_ctl.p;
     *hj = j; *hs = s->st;
@@ -668,20 +798,11 @@ static int inflater_step(szl_inflater *s) {
     }
     if (s->err) return 0;
     if (s->dec_status == INF_FINISHED && !s->no_header && s->st.adler_read != s->adler_dec) { s->err = SZL_E_ADLER_MISMATCH; return 0; }
-    // drop the consumed whole dwords of input (an offset into the vector; the vector itself is compacted once half of it is dead);
-    // keep bitpos relative to the new base
-    uint64_t drop = (s->st.bitpos >> 3) & ~3ull;
-    if (s->st.mode == INF_M_ZHEADER) drop = 0;
-    if (drop > nin) drop = nin & ~3ull;
-    if (drop) {
-        s->hin_pos += (size_t)drop;
-        s->in_base += drop;
-        s->st.bitpos -= 8 * drop;
-        if (s->hin_pos == s->hin.size()) { s->hin.clear(); s->hin_pos = 0; }
-        else if (s->hin_pos > (1u << 20) && s->hin_pos * 2 > s->hin.size()) { s->hin.erase(s->hin.begin(), s->hin.begin() + (ptrdiff_t)s->hin_pos); s->hin_pos = 0; }
-    }
+    inflater_drop_consumed(s);
     return 0;
 }
+
+uint32_t szl_inflater_debug_bulk_calls(const szl_inflater *s) { return s ? s->bulk_calls : 0; }
 
 int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count) { // :715
     if (!s || count < 0 || (!out && count)) return SZL_E_ARG;

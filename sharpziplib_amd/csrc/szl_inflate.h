@@ -33,7 +33,8 @@ struct InfJob {
     int32_t status;
     uint32_t dbg_par;     // [out] rounds decoded by the whole wavefront (the rest: lane 0's careful path, headers, restaging)
     uint32_t dbg_partok;  // [out] tokens of those rounds
-    uint32_t pad;
+    uint32_t stop_at_header; // 1: stop with INF_CHUNK_END as soon as the decoder stands at a block header (the streaming object brings the
+                             // stream to a block boundary before it hands a long input to the chunk-parallel decoder)
 };
 
 struct InfState {
@@ -53,6 +54,8 @@ struct ParMember {                                               // one member b
     uint64_t total;     // output bytes
     uint32_t njobs;
     uint32_t blk0;      // first workgroup of k_convert that belongs to it
+    const uint8_t *win0; // the 32 KiB of output in front of its first job, oldest byte first (nullptr: zeros — a member's start).  Set when a
+                         // streaming Inflater hands the decoder a long piece of input in mid-stream (szl_api_inflate.hip, inflater_bulk)
 };
 
 // k_resolve_*: the jobs of a member in groups of RES_GROUP consecutive ones (a member of thousands of chunks is not resolved

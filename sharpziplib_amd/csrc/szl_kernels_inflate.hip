@@ -616,6 +616,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
                 // ---------------- INF_M_HEADER
                 if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
                 if (PMODE && bitpos >= job.stop_bit) { ev = EV_STOP; ea = INF_CHUNK_END; break; } // the next chunk's block starts here
+                if (PMODE == 0 && job.stop_at_header) { ev = EV_STOP; ea = INF_CHUNK_END; break; } // (streaming object: a block boundary was asked for)
                 if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                 const uint32_t t = (uint32_t)bb & 7;
                 const uint32_t type = t >> 1;

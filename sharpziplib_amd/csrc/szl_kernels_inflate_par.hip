@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_resolve_rel(const uint16_t *__restrict
     const uint64_t *out_off = ooff_all + m.ooff_off;
     const uint64_t *jbase = jbase_all + m.ooff_off;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 32768; i += 1024) wa[i] = g.first ? (uint16_t)0 : (uint16_t)(0x8000u | (uint32_t)i);
+    for (int i = tid; i < 32768; i += 1024) wa[i] = g.first ? (uint16_t)(m.win0 ? m.win0[i] : 0) : (uint16_t)(0x8000u | (uint32_t)i);
     __syncthreads();
     int cur = 0;
     for (uint32_t j = g.j0; j < g.j1; j++) {
@@ -217,11 +217,12 @@ __global__ __launch_bounds__(1024) void k_resolve_rel(const uint16_t *__restrict
 
 // grid = members; groups of member blockIdx.x = [gfirst[b], gfirst[b + 1]); ewins[slot] = entry window of the group
 __global__ __launch_bounds__(1024) void k_resolve_chain(const ResGroup *__restrict__ groups, const uint32_t *__restrict__ gfirst,
-                                                        const uint16_t *__restrict__ gmaps, uint8_t *__restrict__ ewins) {
+                                                        const uint16_t *__restrict__ gmaps, uint8_t *__restrict__ ewins, const ParMember *__restrict__ mem) {
     __shared__ __attribute__((aligned(16))) uint8_t s_e[2][32768];
     const uint32_t g0 = gfirst[blockIdx.x], g1 = gfirst[blockIdx.x + 1];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 32768; i += 1024) s_e[0][i] = 0;
+    const uint8_t *win0 = mem[blockIdx.x].win0;    // what lies in front of the member's first job (a member's start: zeros)
+    for (int i = tid; i < 32768; i += 1024) s_e[0][i] = win0 ? win0[i] : (uint8_t)0;
     __syncthreads();
     int cur = 0;
     for (uint32_t g = g0; g < g1; g++) {
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
         const uint4 *e4 = (const uint4 *)(ewins + g.slot * 32768);
         uint4 *w4 = (uint4 *)s_w[0];
         w4[tid] = e4[tid]; w4[tid + 1024] = e4[tid + 1024];
-    } else for (int i = tid; i < 32768; i += 1024) s_w[0][i] = 0;
-    if (g.first) for (int i = tid; i < 32768; i += 1024) wins[i] = 0;
+    } else for (int i = tid; i < 32768; i += 1024) s_w[0][i] = m.win0 ? m.win0[i] : (uint8_t)0;
+    if (g.first) for (int i = tid; i < 32768; i += 1024) wins[i] = m.win0 ? m.win0[i] : (uint8_t)0;
     __syncthreads();
     int cur = 0;
     for (uint32_t j = g.j0; j < g.j1; j++) {
@@ -320,7 +321,7 @@ int launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_
             attr_mask.fetch_or(bit, std::memory_order_acq_rel);
         }
         hipLaunchKernelGGL(k_resolve_rel, dim3(ngroups), dim3(1024), 131072, st, sym, ooff, jbase, mem, groups, gmaps);
-        hipLaunchKernelGGL(k_resolve_chain, dim3(nmem), dim3(1024), 0, st, groups, gfirst, (const uint16_t *)gmaps, ewins);
+        hipLaunchKernelGGL(k_resolve_chain, dim3(nmem), dim3(1024), 0, st, groups, gfirst, (const uint16_t *)gmaps, ewins, mem);
     }
     hipLaunchKernelGGL(k_resolve_wins, dim3(ngroups), dim3(1024), 0, st, sym, ooff, jbase, wins, mem, groups, chained ? (const uint8_t *)ewins : nullptr);
     return 0;

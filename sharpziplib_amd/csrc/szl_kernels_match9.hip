@@ -90,7 +90,7 @@ __device__ __forceinline__ void b9_stage_window(uint8_t *smem, const uint8_t *d,
 template <bool DBG>
 __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs, const TileDev *__restrict__ tiles,
                                                        const uint16_t *__restrict__ link, MTab mtab, LevelParams P, unsigned long long *dbg,
-                                                       int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1) {
+                                                       int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1, int vtht1) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const TileDev tile = tiles[blockIdx.x];
     const SegDev seg = segs[tile.seg];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     auto sgpr64 = [](uint64_t x) { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32); };
     const int tlen_s = sgpr(tlen), slice_s = sgpr(slice), rem0_s = sgpr(rem0), sw_s = sgpr(sw), bmlo_s = sgpr(bmlo), bmhi_s = sgpr(bmhi), nicel_s = sgpr(nicel),
               chainm2_s = sgpr(chainm2), snapm1_s = sgpr(snapm1), vtht_s = sgpr(vtht), ktail_s = sgpr(ktail), qkeept_s = sgpr(128),
-              tailp_s = sgpr(tailp), mth_s = sgpr(mth), ktail1_s = sgpr(ktail1), wscr_s = sgpr(B9_SCR + (int)(threadIdx.x & ~63u));
+              tailp_s = sgpr(tailp), mth_s = sgpr(mth), ktail1_s = sgpr(ktail1), vtht1_s = sgpr(vtht1), wscr_s = sgpr(B9_SCR + (int)(threadIdx.x & ~63u));
     const uint64_t stratm_s = sgpr64(stratm), mt2b_s = sgpr64((uint64_t)(uintptr_t)mt2b), mtqb_s = sgpr64((uint64_t)(uintptr_t)mtqb);
     uint32_t vzero, vslice;   // (constants in VGPRs: 0 and the slice length; the text sets them)
 #define SZL9_CTXV(X) uint32_t pl##X = 0, cb##X = 0, kk##X = 0, mincb##X = 0, left##X = 0, pb##X = 0, best##X = 2, off##X = 0, cap##X = MAX_MATCH, \
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
                  : [tlen] "s"(tlen_s), [slice] "s"(slice_s), [rem0] "s"(rem0_s), [sw] "s"(sw_s), [bmlo] "s"(bmlo_s),
                    [bmhi] "s"(bmhi_s), [nicel] "s"(nicel_s), [chainm2] "s"(chainm2_s), [snapm1] "s"(snapm1_s), [qkeept] "s"(qkeept_s), [vtht] "s"(vtht_s),
                    [ktail] "s"(ktail_s), [stratm] "s"(stratm_s), [mt2b] "s"(mt2b_s), [mtqb] "s"(mtqb_s),
-                   [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s)
+                   [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s), [vtht1] "s"(vtht1_s)
                  : "vcc", "scc", "memory");
     if (DBG) {
         const unsigned long long t_end = wall_clock64();
@@ -184,8 +184,8 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     int fth = knob("SZL9_FTH", 24), vth = knob("SZL9_VTH", 2), qkeep = knob("SZL9_QKEEP", 64), ktail = knob("SZL9_KTAIL", 2), vtht = knob("SZL9_VTHT", 1);
     // the tail program (szl_match9_asm.h): 0 = the main loop to the end (laboratory); walks of both contexts move into one once they are
     // at most `mth` (<= 64; -1: never); iterations of the one-context walk between two looks at who left
-    int tailp = knob("SZL9_TAILP", 1), mth = knob("SZL9_MTH", 64), ktail1 = knob("SZL9_KTAIL1", 2);
-    mth = mth > 64 ? 64 : mth; ktail1 = ktail1 < 1 ? 1 : ktail1;
+    int tailp = knob("SZL9_TAILP", 1), mth = knob("SZL9_MTH", 64), ktail1 = knob("SZL9_KTAIL1", 1), vtht1 = knob("SZL9_VTHT1", 1);
+    mth = mth > 64 ? 64 : mth; ktail1 = ktail1 < 1 ? 1 : ktail1; vtht1 = vtht1 < 1 ? 1 : vtht1;
     int slice = knob("SZL_SLICE", 128);
     fth = fth < 1 ? 1 : (fth > 64 ? 64 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; ktail = ktail < 1 ? 1 : ktail; vtht = vtht < 1 ? 1 : vtht;
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
@@ -197,8 +197,8 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     }
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B9_THREADS);
-        if (want_dbg) hipLaunchKernelGGL((k_match9<true>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1);
-        else hipLaunchKernelGGL((k_match9<false>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1);
+        if (want_dbg) hipLaunchKernelGGL((k_match9<true>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1);
+        else hipLaunchKernelGGL((k_match9<false>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1);
     }
     return hipGetLastError();
 }

@@ -555,7 +555,7 @@
     "s_cmp_eq_u32 %[n0], 0\n\t" \
     "s_cbranch_scc1 98f\n\t" \
     "s_bcnt1_i32_b64 %[n2], %[vA]\n\t" \
-    "s_cmp_ge_u32 %[n2], %[vtht]\n\t" \
+    "s_cmp_ge_u32 %[n2], %[vtht1]\n\t" \
     "s_cbranch_scc1 64f\n\t" \
     "s_cmp_eq_u64 %[qA], 0\n\t" \
     "s_cbranch_scc1 64f\n\t" \

@@ -5,7 +5,7 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from sharpziplib_amd import corpus
+from sharpziplib_amd import corpus, _lib
 from sharpziplib_amd.deflater import Deflater
 from sharpziplib_amd.batch import Engine
 
@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--entries", type=int, default=2000)
 ap.add_argument("--kib", type=int, default=64)
 ap.add_argument("--level", type=int, default=6)
-ap.add_argument("--inflate-mib", type=int, default=32)
+ap.add_argument("--inflate-mib", type=int, default=256)
 a = ap.parse_args()
 n = a.kib << 10
 data = corpus.generate("enwik", 5, 0, n * a.entries)
@@ -58,18 +58,31 @@ from sharpziplib_amd.streams import InflaterInputStream
 m = a.inflate_mib << 20
 plain = corpus.generate("enwik", 6, 0, m)
 comp = Engine().deflate([plain], level=6)[0].data
-for bufsz, readsz in ((4096, 4096), (65536, 65536), (65536, 1 << 20)):
-    src = io.BytesIO(comp)
-    st = InflaterInputStream(src, Inflater(True), bufsz)
-    out = bytearray(readsz)
-    t0 = time.perf_counter()
-    got = 0
-    h = 0
-    while True:
-        k = st.Read(out, 0, readsz)
-        if k <= 0:
-            break
-        got += k
-    dt = time.perf_counter() - t0
-    assert got == m
-    print("InflaterInputStream, %d B input buffer, Read(%d): %.1f MiB/s of output (%d MiB member)" % (bufsz, readsz, m / 2 ** 20 / dt, a.inflate_mib), flush=True)
+import hashlib
+want = hashlib.sha256(plain.tobytes()).hexdigest()
+L = _lib.lib()
+for bufsz, readsz in ((4096, 4096), (65536, 65536), (1 << 20, 1 << 20), (16 << 20, 4 << 20), (64 << 20, 4 << 20)):
+    best = 0.0
+    for rep in range(2):
+        src = io.BytesIO(comp)
+        inf = Inflater(True)
+        st = InflaterInputStream(src, inf, bufsz)
+        out = np.zeros(readsz, np.uint8)
+        h = hashlib.sha256() if rep == 0 else None
+        t0 = time.perf_counter()
+        got = 0
+        while True:
+            k = st.Read(out, 0, readsz)
+            if k <= 0:
+                break
+            got += k
+            if h:
+                h.update(out[:k].tobytes())
+        dt = time.perf_counter() - t0
+        assert got == m and inf.RemainingInput == 0 and inf.TotalIn == len(comp)
+        if h:
+            assert h.hexdigest() == want
+        else:
+            best = m / 2 ** 20 / dt
+    print("InflaterInputStream, %8d B input buffer, Read(%7d): %8.1f MiB/s of output (%d MiB member; %d pieces through the chunk-parallel decoder)" % (
+        bufsz, readsz, best, a.inflate_mib, L.szl_inflater_debug_bulk_calls(inf._h)), flush=True)

@@ -112,7 +112,7 @@ def main():
                  wnext=0, wend=0, exh=0, tlen=tlen, slice=a.slice, rem0=K["rem0"], sw=K["sw"] & W.M32, bmlo=K["bmlo"], bmhi=K["bmhi"],
                  nicel=P.nice, chainm2=(P.max_chain - 2) & W.M32, snapm1=(P.max_chain - (P.max_chain >> 2) - 1) & W.M32, bexit=64 - a.fth, vth=a.vth, wth=a.wth,
                  wkeep=a.wkeep, qkeep=a.qkeep, qkeept=a.qkeept, vtht=a.vtht, ktail=a.ktail, kt=0, texh=0, stratm=0 if a.strategy == 2 else M64, mt2b=0, mtqb=0,
-                 tailp=a.tailp, mth=a.mth & W.M32, ktail1=a.ktail1, wscr=162368 + 64 * w)
+                 tailp=a.tailp, mth=a.mth & W.M32, ktail1=a.ktail1, vtht1=1, wscr=162368 + 64 * w)
         waves.append(W.Wave(prog, lds, v, s, {"mt2b": mt2, "mtqb": mtq}))
         waves[-1].tail_flag = None if a.notail else "exh"
     t = time.time()
