@@ -160,6 +160,12 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
  * (a second caller waits for the first). */
 int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  int level, int strategy, unsigned flags);
+/* ONE stream over several devices with the input ALREADY RESIDENT: d_in[g] = the input arena in the memory of devices[g] (the caller
+ * uploaded the stream to every device once), d_out0 = the output arena on devices[0] (stream->out_off / out_cap inside it).  The same
+ * position-range units, hand-over check and token gather as szl_deflate_batch_multi_host's one-stream path — without its host
+ * buffers, i.e. without PCIe in the call (bench.py --mode strong times this).  Levels 5-9; same bytes as one engine. */
+int szl_deflate_stream_multi_device(const int *devices, int n_dev, const void *const *d_in, void *d_out0, szl_stream *stream,
+                                    int level, int strategy, unsigned flags);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  unsigned flags);
 
@@ -171,6 +177,9 @@ typedef struct szl_timing {
     float inflate_ms;   /* last szl_inflate_batch_* call: k_inflate time (HIP events) */
     float pilot_ms;     /* stage-B pilot (sample of tiles + read-back) when SZL_MATCH_MODE = 2 asks for one (the default is the full search
                            without a pilot since round 3); in total_ms, not in match_ms */
+    uint32_t links_guard_trips; /* times (this process) stage A's ticket form was caught storing a link out of order — by the check every
+                                   exchange carries or by the sampled first-principles guard — and the call was run again with the form that
+                                   needs no ordering assumption.  0 on every device seen so far; not silent if it ever is not */
 } szl_timing;
 int szl_engine_last_timing(const szl_engine *e, szl_timing *t);
 

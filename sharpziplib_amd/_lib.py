@@ -21,7 +21,7 @@ class Stream(ctypes.Structure):
 class Timing(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "checksum_ms", "links_ms", "match_ms", "parse_ms", "blocks_ms", "encode_ms")] + \
                [(n, ctypes.c_uint64) for n in ("in_bytes", "out_bytes", "tokens", "blocks", "ranges_unmerged", "fallback_walks")] + \
-               [("inflate_ms", ctypes.c_float), ("pilot_ms", ctypes.c_float)]
+               [("inflate_ms", ctypes.c_float), ("pilot_ms", ctypes.c_float), ("links_guard_trips", ctypes.c_uint32)]
 
 
 F_NOWRAP, F_CRC32, F_ADLER32, F_SYNC_FLUSH_BEFORE_FINISH, F_GZIP = 1, 2, 4, 8, 16

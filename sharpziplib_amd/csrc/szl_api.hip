@@ -16,6 +16,7 @@
 
 using namespace szl;
 
+namespace szl { uint32_t links_guard_trips(); }
 struct szl_engine { Engine e; };
 
 static thread_local int g_device = 0;
@@ -80,6 +81,7 @@ void szl_engine_destroy(szl_engine *e) { delete e; }
 int szl_engine_last_timing(const szl_engine *e, szl_timing *t) {
     if (!e || !t) return SZL_E_ARG;
     *t = e->e.timing;
+    t->links_guard_trips = szl::links_guard_trips();
     return 0;
 }
 
@@ -402,7 +404,10 @@ static int multi_run(bool inflate, const int *devices, int n_dev, const void *h_
 //     reach each other, through a host buffer otherwise).  Stage D — block positions from the tokens' own lengths, Huffman trees,
 //     bit packing, checksums, framing — then runs there once.
 // Same bytes as one engine produces (tests/test_gpu_multi.py: several engines on one or more devices against it and the oracle).
-static int stream_multi_run(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *stream, int level, int strategy, unsigned flags) {
+// d_res != nullptr: the stream is RESIDENT — d_res[g] is the input arena in the memory of devices[g] (the caller uploaded it once),
+// d_out_res the output arena on devices[0]; nothing travels between host and devices but the result fields.
+static int stream_multi_run(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *stream, int level, int strategy, unsigned flags,
+                            const void *const *d_res = nullptr, void *d_out_res = nullptr) {
     LevelParams P;
     int rc = level_params(level, strategy, &P);
     if (rc) return rc;
@@ -410,7 +415,8 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     if ((rc = build_batch(stream, 1, flags, level, segs, bnds_unused, &in_total0, &out_total0))) return rc;
     const SegDev whole = segs[0];                       // buf_off = in_off, seg [0, N)
     const int64_t N = (int64_t)stream->in_len;
-    const uint8_t *src = (const uint8_t *)h_in + stream->in_off;
+    const uint8_t *src = d_res ? nullptr : (const uint8_t *)h_in + stream->in_off;
+    auto resident = [&](int g) -> const uint8_t * { return (const uint8_t *)d_res[g] + stream->in_off; };
     const uint64_t window = std::max<uint64_t>((uint64_t)szl::knob("SZL_WINDOW_KIB", 256 * 1024) * 1024 / B_TILE * B_TILE, B_TILE);
     const int64_t WARM = (int64_t)std::max(64, szl::knob("SZL_PART_WARM_KIB", 256)) * 1024;
     const int64_t LOOK = C_WIN_HALO + 1024 + MAX_MATCH + 64;      // bytes a unit sees beyond its end (halo of the last window + hand-over slack)
@@ -444,10 +450,11 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
         const int64_t b1 = g == 0 ? N : std::min<int64_t>(N, pend + LOOK);
         const uint64_t nb = (uint64_t)(b1 - b0);
         int r;
-        if (g != 0) {
+        if (g != 0 && !d_res) {
             if ((r = E.stage_in.ensure(nb + 64))) { o.rc = r; o.err = last_error(); return; }
             if (nb && hipMemcpy(E.stage_in.p, src + b0, nb, hipMemcpyHostToDevice) != hipSuccess) { o.rc = SZL_E_DEVICE; o.err = "H2D failed"; return; }
         }
+        const uint8_t *unit_in = d_res ? resident(g) + b0 : (const uint8_t *)E.stage_in.p;   // (engine 0: b0 == 0, the whole stream)
         SegDev sg{};
         sg.buf_off = 0; sg.abs0 = (uint64_t)b0;               // window bases follow the absolute position (C/DeflaterEngine.cs:371,:771)
         sg.seg_start = (u == 0 ? 0 : (warm_from >= 0 ? warm_from : first)) - b0; sg.seg_end = b1 - b0;
@@ -462,7 +469,7 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
         E.part.force_entry = force_entry >= 0 ? force_entry - b0 : -1;
         if (E.part.force_entry >= 0) sg.seg_start = std::min<int64_t>(sg.seg_start, E.part.force_entry);
         std::vector<SegOut> res;
-        r = E.deflate_windowed((const uint8_t *)E.stage_in.p, nb, nullptr, 0, sg, bnds, P, 0, res, nullptr, window);
+        r = E.deflate_windowed(unit_in, nb, nullptr, 0, sg, bnds, P, 0, res, nullptr, window);
         const Engine::PartRun pr = E.part;
         E.part = Engine::PartRun{};
         if (r == SZL_E_STATE && force_entry < 0 && u != 0) { o.entry = -1; o.exit = -1; o.ntok = 0; return; }   // the warm-up found no clean hand-over: decided in the chain below
@@ -475,13 +482,13 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
         }
     };
     auto worker = [&](int g) {
-        auto fail = [&](int r, const std::string &e) { slot_rc[g] = r; slot_err[g] = e; std::lock_guard<std::mutex> lk(mu); cv.notify_all(); };
+        auto fail = [&](int r, const std::string &e) { std::lock_guard<std::mutex> lk(mu); slot_err[g] = e; slot_rc[g] = r; cv.notify_all(); };   // (published under the mutex the waiter reads them with)
         if (hipSetDevice(devices[g]) != hipSuccess) { fail(SZL_E_DEVICE, "hipSetDevice failed"); return; }
         MultiSlot &slot = g_multi_slots[g];
         if (slot.eng && slot.device != devices[g]) { szl_engine_destroy(slot.eng); slot.eng = nullptr; }
         if (!slot.eng) { slot.eng = szl_engine_create(); slot.device = devices[g]; }
         if (!slot.eng) { fail(SZL_E_DEVICE, last_error()); return; }
-        if (g == 0) {   // engine 0 holds the whole stream
+        if (g == 0 && !d_res) {   // engine 0 holds the whole stream
             Engine &E = slot.eng->e;
             int r = E.stage_in.ensure((uint64_t)N + 64);
             if (r) { fail(r, last_error()); return; }
@@ -569,18 +576,30 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     E0.tokens = nt;                                      // (DevBuf is a plain pointer + capacity; E0 owns it from here)
     SegDev fin = whole;
     fin.buf_off = 0;                                     // engine 0's copy of the stream starts at its buffer's first byte
-    if ((rc = E0.stage_out.ensure(stream->out_cap + 64))) return rc;
+    if (!d_out_res && (rc = E0.stage_out.ensure(stream->out_cap + 64))) return rc;
     fin.out_off = 0;
+    uint8_t *fin_out = d_out_res ? (uint8_t *)d_out_res + stream->out_off : (uint8_t *)E0.stage_out.p;
     std::vector<SegOut> res;
     const unsigned want = ((flags & (SZL_F_CRC32 | SZL_F_GZIP)) ? 1u : 0u) | (((flags & SZL_F_ADLER32) || !(flags & (SZL_F_NOWRAP | SZL_F_GZIP))) ? 2u : 0u);
-    rc = E0.finish_tokens((const uint8_t *)E0.stage_in.p, (uint64_t)N, (uint8_t *)E0.stage_out.p, fin, ntok, want, res, nullptr);
+    rc = E0.finish_tokens(d_res ? resident(0) : (const uint8_t *)E0.stage_in.p, (uint64_t)N, fin_out, fin, ntok, want, res, nullptr);
     if (rc) { (void)hipSetDevice(g_device); return rc; }
     stream->out_len = res[0].out_bytes; stream->crc32 = res[0].crc32; stream->adler32 = res[0].adler32;
     stream->status = res[0].out_bytes <= stream->out_cap ? 0 : SZL_E_OUTPUT_TOO_SMALL;
-    if (stream->status == 0 && stream->out_len &&
+    if (!d_out_res && stream->status == 0 && stream->out_len &&
         hipMemcpy((uint8_t *)h_out + stream->out_off, E0.stage_out.p, stream->out_len, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(g_device); set_error("D2H failed"); return SZL_E_DEVICE; }
     (void)hipSetDevice(g_device);
     return 0;
+}
+
+int szl_deflate_stream_multi_device(const int *devices, int n_dev, const void *const *d_in, void *d_out0, szl_stream *stream, int level, int strategy, unsigned flags) {
+    if (!devices || n_dev < 1 || !d_in || !d_out0 || !stream) return SZL_E_ARG;
+    const int lv = level == -1 ? 6 : level;
+    if (lv < 5 || lv > 9 || strategy < 0 || strategy > 2) { set_error("one stream over several devices: levels 5-9 (DeflateSlow) only"); return SZL_E_UNSUPPORTED; }
+    int ndev_avail = 0;
+    if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
+    for (int g = 0; g < n_dev; g++) if (devices[g] < 0 || devices[g] >= ndev_avail || !d_in[g]) { set_error("device ordinal %d out of range / no input for it", devices[g]); return SZL_E_ARG; }
+    if (stream->in_len < (uint64_t)B_TILE * 4 * (uint64_t)n_dev) { set_error("the stream is too short to be cut into units for %d devices", n_dev); return SZL_E_ARG; }
+    return stream_multi_run(devices, n_dev, nullptr, nullptr, stream, lv, strategy, flags, d_in, d_out0);
 }
 
 int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
@@ -945,7 +964,10 @@ static int run_segment_stored(szl_deflater *d, bool finish) {
     d->chunks.clear(); d->chunks_drained = 0; d->chunk_base = 0;
     int rc = stored_emit(d, blks, fed_now, finish);
     if (rc) return rc;
-    advance_history(d, d->pend.size(), nullptr, false);   // stored bytes are in the window, but in no hash chain
+    if (finish) {   // the stream is over: no history to keep (only Reset() makes the object usable again) — as run_segment does for the coded levels
+        d->hist.clear(); d->hist_flags.clear(); d->hist_has_gaps = false; d->bounds.clear(); d->pend.clear();
+        d->hist_abs = (uint64_t)d->total_in + d->l0_dict;
+    } else advance_history(d, d->pend.size(), nullptr, false);   // stored bytes are in the window, but in no hash chain
     d->engine_seen = d->total_in;
     return 0;
 }

@@ -16,6 +16,7 @@ using namespace szl;
 
 namespace szl {
 void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, bool one_shot, hipStream_t st);
+void launch_inflate_exact(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, ExState *exs, const uint32_t *which, uint32_t n, hipStream_t st);
 void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
@@ -216,7 +217,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             const PS &p = ps[which[q].k]; const uint32_t j = which[q].j;
             InfJob &jb = jobs[q];
             jb.in_off = streams[p.si].in_off; jb.in_len = streams[p.si].in_len;
-            jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : ~0ull;
+            jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : (p.truncated ? p.trunc_bit : ~0ull);   // (a piece of a stream: the dropped job's start)
             if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.reg_cap; }
             else { jb.sym_out = pass == 2 ? sym + p.jbase[j] : nullptr; jb.out_cap = ~0ull >> 2; }
         }
@@ -402,6 +403,49 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     return 0;
 }
 
+
+// A one-shot job that k_inflate left in front of a block for the exact decoder (INF_EXACT): k_inflate_exact takes the stream from the
+// block's header, hands it back at the first block header at which the reference's bit buffer holds nothing but stream bits again
+// (INF_CHUNK_END), k_inflate (long-window form: the history travels in a 32 KiB ring, as in the streaming object) goes on — until a
+// status that ends the job.  `j` / `stt`: the job and state as the first launch left them; updated to the final result.
+static int exact_continue(const uint8_t *d_in, uint8_t *d_out, InfJob &j, InfState &stt, hipStream_t st) {
+    DevBuf dj, ds, dex, dwin, dwhich;
+    int rc;
+    auto done = [&](int r) { dj.release(); ds.release(); dex.release(); dwin.release(); dwhich.release(); return r; };
+    if ((rc = dj.ensure(sizeof(InfJob))) || (rc = ds.ensure(sizeof(InfState))) || (rc = dex.ensure(sizeof(ExState))) || (rc = dwin.ensure(32768)) || (rc = dwhich.ensure(64))) return done(rc);
+    const uint64_t region_off = j.out_off, region_cap = j.out_cap;
+    // the ring the continuation decodes with: position p lives at p & 32767
+    uint8_t *ring = (uint8_t *)dwin.p;
+    if (hipMemsetAsync(ring, 0, 32768, st) != hipSuccess || hipMemsetAsync(dwhich.p, 0, 64, st) != hipSuccess) return done(SZL_E_DEVICE);
+    {
+        const uint64_t hi = stt.outpos, lo = hi > 32768 ? hi - 32768 : 0;
+        uint64_t p = lo;
+        while (p < hi) {
+            const uint64_t r = p & 32767, nb = std::min<uint64_t>(hi - p, 32768 - r);
+            if (hipMemcpyAsync(ring + r, d_out + region_off + p, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) return done(SZL_E_DEVICE);
+            p += nb;
+        }
+    }
+    bool exact = true, fresh = true;
+    for (int iter = 0; iter < 100000; iter++) {
+        InfJob c = j;
+        c.out_off = region_off + stt.outpos; c.out_cap = region_cap > stt.outpos ? region_cap - stt.outpos : 0;
+        c.window = ring; c.keep_window = 1; c.load_window = 1; c.stop_at_header = 0;
+        if (fresh && hipMemsetAsync(dex.p, 0, sizeof(ExState), st) != hipSuccess) return done(SZL_E_DEVICE);
+        fresh = false;
+        if (hipMemcpyAsync(dj.p, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(ds.p, &stt, sizeof(stt), hipMemcpyHostToDevice, st) != hipSuccess) return done(SZL_E_DEVICE);
+        if (exact) launch_inflate_exact(d_in, d_out, (InfJob *)dj.p, (InfState *)ds.p, (ExState *)dex.p, (const uint32_t *)dwhich.p, 1, st);
+        else launch_inflate(d_in, d_out, (InfJob *)dj.p, (InfState *)ds.p, 1, false, st);
+        if (hipMemcpyAsync(&c, dj.p, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&stt, ds.p, sizeof(stt), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { set_error("exact inflate: kernel / copy failed: %s", hipGetErrorString(hipGetLastError())); return done(SZL_E_DEVICE); }
+        j.status = c.status; j.consumed = c.consumed; j.end_bit = c.end_bit; j.out_written = stt.outpos;
+        if (c.status == INF_EXACT) { if (!exact) { exact = true; fresh = true; } continue; }      // (from k_inflate: another such block; from the exact decoder: its launch budget)
+        if (c.status == INF_CHUNK_END && exact) { exact = false; continue; }                       // clean again at a block header
+        break;
+    }
+    return done(0);
+}
+
 extern "C" {
 
 int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_stream *streams, size_t n_all, unsigned flags, void *hip_stream) {
@@ -478,6 +522,9 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
             hipStreamSynchronize(st) != hipSuccess) { cleanup(); set_error("inflate kernel/D2H failed: %s", hipGetErrorString(hipGetLastError())); return SZL_E_DEVICE; }
         cleanup();
         float ms = 0; (void)hipEventElapsedTime(&ms, e->e.ev[0], e->e.ev[1]); e->e.timing.inflate_ms += ms;
+        // streams that stopped in front of a block k_inflate leaves to the exact decoder (corrupt input: rare, one at a time)
+        for (size_t k = 0; k < n; k++)
+            if (jobs[k].status == INF_EXACT && (rc = exact_continue((const uint8_t *)d_in, (uint8_t *)d_out, jobs[k], states[k], st))) return rc;
         if (knob("SZL_DEBUG", 0)) { uint64_t r = 0, p = 0, t = 0, ob = 0; for (auto &j : jobs) { r += j.dbg_rounds; p += j.dbg_par; t += j.dbg_partok; ob += j.out_written; }
             fprintf(stderr, "[szl] inflate: rounds %llu parallel %llu tokens in parallel rounds %llu out bytes %llu\n", (unsigned long long)r, (unsigned long long)p, (unsigned long long)t, (unsigned long long)ob); }
     }
@@ -570,6 +617,8 @@ struct szl_inflater {
     // boundary in the input is decoded by many wavefronts at once (inflater_bulk) and waits in `pend`.
     szl_engine *eng = nullptr;
     DevBuf d_bulk_in, d_bulk_out, d_win_lin;
+    DevBuf d_ex;                   // k_inflate_exact's state ([ExState | which]) once the stream has met a block that needs it
+    bool exact_live = false;       // the exact decoder holds the stream (until it hands it back at a clean block header)
     uint64_t bulk_skip_given = 0;  // do not try again before more input than this has been given (the last attempt found no chain)
     uint32_t bulk_calls = 0;       // (tests / tools: how often the parallel decoder took a piece)
 };
@@ -579,7 +628,7 @@ static void inflater_clear(szl_inflater *s) {
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
     s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
-    s->bulk_skip_given = 0;
+    s->bulk_skip_given = 0; s->exact_live = false;
 }
 
 szl_inflater *szl_inflater_create(int no_header) {
@@ -593,7 +642,7 @@ szl_inflater *szl_inflater_create(int no_header) {
 void szl_inflater_destroy(szl_inflater *s) {
     if (!s) return;
     s->d_in.release(); s->d_out.release(); s->d_win.release(); s->d_job.release(); s->d_state.release(); s->d_ctl.release();
-    s->d_bulk_in.release(); s->d_bulk_out.release(); s->d_win_lin.release();
+    s->d_bulk_in.release(); s->d_bulk_out.release(); s->d_win_lin.release(); s->d_ex.release();
     if (s->eng) szl_engine_destroy(s->eng);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -662,9 +711,10 @@ int szl_inflater_set_dictionary(szl_inflater *s, const uint8_t *p, int n) { // :
 
 // drop the consumed whole dwords of input (an offset into the vector; the vector itself is compacted once half of it is dead);
 // keep bitpos relative to the new base
-static void inflater_drop_consumed(szl_inflater *s) {
+static uint64_t inflater_drop_consumed(szl_inflater *s, uint64_t limit = ~0ull) {
     const size_t nin = s->hin.size() - s->hin_pos;
     uint64_t drop = (s->st.bitpos >> 3) & ~3ull;
+    if (drop > limit) drop = limit & ~3ull;
     if (s->st.mode == INF_M_ZHEADER) drop = 0;
     if (drop > nin) drop = nin & ~3ull;
     if (drop) {
@@ -674,6 +724,7 @@ static void inflater_drop_consumed(szl_inflater *s) {
         if (s->hin_pos == s->hin.size()) { s->hin.clear(); s->hin_pos = 0; }
         else if (s->hin_pos > (1u << 20) && s->hin_pos * 2 > s->hin.size()) { s->hin.erase(s->hin.begin(), s->hin.begin() + (ptrdiff_t)s->hin_pos); s->hin_pos = 0; }
     }
+    return drop;
 }
 
 enum : size_t { BULK_MIN_DEFAULT_KIB = 2048 };
@@ -748,7 +799,7 @@ static int inflater_step(szl_inflater *s) {
     const size_t nin = s->hin.size() - s->hin_pos;
     // a long input: bring the stream to a block header (stop_at_header), then the chunk-parallel decoder
     const size_t bulk_min = (size_t)std::max(256, knob("SZL_INF_STREAM_BULK_KIB", (int)BULK_MIN_DEFAULT_KIB)) * 1024;
-    const bool bulk = nin >= bulk_min && s->given > s->bulk_skip_given && !s->err && s->dec_status != INF_NEED_DICT && knob("SZL_INF_STREAM_BULK", 1) != 0;
+    const bool bulk = nin >= bulk_min && s->given > s->bulk_skip_given && !s->err && s->dec_status != INF_NEED_DICT && !s->exact_live && knob("SZL_INF_STREAM_BULK", 1) != 0;
     if (bulk && s->st.mode == INF_M_HEADER && !s->st.last && s->dec_status == INF_CHUNK_END) {
         rc = inflater_bulk(s);
         if (rc < 0) return rc;
@@ -761,7 +812,8 @@ static int inflater_step(szl_inflater *s) {
     if (!s->h_out && hipHostMalloc((void **)&s->h_out, szl_inflater::OUT_CHUNK + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
     // One step produces at most OUT_CHUNK bytes, so it cannot need more than about that much input (stored data is 1:1):
     // upload a bounded prefix instead of the whole unconsumed input every step (a large SetInput would cost O(n^2) H2D).
-    const size_t nup = std::min<size_t>(nin, szl_inflater::IN_STEP);
+    size_t nup = std::min<size_t>(nin, szl_inflater::IN_STEP);
+    if (s->exact_live && nup < nin && ((nin - nup) & 1)) nup--;   // (the exact decoder's odd-byte rule looks at the parity of the input's end, CS/StreamManipulator.cs:216-222)
     InfJob j{};
     j.in_off = 0; j.in_len = nup; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
     j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1; j.load_window = s->have_dict ? 1 : 0;
@@ -771,6 +823,10 @@ static int inflater_step(szl_inflater *s) {
     *hj = j; *hs = s->st;
     if (nup) memcpy(s->h_ctl + szl_inflater::CTL_HDR, s->hin.data() + s->hin_pos, nup);
     HIPCHK(hipMemcpyAsync(dctl, s->h_ctl, szl_inflater::CTL_HDR + nup, hipMemcpyHostToDevice, nullptr));
+    if (s->exact_live) {
+        launch_inflate_exact(dctl + szl_inflater::CTL_HDR, (uint8_t *)s->d_out.p, (InfJob *)dctl, (InfState *)(dctl + sizeof(InfJob)), (ExState *)s->d_ex.p,
+                             (const uint32_t *)((uint8_t *)s->d_ex.p + sizeof(ExState)), 1, nullptr);
+    } else
     launch_inflate(dctl + szl_inflater::CTL_HDR, (uint8_t *)s->d_out.p, (InfJob *)dctl, (InfState *)(dctl + sizeof(InfJob)), 1, false, nullptr);
     HIPCHK(hipMemcpyAsync(s->h_ctl, dctl, sizeof(InfJob) + sizeof(InfState), hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
@@ -779,6 +835,11 @@ static int inflater_step(szl_inflater *s) {
     // A corrupt token stops the decoder, but everything it decoded before that point is still delivered (the reference hands
     // those bytes out over earlier Inflate() calls and throws only when it reaches the bad token): record the error, keep the
     // bytes; szl_inflater_inflate returns the error once they are drained.
+    if (j.status == INF_EXACT && !s->exact_live) {   // a block for the exact decoder: it starts at the block's header with the next step
+        if ((rc = s->d_ex.ensure(sizeof(ExState) + 64))) return rc;
+        HIPCHK(hipMemset(s->d_ex.p, 0, sizeof(ExState) + 64));
+        s->exact_live = true;
+    } else if (j.status == INF_CHUNK_END && s->exact_live) s->exact_live = false;   // clean again at a block header: k_inflate goes on
     if (j.status < 0) s->err = j.status;
     else s->dec_status = j.status;
     if (j.status == INF_NEED_INPUT && nup < nin) s->fresh_input = true; // only the uploaded prefix ran dry
@@ -798,7 +859,14 @@ static int inflater_step(szl_inflater *s) {
     }
     if (s->err) return 0;
     if (s->dec_status == INF_FINISHED && !s->no_header && s->st.adler_read != s->adler_dec) { s->err = SZL_E_ADLER_MISMATCH; return 0; }
-    inflater_drop_consumed(s);
+    if (s->exact_live) {
+        // the exact decoder's read position (ExState.ws) counts from the first byte uploaded: it moves with the bytes dropped here
+        ExState *dx = (ExState *)s->d_ex.p;
+        uint64_t ws = 0;
+        HIPCHK(hipMemcpy(&ws, &dx->ws, 8, hipMemcpyDeviceToHost));
+        const uint64_t dropped = inflater_drop_consumed(s, ws);
+        if (dropped) { ws -= dropped; HIPCHK(hipMemcpy(&dx->ws, &ws, 8, hipMemcpyHostToDevice)); }
+    } else inflater_drop_consumed(s);
     return 0;
 }
 

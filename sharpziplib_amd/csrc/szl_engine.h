@@ -95,7 +95,7 @@ class Engine {
     hipEvent_t ev[8];
     // checksum kernels run beside stages A-C on this stream (they only share the input bytes)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_guard = nullptr, ev_gjoin = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_guard = nullptr, ev_gjoin = nullptr, ev_zfork = nullptr, ev_zjoin = nullptr;
 };
 
 } // namespace szl

@@ -7,7 +7,9 @@ namespace szl {
 
 // status values written by k_inflate (>= 0); negative values are szl_status error codes
 enum : int { INF_RUNNING = 0, INF_FINISHED = 1, INF_NEED_INPUT = 2, INF_OUTPUT_FULL = 3, INF_NEED_DICT = 4,
-             INF_CHUNK_END = 5 /* chunked decode of one member: reached the block boundary at which the next chunk starts */ };
+             INF_CHUNK_END = 5 /* chunked decode of one member: reached the block boundary at which the next chunk starts */,
+             INF_EXACT = 6 /* k_inflate stands in front of a block whose code set the reference's lookup table decodes differently from a
+                              canonical decoder: k_inflate_exact (szl_kernels_inflate_exact.hip) takes the stream from here */ };
 // decoder modes (the reference's 13 modes collapse to these because a token is decoded atomically)
 enum : uint32_t { INF_M_HEADER = 0, INF_M_STORED = 1, INF_M_HUFF = 2, INF_M_DONE = 3, INF_M_ZHEADER = 4 };
 
@@ -43,6 +45,16 @@ struct InfState {
     int32_t status;
     uint32_t adler_read;
     uint8_t lens[320];
+};
+
+// k_inflate_exact's persistent state (szl_kernels_inflate_exact.hip): the reference's StreamManipulator, Inflater and InflaterDynHeader fields
+struct ExState {
+    uint32_t init;        // 0: derive the bit buffer from InfState.bitpos at a block header; 1: everything below is live
+    uint32_t buffer; int32_t bits; uint32_t lazy; int32_t dirty; uint64_t ws;
+    int32_t mode, neededBits, repLength, repDist, uncomprLen, isLastBlock, trees; uint32_t readAdler;
+    int32_t dh_step, dh_ll, dh_d, dh_m, dh_n, dh_i, dh_index, dh_symbol, dh_len;
+    uint8_t lens[320];
+    int16_t meta[512], litlen[1024], dist[1184];
 };
 
 // chunk-parallel decode of whole members (szl_kernels_inflate_par.hip)

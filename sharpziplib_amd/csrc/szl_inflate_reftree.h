@@ -6,9 +6,10 @@
 //     of that prefix find 0 where their pointer should be and are written into the PRIMARY table at `revcode >> 9` (:153-163),
 //     over whatever was there, and a later long code that reads such an entry as its pointer indexes out of range (the
 //     constructor throws IndexOutOfRangeException).
-// Garbage in, garbage out — but the same garbage: k_inflate switches a block with such a set to this table (lane 0, one token
-// at a time; csrc/szl_kernels_inflate.hip "exact-table mode").  Plain C++ without HIP so that the same text is compiled for the
-// CPU and compared with oracle/szl_inflate_oracle.c entry by entry and symbol by symbol (tests/test_reftree.py).
+// Garbage in, garbage out — but the same garbage: k_inflate stops in front of a block with such a set and k_inflate_exact
+// (csrc/szl_kernels_inflate_exact.hip: the reference's Inflater step for step, its bit buffer included) decodes it through this table.
+// Plain C++ without HIP so that the same text is compiled for the CPU and compared with oracle/szl_inflate_oracle.c entry by entry
+// and symbol by symbol (tests/test_reftree.py).
 #pragma once
 #include <stdint.h>
 

@@ -30,7 +30,6 @@ enum : int { I_WIN = 32768, I_STAGE = 1024, I_LPB = 10, I_DPB = 9, MAX_MATCH_I =
 // last 8 KiB of output live in LDS and matches that reach farther back read the output region itself, which lets a CU keep
 // 10 streams in flight instead of 4.  Streaming jobs (window saved between calls, preset dictionary) keep all 32 KiB in LDS.
 enum : int { I_WIN_SHORT = 8192 };
-static_assert((1 << I_LPB) >= RT_CAP_LITLEN, "the literal/length table of the exact-table mode lives in llut");
 
 __constant__ uint16_t c_cplens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_cplext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -49,11 +48,9 @@ template <int WIN, typename WT>
 struct InfLds {
     WT win[WIN];
     uint32_t stage[I_STAGE / 4 + 4];
-    uint16_t llut[1 << I_LPB];            // (exact-table mode: the reference's literal/length table, RT_CAP_LITLEN entries)
-    union {
-        struct { uint16_t dlut[1 << I_DPB]; HuffTab lt, dt; };
-        int16_t dtree[RT_CAP_DIST];       // exact-table mode: the reference's distance table (the canonical tables are unused then)
-    };
+    uint16_t llut[1 << I_LPB];
+    uint16_t dlut[1 << I_DPB];
+    HuffTab lt, dt;
     uint8_t lens[320];
     uint16_t codes[320];
     uint32_t queue[64];
@@ -65,8 +62,8 @@ struct InfLds {
 // out of DeflaterHuffman.BitReverse as soon as a canonical code reaches 65536 (C/InflaterHuffmanTree.cs:133-166,
 // C/DeflaterHuffman.cs:924-930) — always, because the last code of the longest length is >= 65536 exactly when the
 // lengths' Kraft sum exceeds 1.  Incomplete sets are accepted like there (:116-121 commented out).
-// Returns 2 instead of true for a set on which the reference's table is not a canonical decoder (incomplete, with codes of 10+
-// bits: szl_inflate_reftree.h) — the caller then decodes the block through that table.
+// Returns 2 instead of 1 for a set on which the reference's table is not a canonical decoder (incomplete, with codes of 10+
+// bits: szl_inflate_reftree.h) — the caller then leaves the block to k_inflate_exact.
 __device__ int build_tab(const uint8_t *lens, int n, HuffTab *T, uint16_t *lut, int pb, uint16_t *codes, int lane) {
     for (int i = lane; i < (1 << pb); i += 64) lut[i] = 0;
     // Counts per length, first canonical code and offset of each length, and every symbol's code: all lanes, registers only.
@@ -247,41 +244,29 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
             } else { bitpos = 16; mode = INF_M_HEADER; }
         }
     }
-    // Exact-table mode (wave-uniform): the block's literal/length or distance set is one the reference's lookup table decodes
-    // differently from a canonical decoder (szl_inflate_reftree.h).  Both tables are then built the reference's way (lane 0:
-    // rare, corrupt input only) and lane 0 decodes the block one token at a time through GetSymbol's exact steps.
-    bool refmode = false;
-    auto rebuild_tables = [&]() -> bool {
-        refmode = false;
+    // 0: over-subscribed set (the reference's BuildTree throws); 2: the block's literal/length or distance set is one the reference's
+    // lookup table decodes differently from a canonical decoder (incomplete, with codes of 10+ bits: szl_inflate_reftree.h) — such a
+    // block, and the bit buffer's misbehaviour it can set off, belong to k_inflate_exact (szl_kernels_inflate_exact.hip)
+    auto rebuild_tables = [&]() -> int {
         if (btype == 1) {
             for (int i = lane; i < 288; i += 64) S.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)); // C/InflaterHuffmanTree.cs:34-70
             if (lane < 32) S.lens[288 + lane] = 5;
             __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             build_tab(S.lens, 288, &S.lt, S.llut, I_LPB, S.codes, lane);
             build_tab(S.lens + 288, 32, &S.dt, S.dlut, I_DPB, S.codes, lane);
-            return true;
+            return 1;
         }
         // literal/length tree first, then the distance tree (C/InflaterDynHeader.cs:126-134 via C/Inflater.cs DECODE_DYN_HEADER)
         const int rl = build_tab(S.lens, (int)lnum, &S.lt, S.llut, I_LPB, S.codes, lane);
-        if (!rl) return false;
+        if (!rl) return 0;
         const int rd = build_tab(S.lens + lnum, (int)dnum, &S.dt, S.dlut, I_DPB, S.codes, lane);
-        if (!rd) return false;
-        if (rl == 2 || rd == 2) {
-            int rc = 0;
-            if (lane == 0) {   // C/InflaterDynHeader.cs:126-134: the literal/length table, then the distance table (work space: the token queue, empty here)
-                rc = rt_build(S.lens, (int)lnum, (int16_t *)S.llut, RT_CAP_LITLEN, S.queue, S.queue + 16);
-                if (rc >= 0) rc = rt_build(S.lens + lnum, (int)dnum, S.dtree, RT_CAP_DIST, S.queue, S.queue + 16);
-            }
-            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (__builtin_amdgcn_readfirstlane(rc) < 0) return false;   // IndexOutOfRangeException out of the constructor, like an over-subscribed set
-            refmode = true;
-        }
-        return true;
+        if (!rd) return 0;
+        return (rl == 2 || rd == 2) ? 2 : 1;
     };
     if (PMODE == 0 && status == INF_RUNNING && mode == INF_M_HUFF) {
         if (btype == 2) for (int i = lane; i < 320; i += 64) S.lens[i] = st->lens[i];
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        (void)rebuild_tables(); // a resumed block: these lengths were accepted when its header was read
+        (void)rebuild_tables(); // a resumed block: these lengths were accepted when its header was read (never a set of k_inflate_exact's)
     }
     // second level of the literal/length code for the wave-parallel decode: lane l holds first | count << 16 and the offset of length l
     uint32_t l2a = 0, l2b = 0;
@@ -352,7 +337,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
             const uint64_t P = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bitpos >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bitpos);
-            if (m0 == INF_M_HUFF && sbase != ~0ull && !refmode) {
+            if (m0 == INF_M_HUFF && sbase != ~0ull) {
                 const uint64_t byte0 = P >> 3;
                 const uint64_t availb = in_bits > P ? in_bits - P : 0;
                 const uint64_t room_lim = flushed + ROOM;
@@ -527,22 +512,14 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
                 const uint64_t avail = in_bits > bitpos ? in_bits - bitpos : 0; // valid bits from bitpos on
                 if (mode == INF_M_HUFF) {
                     if (opos + MAX_MATCH_I > room_lim) break;              // apply + flush first
-                    int r;
-                    if (refmode) {                                         // GetSymbol's own steps on the reference's table
-                        r = rt_get_symbol((const int16_t *)S.llut, (uint32_t)bb, avail > 64 ? 64u : (uint32_t)avail);
-                        if (r == RT_NEED_INPUT) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                        if (r == RT_CODELEN_ZERO) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; }
-                    } else {
-                        r = decode_sym(&S.lt, S.llut, I_LPB, (uint32_t)bb);
-                        // no code for these bits (an incomplete set, every code of which is at most 9 bits long — sets with longer
-                        // codes decode in exact-table mode): GetSymbol throws when it can peek 9 bits and reads the empty slot as
-                        // "symbol 0, 0 bits" when it cannot (C/InflaterHuffmanTree.cs:184-193 vs :224-233)
-                        // (a chunk job of the parallel path has no output bound in its count pass: there anything odd is an error, and the member
-                        // goes to the one-wavefront decoder)
-                        if (r < 0) { if (avail >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; } r = 0; }
-                    }
+                    int r = decode_sym(&S.lt, S.llut, I_LPB, (uint32_t)bb);
+                    // no code for these bits (an incomplete set, every code of which is at most 9 bits long — sets with longer codes are
+                    // k_inflate_exact's): GetSymbol throws when it can peek 9 bits and reads the empty slot as "symbol 0, 0 bits" when it
+                    // cannot (C/InflaterHuffmanTree.cs:184-193 vs :224-233).  (A chunk job of the parallel path has no output bound in its
+                    // count pass: there anything odd is an error, and the member goes to the one-wavefront decoder.)
+                    if (r < 0) { if (avail >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; } r = 0; }
                     const uint32_t sl = (uint32_t)r >> 16, sym = (uint32_t)r & 0xFFFF;
-                    if (!refmode && avail < sl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    if (avail < sl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                     if (sym < 256) {
                         if (opos + 1 > out_limit) { ev = EV_STOP; ea = INF_OUTPUT_FULL; break; }
                         bb >>= sl; nb -= (int)sl; bitpos += sl;
@@ -559,7 +536,6 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
                     const uint32_t xl = (ls < 8 || ls == 28) ? 0u : ((ls - 4) >> 2);
                     const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << xl));
                     const uint32_t len = lbase + ((uint32_t)tb & ((1u << xl) - 1));
-                    if (refmode && avail < used + xl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }   // PeekBits(neededBits) < 0 (:334); also once an entry has dropped more bits than there were
                     tb >>= xl; tn -= (int)xl; used += xl;
                     if (tn < 28) { // top up (the staged window always has >= 8 readable bytes past bytepos)
                         uint32_t o = (uint32_t)(((bitpos + used + tn) >> 3) - sbase);
@@ -567,30 +543,20 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
                         tb |= (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, o & 3) << tn;
                         tn += 32;
                     }
-                    int rd;
-                    if (refmode) {
+                    int rd = decode_sym(&S.dt, S.dlut, I_DPB, (uint32_t)tb);
+                    if (rd < 0) {                                      // (see the literal/length code above)
                         if (avail < used) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                        const uint64_t left = avail - used;
-                        rd = rt_get_symbol(S.dtree, (uint32_t)tb, left > 64 ? 64u : (uint32_t)left);
-                        if (rd == RT_NEED_INPUT) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                        if (rd == RT_CODELEN_ZERO) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; }
-                    } else {
-                        rd = decode_sym(&S.dt, S.dlut, I_DPB, (uint32_t)tb);
-                        if (rd < 0) {                                      // (see the literal/length code above)
-                            if (avail < used) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
-                            if (avail - used >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; }
-                            rd = 0;
-                        }
+                        if (avail - used >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; }
+                        rd = 0;
                     }
                     const uint32_t dl = (uint32_t)rd >> 16, dsym = (uint32_t)rd & 0xFFFF;
-                    if (dsym >= 30) { ev = EV_STOP; ea = (!refmode && avail < used + dl) ? INF_NEED_INPUT : SZL_E_ILLEGAL_DIST_CODE; break; } // :356-359
+                    if (dsym >= 30) { ev = EV_STOP; ea = avail < used + dl ? INF_NEED_INPUT : SZL_E_ILLEGAL_DIST_CODE; break; } // :356-359
                     tb >>= dl; tn -= (int)dl; used += dl;
                     const uint32_t xd = dsym < 4 ? 0u : ((dsym >> 1) - 1);                        // CPDIST/CPDEXT :50-68
                     const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << xd);
                     const uint32_t dist = dbase + ((uint32_t)tb & ((1u << xd) - 1));
                     tb >>= xd; tn -= (int)xd; used += xd;
-                    // (exact-table mode: an entry out of a partial prefix drops its bits without looking, :194 — only PeekBits(neededBits) can fail here)
-                    if (refmode ? (xd != 0 && avail < used) : (avail < used)) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
+                    if (avail < used) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                     if (opos + len > out_limit) { ev = EV_STOP; ea = INF_OUTPUT_FULL; break; } // not consumed: decoded again next call
                     bb = tb; nb = tn; bitpos += used;
                     S.queue[ntok++] = len | (dist << 16); opos += len;
@@ -717,6 +683,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
                         ev = EV_RESTAGE; ea = (int)(uint32_t)(bitpos >> 3); eb = (int)(uint32_t)((bitpos >> 3) >> 32); break;
                     }
                     if (fail < 0) { ev = EV_STOP; ea = fail; break; }
+                    eb = (int)(uint32_t)(hp - bitpos);                 // the header's bits: k_inflate_exact starts in front of them
                     bb = hb; nb = hn; bitpos = hp;
                     lastblk |= t & 1; btype = 2; lnum = nl; dnum = nd; mode = INF_M_HUFF;
                     ev = EV_TABLES; ea = 2 | (int)(nl << 8) | (int)(nd << 20); break;
@@ -828,8 +795,16 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 
         } break;
         case EV_TABLES:
             btype = (uint32_t)ea & 3; lnum = ((uint32_t)ea >> 8) & 0xFFF; dnum = ((uint32_t)ea >> 20) & 0xFF;
-            if (!rebuild_tables()) status = SZL_E_CODE_OVERSUBSCRIBED;
-            else if (PMODE && refmode) status = SZL_E_CODELEN_ZERO;   // chunked decode of a member: any error makes the parallel path step aside (the one-wavefront decoder has the exact-table mode)
+            {
+                const int rt = rebuild_tables();
+                if (rt == 0) status = SZL_E_CODE_OVERSUBSCRIBED;
+                else if (rt == 2) {
+                    // a chunk job of a member: any error makes the parallel path step aside; the one-wavefront decoder then stops here
+                    // with the stream back at the block's header (nothing of the block is consumed) and k_inflate_exact goes on
+                    if (PMODE) status = SZL_E_CODELEN_ZERO;
+                    else { status = INF_EXACT; bitpos -= (uint64_t)(uint32_t)eb; bb = 0; nb = -1; mode = INF_M_HEADER; lastblk = 0; }
+                }
+            }
             load_second_level();
             break;
         case EV_STORED: {

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) void k_links_guard(const uint8_t *__restrict__ 
 __global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict__ in, uint64_t in_total,
                                                       const SegDev *__restrict__ segs, const uint64_t *__restrict__ bnds,
                                                       const SpanDev *__restrict__ spans, uint16_t *__restrict__ link,
-                                                      const uint32_t *__restrict__ hflags) {
+                                                      const uint32_t *__restrict__ hflags, unsigned long long *order_flag) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem3[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // LDS byte addresses for the hand-written part (the compiler turns volatile accesses through generic pointers into
@@ -502,18 +502,23 @@ __global__ __launch_bounds__(A_THREADS) void k_links3(const uint8_t *__restrict_
                 : "scc", "memory");
         }
         // ---- links of the four slices
+        bool disorder = false;
 #pragma unroll
         for (int u = 0; u < A3_U; u++) {
             const int64_t q = warm0 + 64 * (A3_U * t + u) + lane;
-            if (q >= span.start && q < span.end) {
-                uint32_t dist = 0;
-                if ((m_ins[u] >> lane) & 1) {
-                    dist = (uint32_t)q - e_old[u];
-                    if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
-                }
-                lk[q] = (uint16_t)dist;
+            uint32_t dist = 0;
+            if ((m_ins[u] >> lane) & 1) {
+                dist = (uint32_t)q - e_old[u];
+                // EVERY exchange checks the assumption it rests on: what a lane receives is a position in front of its own (the table's
+                // earlier content, or a lower lane of the same exchange).  If the LDS served two lanes with one bucket in descending
+                // order, the lower lane — served second — would receive the HIGHER lane's position: a distance <= 0.  Any service order
+                // other than ascending has such a pair, so this is a complete check of the order, on every position, not a sample.
+                if ((int32_t)dist <= 0) disorder = true;
+                if (dist > 32767u) dist = 0; // candidates farther than the window are never followed (:609)
             }
+            if (q >= span.start && q < span.end) lk[q] = (uint16_t)dist;
         }
+        if (order_flag && __any(disorder) && lane == 0) atomicAdd(order_flag, 1ull);
     }
 }
 
@@ -1023,7 +1028,9 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
 
 // hflags (optional, single streaming segment): bit q = buffer position q of the history was inserted into the hash chains
 static std::atomic<int> g_links3_distrusted{0};   // the guard caught k_links3 storing a wrong link: this process uses k_links2 from then on
-void links_distrust_ticket_form() { g_links3_distrusted.store(1, std::memory_order_release); }
+static std::atomic<uint32_t> g_links3_trips{0};
+void links_distrust_ticket_form() { g_links3_distrusted.store(1, std::memory_order_release); g_links3_trips.fetch_add(1, std::memory_order_acq_rel); }
+uint32_t links_guard_trips() { return g_links3_trips.load(std::memory_order_acquire); }
 bool links_ticket_form_distrusted() { return g_links3_distrusted.load(std::memory_order_acquire) != 0; }
 
 void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, const uint64_t *bnds, const SpanDev *spans,
@@ -1047,7 +1054,8 @@ void launch_links(const uint8_t *in, uint64_t in_total, const SegDev *segs, cons
         probe_done.fetch_or(dev_bit, std::memory_order_release);
     }
     if (which == 3 && (probe_ok.load(std::memory_order_acquire) & dev_bit)) {
-        hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link, hflags);
+        hipLaunchKernelGGL(k_links3, dim3(nspans), dim3(A_THREADS), A3_LDS_BYTES, st, in, in_total, segs, bnds, spans, link, hflags,
+                           knob("SZL_LINKS_GUARD", 1) ? guard_flag : (unsigned long long *)nullptr);
         if (guard_flag && knob("SZL_LINKS_GUARD", 1)) {           // one sampled position per 4 MiB, 8..256 of them
             const int lab_break = knob("SZL_LINKS_GUARD_TEST", 0);   // (tests: pretend a mismatch, to exercise the fallback)
             uint64_t ns = span_bytes >> 22;

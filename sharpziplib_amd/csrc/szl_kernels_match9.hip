@@ -181,7 +181,7 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
     // thresholds (tools/sim_match9.py counts instructions per position for any of them on the CPU)
-    int fth = knob("SZL9_FTH", 24), vth = knob("SZL9_VTH", 2), qkeep = knob("SZL9_QKEEP", 64), ktail = knob("SZL9_KTAIL", 2), vtht = knob("SZL9_VTHT", 1);
+    int fth = knob("SZL9_FTH", 16), vth = knob("SZL9_VTH", 2), qkeep = knob("SZL9_QKEEP", 64), ktail = knob("SZL9_KTAIL", 2), vtht = knob("SZL9_VTHT", 1);
     // the tail program (szl_match9_asm.h): 0 = the main loop to the end (laboratory); walks of both contexts move into one once they are
     // at most `mth` (<= 64; -1: never); iterations of the one-context walk between two looks at who left
     int tailp = knob("SZL9_TAILP", 1), mth = knob("SZL9_MTH", 64), ktail1 = knob("SZL9_KTAIL1", 1), vtht1 = knob("SZL9_VTHT1", 1);

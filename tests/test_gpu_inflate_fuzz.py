@@ -38,8 +38,9 @@ def _compare(name, stream, status, out, consumed, failures):
     n, delivered, cons = O.inflate_probe(stream, max_out=CAP)
     if O.inflate_probe.quirk_sets:
         # The stream holds an INCOMPLETE code-length set with codes of 10+ bits: the reference's lookup table then differs from
-        # every canonical decoder (C/InflaterHuffmanTree.cs:153-163,200-203).  The device builds that very table for such a
-        # block (csrc/szl_inflate_reftree.h) — compared like every other stream; only counted here.
+        # every canonical decoder (C/InflaterHuffmanTree.cs:153-163,200-203), and an entry of it can make StreamManipulator drop more
+        # bits than it holds (CS/StreamManipulator.cs:86-90).  The device decodes such a block with k_inflate_exact — that very
+        # table (csrc/szl_inflate_reftree.h) and that very bit buffer — compared like every other stream; only counted here.
         QUIRKS.append(name)
     if n >= 0:
         if status != 0 or out != delivered or consumed != cons:

@@ -44,8 +44,9 @@ def _bulk(inf):
 @pytest.mark.parametrize("kind,level", [("enwik", 6), ("logs", 9), ("dickens", 5)])
 def test_whole_member_in_one_setinput(kind, level):
     from sharpziplib_amd.inflater import Inflater
-    plain = C.generate(kind, 77, 0, 24 << 20)
+    plain = C.generate(kind, 77, 0, (96 if kind == "logs" else 24) << 20)
     comp = O.deflate(plain, level)
+    assert len(comp) > (3 << 20)
     inf = Inflater(True)
     got = _inflate_all(inf, [comp + b"TRAILING-BYTES"])
     assert got == plain.tobytes()
@@ -69,17 +70,18 @@ def test_pieces_of_many_sizes_and_zlib_framing():
 
 def test_small_and_large_inputs_mixed_and_no_dynamic_blocks():
     from sharpziplib_amd.inflater import Inflater
-    plain = C.generate("logs", 79, 0, 20 << 20)
+    plain = C.generate("logs", 79, 0, 80 << 20)
     comp = O.deflate(plain, 6)
     # 4 KiB pieces first (one wavefront), then the rest at once (parallel), to a stream that continues in 64 KiB pieces
     cut1, cut2 = 300000, len(comp) - 500000
-    pieces = [comp[o:o + 4096] for o in range(0, cut1, 4096)] + [comp[cut1:cut2]] + [comp[o:o + 65536] for o in range(cut2, len(comp), 65536)]
+    assert cut2 - cut1 > (3 << 20)
+    pieces = [comp[o:min(o + 4096, cut1)] for o in range(0, cut1, 4096)] + [comp[cut1:cut2]] + [comp[o:o + 65536] for o in range(cut2, len(comp), 65536)]
     inf = Inflater(True)
     assert _inflate_all(inf, pieces, read=100000) == plain.tobytes() and inf.IsFinished and inf.TotalIn == len(comp)
     assert _bulk(inf) >= 1
     # stored blocks only (level 0) and random bytes: nothing for the block finder — the ordinary decoder does it all
     rnd = C.random_bytes(6 << 20, seed=9)
-    for c, want in ((O.deflate(plain[:8 << 20], 0), plain[:8 << 20].tobytes()), (O.deflate(rnd, 6), rnd.tobytes())):
+    for c, want in ((O.deflate(plain[:8 << 20], 0), plain[:8 << 20].tobytes()), (O.deflate(rnd, 6), rnd.tobytes())):   # (both > 2 MiB)
         inf = Inflater(True)
         got = _inflate_all(inf, [c])
         assert got == want and inf.IsFinished and inf.TotalIn == len(c)

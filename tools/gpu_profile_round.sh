@@ -37,7 +37,7 @@ for tag in ('sq1', 'sq2'):
         for r in csv.DictReader(open(f)):
             sq[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']] += float(r['Counter_Value'])
 json.dump({k: {c: int(v) for c, v in d.items()} for k, d in sq.items() if k.startswith('szl::')}, open(O + '/pmc_sq_1gib.json', 'w'), indent=1)
-for k in ('szl::k_match4<false>', 'szl::k_spec_win<16>', 'szl::k_links3'):
+for k in ('szl::k_match9<false>', 'szl::k_spec_win<32>', 'szl::k_links3'):
     print(k, tr.get(k), dict(sq.get(k, {})))
 PY
 rm -rf $O/stats $O/pmc
@@ -47,5 +47,4 @@ python $R/tools/gpu_inflate_big.py 1024 2>&1 | grep -v "stage B\|links\|match_ms
 python $R/tools/gpu_inflate_big.py 1024 logs 2>&1 | tail -1 >> $O/inflate_round.log
 python $R/tools/gpu_small_call.py 200 > $O/small_calls.log 2>&1
 python $R/tools/gpu_fast.py 4 4000 > $O/levels_1_4.log 2>&1
-python $R/tools/gpu_stream_latency.py --entries 500 > $O/stream_latency.log 2>&1
-tail -n 30 $O/inflate_round.log $O/small_calls.log $O/levels_1_4.log $O/stream_latency.log
+tail -n 30 $O/inflate_round.log $O/small_calls.log $O/levels_1_4.log
