@@ -7,9 +7,9 @@ shard of the seeded enwik-style corpus that is already resident in HBM.
   --gpus N (default mode "weak"): one process per GPU, every rank compresses its own 1 GiB shard of the corpus, no data-path
       collective (the path shards by independent streams) -> weak scaling.  Started under torch.distributed.run the script
       is one rank; started plainly with N > 1 it launches its own N ranks (127.0.0.1 rendezvous) and relays their line.
-  --mode strong: ONE 1 GiB stream over N devices in one process (szl_deflate_batch_multi_host: position-range units taken
-      dynamically, tokens gathered on device 0) -> "scaling": "strong".  That entry point takes host buffers, so its time
-      includes the PCIe copies; the line says so.
+  --mode strong: ONE 1 GiB stream over N devices in one process (szl_deflate_stream_multi_device: position-range units taken
+      dynamically, tokens gathered on device 0) -> "scaling": "strong".  The stream is uploaded to every device before the timed
+      region: no PCIe in the step.
   --stub: no GPU, no library — ranks sleep instead of compressing (gloo).  tests/test_bench_launcher.py drives the launcher,
       the barriers, the MAX reduction and the JSON contract with it on the CPU.
 Prints ONE JSON line on rank 0.  At N=1 the line also carries "configs": the other BASELINE configs (3, 4(i), 4(ii), 5)
@@ -358,37 +358,55 @@ def run_stub(args, rank, world, dist):
 
 
 def run_strong(args, rank, world, dist):
-    """ONE stream over all devices of the node (one process): only rank 0 works when started under a launcher."""
+    """ONE stream over all devices of the node (one process): only rank 0 works when started under a launcher.  The stream is RESIDENT
+    on every device before the timed region (szl_deflate_stream_multi_device): no PCIe in the step."""
     import hashlib
-    import numpy as np
+    import torch
     from sharpziplib_amd import _lib, corpus
-    from sharpziplib_amd.batch import deflate_multi
+    from sharpziplib_amd.batch import Engine, deflate_stream_multi_device
     if rank == 0:
         n = args.mib << 20
         host = corpus.generate("enwik", 0xE9, 0, n)
         ndev = int(_lib.lib().szl_device_count())
         assert ndev >= args.gpus, "--gpus %d but the library sees %d device(s)" % (args.gpus, ndev)
         devices = list(range(args.gpus))
+        d_ins = []
+        for g in devices:
+            t = torch.empty(n + 64, dtype=torch.uint8, device=torch.device("cuda", g))
+            t[:n].copy_(torch.from_numpy(host))
+            d_ins.append(t)
+        streams, _, out_total = Engine.layout([n])
+        d_out = torch.empty(out_total + 64, dtype=torch.uint8, device=torch.device("cuda", devices[0]))
+        flags = _lib.F_NOWRAP | _lib.F_CRC32
+
+        def step():
+            deflate_stream_multi_device([t.data_ptr() for t in d_ins], d_out.data_ptr(), devices, streams, level=args.level, flags=flags)
         for _ in range(args.warmup):
-            deflate_multi([host], devices, level=args.level, crc32=True)
+            step()
+        for g in devices:
+            torch.cuda.synchronize(g)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            (r,) = deflate_multi([host], devices, level=args.level, crc32=True)
+            step()
+        for g in devices:
+            torch.cuda.synchronize(g)
         elapsed = time.perf_counter() - t0
-        assert r.status == 0
+        assert streams[0].status == 0
+        out_len = int(streams[0].out_len)
+        comp = d_out[:out_len].cpu().numpy().tobytes()
         gpath = os.path.join(ROOT, "tests", "golden", "headline_golden.json")
         checked = "not the golden workload"
         if args.mib == 1024 and args.level == 6 and os.path.exists(gpath):
             g = json.load(open(gpath))["cases"]["cfg2_enwik_1g_l6"]
-            assert len(r.data) == g["out_len"] and hashlib.sha256(r.data).hexdigest() == g["out_sha256"] and r.crc32 == g["crc32"], \
+            assert out_len == g["out_len"] and hashlib.sha256(comp).hexdigest() == g["out_sha256"] and int(streams[0].crc32) == g["crc32"], \
                 "the stream compressed by %d devices differs from the oracle's (golden sha256)" % args.gpus
             checked = "sha256 == oracle golden"
         line = {"metric": METRIC, "value": round(n * args.steps / elapsed / 2 ** 20, 1), "unit": "MiB/s", "n_gpus": args.gpus, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "u8", "data": "synthetic", "ratio": round(len(r.data) / n, 5),
-                "config": {"workload": "configs[1] as ONE %d MiB stream over %d device(s) (szl_deflate_batch_multi_host: position-range units, "
-                                       "tokens gathered on device 0); HOST buffers in and out: the time includes the PCIe copies" % (args.mib, args.gpus),
-                           "level": args.level, "parallelism": "one-stream x%d" % args.gpus, "input_resident": False},
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic", "ratio": round(out_len / n, 5),
+                "config": {"workload": "configs[1] as ONE %d MiB stream over %d device(s) (szl_deflate_stream_multi_device: position-range units, "
+                                       "tokens gathered on device 0); the stream is resident on every device before the timed region" % (args.mib, args.gpus),
+                           "level": args.level, "parallelism": "one-stream x%d" % args.gpus, "input_resident": True},
                 "parity": [checked]}
         print(json.dumps(line), flush=True)
     if dist is not None:

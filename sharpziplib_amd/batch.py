@@ -160,3 +160,12 @@ def inflate_multi(buffers, out_sizes, devices, nowrap=True, crc32=False):
     _lib.check(L.szl_inflate_batch_multi_host(devs, len(devices), hin.ctypes.data, hout.ctypes.data, arr, len(bufs), flags),
                "szl_inflate_batch_multi_host")
     return [(Result(hout[s.out_off:s.out_off + s.out_len].tobytes(), s.crc32, s.adler32, s.status), int(s.in_consumed)) for s in arr]
+
+
+def deflate_stream_multi_device(d_in_ptrs, d_out_ptr, devices, stream, level=6, strategy=0, flags=_lib.F_NOWRAP):
+    """ONE stream over several devices, input already resident on each of them (szl_deflate_stream_multi_device): d_in_ptrs[g] = device
+    pointer of the input arena on devices[g], d_out_ptr = output arena on devices[0]; `stream` = a one-element Stream array."""
+    L = _lib.lib()
+    devs = (ctypes.c_int * len(devices))(*devices)
+    ptrs = (ctypes.c_void_p * len(devices))(*d_in_ptrs)
+    _lib.check(L.szl_deflate_stream_multi_device(devs, len(devices), ptrs, d_out_ptr, stream, level, strategy, flags), "szl_deflate_stream_multi_device")
