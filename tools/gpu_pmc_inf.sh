@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_L
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out -o p$i -- python $R/tools/gpu_inflate_one.py "$@" > $R/$out/run$i.txt 2> $R/$out/err$i.txt
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out -o p$i -- python $R/tools/gpu_lab.py inflate_one "$@" > $R/$out/run$i.txt 2> $R/$out/err$i.txt
 done
 cd $R
 python3 - $out <<'PY'

@@ -1,6 +1,6 @@
 """stage times of one stream of a data class (python tools/gpu_class_stats.py class MiB level)"""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np
 from sharpziplib_amd import corpus as C
 from sharpziplib_amd.batch import Engine

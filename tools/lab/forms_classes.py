@@ -1,6 +1,6 @@
 """full search vs on-demand stage B across data classes (is there any data where the on-demand form still wins?)"""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np
 from sharpziplib_amd import corpus as C
 from sharpziplib_amd.batch import Engine

@@ -1,7 +1,7 @@
 """PCIe-inclusive rate of the host-buffer entry point (szl_deflate_batch_host) on one 1 GiB stream: wall clock around the call,
 with and without the overlapped input copy; output checked against the frozen oracle hash."""
 import sys, os, time, hashlib, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sharpziplib_amd import _lib, corpus

@@ -4,7 +4,7 @@ if not sys.argv[1].endswith(".run"):
     for so in sys.argv[1:]:
         subprocess.call([sys.executable, __file__, so + ".run"])
     sys.exit(0)
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from sharpziplib_amd import _lib
 so = sys.argv[1][:-4]
 _lib.SO = os.path.join(_lib.CSRC, so)

@@ -1,6 +1,6 @@
 """A few members of about 1 MiB through inflate with the pass times (python tools/gpu_inflate_few.py N KiB)"""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from sharpziplib_amd import corpus as C, _lib
 from sharpziplib_amd.batch import Engine
 L = _lib.lib(); eng = Engine()

@@ -1,6 +1,6 @@
 """One inflate call for counter collection: N x S KiB members (python tools/gpu_inflate_one.py N S_KiB [kind])."""
 import sys
-import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from sharpziplib_amd import corpus as C
 from sharpziplib_amd.batch import Engine
 nm, msz = int(sys.argv[1]), int(sys.argv[2]) << 10

@@ -1,6 +1,6 @@
 """Members of a few hundred KiB: one wavefront each vs the chunk-parallel form (SZL_INF_PAR_MIN_KIB sweep)."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from sharpziplib_amd import corpus as C, _lib
 from sharpziplib_amd.batch import Engine
 L = _lib.lib()

@@ -1,6 +1,6 @@
 """config 5 (logs, level 9): the stage-B forms side by side on one resident stream (python tools/gpu_logs9.py [MiB])."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from sharpziplib_amd import corpus as C, _lib
 from sharpziplib_amd.batch import Engine
 L = _lib.lib(); eng = Engine()

@@ -1,7 +1,7 @@
 """One stream over several engines (GPU box): which parts ran, how many were re-run, timing against one engine.
 Usage: python tools/gpu_multi_stream.py [MiB=512] [engines=2] [level=6]   (SZL_DEBUG=1 prints the parts)"""
 import hashlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sharpziplib_amd import corpus as C, _lib

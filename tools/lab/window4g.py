@@ -2,7 +2,7 @@
 Prints the workspace peak of each and checks that the two outputs are the same bytes (sha256) and inflate to the input's CRC.
 Usage: python tools/gpu_window4g.py [GiB=4] [level=9]"""
 import hashlib, os, sys, time, zlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sharpziplib_amd import corpus as C, _lib
