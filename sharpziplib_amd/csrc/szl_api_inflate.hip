@@ -111,6 +111,9 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         std::vector<Cnt> cnt; std::vector<char> have;
         std::vector<uint64_t> reg;       // single pass: staging region (first symbol) of each job
         uint64_t reg_cap = 0;            //              and its size in symbols
+        std::vector<uint64_t> regc;      //              (per job: a job that overran its region is run again in one of the large ones)
+        std::vector<uint64_t> spare, spare_big;   // unused regions: for the jobs a chain repair adds / for jobs that overran theirs
+        uint64_t big_cap = 0;
         bool alive = true, ok = false, truncated = false;
         uint64_t trunc_bit = 0;          // (piece of a stream) start bit of the dropped last job
         std::vector<uint64_t> ooff, jbase; uint64_t total = 0, end_byte = 0; uint32_t adler_read = 0;
@@ -188,6 +191,15 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             p.reg_cap = (uint64_t)(1.5 * expand * (double)p.chunk_bytes) + 65536;
             p.reg.resize(p.sb.size());
             for (auto &r : p.reg) { r = reg_total; reg_total += p.reg_cap; }
+            p.regc.assign(p.sb.size(), p.reg_cap);
+            // a chain that needs repair (a block boundary no candidate start named) or a job whose output outgrew the estimate used to
+            // send the whole member through the count-first form — finder, count passes and symbol pass again (64 x 1 MiB members: 35
+            // of them, +21 ms).  Now the single pass repairs in place: spare regions for the jobs a repair adds, a few large ones for
+            // jobs to be run again with more room; only a member that runs out of those takes the other form.
+            const size_t nsp = p.sb.size() / 4 + 4;
+            for (size_t k = 0; k < nsp; k++) { p.spare.push_back(reg_total); reg_total += p.reg_cap; }
+            p.big_cap = 4 * p.reg_cap;
+            for (int k = 0; k < 2; k++) { p.spare_big.push_back(reg_total); reg_total += p.big_cap; }
         }
     }
     // Staging is sized from the CALLER's out_cap (an upper bound he chose, possibly an untrusted ISIZE trailer): a generous capacity must
@@ -218,7 +230,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             InfJob &jb = jobs[q];
             jb.in_off = streams[p.si].in_off; jb.in_len = streams[p.si].in_len;
             jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : (p.truncated ? p.trunc_bit : ~0ull);   // (a piece of a stream: the dropped job's start)
-            if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.reg_cap; }
+            if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.regc[j]; }
             else { jb.sym_out = pass == 2 ? sym + p.jbase[j] : nullptr; jb.out_cap = ~0ull >> 2; }
         }
         int r;
@@ -231,7 +243,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         return 0;
     };
     // ---- 2. first pass over every job (count, or symbols straight away) + chain check / repair (per member; the launches are shared)
-    for (int iter = 0; iter < (single_pass ? 1 : 6); iter++) {
+    for (int iter = 0; iter < (single_pass ? 5 : 6); iter++) {
         std::vector<Ref> which;
         for (uint32_t k = 0; k < ps.size(); k++) {
             PS &p = ps[k];
@@ -247,19 +259,27 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         for (auto &p : ps) {
             if (!p.alive || p.ok) continue;
             // walk the chain from job 0; keep the starts it visits
-            std::vector<uint64_t> nsb, nreg; std::vector<Cnt> ncnt; std::vector<char> nhave;
+            std::vector<uint64_t> nsb, nreg, nregc; std::vector<Cnt> ncnt; std::vector<char> nhave;
             uint32_t j = 0;
             bool ok = true;
             for (;;) {
                 nsb.push_back(p.sb[j]); ncnt.push_back(p.cnt[j]); nhave.push_back(1);
-                if (single_pass) nreg.push_back(p.reg[j]);
+                if (single_pass) { nreg.push_back(p.reg[j]); nregc.push_back(p.regc[j]); }
                 const Cnt &c = p.cnt[j];
                 if (c.status == INF_FINISHED) break;               // the member's last block ended inside this job
                 if (sm && c.status == INF_NEED_INPUT && nsb.size() > 1) {
                     // a piece of a stream: the input ends inside the last job's blocks — that job is left to a later call
                     nsb.pop_back(); ncnt.pop_back(); nhave.pop_back();
-                    if (single_pass) nreg.pop_back();
+                    if (single_pass) { nreg.pop_back(); nregc.pop_back(); }
                     p.truncated = true; p.trunc_bit = p.sb[j];
+                    break;
+                }
+                if (single_pass && c.status == INF_OUTPUT_FULL && p.regc[j] < p.big_cap && !p.spare_big.empty()) {
+                    // the job's output outgrew its staging region: again, in a large one; everything behind it keeps what it has
+                    nreg.back() = p.spare_big.back(); p.spare_big.pop_back(); nregc.back() = p.big_cap;
+                    ncnt.back() = Cnt{}; nhave.back() = 0;
+                    ok = false;
+                    for (uint32_t m2 = j + 1; m2 < p.sb.size(); m2++) { nsb.push_back(p.sb[m2]); ncnt.push_back(p.cnt[m2]); nhave.push_back(p.have[m2]); nreg.push_back(p.reg[m2]); nregc.push_back(p.regc[m2]); }
                     break;
                 }
                 if (c.status != INF_CHUNK_END) {                   // an error on the chain is a real error of the stream —
@@ -274,19 +294,24 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 // ran with an earlier stop, but a decode that stops at the first block boundary >= stop also stops there for
                 // any stop in (previous boundary, end_bit]: its count stays valid.)
                 ok = false;
-                if (single_pass) { p.alive = false; if (retry) retry->push_back(p.si); break; }
+                if (single_pass && p.spare.empty()) { p.alive = false; if (retry) retry->push_back(p.si); break; }
                 nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
-                for (; m < p.sb.size(); m++) { nsb.push_back(p.sb[m]); ncnt.push_back(p.cnt[m]); nhave.push_back(p.have[m]); }
+                if (single_pass) { nreg.push_back(p.spare.back()); p.spare.pop_back(); nregc.push_back(p.reg_cap); }
+                for (; m < p.sb.size(); m++) {
+                    nsb.push_back(p.sb[m]); ncnt.push_back(p.cnt[m]); nhave.push_back(p.have[m]);
+                    if (single_pass) { nreg.push_back(p.reg[m]); nregc.push_back(p.regc[m]); }
+                }
                 break;
             }
             if (!p.alive) continue;
             p.sb.swap(nsb); p.cnt.swap(ncnt); p.have.swap(nhave);
-            if (single_pass) p.reg.swap(nreg);
+            if (single_pass) { p.reg.swap(nreg); p.regc.swap(nregc); }
             if (ok) p.ok = true; else pending = true;
         }
         if (dbg) fprintf(stderr, "[szl] inflate par: %s pass %d over %zu jobs\n", single_pass ? "symbol" : "count", iter, which.size());
         if (!pending) break;
     }
+    if (single_pass && retry) for (auto &p : ps) if (p.alive && !p.ok) { p.alive = false; retry->push_back(p.si); }   // (out of repair rounds: the count-first form)
     lap(single_pass ? "symbol pass (single)" : "count passes");
     // ---- layout of what was proven
     uint64_t sym_total = 0, win_total = 0, ooff_total = 0, njobs_total = 0;
