@@ -124,7 +124,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(st); const double t = now(); fprintf(stderr, "[szl] inflate par: %-28s %8.2f ms\n", what, t - t_prev); t_prev = t; } };
-    // Chunk size: the symbol pass is a fixed number of wavefront slots (10 chunk jobs per CU since round 4 — 8 KiB of LDS window + tables each, 168 registers —; the numbers below were measured with 8) times
+    // Chunk size: the symbol pass is a fixed number of wavefront slots (8 chunk jobs per CU: 8 KiB of LDS window + tables each) times
     // the one-wavefront decode of a chunk, so what counts is how evenly the jobs fill the slots — a 1 GiB text member: 128 KiB chunks
     // = 3034 jobs = 1.5 rounds of the 2048 slots, 56 ms; 192 KiB = one round, 43 ms; a 1 GiB log member (70 MiB compressed): 128 KiB =
     // a quarter of the slots, 37 ms; 64 KiB 25 ms.  So: r whole rounds of the slots with chunks of at most ~192 KiB, at least 32 KiB.
@@ -135,7 +135,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        const uint64_t slots = (uint64_t)std::max(1, knob("SZL_INF_SLOTS_PER_CU", 10)) * (uint64_t)cus;
+        const uint64_t slots = 8ull * (uint64_t)cus;
         const uint64_t rounds = std::max<uint64_t>(1, (total_in + slots * (192ull << 10) - 1) / (slots * (192ull << 10)));
         chunk_max = std::min<uint64_t>(std::max<uint64_t>((total_in / (slots * rounds) + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
     }

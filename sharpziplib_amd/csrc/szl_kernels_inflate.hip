@@ -22,10 +22,6 @@
 
 namespace szl {
 
-#ifndef SZL_INF_LB2
-#define SZL_INF_LB2 3   // wavefronts per SIMD the symbol pass's register allocation must allow: 168 registers instead of 210, no scratch; the LDS
-                      // (15 KiB per job) then admits 10 chunk jobs per CU instead of 8: a 512 MiB text member 28.5 -> 26.2 ms (profiles/r04/inflate_slots.log)
-#endif
 #ifndef SZL_INF_NPO
 #define SZL_INF_NPO 4   // bit offsets every lane decodes speculatively per round (64 * NPO bits of input per round; 6 and 8 measured: +-1 %)
 #endif
@@ -183,7 +179,7 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
 // position reached.  2 = symbol pass: the same decode, writing 16-bit symbols to job.sym_out — a byte, or 0x8000 | i for
 // "byte i of the 32 KiB in front of this chunk" (what a back-reference reaching before the chunk reads; resolved afterwards).
 template <bool SHORTWIN, int PMODE>
-__global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? SZL_INF_LB2 : 1)) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
+__global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? 2 : 1)) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
     // (round 2 measured the 4096-entry window slower for one long member — 74 -> 93 ms per 256 MiB — when every far read was an
     // agent-scope load that missed the L2; round 3, with workgroup-scope far reads, it wins)
