@@ -163,8 +163,14 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
         e.update(more)
         out[name] = e
 
+    t_begin = time.perf_counter()
+    budget_s = float(os.environ.get("SZL_BENCH_CONFIGS_BUDGET_S", "600"))   # the other configs never hold the headline up for longer than this
+
     def guarded(name, fn):
         t = time.perf_counter()
+        if t - t_begin > budget_s:
+            out[name] = {"skipped": "time budget for the other configs (%.0f s) used up" % budget_s}
+            return
         try:
             fn()
         except Exception as e:                    # (an entry that cannot run — memory on a shared box — or fails its check says so; the headline stands on its own)
