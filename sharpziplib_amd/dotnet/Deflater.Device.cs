@@ -220,8 +220,40 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 			}
 		}
 
-		/// <summary>Raw-deflate every entry (level as in Deflater); returns the compressed bytes and fills crc32[i].</summary>
-		public unsafe byte[][] Deflate(System.Collections.Generic.IReadOnlyList<ArraySegment<byte>> entries, int level, out uint[] crc32)
+		/// <summary>Raw-deflate every entry (level as in Deflater); returns the compressed bytes and fills crc32[i].
+		/// The entries of one device call are packed into ONE managed byte[] each way, so a call is limited to 2 GiB of input and
+		/// 2 GiB of worst-case output (szl_deflate_bound); a longer list is cut into consecutive calls below that limit.  A single
+		/// entry whose bound alone exceeds it is an ArgumentException (feed it through the streaming Deflater instead).</summary>
+		public byte[][] Deflate(System.Collections.Generic.IReadOnlyList<ArraySegment<byte>> entries, int level, out uint[] crc32)
+		{
+			const ulong Limit = 0x7FFFFFC7UL - 8UL;                              // largest byte[] the runtime allocates, minus the slack below
+			int total = entries.Count;
+			var all = new byte[total][];
+			crc32 = new uint[total];
+			int first = 0;
+			while (first < total)
+			{
+				ulong inSum = 0, outSum = 0;
+				int last = first;
+				while (last < total)
+				{
+					ulong len = (ulong)entries[last].Count;
+					ulong cap = (SzlNative.szl_deflate_bound(len) + 3UL) & ~3UL;
+					if (cap > Limit) throw new ArgumentException("entry " + last + " is too long for one batched call (" + len + " bytes)", nameof(entries));
+					if (last > first && (inSum + len > Limit || outSum + cap > Limit)) break;
+					inSum += len; outSum += cap; last++;
+				}
+				var part = new ArraySegment<byte>[last - first];
+				for (int i = first; i < last; i++) part[i - first] = entries[i];
+				byte[][] got = DeflateOneCall(part, level, out uint[] crcs);
+				Array.Copy(got, 0, all, first, got.Length);
+				Array.Copy(crcs, 0, crc32, first, crcs.Length);
+				first = last;
+			}
+			return all;
+		}
+
+		private unsafe byte[][] DeflateOneCall(System.Collections.Generic.IReadOnlyList<ArraySegment<byte>> entries, int level, out uint[] crc32)
 		{
 			int n = entries.Count;
 			var st = new SzlNative.SzlStream[n];
