@@ -166,6 +166,8 @@ int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in
  * buffers, i.e. without PCIe in the call (bench.py --mode strong times this).  Levels 5-9; same bytes as one engine. */
 int szl_deflate_stream_multi_device(const int *devices, int n_dev, const void *const *d_in, void *d_out0, szl_stream *stream,
                                     int level, int strategy, unsigned flags);
+/* The multi-device entry points keep one engine per device slot (work space included) between calls; this frees them. */
+int szl_multi_release(void);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  unsigned flags);
 

@@ -513,15 +513,30 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     std::vector<uint8_t> bounce;                         // devices that cannot reach device 0: through the host
     int fatal = 0; std::string fatal_msg;
     auto set_fatal = [&](int r, const std::string &m) { if (!fatal) { fatal = r; fatal_msg = m; } };
-    if ((rc = nt.ensure(((uint64_t)N + 16) * 4))) set_fatal(rc, last_error());
+    // sized for text (a token covers three bytes on average there) and grown when a unit's tokens do not fit — a token covers at
+    // least one byte, so 4 bytes per input byte is the ceiling, but reserving that up front held 4 GiB per GiB of input
+    if ((rc = nt.ensure(std::min<uint64_t>(((uint64_t)N + 16) * 4, ((uint64_t)N / 2 + 65536) * 4)))) set_fatal(rc, last_error());
     if (!fatal && hipStreamCreateWithFlags(&gst, hipStreamNonBlocking) != hipSuccess) set_fatal(SZL_E_DEVICE, "stream for the token gather");
     uint64_t at = 0;
     int reruns = 0;
     bool workers_joined = false;
     auto join_workers = [&]() { if (!workers_joined) { for (auto &t : th) t.join(); workers_joined = true; (void)hipSetDevice(devices[0]); } };
+    auto grow_nt = [&](uint64_t need_bytes) -> bool {       // (devices[0] is current; copies already queued on gst are waited for)
+        if (need_bytes <= nt.cap) return true;
+        if (gst && hipStreamSynchronize(gst) != hipSuccess) return false;
+        uint64_t want = std::max<uint64_t>(need_bytes, 2 * (uint64_t)nt.cap);
+        want = std::max<uint64_t>(need_bytes, std::min<uint64_t>(want, ((uint64_t)N + 16) * 4));
+        DevBuf nb;
+        if (nb.ensure(want)) return false;
+        if (at && hipMemcpy(nb.p, nt.p, at * 4, hipMemcpyDeviceToDevice) != hipSuccess) { nb.release(); return false; }
+        nt.release();
+        nt = nb;
+        return true;
+    };
     auto gather = [&](int u) -> bool {
         Unit &x = un[u];
         if (!x.ntok) return true;
+        if (!grow_nt((at + x.ntok + 16) * 4)) return false;
         const int sd = devices[x.slot];
         int can = 1;
         if (sd != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], sd) != hipSuccess) can = 0;
@@ -587,6 +602,13 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     stream->status = res[0].out_bytes <= stream->out_cap ? 0 : SZL_E_OUTPUT_TOO_SMALL;
     if (!d_out_res && stream->status == 0 && stream->out_len &&
         hipMemcpy((uint8_t *)h_out + stream->out_off, E0.stage_out.p, stream->out_len, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipSetDevice(g_device); set_error("D2H failed"); return SZL_E_DEVICE; }
+    (void)hipSetDevice(g_device);
+    return 0;
+}
+
+int szl_multi_release(void) {   // the engines (and their device memory) the multi-device entry points keep between calls
+    std::lock_guard<std::mutex> multi_lock(g_multi_mu);
+    for (auto &slot : g_multi_slots) if (slot.eng) { if (slot.device >= 0) (void)hipSetDevice(slot.device); szl_engine_destroy(slot.eng); slot.eng = nullptr; slot.device = -1; }
     (void)hipSetDevice(g_device);
     return 0;
 }

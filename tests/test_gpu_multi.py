@@ -178,3 +178,19 @@ def test_one_stream_resident_on_every_device(nslots):
     for b in d_ins:
         b.free()
     d_out.free()
+
+
+def test_multi_release_frees_the_pooled_engines_and_calls_work_again():
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import deflate_multi
+    bufs = _bufs(12, 21)
+    a = deflate_multi(bufs, _devs(3), level=6)
+    assert _lib.lib().szl_multi_release() == 0
+    b = deflate_multi(bufs, _devs(2), level=6)
+    assert [r.data for r in a] == [r.data for r in b] == [O.deflate(x, 6) for x in bufs]
+    # incompressible data: a token per byte — the gather buffer of the one-stream path starts at text density and has to grow
+    rnd = C.random_bytes(96 << 20, seed=4)
+    (r,) = deflate_multi([rnd], _devs(2), level=6, crc32=True)
+    assert r.status == 0 and r.crc32 == O.crc32(rnd)
+    import zlib
+    assert zlib.decompress(r.data, -15) == rnd.tobytes()
