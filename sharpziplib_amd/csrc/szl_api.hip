@@ -1225,10 +1225,16 @@ static int function_switch(szl_deflater *d, int level) {
         // if that is not empty, then UpdateHash() (:327-333)
         std::vector<L0Blk> blks;
         const int64_t wp0 = pend_abs + (int64_t)d->l0_dict;
+        L0State l0 = d->l0;                           // (replayed on a copy: the object is untouched if the call fails below)
         for (size_t i = 0; i < ndr; i++) {
             uint64_t avail = d->chunks[i];
-            while (l0_engine_deflate(d->l0, avail, false, false, blks)) { }
+            while (l0_engine_deflate(l0, avail, false, false, blks)) { }
         }
+        // ins_h = window[strstart] << 5 ^ window[strstart + 1] (:409).  The value itself never matters — FillWindow() calls UpdateHash()
+        // again as soon as three bytes of lookahead are there (:396-399) and InsertString() needs as many — but the READ does: with
+        // DeflateStored at one of the last two indices of a full window it is past the array, and the reference throws.
+        if ((int64_t)l0.strstart + 1 >= 2 * WSIZE) { set_error("SetLevel: the reference's UpdateHash() reads past its window array here (IndexOutOfRangeException, C/DeflaterEngine.cs:409)"); return SZL_E_INDEX; }
+        d->l0 = l0;
         if (d->l0.strstart > d->l0.blockStart) {
             blks.push_back(L0Blk{(uint64_t)(d->l0.blockStart - 1 + d->l0.base), (uint32_t)(d->l0.strstart - d->l0.blockStart), 0u});
             d->l0.blockStart = d->l0.strstart;
@@ -1236,10 +1242,6 @@ static int function_switch(szl_deflater *d, int level) {
         const int64_t X_w = (int64_t)d->l0.strstart - 1 + d->l0.base;
         const uint64_t X_rel = X_w > wp0 ? (uint64_t)(X_w - wp0) : 0;
         if (X_rel > d->pend.size()) { set_error("internal: level-0 replay ran past the pending bytes"); return SZL_E_STATE; }
-        // ins_h = window[strstart] << 5 ^ window[strstart + 1] (:409).  The value itself never matters — FillWindow() calls UpdateHash()
-        // again as soon as three bytes of lookahead are there (:396-399) and InsertString() needs as many — but the READ does: with
-        // DeflateStored at one of the last two indices of a full window it is past the array, and the reference throws.
-        if ((int64_t)d->l0.strstart + 1 >= 2 * WSIZE) { set_error("SetLevel: the reference's UpdateHash() reads past its window array here (IndexOutOfRangeException, C/DeflaterEngine.cs:409)"); return SZL_E_INDEX; }
         if (!blks.empty()) { if ((rc = stored_emit(d, blks, X_rel, false))) return rc; }
         look = (uint64_t)d->l0.lookahead;
         advance_history(d, X_rel, nullptr, false);      // stored bytes are in the window but in no hash chain
@@ -1288,6 +1290,7 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Defla
             if (d->level == 0 && d->l0.lookahead > 0) {  // DeflateStored takes the lookahead a coded function left in the window (:621-623)
                 uint64_t none = 0; std::vector<L0Blk> nb;
                 while (l0_engine_deflate(d->l0, none, false, false, nb)) { }
+                if (!nb.empty()) { set_error("internal: DeflateStored emitted a block from the lookahead alone"); return SZL_E_STATE; }   // (never: at most 261 bytes wait there)
             }
             break;
         }
