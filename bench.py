@@ -337,6 +337,50 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
         finally:
             e2.close()
     guarded("5_level9_logs", c5)
+
+    # ---- config 4 through the class it names: InflaterInputStream (host mirror of CS/InflaterInputStream.cs over the streaming C ABI),
+    # by the buffer size its constructor is given (:342-396).  Wall clock of Read() loops over a 128 MiB member, host buffers both ways.
+    def cstream():
+        import io
+        from sharpziplib_amd.inflater import Inflater
+        from sharpziplib_amd.streams import InflaterInputStream
+        m = 128 << 20
+        plain = gen_parallel("enwik", 6, m)
+        e2 = Engine()
+        try:
+            comp, comp_small = [r.data for r in e2.deflate([plain, plain[:8 << 20]], level=level)]
+        finally:
+            e2.close()
+
+        def read_all(member, n_out, bufsz, check):
+            inf = Inflater(True)
+            st = InflaterInputStream(io.BytesIO(member), inf, bufsz)
+            buf = np.zeros(4 << 20, np.uint8)
+            got, crc = 0, 0
+            t = time.perf_counter()
+            while True:
+                k = st.Read(buf, 0, buf.size)
+                if k <= 0:
+                    break
+                got += k
+                if check:
+                    crc = zlib.crc32(buf[:k].tobytes(), crc)
+            dt = time.perf_counter() - t
+            assert got == n_out and inf.TotalIn == len(member) and inf.RemainingInput == 0, "InflaterInputStream(%d)" % bufsz
+            if check:
+                assert crc == zlib.crc32(plain[:n_out].tobytes()), "InflaterInputStream(%d): bytes differ" % bufsz
+            return n_out / 2 ** 20 / dt, int(_lib.lib().szl_inflater_debug_bulk_calls(inf._h))
+        rates = {}
+        r, _ = read_all(comp_small, 8 << 20, 65536, False)
+        rates["64_KiB_buffer_mib_s"] = round(r, 1)                    # (one wavefront: an 8 MiB member is enough to see it)
+        for bufsz in (16 << 20, 64 << 20):
+            read_all(comp, m, bufsz, True)                            # checked, untimed (also the first call's allocations)
+            r, pieces = read_all(comp, m, bufsz, False)
+            rates["%d_MiB_buffer_mib_s" % (bufsz >> 20)] = round(r, 1)
+            rates["%d_MiB_buffer_parallel_pieces" % (bufsz >> 20)] = pieces
+        out["4s_InflaterInputStream_128MiB_member_by_buffer_size"] = dict(rates, checked="length, TotalIn, RemainingInput; CRC-32 of the bytes read (16 / 64 MiB buffers)",
+                                                                        note="wall clock incl. the host copies of the unchanged adapter path (DESIGN.md §5)")
+    guarded("4s_InflaterInputStream", cstream)
     return out
 
 
