@@ -164,7 +164,7 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
         out[name] = e
 
     t_begin = time.perf_counter()
-    budget_s = float(os.environ.get("SZL_BENCH_CONFIGS_BUDGET_S", "600"))   # the other configs never hold the headline up for longer than this
+    budget_s = float(os.environ.get("SZL_BENCH_CONFIGS_BUDGET_S", "300"))   # the other configs never hold the headline up for longer than this
 
     def guarded(name, fn):
         t = time.perf_counter()
