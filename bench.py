@@ -597,7 +597,7 @@ def run_weak(args, rank, local_rank, world, dist):
                          "whole_pass_frac": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK, 5)},
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (rank 0 at N = 1 only: the contract)
             import oracle_ffi as O
             sample = min(args.cpu_sample_mib << 20, n)
             t1 = time.perf_counter()
