@@ -320,6 +320,30 @@ int szo_iht_symbol(const int16_t *tree, int treeSize, uint32_t bits, int avail, 
     return sym;
 }
 
+/* Test hook (tests/test_reftree.py): a script of StreamManipulator / GetSymbol operations on one SetInput(buf, 0, n) — the device's
+ * emulation of the bit buffer (csrc/szl_inflate_reftree.h ExSM) runs the same script.  ops[2i] = 0 PeekBits(arg), 1 DropBits(arg),
+ * 2 SkipToByteBoundary, 3 AvailableBits, 4 AvailableBytes, 5 GetSymbol(tree); results[i] = the value returned (0 for void). */
+int szo_sm_script(const uint8_t *buf, int n, const int32_t *ops, int nops, const int16_t *tree, int treeSize, int32_t *results) {
+    SM in; sm_reset(&in);
+    if (sm_set_input(&in, buf, 0, n) < 0) return -1;
+    IHT t; t.tree = (int16_t *)tree; t.treeSize = treeSize;
+    for (int i = 0; i < nops; i++) {
+        const int op = ops[2 * i], arg = ops[2 * i + 1];
+        int r = 0;
+        switch (op) {
+        case 0: r = sm_peek(&in, arg); break;
+        case 1: sm_drop(&in, arg); break;
+        case 2: sm_skip_to_byte(&in); break;
+        case 3: r = in.bitsInBuffer_; break;
+        case 4: r = sm_available_bytes(&in); break;
+        case 5: r = iht_get_symbol(&t, &in); break;
+        default: return -2;
+        }
+        results[i] = r;
+    }
+    return 0;
+}
+
 /* ================================================================= InflaterDynHeader.cs
  * The C# iterator state machine (:42-120) restated as an explicit resumable state machine. */
 static const int MetaCodeLengthIndex[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};

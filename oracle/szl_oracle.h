@@ -125,6 +125,7 @@ int szo_quirk_sets_seen(int reset);
 /* test hooks: BuildTree's table (returns treeSize or an error) and one GetSymbol with `avail` bits of input left */
 int szo_iht_table(const uint8_t *codeLengths, int n, int16_t *out, int cap);
 int szo_iht_symbol(const int16_t *tree, int treeSize, uint32_t bits, int avail, int *dropped);
+int szo_sm_script(const uint8_t *buf, int n, const int32_t *ops, int nops, const int16_t *tree, int treeSize, int32_t *results);
 /* Same, asking for one byte per Inflate() call: *produced = bytes delivered before the error (or in total). */
 int64_t szo_inflate_probe(const uint8_t *in, size_t n, int no_header, uint8_t *out, size_t out_cap, size_t *consumed,
                           size_t *produced);

@@ -115,4 +115,69 @@ SZL_RT_FN int rt_get_symbol(const int16_t *tree, uint32_t bits, uint32_t avail) 
     return RT_NEED_INPUT;
 }
 
+// ---- the reference's StreamManipulator (CS/StreamManipulator.cs) as k_inflate_exact runs it: a 32-bit buffer filled 16 bits at a
+// time, DropBits that does not look (so bitsInBuffer_ can go negative when GetSymbol drops a garbage entry's bit count after peeking
+// 9 bits), PeekBits that then shifts what it loads by a negative count (C# masks shift counts to 5 bits).  Plain C++ like the table
+// code above: tests/test_reftree.py runs random peek / drop scripts against the oracle's StreamManipulator.
+struct ExSM {            // CS/StreamManipulator.cs
+    const uint8_t *in; uint64_t we;     // window_, windowEnd_
+    uint64_t ws;                        // windowStart_
+    uint32_t buffer; int32_t bits;      // buffer_, bitsInBuffer_
+    uint32_t lazy;                      // see the header: the 16 bits a peek before the block may already have loaded
+    int32_t dirty;                      // > 0: bits still to be dropped before the buffer holds nothing but stream bits again
+};
+SZL_RT_FN uint32_t ex_load16(ExSM &s) {
+    const uint32_t lo = s.ws < s.we ? s.in[s.ws] : 0u, hi = s.ws + 1 < s.we ? s.in[s.ws + 1] : 0u;
+    s.ws += 2;
+    return lo | (hi << 8);
+}
+SZL_RT_FN int ex_peek(ExSM &s, int n) {   // :31-48
+    if (s.bits < n) {
+        if (s.ws >= s.we) return -1;
+        const uint32_t v = ex_load16(s);
+        s.buffer |= (uint32_t)((int32_t)v << (s.bits & 31));
+        s.bits += 16;
+        s.lazy = 0;
+    }
+    return (int)(s.buffer & ((1u << (n & 31)) - 1u));
+}
+SZL_RT_FN void ex_drop(ExSM &s, int k) {  // :86-90
+    if (s.lazy && k > s.bits && s.ws < s.we) { const uint32_t v = ex_load16(s); s.buffer |= v << (s.bits & 31); s.bits += 16; s.lazy = 0; }
+    if (k > s.bits) s.dirty = 32 + 16; else if (s.dirty > 0) s.dirty -= k;
+    s.buffer >>= (k & 31);
+    s.bits -= k;
+}
+SZL_RT_FN int64_t ex_available_bytes(const ExSM &s) { return (int64_t)s.we - (int64_t)s.ws + (int64_t)(s.bits >> 3); }  // :131
+
+// GetSymbol (C/InflaterHuffmanTree.cs:181-235) on the live bit buffer.  >= 0 symbol, -1 need input, -2 "invalid codelength 0"
+SZL_RT_FN int ex_get_symbol(const int16_t *tree, ExSM &s) {
+    int lookahead, symbol;
+    if ((lookahead = ex_peek(s, 9)) >= 0) {
+        symbol = tree[lookahead];
+        const int bitlen = symbol & 15;
+        if (symbol >= 0) {
+            if (bitlen == 0) return -2;
+            ex_drop(s, bitlen);
+            return symbol >> 4;
+        }
+        const int subtree = -(symbol >> 4);
+        if ((lookahead = ex_peek(s, bitlen)) >= 0) {
+            symbol = tree[subtree | (lookahead >> 9)];
+            ex_drop(s, symbol & 15);
+            return symbol >> 4;
+        }
+        const int bits = s.bits;
+        lookahead = ex_peek(s, bits);
+        symbol = tree[subtree | (lookahead >> 9)];
+        if ((symbol & 15) <= bits) { ex_drop(s, symbol & 15); return symbol >> 4; }
+        return -1;
+    }
+    const int bits = s.bits;
+    lookahead = ex_peek(s, bits);
+    symbol = tree[lookahead & 511];
+    if (symbol >= 0 && (symbol & 15) <= bits) { ex_drop(s, symbol & 15); return symbol >> 4; }
+    return -1;
+}
+
+
 } // namespace szl

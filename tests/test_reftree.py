@@ -25,6 +25,8 @@ def rt(tmp_path_factory):
     L.rt_symbol.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
     L.rt_quirk.restype = ctypes.c_int
     L.rt_quirk.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.rt_sm_script.restype = ctypes.c_int
+    L.rt_sm_script.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     return L
 
 
@@ -95,3 +97,50 @@ def test_capacity_bound_holds():
         if sz > 0:
             worst = max(worst, sz)
     assert worst <= 1024
+
+
+def test_bit_buffer_scripts_equal_the_oracles_streammanipulator(rt):
+    """The emulation of StreamManipulator k_inflate_exact decodes with (ExSM: 16-bit loads, the odd first byte, DropBits that does not
+    look, PeekBits shifting by a negative count) against the oracle's restatement, on random scripts: peeks of 1-16 bits, drops of what
+    was peeked — and, every so often, of MORE than the buffer holds (what GetSymbol does with a garbage table entry) —, byte alignment,
+    the counters.  (GetSymbol on a clean buffer is covered above; on a buffer that has underflowed the reference indexes its table
+    with whatever the negative count masks out of the buffer — an IndexOutOfRangeException in C#, nothing to compare.)"""
+    ORA = _oracle()
+    ORA.szo_sm_script.restype = ctypes.c_int
+    ORA.szo_sm_script.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(0x5A)
+    underflows = 0
+    for case in range(400):
+        n = int(rng.integers(2, 300))
+        buf = rng.integers(0, 256, size=n + 8, dtype=np.uint8)      # (slack behind the input: neither side may read it)
+        # a table with the reference's quirks for GetSymbol
+        tree = np.zeros(4096, dtype=np.int16)
+        while True:
+            lens = _random_set(rng, 286, ["drop", "longer"][case % 2])
+            if ORA.szo_iht_table(lens.ctypes.data, 286, tree.ctypes.data, tree.size) > 0:
+                break
+        tsz = ORA.szo_iht_table(lens.ctypes.data, 286, tree.ctypes.data, tree.size)
+        ops = []
+        bits_known = 0
+        for k in range(int(rng.integers(5, 120))):
+            r = rng.random()
+            if r < 0.35:
+                a = int(rng.integers(1, 17)); ops += [0, a]
+            elif r < 0.6:
+                ops += [1, int(rng.integers(0, 10))]
+            elif r < 0.68:
+                ops += [1, int(rng.integers(10, 16))]; underflows += 1     # may exceed what the buffer holds
+            elif r < 0.73:
+                ops += [2, 0]
+            elif r < 0.8:
+                ops += [3, 0]
+            else:
+                ops += [4, 0]
+        ops = np.array(ops, dtype=np.int32)
+        nops = ops.size // 2
+        want = np.zeros(nops, dtype=np.int32); got = np.zeros(nops, dtype=np.int32)
+        assert ORA.szo_sm_script(buf.ctypes.data, n, ops.ctypes.data, nops, tree.ctypes.data, tsz, want.ctypes.data) == 0
+        assert rt.rt_sm_script(buf.ctypes.data, n, ops.ctypes.data, nops, tree.ctypes.data, got.ctypes.data) == 0
+        bad = np.flatnonzero(want != got)
+        assert bad.size == 0, (case, n, int(bad[0]), ops[2 * bad[0]:2 * bad[0] + 2].tolist(), int(want[bad[0]]), int(got[bad[0]]), ops[:2 * bad[0] + 2].reshape(-1, 2).tolist()[-8:])
+    assert underflows > 500
