@@ -1,0 +1,48 @@
+"""The product's MACHINE CODE on the CPU: tools/gfxsim interprets the gfx950 assembly of every kernel (hipcc -S of the same
+sources, same flags) under the product's own host objects linked against a fake HIP runtime, and the results are compared with
+the oracle exactly as the GPU tests do (levels 0-9, data classes, the streaming objects with SetLevel / Reset / dictionary,
+Inflater on valid, corrupted and quirk-set streams).  Each suite of tools/gfxsim/suite.py runs in its own process (the
+interpreter replaces the package's library handle; the other CPU tests must keep seeing the real one), all of them at once.
+
+This is evidence about the instruction text, not about the chip: no timing, no inter-wavefront memory ordering, and the LDS
+exchange order of DESIGN 4.1 is modelled, not proved.  The GPU tests (-m gpu) stay the parity tests proper.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUITES = ["deflate_levels", "deflate_shapes", "deflater_object", "inflate", "inflate_corrupt"]
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc is needed for the device assembly")
+
+
+@pytest.fixture(scope="module")
+def runs():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gfxsim import harness
+    harness.build()                                   # libszl_amd.so's objects, the fake runtime, the kernels' assembly (cached)
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    env.pop("SZL_DEBUG", None)
+    procs = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s], cwd=ROOT, env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for s in SUITES}
+    yield procs
+    for p in procs.values():
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.parametrize("suite", SUITES)
+def test_machine_code_equals_oracle(runs, suite):
+    p = runs[suite]
+    try:
+        out, _ = p.communicate(timeout=1500)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        pytest.fail("suite %s did not finish" % suite)
+    assert p.returncode == 0 and ("ok %s:" % suite) in out, out[-4000:]
+    print(out.strip().splitlines()[-1])

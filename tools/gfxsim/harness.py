@@ -72,8 +72,10 @@ _CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_char_p, ctypes.c_uint, ctypes.c_ui
                        ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t)
 
 
-def attach(verbose=False):
-    """-> (Runtime, product C ABI through the simulated device).  Idempotent."""
+def attach(verbose=False, fast_probe=False):
+    """-> (Runtime, product C ABI through the simulated device).  Idempotent.
+    fast_probe: k_probe_xchg_order (once per process, 512 rounds = 4.7 M instructions, 20 s here) runs 8 rounds instead — the
+    interpreter serves an exchange in ascending lane order by construction, the probe has nothing to find out about it."""
     if "rt" in _state:
         return _state["rt"], _state["lib"]
     sim = build()
@@ -100,6 +102,8 @@ def attach(verbose=False):
             vals = []
             for i, a in enumerate(explicit):
                 vals.append(ctypes.string_at(args[i], a[".size"]))
+            if fast_probe and "k_probe_xchg_order" in kname:
+                vals[0] = (8).to_bytes(4, "little")
             if rt.verbose:
                 print("[gfxsim] %s grid=(%d,%d,%d) block=(%d,%d,%d) lds+%d" % (kname[:110], gx, gy, gz, bx, by, bz, shmem), flush=True)
             rt.launch(kname, (gx, gy, gz), (bx, by, bz), vals, dyn_lds=shmem)
@@ -118,9 +122,9 @@ def attach(verbose=False):
     return rt, lib
 
 
-def use():
+def use(fast_probe=False):
     """route sharpziplib_amd's mirrors (Engine, Deflater, Inflater ...) through the simulated device"""
-    rt, lib = attach()
+    rt, lib = attach(fast_probe=fast_probe)
     from sharpziplib_amd import _lib as L
     L._lib = lib
     return rt

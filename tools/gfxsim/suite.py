@@ -1,0 +1,242 @@
+"""gfxsim.suite — parity cases of the product's MACHINE CODE on the CPU interpreter, against the oracle.
+
+    python tools/gfxsim/suite.py <suite> [...]        (run from the repo root; `list` names the suites)
+
+Every case goes through the product's C ABI (libszl_amd's own host objects linked against the fake runtime) and the gfx950
+assembly of its kernels, interpreted instruction by instruction; the expected bytes come from oracle/ exactly as in the GPU
+tests — whose helpers these suites reuse with small sizes.  What the interpreter cannot show: timing, memory-ordering between
+wavefronts, hardware behaviour outside the ISA text (DESIGN 4.1's exchange order is MODELLED as ascending here, not proved).
+Test infrastructure only; tests/test_sim_product_code.py runs each suite in its own process.
+"""
+import os
+import sys
+import time
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np                                   # noqa: E402
+
+
+def _attach():
+    from gfxsim import harness
+    rt = harness.use(fast_probe=True)
+    return harness, rt
+
+
+def _classes():
+    from sharpziplib_amd import corpus as C
+    return {"dickens": lambda n: C.generate("dickens", 0xD1CE, 0, n), "logs": lambda n: C.generate("logs", 0x106, 0, n),
+            "random": lambda n: C.random_bytes(n), "zeros": lambda n: C.zeros(n), "acgt": lambda n: C.four_symbol(n),
+            "p10": lambda n: C.period10(n), "mixed": lambda n: C.mixed(n)}
+
+
+def suite_deflate_levels():
+    """the batch entry point, levels 0-9 x data classes, raw and zlib framing, checksums"""
+    import oracle_ffi as O
+    from sharpziplib_amd.batch import Engine
+    e = Engine()
+    cl = _classes()
+    n = 0
+    for name in ("dickens", "logs", "random", "mixed"):
+        data = cl[name](2000)
+        for lv in range(10):
+            r = e.deflate([data], level=lv, crc32=True, adler32=True)[0]
+            assert r.status == 0 and r.data == O.deflate(data, lv), (name, lv)
+            assert r.crc32 == O.crc32(data) and r.adler32 == O.adler32(data), (name, lv)
+            n += 1
+    for lv in (1, 6):
+        data = cl["dickens"](1500)
+        r = e.deflate([data], level=lv, nowrap=False)[0]
+        assert r.data == O.deflate(data, lv, nowrap=False) and zlib.decompress(r.data) == data.tobytes()
+        n += 1
+    e.close()
+    return n
+
+
+def suite_deflate_shapes():
+    """several streams in one call, the tiny vectors of the reference's behaviour, sizes around MIN_LOOKAHEAD, strategies"""
+    import oracle_ffi as O
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd import corpus as C
+    e = Engine()
+    n = 0
+    for data, hexout in [(b"", "0300"), (b"x", "ab0000"), (b"Hello", "f348cdc9c90700"), (b"Hello, world", "f348cdc9c9d75128cf2fca490100"),
+                         (b"a" * 32, "4b240000"), (b"abc" * 10, "4b4c4ac68300"), (b"testfile contents\n", "2b492d2e49cbcc495548cecf2b49cd2b29e60200")]:
+        assert e.deflate([data], level=6)[0].data.hex() == hexout, data
+        n += 1
+    sizes = [0, 1, 2, 3, 4, 261, 262, 263, 700, 1031]
+    bufs = [C.generate("dickens", 21 + i, 0, s) if s else np.zeros(0, np.uint8) for i, s in enumerate(sizes)]
+    for lv in (1, 6, 9):
+        res = e.deflate(bufs, level=lv, crc32=True)
+        for b, r in zip(bufs, res):
+            assert r.status == 0 and r.data == O.deflate(b, lv) and r.crc32 == O.crc32(b), (lv, b.size)
+            n += 1
+    data = C.mixed(3000)
+    for strategy in (1, 2):
+        for lv in (3, 6):
+            r = e.deflate([data], level=lv, strategy=strategy)[0]
+            assert r.data == O.deflate(data, lv, strategy=strategy), (strategy, lv)
+            n += 1
+    e.close()
+    return n
+
+
+def suite_deflater_object():
+    """the streaming Deflater: SetInput pieces, Flush, SetLevel / SetStrategy in mid-stream (all three compression functions),
+    Reset with stale bits, a preset dictionary — tests/test_gpu_setlevel.py's driver with small totals"""
+    import oracle_ffi as O
+    import test_gpu_setlevel as TS
+    import test_gpu_reset_bits as TR
+    from sharpziplib_amd import corpus as C
+    from sharpziplib_amd.deflater import Deflater
+    small = (1, 3, 100, 261, 262, 263, 700, 1500)
+    n = 0
+    for levels, seed, kw in (([5, 6, 7, 8, 9], 1, {}), ([5, 6, 9], 11, dict(strategies=(0, 1, 2))), ([1, 2, 3, 4], 21, dict(strategies=(0, 2))),
+                             ([1, 2, 3, 4, 5, 6, 7, 9], 41, dict(flush_p=0.4, cross_kind_at_flush=True)),
+                             ([1, 2, 3, 4, 5, 6, 7, 9], 51, dict(cross_p=0.7)), ([0, 1, 3, 4, 5, 6, 9], 61, dict(cross_p=0.8)),
+                             ([0, 2, 6], 81, dict(cross_p=0.9, flush_p=0.05))):
+        TS._run(levels, seed, total=7000, chunk_sizes=small, **kw)
+        n += 1
+    for level, nowrap in ((6, True), (1, False)):
+        d, o = Deflater(level, nowrap), O.Deflater(level, nowrap)
+        a = C.generate("enwik", 3, 0, 1234)
+        d.SetInput(a); o.set_input(a)
+        d.Flush(); o.flush()
+        got, ref = TR._drain(d, o)
+        assert got == ref
+        b = C.generate("logs", 53, 0, 2100)
+        TR._second_stream(d, o, b, "level %d" % level)
+        TR._second_stream(d, o, a[:777], "level %d (after Finish)" % level)
+        n += 1
+    # preset dictionary (C/Deflater.cs:407-421 -> C/DeflaterEngine.cs:198-229)
+    dic = C.generate("dickens", 5, 0, 900)
+    data = np.concatenate([dic[300:700], C.generate("dickens", 6, 0, 1500)])
+    for level in (1, 6):
+        d, o = Deflater(level, False), O.Deflater(level, False)
+        d.SetDictionary(dic); o.set_dictionary(dic)
+        d.SetInput(data); o.set_input(data)
+        d.Finish(); o.finish()
+        got, ref = TR._drain(d, o)
+        assert got == ref, ("dictionary", level)
+        n += 1
+    return n
+
+
+def suite_inflate():
+    """the batch Inflater and the streaming object on streams of several encoders and block mixes; gzip / zlib framing"""
+    import oracle_ffi as O
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd.inflater import Inflater
+    from sharpziplib_amd import corpus as C
+    e = Engine()
+    n = 0
+    text = C.generate("dickens", 0xD1CE, 0, 6000)
+    members = []
+    for lv in (0, 1, 6, 9):
+        co = zlib.compressobj(lv, zlib.DEFLATED, -15)
+        members.append((text, co.compress(text.tobytes()) + co.flush()))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+    members.append((text, co.compress(text.tobytes()) + co.flush()))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)                        # flush mix: sync-flushed pieces, a stored block in between
+    mix = co.compress(text[:2000].tobytes()) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(text[2000:4000].tobytes()) + co.flush(zlib.Z_FULL_FLUSH) + \
+        co.compress(text[4000:].tobytes()) + co.flush()
+    members.append((text, mix))
+    for name in ("logs", "random", "zeros", "mixed"):
+        d = _classes()[name](3000)
+        members.append((d, O.deflate(d, 6)))
+    res = e.inflate([m for _, m in members], [d.size for d, _ in members], crc32=True)
+    for (d, m), (r, used) in zip(members, res):
+        assert r.status == 0 and r.data == d.tobytes() and used == len(m) and r.crc32 == zlib.crc32(d.tobytes())
+        n += 1
+    # trailing bytes are not consumed; zlib framing with Adler-32
+    z = zlib.compress(text.tobytes(), 6) + b"TRAILER"
+    (r, used), = e.inflate([z], [text.size], nowrap=False, adler32=True)
+    assert r.status == 0 and r.data == text.tobytes() and used == len(z) - 7 and r.adler32 == zlib.adler32(text.tobytes())
+    n += 1
+    # the streaming object: input in pieces, output in small calls, RemainingInput exact
+    inf = Inflater(True)
+    comp = members[2][1] + b"xyz"
+    out = bytearray()
+    buf = bytearray(700)
+    pos = 0
+    while not inf.IsFinished:
+        if inf.IsNeedingInput:
+            inf.SetInput(comp[pos:pos + 500]); pos += 500
+        k = inf.Inflate(buf)
+        out += buf[:k]
+    assert bytes(out) == text.tobytes() and inf.TotalOut == text.size
+    assert inf.TotalIn == len(comp) - 3, (inf.TotalIn, len(comp))
+    n += 1
+    e.close()
+    return n
+
+
+def suite_inflate_corrupt():
+    """hand-assembled and corrupted streams, the code sets the reference's table decodes differently (k_inflate_exact) included:
+    status, bytes and in_consumed against the oracle — tests/test_gpu_inflate_fuzz.py's generators and comparison on a sample"""
+    import oracle_ffi as O
+    import corrupt_streams as CS
+    import test_gpu_inflate_fuzz as TF
+    from sharpziplib_amd import corpus as C
+    from sharpziplib_amd.batch import Engine
+    e = Engine()
+    TF.CAP = 8192
+    rng = np.random.default_rng(20260922)
+    valid = []
+    for kind, seed, n in (("dickens", 11, 1500), ("logs", 13, 2500)):
+        d = C.generate(kind, seed, 0, n)
+        valid += [("%s_L6" % kind, O.deflate(d, 6)), ("%s_L1" % kind, O.deflate(d, 1)), ("%s_L9_flush" % kind, O.deflate(d, 9, flush=True))]
+    valid.append(("random_stored", O.deflate(C.random_bytes(900, seed=5), 6)))
+    valid.append(("tiny_static", O.deflate(np.frombuffer(b"hello hello hello hello", np.uint8), 6)))
+    cases = CS.crafted() + valid + CS.mutations(valid, rng, n_flip=6, n_trunc=2)
+    for name, s in valid:                                     # flips in the header region (code-length sets, repeat errors)
+        b = np.frombuffer(s, np.uint8)
+        for k in range(6):
+            pos = int(rng.integers(0, min(b.size, 60) * 8))
+            m = b.copy(); m[pos >> 3] ^= 1 << (pos & 7)
+            cases.append(("%s_hdrflip@%d" % (name, pos), m.tobytes()))
+    TF.QUIRKS.clear()
+    quirk = CS.crafted_long_code_incomplete() + CS.quirk_set_streams(np.random.default_rng(0xA16A16), 60)
+    fails = TF._run_batch(e, cases + quirk)
+    assert not fails, "%d of %d differ:\n%s" % (len(fails), len(cases) + len(quirk), "\n".join(fails[:10]))
+    assert len(TF.QUIRKS) > 20, len(TF.QUIRKS)                # the class k_inflate_exact exists for
+    stream_cases = cases[::5] + quirk[::4]
+    fails = TF._run_streaming(stream_cases)
+    assert not fails, "\n".join(fails[:10])
+    e.close()
+    return len(cases) + len(quirk) + len(stream_cases)
+
+
+SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
+          "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt}
+
+
+def main(argv):
+    if not argv or argv[0] == "list":
+        print("\n".join(SUITES))
+        return 0
+    harness, rt = _attach()
+    rc = 0
+    for name in argv:
+        t = time.time()
+        try:
+            n = SUITES[name]()
+            instr = sum(sum(v.values()) for v in rt.stats.values())
+            print("ok %s: %d cases, %.0f s, %d kernel launches, %.1f M wave instructions interpreted" % (name, n, time.time() - t, len(rt.launches), instr / 1e6), flush=True)
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            for msg in harness.errors()[-3:]:
+                print("  [gfxsim] " + msg)
+            print("FAILED %s" % name, flush=True)
+            rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
