@@ -212,8 +212,107 @@ def suite_inflate_corrupt():
     return len(cases) + len(quirk) + len(stream_cases)
 
 
+def _knobs(**kw):
+    from sharpziplib_amd import _lib
+    for k, v in kw.items():
+        _lib.lib().szl_debug_set(k.encode(), int(v))
+
+
+FORGET = -2147483648
+
+
+def suite_forms():
+    """the forms the defaults do not take at small sizes: the window pipeline of long streams (64 KiB windows), stage B's other
+    forms (k_match4, the on-demand walk), stage A's bucketed form (k_links2), ranges that never merge (zeros / periodic data)"""
+    import oracle_ffi as O
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd import corpus as C
+    n = 0
+    text = C.generate("enwik", 0xE9, 0, 100000)
+    try:
+        _knobs(SZL_WINDOW_KIB=64, SZL_WINDOW_FROM_KIB=0)
+        e = Engine()
+        for data, lv in ((text, 6), (C.zeros(90000), 9)):
+            r = e.deflate([data], level=lv, crc32=True)[0]
+            assert r.status == 0 and r.data == O.deflate(data, lv) and r.crc32 == O.crc32(data), ("window", lv)
+            n += 1
+        e.close()
+    finally:
+        _knobs(SZL_WINDOW_KIB=256 * 1024, SZL_WINDOW_FROM_KIB=2048 * 1024)
+    small = C.generate("dickens", 3, 0, 24000)
+    for knobs, levels in ((dict(SZL_B9=0), (6, 9)), (dict(SZL_LINKS=2), (6,)), (dict(SZL_MATCH_MODE=1), (9,))):
+        try:
+            _knobs(**knobs)
+            e = Engine()
+            if "SZL_MATCH_MODE" in knobs:
+                e.debug_match_mode(1)                      # the on-demand walk (k_match_lazy), forced
+            for lv in levels:
+                r = e.deflate([small], level=lv)[0]
+                assert r.status == 0 and r.data == O.deflate(small, lv), (knobs, lv)
+                n += 1
+            e.close()
+        finally:
+            _knobs(**{k: FORGET for k in knobs})
+    e = Engine()
+    for data, lv in ((C.zeros(40000), 6), (C.period10(30000), 9), (C.four_symbol(20000), 6)):
+        r = e.deflate([data], level=lv)[0]
+        assert r.status == 0 and r.data == O.deflate(data, lv), ("never merging", lv)
+        n += 1
+    e.close()
+    return n
+
+
+def suite_inflate_parallel():
+    """one member on many wavefronts (finder, chunk jobs, window chain, convert) with 16 KiB chunks, against the one-wavefront
+    decoder and the input; a damaged member steps aside with the reference's status; the streaming object's long-input path"""
+    import oracle_ffi as O
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd.inflater import Inflater
+    from sharpziplib_amd import corpus as C
+    n = 0
+    e = Engine()
+    try:
+        data = C.generate("enwik", 0xE9, 0, 360000)         # (a member needs 8 chunks of 16 KiB and 4 block starts found to go parallel)
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 4)     # memLevel 4: a block every 1024 tokens
+        members = [("zlib6_small_blocks", co.compress(data.tobytes()) + co.flush())]
+        for name, m in members:
+            assert len(m) > 131072
+            _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64)
+            (r, used), = e.inflate([m], [data.size], crc32=True)
+            jobs = int(_lib.lib().szl_engine_debug_par_jobs(e._h))
+            assert jobs >= 4, jobs
+            assert r.status == 0 and r.data == data.tobytes() and used == len(m) and r.crc32 == zlib.crc32(data.tobytes()), name
+            n += 1
+        bad = bytearray(members[0][1]); bad[90000] ^= 0x10
+        (rp, up), = e.inflate([bytes(bad)], [data.size])
+        _knobs(SZL_INF_PAR_MIN_KIB=1 << 22)
+        (rs, us), = e.inflate([bytes(bad)], [data.size])
+        assert (rp.status, up, rp.data) == (rs.status, us, rs.data)
+        no, delivered, cons = O.inflate_probe(bytes(bad), max_out=data.size)
+        assert (no >= 0) == (rs.status == 0)
+        n += 1
+        # the streaming Inflater given the whole member at once (SetInput >= the bulk threshold)
+        _knobs(SZL_INF_PAR_MIN_KIB=64, SZL_INF_STREAM_BULK_KIB=64)
+        inf = Inflater(True)
+        inf.SetInput(members[0][1] + b"tail")
+        out = bytearray()
+        buf = bytearray(50000)
+        while not inf.IsFinished:
+            k = inf.Inflate(buf)
+            assert k > 0
+            out += buf[:k]
+        assert bytes(out) == data.tobytes() and inf.RemainingInput == 4 and inf.TotalIn == len(members[0][1])
+        n += 1
+    finally:
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_STREAM_BULK_KIB=FORGET)
+        e.close()
+    return n
+
+
 SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
-          "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt}
+          "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt,
+          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel}
 
 
 def main(argv):
