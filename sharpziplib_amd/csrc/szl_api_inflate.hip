@@ -21,6 +21,7 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
 void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st);
+int inflate_slots_per_cu();
 void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st);
 int launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem,
                         const ResGroup *groups, uint32_t ngroups, const uint32_t *gfirst, bool chained, uint16_t *gmaps, uint8_t *ewins, hipStream_t st);
@@ -135,7 +136,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        const uint64_t slots = 8ull * (uint64_t)cus;
+        const uint64_t slots = (uint64_t)inflate_slots_per_cu() * (uint64_t)cus;
         const uint64_t rounds = std::max<uint64_t>(1, (total_in + slots * (192ull << 10) - 1) / (slots * (192ull << 10)));
         chunk_max = std::min<uint64_t>(std::max<uint64_t>((total_in / (slots * rounds) + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
     }

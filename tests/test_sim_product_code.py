@@ -15,7 +15,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["forms", "inflate_parallel", "deflate_levels", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate"]   # longest first
+SUITES = ["forms", "inflate_parallel", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate"]   # longest first
 HIPCC = "/opt/rocm/bin/hipcc"
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc is needed for the device assembly")
