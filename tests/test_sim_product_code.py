@@ -1,7 +1,7 @@
 """The product's MACHINE CODE on the CPU: tools/gfxsim interprets the gfx950 assembly of every kernel (hipcc -S of the same
 sources, same flags) under the product's own host objects linked against a fake HIP runtime, and the results are compared with
 the oracle exactly as the GPU tests do (levels 0-9, data classes, the streaming objects with SetLevel / Reset / dictionary,
-Inflater on valid, corrupted and quirk-set streams, one member on many wavefronts, the window pipeline and stage A / B's other forms).  Each suite of tools/gfxsim/suite.py runs in its own process (the
+Inflater on valid, corrupted and quirk-set streams, one member on many wavefronts, the window pipeline and stage A / B's other forms, two devices behind the multi-device entry points).  Each suite of tools/gfxsim/suite.py runs in its own process (the
 interpreter replaces the package's library handle; the other CPU tests must keep seeing the real one), all of them at once.
 
 This is evidence about the instruction text, not about the chip: no timing, no inter-wavefront memory ordering, and the LDS
@@ -15,7 +15,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["forms", "inflate_parallel", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate"]   # longest first
+SUITES = ["forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate"]   # longest first
 HIPCC = "/opt/rocm/bin/hipcc"
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc is needed for the device assembly")

@@ -331,9 +331,56 @@ def suite_inflate_dense():
     return 1
 
 
+def suite_multi_device():
+    """two (fake) devices behind the C ABI: streams split into groups (szl_deflate_batch_multi_host / szl_inflate_batch_multi_host, one
+    host thread and engine per device), ONE stream cut into position-range units with warm-up and hand-over check
+    (stream_multi_run), a bad ordinal, szl_multi_release — the host logic of SURVEY 8e with distinct ordinals"""
+    import oracle_ffi as O
+    from gfxsim import harness
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import deflate_multi, inflate_multi
+    from sharpziplib_amd import corpus as C
+    harness._state["fake"].fakehip_set_device_count(2)
+    assert _lib.lib().szl_device_count() == 2
+    n = 0
+    rng = np.random.default_rng(7)
+    bufs = [C.generate(("dickens", "logs", "enwik")[i % 3], 500 + i, 0, int(rng.integers(0, 2500))) for i in range(7)]
+    for devices in ([0, 1], [1, 0, 1]):
+        res = deflate_multi(bufs, devices, level=6, crc32=True)
+        for b, r in zip(bufs, res):
+            assert r.status == 0 and r.data == O.deflate(b, 6) and r.crc32 == O.crc32(b), devices
+        n += 1
+    comp = [r.data for r in res]
+    back = inflate_multi(comp, [b.size for b in bufs], [1, 0], crc32=True)
+    for b, c, (r, used) in zip(bufs, comp, back):
+        assert r.status == 0 and r.data == b.tobytes() and used == len(c) and r.crc32 == O.crc32(b)
+    n += 1
+    res = deflate_multi([bufs[1], np.zeros(0, np.uint8)], [0, 1, 0, 1], level=9)          # fewer streams than device slots, an empty stream
+    assert [r.data for r in res] == [O.deflate(bufs[1], 9), O.deflate(np.zeros(0, np.uint8), 9)]
+    n += 1
+    try:
+        deflate_multi([b"abc"], [0, 2])
+        raise AssertionError("ordinal 2 of 2 devices was accepted")
+    except _lib.SzlError:
+        n += 1
+    try:
+        _knobs(SZL_PART_MIN_KIB=64, SZL_WINDOW_KIB=64, SZL_PART_WARM_KIB=64)
+        data = C.generate("enwik", 0x5EED, 0, 180000)
+        (r,) = deflate_multi([data], [0, 1], level=6, crc32=True)
+        assert r.status == 0 and r.crc32 == O.crc32(data) and r.data == O.deflate(data, 6)
+        n += 1
+    finally:
+        _knobs(SZL_PART_MIN_KIB=FORGET, SZL_WINDOW_KIB=FORGET, SZL_PART_WARM_KIB=FORGET)
+    assert _lib.lib().szl_multi_release() == 0
+    res = deflate_multi(bufs[:3], [1, 0], level=6)
+    assert [r.data for r in res] == [O.deflate(b, 6) for b in bufs[:3]]
+    n += 1
+    return n
+
+
 SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
           "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt,
-          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense}
+          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device}
 
 
 def main(argv):
