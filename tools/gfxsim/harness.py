@@ -96,6 +96,7 @@ def attach(verbose=False, fast_probe=False):
 
     def on_launch(name, gx, gy, gz, bx, by, bz, args, shmem):
         try:
+            np.seterr(over="ignore", invalid="ignore", divide="ignore")     # (numpy's error state is per thread: the engine launches from worker threads too)
             kname = name.decode()
             mod, k = rt.kernels[kname]
             explicit = [a for a in k.args if not a.get(".value_kind", "").startswith("hidden_")]
