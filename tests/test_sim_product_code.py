@@ -26,7 +26,7 @@ def runs():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from gfxsim import harness
     harness.build()                                   # libszl_amd.so's objects, the fake runtime, the kernels' assembly (cached)
-    env = dict(os.environ, PYTHONHASHSEED="0")
+    env = dict(os.environ, PYTHONHASHSEED="0", GFXSIM_POISON="1")   # LDS and fresh device memory start as garbage, as on the device
     env.pop("SZL_DEBUG", None)
     procs = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s], cwd=ROOT, env=env,
                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for s in SUITES}

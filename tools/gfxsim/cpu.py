@@ -519,6 +519,8 @@ class Wave:
                     fn = I.fn = decode(self.mod, I, self.pc - 1)
                 if self.trace is not None:
                     self.trace(self, I)
+                if self.mem.shadow is not None:
+                    self.mem.where = (self.kernel.name, I.line)
                 fn(self)
                 n += 1
                 c = I.cls
@@ -1352,6 +1354,22 @@ def _decode_scratch(mod, I, rest):
     return None
 
 
+def _lds_rd(w, a, n):
+    """memcheck: LDS is not cleared between workgroups on the device — a read of bytes this workgroup has not written sees leftovers"""
+    d = w.wg.lds_def
+    if d is not None and a.size:
+        ok = d[a[:, None] + np.arange(n)]
+        if not ok.all():
+            bad = np.nonzero(~ok.all(axis=1))[0][0]
+            w.mem._finding("LDS read of bytes this workgroup has not written", int(a[bad]))
+
+
+def _lds_wr(w, a, n):
+    d = w.wg.lds_def
+    if d is not None and a.size:
+        d[(a[:, None] + np.arange(n)).ravel()] = True
+
+
 def _lds_check(w, a, n):
     if a.size and (a.min() < 0 or a.max() + n > w.lds.size):
         raise SimError("LDS access out of range: byte %d..%d of %d" % (int(a.min()), int(a.max()) + n, w.lds.size))
@@ -1378,6 +1396,7 @@ def _decode_ds(mod, I):
                 for k, off in enumerate((o0, o1)):
                     a = (base + off) & M32
                     _lds_check(w, a, el)
+                    _lds_rd(w, a, el)
                     raw = w.lds[a[:, None] + AR[el]]
                     _load_to_regs(w, d0 + k * (el // 4), raw, "w", lanes)
             return f
@@ -1390,6 +1409,7 @@ def _decode_ds(mod, I):
             for off, s in ((o0, s0), (o1, s1)):
                 a = (base + off) & M32
                 _lds_check(w, a, el)
+                _lds_wr(w, a, el)
                 w.lds[(a[:, None] + AR[el]).ravel()] = _regs_to_bytes(w, s, el, 0, lanes).ravel()
         return f
     if name.startswith("read_"):
@@ -1401,6 +1421,7 @@ def _decode_ds(mod, I):
                 return
             a = (w.V[na][lanes].astype(np.int64) + imm) & M32
             _lds_check(w, a, nbytes)
+            _lds_rd(w, a, nbytes)
             _load_to_regs(w, d0, w.lds[a[:, None] + AR[nbytes]], kind, lanes)
         return f
     if name.startswith("write_"):
@@ -1413,6 +1434,7 @@ def _decode_ds(mod, I):
                 return
             a = (w.V[na][lanes].astype(np.int64) + imm) & M32
             _lds_check(w, a, nbytes)
+            _lds_wr(w, a, nbytes)
             w.lds[(a[:, None] + AR[nbytes]).ravel()] = _regs_to_bytes(w, s0, nbytes, shift, lanes, file).ravel()
         return f
     if name in ("bpermute_b32", "permute_b32"):
@@ -1460,11 +1482,13 @@ def _decode_ds(mod, I):
             for l in w.lanes:
                 a = (int(w.V[na][l]) + imm) & M32
                 _lds_check(w, np.array([a]), wd // 8)
+                _lds_rd(w, np.array([a]), wd // 8)
                 old = int.from_bytes(w.lds[a:a + wd // 8].tobytes(), "little")
                 cmpv = int(w.V[nc][l]) | ((int(w.V[nc + 1][l]) << 32) if wd == 64 else 0)
                 if old == cmpv:
                     new = int(w.V[nd][l]) | ((int(w.V[nd + 1][l]) << 32) if wd == 64 else 0)
                     w.lds[a:a + wd // 8] = np.frombuffer(new.to_bytes(wd // 8, "little"), dtype=U8)
+                    _lds_wr(w, np.array([a]), wd // 8)
                 if rtn:
                     w.V[d0][l] = old & M32
                     if wd == 64:
@@ -1484,6 +1508,9 @@ def _decode_ds(mod, I):
             a = (int(w.V[na][l]) + imm) & M32
             if a < 0 or a + nb > lds.size:
                 raise SimError("LDS atomic out of range: %d" % a)
+            if w.wg.lds_def is not None:
+                _lds_rd(w, np.array([a]), nb)
+                w.wg.lds_def[a:a + nb] = True
             old = int.from_bytes(lds[a:a + nb].tobytes(), "little")
             data = int(w.V[nd][l]) | ((int(w.V[nd + 1][l]) << 32) if wd == 64 else 0)
             new = fn(old, data, wd) & ((1 << wd) - 1)

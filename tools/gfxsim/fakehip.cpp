@@ -22,6 +22,7 @@
 namespace {
 std::mutex g_mu;
 unsigned char *g_arena = nullptr;
+unsigned char *g_shadow = nullptr;                 // one byte per arena byte: 0 = never allocated, 1 = allocated, 2 = allocated and written (gfxsim memcheck)
 size_t g_arena_size = 0, g_top = 4096;
 std::map<const void *, std::string> g_kernels;     // host stub -> device (mangled) name
 std::map<void *, size_t> g_allocs;
@@ -41,6 +42,16 @@ void ensure_arena() {
     void *p = mmap(nullptr, g_arena_size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (p == MAP_FAILED) { perror("fakehip: mmap"); abort(); }
     g_arena = (unsigned char *)p;
+    void *q = mmap(nullptr, g_arena_size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (q == MAP_FAILED) { perror("fakehip: mmap (shadow)"); abort(); }
+    g_shadow = (unsigned char *)q;
+}
+bool in_arena(const void *p) { return g_arena && (const unsigned char *)p >= g_arena && (const unsigned char *)p < g_arena + g_arena_size; }
+void shadow_set(const void *p, unsigned char v, size_t n) { if (n && in_arena(p)) memset(g_shadow + ((const unsigned char *)p - g_arena), v, n); }
+void shadow_copy(const void *d, const void *s, size_t n) {          // what a memcpy does to the shadow of its destination
+    if (!n || !in_arena(d)) return;
+    if (in_arena(s)) memmove(g_shadow + ((const unsigned char *)d - g_arena), g_shadow + ((const unsigned char *)s - g_arena), n);
+    else shadow_set(d, 2, n);                                       // bytes from host memory are defined
 }
 void *arena_alloc(size_t n, size_t align = 256) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -49,6 +60,9 @@ void *arena_alloc(size_t n, size_t align = 256) {
     if (p + n + 256 > g_arena_size) return nullptr;
     g_top = p + n + 256;                            // 256 bytes between allocations
     g_allocs[g_arena + p] = n;
+    memset(g_shadow + p, 1, n);
+    static const bool poison = getenv("GFXSIM_POISON") != nullptr;   // device memory is not zero after hipMalloc
+    if (poison) memset(g_arena + p, 0xCD, n);
     return g_arena + p;
 }
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -59,6 +73,7 @@ extern "C" {
 // ---- hooks for the Python side -----------------------------------------------------------------------------------
 void fakehip_set_launch_callback(launch_cb_t cb) { g_cb = cb; }
 void *fakehip_arena_base() { ensure_arena(); return g_arena; }
+void *fakehip_shadow_base() { ensure_arena(); return g_shadow; }
 size_t fakehip_arena_size() { ensure_arena(); return g_arena_size; }
 size_t fakehip_arena_top() { return g_top; }
 void *fakehip_alloc(size_t n) { return arena_alloc(n); }
@@ -117,15 +132,15 @@ hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hip
 // ---- memory ------------------------------------------------------------------------------------------------------
 hipError_t hipMalloc(void **p, size_t n) { *p = arena_alloc(n ? n : 1); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }
 hipError_t hipFree(void *) { return hipSuccess; }                     // bump allocator: nothing is reused, so stale pointers stay visible to the checks
-hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = arena_alloc(n ? n : 1); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = arena_alloc(n ? n : 1); shadow_set(*p, 2, n ? n : 1); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }   // (the host writes it without telling anyone: defined)
 hipError_t hipHostFree(void *) { return hipSuccess; }
 hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { ensure_arena(); *tot = g_arena_size; *fr = g_arena_size - g_top; return hipSuccess; }
-hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyPeer(void *d, int, const void *s, int, size_t n) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) { memmove(d, s, n); shadow_copy(d, s, n); } return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) { memmove(d, s, n); shadow_copy(d, s, n); } return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { if (n) { memmove(d, s, n); shadow_copy(d, s, n); } return hipSuccess; }
+hipError_t hipMemcpyPeer(void *d, int, const void *s, int, size_t n) { if (n) { memmove(d, s, n); shadow_copy(d, s, n); } return hipSuccess; }
+hipError_t hipMemset(void *d, int v, size_t n) { if (n) { memset(d, v, n); shadow_set(d, 2, n); } return hipSuccess; }
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) { memset(d, v, n); shadow_set(d, 2, n); } return hipSuccess; }
 
 // ---- streams and events (everything is synchronous) --------------------------------------------------------------
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(16); return hipSuccess; }

@@ -45,11 +45,15 @@ def build(jobs=8):
     fake = os.path.join(BUILD, "libfakehip.so")
     src = os.path.join(HERE, "fakehip.cpp")
     if _newer(fake, [src]):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I/opt/rocm/include", src, "-o", fake, "-lpthread"])
+        tmp = "%s.%d.tmp" % (fake, os.getpid())                     # (several suites may start at once: never a half-written library)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I/opt/rocm/include", src, "-o", tmp, "-lpthread"])
+        os.replace(tmp, fake)
     objs = [os.path.join(CSRC, u + ".o") for u in KERNEL_UNITS]
     sim = os.path.join(BUILD, "libszl_amd_sim.so")
     if _newer(sim, objs + [fake]):
-        subprocess.check_call(["g++", "-shared", "-fPIC", "-o", sim, *objs, "-L" + BUILD, "-lfakehip", "-Wl,-rpath," + BUILD, "-lpthread"])
+        tmp = "%s.%d.tmp" % (sim, os.getpid())
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-o", tmp, *objs, "-L" + BUILD, "-lfakehip", "-Wl,-rpath," + BUILD, "-lpthread"])
+        os.replace(tmp, sim)
     # device assembly, in parallel
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))] + [os.path.join(ROOT, "include", "szl.h")]
     procs = []
@@ -72,7 +76,7 @@ _CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_char_p, ctypes.c_uint, ctypes.c_ui
                        ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t)
 
 
-def attach(verbose=False, fast_probe=False):
+def attach(verbose=False, fast_probe=False, memcheck=False):
     """-> (Runtime, product C ABI through the simulated device).  Idempotent.
     fast_probe: k_probe_xchg_order (once per process, 512 rounds = 4.7 M instructions, 20 s here) runs 8 rounds instead — the
     interpreter serves an exchange in ascending lane order by construction, the probe has nothing to find out about it."""
@@ -88,6 +92,9 @@ def attach(verbose=False, fast_probe=False):
     arena = np.ctypeslib.as_array((ctypes.c_ubyte * size).from_address(base))
     mem = Memory(buffer=arena, base=base)
     mem.alloc = lambda n, align=256: fake.fakehip_alloc(n)        # one allocator for host code and interpreter
+    if memcheck:                                                  # every global access is checked against the runtime's shadow bytes
+        fake.fakehip_shadow_base.restype = ctypes.c_void_p
+        mem.shadow = np.ctypeslib.as_array((ctypes.c_ubyte * size).from_address(fake.fakehip_shadow_base()))
     rt = Runtime(mem)
     rt.verbose = verbose
     for u in KERNEL_UNITS:
@@ -123,9 +130,11 @@ def attach(verbose=False, fast_probe=False):
     return rt, lib
 
 
-def use(fast_probe=False):
-    """route sharpziplib_amd's mirrors (Engine, Deflater, Inflater ...) through the simulated device"""
-    rt, lib = attach(fast_probe=fast_probe)
+def use(fast_probe=False, memcheck=False):
+    """route sharpziplib_amd's mirrors (Engine, Deflater, Inflater ...) through the simulated device.
+    memcheck: global loads, stores and atomics are checked byte by byte — a read of device memory that no copy, memset or kernel
+    store has written, or any access outside the allocations, is recorded with kernel and assembly line (Runtime.memcheck_report())."""
+    rt, lib = attach(fast_probe=fast_probe, memcheck=memcheck)
     from sharpziplib_amd import _lib as L
     L._lib = lib
     return rt

@@ -32,6 +32,33 @@ class Memory:
         self.size = self.a.size
         self.top = 256
         self.allocs = {}
+        self.shadow = None          # memcheck: one byte per arena byte (0 never allocated, 1 allocated, 2 written); None = off
+        self.findings = {}          # (kind, kernel, line) -> [count, first address]
+        self.where = ("", 0)        # (kernel, source line) of the access being made — set by the wave's run loop while memcheck is on
+
+    def _finding(self, kind, addr):
+        k = (kind,) + self.where
+        f = self.findings.get(k)
+        if f is None:
+            self.findings[k] = [1, int(addr)]
+        else:
+            f[0] += 1
+
+    def check_read(self, i, n):
+        """i: numpy array of arena offsets (first byte of each lane's access), n bytes each"""
+        sh = self.shadow[i[:, None] + np.arange(n)]
+        if (sh != 2).any():
+            bad = np.nonzero((sh != 2).any(axis=1))[0][0]
+            col = np.nonzero(sh[bad] != 2)[0][0]
+            self._finding("read of never-allocated memory" if sh[bad][col] == 0 else "read of memory nobody wrote", self.base + int(i[bad]) + int(col))
+
+    def check_write(self, i, n):
+        idx = (i[:, None] + np.arange(n)).ravel()
+        sh = self.shadow[idx]
+        if (sh == 0).any():
+            self._finding("write to never-allocated memory", self.base + int(idx[np.nonzero(sh == 0)[0][0]]))
+            idx = idx[sh != 0]
+        self.shadow[idx] = 2
 
     def alloc(self, n, align=256):
         p = (self.top + align - 1) // align * align
@@ -48,6 +75,8 @@ class Memory:
         return self.a[i:i + n]
 
     def read_dwords(self, addr, n):
+        if self.shadow is not None:
+            self.check_read(np.array([addr - self.base], dtype=np.int64), 4 * n)
         return [int(x) for x in self.view(addr, 4 * n).view("<u4")] if addr % 4 == 0 else \
             [int.from_bytes(self.view(addr + 4 * j, 4).tobytes(), "little") for j in range(n)]
 
@@ -60,6 +89,8 @@ class Memory:
         if i.min() < 0 or i.max() + n > self.size:
             bad = addr[(i < 0) | (i + n > self.size)][0]
             raise SimError("global read at 0x%x (+%d) is outside the arena" % (int(bad), n))
+        if self.shadow is not None:
+            self.check_read(i, n)
         return self.a[i[:, None] + AR[n]]
 
     def scatter(self, addr, data):
@@ -68,13 +99,20 @@ class Memory:
         if i.min() < 0 or i.max() + n > self.size:
             bad = addr[(i < 0) | (i + n > self.size)][0]
             raise SimError("global write at 0x%x (+%d) is outside the arena" % (int(bad), n))
+        if self.shadow is not None:
+            self.check_write(i, n)
         self.a[(i[:, None] + AR[n]).ravel()] = data.ravel()
+
+
+POISON = bool(os.environ.get("GFXSIM_POISON"))      # LDS starts as garbage, as on the device (leftovers of earlier workgroups), instead of zeros
+_poison_rng = np.random.default_rng(0x5EED)
 
 
 class WorkGroup:
     def __init__(self, wid, lds_bytes):
         self.id = wid
-        self.lds = np.zeros(lds_bytes, dtype=U8)
+        self.lds = _poison_rng.integers(0, 256, lds_bytes, dtype=U8) if POISON else np.zeros(lds_bytes, dtype=U8)
+        self.lds_def = None         # memcheck: which LDS bytes this workgroup has written
         self.waves = []
 
 
@@ -103,6 +141,7 @@ class Runtime:
                 continue
             base = self.mem.alloc(len(buf), 256)
             self.mem.view(base, len(buf))[:] = np.frombuffer(bytes(buf), dtype=U8)
+            self.defined(base, len(buf))
             for sym, (s, off) in mod.datasym.items():
                 if s == sec:
                     self.symaddr[(mod.index, sym)] = base + off
@@ -151,6 +190,14 @@ class Runtime:
             return mod.absolute[name] & M32
         raise SimError("symbol %s has no value the model knows" % name)
 
+    def defined(self, addr, n):
+        if self.mem.shadow is not None:
+            self.mem.shadow[addr - self.mem.base:addr - self.mem.base + n] = 2
+
+    def memcheck_report(self):
+        """[(kind, kernel, source line, count, first address)] — findings of the memcheck mode, most frequent first"""
+        return sorted(((k[0], k[1], k[2], v[0], v[1]) for k, v in self.mem.findings.items()), key=lambda t: -t[3])
+
     # ---- memory access from waves -----------------------------------------------------------------------------
     def read(self, w, addr, n, flat):
         if flat:
@@ -161,6 +208,8 @@ class Runtime:
                 a = addr & M32
                 if a.min() < 0 or a.max() + n > w.lds.size:
                     raise SimError("flat LDS read out of range")
+                if w.wg.lds_def is not None and not w.wg.lds_def[a[:, None] + np.arange(n)].all():
+                    self.mem._finding("LDS read of bytes this workgroup has not written", int(a[0]))
                 return w.lds[a[:, None] + AR[n]]
             if (hi == PRIVATE_HI).any():
                 raise SimError("flat access to the private aperture is not modelled")
@@ -176,6 +225,8 @@ class Runtime:
                 n = data.shape[1]
                 if a.min() < 0 or a.max() + n > w.lds.size:
                     raise SimError("flat LDS write out of range")
+                if w.wg.lds_def is not None:
+                    w.wg.lds_def[(a[:, None] + np.arange(n)).ravel()] = True
                 w.lds[(a[:, None] + AR[n]).ravel()] = data.ravel()
                 return
             if (hi == PRIVATE_HI).any():
@@ -186,6 +237,8 @@ class Runtime:
         if flat and (a >> 32) == SHARED_HI:
             a &= M32
             return int.from_bytes(w.lds[a:a + n].tobytes(), "little")
+        if self.mem.shadow is not None:
+            self.mem.check_read(np.array([a - self.mem.base], dtype=np.int64), n)
         return int.from_bytes(self.mem.view(a, n).tobytes(), "little")
 
     def write_int(self, w, a, v, n, flat):
@@ -194,6 +247,8 @@ class Runtime:
             a &= M32
             w.lds[a:a + n] = b
         else:
+            if self.mem.shadow is not None:
+                self.mem.check_write(np.array([a - self.mem.base], dtype=np.int64), n)
             self.mem.view(a, n)[:] = b
 
     # ---- dispatch ----------------------------------------------------------------------------------------------
@@ -244,8 +299,9 @@ class Runtime:
         block = tuple(block) + (1,) * (3 - len(block))
         if kernarg is None:
             kernarg = self.pack_args(k, args or [], grid, block, dyn_lds)
-        ka = self.mem.alloc(max(len(kernarg), 8), 256)
+        ka = self.mem.alloc(len(kernarg) + 64, 256)        # (the compiler rounds its scalar loads of the segment up: s_load_dwordx8 over 7 pointers)
         self.mem.view(ka, len(kernarg))[:] = np.frombuffer(kernarg, dtype=U8)
+        self.defined(ka, len(kernarg) + 64)
         d = k.desc
         lds_bytes = d.get("group_segment_fixed_size", 0) + dyn_lds
         threads = block[0] * block[1] * block[2]
@@ -271,6 +327,8 @@ class Runtime:
     def _make_wg(self, mod, k, wid, ka, block, threads, nwaves, lds_bytes):
         d = k.desc
         wg = WorkGroup(wid, lds_bytes)
+        if self.mem.shadow is not None:
+            wg.lds_def = np.zeros(lds_bytes, dtype=bool)
         for wi in range(nwaves):
             w = Wave(self, mod, k, wg, wi)
             w.trace = self.trace

@@ -24,7 +24,7 @@ import numpy as np                                   # noqa: E402
 
 def _attach():
     from gfxsim import harness
-    rt = harness.use(fast_probe=True)
+    rt = harness.use(fast_probe=True, memcheck=bool(os.environ.get("GFXSIM_MEMCHECK")))
     return harness, rt
 
 
@@ -402,6 +402,11 @@ def main(argv):
                 print("  [gfxsim] " + msg)
             print("FAILED %s" % name, flush=True)
             rc = 1
+    if rt.mem.shadow is not None:
+        rep = rt.memcheck_report()
+        print("memcheck: %d distinct findings" % len(rep))
+        for kind, kern, line, cnt, addr in rep:
+            print("  %-36s %6d x  %s (assembly line %d), first at 0x%x" % (kind, cnt, kern[:70], line, addr))
     return rc
 
 
