@@ -519,8 +519,10 @@ class Wave:
                     fn = I.fn = decode(self.mod, I, self.pc - 1)
                 if self.trace is not None:
                     self.trace(self, I)
-                if self.mem.shadow is not None:
+                if self.mem.shadow is not None or self.rt.racecheck:
                     self.mem.where = (self.kernel.name, I.line)
+                    if self.rt.racecheck:
+                        self.mem.agent = (self.wg.number * 64 + self.index, self.wg.epoch)
                 fn(self)
                 n += 1
                 c = I.cls
@@ -1354,8 +1356,47 @@ def _decode_scratch(mod, I, rest):
     return None
 
 
+class Race:
+    """racecheck: per LDS byte, who wrote / read it since the workgroup's last barrier.  The interpreter runs the wavefronts of a
+    workgroup one slice after the other, so a race cannot change ITS result — this flags accesses whose order the hardware does not fix:
+    two wavefronts touching the same byte between two barriers, one of them writing, not both atomically."""
+
+    def __init__(self, n):
+        self.epoch = 1
+        self.wr_wave = np.full(n, -1, dtype=np.int16)
+        self.wr_epoch = np.zeros(n, dtype=np.int32)
+        self.wr_atomic = np.zeros(n, dtype=bool)
+        self.rd_wave = np.full(n, -1, dtype=np.int16)        # -2: several wavefronts
+        self.rd_epoch = np.zeros(n, dtype=np.int32)
+
+    def access(self, w, idx, kind):
+        me, E = w.index, self.epoch
+        wcur = self.wr_epoch[idx] == E
+        other_w = wcur & (self.wr_wave[idx] != me)
+        if kind == "r":
+            if other_w.any():
+                w.mem._finding("LDS race: read of a byte another wavefront wrote since the last barrier", int(idx[np.nonzero(other_w)[0][0]]))
+            rcur = self.rd_epoch[idx] == E
+            self.rd_wave[idx] = np.where(rcur & (self.rd_wave[idx] != me), -2, me)
+            self.rd_epoch[idx] = E
+            return
+        rcur = (self.rd_epoch[idx] == E) & (self.rd_wave[idx] != me)
+        if kind == "a":
+            other_w &= ~self.wr_atomic[idx]
+        if other_w.any():
+            w.mem._finding("LDS race: write to a byte another wavefront wrote since the last barrier" + (" (atomic vs plain)" if kind == "a" else ""),
+                           int(idx[np.nonzero(other_w)[0][0]]))
+        if rcur.any():
+            w.mem._finding("LDS race: write to a byte another wavefront read since the last barrier", int(idx[np.nonzero(rcur)[0][0]]))
+        self.wr_wave[idx] = me
+        self.wr_epoch[idx] = E
+        self.wr_atomic[idx] = kind == "a"
+
+
 def _lds_rd(w, a, n):
     """memcheck: LDS is not cleared between workgroups on the device — a read of bytes this workgroup has not written sees leftovers"""
+    if w.wg.race is not None and a.size:
+        w.wg.race.access(w, (a[:, None] + np.arange(n)).ravel(), "r")
     d = w.wg.lds_def
     if d is not None and a.size:
         ok = d[a[:, None] + np.arange(n)]
@@ -1365,6 +1406,8 @@ def _lds_rd(w, a, n):
 
 
 def _lds_wr(w, a, n):
+    if w.wg.race is not None and a.size:
+        w.wg.race.access(w, (a[:, None] + np.arange(n)).ravel(), "w")
     d = w.wg.lds_def
     if d is not None and a.size:
         d[(a[:, None] + np.arange(n)).ravel()] = True
@@ -1482,13 +1525,15 @@ def _decode_ds(mod, I):
             for l in w.lanes:
                 a = (int(w.V[na][l]) + imm) & M32
                 _lds_check(w, np.array([a]), wd // 8)
-                _lds_rd(w, np.array([a]), wd // 8)
+                if w.wg.race is not None:
+                    w.wg.race.access(w, np.arange(a, a + wd // 8), "a")
                 old = int.from_bytes(w.lds[a:a + wd // 8].tobytes(), "little")
                 cmpv = int(w.V[nc][l]) | ((int(w.V[nc + 1][l]) << 32) if wd == 64 else 0)
                 if old == cmpv:
                     new = int(w.V[nd][l]) | ((int(w.V[nd + 1][l]) << 32) if wd == 64 else 0)
                     w.lds[a:a + wd // 8] = np.frombuffer(new.to_bytes(wd // 8, "little"), dtype=U8)
-                    _lds_wr(w, np.array([a]), wd // 8)
+                    if w.wg.lds_def is not None:
+                        w.wg.lds_def[a:a + wd // 8] = True
                 if rtn:
                     w.V[d0][l] = old & M32
                     if wd == 64:
@@ -1508,9 +1553,13 @@ def _decode_ds(mod, I):
             a = (int(w.V[na][l]) + imm) & M32
             if a < 0 or a + nb > lds.size:
                 raise SimError("LDS atomic out of range: %d" % a)
+            if w.wg.race is not None:
+                w.wg.race.access(w, np.arange(a, a + nb), "a")
             if w.wg.lds_def is not None:
-                _lds_rd(w, np.array([a]), nb)
-                w.wg.lds_def[a:a + nb] = True
+                d_ = w.wg.lds_def
+                if not d_[a:a + nb].all():
+                    w.mem._finding("LDS read of bytes this workgroup has not written", a)
+                d_[a:a + nb] = True
             old = int.from_bytes(lds[a:a + nb].tobytes(), "little")
             data = int(w.V[nd][l]) | ((int(w.V[nd + 1][l]) << 32) if wd == 64 else 0)
             new = fn(old, data, wd) & ((1 << wd) - 1)

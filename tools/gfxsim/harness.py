@@ -76,7 +76,7 @@ _CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_char_p, ctypes.c_uint, ctypes.c_ui
                        ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t)
 
 
-def attach(verbose=False, fast_probe=False, memcheck=False):
+def attach(verbose=False, fast_probe=False, memcheck=False, racecheck=False):
     """-> (Runtime, product C ABI through the simulated device).  Idempotent.
     fast_probe: k_probe_xchg_order (once per process, 512 rounds = 4.7 M instructions, 20 s here) runs 8 rounds instead — the
     interpreter serves an exchange in ascending lane order by construction, the probe has nothing to find out about it."""
@@ -97,11 +97,18 @@ def attach(verbose=False, fast_probe=False, memcheck=False):
         mem.shadow = np.ctypeslib.as_array((ctypes.c_ubyte * size).from_address(fake.fakehip_shadow_base()))
     rt = Runtime(mem)
     rt.verbose = verbose
+    rt.racecheck = racecheck
     for u in KERNEL_UNITS:
         rt.load_file(os.path.join(BUILD, u + ".s"))
     errors = []
+    import threading
+    one_at_a_time = threading.Lock()          # the engine launches from several host threads (one per device): one interpreter, one launch at a time
 
     def on_launch(name, gx, gy, gz, bx, by, bz, args, shmem):
+        with one_at_a_time:
+            return _on_launch(name, gx, gy, gz, bx, by, bz, args, shmem)
+
+    def _on_launch(name, gx, gy, gz, bx, by, bz, args, shmem):
         try:
             np.seterr(over="ignore", invalid="ignore", divide="ignore")     # (numpy's error state is per thread: the engine launches from worker threads too)
             kname = name.decode()
@@ -130,11 +137,11 @@ def attach(verbose=False, fast_probe=False, memcheck=False):
     return rt, lib
 
 
-def use(fast_probe=False, memcheck=False):
+def use(fast_probe=False, memcheck=False, racecheck=False):
     """route sharpziplib_amd's mirrors (Engine, Deflater, Inflater ...) through the simulated device.
     memcheck: global loads, stores and atomics are checked byte by byte — a read of device memory that no copy, memset or kernel
     store has written, or any access outside the allocations, is recorded with kernel and assembly line (Runtime.memcheck_report())."""
-    rt, lib = attach(fast_probe=fast_probe, memcheck=memcheck)
+    rt, lib = attach(fast_probe=fast_probe, memcheck=memcheck, racecheck=racecheck)
     from sharpziplib_amd import _lib as L
     L._lib = lib
     return rt

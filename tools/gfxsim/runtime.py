@@ -35,6 +35,8 @@ class Memory:
         self.shadow = None          # memcheck: one byte per arena byte (0 never allocated, 1 allocated, 2 written); None = off
         self.findings = {}          # (kind, kernel, line) -> [count, first address]
         self.where = ("", 0)        # (kernel, source line) of the access being made — set by the wave's run loop while memcheck is on
+        self.race_log = None        # racecheck: [(kind, arena offsets, bytes per lane, agent, epoch, line)] of the launch in flight
+        self.agent = (0, 0)         # (workgroup number * 64 + wavefront, barrier epoch of its workgroup) — set by the wave's run loop
 
     def _finding(self, kind, addr):
         k = (kind,) + self.where
@@ -91,6 +93,8 @@ class Memory:
             raise SimError("global read at 0x%x (+%d) is outside the arena" % (int(bad), n))
         if self.shadow is not None:
             self.check_read(i, n)
+        if self.race_log is not None:
+            self.race_log.append(("r", i.copy(), n, self.agent[0], self.agent[1], self.where[1]))
         return self.a[i[:, None] + AR[n]]
 
     def scatter(self, addr, data):
@@ -101,6 +105,8 @@ class Memory:
             raise SimError("global write at 0x%x (+%d) is outside the arena" % (int(bad), n))
         if self.shadow is not None:
             self.check_write(i, n)
+        if self.race_log is not None:
+            self.race_log.append(("w", i.copy(), n, self.agent[0], self.agent[1], self.where[1]))
         self.a[(i[:, None] + AR[n]).ravel()] = data.ravel()
 
 
@@ -113,6 +119,7 @@ class WorkGroup:
         self.id = wid
         self.lds = _poison_rng.integers(0, 256, lds_bytes, dtype=U8) if POISON else np.zeros(lds_bytes, dtype=U8)
         self.lds_def = None         # memcheck: which LDS bytes this workgroup has written
+        self.race = None            # racecheck (cpu.Race)
         self.waves = []
 
 
@@ -130,6 +137,7 @@ class Runtime:
         self.resident = 1
         self.trace = None
         self.verbose = False
+        self.racecheck = False
 
     # ---- code objects ------------------------------------------------------------------------------------------
     def load(self, text, name="<asm>"):
@@ -249,6 +257,8 @@ class Runtime:
         else:
             if self.mem.shadow is not None:
                 self.mem.check_write(np.array([a - self.mem.base], dtype=np.int64), n)
+            if self.mem.race_log is not None:
+                self.mem.race_log.append(("a", np.array([a - self.mem.base], dtype=np.int64), n, self.mem.agent[0], self.mem.agent[1], self.mem.where[1]))
             self.mem.view(a, n)[:] = b
 
     # ---- dispatch ----------------------------------------------------------------------------------------------
@@ -309,6 +319,9 @@ class Runtime:
         st = self.stats.setdefault(name, {})
         total_wg = grid[0] * grid[1] * grid[2]
         self.launches.append((name, grid, block))
+        if self.racecheck:
+            self.mem.race_log = []
+            self._wg_counter = 0
         pending = [(x, y, z) for z in range(grid[2]) for y in range(grid[1]) for x in range(grid[0])]
         active = []
         pi = 0
@@ -323,12 +336,86 @@ class Runtime:
                         for c, n in w.count.items():
                             st[c] = st.get(c, 0) + n
         # the kernarg block stays allocated (bump allocator); small
+        if self.racecheck:
+            self._analyse_races(name)
+            self.mem.race_log = None
+
+    def _analyse_races(self, name):
+        """global memory, one launch: a byte touched by two different wavefronts, at least one of them writing, not both atomically, and
+        not on two sides of a barrier of their common workgroup.  (Accesses of different workgroups are never ordered inside a launch.)"""
+        log = self.mem.race_log
+        if not log or "rocprim" in name:           # (rocprim's decoupled look-back scan synchronises through flags in global memory by design)
+            return
+        nent = sum(e[1].size * e[2] for e in log)
+        if nent > 60_000_000:
+            self.mem.findings[("racecheck skipped (launch too large)", name, 0)] = [1, 0]
+            return
+        def cat(kinds):
+            sel = [e for e in log if e[0] in kinds]
+            if not sel:
+                z = np.zeros(0, dtype=np.int64)
+                return z, z, z, z
+            idx = np.concatenate([(e[1][:, None] + np.arange(e[2])).ravel() for e in sel])
+            ag = np.concatenate([np.full(e[1].size * e[2], e[3], dtype=np.int64) for e in sel])
+            ep = np.concatenate([np.full(e[1].size * e[2], e[4], dtype=np.int64) for e in sel])
+            ln = np.concatenate([np.full(e[1].size * e[2], e[5], dtype=np.int64) for e in sel])
+            return idx, ag, ep, ln
+        def groups(idx, ag, ep, ln):
+            """per distinct byte: (byte, min agent, max agent, min epoch, max epoch, a line)"""
+            if not idx.size:
+                z = np.zeros(0, dtype=np.int64)
+                return z, z, z, z, z, z
+            o = np.argsort(idx, kind="stable")
+            idx, ag, ep, ln = idx[o], ag[o], ep[o], ln[o]
+            first = np.nonzero(np.r_[True, idx[1:] != idx[:-1]])[0]
+            return (idx[first], np.minimum.reduceat(ag, first), np.maximum.reduceat(ag, first), np.minimum.reduceat(ep, first),
+                    np.maximum.reduceat(ep, first), ln[first])
+        def unordered(amin, amax, emin, emax):
+            """two different wavefronts, and no barrier of a common workgroup provably between them"""
+            return (amin != amax) & (((amin >> 6) != (amax >> 6)) | (emin == emax))
+        wi, wa, we, wl = cat("w")
+        b, amin, amax, emin, emax, ln = groups(wi, wa, we, wl)
+        bad = unordered(amin, amax, emin, emax)
+        if bad.any():
+            k = np.nonzero(bad)[0]
+            self.mem.findings[("global race: two wavefronts write the same byte in one launch", name, int(ln[k[0]]))] = [int(k.size), int(self.mem.base + b[k[0]])]
+        # plain write vs atomic update of the same byte by different wavefronts
+        ai, aa, ae, al = cat("a")
+        if ai.size and wi.size:
+            ab, aamin, aamax, aemin, aemax, aln = groups(ai, aa, ae, al)
+            common, ia, ib = np.intersect1d(b, ab, assume_unique=True, return_indices=True)
+            if common.size:
+                bad = unordered(np.minimum(amin[ia], aamin[ib]), np.maximum(amax[ia], aamax[ib]), np.minimum(emin[ia], aemin[ib]), np.maximum(emax[ia], aemax[ib]))
+                if bad.any():
+                    k = np.nonzero(bad)[0]
+                    self.mem.findings[("global race: a byte is written plainly by one wavefront and atomically by another in one launch", name, int(aln[ib][k[0]]))] = \
+                        [int(k.size), int(self.mem.base + common[k[0]])]
+        # reads against writes (plain or atomic) of other wavefronts
+        ri, ra, re_, rl = cat("r")
+        if ri.size and (wi.size or ai.size):
+            xb, xamin, xamax, xemin, xemax, xl = groups(np.concatenate([wi, ai]), np.concatenate([wa, aa]), np.concatenate([we, ae]), np.concatenate([wl, al]))
+            rb, ramin, ramax, remin, remax, rln = groups(ri, ra, re_, rl)
+            common, ia, ib = np.intersect1d(xb, rb, assume_unique=True, return_indices=True)
+            if common.size:
+                amin = np.minimum(xamin[ia], ramin[ib]); amax = np.maximum(xamax[ia], ramax[ib])
+                emin = np.minimum(xemin[ia], remin[ib]); emax = np.maximum(xemax[ia], remax[ib])
+                bad = unordered(amin, amax, emin, emax)
+                if bad.any():
+                    k = np.nonzero(bad)[0]
+                    self.mem.findings[("global race: a byte is read by one wavefront and written by another in one launch", name, int(xl[ia][k[0]]))] = [int(k.size), int(self.mem.base + common[k[0]])]
 
     def _make_wg(self, mod, k, wid, ka, block, threads, nwaves, lds_bytes):
         d = k.desc
         wg = WorkGroup(wid, lds_bytes)
+        if self.racecheck:
+            wg.number = self._wg_counter
+            self._wg_counter += 1
+            wg.epoch = 1
         if self.mem.shadow is not None:
             wg.lds_def = np.zeros(lds_bytes, dtype=bool)
+        if self.racecheck and nwaves > 1 and lds_bytes:
+            from .cpu import Race
+            wg.race = Race(lds_bytes)
         for wi in range(nwaves):
             w = Wave(self, mod, k, wg, wi)
             w.trace = self.trace
@@ -400,6 +487,10 @@ class Runtime:
                 for w in live:
                     w.at_barrier = False
                 progressed = True
+                if wg.race is not None:
+                    wg.race.epoch += 1
+                if self.racecheck:
+                    wg.epoch += 1
             if not progressed:
                 raise SimError("workgroup %s makes no progress" % (wg.id,))
             if budget is not None and spent >= budget:

@@ -24,7 +24,7 @@ import numpy as np                                   # noqa: E402
 
 def _attach():
     from gfxsim import harness
-    rt = harness.use(fast_probe=True, memcheck=bool(os.environ.get("GFXSIM_MEMCHECK")))
+    rt = harness.use(fast_probe=True, memcheck=bool(os.environ.get("GFXSIM_MEMCHECK")), racecheck=bool(os.environ.get("GFXSIM_RACECHECK")))
     return harness, rt
 
 
@@ -402,7 +402,7 @@ def main(argv):
                 print("  [gfxsim] " + msg)
             print("FAILED %s" % name, flush=True)
             rc = 1
-    if rt.mem.shadow is not None:
+    if rt.mem.shadow is not None or rt.racecheck:
         rep = rt.memcheck_report()
         print("memcheck: %d distinct findings" % len(rep))
         for kind, kern, line, cnt, addr in rep:
