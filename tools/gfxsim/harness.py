@@ -98,6 +98,8 @@ def attach(verbose=False, fast_probe=False, memcheck=False, racecheck=False):
     rt = Runtime(mem)
     rt.verbose = verbose
     rt.racecheck = racecheck
+    if os.environ.get("GFXSIM_SCHED"):         # schedule fuzzing: results must not depend on how the wavefronts interleave
+        rt.sched = np.random.default_rng(int(os.environ["GFXSIM_SCHED"]))
     for u in KERNEL_UNITS:
         rt.load_file(os.path.join(BUILD, u + ".s"))
     errors = []

@@ -138,6 +138,7 @@ class Runtime:
         self.trace = None
         self.verbose = False
         self.racecheck = False
+        self.sched = None           # schedule fuzzing: a numpy Generator — random slice lengths, wavefront order and 8 workgroups in flight
 
     # ---- code objects ------------------------------------------------------------------------------------------
     def load(self, text, name="<asm>"):
@@ -325,12 +326,16 @@ class Runtime:
         pending = [(x, y, z) for z in range(grid[2]) for y in range(grid[1]) for x in range(grid[0])]
         active = []
         pi = 0
+        resident = self.resident if self.sched is None else max(self.resident, 8)
         while pi < len(pending) or active:
-            while pi < len(pending) and len(active) < self.resident:
+            while pi < len(pending) and len(active) < resident:
                 active.append(self._make_wg(mod, k, pending[pi], ka, block, threads, nwaves, lds_bytes))
                 pi += 1
-            for wg in list(active):
-                if self._run_wg(wg, self.slice * 4 if self.resident > 1 else None):
+            order = list(active)
+            if self.sched is not None:
+                self.sched.shuffle(order)
+            for wg in order:
+                if self._run_wg(wg, (self.slice * 4 if self.sched is None else int(self.sched.integers(50, 3000))) if resident > 1 else None):
                     active.remove(wg)
                     for w in wg.waves:
                         for c, n in w.count.items():
@@ -469,13 +474,17 @@ class Runtime:
         while True:
             progressed = False
             alive = 0
-            for w in wg.waves:
+            waves = wg.waves
+            if self.sched is not None:
+                waves = list(waves)
+                self.sched.shuffle(waves)
+            for w in waves:
                 if w.done:
                     continue
                 alive += 1
                 if w.at_barrier:
                     continue
-                n = w.run(self.slice)
+                n = w.run(self.slice if self.sched is None else int(self.sched.integers(1, 700)))
                 spent += n
                 progressed = progressed or n > 0
                 if w.steps > self.max_steps_per_wave:
