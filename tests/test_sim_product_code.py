@@ -15,7 +15,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate"]   # longest first
+SUITES = ["forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate",
+          "exchange_order@desc", "exchange_order@flaky:30:130"]   # longest first; @ = the lane order ds_wrxchg is served in (fault injection)
 HIPCC = "/opt/rocm/bin/hipcc"
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc is needed for the device assembly")
@@ -28,7 +29,8 @@ def runs():
     harness.build()                                   # libszl_amd.so's objects, the fake runtime, the kernels' assembly (cached)
     env = dict(os.environ, PYTHONHASHSEED="0", GFXSIM_POISON="1")   # LDS and fresh device memory start as garbage, as on the device
     env.pop("SZL_DEBUG", None)
-    procs = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s], cwd=ROOT, env=env,
+    procs = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s.split("@")[0]], cwd=ROOT,
+                                 env=dict(env, **({"GFXSIM_XCHG": s.split("@")[1]} if "@" in s else {})),
                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for s in SUITES}
     yield procs
     for p in procs.values():
@@ -44,5 +46,5 @@ def test_machine_code_equals_oracle(runs, suite):
     except subprocess.TimeoutExpired:
         p.kill()
         pytest.fail("suite %s did not finish" % suite)
-    assert p.returncode == 0 and ("ok %s:" % suite) in out, out[-4000:]
+    assert p.returncode == 0 and ("ok %s:" % suite.split("@")[0]) in out, out[-4000:]
     print(out.strip().splitlines()[-1])

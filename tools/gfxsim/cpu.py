@@ -10,6 +10,8 @@ ascending order.
 
 Test infrastructure only.
 """
+import os
+
 import numpy as np
 
 from .asm import AsmError, f32_bits
@@ -1356,6 +1358,12 @@ def _decode_scratch(mod, I, rest):
     return None
 
 
+XCHG_MODE = os.environ.get("GFXSIM_XCHG") or None      # None | "desc" | "flaky:<per mille>"
+XCHG_FLAKY = int(XCHG_MODE.split(":")[1]) if XCHG_MODE and XCHG_MODE.startswith("flaky:") else 0
+XCHG_AFTER = [int(XCHG_MODE.split(":")[2])] if XCHG_MODE and XCHG_MODE.count(":") == 2 else [0]    # "flaky:<per mille>:<n>": only after n exchanges (the probe passes)
+_xchg_rng = np.random.default_rng(int(os.environ.get("GFXSIM_XCHG_SEED", "165")))
+
+
 class Race:
     """racecheck: per LDS byte, who wrote / read it since the workgroup's last barrier.  The interpreter runs the wavefronts of a
     workgroup one slice after the other, so a race cannot change ITS result — this flags accesses whose order the hardware does not fix:
@@ -1547,9 +1555,21 @@ def _decode_ds(mod, I):
     else:
         d0, na, nd = None, o[0][1], o[1][1]
     nb = wd // 8
+    swap = key == "swap"
     def f(w):
         lds = w.lds
-        for l in w.lanes:            # ascending lane order
+        lanes = w.lanes              # ascending lane order — what DESIGN 4.1 assumes of the chip for ds_wrxchg and checks there
+        if swap and XCHG_MODE is not None:
+            # what if the chip served an exchange in another order?  (tests of the product's safety net: probe, per-exchange check, k_links2)
+            if XCHG_MODE == "desc":
+                lanes = lanes[::-1]
+            elif XCHG_AFTER[0] > 0:
+                XCHG_AFTER[0] -= 1
+            elif _xchg_rng.integers(0, 1000) < XCHG_FLAKY and lanes.size > 1:
+                lanes = lanes.copy()
+                i = int(_xchg_rng.integers(0, lanes.size - 1))
+                lanes[i], lanes[i + 1] = lanes[i + 1], lanes[i]
+        for l in lanes:
             a = (int(w.V[na][l]) + imm) & M32
             if a < 0 or a + nb > lds.size:
                 raise SimError("LDS atomic out of range: %d" % a)

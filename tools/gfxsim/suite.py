@@ -378,9 +378,41 @@ def suite_multi_device():
     return n
 
 
+def suite_exchange_order():
+    """fault injection (GFXSIM_XCHG=desc | flaky:<per mille>:<after n exchanges>): the interpreter serves ds_wrxchg in another lane order than
+    DESIGN 4.1 assumes of the chip — always (the probe must refuse k_links3) or now and then after the probe has passed (the check every
+    exchange carries must notice, the call is run again with k_links2).  Whatever happens, the bytes are the oracle's."""
+    import oracle_ffi as O
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd import corpus as C
+    mode = os.environ.get("GFXSIM_XCHG", "")
+    assert mode, "run with GFXSIM_XCHG=desc or flaky:<per mille>:<after>"
+    from gfxsim import harness
+    rt = harness._state["rt"]
+    e = Engine()
+    rng = np.random.default_rng(int(os.environ.get("GFXSIM_XCHG_SEED", "165")))
+    gens = [lambda n: C.zeros(n), lambda n: C.period10(n), lambda n: C.four_symbol(n), lambda n: np.tile(np.frombuffer(b"abcabcabd", np.uint8), n // 9 + 1)[:n],
+            lambda n: C.generate("logs", 5, 0, n), lambda n: C.mixed(n, seed=3)]
+    n = 0
+    for k in range(12):
+        data = gens[k % len(gens)](int(rng.integers(300, 4000)))
+        lv = (1, 6, 9, 3, 5)[k % 5]
+        r = e.deflate([data], level=lv)[0]
+        assert r.status == 0 and r.data == O.deflate(data, lv), (mode, k, lv)
+        n += 1
+    l3 = sum(1 for a, b, c in rt.launches if "k_links3" in a)
+    l2 = sum(1 for a, b, c in rt.launches if "k_links2" in a)
+    trips = e.timing()["links_guard_trips"]
+    print("exchange order %s: k_links3 launches %d, k_links2 launches %d, guard trips %d" % (mode, l3, l2, trips))
+    if mode == "desc":
+        assert l3 == 0 and l2 == 12
+    e.close()
+    return n
+
+
 SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
           "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt,
-          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device}
+          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order}
 
 
 def main(argv):
