@@ -645,12 +645,19 @@ struct szl_inflater {
     DevBuf d_bulk_in, d_bulk_out, d_win_lin;
     DevBuf d_ex;                   // k_inflate_exact's state ([ExState | which]) once the stream has met a block that needs it
     bool exact_live = false;       // the exact decoder holds the stream (until it hands it back at a clean block header)
+    // SZL_INF_PINNED=1 (not the default; unmeasured — round 4 ended without GPU minutes): the bytes of a long piece come back through ONE
+    // pinned buffer that is kept for the object's life and are handed out from there, instead of a std::vector that is grown (zero-filled,
+    // page-faulted) for every piece and filled by a pageable copy.  `pv` bytes are older than anything in `pend`.
+    uint8_t *h_bulk = nullptr; size_t h_bulk_cap = 0;
+    size_t pv_n = 0, pv_pos = 0;
     uint64_t bulk_skip_given = 0;  // do not try again before more input than this has been given (the last attempt found no chain)
     uint32_t bulk_calls = 0;       // (tests / tools: how often the parallel decoder took a piece)
 };
 
+static inline size_t inflater_waiting(const szl_inflater *s) { return (s->pv_n - s->pv_pos) + (s->pend.size() - s->pend_pos); }   // decoded, not handed out
+
 static void inflater_clear(szl_inflater *s) {
-    s->hin.clear(); s->hin_pos = 0; s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0;
+    s->hin.clear(); s->hin_pos = 0; s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0; s->pv_n = s->pv_pos = 0;
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
     s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
@@ -672,6 +679,7 @@ void szl_inflater_destroy(szl_inflater *s) {
     if (s->eng) szl_engine_destroy(s->eng);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->h_bulk) (void)hipHostFree(s->h_bulk);
     delete s;
 }
 int szl_inflater_reset(szl_inflater *s) { if (!s) return SZL_E_ARG; inflater_clear(s); return 0; }
@@ -691,7 +699,7 @@ int szl_inflater_needs_input(const szl_inflater *s) { // :783 — all given inpu
     return s->dec_status == INF_NEED_INPUT && !s->fresh_input;
 }
 int szl_inflater_needs_dictionary(const szl_inflater *s) { return s && s->dec_status == INF_NEED_DICT; } // :794
-int szl_inflater_is_finished(const szl_inflater *s) { return s && s->dec_status == INF_FINISHED && s->pend_pos == s->pend.size(); } // :806
+int szl_inflater_is_finished(const szl_inflater *s) { return s && s->dec_status == INF_FINISHED && inflater_waiting(s) == 0; } // :806
 int64_t szl_inflater_total_in(const szl_inflater *s) { return s ? (int64_t)s->given - szl_inflater_remaining_input(s) : 0; } // :862
 int64_t szl_inflater_total_out(const szl_inflater *s) { return s ? s->total_out : 0; }
 static void fold_adler(szl_inflater *s) {
@@ -795,10 +803,26 @@ static int inflater_bulk(szl_inflater *s) {
     if (!taken[0] || sm.end_bit <= s->st.bitpos) return 0;
     const uint64_t total = res[0].out_written;
     // the decoded bytes wait in `pend` (the decoder runs ahead of the caller as in inflater_step)
-    size_t old = s->pend.size();
-    if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
-    s->pend.resize(old + total);
-    if (total) HIPCHK(hipMemcpy(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost));
+    bool through_pinned = false;
+    if (total && inflater_waiting(s) == 0 && knob("SZL_INF_PINNED", 0) != 0) {
+        if (s->h_bulk_cap < total) {
+            if (s->h_bulk) { (void)hipHostFree(s->h_bulk); s->h_bulk = nullptr; s->h_bulk_cap = 0; }
+            const size_t want = (size_t)total + (size_t)total / 4 + (1u << 20);
+            if (hipHostMalloc((void **)&s->h_bulk, want, hipHostMallocDefault) == hipSuccess) s->h_bulk_cap = want;
+            else { s->h_bulk = nullptr; (void)hipGetLastError(); }       // no pinned memory of that size: the pageable form below
+        }
+        if (s->h_bulk_cap >= total) {
+            HIPCHK(hipMemcpy(s->h_bulk, s->d_bulk_out.p, total, hipMemcpyDeviceToHost));
+            s->pend.clear(); s->pend_pos = 0; s->pv_n = (size_t)total; s->pv_pos = 0;
+            through_pinned = true;
+        }
+    }
+    if (!through_pinned) {
+        size_t old = s->pend.size();
+        if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
+        s->pend.resize(old + total);
+        if (total) HIPCHK(hipMemcpy(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost));
+    }
     if (!s->no_header && total) {
         std::vector<std::pair<uint64_t, uint64_t>> regs{{0, total}};
         std::vector<std::pair<uint32_t, uint32_t>> init{{0u, s->adler_dec}}, out;
@@ -900,20 +924,23 @@ uint32_t szl_inflater_debug_bulk_calls(const szl_inflater *s) { return s ? s->bu
 
 int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count) { // :715
     if (!s || count < 0 || (!out && count)) return SZL_E_ARG;
-    if (s->err && s->pend_pos == s->pend.size()) return s->err;
+    if (s->err && inflater_waiting(s) == 0) return s->err;
     int copied = 0;
     for (;;) {
-        size_t avail = s->pend.size() - s->pend_pos;
+        const bool from_pv = s->pv_pos < s->pv_n;                 // (the pinned piece is older than whatever waits in `pend`)
+        size_t avail = from_pv ? s->pv_n - s->pv_pos : s->pend.size() - s->pend_pos;
         if (s->err && avail == 0) return copied ? copied : s->err; // bytes decoded before the error went out first
         if (avail && count) {
             size_t k = std::min<size_t>(avail, (size_t)count);
-            memcpy(out, s->pend.data() + s->pend_pos, k);
+            memcpy(out, from_pv ? s->h_bulk + s->pv_pos : s->pend.data() + s->pend_pos, k);
             if (!s->no_header) { // Adler of what has been handed out == adler.Update in Inflate (:752-756); folded lazily on the device
                 s->unsummed.insert(s->unsummed.end(), out, out + k);
                 if (s->unsummed.size() > (4u << 20)) fold_adler(s);
             }
-            s->pend_pos += k; out += k; count -= (int)k; copied += (int)k; s->total_out += (int64_t)k;
+            if (from_pv) s->pv_pos += k; else s->pend_pos += k;
+            out += k; count -= (int)k; copied += (int)k; s->total_out += (int64_t)k;
             if (count == 0) return copied;
+            if (from_pv) continue;                                 // (the rest of the request from `pend`, if anything waits there)
         }
         if (s->dec_status == INF_FINISHED) return copied;
         if (s->dec_status == INF_NEED_DICT) return copied;                      // IsNeedingDictionary: the caller must SetDictionary

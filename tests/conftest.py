@@ -11,3 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    # SZL_SIM=1: the GPU-marked tests run against tools/gfxsim (the product's machine code interpreted on the CPU) instead of a device —
+    # `SZL_SIM=1 python -m pytest tests/test_gpu_gzip.py -m gpu`; only the small ones are practical (≈230 k wave-instructions per second)
+    if os.environ.get("SZL_SIM"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from gfxsim import harness
+        harness.use(fast_probe=True)

@@ -15,7 +15,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate",
+SUITES = ["inflate_stream_bulk", "forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate",
           "exchange_order@desc", "exchange_order@flaky:30:130"]   # longest first; @ = the lane order ds_wrxchg is served in (fault injection)
 HIPCC = "/opt/rocm/bin/hipcc"
 

@@ -264,7 +264,7 @@ def suite_forms():
 
 def suite_inflate_parallel():
     """one member on many wavefronts (finder, chunk jobs, window chain, convert) with 16 KiB chunks, against the one-wavefront
-    decoder and the input; a damaged member steps aside with the reference's status; the streaming object's long-input path"""
+    decoder and the input; a damaged member steps aside with the reference's status"""
     import oracle_ffi as O
     from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
@@ -292,20 +292,8 @@ def suite_inflate_parallel():
         no, delivered, cons = O.inflate_probe(bytes(bad), max_out=data.size)
         assert (no >= 0) == (rs.status == 0)
         n += 1
-        # the streaming Inflater given the whole member at once (SetInput >= the bulk threshold)
-        _knobs(SZL_INF_PAR_MIN_KIB=64, SZL_INF_STREAM_BULK_KIB=64)
-        inf = Inflater(True)
-        inf.SetInput(members[0][1] + b"tail")
-        out = bytearray()
-        buf = bytearray(50000)
-        while not inf.IsFinished:
-            k = inf.Inflate(buf)
-            assert k > 0
-            out += buf[:k]
-        assert bytes(out) == data.tobytes() and inf.RemainingInput == 4 and inf.TotalIn == len(members[0][1])
-        n += 1
     finally:
-        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_STREAM_BULK_KIB=FORGET)
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET)
         e.close()
     return n
 
@@ -410,9 +398,45 @@ def suite_exchange_order():
     return n
 
 
+def suite_inflate_stream_bulk():
+    """the streaming Inflater given a long input (InflaterInputStream with a large buffer): SetInput of 256 KiB or more goes to the
+    chunk-parallel decoder from the carried window (inflater_bulk) — zlib framing, input in two pieces, reads of 1 byte to 200 KB,
+    RemainingInput / Adler exact; once through the pageable hand-out (default) and once through the pinned one (SZL_INF_PINNED=1)"""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.inflater import Inflater
+    from sharpziplib_amd import corpus as C
+    data = C.generate("enwik", 0xE9, 0, 760000)
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 4)          # memLevel 4: a block every 1024 tokens
+    z = co.compress(data.tobytes()) + co.flush() + b"tail"
+    cut = 270 * 1024
+    assert len(z) > cut + 4096
+    n = 0
+    try:
+        _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64, SZL_INF_STREAM_BULK_KIB=256)
+        for pinned in (0, 1):
+            _knobs(SZL_INF_PINNED=pinned)
+            inf = Inflater(False)
+            inf.SetInput(z[:cut])
+            out = bytearray()
+            sizes = [1, 4096, 70000, 7, 200000]
+            k = 0
+            while not inf.IsFinished:
+                if inf.IsNeedingInput:
+                    inf.SetInput(z[cut:])
+                buf = bytearray(sizes[k % len(sizes)]); k += 1
+                out += buf[:inf.Inflate(buf)]
+            assert bytes(out) == data.tobytes(), (pinned, len(out))
+            assert inf.RemainingInput == 4 and inf.TotalIn == len(z) - 4 and inf.Adler == zlib.adler32(data.tobytes()), pinned
+            assert _lib.lib().szl_inflater_debug_bulk_calls(inf._h) >= 1, pinned
+            n += 1
+    finally:
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_STREAM_BULK_KIB=FORGET, SZL_INF_PINNED=FORGET)
+    return n
+
+
 SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
           "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt,
-          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order}
+          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order, "inflate_stream_bulk": suite_inflate_stream_bulk}
 
 
 def main(argv):
