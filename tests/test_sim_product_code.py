@@ -15,12 +15,12 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["inflate_stream_bulk", "forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "deflate_shapes", "inflate",
+SUITES = ["inflate_stream_bulk", "forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "framing", "deflate_shapes", "inflate",
           "exchange_order@desc", "exchange_order@flaky:30:130"]   # longest first; @ = the lane order ds_wrxchg is served in (fault injection)
 HIPCC = "/opt/rocm/bin/hipcc"
 # ≈720 CPU-seconds in all, spread over the cores (140 s of wall time on 8); a box with fewer than 4 cores runs the core suites only
 if (os.cpu_count() or 1) < 4:
-    SUITES = [s for s in SUITES if s in ("deflate_levels", "deflater_object", "deflate_shapes", "inflate", "inflate_corrupt", "exchange_order@desc")]
+    SUITES = [s for s in SUITES if s in ("deflate_levels", "deflater_object", "deflate_shapes", "inflate", "inflate_corrupt", "framing", "exchange_order@desc")]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc is needed for the device assembly")
 

@@ -434,9 +434,107 @@ def suite_inflate_stream_bulk():
     return n
 
 
+def suite_framing():
+    """gzip members on the device (SZL_F_GZIP: header, CRC-32 / ISIZE trailer) through GZipOutputStream / GZipInputStream and the batch
+    member writer / reader; a zip archive around one batched call (zipbatch) read back by Python's zipfile and by the device; zlib framing
+    with a preset dictionary on both sides (FDICT, NEED_DICT); a sync flush"""
+    import datetime
+    import gzip
+    import io
+    import struct
+    import zipfile
+    import oracle_ffi as O
+    from sharpziplib_amd import corpus as C
+    from sharpziplib_amd import gzipstream as G
+    from sharpziplib_amd import zipbatch as Z
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.inflater import Inflater
+    n = 0
+    data = C.generate("enwik", 3, 0, 5000)
+    for level in (1, 6):
+        bio = io.BytesIO()
+        g = G.GZipOutputStream(bio)
+        g.IsStreamOwner = False
+        g.SetLevel(level)
+        g.FileName = "some/dir/h\xe9llo.txt"
+        g.ModifiedTime = 1234567890
+        for a in range(0, data.size, 1701):
+            g.Write(data[a:a + 1701])
+        g.Finish()
+        got = bio.getvalue()
+        hdr = bytes([0x1F, 0x8B, 8, 8]) + (1234567890).to_bytes(4, "little") + bytes([0, 255]) + "h\xe9llo.txt".encode("latin-1") + b"\0"
+        assert got == hdr + O.deflate(data, level) + zlib.crc32(data.tobytes()).to_bytes(4, "little") + data.size.to_bytes(4, "little"), level
+        assert gzip.decompress(got) == data.tobytes()
+        n += 1
+    two = got + gzip.compress(b"second member " * 40, 9) + b"\0\0garbage"
+    st = G.GZipInputStream(io.BytesIO(two))
+    assert st.read_all(chunk=900) == data.tobytes() + b"second member " * 40
+    n += 1
+    datas = [C.generate("logs", 40 + i, 0, 700 + 300 * i) for i in range(4)] + [np.zeros(0, np.uint8)]
+    members = G.write_members(datas, level=6, names=["a.log", None, "c", None, "empty"], mtimes=[1, 2, 3, 4, 5])
+    for m, d in zip(members, datas):
+        assert gzip.decompress(m) == d.tobytes()
+    back = G.read_members(members)
+    assert [g for g, _ in back] == [d.tobytes() for d in datas] and [nm for _, nm in back] == ["a.log", None, "c", None, "empty"]
+    n += 1
+    # zip archive: local headers / descriptors / central directory around ONE device call
+    rng = np.random.default_rng(9)
+    ents = [("dir/f%02d.txt" % i, C.generate(("dickens", "logs", "enwik")[i % 3], 70 + i, 0, int(rng.integers(0, 3000)))) for i in range(9)]
+    z = Z.write_zip(ents, level=6, when=datetime.datetime(2025, 6, 1, 8, 0, 0))
+    zf = zipfile.ZipFile(io.BytesIO(z))
+    assert zf.testzip() is None
+    for info, (name, d) in zip(zf.infolist(), ents):
+        sig, _, _, _, _, _, csize, _, nlen, xlen = struct.unpack_from("<IHHHIIIIHH", z, info.header_offset)
+        p0 = info.header_offset + 30 + nlen + xlen
+        assert info.filename == name and info.CRC == zlib.crc32(d.tobytes()) and z[p0:p0 + csize] == O.deflate(d, 6), name
+    assert Z.read_zip(z) == [(nm, d.tobytes()) for nm, d in ents]
+    bio = io.BytesIO()
+    with zipfile.ZipFile(bio, "w", zipfile.ZIP_DEFLATED, compresslevel=9) as zw:
+        for name, d in ents[:5]:
+            zw.writestr(name, d.tobytes())
+    assert Z.read_zip(bio.getvalue()) == [(nm, d.tobytes()) for nm, d in ents[:5]]
+    n += 2
+    # preset dictionary through zlib framing: the Deflater sets FDICT, the Inflater asks for the dictionary (C/Inflater.cs:211-249,:606-620)
+    dic = C.generate("dickens", 5, 0, 1200)
+    msg = np.concatenate([dic[200:900], C.generate("dickens", 6, 0, 1800)])
+    d = Deflater(6, False)
+    d.SetDictionary(dic)
+    d.SetInput(msg); d.Finish()
+    buf = np.zeros(8192, np.uint8)
+    k = d.Deflate(buf)
+    comp = buf[:k].tobytes()
+    o = O.Deflater(6, False); o.set_dictionary(dic); o.set_input(msg); o.finish()
+    assert comp == o.deflate(8192)
+    zd = zlib.decompressobj(zdict=dic.tobytes())
+    assert zd.decompress(comp) == msg.tobytes()
+    inf = Inflater(False)
+    inf.SetInput(comp)
+    out = bytearray(4000)
+    assert inf.Inflate(out) == 0 and inf.IsNeedingDictionary
+    inf.SetDictionary(dic)
+    got = bytearray()
+    while not inf.IsFinished:
+        k = inf.Inflate(out)
+        assert k > 0
+        got += out[:k]
+    assert bytes(got) == msg.tobytes() and inf.Adler == zlib.adler32(msg.tobytes())
+    n += 1
+    # a sync flush in mid-stream: the bytes so far decode on their own
+    d = Deflater(9, True); o = O.Deflater(9, True)
+    d.SetInput(data[:2500]); o.set_input(data[:2500]); d.Flush(); o.flush()
+    k = d.Deflate(buf)
+    first = buf[:k].tobytes()
+    assert first == o.deflate(8192) and zlib.decompressobj(-15).decompress(first) == data[:2500].tobytes()
+    d.SetInput(data[2500:]); o.set_input(data[2500:]); d.Finish(); o.finish()
+    k = d.Deflate(buf)
+    assert buf[:k].tobytes() == o.deflate(8192)
+    n += 1
+    return n
+
+
 SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
           "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt,
-          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order, "inflate_stream_bulk": suite_inflate_stream_bulk}
+          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order, "inflate_stream_bulk": suite_inflate_stream_bulk, "framing": suite_framing}
 
 
 def main(argv):
