@@ -83,7 +83,8 @@ static int64_t full_search_len(uint64_t emit, int64_t tile_len, int which) {
     if (which == 2) {
         int64_t len = match2_tile();
         if (knob("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
-        while (len > 2048 && emit / (uint64_t)len < 128) len >>= 1;     // a small call gets shorter tiles (see tile_len)
+        const int64_t floor_len = std::max(2048, knob("SZL_TILE_FLOOR", 2048));   // (lab / tools/gfxsim: full-length tiles on a small input — the steady state of a long stream)
+        while (len > floor_len && emit / (uint64_t)len < 128) len >>= 1;     // a small call gets shorter tiles (see tile_len)
         return len;
     }
     if (which != 4) return 0;
