@@ -804,7 +804,7 @@ static int inflater_bulk(szl_inflater *s) {
     const uint64_t total = res[0].out_written;
     // the decoded bytes wait in `pend` (the decoder runs ahead of the caller as in inflater_step)
     bool through_pinned = false;
-    if (total && inflater_waiting(s) == 0 && knob("SZL_INF_PINNED", 0) != 0) {
+    if (total && total <= (1ull << 30) && inflater_waiting(s) == 0 && knob("SZL_INF_PINNED", 0) != 0) {   // (a piece beyond 1 GiB is not pinned)
         if (s->h_bulk_cap < total) {
             if (s->h_bulk) { (void)hipHostFree(s->h_bulk); s->h_bulk = nullptr; s->h_bulk_cap = 0; }
             const size_t want = (size_t)total + (size_t)total / 4 + (1u << 20);
