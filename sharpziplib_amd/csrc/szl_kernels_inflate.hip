@@ -178,10 +178,11 @@ __device__ __forceinline__ int decode_sym(const HuffTab *T, const uint16_t *lut,
 // the blocks from job.start_bit up to the block boundary job.stop_bit, produce no bytes, report the output length and the bit
 // position reached.  2 = symbol pass: the same decode, writing 16-bit symbols to job.sym_out — a byte, or 0x8000 | i for
 // "byte i of the 32 KiB in front of this chunk" (what a back-reference reaching before the chunk reads; resolved afterwards).
-// DENSE (symbol pass only, behind SZL_INF_SLOTS_PER_CU >= 10): the register allocation for 3 wavefronts per SIMD (168 registers instead
+// DENSE (symbol pass only, behind SZL_INF_DENSE=1; SZL_INF_SLOTS_PER_CU sizes the chunks for the jobs a CU then holds): the register allocation for 3 wavefronts per SIMD (168 registers instead
 // of 210, no scratch), so that the LDS (15 KiB per job) admits 10 chunk jobs per CU instead of 8.  Round 4 measured a 512 MiB text member
 // 28.5 -> 26.2 ms with it (profiles/r04/inflate_slots.log in the history of 9e0c386) but could not finish the A/B of the whole bench for
-// want of GPU minutes: NOT the default; the same source, another register budget (checked on the interpreter: tools/gfxsim suite inflate_parallel).
+// want of GPU minutes; the round's last GPU seconds then showed 64 x 4 MiB members THREE TIMES SLOWER with both knobs set
+// (profiles/r04/r5_dense_on_64x4mib_members.log): NOT the default; the same source, another register budget (checked on the interpreter: tools/gfxsim suite inflate_parallel).
 template <bool SHORTWIN, int PMODE, bool DENSE = false>
 __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DENSE ? 3 : 2) : 1)) void k_inflate(const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
                                                 InfJob *jobs, InfState *states, uint32_t njobs) {
@@ -873,12 +874,12 @@ void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *sta
 }
 // chunk jobs of one member: pass 1 (count) or 2 (symbols); `in` = first byte of the member
 int knob(const char *name, int dflt);
-// chunk jobs of the symbol pass per CU (sizes the chunks in inflate_members_parallel and picks the register budget here): 8, or 10 = DENSE
+// chunk jobs of the symbol pass per CU the chunks are sized for in inflate_members_parallel: 8 (10 with SZL_INF_DENSE's register budget)
 int inflate_slots_per_cu() { const int v = knob("SZL_INF_SLOTS_PER_CU", 8); return v < 1 ? 1 : v; }
 void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st) {
     if (!njobs) return;
     if (pass == 1) hipLaunchKernelGGL((k_inflate<true, 1>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
-    else if (inflate_slots_per_cu() >= 10) hipLaunchKernelGGL((k_inflate<true, 2, true>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
+    else if (knob("SZL_INF_DENSE", 0) != 0) hipLaunchKernelGGL((k_inflate<true, 2, true>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
     else hipLaunchKernelGGL((k_inflate<true, 2>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
 }
 

@@ -299,7 +299,7 @@ def suite_inflate_parallel():
 
 
 def suite_inflate_dense():
-    """the symbol pass compiled for 3 wavefronts per SIMD (SZL_INF_SLOTS_PER_CU=10: k_inflate<true, 2, true>, another register
+    """the symbol pass compiled for 3 wavefronts per SIMD (SZL_INF_DENSE=1: k_inflate<true, 2, true>, another register
     allocation of the same source; not the default) on one member, against the input"""
     from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
@@ -309,12 +309,12 @@ def suite_inflate_dense():
         data = C.generate("enwik", 0xE9, 0, 360000)
         co = zlib.compressobj(6, zlib.DEFLATED, -15, 4)
         m = co.compress(data.tobytes()) + co.flush()
-        _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64, SZL_INF_SLOTS_PER_CU=10)
+        _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64, SZL_INF_SLOTS_PER_CU=10, SZL_INF_DENSE=1)
         (r, used), = e.inflate([m], [data.size], crc32=True)
         assert int(_lib.lib().szl_engine_debug_par_jobs(e._h)) >= 4
         assert r.status == 0 and r.data == data.tobytes() and used == len(m) and r.crc32 == zlib.crc32(data.tobytes())
     finally:
-        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_SLOTS_PER_CU=FORGET)
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET)
         e.close()
     return 1
 

@@ -4,7 +4,8 @@
 
 Everything runs in one process on one device; every line is `what | knob = value | time` and every output is compared with the input /
 the default's bytes.  Nothing here changes a default: the winners are set in the source afterwards.
-  1. one text member through the chunk-parallel Inflater: SZL_INF_SLOTS_PER_CU = 8 (default) / 10 (k_inflate<true,2,DENSE>: 168 registers)
+  1. the chunk-parallel Inflater on one member and on 64 x 4 MiB members: SZL_INF_SLOTS_PER_CU = 8 / 10 (chunk sizing) x SZL_INF_DENSE = 0 / 1
+     (k_inflate<true,2,DENSE>: 168 registers) — round 4's last GPU seconds: both set, one member -15 %, the members 3 x SLOWER
   2. InflaterInputStream over that member with 16 MiB and 64 MiB buffers: SZL_INF_PINNED = 0 (default) / 1
   3. raw deflate level 6 of the same text (the bench step): the default, then the stage-B knobs one at a time (SZL9_FTH, SZL_TILE_LEN)
 """
@@ -50,17 +51,26 @@ comp = r0.data
 want = hashlib.sha256(plain.tobytes()).hexdigest()
 print("member: %.2f MiB of text -> %d bytes" % (a.mib, len(comp)), flush=True)
 
-# ---- 1. chunk jobs per CU in the symbol pass
-for slots in (8, 10, 8, 10):
-    knob("SZL_INF_SLOTS_PER_CU", slots)
+# ---- 1. the symbol pass: chunk sizing (jobs per CU the chunks are cut for) x register budget of the kernel, on two shapes
+msz = 4 << 20
+parts = [plain[i * msz:(i + 1) * msz] for i in range(min(64, n // msz))]
+mcomps = [r.data for r in eng.deflate(parts, level=6)] if parts else []
+for slots, dense in ((8, 0), (10, 0), (8, 1), (10, 1), (8, 0)):
+    knob("SZL_INF_SLOTS_PER_CU", slots); knob("SZL_INF_DENSE", dense)
     best = 1e9
     for rep in range(3):
         (r, used), = eng.inflate([comp], [n], crc32=True)
         assert r.status == 0 and used == len(comp) and r.crc32 == r0.crc32
         best = min(best, eng.timing()["inflate_ms"])
     assert hashlib.sha256(r.data).hexdigest() == want
-    print("inflate one member | SZL_INF_SLOTS_PER_CU = %2d | %8.2f ms (best of 3), %6.1f GiB/s" % (slots, best, a.mib / 1024 / (best * 1e-3)), flush=True)
-knob("SZL_INF_SLOTS_PER_CU", FORGET)
+    bm = 1e9
+    for rep in range(3 if mcomps else 0):
+        out = eng.inflate(mcomps, [msz] * len(mcomps))
+        bm = min(bm, eng.timing()["inflate_ms"])
+    assert all(o[0].data == p.tobytes() for o, p in zip(out, parts)) if mcomps else True
+    print("inflate | SZL_INF_SLOTS_PER_CU = %2d SZL_INF_DENSE = %d | one member %8.2f ms (%5.1f GiB/s) | %d x 4 MiB members %8.2f ms" % (
+        slots, dense, best, a.mib / 1024 / (best * 1e-3), len(mcomps), bm if mcomps else 0.0), flush=True)
+knob("SZL_INF_SLOTS_PER_CU", FORGET); knob("SZL_INF_DENSE", FORGET)
 
 # ---- 2. the unchanged-host read path with room
 for bufsz in ((64 << 20,) if a.quick else (16 << 20, 64 << 20)):
