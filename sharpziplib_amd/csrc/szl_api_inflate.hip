@@ -10,6 +10,7 @@
 #include <new>
 #include <vector>
 #include "szl_engine.h"
+#include "szl_inflate_sizing.h"
 #include "szl_inflate.h"
 
 using namespace szl;
@@ -130,25 +131,27 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     // = 3034 jobs = 1.5 rounds of the 2048 slots, 56 ms; 192 KiB = one round, 43 ms; a 1 GiB log member (70 MiB compressed): 128 KiB =
     // a quarter of the slots, 37 ms; 64 KiB 25 ms.  So: r whole rounds of the slots with chunks of at most ~192 KiB, at least 32 KiB.
     uint64_t chunk_max = (uint64_t)std::max(16, knob("SZL_INF_CHUNK_KIB", 128)) * 1024;
-    if (knob("SZL_INF_CHUNK_KIB", 0) == 0) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint64_t slots = (uint64_t)inflate_slots_per_cu() * (uint64_t)cus;
+    const bool auto_size = knob("SZL_INF_CHUNK_KIB", 0) == 0;
+    std::vector<uint64_t> in_lens;
+    for (size_t ci : cand) in_lens.push_back(streams[ci].in_len);
+    if (auto_size) {
         uint64_t total_in = 0;
-        for (size_t ci : cand) total_in += streams[ci].in_len;
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        const uint64_t slots = (uint64_t)inflate_slots_per_cu() * (uint64_t)cus;
-        const uint64_t rounds = std::max<uint64_t>(1, (total_in + slots * (192ull << 10) - 1) / (slots * (192ull << 10)));
-        chunk_max = std::min<uint64_t>(std::max<uint64_t>((total_in / (slots * rounds) + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
+        for (uint64_t v : in_lens) total_in += v;
+        chunk_max = inflate_chunk_max(total_in, slots);
     }
+    // (szl_inflate_sizing.h; SZL_INF_TRIM_TAIL=1 — not the default, unmeasured — trims a tail round of a few stragglers away; only with
+    // the library's own sizing, never when a test or a tool has fixed the chunk size)
+    const std::vector<ChunkPlan> plans = inflate_chunk_plans(in_lens, chunk_max, slots, auto_size && knob("SZL_INF_TRIM_TAIL", 0) != 0);
     uint64_t nstart_total = 0;
-    for (size_t ci : cand) {
-        const szl_stream &s = streams[ci];
-        PS p; p.si = ci;
-        uint64_t cb = s.in_len / 32;                              // short members get smaller chunks: at least ~32 of them
-        cb = std::min<uint64_t>(std::max<uint64_t>(cb & ~1023ull, 16384), chunk_max);
-        p.chunk_bytes = cb;
-        if (s.in_len < 8 * cb || s.in_len >= (1ull << 60)) continue;
-        p.nchunks = (uint32_t)std::min<uint64_t>((s.in_len + cb - 1) / cb, 1u << 20);
+    for (size_t k = 0; k < cand.size(); k++) {
+        if (!plans[k].chunk_bytes) continue;
+        PS p; p.si = cand[k];
+        p.chunk_bytes = plans[k].chunk_bytes;
+        p.nchunks = plans[k].nchunks;
         p.first_bit = sm ? sm->first_bit : 0; p.start_off = nstart_total; nstart_total += p.nchunks;
         ps.push_back(std::move(p));
     }
