@@ -353,7 +353,7 @@ def suite_multi_device():
         n += 1
     try:
         _knobs(SZL_PART_MIN_KIB=64, SZL_WINDOW_KIB=64, SZL_PART_WARM_KIB=64)
-        data = C.generate("enwik", 0x5EED, 0, 180000)
+        data = C.generate("enwik", 0x5EED, 0, 140000)
         (r,) = deflate_multi([data], [0, 1], level=6, crc32=True)
         assert r.status == 0 and r.crc32 == O.crc32(data) and r.data == O.deflate(data, 6)
         n += 1
@@ -401,7 +401,7 @@ def suite_exchange_order():
 def suite_inflate_stream_bulk():
     """the streaming Inflater given a long input (InflaterInputStream with a large buffer): SetInput of 256 KiB or more goes to the
     chunk-parallel decoder from the carried window (inflater_bulk) — zlib framing, input in two pieces, reads of 1 byte to 200 KB,
-    RemainingInput / Adler exact; once through the pageable hand-out (default) and once through the pinned one (SZL_INF_PINNED=1)"""
+    RemainingInput / Adler exact; through the pageable hand-out (default) and, with GFXSIM_PINNED_TOO=1, the pinned one (SZL_INF_PINNED=1)"""
     from sharpziplib_amd import _lib
     from sharpziplib_amd.inflater import Inflater
     from sharpziplib_amd import corpus as C
@@ -413,7 +413,7 @@ def suite_inflate_stream_bulk():
     n = 0
     try:
         _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64, SZL_INF_STREAM_BULK_KIB=256)
-        for pinned in (0, 1):
+        for pinned in ((0, 1) if os.environ.get("GFXSIM_PINNED_TOO") else (0,)):      # (the pinned hand-out measured no gain on the device: checked on request only)
             _knobs(SZL_INF_PINNED=pinned)
             inf = Inflater(False)
             inf.SetInput(z[:cut])
