@@ -674,7 +674,10 @@ __device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool ac
     }
 }
 
-template <int W>
+// WB4 (SZL_SPEC_WB=1 in the LABORATORY library, libszl_amd_lab.so; unmeasured on the device): the write-back of a round's tokens takes four ranges per store instruction
+// (16 lanes each) out of a compacted list instead of one range per iteration of a loop over up to 64 of them — on the interpreter the loop
+// is 17-20 % of this kernel's instructions (profiles/r04/gfxsim_srcprof_k_spec_win.log).
+template <int W, bool WB4 = false>
 __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                                  uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
                                                  uint32_t *visited, unsigned long long *counters, uint32_t *spec_tok) {
@@ -719,11 +722,33 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
         if (active && L == 0 && x >= re) active = false;
         __syncthreads();
         if (spec_tok) { // the k-th token of this range's speculative path goes to spec_tok[range start + k] (k_emit_copy reads them back)
-            for (uint64_t m = __ballot(nt > 0); m; m &= m - 1) {
-                const int j = __builtin_ctzll(m);
-                const int ntj = __builtin_amdgcn_readlane(nt, j);
-                uint32_t *dst = spec_tok + readlane64((int64_t)(s.buf_off + (uint64_t)rs + count), j);
-                if (lane < ntj) dst[lane] = sm2[j * STRIDE + lane];
+            if constexpr (WB4) {
+                __shared__ uint32_t wb_j[64], wb_n[64];           // (inside the discarded branch of the default build: its LDS layout is untouched)
+                __shared__ uint64_t wb_dst[64];
+                const uint64_t m = __ballot(nt > 0);
+                const int nact = __builtin_popcountll(m);
+                if (nt > 0) {
+                    const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    wb_j[rank] = (uint32_t)lane; wb_n[rank] = (uint32_t)nt;
+                    wb_dst[rank] = (uint64_t)(uintptr_t)(spec_tok + (s.buf_off + (uint64_t)rs + count));
+                }
+                __syncthreads();
+                const int g = lane >> 4, k0 = lane & 15;
+                for (int i = 0; i < nact; i += 4) {
+                    const int r = i + g;
+                    if (r < nact) {
+                        const uint32_t j = wb_j[r], n = wb_n[r];
+                        uint32_t *dst = (uint32_t *)(uintptr_t)wb_dst[r];
+                        for (uint32_t k = (uint32_t)k0; k < n; k += 16) dst[k] = sm2[j * STRIDE + k];
+                    }
+                }
+            } else {
+                for (uint64_t m = __ballot(nt > 0); m; m &= m - 1) {
+                    const int j = __builtin_ctzll(m);
+                    const int ntj = __builtin_amdgcn_readlane(nt, j);
+                    uint32_t *dst = spec_tok + readlane64((int64_t)(s.buf_off + (uint64_t)rs + count), j);
+                    if (lane < ntj) dst[lane] = sm2[j * STRIDE + lane];
+                }
             }
             __syncthreads();
         }
@@ -876,6 +901,7 @@ __global__ __launch_bounds__(64) void k_emit_copy(const uint8_t *in, const uint1
     }
 }
 
+int knob(const char *name, int dflt);
 static int cwin_mode() {
     // (measured again in round 3, after the match tables were packed: 32 positions of window per lane — 1 GiB: parse 6.7 -> 5.8 ms, a
     // 64 KiB call 0.38 -> 0.34 ms; 64 is better still for small calls and worse for large ones)
@@ -890,6 +916,10 @@ void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDe
     const int cw = cwin_mode();
     const dim3 wg((unsigned)((nranges + 63) / 64));
     if (cw == 64) { hipLaunchKernelGGL(k_spec_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+#if SZL_LAB   // (laboratory library only: one more instantiation in this unit changes the inliner's decisions for the kernels next to it —
+              // compared instruction by instruction against the build the device has verified; the product's code stays what it was)
+    if (cw == 32 && knob("SZL_SPEC_WB", 0) != 0) { hipLaunchKernelGGL((k_spec_win<32, true>), wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+#endif
     if (cw == 32) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
     if (cw == 16) { hipLaunchKernelGGL(k_spec_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
     if (cw == 8) { hipLaunchKernelGGL(k_spec_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }

@@ -8,7 +8,8 @@ the default's bytes.  Nothing here changes a default: the winners are set in the
      (k_inflate<true,2,DENSE>: 168 registers) x SZL_INF_TRIM_TAIL = 0 / 1 (no tail round of stragglers: 64 x 4 MiB members are 2112 jobs for
      2048 slots with the default sizing) — round 4's last GPU seconds: slots 10 + DENSE, one member -15 %, the members 3 x SLOWER (unexplained)
   2. InflaterInputStream over that member with 16 MiB and 64 MiB buffers: SZL_INF_PINNED = 0 (default) / 1
-  3. raw deflate level 6 of the same text (the bench step): the default, then the stage-B knobs one at a time (SZL9_FTH, SZL_TILE_LEN)
+  3. raw deflate level 6 of the same text (the bench step): the default, then the stage-B knobs one at a time (SZL9_FTH, SZL_TILE_LEN);
+     with --lab also SZL_SPEC_WB = 0 / 1 (k_spec_win's write-back, four ranges per store: -14 % of the kernel's instructions on the interpreter)
 """
 import argparse
 import hashlib
@@ -33,8 +34,11 @@ FORGET = -2147483648
 ap = argparse.ArgumentParser()
 ap.add_argument("--mib", type=int, default=512)
 ap.add_argument("--quick", action="store_true")
+ap.add_argument("--lab", action="store_true", help="the laboratory library (libszl_amd_lab.so): also SZL_SPEC_WB, the four-ranges-per-store write-back of k_spec_win")
 ap.add_argument("--kib", type=int, default=0, help="(tools/gfxsim dry run) a member of this many KiB instead of --mib")
 a = ap.parse_args()
+if a.lab:
+    _lib._lib = _lib.lab_lib()
 L = _lib.lib()
 
 
@@ -121,7 +125,7 @@ def step(label):
 
 step("defaults")
 if not a.quick:
-    for name, values in (("SZL9_FTH", (12, 16, 20)), ("SZL_TILE_LEN", (18432, 20480, 21504))):
+    for name, values in ((("SZL_SPEC_WB", (0, 1, 0, 1)),) if a.lab else ()) + (("SZL9_FTH", (12, 16, 20)), ("SZL_TILE_LEN", (18432, 20480, 21504))):
         for v in values:
             knob(name, v)
             step("%s = %d" % (name, v))
