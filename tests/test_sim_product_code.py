@@ -16,7 +16,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUITES = ["inflate_stream_bulk", "forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "framing", "deflate_shapes", "inflate",
-          "exchange_order@desc", "exchange_order@flaky:30:130"]   # longest first; @ = the lane order ds_wrxchg is served in (fault injection)
+          "exchange_order@desc", "exchange_order@flaky:30:130", "lab_forms@lab"]   # longest first; @ = the lane order ds_wrxchg is served in (fault injection) / the laboratory library
 HIPCC = "/opt/rocm/bin/hipcc"
 # ≈720 CPU-seconds in all, spread over the cores (140 s of wall time on 8); a box with fewer than 4 cores runs the core suites only
 if (os.cpu_count() or 1) < 4:
@@ -33,7 +33,7 @@ def runs():
     env = dict(os.environ, PYTHONHASHSEED="0", GFXSIM_POISON="1")   # LDS and fresh device memory start as garbage, as on the device
     env.pop("SZL_DEBUG", None)
     procs = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s.split("@")[0]], cwd=ROOT,
-                                 env=dict(env, **({"GFXSIM_XCHG": s.split("@")[1]} if "@" in s else {})),
+                                 env=dict(env, **({("GFXSIM_LAB" if s.endswith("@lab") else "GFXSIM_XCHG"): s.split("@")[1]} if "@" in s else {})),
                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for s in SUITES}
     yield procs
     for p in procs.values():

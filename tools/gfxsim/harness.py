@@ -39,16 +39,22 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+LAB = bool(os.environ.get("GFXSIM_LAB"))       # the laboratory library (-DSZL_LAB=1: the dropped forms of stage B, SZL_SPEC_WB) instead of the product
+if LAB:
+    BUILD = os.path.join(BUILD, "lab")
+    KERNEL_UNITS = KERNEL_UNITS + ["szl_kernels_match3", "szl_kernels_match5"]
+
+
 def build(jobs=8):
     os.makedirs(BUILD, exist_ok=True)
-    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", CSRC, "libszl_amd.so"])
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", CSRC, "libszl_amd_lab.so" if LAB else "libszl_amd.so"])
     fake = os.path.join(BUILD, "libfakehip.so")
     src = os.path.join(HERE, "fakehip.cpp")
     if _newer(fake, [src]):
         tmp = "%s.%d.tmp" % (fake, os.getpid())                     # (several suites may start at once: never a half-written library)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I/opt/rocm/include", src, "-o", tmp, "-lpthread"])
         os.replace(tmp, fake)
-    objs = [os.path.join(CSRC, u + ".o") for u in KERNEL_UNITS]
+    objs = [os.path.join(CSRC, ("lab_" if LAB else "") + u + ".o") for u in KERNEL_UNITS]
     sim = os.path.join(BUILD, "libszl_amd_sim.so")
     if _newer(sim, objs + [fake]):
         tmp = "%s.%d.tmp" % (sim, os.getpid())
@@ -60,7 +66,7 @@ def build(jobs=8):
     for u in KERNEL_UNITS:
         s, out = os.path.join(CSRC, u + ".hip"), os.path.join(BUILD, u + ".s")
         if _newer(out, [s] + hdrs):
-            procs.append((u, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-DSZL_LAB=0",
+            procs.append((u, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-DSZL_LAB=%d" % int(LAB),
                                                s, "-o", out], stderr=subprocess.DEVNULL)))
             if len(procs) >= jobs:
                 u0, p0 = procs.pop(0)

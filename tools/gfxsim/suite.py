@@ -532,9 +532,44 @@ def suite_framing():
     return n
 
 
+def suite_lab_forms():
+    """the LABORATORY library (GFXSIM_LAB=1: libszl_amd_lab.so's objects) on the interpreter: stage B's dropped forms — chain compression
+    (SZL_MATCH_KERNEL=3), the ring (4), the bucket-order search (5) — and k_spec_win's four-ranges-per-store write-back (SZL_SPEC_WB=1),
+    each against the oracle (tests/test_gpu_stage_b_forms.py's subject, small)"""
+    import oracle_ffi as O
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd import corpus as C
+    assert os.environ.get("GFXSIM_LAB"), "run with GFXSIM_LAB=1"
+    n = 0
+    data = C.generate("dickens", 3, 0, 12000)
+    for knobs, levels in ((dict(SZL_MATCH_KERNEL=3), (6,)), (dict(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=64), (9,)),
+                          (dict(SZL_MATCH_KERNEL=5), (6,)), (dict(SZL_SPEC_WB=1), (5, 9))):
+        try:
+            _knobs(**knobs)
+            e = Engine()
+            for lv in levels:
+                r = e.deflate([data], level=lv)[0]
+                assert r.status == 0 and r.data == O.deflate(data, lv), (knobs, lv)
+                n += 1
+            e.close()
+        finally:
+            _knobs(**{k: FORGET for k in knobs})
+    e = Engine()
+    _knobs(SZL_SPEC_WB=1)
+    try:
+        for d2, lv in ((C.generate("logs", 5, 0, 30000), 6), (C.mixed(25000, seed=5), 9), (C.zeros(20000), 6)):
+            r = e.deflate([d2], level=lv)[0]
+            assert r.data == O.deflate(d2, lv), ("write-back", lv)
+            n += 1
+    finally:
+        _knobs(SZL_SPEC_WB=FORGET)
+    e.close()
+    return n
+
+
 SUITES = {"deflate_levels": suite_deflate_levels, "deflate_shapes": suite_deflate_shapes, "deflater_object": suite_deflater_object,
           "inflate": suite_inflate, "inflate_corrupt": suite_inflate_corrupt,
-          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order, "inflate_stream_bulk": suite_inflate_stream_bulk, "framing": suite_framing}
+          "forms": suite_forms, "inflate_parallel": suite_inflate_parallel, "inflate_dense": suite_inflate_dense, "multi_device": suite_multi_device, "exchange_order": suite_exchange_order, "inflate_stream_bulk": suite_inflate_stream_bulk, "framing": suite_framing, "lab_forms": suite_lab_forms}
 
 
 def main(argv):
