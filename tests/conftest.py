@@ -20,3 +20,23 @@ def pytest_sessionstart(session):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from gfxsim import harness
         harness.use(fast_probe=True)
+
+
+def pytest_collection_finish(session):
+    # the interpreter suites (tests/test_sim_product_code.py) are a dozen single-threaded processes: started now, they run beside the
+    # other CPU tests instead of after them
+    if any("test_sim_product_code.py" in it.nodeid for it in session.items):
+        try:
+            import test_sim_product_code as T
+            if os.path.exists(T.HIPCC):
+                T.start_all()
+        except Exception:
+            pass                                       # (the module's own fixture reports what is wrong)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        import test_sim_product_code as T
+        T.stop_all()
+    except Exception:
+        pass

@@ -25,20 +25,37 @@ if (os.cpu_count() or 1) < 4:
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc is needed for the device assembly")
 
 
-@pytest.fixture(scope="module")
-def runs():
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from gfxsim import harness
-    harness.build()                                   # libszl_amd.so's objects, the fake runtime, the kernels' assembly (cached)
-    env = dict(os.environ, PYTHONHASHSEED="0", GFXSIM_POISON="1")   # LDS and fresh device memory start as garbage, as on the device
-    env.pop("SZL_DEBUG", None)
-    procs = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s.split("@")[0]], cwd=ROOT,
-                                 env=dict(env, **({("GFXSIM_LAB" if s.endswith("@lab") else "GFXSIM_XCHG"): s.split("@")[1]} if "@" in s else {})),
-                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for s in SUITES}
-    yield procs
-    for p in procs.values():
+_PROCS = None
+
+
+def start_all():
+    """start every suite's process (idempotent).  tests/conftest.py calls this as soon as collection shows that this module will run, so
+    that the interpreter works on the other cores while the rest of the CPU suite runs on one."""
+    global _PROCS
+    if _PROCS is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from gfxsim import harness
+        harness.build()                               # libszl_amd.so's objects, the fake runtime, the kernels' assembly (cached)
+        if any(s.endswith("@lab") for s in SUITES):
+            subprocess.check_call([sys.executable, "-c", "import os,sys; os.environ['GFXSIM_LAB']='1'; sys.path.insert(0, %r); from gfxsim import harness; harness.build()" % os.path.join(ROOT, "tools")])
+        env = dict(os.environ, PYTHONHASHSEED="0", GFXSIM_POISON="1")   # LDS and fresh device memory start as garbage, as on the device
+        env.pop("SZL_DEBUG", None)
+        _PROCS = {s: subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gfxsim", "suite.py"), s.split("@")[0]], cwd=ROOT,
+                                      env=dict(env, **({("GFXSIM_LAB" if s.endswith("@lab") else "GFXSIM_XCHG"): s.split("@")[1]} if "@" in s else {})),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for s in SUITES}
+    return _PROCS
+
+
+def stop_all():
+    for p in (_PROCS or {}).values():
         if p.poll() is None:
             p.kill()
+
+
+@pytest.fixture(scope="module")
+def runs():
+    yield start_all()
+    stop_all()
 
 
 @pytest.mark.parametrize("suite", SUITES)
