@@ -31,6 +31,7 @@ thread_local CallCfg t_cfg;
 typedef int (*launch_cb_t)(const char *name, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, void **args, size_t shmem);
 launch_cb_t g_cb = nullptr;
 int g_ndev = 1;
+int cus() { static const int n = getenv("FAKEHIP_CUS") ? atoi(getenv("FAKEHIP_CUS")) : 256; return n > 0 ? n : 256; }   // (a small device reproduces the library's sizing decisions at small sizes)
 thread_local int t_dev = 0;
 thread_local hipError_t t_last = hipSuccess;
 
@@ -106,13 +107,13 @@ hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600 *p, int) {
     memset(p, 0, sizeof *p);
     strcpy(p->name, "gfxsim (CPU interpreter)");
     strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-");
-    p->multiProcessorCount = 256; p->warpSize = 64; p->totalGlobalMem = g_arena_size ? g_arena_size : (64ull << 30);
+    p->multiProcessorCount = cus(); p->warpSize = 64; p->totalGlobalMem = g_arena_size ? g_arena_size : (64ull << 30);
     p->sharedMemPerBlock = 65536; p->maxSharedMemoryPerMultiProcessor = 163840; p->maxThreadsPerBlock = 1024;
     return hipSuccess;
 }
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) {
     switch (a) {
-    case hipDeviceAttributeMultiprocessorCount: *v = 256; break;
+    case hipDeviceAttributeMultiprocessorCount: *v = cus(); break;
     case hipDeviceAttributeWarpSize: *v = 64; break;
     case hipDeviceAttributeMaxSharedMemoryPerBlock: *v = 65536; break;
     case hipDeviceAttributeMaxThreadsPerBlock: *v = 1024; break;
