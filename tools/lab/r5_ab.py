@@ -6,7 +6,7 @@ Everything runs in one process on one device; every line is `what | knob = value
 the default's bytes.  Nothing here changes a default: the winners are set in the source afterwards.
   1. the chunk-parallel Inflater on one member and on 64 x 4 MiB members: SZL_INF_SLOTS_PER_CU = 8 / 10 (chunk sizing) x SZL_INF_DENSE = 0 / 1
      (k_inflate<true,2,DENSE>: 168 registers) x SZL_INF_TRIM_TAIL = 0 / 1 (no tail round of stragglers: 64 x 4 MiB members are 2112 jobs for
-     2048 slots with the default sizing) — round 4's last GPU seconds: slots 10 + DENSE, one member -15 %, the members 3 x SLOWER (unexplained)
+     2048 slots with the default sizing) — round 4's last GPU seconds: slots 10 + DENSE, one member -15 %, the members 3 x SLOWER (chain repairs with the smaller chunks: profiles/r04/r5_dense_on_64x4mib_members.log)
   2. InflaterInputStream over that member with 16 MiB and 64 MiB buffers: SZL_INF_PINNED = 0 (default) / 1
   3. raw deflate level 6 of the same text (the bench step): the default, then the stage-B knobs one at a time (SZL9_FTH, SZL_TILE_LEN);
      with --lab also SZL_SPEC_WB = 0 / 1 (k_spec_win's write-back, four ranges per store: -14 % of the kernel's instructions on the interpreter)
