@@ -194,8 +194,18 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             const double expand = (double)s.out_cap / (double)s.in_len;
             p.reg_cap = (uint64_t)(1.5 * expand * (double)p.chunk_bytes) + 65536;
             p.reg.resize(p.sb.size());
-            for (auto &r : p.reg) { r = reg_total; reg_total += p.reg_cap; }
             p.regc.assign(p.sb.size(), p.reg_cap);
+            // SZL_INF_REG_BY_SPAN=1 (not the default: unmeasured): a job decodes from its start to the NEXT FOUND start — two or three chunks
+            // where a chunk holds no block header (chunks shorter than the stream's blocks: 39 KiB chunks against the ~40 KiB blocks of a
+            // reference-made stream) — so its region follows that span, never below the per-chunk size.  Round 4: such jobs overran their
+            // regions and were run again in a pass of their own, each as long as a round (profiles/r04/r5_dense_on_64x4mib_members.log).
+            if (knob("SZL_INF_REG_BY_SPAN", 0) != 0)
+                for (size_t j = 0; j < p.sb.size(); j++) {
+                    const uint64_t end_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : s.in_len * 8;
+                    const uint64_t span = (end_bit > p.sb[j] ? end_bit - p.sb[j] : 0) / 8 + 1;
+                    p.regc[j] = std::max<uint64_t>(p.reg_cap, (uint64_t)(1.5 * expand * (double)span) + 65536);
+                }
+            for (size_t j = 0; j < p.sb.size(); j++) { p.reg[j] = reg_total; reg_total += p.regc[j]; }
             // a chain that needs repair (a block boundary no candidate start named) or a job whose output outgrew the estimate used to
             // send the whole member through the count-first form — finder, count passes and symbol pass again (64 x 1 MiB members: 35
             // of them, +21 ms).  Now the single pass repairs in place: spare regions for the jobs a repair adds, a few large ones for
@@ -298,6 +308,8 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 // ran with an earlier stop, but a decode that stops at the first block boundary >= stop also stops there for
                 // any stop in (previous boundary, end_bit]: its count stays valid.)
                 ok = false;
+                if (dbg) fprintf(stderr, "[szl] inflate par: member %zu: job %u (start bit %llu) ended at bit %llu where nobody starts (next listed start: %s%llu) — repair\n",
+                                 p.si, j, (unsigned long long)p.sb[j], (unsigned long long)c.end_bit, m < p.sb.size() ? "" : "none ", m < p.sb.size() ? (unsigned long long)p.sb[m] : 0ull);
                 if (single_pass && p.spare.empty()) { p.alive = false; if (retry) retry->push_back(p.si); break; }
                 nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
                 if (single_pass) { nreg.push_back(p.spare.back()); p.spare.pop_back(); nregc.push_back(p.reg_cap); }

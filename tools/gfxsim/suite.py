@@ -300,7 +300,8 @@ def suite_inflate_parallel():
 
 def suite_inflate_dense():
     """the symbol pass compiled for 3 wavefronts per SIMD (SZL_INF_DENSE=1: k_inflate<true, 2, true>, another register
-    allocation of the same source; not the default) on one member, against the input"""
+    allocation of the same source; not the default) on one member, against the input; staging regions by span and tail trimming
+    (SZL_INF_REG_BY_SPAN, SZL_INF_TRIM_TAIL: not the defaults either) on a reference-made member"""
     from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
     from sharpziplib_amd import corpus as C
@@ -313,10 +314,23 @@ def suite_inflate_dense():
         (r, used), = e.inflate([m], [data.size], crc32=True)
         assert int(_lib.lib().szl_engine_debug_par_jobs(e._h)) >= 4
         assert r.status == 0 and r.data == data.tobytes() and used == len(m) and r.crc32 == zlib.crc32(data.tobytes())
+        _knobs(SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET)
+        import oracle_ffi as O
+        n = 1
+        # staging regions sized by a job's span (SZL_INF_REG_BY_SPAN=1, not the default) and the tail-round trimming, on a reference-made member
+        # whose blocks are longer than the 16 KiB chunks (jobs span several chunks)
+        small = C.generate("enwik", 0xE9, 0, 360000)
+        ms = O.deflate(small, 6)
+        _knobs(SZL_INF_REG_BY_SPAN=1, SZL_INF_TRIM_TAIL=1)
+        (r, used), = e.inflate([ms], [small.size], crc32=True)
+        assert int(_lib.lib().szl_engine_debug_par_jobs(e._h)) >= 3
+        assert r.status == 0 and r.data == small.tobytes() and used == len(ms)
+        _knobs(SZL_INF_REG_BY_SPAN=FORGET, SZL_INF_TRIM_TAIL=FORGET)
+        n += 1
     finally:
-        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET)
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET, SZL_INF_REG_BY_SPAN=FORGET, SZL_INF_TRIM_TAIL=FORGET)
         e.close()
-    return 1
+    return n
 
 
 def suite_multi_device():

@@ -6,7 +6,8 @@ Everything runs in one process on one device; every line is `what | knob = value
 the default's bytes.  Nothing here changes a default: the winners are set in the source afterwards.
   1. the chunk-parallel Inflater on one member and on 64 x 4 MiB members: SZL_INF_SLOTS_PER_CU = 8 / 10 (chunk sizing) x SZL_INF_DENSE = 0 / 1
      (k_inflate<true,2,DENSE>: 168 registers) x SZL_INF_TRIM_TAIL = 0 / 1 (no tail round of stragglers: 64 x 4 MiB members are 2112 jobs for
-     2048 slots with the default sizing) — round 4's last GPU seconds: slots 10 + DENSE, one member -15 %, the members 3 x SLOWER (chain repairs with the smaller chunks: profiles/r04/r5_dense_on_64x4mib_members.log)
+     2048 slots with the default sizing) — round 4's last GPU seconds: slots 10 + DENSE, one member -15 %, the members 3 x SLOWER (jobs that span two of the
+     smaller chunks overran their staging regions and were run again, a pass each: SZL_INF_REG_BY_SPAN = 1 sizes a job's region by its span)
   2. InflaterInputStream over that member with 16 MiB and 64 MiB buffers: SZL_INF_PINNED = 0 (default) / 1
   3. raw deflate level 6 of the same text (the bench step): the default, then the stage-B knobs one at a time (SZL9_FTH, SZL_TILE_LEN);
      with --lab also SZL_SPEC_WB = 0 / 1 (k_spec_win's write-back, four ranges per store: -14 % of the kernel's instructions on the interpreter)
@@ -60,8 +61,8 @@ print("member: %.2f MiB of text -> %d bytes" % (a.mib, len(comp)), flush=True)
 msz = 4 << 20
 parts = [plain[i * msz:(i + 1) * msz] for i in range(min(64, n // msz))]
 mcomps = [r.data for r in eng.deflate(parts, level=6)] if parts else []
-for slots, dense, trim in ((8, 0, 0), (8, 0, 1), (10, 0, 0), (8, 1, 0), (10, 1, 0), (10, 1, 1), (8, 0, 0)):
-    knob("SZL_INF_SLOTS_PER_CU", slots); knob("SZL_INF_DENSE", dense); knob("SZL_INF_TRIM_TAIL", trim)
+for slots, dense, trim, span in ((8, 0, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 1, 1), (10, 0, 0, 1), (10, 1, 0, 0), (10, 1, 0, 1), (10, 1, 1, 1), (8, 0, 0, 0)):
+    knob("SZL_INF_SLOTS_PER_CU", slots); knob("SZL_INF_DENSE", dense); knob("SZL_INF_TRIM_TAIL", trim); knob("SZL_INF_REG_BY_SPAN", span)
     best = 1e9
     for rep in range(3):
         (r, used), = eng.inflate([comp], [n], crc32=True)
@@ -73,9 +74,9 @@ for slots, dense, trim in ((8, 0, 0), (8, 0, 1), (10, 0, 0), (8, 1, 0), (10, 1, 
         out = eng.inflate(mcomps, [msz] * len(mcomps))
         bm = min(bm, eng.timing()["inflate_ms"])
     assert all(o[0].data == p.tobytes() for o, p in zip(out, parts)) if mcomps else True
-    print("inflate | SZL_INF_SLOTS_PER_CU = %2d SZL_INF_DENSE = %d SZL_INF_TRIM_TAIL = %d | one member %8.2f ms (%5.1f GiB/s) | %d x 4 MiB members %8.2f ms" % (
-        slots, dense, trim, best, a.mib / 1024 / (best * 1e-3), len(mcomps), bm if mcomps else 0.0), flush=True)
-knob("SZL_INF_SLOTS_PER_CU", FORGET); knob("SZL_INF_DENSE", FORGET); knob("SZL_INF_TRIM_TAIL", FORGET)
+    print("inflate | SZL_INF_SLOTS_PER_CU = %2d SZL_INF_DENSE = %d SZL_INF_TRIM_TAIL = %d SZL_INF_REG_BY_SPAN = %d | one member %8.2f ms (%5.1f GiB/s) | %d x 4 MiB members %8.2f ms" % (
+        slots, dense, trim, span, best, a.mib / 1024 / (best * 1e-3), len(mcomps), bm if mcomps else 0.0), flush=True)
+knob("SZL_INF_SLOTS_PER_CU", FORGET); knob("SZL_INF_DENSE", FORGET); knob("SZL_INF_TRIM_TAIL", FORGET); knob("SZL_INF_REG_BY_SPAN", FORGET)
 
 # ---- 2. the unchanged-host read path with room
 for bufsz in ((64 << 20,) if a.quick else (16 << 20, 64 << 20)):
