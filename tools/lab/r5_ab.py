@@ -4,7 +4,7 @@
 
 Everything runs in one process on one device; every line is `what | knob = value | time` and every output is compared with the input /
 the default's bytes.  Nothing here changes a default: the winners are set in the source afterwards.
-  1. the chunk-parallel Inflater on one member and on 64 x 4 MiB members: SZL_INF_SLOTS_PER_CU = 8 / 10 (chunk sizing) x SZL_INF_DENSE = 0 / 1
+  1. the chunk-parallel Inflater on one member and on 64 x 1 MiB members: SZL_INF_SLOTS_PER_CU = 8 / 10 (chunk sizing) x SZL_INF_DENSE = 0 / 1
      (k_inflate<true,2,DENSE>: 168 registers) x SZL_INF_TRIM_TAIL = 0 / 1 (no tail round of stragglers: 64 x 4 MiB members are 2112 jobs for
      2048 slots with the default sizing) — round 4's last GPU seconds: slots 10 + DENSE, one member -15 %, the members 3 x SLOWER (jobs that span two of the
      smaller chunks overran their staging regions and were run again, a pass each: SZL_INF_REG_BY_SPAN = 1 sizes a job's region by its span)
@@ -58,7 +58,7 @@ want = hashlib.sha256(plain.tobytes()).hexdigest()
 print("member: %.2f MiB of text -> %d bytes" % (a.mib, len(comp)), flush=True)
 
 # ---- 1. the symbol pass: chunk sizing (jobs per CU the chunks are cut for) x register budget of the kernel, on two shapes
-msz = 4 << 20
+msz = 1 << 20                                      # (64 x 1 MiB: the shape that stands at 3.4 GiB/s, with a second symbol pass over 35 jobs)
 parts = [plain[i * msz:(i + 1) * msz] for i in range(min(64, n // msz))]
 mcomps = [r.data for r in eng.deflate(parts, level=6)] if parts else []
 for slots, dense, trim, span in ((8, 0, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 1, 1), (10, 0, 0, 1), (10, 1, 0, 0), (10, 1, 0, 1), (10, 1, 1, 1), (8, 0, 0, 0)):
@@ -74,7 +74,7 @@ for slots, dense, trim, span in ((8, 0, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0
         out = eng.inflate(mcomps, [msz] * len(mcomps))
         bm = min(bm, eng.timing()["inflate_ms"])
     assert all(o[0].data == p.tobytes() for o, p in zip(out, parts)) if mcomps else True
-    print("inflate | SZL_INF_SLOTS_PER_CU = %2d SZL_INF_DENSE = %d SZL_INF_TRIM_TAIL = %d SZL_INF_REG_BY_SPAN = %d | one member %8.2f ms (%5.1f GiB/s) | %d x 4 MiB members %8.2f ms" % (
+    print("inflate | SZL_INF_SLOTS_PER_CU = %2d SZL_INF_DENSE = %d SZL_INF_TRIM_TAIL = %d SZL_INF_REG_BY_SPAN = %d | one member %8.2f ms (%5.1f GiB/s) | %d x 1 MiB members %8.2f ms" % (
         slots, dense, trim, span, best, a.mib / 1024 / (best * 1e-3), len(mcomps), bm if mcomps else 0.0), flush=True)
 knob("SZL_INF_SLOTS_PER_CU", FORGET); knob("SZL_INF_DENSE", FORGET); knob("SZL_INF_TRIM_TAIL", FORGET); knob("SZL_INF_REG_BY_SPAN", FORGET)
 
