@@ -78,6 +78,22 @@ for slots, dense, trim, span in ((8, 0, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0
         slots, dense, trim, span, best, a.mib / 1024 / (best * 1e-3), len(mcomps), bm if mcomps else 0.0), flush=True)
 knob("SZL_INF_SLOTS_PER_CU", FORGET); knob("SZL_INF_DENSE", FORGET); knob("SZL_INF_TRIM_TAIL", FORGET); knob("SZL_INF_REG_BY_SPAN", FORGET)
 
+# ---- 1b. many mid-size members: one wavefront per member (the library's choice above 128 streams) against the chunked form, with and
+#          without the span-sized regions (512 x 1 MiB stood at 51.8 ms = 9.65 GiB/s one wavefront each; chunked it lost while every member cost a second pass)
+many = [plain[i * msz:(i + 1) * msz] for i in range(min(512, n // msz))]
+if len(many) > 128:
+    mc = [r.data for r in eng.deflate(many, level=6)]
+    for parmin, span in ((FORGET, 0), (128, 0), (128, 1), (FORGET, 0)):
+        knob("SZL_INF_PAR_MIN_KIB", parmin); knob("SZL_INF_REG_BY_SPAN", span)
+        bm = 1e9
+        for rep in range(3):
+            out = eng.inflate(mc, [msz] * len(mc))
+            bm = min(bm, eng.timing()["inflate_ms"])
+        assert all(o[0].data == p.tobytes() for o, p in zip(out, many))
+        print("inflate %d x 1 MiB members | SZL_INF_PAR_MIN_KIB = %s SZL_INF_REG_BY_SPAN = %d | %8.2f ms (%5.1f GiB/s), %d chunk jobs" % (
+            len(mc), "default" if parmin == FORGET else parmin, span, bm, len(mc) / 1024 / (bm * 1e-3), L.szl_engine_debug_par_jobs(eng._h)), flush=True)
+    knob("SZL_INF_PAR_MIN_KIB", FORGET); knob("SZL_INF_REG_BY_SPAN", FORGET)
+
 # ---- 2. the unchanged-host read path with room
 for bufsz in ((64 << 20,) if a.quick else (16 << 20, 64 << 20)):
     for pinned in (0, 1, 0, 1):
