@@ -58,7 +58,7 @@ want = hashlib.sha256(plain.tobytes()).hexdigest()
 print("member: %.2f MiB of text -> %d bytes" % (a.mib, len(comp)), flush=True)
 
 # ---- 1. the symbol pass: chunk sizing (jobs per CU the chunks are cut for) x register budget of the kernel, on two shapes
-msz = 1 << 20                                      # (64 x 1 MiB: the shape that stands at 3.4 GiB/s, with a second symbol pass over 35 jobs)
+msz = (1 << 20) if not a.kib else 256            # (64 x 1 MiB: the shape that stands at 3.4 GiB/s, with a second symbol pass over 35 jobs)
 parts = [plain[i * msz:(i + 1) * msz] for i in range(min(64, n // msz))]
 mcomps = [r.data for r in eng.deflate(parts, level=6)] if parts else []
 for slots, dense, trim, span in ((8, 0, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 1, 1), (10, 0, 0, 1), (10, 1, 0, 0), (10, 1, 0, 1), (10, 1, 1, 1), (8, 0, 0, 0)):
