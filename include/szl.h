@@ -233,9 +233,38 @@ int szl_inflater_remaining_input(const szl_inflater *s);                    /* R
 int64_t szl_inflater_total_in(const szl_inflater *s);                       /* TotalIn          C/Inflater.cs:862 */
 int64_t szl_inflater_total_out(const szl_inflater *s);                      /* TotalOut         C/Inflater.cs:848 */
 uint32_t szl_inflater_adler(const szl_inflater *s);                         /* Adler            C/Inflater.cs:823 */
+/* --- the device-aware InflaterInputBuffer / InflaterInputStream (CS/InflaterInputStream.cs:14-330, :342-700; INTEGRATION.md file 3) ---
+ * The reference's buffer class reads `bufferSize` bytes (default 4096, :22, :342-358; GZipInputStream passes 4096,
+ * S/GZip/GzipInputStream.cs:72) from the base stream and hands them to Inflater.SetInput.  One wavefront decodes such a piece at
+ * ~17 MiB/s; the chunk-parallel decoder needs megabytes per SetInput.  The device-aware buffer class therefore reads AHEAD (16 MiB
+ * unless the constructor asked for more) into a buffer of pinned host memory — obtained here — and everything else of the class
+ * (Available, RawData/RawLength, ClearText, ReadLeByte .. ReadLeLong, ReadRawBuffer, ReadClearTextBuffer, CryptoTransform) works on
+ * that buffer as it did on the small one, so GZipInputStream / ZipInputStream still find their trailers in it.
+ *   szl_host_alloc / szl_host_free: a buffer of pinned host memory (a shim whose runtime owns the array pins it and calls
+ *   szl_host_register / szl_host_unregister instead).  A SetInput from such a buffer is taken WITHOUT a host copy when the object holds
+ *   no older input: the object keeps the pointer, as the reference's StreamManipulator keeps the caller's array
+ *   (CS/StreamManipulator.cs:244-262), the device reads it by DMA, and the few bytes the decoder leaves unconsumed are copied away
+ *   before IsNeedingInput turns true (the moment the reference allows the caller to refill the array). */
+void *szl_host_alloc(size_t n);
+void szl_host_free(void *p);
+int szl_host_register(void *p, size_t n);
+int szl_host_unregister(void *p);
+/* The object stops referring to the caller's pinned buffer now (what it has not consumed moves into its own memory): called by the
+ * stream shim before it frees or refills a buffer out of turn — Dispose() of a stream whose Inflater lives on (InflaterPool). */
+int szl_inflater_detach_input(szl_inflater *s);
+/* CRC-32 of the bytes handed out by Inflate() so far, kept on the device beside the decode (what GZipInputStream / ZipInputStream
+ * accumulate on the CPU over every buffer they return: S/GZip/GzipInputStream.cs:141, S/Zip/ZipInputStream.cs:673): a device-aware
+ * container stream switches it on before the first SetInput (and again after Reset: it stays on) and reads it where the reference
+ * reads crc.Value.  Off by default; 0 when off. */
+int szl_inflater_enable_crc32(szl_inflater *s, int on);
+uint32_t szl_inflater_crc32(const szl_inflater *s);
 /* Parity / measurement tap: pieces of this streaming Inflater's input that went to the chunk-parallel decoder (a SetInput of 2 MiB or
  * more — InflaterInputStream with a large buffer, CS/InflaterInputStream.cs:342-396 — is not decoded by one wavefront) */
 uint32_t szl_inflater_debug_bulk_calls(const szl_inflater *s);
+/* Measurement tap: wall-clock milliseconds this object has spent, by part — [0] SetInput, [1] upload of long pieces, [2] their decode
+ * (finder, symbol pass, windows, bytes), [3] their download, [4] checksums, [5] all decoder steps together ([1]..[4] are inside),
+ * [6] the copies out of Inflate(), [7] unused. */
+int szl_inflater_debug_times(const szl_inflater *s, double *ms8);
 
 /* Batch inflate of independent raw-deflate / zlib streams (zip entries, gzip members): one
  * wavefront per stream.  streams[i].in_* = compressed bytes, out_* = region for the decompressed

@@ -82,7 +82,7 @@ def _load(path):
         "szl_debug_set": (i32, [ctypes.c_char_p, i32]),
         "szl_engine_debug_workspace": (u64, [vp]),
         "szl_engine_debug_par_jobs": (ctypes.c_uint32, [vp]),
-        "szl_inflater_debug_bulk_calls": (ctypes.c_uint32, [vp]),
+        "szl_inflater_debug_bulk_calls": (ctypes.c_uint32, [vp]), "szl_inflater_debug_times": (i32, [vp, vp]),
         "szl_debug_stored_layout": (i32, [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]),
         "szl_inflater_create": (vp, [i32]), "szl_inflater_destroy": (None, [vp]), "szl_inflater_reset": (i32, [vp]),
         "szl_inflater_set_input": (i32, [vp, vp, i32]), "szl_inflater_set_dictionary": (i32, [vp, vp, i32]),
@@ -90,6 +90,8 @@ def _load(path):
         "szl_inflater_needs_dictionary": (i32, [vp]), "szl_inflater_is_finished": (i32, [vp]),
         "szl_inflater_remaining_input": (i32, [vp]), "szl_inflater_total_in": (i64, [vp]),
         "szl_inflater_total_out": (i64, [vp]), "szl_inflater_adler": (u32, [vp]),
+        "szl_inflater_enable_crc32": (i32, [vp, i32]), "szl_inflater_crc32": (u32, [vp]), "szl_inflater_detach_input": (i32, [vp]),
+        "szl_host_alloc": (vp, [sz]), "szl_host_free": (None, [vp]), "szl_host_register": (i32, [vp, sz]), "szl_host_unregister": (i32, [vp]),
         "szl_inflate_batch_device": (i32, [vp, vp, vp, vp, sz, ctypes.c_uint, vp]),
         "szl_inflate_batch_host": (i32, [vp, vp, vp, vp, sz, ctypes.c_uint]),
     }

@@ -1339,5 +1339,46 @@ static int checksum_host(unsigned want, uint32_t value, const void *data, size_t
     if (C.din.cap > (64u << 20)) C.din.release();        // (do not sit on a large input copy)
     return 0;
 }
+// ---- pinned I/O buffers of the device-aware stream classes (include/szl.h) ---------------------------------------------------------
+namespace {
+struct PinnedRange { const uint8_t *p; size_t n; bool ours; };
+std::mutex g_pin_mu;
+std::vector<PinnedRange> g_pinned;
+}
+namespace szl {
+bool host_is_pinned(const void *p, size_t n) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const PinnedRange &r : g_pinned) if ((const uint8_t *)p >= r.p && (const uint8_t *)p + n <= r.p + r.n) return true;
+    return false;
+}
+}
+extern "C" void *szl_host_alloc(size_t n) {
+    if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return nullptr; }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("pinned host memory (%zu bytes)", n); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.push_back(PinnedRange{(const uint8_t *)p, n, true});
+    return p;
+}
+static bool pinned_forget(void *p, bool ours) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pinned.size(); i++)
+        if (g_pinned[i].p == (const uint8_t *)p && g_pinned[i].ours == ours) { g_pinned.erase(g_pinned.begin() + (ptrdiff_t)i); return true; }
+    return false;
+}
+extern "C" void szl_host_free(void *p) { if (p && pinned_forget(p, true)) (void)hipHostFree(p); }
+extern "C" int szl_host_register(void *p, size_t n) {
+    if (!p || !n) return SZL_E_ARG;
+    if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
+    if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostRegister(%zu bytes) failed", n); return SZL_E_NOMEM; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.push_back(PinnedRange{(const uint8_t *)p, n, false});
+    return 0;
+}
+extern "C" int szl_host_unregister(void *p) {
+    if (!p || !pinned_forget(p, false)) return SZL_E_ARG;
+    return hipHostUnregister(p) == hipSuccess ? 0 : SZL_E_DEVICE;
+}
+
 extern "C" int szl_crc32(uint32_t value, const void *p, size_t n, uint32_t *out) { return checksum_host(1, value, p, n, out); }
 extern "C" int szl_adler32(uint32_t value, const void *p, size_t n, uint32_t *out) { return checksum_host(2, value, p, n, out); }

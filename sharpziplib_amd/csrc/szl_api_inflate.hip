@@ -143,9 +143,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         for (uint64_t v : in_lens) total_in += v;
         chunk_max = inflate_chunk_max(total_in, slots);
     }
-    // (szl_inflate_sizing.h; SZL_INF_TRIM_TAIL=1 — not the default, unmeasured — trims a tail round of a few stragglers away; only with
-    // the library's own sizing, never when a test or a tool has fixed the chunk size)
-    const std::vector<ChunkPlan> plans = inflate_chunk_plans(in_lens, chunk_max, slots, auto_size && knob("SZL_INF_TRIM_TAIL", 0) != 0);
+    const std::vector<ChunkPlan> plans = inflate_chunk_plans(in_lens, chunk_max);   // (szl_inflate_sizing.h)
     uint64_t nstart_total = 0;
     for (size_t k = 0; k < cand.size(); k++) {
         if (!plans[k].chunk_bytes) continue;
@@ -195,16 +193,16 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             p.reg_cap = (uint64_t)(1.5 * expand * (double)p.chunk_bytes) + 65536;
             p.reg.resize(p.sb.size());
             p.regc.assign(p.sb.size(), p.reg_cap);
-            // SZL_INF_REG_BY_SPAN=1 (not the default: unmeasured): a job decodes from its start to the NEXT FOUND start — two or three chunks
-            // where a chunk holds no block header (chunks shorter than the stream's blocks: 39 KiB chunks against the ~40 KiB blocks of a
-            // reference-made stream) — so its region follows that span, never below the per-chunk size.  Round 4: such jobs overran their
-            // regions and were run again in a pass of their own, each as long as a round (profiles/r04/r5_dense_on_64x4mib_members.log).
-            if (knob("SZL_INF_REG_BY_SPAN", 0) != 0)
-                for (size_t j = 0; j < p.sb.size(); j++) {
-                    const uint64_t end_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : s.in_len * 8;
-                    const uint64_t span = (end_bit > p.sb[j] ? end_bit - p.sb[j] : 0) / 8 + 1;
-                    p.regc[j] = std::max<uint64_t>(p.reg_cap, (uint64_t)(1.5 * expand * (double)span) + 65536);
-                }
+            // A job decodes from its start to the NEXT FOUND start — two or three chunks where a chunk holds no block header (chunks
+            // shorter than the stream's blocks: 16 KiB chunks against the ~40 KiB blocks of a reference-made stream) — so its region
+            // follows that span, never below the per-chunk size.  Sized per chunk, such jobs overran their regions and were run again
+            // in a pass of their own, each as long as a round: 64 x 1 MiB members 18.2 -> 15.4 ms, 512 of them in chunks 43.2 -> 40.4
+            // (profiles/r05/r5_ab.log; round 4 had found the cause on the interpreter and shipped it behind SZL_INF_REG_BY_SPAN).
+            for (size_t j = 0; j < p.sb.size(); j++) {
+                const uint64_t end_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : s.in_len * 8;
+                const uint64_t span = (end_bit > p.sb[j] ? end_bit - p.sb[j] : 0) / 8 + 1;
+                p.regc[j] = std::max<uint64_t>(p.reg_cap, (uint64_t)(1.5 * expand * (double)span) + 65536);
+            }
             for (size_t j = 0; j < p.sb.size(); j++) { p.reg[j] = reg_total; reg_total += p.regc[j]; }
             // a chain that needs repair (a block boundary no candidate start named) or a job whose output outgrew the estimate used to
             // send the whole member through the count-first form — finder, count passes and symbol pass again (64 x 1 MiB members: 35
@@ -505,9 +503,10 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     // Long members are decoded by many wavefronts each (inflate_members_parallel); whatever that does not take joins the batch of
     // one wavefront per stream.  With thousands of streams in a call that batch fills the device by itself and has no
     // per-stream host work at all, so the chunked form is used while the call would leave wavefront slots empty.
-    // (members of 128-512 KiB compressed: chunked only while the call has few streams — 64 x 1 MiB members 56 -> 34 ms, but 512 of them
-    // 57 -> 100 ms: their chunks are 16 KiB, and the finder / chain / resolve passes cost more than idle wavefront slots)
-    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", n_all <= 128 ? 128 : 512)) * 1024;
+    // (members of 128-512 KiB compressed: chunked only while the call has few streams — 64 x 1 MiB members 56 -> 34 -> 15.4 ms over the
+    // rounds; 512 of them were 57 -> 100 ms in round 2, when every member cost a second symbol pass; with regions sized by span they are
+    // 51.6 -> 40.4 ms in chunks, profiles/r05/r5_ab.log: the limit moved from 128 to 512 streams, a quarter of the wavefront slots)
+    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", n_all <= 512 ? 128 : 512)) * 1024;
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
@@ -626,12 +625,47 @@ int szl_inflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
 // ---------------------------------------------------------------------------------------------
 // Inflater (streaming object).  The decoder runs ahead of the caller: each kernel call decodes as
 // much of the input given so far as fits a 256 KiB device buffer; Inflate() hands the bytes out.
+// Pinned host memory that grows and keeps its contents.  Both byte queues of the streaming object live in it: the compressed bytes the
+// caller has given (uploaded by DMA at link speed instead of through the runtime's staging of pageable memory) and the decoded bytes
+// waiting for Inflate() (downloaded the same way; no page faults, no zero fill when a piece of 170 MiB arrives — round 4's
+// std::vector<uint8_t> spent 57 of the 67 ms a 64 MiB piece cost on exactly that, profiles/r05/r5_ab.log).
+struct HostBuf {
+    uint8_t *p = nullptr; size_t n = 0;        // the bytes: in `own`, or — while `borrowed` — in the caller's pinned buffer
+    uint8_t *own = nullptr; size_t cap = 0;    // our allocation
+    bool borrowed = false;
+    size_t size() const { return n; }
+    uint8_t *data() const { return p; }
+    void clear() { n = 0; p = own; borrowed = false; }
+    int reserve(size_t want) {                    // contents [0, n) are kept (never called while borrowed)
+        if (want <= cap) return 0;
+        size_t ncap = std::max(want, cap + cap / 2);
+        ncap = (ncap + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+        uint8_t *q = nullptr;
+        if (hipHostMalloc((void **)&q, ncap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("pinned host memory (%zu bytes)", ncap); return SZL_E_NOMEM; }
+        if (n) memcpy(q, own, n);
+        if (own) (void)hipHostFree(own);
+        p = own = q; cap = ncap;
+        return 0;
+    }
+    int append(const uint8_t *src, size_t k) { int rc = reserve(n + k); if (rc) return rc; if (k) memcpy(own + n, src, k); n += k; return 0; }
+    int grow(size_t k) { int rc = reserve(n + k); if (rc) return rc; n += k; return 0; }   // k more bytes, uninitialised
+    void erase_front(size_t k) { if (k >= n) { n = 0; return; } memmove(p, p + k, n - k); n -= k; }
+    void borrow(const uint8_t *q, size_t k) { p = const_cast<uint8_t *>(q); n = k; borrowed = true; }   // (only into an empty buffer)
+    int unborrow(size_t from) {                   // the bytes [from, n) move into our own memory, to offset 0
+        if (!borrowed) return 0;
+        const uint8_t *q = p; const size_t k = n > from ? n - from : 0;
+        p = own; n = 0; borrowed = false;
+        return append(q + from, k);
+    }
+    void release() { if (own) (void)hipHostFree(own); p = own = nullptr; n = cap = 0; borrowed = false; }
+};
+
 struct szl_inflater {
     int no_header = 0;
-    std::vector<uint8_t> hin;      // compressed bytes not yet consumed (hin[0] is stream byte `in_base`)
+    HostBuf hin;                   // compressed bytes not yet consumed (hin[0] is stream byte `in_base`); pinned
     uint64_t given = 0;            // total bytes ever passed to SetInput
     uint64_t in_base = 0;          // stream offset of hin[0]
-    std::vector<uint8_t> pend;     // decoded bytes not yet handed out
+    HostBuf pend;                  // decoded bytes not yet handed out; pinned
     size_t pend_pos = 0;
     int64_t total_out = 0;
     InfState st{};                 // host mirror of the device state (bitpos relative to in_base)
@@ -639,43 +673,47 @@ struct szl_inflater {
     int err = 0;                   // sticky error
     bool fresh_input = false;      // bytes were added since the decoder last reported NEED_INPUT
     bool have_dict = false;        // a preset dictionary sits in the device window
-    uint32_t adler = 1;            // Adler-32 of the bytes handed out so far (zlib mode), excluding `unsummed`
-    std::vector<uint8_t> unsummed; // handed-out bytes not yet folded into `adler` (folded on the device, lazily)
-    uint32_t adler_dec = 1;        // Adler-32 of everything decoded so far
+    // Checksums of the bytes handed out so far (Inflater.Adler, C/Inflater.cs:823; the CRC-32 is what GZipInputStream keeps over what it
+    // read, S/GZip/GzipInputStream.cs:141) = the checksum of everything in front of pend[0] (`*_base`) continued over pend[0 .. pend_pos):
+    // evaluated when asked for, on the device; nothing is copied per Inflate() call.  `*_dec` run over everything decoded so far, piece by
+    // piece on the device, and become the base whenever `pend` has been drained (decoded == handed out at that moment).
+    uint32_t adler_base = 1, crc_base = 0;
+    uint32_t adler_dec = 1, crc_dec = 0;
+    bool want_crc = false;         // szl_inflater_enable_crc32
     size_t hin_pos = 0;            // bytes at the front of hin that are consumed already (dropped in bulk, not per step)
     DevBuf d_in, d_out, d_win, d_job, d_state;
     static constexpr size_t OUT_CHUNK = 256 * 1024;
     // One step = one upload, one launch, two small downloads: job, state and the input prefix travel as ONE block through pinned
-    // host memory (`h_ctl` -> `d_ctl`: [InfJob | InfState | input]), the decoded bytes come back through a pinned buffer.
+    // host memory (`h_ctl` -> `d_ctl`: [InfJob | InfState | input]), the decoded bytes come back into `pend` (pinned).
     // (Before: three synchronous pageable copies up, three down and an erase at the front of the input vector per Inflate() call
     // that ran dry — InflaterInputStream.Fill gives 4 KiB at a time, CS/InflaterInputStream.cs:115,658.)
     static constexpr size_t IN_STEP = OUT_CHUNK + (64u << 10);
     static constexpr size_t CTL_HDR = (sizeof(InfJob) + sizeof(InfState) + 63) & ~(size_t)63;
-    uint8_t *h_ctl = nullptr, *h_out = nullptr;
+    uint8_t *h_ctl = nullptr;
     DevBuf d_ctl;
-    // A LONG input (InflaterInputStream with a large buffer, CS/InflaterInputStream.cs:342-396: the size is a constructor argument) goes
-    // to the chunk-parallel decoder: the one-wavefront decoder brings the stream to a block header, then everything up to the last block
-    // boundary in the input is decoded by many wavefronts at once (inflater_bulk) and waits in `pend`.
+    // A LONG input (InflaterInputStream with a large buffer, CS/InflaterInputStream.cs:342-396: the size is a constructor argument; the
+    // device-aware InflaterInputBuffer reads 16 MiB ahead whatever it was given) goes to the chunk-parallel decoder: the one-wavefront
+    // decoder brings the stream to a block header, then everything up to the last block boundary in the input is decoded by many
+    // wavefronts at once (inflater_bulk) and waits in `pend`.
     szl_engine *eng = nullptr;
     DevBuf d_bulk_in, d_bulk_out, d_win_lin;
     DevBuf d_ex;                   // k_inflate_exact's state ([ExState | which]) once the stream has met a block that needs it
     bool exact_live = false;       // the exact decoder holds the stream (until it hands it back at a clean block header)
-    // SZL_INF_PINNED=1 (not the default; unmeasured — round 4 ended without GPU minutes): the bytes of a long piece come back through ONE
-    // pinned buffer that is kept for the object's life and are handed out from there, instead of a std::vector that is grown (zero-filled,
-    // page-faulted) for every piece and filled by a pageable copy.  `pv` bytes are older than anything in `pend`.
-    uint8_t *h_bulk = nullptr; size_t h_bulk_cap = 0;
-    size_t pv_n = 0, pv_pos = 0;
     uint64_t bulk_skip_given = 0;  // do not try again before more input than this has been given (the last attempt found no chain)
     uint32_t bulk_calls = 0;       // (tests / tools: how often the parallel decoder took a piece)
+    double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // measurement tap (szl_inflater_debug_times): SetInput, upload, parallel decode, download, checksums, one-wavefront steps, hand-out copies
 };
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Lap { double &acc; double t0; explicit Lap(double &a) : acc(a), t0(now_ms()) {} ~Lap() { acc += now_ms() - t0; } };
 
-static inline size_t inflater_waiting(const szl_inflater *s) { return (s->pv_n - s->pv_pos) + (s->pend.size() - s->pend_pos); }   // decoded, not handed out
+enum : size_t { BORROW_MIN = 256u << 10 };
+static inline size_t inflater_waiting(const szl_inflater *s) { return s->pend.size() - s->pend_pos; }   // decoded, not handed out
 
 static void inflater_clear(szl_inflater *s) {
-    s->hin.clear(); s->hin_pos = 0; s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0; s->pv_n = s->pv_pos = 0;
+    s->hin.clear(); s->hin_pos = 0; s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0;
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
-    s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler = 1; s->adler_dec = 1; s->unsummed.clear();
+    s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler_base = 1; s->adler_dec = 1; s->crc_base = 0; s->crc_dec = 0;
     s->bulk_skip_given = 0; s->exact_live = false;
 }
 
@@ -693,8 +731,7 @@ void szl_inflater_destroy(szl_inflater *s) {
     s->d_bulk_in.release(); s->d_bulk_out.release(); s->d_win_lin.release(); s->d_ex.release();
     if (s->eng) szl_engine_destroy(s->eng);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
-    if (s->h_out) (void)hipHostFree(s->h_out);
-    if (s->h_bulk) (void)hipHostFree(s->h_bulk);
+    s->hin.release(); s->pend.release();
     delete s;
 }
 int szl_inflater_reset(szl_inflater *s) { if (!s) return SZL_E_ARG; inflater_clear(s); return 0; }
@@ -717,24 +754,60 @@ int szl_inflater_needs_dictionary(const szl_inflater *s) { return s && s->dec_st
 int szl_inflater_is_finished(const szl_inflater *s) { return s && s->dec_status == INF_FINISHED && inflater_waiting(s) == 0; } // :806
 int64_t szl_inflater_total_in(const szl_inflater *s) { return s ? (int64_t)s->given - szl_inflater_remaining_input(s) : 0; } // :862
 int64_t szl_inflater_total_out(const szl_inflater *s) { return s ? s->total_out : 0; }
-static void fold_adler(szl_inflater *s) {
-    if (s->unsummed.empty()) return;
-    uint32_t v = s->adler;
-    if (szl_adler32(s->adler, s->unsummed.data(), s->unsummed.size(), &v) == 0) s->adler = v;
-    s->unsummed.clear();
+// checksum of the bytes handed out so far: the base continued over the handed-out front of `pend` (which == 1: CRC-32, 2: Adler-32)
+static uint32_t handed_out_checksum(const szl_inflater *s, unsigned which) {
+    uint32_t v = which == 1 ? s->crc_base : s->adler_base;
+    if (s->pend_pos) {
+        uint32_t w = v;
+        if ((which == 1 ? szl_crc32(v, s->pend.data(), s->pend_pos, &w) : szl_adler32(v, s->pend.data(), s->pend_pos, &w)) == 0) v = w;
+    }
+    return v;
 }
-uint32_t szl_inflater_adler(const szl_inflater *cs) { // :823
-    szl_inflater *s = const_cast<szl_inflater *>(cs);
+uint32_t szl_inflater_adler(const szl_inflater *s) { // :823
     if (!s || s->no_header) return 0;
     if (s->dec_status == INF_NEED_DICT) return s->st.adler_read; // IsNeedingDictionary => readAdler (:827-830)
-    fold_adler(s);
-    return s->adler;
+    return handed_out_checksum(s, 2);
+}
+int szl_inflater_enable_crc32(szl_inflater *s, int on) {
+    if (!s) return SZL_E_ARG;
+    if (s->given != 0 && (on != 0) != s->want_crc) { set_error("the CRC-32 is switched before the first SetInput (or after Reset)"); return SZL_E_STATE; }
+    s->want_crc = on != 0;
+    return 0;
+}
+uint32_t szl_inflater_crc32(const szl_inflater *s) { return s && s->want_crc ? handed_out_checksum(s, 1) : 0; }
+
+// `pend` is about to receive a piece: if everything in it has been handed out, drop it — decoded == handed out at this moment, so the
+// running checksums of the decoded bytes become the base of the handed-out ones
+static void pend_recycle(szl_inflater *s) {
+    if (s->pend_pos == s->pend.size()) { s->pend.clear(); s->pend_pos = 0; s->adler_base = s->adler_dec; s->crc_base = s->crc_dec; }
+}
+// the piece of `total` bytes at d_p (device) has just been decoded: running checksums of the decoded bytes
+static int checksum_decoded(szl_inflater *s, const uint8_t *d_p, uint64_t total) {
+    const unsigned want = (s->no_header ? 0u : 2u) | (s->want_crc ? 1u : 0u);
+    if (!want || !total) return 0;
+    std::vector<std::pair<uint64_t, uint64_t>> regs{{0, total}};
+    std::vector<std::pair<uint32_t, uint32_t>> init{{s->crc_dec, s->adler_dec}}, out;
+    int rc = region_checksums(d_p, regs, want, out, &init, nullptr);
+    if (rc) return rc;
+    if (want & 1u) s->crc_dec = out[0].first;
+    if (want & 2u) s->adler_dec = out[0].second;
+    return 0;
 }
 
 int szl_inflater_set_input(szl_inflater *s, const uint8_t *p, int n) { // :629
     if (!s || n < 0 || (!p && n)) return SZL_E_ARG;
     if (!szl_inflater_needs_input(s) && s->given != 0) { set_error("Old input was not completely processed"); return SZL_E_STATE; }
-    s->hin.insert(s->hin.end(), p, p + n);
+    Lap lap(s->t_ms[0]);
+    if (s->hin_pos == s->hin.size()) { s->hin.clear(); s->hin_pos = 0; }
+    int rc = 0;
+    // a long piece out of a pinned buffer (the device-aware InflaterInputBuffer's, szl_host_alloc) into an object that holds nothing older:
+    // no host copy — the pointer is kept, as CS/StreamManipulator.cs:244-262 keeps the caller's array, until the decoder has run over it
+    if (s->hin.size() == 0 && (size_t)n >= BORROW_MIN && host_is_pinned(p, (size_t)n)) s->hin.borrow(p, (size_t)n);
+    else {
+        if (s->hin.borrowed) { if ((rc = s->hin.unborrow(s->hin_pos))) return rc; s->hin_pos = 0; }
+        rc = s->hin.append(p, (size_t)n);
+    }
+    if (rc) return rc;
     s->given += (uint64_t)n;
     if (n) s->fresh_input = true;
     return 0;
@@ -771,14 +844,20 @@ static uint64_t inflater_drop_consumed(szl_inflater *s, uint64_t limit = ~0ull) 
         s->in_base += drop;
         s->st.bitpos -= 8 * drop;
         if (s->hin_pos == s->hin.size()) { s->hin.clear(); s->hin_pos = 0; }
-        else if (s->hin_pos > (1u << 20) && s->hin_pos * 2 > s->hin.size()) { s->hin.erase(s->hin.begin(), s->hin.begin() + (ptrdiff_t)s->hin_pos); s->hin_pos = 0; }
+        else if (!s->hin.borrowed && s->hin_pos > (1u << 20) && s->hin_pos * 2 > s->hin.size()) { s->hin.erase_front(s->hin_pos); s->hin_pos = 0; }
     }
     return drop;
 }
 
 enum : size_t { BULK_MIN_DEFAULT_KIB = 2048 };
+// What one call of the chunk-parallel decoder may hold (round-4 ADVICE): the reference's Inflater runs in constant memory, and DEFLATE
+// expands up to 1032:1, so "decode everything the caller gave" would turn a SetInput of hostile megabytes into gigabytes on the device
+// and in pinned host memory.  A piece is cut so that its EXPECTED output stays within SZL_INF_BULK_OUT_MIB (the rest of the input is
+// taken by the next pieces), and a piece whose REAL output is beyond twice that is not taken at all: it is tried once more at a size
+// scaled by what it showed, and otherwise left to the one-wavefront decoder, which hands out 256 KiB per step.
+enum : int { BULK_OUT_DEFAULT_MIB = 512 };
 
-// The chunk-parallel decoder on everything the caller has given and the decoder has not consumed.  The stream stands at a block
+// The chunk-parallel decoder on what the caller has given and the decoder has not consumed.  The stream stands at a block
 // header (st.mode == INF_M_HEADER, not the last block).  Returns 1 = a piece was decoded into `pend`, 0 = not taken (the caller goes
 // on with the one-wavefront decoder), < 0 = device failure.
 static int inflater_bulk(szl_inflater *s) {
@@ -786,8 +865,18 @@ static int inflater_bulk(szl_inflater *s) {
     const size_t nin = s->hin.size() - s->hin_pos;
     if (!s->eng && !(s->eng = szl_engine_create())) return SZL_E_NOMEM;
     Engine &E = s->eng->e;
+    // staging of the single pass is sized from an expected expansion: what this stream has shown so far, generously (a piece that
+    // overruns it goes through the count-first form below)
+    const uint64_t cons = s->in_base + (s->st.bitpos >> 3);
+    double expand = cons > 65536 ? 1.5 * (double)s->st.outpos / (double)cons : 6.0;
+    if (expand < 4.0) expand = 4.0;
+    if (expand > 64.0) expand = 64.0;
+    const uint64_t out_budget = (uint64_t)std::max(16, knob("SZL_INF_BULK_OUT_MIB", (int)BULK_OUT_DEFAULT_MIB)) << 20;
+    const size_t bulk_min = (size_t)std::max(256, knob("SZL_INF_STREAM_BULK_KIB", (int)BULK_MIN_DEFAULT_KIB)) * 1024;
+    size_t take = nin;
+    if ((double)take * expand > (double)out_budget) take = std::max<size_t>((size_t)((double)out_budget / expand), std::min(nin, bulk_min)) & ~(size_t)3;
     if ((rc = s->d_bulk_in.ensure(nin + 64)) || (rc = s->d_win_lin.ensure(2 * 32768)) || (rc = s->d_win.ensure(32768))) return rc;
-    HIPCHK(hipMemcpy(s->d_bulk_in.p, s->hin.data() + s->hin_pos, nin, hipMemcpyHostToDevice));
+    { Lap lap(s->t_ms[1]); HIPCHK(hipMemcpy(s->d_bulk_in.p, s->hin.data() + s->hin_pos, std::min(nin, take + 64), hipMemcpyHostToDevice)); }   // (pinned source: DMA)
     // the window the one-wavefront decoder keeps is a ring indexed by output position & 32767; the chunk jobs' windows are linear
     // (oldest byte first): linear[i] = ring[(outpos + i) & 32767]
     uint8_t *ring = (uint8_t *)s->d_win.p, *lin = (uint8_t *)s->d_win_lin.p, *lin_out = lin + 32768;
@@ -797,53 +886,42 @@ static int inflater_bulk(szl_inflater *s) {
         HIPCHK(hipMemcpy(lin, ring + r0, 32768 - r0, hipMemcpyDeviceToDevice));
         if (r0) HIPCHK(hipMemcpy(lin + (32768 - r0), ring, r0, hipMemcpyDeviceToDevice));
     }
-    szl_stream ps{};
-    ps.in_off = 0; ps.in_len = nin; ps.out_off = 0;
-    // staging of the single pass is sized from an expected expansion: what this stream has shown so far, generously (a piece that
-    // overruns it goes through the count-first form below)
-    const uint64_t cons = s->in_base + (s->st.bitpos >> 3);
-    double expand = cons > 65536 ? 1.5 * (double)s->st.outpos / (double)cons : 6.0;
-    if (expand < 4.0) expand = 4.0;
-    if (expand > 64.0) expand = 64.0;
-    ps.out_cap = (uint64_t)(expand * (double)nin);
     ParStream sm;
-    sm.first_bit = s->st.bitpos; sm.win0 = lin; sm.win_out = lin_out;
-    sm.alloc_out = [&](uint64_t total) -> uint8_t * { return s->d_bulk_out.ensure(total + 64) ? nullptr : (uint8_t *)s->d_bulk_out.p; };
-    std::vector<size_t> cand{0}, retry;
     std::vector<char> taken(1, 0);
     std::vector<ParResult> res(1);
-    rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, cand, false, knob("SZL_INF_SINGLE_PASS", 1) != 0, nullptr, taken, res, &retry, &sm);
-    if (rc >= 0 && !taken[0] && !retry.empty()) rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, retry, false, false, nullptr, taken, res, nullptr, &sm);
-    if (rc < 0) return rc;
+    uint64_t refused_total = 0;                      // the piece's real output when it was beyond the bound
+    const double t_dec0 = now_ms();
+    for (int attempt = 0; attempt < 2; attempt++) {
+        szl_stream ps{};
+        ps.in_off = 0; ps.in_len = take; ps.out_off = 0;
+        ps.out_cap = (uint64_t)(expand * (double)take);
+        sm = ParStream{};
+        sm.first_bit = s->st.bitpos; sm.win0 = lin; sm.win_out = lin_out;
+        refused_total = 0;
+        sm.alloc_out = [&](uint64_t total) -> uint8_t * {
+            if (total > 2 * out_budget) { refused_total = total; return nullptr; }
+            return s->d_bulk_out.ensure(total + 64) ? nullptr : (uint8_t *)s->d_bulk_out.p;
+        };
+        std::vector<size_t> cand{0}, retry;
+        taken[0] = 0;
+        rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, cand, false, knob("SZL_INF_SINGLE_PASS", 1) != 0, nullptr, taken, res, &retry, &sm);
+        if (rc >= 0 && !taken[0] && !retry.empty() && !refused_total) rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, retry, false, false, nullptr, taken, res, nullptr, &sm);
+        if (rc < 0) return rc;
+        if (taken[0] || !refused_total) break;
+        // far more output than this stream had shown: a piece scaled to the bound by what it showed, at least the path's minimum
+        const size_t smaller = (size_t)((double)take * (double)out_budget / (double)refused_total) & ~(size_t)3;
+        if (smaller < bulk_min || smaller >= take) break;
+        take = smaller;
+    }
+    s->t_ms[2] += now_ms() - t_dec0;
     if (!taken[0] || sm.end_bit <= s->st.bitpos) return 0;
     const uint64_t total = res[0].out_written;
-    // the decoded bytes wait in `pend` (the decoder runs ahead of the caller as in inflater_step)
-    bool through_pinned = false;
-    if (total && total <= (1ull << 30) && inflater_waiting(s) == 0 && knob("SZL_INF_PINNED", 0) != 0) {   // (a piece beyond 1 GiB is not pinned)
-        if (s->h_bulk_cap < total) {
-            if (s->h_bulk) { (void)hipHostFree(s->h_bulk); s->h_bulk = nullptr; s->h_bulk_cap = 0; }
-            const size_t want = (size_t)total + (size_t)total / 4 + (1u << 20);
-            if (hipHostMalloc((void **)&s->h_bulk, want, hipHostMallocDefault) == hipSuccess) s->h_bulk_cap = want;
-            else { s->h_bulk = nullptr; (void)hipGetLastError(); }       // no pinned memory of that size: the pageable form below
-        }
-        if (s->h_bulk_cap >= total) {
-            HIPCHK(hipMemcpy(s->h_bulk, s->d_bulk_out.p, total, hipMemcpyDeviceToHost));
-            s->pend.clear(); s->pend_pos = 0; s->pv_n = (size_t)total; s->pv_pos = 0;
-            through_pinned = true;
-        }
-    }
-    if (!through_pinned) {
-        size_t old = s->pend.size();
-        if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
-        s->pend.resize(old + total);
-        if (total) HIPCHK(hipMemcpy(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost));
-    }
-    if (!s->no_header && total) {
-        std::vector<std::pair<uint64_t, uint64_t>> regs{{0, total}};
-        std::vector<std::pair<uint32_t, uint32_t>> init{{0u, s->adler_dec}}, out;
-        if ((rc = region_checksums((const uint8_t *)s->d_bulk_out.p, regs, 2u, out, &init, nullptr))) return rc;
-        s->adler_dec = out[0].second;
-    }
+    // the decoded bytes wait in `pend` (the decoder runs ahead of the caller as in inflater_step): one DMA into pinned memory
+    pend_recycle(s);
+    const size_t old = s->pend.size();
+    if ((rc = s->pend.grow(total))) return rc;
+    { Lap lap(s->t_ms[3]); if (total) HIPCHK(hipMemcpy(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost)); }
+    { Lap lap(s->t_ms[4]); if ((rc = checksum_decoded(s, (const uint8_t *)s->d_bulk_out.p, total))) return rc; }
     // the state the one-wavefront decoder continues from: a block header (or, behind the final block, "last block done")
     s->st.outpos += total;
     s->st.bitpos = sm.end_bit;
@@ -874,7 +952,6 @@ static int inflater_step(szl_inflater *s) {
     if ((rc = s->d_ctl.ensure(szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64)) || (rc = s->d_out.ensure(szl_inflater::OUT_CHUNK + 64)) ||
         (rc = s->d_win.ensure(32768))) return rc;
     if (!s->h_ctl && hipHostMalloc((void **)&s->h_ctl, szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
-    if (!s->h_out && hipHostMalloc((void **)&s->h_out, szl_inflater::OUT_CHUNK + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
     // One step produces at most OUT_CHUNK bytes, so it cannot need more than about that much input (stored data is 1:1):
     // upload a bounded prefix instead of the whole unconsumed input every step (a large SetInput would cost O(n^2) H2D).
     size_t nup = std::min<size_t>(nin, szl_inflater::IN_STEP);
@@ -909,18 +986,12 @@ static int inflater_step(szl_inflater *s) {
     else s->dec_status = j.status;
     if (j.status == INF_NEED_INPUT && nup < nin) s->fresh_input = true; // only the uploaded prefix ran dry
     if (j.out_written) {
-        size_t old = s->pend.size();
-        if (s->pend_pos == old) { s->pend.clear(); s->pend_pos = 0; old = 0; }
-        s->pend.resize(old + j.out_written);
-        HIPCHK(hipMemcpyAsync(s->h_out, s->d_out.p, j.out_written, hipMemcpyDeviceToHost, nullptr));
+        pend_recycle(s);
+        const size_t old = s->pend.size();
+        if ((rc = s->pend.grow(j.out_written))) return rc;
+        HIPCHK(hipMemcpyAsync(s->pend.data() + old, s->d_out.p, j.out_written, hipMemcpyDeviceToHost, nullptr));   // (pinned destination)
         HIPCHK(hipStreamSynchronize(nullptr));
-        memcpy(s->pend.data() + old, s->h_out, j.out_written);
-        if (!s->no_header) { // running Adler-32 of the decoded bytes, on the device (K/Adler32.cs)
-            std::vector<std::pair<uint64_t, uint64_t>> regs{{0, j.out_written}};
-            std::vector<std::pair<uint32_t, uint32_t>> init{{0u, s->adler_dec}}, out;
-            if ((rc = region_checksums((const uint8_t *)s->d_out.p, regs, 2u, out, &init, nullptr))) return rc;
-            s->adler_dec = out[0].second;
-        }
+        if ((rc = checksum_decoded(s, (const uint8_t *)s->d_out.p, j.out_written))) return rc;   // K/Adler32.cs, K/Crc32.cs: on the device
     }
     if (s->err) return 0;
     if (s->dec_status == INF_FINISHED && !s->no_header && s->st.adler_read != s->adler_dec) { s->err = SZL_E_ADLER_MISMATCH; return 0; }
@@ -936,32 +1007,48 @@ static int inflater_step(szl_inflater *s) {
 }
 
 uint32_t szl_inflater_debug_bulk_calls(const szl_inflater *s) { return s ? s->bulk_calls : 0; }
+int szl_inflater_debug_times(const szl_inflater *s, double *ms8) { if (!s || !ms8) return SZL_E_ARG; memcpy(ms8, s->t_ms, sizeof s->t_ms); return 0; }
 
+int szl_inflater_detach_input(szl_inflater *s) {
+    if (!s) return SZL_E_ARG;
+    if (!s->hin.borrowed) return 0;
+    const int rc = s->hin.unborrow(s->hin_pos);
+    s->hin_pos = 0;
+    return rc;
+}
+static int inflater_inflate(szl_inflater *s, uint8_t *out, int count);
 int szl_inflater_inflate(szl_inflater *s, uint8_t *out, int count) { // :715
     if (!s || count < 0 || (!out && count)) return SZL_E_ARG;
+    const int r = inflater_inflate(s, out, count);
+    // a borrowed input buffer goes back to the caller the moment IsNeedingInput turns true (he may refill it then): what the decoder
+    // has left of it — less than a block — moves into the object's own memory
+    if (s->hin.borrowed && (s->err || szl_inflater_needs_input(s) || s->dec_status == INF_FINISHED)) {
+        const int rc = s->hin.unborrow(s->hin_pos);
+        s->hin_pos = 0;
+        if (rc) return rc;
+    }
+    return r;
+}
+static int inflater_inflate(szl_inflater *s, uint8_t *out, int count) {
     if (s->err && inflater_waiting(s) == 0) return s->err;
     int copied = 0;
     for (;;) {
-        const bool from_pv = s->pv_pos < s->pv_n;                 // (the pinned piece is older than whatever waits in `pend`)
-        size_t avail = from_pv ? s->pv_n - s->pv_pos : s->pend.size() - s->pend_pos;
+        const size_t avail = s->pend.size() - s->pend_pos;
         if (s->err && avail == 0) return copied ? copied : s->err; // bytes decoded before the error went out first
         if (avail && count) {
-            size_t k = std::min<size_t>(avail, (size_t)count);
-            memcpy(out, from_pv ? s->h_bulk + s->pv_pos : s->pend.data() + s->pend_pos, k);
-            if (!s->no_header) { // Adler of what has been handed out == adler.Update in Inflate (:752-756); folded lazily on the device
-                s->unsummed.insert(s->unsummed.end(), out, out + k);
-                if (s->unsummed.size() > (4u << 20)) fold_adler(s);
-            }
-            if (from_pv) s->pv_pos += k; else s->pend_pos += k;
+            const size_t k = std::min<size_t>(avail, (size_t)count);
+            { Lap lap(s->t_ms[6]); memcpy(out, s->pend.data() + s->pend_pos, k); }   // (the checksums of what has been handed out: handed_out_checksum)
+            s->pend_pos += k;
             out += k; count -= (int)k; copied += (int)k; s->total_out += (int64_t)k;
             if (count == 0) return copied;
-            if (from_pv) continue;                                 // (the rest of the request from `pend`, if anything waits there)
         }
         if (s->dec_status == INF_FINISHED) return copied;
         if (s->dec_status == INF_NEED_DICT) return copied;                      // IsNeedingDictionary: the caller must SetDictionary
         if (s->dec_status == INF_NEED_INPUT && !s->fresh_input) return copied; // IsNeedingInput
         if (s->err) return copied; // (count == 0 with bytes still pending: nothing to hand out, nothing more to decode)
+        const double t_step0 = now_ms();
         int rc = inflater_step(s);
+        s->t_ms[5] += now_ms() - t_step0;    // (includes the parallel pieces: [1]..[4] are inside it)
         if (rc) return rc;
         if (count == 0) return copied; // Inflate(…, 0): "count may be zero" still advances the decoder (:738-745)
     }

@@ -46,6 +46,9 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		[DllImport(Lib)] internal static extern long szl_inflater_total_in(IntPtr s);
 		[DllImport(Lib)] internal static extern long szl_inflater_total_out(IntPtr s);
 		[DllImport(Lib)] internal static extern uint szl_inflater_adler(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_detach_input(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_enable_crc32(IntPtr s, int on);
+		[DllImport(Lib)] internal static extern uint szl_inflater_crc32(IntPtr s);
 
 		// batch entry points (include/szl.h): the feed for ZipOutputStream.PutNextPassthroughEntry (INTEGRATION.md §3) and for
 		// multi-member gzip; the *_multi_* forms spread the streams — or the position ranges of ONE long stream — over several GPUs
@@ -154,7 +157,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 			h = SzlNative.szl_inflater_create(noHeader ? 1 : 0);
 			if (h == IntPtr.Zero) throw SzlNative.Map(-3, nameof(noHeader));
 		}
-		public void Reset() { SzlNative.szl_inflater_reset(h); }                                         // Inflater.cs:188
+		public void Reset() { SzlNative.szl_inflater_reset(h); input = null; }                           // Inflater.cs:188
 		public void SetInput(byte[] buffer) { SetInput(buffer, 0, buffer.Length); }
 		public unsafe void SetInput(byte[] buffer, int index, int count)                                 // :629
 		{
@@ -163,7 +166,20 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 			if (count < 0) throw new ArgumentOutOfRangeException(nameof(count), "Cannot be negative");
 			if (index > buffer.Length - count) throw new ArgumentOutOfRangeException(nameof(count));
 			fixed (byte* p = buffer) Check(SzlNative.szl_inflater_set_input(h, p + index, count), nameof(SetInput));
+			// A long piece out of a buffer the device-aware InflaterInputBuffer pinned and registered (InflaterInputStream.Device.cs) is
+			// read in place, as the reference's StreamManipulator keeps `window_ = buffer` (CS/StreamManipulator.cs:244-262): keep the
+			// array reachable until the object has let go of it (IsNeedingInput, Reset, DetachInput).
+			input = buffer;
 		}
+		private byte[] input;
+		/// <summary>The object stops referring to the caller's buffer (what it has not consumed moves into its own memory):
+		/// InflaterInputStream.Dispose calls this before a pooled Inflater outlives the stream's buffer.</summary>
+		internal void DetachInput() { SzlNative.szl_inflater_detach_input(h); input = null; }
+		/// <summary>CRC-32 of the bytes handed out, kept on the device beside the decode (include/szl.h): a device-aware
+		/// GZipInputStream / ZipInputStream switches it on before the first SetInput and reads it where the reference reads crc.Value
+		/// (S/GZip/GzipInputStream.cs:141,337; S/Zip/ZipInputStream.cs:673).</summary>
+		internal void EnableCrc32(bool on = true) { Check(SzlNative.szl_inflater_enable_crc32(h, on ? 1 : 0), nameof(EnableCrc32)); }
+		internal long Crc32 => SzlNative.szl_inflater_crc32(h);
 		public void SetDictionary(byte[] buffer) { SetDictionary(buffer, 0, buffer.Length); }
 		public unsafe void SetDictionary(byte[] buffer, int index, int count)                            // :563
 		{

@@ -118,49 +118,39 @@ class GZipOutputStream(DeflaterOutputStream):
 
 class GZipInputStream(InflaterInputStream):
     """new GZipInputStream(stream[, size]); Read; GetFilename — members may be concatenated, trailing garbage after a
-    complete member ends the stream quietly (:107-153)."""
+    complete member ends the stream quietly (:107-153).  Over the device-aware InflaterInputStream / InflaterInputBuffer
+    (streams.py): the default constructor reads 16 MiB ahead, header and trailer are parsed out of that same buffer with the
+    buffer class's own ReadLeByte / ReadClearTextBuffer (:203-291, :305-351).  `deviceCrc` (default): the CRC-32 of what was read
+    is kept by the Inflater on the device beside the decode (include/szl.h szl_inflater_crc32) instead of a host pass over every
+    buffer returned (:141); `deviceCrc=False` is the reference's own arrangement."""
 
-    def __init__(self, baseInputStream, size=4096):
+    def __init__(self, baseInputStream, size=4096, readAhead=None, deviceCrc=True):
         from .inflater import Inflater
-        super().__init__(baseInputStream, Inflater(True), size)
+        super().__init__(baseInputStream, Inflater(True), size, readAhead)
         self._read_header = False
         self._completed_last_block = False
         self._crc = 0
         self._file_name = None
+        self._device_crc = bool(deviceCrc)
+        if self._device_crc:
+            self.inf.EnableCrc32()
 
     def GetFilename(self):
         return self._file_name
 
-    # InflaterInputBuffer.ReadLeByte / ReadClearTextBuffer (CS/InflaterInputStream.cs:194-260)
-    def _le_byte(self):
+    def _le_byte(self):                                   # inputBuffer.ReadLeByte with the message ReadHeader gives (:203)
         ib = self.inputBuffer
-        if ib.available <= 0:
+        if ib.Available <= 0:
             ib.Fill()
-            if ib.available <= 0:
+            if ib.Available <= 0:
                 raise EOFError("EOS reading GZIP header")
-        b = int(ib.clearText[ib.clearTextLength - ib.available])
-        ib.available -= 1
-        return b
-
-    def _read_clear(self, n):
-        out = bytearray()
-        while len(out) < n:
-            ib = self.inputBuffer
-            if ib.available <= 0:
-                ib.Fill()
-                if ib.available <= 0:
-                    raise EOFError("EOS reading GZIP footer")
-            k = min(n - len(out), ib.available)
-            s = ib.clearTextLength - ib.available
-            out += ib.clearText[s:s + k].tobytes()
-            ib.available -= k
-        return bytes(out)
+        return ib.ReadLeByte()
 
     def _header(self):                                    # ReadHeader :170-303
         ib = self.inputBuffer
-        if ib.available <= 0:
+        if ib.Available <= 0:
             ib.Fill()
-            if ib.available <= 0:
+            if ib.Available <= 0:
                 return False                              # no header: EOF
         seen = bytearray()
 
@@ -206,12 +196,20 @@ class GZipInputStream(InflaterInputStream):
 
     def _footer(self):                                    # ReadFooter :305-351
         total_out = self.inf.TotalOut & 0xFFFFFFFF
-        self.inputBuffer.available += self.inf.RemainingInput
+        ours = self.inf.Crc32 if self._device_crc else self._crc
+        self.inputBuffer.Available += self.inf.RemainingInput
         self.inf.Reset()
-        f = self._read_clear(8)
+        f = np.zeros(8, np.uint8)
+        need = 8
+        while need > 0:                                   # :317-327
+            k = self.inputBuffer.ReadClearTextBuffer(f, 8 - need, need)
+            if k <= 0:
+                raise EOFError("EOS reading GZIP footer")
+            need -= k
+        f = f.tobytes()
         crc = int.from_bytes(f[0:4], "little")
-        if crc != self._crc:
-            raise GZipException('GZIP crc sum mismatch, theirs "%08x" and ours "%08x"' % (crc, self._crc))
+        if crc != ours:
+            raise GZipException('GZIP crc sum mismatch, theirs "%08x" and ours "%08x"' % (crc, ours))
         if total_out != int.from_bytes(f[4:8], "little"):
             raise GZipException("Number of bytes mismatch in footer")
         self._read_header = False
@@ -228,7 +226,7 @@ class GZipInputStream(InflaterInputStream):
                         return 0                          # trailing garbage after a complete member
                     raise
             n = super().Read(buffer, offset, count)
-            if n > 0:
+            if n > 0 and not self._device_crc:
                 self._crc = _crc32(self._crc, np.frombuffer(buffer, dtype=np.uint8)[offset:offset + n])
             if self.inf.IsFinished:
                 self._footer()

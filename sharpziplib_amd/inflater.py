@@ -31,6 +31,11 @@ class Inflater:
         s = self._L.szl_inflater_set_input(self._h, a.ctypes.data, count)
         if s < 0:
             _raise(s, "SetInput")
+        self._input = a            # (a long piece out of a pinned buffer is read in place, include/szl.h: the array lives as long as it is referred to)
+
+    def DetachInput(self):
+        self._L.szl_inflater_detach_input(self._h)
+        self._input = None
 
     def SetDictionary(self, buffer, index=0, count=None):
         a = np.ascontiguousarray(np.frombuffer(buffer, dtype=np.uint8))
@@ -82,3 +87,13 @@ class Inflater:
     @property
     def Adler(self):
         return self._L.szl_inflater_adler(self._h)
+
+    # device-side CRC-32 of the bytes handed out (include/szl.h: what GZipInputStream / ZipInputStream keep on the CPU)
+    def EnableCrc32(self, on=True):
+        s = self._L.szl_inflater_enable_crc32(self._h, 1 if on else 0)
+        if s < 0:
+            _raise(s, "EnableCrc32")
+
+    @property
+    def Crc32(self):
+        return self._L.szl_inflater_crc32(self._h)

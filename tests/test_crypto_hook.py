@@ -48,7 +48,8 @@ class PkzipClassic:
         return count
 
 
-def test_encrypt_after_deflate_decrypt_before_inflate():
+@pytest.mark.parametrize("read_ahead", [0, None])
+def test_encrypt_after_deflate_decrypt_before_inflate(read_ahead):
     from sharpziplib_amd.deflater import Deflater
     from sharpziplib_amd.inflater import Inflater
     from sharpziplib_amd.streams import DeflaterOutputStream, InflaterInputStream
@@ -68,7 +69,7 @@ def test_encrypt_after_deflate_decrypt_before_inflate():
     assert cipher == ref.tobytes()                                 # same bytes, same order: the hook saw exactly the codec's output
     assert cipher != plain and dos.cryptoTransform_ is None
     # read side: the hook decrypts each filled buffer before SetInput
-    iis = InflaterInputStream(io.BytesIO(cipher), Inflater(True), 4096)
+    iis = InflaterInputStream(io.BytesIO(cipher), Inflater(True), 4096, readAhead=read_ahead)
     iis.inputBuffer.SetCryptoTransform(PkzipClassic(pw, False))
     out = np.zeros(data.size, np.uint8)
     got = 0

@@ -112,13 +112,14 @@ def test_gpu_deflate_then_gpu_inflate(eng):
 # ---- streaming object through the InflaterInputStream mirror (T/Base/InflaterDeflaterTests.cs:23-47)
 @pytest.mark.parametrize("zlib_framing", [True, False])
 @pytest.mark.parametrize("bufsize", [1024, 4096, 65536])
-def test_inflater_input_stream(zlib_framing, bufsize):
+@pytest.mark.parametrize("read_ahead", [0, None])     # 0: the reference's buffer sizes (4 KiB pieces for one wavefront); None: the device-aware default
+def test_inflater_input_stream(zlib_framing, bufsize, read_ahead):
     from sharpziplib_amd.inflater import Inflater
     from sharpziplib_amd.streams import InflaterInputStream
     data = C.mixed(600000, seed=33)
     comp = O.deflate(data, 6, nowrap=not zlib_framing, flush=True)
     inf = Inflater(not zlib_framing)
-    s = InflaterInputStream(io.BytesIO(comp + b"XYZ" * 5), inf, bufsize)
+    s = InflaterInputStream(io.BytesIO(comp + b"XYZ" * 5), inf, bufsize, readAhead=read_ahead)
     buf2 = np.zeros(data.size, np.uint8)
     idx, count = 0, buf2.size
     while True:

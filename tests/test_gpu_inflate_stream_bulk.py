@@ -133,7 +133,7 @@ def test_gzip_and_inflaterinputstream_with_large_buffers():
     comp = O.deflate(plain, 6)
     for bufsz in (1 << 20, 16 << 20, 64 << 20):
         inf = Inflater(True)
-        st = InflaterInputStream(io.BytesIO(comp), inf, bufsz)
+        st = InflaterInputStream(io.BytesIO(comp), inf, bufsz, readAhead=0)    # (the reference's sizes: what the constructor says)
         out = np.zeros(4 << 20, np.uint8)
         got = bytearray()
         while True:

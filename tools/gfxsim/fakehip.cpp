@@ -135,6 +135,8 @@ hipError_t hipMalloc(void **p, size_t n) { *p = arena_alloc(n ? n : 1); return *
 hipError_t hipFree(void *) { return hipSuccess; }                     // bump allocator: nothing is reused, so stale pointers stay visible to the checks
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = arena_alloc(n ? n : 1); shadow_set(*p, 2, n ? n : 1); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }   // (the host writes it without telling anyone: defined)
 hipError_t hipHostFree(void *) { return hipSuccess; }
+hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { ensure_arena(); *tot = g_arena_size; *fr = g_arena_size - g_top; return hipSuccess; }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) { memmove(d, s, n); shadow_copy(d, s, n); } return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) { memmove(d, s, n); shadow_copy(d, s, n); } return hipSuccess; }

@@ -300,8 +300,8 @@ def suite_inflate_parallel():
 
 def suite_inflate_dense():
     """the symbol pass compiled for 3 wavefronts per SIMD (SZL_INF_DENSE=1: k_inflate<true, 2, true>, another register
-    allocation of the same source; not the default) on one member, against the input; staging regions by span and tail trimming
-    (SZL_INF_REG_BY_SPAN, SZL_INF_TRIM_TAIL: not the defaults either) on a reference-made member"""
+    allocation of the same source; not the default) on one member, against the input; a reference-made member whose blocks are longer
+    than the chunks (jobs span several chunks: staging regions by span)"""
     from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
     from sharpziplib_amd import corpus as C
@@ -317,18 +317,15 @@ def suite_inflate_dense():
         _knobs(SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET)
         import oracle_ffi as O
         n = 1
-        # staging regions sized by a job's span (SZL_INF_REG_BY_SPAN=1, not the default) and the tail-round trimming, on a reference-made member
-        # whose blocks are longer than the 16 KiB chunks (jobs span several chunks)
+        # a reference-made member whose blocks are longer than the 16 KiB chunks (jobs span several chunks; staging regions sized by span)
         small = C.generate("enwik", 0xE9, 0, 360000)
         ms = O.deflate(small, 6)
-        _knobs(SZL_INF_REG_BY_SPAN=1, SZL_INF_TRIM_TAIL=1)
         (r, used), = e.inflate([ms], [small.size], crc32=True)
         assert int(_lib.lib().szl_engine_debug_par_jobs(e._h)) >= 3
         assert r.status == 0 and r.data == small.tobytes() and used == len(ms)
-        _knobs(SZL_INF_REG_BY_SPAN=FORGET, SZL_INF_TRIM_TAIL=FORGET)
         n += 1
     finally:
-        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET, SZL_INF_REG_BY_SPAN=FORGET, SZL_INF_TRIM_TAIL=FORGET)
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_SLOTS_PER_CU=FORGET, SZL_INF_DENSE=FORGET)
         e.close()
     return n
 
@@ -415,10 +412,14 @@ def suite_exchange_order():
 def suite_inflate_stream_bulk():
     """the streaming Inflater given a long input (InflaterInputStream with a large buffer): SetInput of 256 KiB or more goes to the
     chunk-parallel decoder from the carried window (inflater_bulk) — zlib framing, input in two pieces, reads of 1 byte to 200 KB,
-    RemainingInput / Adler exact; through the pageable hand-out (default) and, with GFXSIM_PINNED_TOO=1, the pinned one (SZL_INF_PINNED=1)"""
+    RemainingInput / Adler exact; then the device-aware read path: GZipInputStream over the read-ahead InflaterInputBuffer (pinned buffer,
+    SetInput without a host copy, CRC-32 kept on the device) on two members and trailing garbage"""
+    import gzip
+    import io
     from sharpziplib_amd import _lib
     from sharpziplib_amd.inflater import Inflater
     from sharpziplib_amd import corpus as C
+    from sharpziplib_amd import gzipstream as G
     data = C.generate("enwik", 0xE9, 0, 760000)
     co = zlib.compressobj(6, zlib.DEFLATED, 15, 4)          # memLevel 4: a block every 1024 tokens
     z = co.compress(data.tobytes()) + co.flush() + b"tail"
@@ -427,24 +428,45 @@ def suite_inflate_stream_bulk():
     n = 0
     try:
         _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64, SZL_INF_STREAM_BULK_KIB=256)
-        for pinned in ((0, 1) if os.environ.get("GFXSIM_PINNED_TOO") else (0,)):      # (the pinned hand-out measured no gain on the device: checked on request only)
-            _knobs(SZL_INF_PINNED=pinned)
-            inf = Inflater(False)
-            inf.SetInput(z[:cut])
-            out = bytearray()
-            sizes = [1, 4096, 70000, 7, 200000]
-            k = 0
-            while not inf.IsFinished:
-                if inf.IsNeedingInput:
-                    inf.SetInput(z[cut:])
-                buf = bytearray(sizes[k % len(sizes)]); k += 1
-                out += buf[:inf.Inflate(buf)]
-            assert bytes(out) == data.tobytes(), (pinned, len(out))
-            assert inf.RemainingInput == 4 and inf.TotalIn == len(z) - 4 and inf.Adler == zlib.adler32(data.tobytes()), pinned
-            assert _lib.lib().szl_inflater_debug_bulk_calls(inf._h) >= 1, pinned
+        inf = Inflater(False)
+        inf.SetInput(z[:cut])
+        out = bytearray()
+        sizes = [1, 4096, 70000, 7, 200000]
+        k = 0
+        while not inf.IsFinished:
+            if inf.IsNeedingInput:
+                inf.SetInput(z[cut:])
+            buf = bytearray(sizes[k % len(sizes)]); k += 1
+            out += buf[:inf.Inflate(buf)]
+            if k == 3:
+                assert inf.Adler == zlib.adler32(bytes(out))     # (in mid-stream: the checksum of what has been handed out, not of what was decoded)
+        assert bytes(out) == data.tobytes(), len(out)
+        assert inf.RemainingInput == 4 and inf.TotalIn == len(z) - 4 and inf.Adler == zlib.adler32(data.tobytes())
+        assert _lib.lib().szl_inflater_debug_bulk_calls(inf._h) >= 1
+        n += 1
+        # the device-aware classes: 300 KiB of read-ahead (the library's 16 MiB at this suite's scale), a pinned RawData, device CRC
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 4)
+        m1 = co.compress(data.tobytes()) + co.flush()
+        small = b"second member " * 40
+        src = m1 + gzip.compress(small, 9) + b"\0\0garbage"
+        st = G.GZipInputStream(io.BytesIO(src), 4096, readAhead=300 << 10)
+        assert st.inputBuffer._pin is not None and st.inputBuffer.RawData.size == min(300 << 10, len(src) + 1)
+        assert st.read_all(chunk=150001) == data.tobytes() + small
+        assert _lib.lib().szl_inflater_debug_bulk_calls(st.inf._h) >= 1
+        st.Dispose()
+        n += 1
+        for dev_crc in (True, False):                                             # (small members: the CRC-32 on the device and the reference's way)
+            two = gzip.compress(small, 6) + gzip.compress(small[::-1], 9)
+            assert G.GZipInputStream(io.BytesIO(two), deviceCrc=dev_crc).read_all(chunk=100) == small + small[::-1]
+            bad = bytearray(two); bad[len(gzip.compress(small, 6)) - 8] ^= 1      # the first member's CRC-32 trailer
+            try:
+                G.GZipInputStream(io.BytesIO(bytes(bad)), deviceCrc=dev_crc).read_all(chunk=100)
+                raise AssertionError("a wrong CRC-32 went unnoticed")
+            except G.GZipException as e:
+                assert "crc sum mismatch" in str(e)
             n += 1
     finally:
-        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_STREAM_BULK_KIB=FORGET, SZL_INF_PINNED=FORGET)
+        _knobs(SZL_INF_CHUNK_KIB=FORGET, SZL_INF_PAR_MIN_KIB=FORGET, SZL_INF_STREAM_BULK_KIB=FORGET, SZL_INF_BULK_OUT_MIB=FORGET)
     return n
 
 
