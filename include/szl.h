@@ -252,6 +252,13 @@ int szl_host_unregister(void *p);
 /* The object stops referring to the caller's pinned buffer now (what it has not consumed moves into its own memory): called by the
  * stream shim before it frees or refills a buffer out of turn — Dispose() of a stream whose Inflater lives on (InflaterPool). */
 int szl_inflater_detach_input(szl_inflater *s);
+/* Hint of the stream shim, given with every SetInput: more != 0 — the buffer just given was filled completely, so more input follows
+ * (InflaterInputBuffer.Fill read its whole length, CS/InflaterInputStream.cs:115-128).  A piece decoded by the chunk-parallel decoder then
+ * ends on its last block boundary and the object asks for input at once instead of running one wavefront over the cut block behind it;
+ * the next piece starts on that boundary.  more == 0 takes the promise back (the base stream has ended): returns 1 if a remainder was
+ * waiting — the next Inflate() decodes it, so a truncated stream still delivers every byte it holds — else 0.  Never set: the object
+ * decodes everything it is given before it asks for more, as the reference does. */
+int szl_inflater_expect_more(szl_inflater *s, int more);
 /* CRC-32 of the bytes handed out by Inflate() so far, kept on the device beside the decode (what GZipInputStream / ZipInputStream
  * accumulate on the CPU over every buffer they return: S/GZip/GzipInputStream.cs:141, S/Zip/ZipInputStream.cs:673): a device-aware
  * container stream switches it on before the first SetInput (and again after Reset: it stays on) and reads it where the reference
@@ -263,7 +270,7 @@ uint32_t szl_inflater_crc32(const szl_inflater *s);
 uint32_t szl_inflater_debug_bulk_calls(const szl_inflater *s);
 /* Measurement tap: wall-clock milliseconds this object has spent, by part — [0] SetInput, [1] upload of long pieces, [2] their decode
  * (finder, symbol pass, windows, bytes), [3] their download, [4] checksums, [5] all decoder steps together ([1]..[4] are inside),
- * [6] the copies out of Inflate(), [7] unused. */
+ * [6] the copies out of Inflate(), [7] the one-wavefront steps alone. */
 int szl_inflater_debug_times(const szl_inflater *s, double *ms8);
 
 /* Batch inflate of independent raw-deflate / zlib streams (zip entries, gzip members): one

@@ -90,7 +90,7 @@ def _load(path):
         "szl_inflater_needs_dictionary": (i32, [vp]), "szl_inflater_is_finished": (i32, [vp]),
         "szl_inflater_remaining_input": (i32, [vp]), "szl_inflater_total_in": (i64, [vp]),
         "szl_inflater_total_out": (i64, [vp]), "szl_inflater_adler": (u32, [vp]),
-        "szl_inflater_enable_crc32": (i32, [vp, i32]), "szl_inflater_crc32": (u32, [vp]), "szl_inflater_detach_input": (i32, [vp]),
+        "szl_inflater_enable_crc32": (i32, [vp, i32]), "szl_inflater_crc32": (u32, [vp]), "szl_inflater_detach_input": (i32, [vp]), "szl_inflater_expect_more": (i32, [vp, i32]),
         "szl_host_alloc": (vp, [sz]), "szl_host_free": (None, [vp]), "szl_host_register": (i32, [vp, sz]), "szl_host_unregister": (i32, [vp]),
         "szl_inflate_batch_device": (i32, [vp, vp, vp, vp, sz, ctypes.c_uint, vp]),
         "szl_inflate_batch_host": (i32, [vp, vp, vp, vp, sz, ctypes.c_uint]),

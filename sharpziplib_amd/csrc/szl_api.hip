@@ -821,13 +821,37 @@ static int reset_stale_bits(szl_deflater *d, uint8_t *out) {
 }
 int szl_deflater_reset(szl_deflater *d) {
     if (!d) return SZL_E_ARG;
+    // DeflaterEngine.Reset() does not touch inputBuf / inputOff / inputEnd (C/DeflaterEngine.cs:234-253): input the engine has not taken
+    // yet — a SetInput that no Deflate() call has followed — is still there, IsNeedingInput stays false, and the first Deflate() of the
+    // next stream compresses those bytes as its beginning.  (Round 4 dropped them: silently different bytes, and a second SetInput
+    // succeeded where the reference throws "Old input was not completely processed".)
+    std::vector<uint8_t> unseen;
+    if (d->chunks_drained < d->chunks.size()) {
+        const uint64_t k = d->chunks.back();
+        if (k <= d->pend.size()) { unseen.assign(d->pend.end() - (ptrdiff_t)k, d->pend.end()); d->pend.resize(d->pend.size() - (size_t)k); d->chunks.pop_back(); d->total_in -= (int64_t)k; }
+    }
     uint8_t stale = 0;
     const int rc = reset_stale_bits(d, &stale);
     deflater_clear(d);
     d->stale = rc ? 0 : stale;
+    if (!unseen.empty()) {
+        d->pend = std::move(unseen);
+        d->chunks.push_back((uint64_t)d->pend.size());
+        d->total_in = (int64_t)d->pend.size();
+    }
     return rc;
 }
 // a parameter change while bytes are pending: it takes effect where the reference's engine stands
+// SZL_STRICT=1 (off by default): a parameter or function change is refused when the reference's engine could already have
+// produced a block from the pending input (16384 tokens need at least as many bytes, C/DeflaterHuffman.cs:863).  Where the reference's
+// engine stands then depends on how much output the caller has taken (it pauses while `pending` holds bytes, C/DeflaterEngine.cs:126-139);
+// this backend compresses at Flush() / Finish() and places the change where the engine stands for a caller who DRAINS Deflate() — the
+// reference's own stream classes do (CS/DeflaterOutputStream.cs:242-272).  Strict mode is for finding call sites that do not.
+static int strict_refuses(const szl_deflater *d) {
+    if (knob("SZL_STRICT", 0) == 0 || d->pend.size() < 16384) return 0;
+    set_error("SZL_STRICT: SetLevel / SetStrategy with %zu bytes pending — exact only for callers that drain Deflate() (C/DeflaterEngine.cs:126-139)", d->pend.size());
+    return SZL_E_UNSUPPORTED;
+}
 static int pend_switch(szl_deflater *d, int level, int strategy) {
     const int64_t at = d->engine_seen > (MIN_LOOKAHEAD - 1) ? d->engine_seen - (MIN_LOOKAHEAD - 1) : 0;
     d->switches.push_back(szl_deflater::Sw{(uint64_t)at, level, strategy});
@@ -838,6 +862,7 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) return SZL_E_ARG;
     if (level == d->level) return 0;                       // C/Deflater.cs:357
+    if (strict_refuses(d)) return SZL_E_UNSUPPORTED;
     // Another compression function (DeflateStored / DeflateFast / DeflateSlow, C/DeflaterConstants.cs:146): the reference flushes a block
     // with the OLD function where its engine stands and continues with the new one (C/DeflaterEngine.cs:319-359) — with bytes pending,
     // to or from level 0, any number of times.  The three functions leave different hash chains behind (level 0 inserts nothing,
@@ -856,6 +881,7 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
 int szl_deflater_get_level(const szl_deflater *d) { return d ? d->level : SZL_E_ARG; }
 int szl_deflater_set_strategy(szl_deflater *d, int s) {
     if (!d || s < 0 || s > 2) return SZL_E_ARG;
+    if (s != d->strategy && strict_refuses(d)) return SZL_E_UNSUPPORTED;
     if (s != d->strategy && !d->pend.empty() && d->level != 0) { int rc = pend_switch(d, d->level, s); if (rc) return rc; }
     else if (d->pend.empty()) d->base_strategy = s;
     d->strategy = s;

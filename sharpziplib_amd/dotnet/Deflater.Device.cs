@@ -47,6 +47,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		[DllImport(Lib)] internal static extern long szl_inflater_total_out(IntPtr s);
 		[DllImport(Lib)] internal static extern uint szl_inflater_adler(IntPtr s);
 		[DllImport(Lib)] internal static extern int szl_inflater_detach_input(IntPtr s);
+		[DllImport(Lib)] internal static extern int szl_inflater_expect_more(IntPtr s, int more);
 		[DllImport(Lib)] internal static extern int szl_inflater_enable_crc32(IntPtr s, int on);
 		[DllImport(Lib)] internal static extern uint szl_inflater_crc32(IntPtr s);
 
@@ -175,6 +176,10 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		/// <summary>The object stops referring to the caller's buffer (what it has not consumed moves into its own memory):
 		/// InflaterInputStream.Dispose calls this before a pooled Inflater outlives the stream's buffer.</summary>
 		internal void DetachInput() { SzlNative.szl_inflater_detach_input(h); input = null; }
+		/// <summary>Hint of the stream shim (include/szl.h szl_inflater_expect_more): true — the buffer just given was filled to the brim, more
+		/// input follows, a parallel piece may end on its last block boundary and ask for input at once; false — the base stream has ended.
+		/// Returns true if a remainder was waiting for input that will not come (the next Inflate() decodes it).</summary>
+		internal bool ExpectMoreInput(bool more) => SzlNative.szl_inflater_expect_more(h, more ? 1 : 0) == 1;
 		/// <summary>CRC-32 of the bytes handed out, kept on the device beside the decode (include/szl.h): a device-aware
 		/// GZipInputStream / ZipInputStream switches it on before the first SetInput and reads it where the reference reads crc.Value
 		/// (S/GZip/GzipInputStream.cs:141,337; S/Zip/ZipInputStream.cs:673).</summary>

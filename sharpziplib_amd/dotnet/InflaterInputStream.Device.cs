@@ -58,7 +58,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 		{
 			byte[] a = GC.AllocateUninitializedArray<byte>(size, pinned: true);
 			registered = false;
-			if (size >= (256 << 10))
+			if (size >= (64 << 10))
 				fixed (byte* p = a) registered = SzlHost.szl_host_register(p, (UIntPtr)(uint)size) == 0;
 			return a;
 		}
@@ -81,6 +81,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			{
 				inflater.SetInput(clearText, clearTextLength - available, available);
 				available = 0;
+				inflater.ExpectMoreInput(rawLength == rawData.Length);   // a buffer filled to the brim promises more (include/szl.h)
 			}
 		}
 
@@ -218,7 +219,14 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			if (inputBuffer.Available <= 0)
 			{
 				inputBuffer.Fill();
-				if (inputBuffer.Available <= 0) throw new SharpZipBaseException("Unexpected EOF");
+				if (inputBuffer.Available <= 0)
+				{
+					// The base stream has ended: the promise of more input is taken back.  If the remainder of the last parallel piece was
+					// waiting for it, Inflate() decodes it now and Read() goes on — a truncated stream delivers every byte it holds before
+					// "Unexpected EOF", as the reference's does.
+					if (inf.ExpectMoreInput(false)) return;
+					throw new SharpZipBaseException("Unexpected EOF");
+				}
 			}
 			inputBuffer.SetInflaterInput(inf);
 		}

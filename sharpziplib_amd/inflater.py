@@ -33,6 +33,10 @@ class Inflater:
             _raise(s, "SetInput")
         self._input = a            # (a long piece out of a pinned buffer is read in place, include/szl.h: the array lives as long as it is referred to)
 
+    def ExpectMoreInput(self, more):
+        """the stream shim's hint (include/szl.h szl_inflater_expect_more); returns True if a deferred remainder was released"""
+        return self._L.szl_inflater_expect_more(self._h, 1 if more else 0) == 1
+
     def DetachInput(self):
         self._L.szl_inflater_detach_input(self._h)
         self._input = None

@@ -139,7 +139,7 @@ class InflaterInputBuffer:
                     size = max(bufferSize, min(size, left + 1))
             except (AttributeError, OSError, ValueError):
                 pass
-        self._pin = _PinnedArray(size) if size >= (256 << 10) else None
+        self._pin = _PinnedArray(size) if size >= (64 << 10) else None
         self.rawData = self._pin.array if self._pin else np.zeros(size, dtype=np.uint8)
         self.rawLength = 0
         self.available = 0
@@ -194,6 +194,9 @@ class InflaterInputBuffer:
         if self.available > 0:
             inflater.SetInput(self.clearText, self.clearTextLength - self.available, self.available)
             self.available = 0
+            # device-aware: a buffer that Fill() filled to the brim promises more input (include/szl.h szl_inflater_expect_more)
+            if hasattr(inflater, "ExpectMoreInput"):
+                inflater.ExpectMoreInput(self.rawLength == self.rawData.size)
 
     def Fill(self):                                             # :115
         self.rawLength = 0
@@ -331,6 +334,11 @@ class InflaterInputStream:
         if self.inputBuffer.Available <= 0:
             self.inputBuffer.Fill()
             if self.inputBuffer.Available <= 0:
+                # device-aware: the base stream has ended — the promise of more input is taken back; if a remainder of the last piece
+                # was waiting for it, Inflate() decodes it now and Read() goes on (a truncated stream delivers every byte it holds
+                # before "Unexpected EOF", as the reference's does)
+                if hasattr(self.inf, "ExpectMoreInput") and self.inf.ExpectMoreInput(False):
+                    return
                 raise SharpZipBaseException("Unexpected EOF")
         self.inputBuffer.SetInflaterInput(self.inf)
 

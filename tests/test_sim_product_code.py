@@ -15,7 +15,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["inflate_stream_bulk", "forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense", "inflate_corrupt", "deflater_object", "framing", "deflate_shapes", "inflate",
+SUITES = ["inflate_stream_bulk", "forms", "inflate_parallel", "multi_device", "deflate_levels", "inflate_dense@lab", "inflate_corrupt", "deflater_object", "framing", "deflate_shapes", "inflate",
           "exchange_order@desc", "exchange_order@flaky:30:130", "lab_forms@lab"]   # longest first; @ = the lane order ds_wrxchg is served in (fault injection) / the laboratory library
 HIPCC = "/opt/rocm/bin/hipcc"
 # ≈720 CPU-seconds in all, spread over the cores (140 s of wall time on 8); a box with fewer than 4 cores runs the core suites only

@@ -23,6 +23,7 @@ FORGET = -2147483648
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
 a = ap.parse_args()
+_lib._lib = _lib.lab_lib()          # (round 5: the dense build lives in the laboratory library only)
 L = _lib.lib()
 eng = Engine()
 plain = corpus.generate("enwik", 0xE9, 0, 1 << 30)
