@@ -192,6 +192,24 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
     if n >= (64 << 20):
         guarded("4i_inflate_one_%dMiB_member" % (n >> 20), c4i_1g)
 
+    # ---- the CPU beside the inflate configs: the oracle's Inflater (kind "port": C restatement of C/Inflater.cs), one thread, on a bounded
+    # sample of the same stream — the first 96 MiB of the corpus as one member (what one core of the box decodes while the device decodes 1 GiB)
+    def cpu_inflate():
+        m = min(n, 96 << 20)
+        sample = d_in[:m].cpu().numpy()
+        e2 = Engine()
+        try:
+            comp = e2.deflate([sample], level=level)[0].data
+        finally:
+            e2.close()
+        t = time.perf_counter()
+        got, back, _ = O.inflate(np.frombuffer(comp, dtype=np.uint8), max_out=m + 16)
+        dt = time.perf_counter() - t
+        assert got == m and zlib.crc32(back) == zlib.crc32(sample), "oracle Inflater"
+        out["cpu_baseline_inflate"] = {"value": round(m / 2 ** 20 / dt, 1), "unit": "MiB/s of output", "cores": 1, "kind": "port",
+                                       "sample": "one raw-deflate member of the corpus' first %d MiB (level %d), oracle Inflater, one thread" % (m >> 20, level)}
+    guarded("cpu_baseline_inflate", cpu_inflate)
+
     big_n = (2 if quick else 8) * GiB
     host_big = gen_parallel("enwik", 0x21B0, big_n)
     d_big = upload(host_big)
@@ -263,7 +281,19 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
                 s = st3[i]
                 got = o3[s.out_off:s.out_off + s.out_len].cpu().numpy().tobytes()
                 assert got == O.deflate(host_big[i * esz:(i + 1) * esz], level) and s.crc32 == zlib.crc32(host_big[i * esz:(i + 1) * esz].tobytes()), "entry %d" % i
-            entry("3_zip_%d_x_64KiB_deflate" % n3, n3 * esz, comp3, tm["total_ms"], "4 entries == oracle bytes + CRC-32; all entries inflated back below",
+            checked = "4 entries == oracle bytes + CRC-32; all entries inflated back below"
+            gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "headline_golden.json")))["cases"].get("cfg3_100000x64k_enwik_l6")
+            if gold and n3 * esz == gold["n"] and level == gold["level"] and esz == gold["entry"]:
+                # EVERY entry against the oracle's frozen digests: sha256 over the entries' compressed bytes in order, and over their CRC-32s
+                ho = o3.cpu().numpy()
+                h, hc = hashlib.sha256(), hashlib.sha256()
+                for s in st3:
+                    h.update(ho[s.out_off:s.out_off + s.out_len])
+                    hc.update(int(s.crc32).to_bytes(4, "little"))
+                assert comp3 == gold["out_len"] and h.hexdigest() == gold["out_sha256"] and hc.hexdigest() == gold["crc_sha256"], "config 3: the entries differ from the oracle's frozen digest"
+                del ho
+                checked = "ALL %d entries: sha256 of their compressed bytes and of their CRC-32s == the oracle's frozen digests; all inflated back below" % n3
+            entry("3_zip_%d_x_64KiB_deflate" % n3, n3 * esz, comp3, tm["total_ms"], checked,
                   ratio=round(comp3 / (n3 * esz), 4), stage_ms={k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")})
             ist, oo = inflate_table(st3, [esz] * n3)
             b3 = alloc(oo)
@@ -390,6 +420,60 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
         out["4s_GZipInputStream_256MiB_member_by_constructor"] = dict(rates, checked="length; zlib.crc32 of every byte read (untimed pass); the member's CRC-32 / ISIZE trailer against the device CRC-32 (timed passes)",
                                                                      note="wall clock incl. every host copy of the adapter path; Python mirrors of the reference's classes (DESIGN.md §5)")
     guarded("4s_InflaterInputStream", cstream)
+
+    # ---- config 2 through the class it names: GZipOutputStream (host mirror of S/GZip/GzipOutputStream.cs over the streaming Deflater) on
+    # the headline's own 1 GiB, host buffers both ways, wall clock from the first Write to the last byte in the sink.  The Deflater keeps
+    # what is written in pinned memory and uploads it while the caller is still writing; the CRC-32 runs on the device.  Two call patterns:
+    # 16 MiB writes (what the C ABI sustains), and the reference's 4 KiB habit on a 64 MiB sample (the Python mirror's per-call cost).
+    def cgzip():
+        from sharpziplib_amd.gzipstream import GZipOutputStream
+        host = d_in[:n].cpu().numpy()
+
+        class Sink:                                                   # keeps what it is given (no copy into one growing buffer)
+            def __init__(self):
+                self.parts, self.n = [], 0
+
+            def writable(self):
+                return True
+
+            def write(self, b):
+                self.parts.append(b); self.n += len(b)
+
+            def flush(self):
+                pass
+
+            def close(self):
+                pass
+
+        def run(data, piece, bufsize):
+            sink = Sink()
+            t = time.perf_counter()
+            g = GZipOutputStream(sink, bufsize)
+            g.SetLevel(level); g.ModifiedTime = 0
+            for o in range(0, data.size, piece):
+                g.Write(data[o:o + piece])
+            g.Finish()
+            return time.perf_counter() - t, sink
+        run(host[:64 << 20], 16 << 20, 16 << 20)                      # (first call: allocations)
+        dt, sink = min((run(host, 16 << 20, 16 << 20) for _ in range(2)), key=lambda r: r[0])
+        gz = b"".join(sink.parts)
+        body = gz[10:-8]
+        crc = int.from_bytes(gz[-8:-4], "little")
+        assert gz[:4] == b"\x1f\x8b\x08\x00" and int.from_bytes(gz[-4:], "little") == (n & 0xFFFFFFFF), "gzip framing"
+        checked = "trailer CRC-32 == zlib.crc32 of the input, ISIZE"
+        assert crc == zlib.crc32(host), "device CRC-32 of the written bytes"
+        gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "headline_golden.json")))["cases"].get("cfg2_enwik_1g_l6")
+        if gold and n == gold["n"] and level == gold["level"]:
+            assert len(body) == gold["out_len"] and hashlib.sha256(body).hexdigest() == gold["out_sha256"], "GZipOutputStream body != the oracle's frozen bytes"
+            checked += "; deflate body sha256 == oracle golden"
+        else:
+            assert zlib.decompress(body, -15) == host.tobytes(), "GZipOutputStream body does not inflate to the input"
+            checked += "; body inflates to the input (zlib)"
+        dt4, sink4 = run(host[:64 << 20], 4096, 4096)
+        out["2s_GZipOutputStream_%dMiB_wall" % (n >> 20)] = {"wall_ms": round(dt * 1e3, 1), "mib_s": round(n / 2 ** 20 / dt, 1), "write_bytes": 16 << 20, "checked": checked,
+                                                           "reference_habit_4KiB_writes_64MiB_sample_mib_s": round(64 / dt4, 1),
+                                                           "note": "wall clock incl. every host copy; Python mirror of the reference's class (the 4 KiB figure is Python call overhead: 3 calls through ctypes per write)"}
+    guarded("2s_GZipOutputStream", cgzip)
     return out
 
 

@@ -104,6 +104,11 @@ int szl_deflater_is_finished(const szl_deflater *d);                       /* Is
 int64_t szl_deflater_total_in(const szl_deflater *d);                      /* TotalIn          C/Deflater.cs:226 */
 int64_t szl_deflater_total_out(const szl_deflater *d);                     /* TotalOut         C/Deflater.cs:237 */
 uint32_t szl_deflater_adler(const szl_deflater *d);                        /* Adler            C/Deflater.cs:215 */
+/* CRC-32 of the input given so far, kept on the device beside the compression (what GZipOutputStream / ZipOutputStream accumulate on the
+ * CPU over every Write: S/GZip/GzipOutputStream.cs:210, S/Zip/ZipOutputStream.cs:700): a device-aware container stream switches it on
+ * before the first SetInput and reads it where the reference reads crc.Value.  Off by default; 0 when off. */
+int szl_deflater_enable_crc32(szl_deflater *d, int on);
+uint32_t szl_deflater_crc32(const szl_deflater *d);
 
 /* ------------------------------------------------------------------------------------------
  * Batch / device-resident entry points (SURVEY §8b "one-shot batch entry points"): the fast path

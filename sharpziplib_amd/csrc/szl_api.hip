@@ -721,13 +721,21 @@ struct szl_deflater {
     std::vector<uint32_t> hist_flags; // levels 1-4: "inserted into the hash chains" bit per hist byte (DeflateFast skips long matches)
     uint64_t hist_abs = 0;          // absolute stream position of hist[0]
     std::vector<uint64_t> bounds;   // absolute positions of earlier segment ends that still lie inside hist
-    std::vector<uint8_t> pend;      // bytes given by SetInput since the last Flush()
+    // bytes given by SetInput since the last Flush(): pinned, and — at the coded levels — uploaded as they arrive (`up_done` of them lie
+    // at d_in[up_H ..), `up_H` = the length of the history the layout assumed), so that Flush() / Finish() find the input on the device
+    // instead of starting with a pageable copy of all of it (1 GiB: ~100 ms before the first kernel)
+    PinVec pend;
+    size_t up_done = 0, up_H = 0;
+    hipStream_t up_stream = nullptr;
+    // CRC-32 of the input, on the device beside the Adler-32 (szl_deflater_enable_crc32: what GZipOutputStream / ZipOutputStream keep on
+    // the CPU over every Write, S/GZip/GzipOutputStream.cs:210, S/Zip/ZipOutputStream.cs:700)
+    bool want_crc = false; uint32_t crc = 0;
     std::vector<uint64_t> chunks;   // SetInput sizes since the last Flush() (level 0 block cuts depend on them)
     uint64_t chunk_base = 0;        // offset of chunks[0] inside `pend` (not 0 after a function switch: the lookahead the old function left)
     L0State l0;
     size_t chunks_drained = 0;      // chunks after which Deflate() ran while no Flush/Finish was pending
     uint64_t l0_dict = 0;           // bytes of preset dictionary in front of the stream (window positions, not TotalIn)
-    std::vector<uint8_t> outq;      // compressed bytes not yet handed out
+    PinVec outq;                    // compressed bytes not yet handed out (pinned: filled by DMA)
     size_t outpos = 0;
     uint32_t carry_bits = 0; uint8_t carry_byte = 0;
     // PendingBuffer.Reset() clears bitCount but not `bits` (C/PendingBuffer.cs:43): what an unfinished stream left in the bit buffer
@@ -748,15 +756,15 @@ struct szl_deflater {
     bool hist_has_gaps = false;     // the history holds positions a DeflateFast level did not insert (beyond the segment-end rule)
     szl_engine *eng = nullptr;
     DevBuf d_in, d_out;
-    std::vector<uint8_t> h_out;
+    PinVec h_out;
 };
 
 static void deflater_clear(szl_deflater *d) {
     d->state = d->nowrap ? BUSY_STATE : INIT_STATE;
     d->total_in = d->total_out = 0;
-    d->hist.clear(); d->hist_flags.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->outq.clear(); d->outpos = 0;
+    d->hist.clear(); d->hist_flags.clear(); d->hist_abs = 0; d->bounds.clear(); d->pend.clear(); d->up_done = 0; d->outq.clear(); d->outpos = 0;
     d->chunks.clear(); d->chunks_drained = 0; d->chunk_base = 0; d->l0 = L0State{}; d->dict_adler = 0; d->l0_dict = 0;
-    d->carry_bits = 0; d->carry_byte = 0; d->adler = 1;
+    d->carry_bits = 0; d->carry_byte = 0; d->adler = 1; d->crc = 0; d->up_done = 0; d->up_H = 0;
     d->switches.clear(); d->engine_seen = 0; d->base_level = d->level; d->base_strategy = d->strategy; d->hist_has_gaps = false;
 }
 
@@ -773,6 +781,7 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
 }
 void szl_deflater_destroy(szl_deflater *d) {
     if (!d) return;
+    if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); (void)hipStreamDestroy(d->up_stream); }
     d->d_in.release(); d->d_out.release();
     szl_engine_destroy(d->eng);
     delete d;
@@ -819,7 +828,7 @@ static int reset_stale_bits(szl_deflater *d, uint8_t *out) {
     *out = c && (fend >> 3) < d->h_out.size() ? (uint8_t)(d->h_out[fend >> 3] & ((1u << c) - 1u)) : 0;
     return 0;
 }
-int szl_deflater_reset(szl_deflater *d) {
+static int deflater_reset(szl_deflater *d) {
     if (!d) return SZL_E_ARG;
     // DeflaterEngine.Reset() does not touch inputBuf / inputOff / inputEnd (C/DeflaterEngine.cs:234-253): input the engine has not taken
     // yet — a SetInput that no Deflate() call has followed — is still there, IsNeedingInput stays false, and the first Deflate() of the
@@ -835,7 +844,7 @@ int szl_deflater_reset(szl_deflater *d) {
     deflater_clear(d);
     d->stale = rc ? 0 : stale;
     if (!unseen.empty()) {
-        d->pend = std::move(unseen);
+        d->pend.append(unseen.data(), unseen.size());
         d->chunks.push_back((uint64_t)d->pend.size());
         d->total_in = (int64_t)d->pend.size();
     }
@@ -857,7 +866,7 @@ static int pend_switch(szl_deflater *d, int level, int strategy) {
     d->switches.push_back(szl_deflater::Sw{(uint64_t)at, level, strategy});
     return 0;
 }
-int szl_deflater_set_level(szl_deflater *d, int level) {
+static int deflater_set_level(szl_deflater *d, int level) {
     if (!d) return SZL_E_ARG;
     if (level == -1) level = 6;
     else if (level < 0 || level > 9) return SZL_E_ARG;
@@ -879,7 +888,7 @@ int szl_deflater_set_level(szl_deflater *d, int level) {
     return 0;
 }
 int szl_deflater_get_level(const szl_deflater *d) { return d ? d->level : SZL_E_ARG; }
-int szl_deflater_set_strategy(szl_deflater *d, int s) {
+static int deflater_set_strategy(szl_deflater *d, int s) {
     if (!d || s < 0 || s > 2) return SZL_E_ARG;
     if (s != d->strategy && strict_refuses(d)) return SZL_E_UNSUPPORTED;
     if (s != d->strategy && !d->pend.empty() && d->level != 0) { int rc = pend_switch(d, d->level, s); if (rc) return rc; }
@@ -909,12 +918,38 @@ int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n) { // C
     d->l0_dict = (uint64_t)len;
     return 0;
 }
-int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n) {
+// Pending bytes travel to the device while the caller is still writing (coded levels; level 0 lays its blocks out on the host and
+// uploads at the flush).  Best effort: whatever fails here is simply uploaded at the flush.
+static void eager_upload(szl_deflater *d) {
+    const size_t UP_SLAB = (size_t)std::max(1, knob("SZL_UP_SLAB_KIB", 4096)) << 10;   // (tests: small slabs)
+    if (d->level == 0 || d->pend.size() < d->up_done + UP_SLAB) return;
+    const size_t H = d->hist.size();
+    if (d->up_done && d->up_H != H) d->up_done = 0;                       // (the layout is [history | pending bytes])
+    if (!d->up_stream && hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) { d->up_stream = nullptr; (void)hipGetLastError(); return; }
+    if (d->d_in.ensure_keep(H + d->pend.size() + 64, d->up_done ? H + d->up_done : 0, d->up_stream)) { d->up_done = 0; return; }
+    d->up_H = H;
+    d->pend.busy = d->up_stream;
+    if (hipMemcpyAsync((uint8_t *)d->d_in.p + H + d->up_done, d->pend.data() + d->up_done, d->pend.size() - d->up_done, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) { (void)hipGetLastError(); d->up_done = 0; return; }
+    d->up_done = d->pend.size();
+}
+// the rest of the pending bytes (and the history in front of them) at a flush; afterwards d_in = [hist | pend]
+static int finish_upload(szl_deflater *d, uint64_t H, uint64_t n) {
+    int rc;
+    if (d->up_done > n || d->up_H != H) d->up_done = 0;
+    if ((rc = d->d_in.ensure_keep(H + n + 64, d->up_done ? H + d->up_done : 0, d->up_stream))) return rc;
+    if (H && hipMemcpyAsync(d->d_in.p, d->hist.data(), H, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    if (n > d->up_done && hipMemcpyAsync((uint8_t *)d->d_in.p + H + d->up_done, d->pend.data() + d->up_done, n - d->up_done, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    if (hipStreamSynchronize(d->up_stream) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    d->up_done = (size_t)n; d->up_H = (size_t)H;
+    return 0;
+}
+static int deflater_set_input(szl_deflater *d, const uint8_t *p, int n) {
     if (!d) return SZL_E_ARG;
     if ((d->state & IS_FINISHING) != 0) { set_error("Finish() already called"); return SZL_E_STATE; } // :333-336
     if (n < 0 || (!p && n)) return SZL_E_ARG;
     if (d->chunks_drained != d->chunks.size()) { set_error("Old input was not completely processed"); return SZL_E_STATE; } // C/DeflaterEngine.cs:163-166
-    d->pend.insert(d->pend.end(), p, p + n);
+    d->pend.append(p, (size_t)n);
+    eager_upload(d);
     d->chunks.push_back((uint64_t)n);
     d->total_in += n;
     return 0;
@@ -947,12 +982,15 @@ static int stored_emit(szl_deflater *d, const std::vector<L0Blk> &blks, uint64_t
         out_total += 5 + (uint64_t)blks[i].len;
     }
     int rc;
+    if (d->up_stream) (void)hipStreamSynchronize(d->up_stream);          // (uploads of an earlier, coded level into d_in)
+    d->up_done = 0;
     if ((rc = d->d_in.ensure(n + 64)) || (rc = d->d_out.ensure(out_total + 64))) return rc;
     if (n && hipMemcpy(d->d_in.p, d->pend.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
-    uint32_t adler = d->adler;
-    rc = d->eng->e.deflate_stored((const uint8_t *)d->d_in.p, (uint8_t *)d->d_out.p, sb, d->nowrap ? 0u : 2u, 0, fed_now < n ? fed_now : n, 0, d->adler, nullptr, &adler, nullptr);
+    uint32_t adler = d->adler, crc = d->crc;
+    rc = d->eng->e.deflate_stored((const uint8_t *)d->d_in.p, (uint8_t *)d->d_out.p, sb, (d->nowrap ? 0u : 2u) | (d->want_crc ? 1u : 0u), 0, fed_now < n ? fed_now : n, d->crc, d->adler, &crc, &adler, nullptr);
     if (rc) return rc;
     if (!d->nowrap) d->adler = adler;
+    if (d->want_crc) d->crc = crc;
     // A stored block after a compressed era starts inside a byte: its three header bits follow the carried bits, then the stream is
     // byte aligned (FlushStoredBlock: WriteBits(3) + AlignToByte, C/DeflaterHuffman.cs:766-779, C/PendingBuffer.cs:143-155)
     size_t old = d->outq.size();
@@ -997,7 +1035,7 @@ static void advance_history(szl_deflater *d, uint64_t X_rel, const std::vector<u
     }
     d->hist_abs = d->hist_abs + first;
     d->hist.swap(nh); d->hist_flags.swap(nf); d->hist_has_gaps = gaps;
-    d->pend.erase(d->pend.begin(), d->pend.begin() + (ptrdiff_t)X_rel);
+    d->pend.erase_front((size_t)X_rel); d->up_done = 0;
     d->bounds.erase(std::remove_if(d->bounds.begin(), d->bounds.end(), [&](uint64_t b) { return b <= d->hist_abs; }), d->bounds.end());
 }
 static int run_segment_stored(szl_deflater *d, bool finish) {
@@ -1013,7 +1051,7 @@ static int run_segment_stored(szl_deflater *d, bool finish) {
     int rc = stored_emit(d, blks, fed_now, finish);
     if (rc) return rc;
     if (finish) {   // the stream is over: no history to keep (only Reset() makes the object usable again) — as run_segment does for the coded levels
-        d->hist.clear(); d->hist_flags.clear(); d->hist_has_gaps = false; d->bounds.clear(); d->pend.clear();
+        d->hist.clear(); d->hist_flags.clear(); d->hist_has_gaps = false; d->bounds.clear(); d->pend.clear(); d->up_done = 0;
         d->hist_abs = (uint64_t)d->total_in + d->l0_dict;
     } else advance_history(d, d->pend.size(), nullptr, false);   // stored bytes are in the window, but in no hash chain
     d->engine_seen = d->total_in;
@@ -1077,10 +1115,8 @@ static int run_segment(szl_deflater *d, bool finish) {
     const uint64_t H = d->hist.size(), n = d->pend.size();
     const uint64_t in_total = H + n;
     const uint64_t cap = (szl_deflate_bound(n) + 16 + 3) & ~3ull;
-    if ((rc = d->d_in.ensure(in_total + 64))) return rc;
+    if ((rc = finish_upload(d, H, n))) return rc;                        // (most of the pending bytes are there already: eager_upload)
     if ((rc = d->d_out.ensure(cap + 64))) return rc;
-    if (H && hipMemcpy(d->d_in.p, d->hist.data(), H, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
-    if (n && hipMemcpy((uint8_t *)d->d_in.p + H, d->pend.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
     std::vector<SegDev> segs(1);
     std::vector<uint64_t> bnds;
     for (uint64_t b : d->bounds) if (b > d->hist_abs) bnds.push_back(b - d->hist_abs);
@@ -1091,33 +1127,37 @@ static int run_segment(szl_deflater *d, bool finish) {
     s.bnd_off = 0; s.bnd_cnt = (uint32_t)bnds.size();
     s.finish = finish ? 1 : 0;
     s.flags = finish ? ((d->nowrap ? 0u : (uint32_t)SEG_ZLIB_TRAILER)) : (uint32_t)SEG_SYNC_PAD;
-    s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = 0;
+    s.out_off = 0; s.out_cap = cap; s.start_bit = d->carry_bits; s.adler_init = d->adler; s.crc_init = d->crc;
     std::vector<SegOut> res;
     Engine &E = d->eng->e;
     E.sw_pos_in = sw_pos; E.sw_P_in = sw_P;
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = !finish; /* (the inserted bits of the tail are history for a next segment only) */ }
     else if (d->hist_has_gaps && H) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); }   // stage A must skip what DeflateFast skipped
-    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, d->nowrap ? 0u : 2u, res, nullptr);
+    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, (d->nowrap ? 0u : 2u) | (d->want_crc ? 1u : 0u), res, nullptr);
     E.fast_hist_in.clear(); E.fast_want_tail = false; E.sw_pos_in.clear(); E.sw_P_in.clear();
     if (rc) return rc;
     const uint64_t end_bit = res[0].end_bit;
     const uint64_t bytes = (end_bit + 7) >> 3;
-    d->h_out.resize(bytes + 1);
-    if (bytes && hipMemcpy(d->h_out.data(), d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
-    if (d->carry_bits && bytes) d->h_out[0] |= d->carry_byte;
-    if (d->stale && bytes) { d->h_out[0] |= d->stale; d->stale = 0; }
+    // the segment's bytes come straight into the output queue (pinned: one DMA, no second host copy)
+    const size_t q0 = d->outq.size();
+    d->outq.resize(q0 + (size_t)bytes + 1);
+    uint8_t *ho = d->outq.data() + q0;
+    if (bytes && hipMemcpy(ho, d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    if (d->carry_bits && bytes) ho[0] |= d->carry_byte;
+    if (d->stale && bytes) { ho[0] |= d->stale; d->stale = 0; }
     if (!d->nowrap) d->adler = res[0].adler32;
+    if (d->want_crc) d->crc = res[0].crc32;
     uint64_t whole = finish ? bytes : (end_bit >> 3);
-    d->outq.insert(d->outq.end(), d->h_out.begin(), d->h_out.begin() + whole);
     if (finish) { d->carry_bits = 0; d->carry_byte = 0; }
     else {
         d->carry_bits = (uint32_t)(end_bit & 7);
-        d->carry_byte = d->carry_bits ? d->h_out[whole] : 0;
+        d->carry_byte = d->carry_bits ? ho[whole] : 0;
     }
+    d->outq.resize(q0 + (size_t)whole);
     if (finish) {   // the stream is over (only Reset() makes the object usable again, and it clears all of this): no history to keep —
                     // the per-entry pattern of ZipOutputStream (Reset + SetInput + Finish) paid 0.1-0.2 ms of host time for it
-        d->hist.clear(); d->hist_flags.clear(); d->hist_has_gaps = false; d->bounds.clear(); d->pend.clear();
+        d->hist.clear(); d->hist_flags.clear(); d->hist_has_gaps = false; d->bounds.clear(); d->pend.clear(); d->up_done = 0;
         d->hist_abs = (uint64_t)d->total_in + d->l0_dict;
         d->switches.clear(); d->base_level = d->level; d->base_strategy = d->strategy; d->engine_seen = d->total_in;
         return 0;
@@ -1155,7 +1195,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     }
     d->hist_abs = d->hist_abs + H + n - keep;
     d->hist.swap(nh);
-    d->pend.clear();
+    d->pend.clear(); d->up_done = 0;
     d->switches.clear(); d->base_level = d->level; d->base_strategy = d->strategy; d->engine_seen = d->total_in;
     d->bounds.erase(std::remove_if(d->bounds.begin(), d->bounds.end(), [&](uint64_t b) { return b <= d->hist_abs; }), d->bounds.end());
     return 0;
@@ -1180,9 +1220,7 @@ static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out, uint64
     const uint64_t H = d->hist.size(), n = seen;
     const uint64_t in_total = H + n;
     const uint64_t cap = (szl_deflate_bound(n) + 16 + 3) & ~3ull;
-    if ((rc = d->d_in.ensure(in_total + 64)) || (rc = d->d_out.ensure(cap + 64))) return rc;
-    if (H && hipMemcpy(d->d_in.p, d->hist.data(), H, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
-    if (hipMemcpy((uint8_t *)d->d_in.p + H, d->pend.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
+    if ((rc = finish_upload(d, H, n)) || (rc = d->d_out.ensure(cap + 64))) return rc;
     std::vector<SegDev> segs(1);
     std::vector<uint64_t> bnds;
     for (uint64_t b : d->bounds) if (b > d->hist_abs) bnds.push_back(b - d->hist_abs);
@@ -1217,10 +1255,11 @@ static int cut_coded(szl_deflater *d, uint64_t seen, uint64_t *x_rel_out, uint64
     if (d->stale && bytes) { d->h_out[0] |= d->stale; d->stale = 0; }
     if (end_bit_out) *end_bit_out = end_bit;
     const uint64_t whole = end_bit >> 3;
-    d->outq.insert(d->outq.end(), d->h_out.begin(), d->h_out.begin() + whole);
+    d->outq.append(d->h_out.data(), (size_t)whole);
     d->carry_bits = (uint32_t)(end_bit & 7);
     d->carry_byte = d->carry_bits ? d->h_out[whole] : 0;
     if (!d->nowrap && X_rel) { uint32_t a = d->adler; if ((rc = szl_adler32(d->adler, d->pend.data(), (size_t)X_rel, &a))) return rc; d->adler = a; }
+    if (d->want_crc && X_rel) { uint32_t c = d->crc; if ((rc = szl_crc32(d->crc, d->pend.data(), (size_t)X_rel, &c))) return rc; d->crc = c; }
     // history: DeflateSlow inserted every position in front of the cut (each had MIN_LOOKAHEAD bytes in front of it); DeflateFast the
     // ones its flags say
     std::vector<uint32_t> ff;
@@ -1292,7 +1331,7 @@ static int function_switch(szl_deflater *d, int level) {
     return 0;
 }
 
-int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Deflater.cs:427
+static int deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Deflater.cs:427
     if (!d || length < 0 || (!out && length)) return SZL_E_ARG;
     if (d->state == CLOSED_STATE) return SZL_E_STATE;
     const int orig = length;
@@ -1326,6 +1365,26 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/Defla
         else return SZL_E_STATE;
     }
     return orig - length;
+}
+
+// The entry points proper: no C++ exception leaves the library (an allocation that fails is SZL_E_NOMEM — round-4 ADVICE)
+#define SZL_GUARDED(call) do { try { return (call); } catch (const std::bad_alloc &) { set_error("out of host memory"); return SZL_E_NOMEM; } catch (...) { set_error("internal error"); return SZL_E_STATE; } } while (0)
+int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n) { SZL_GUARDED(deflater_set_input(d, p, n)); }
+int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { SZL_GUARDED(deflater_deflate(d, out, length)); }
+int szl_deflater_reset(szl_deflater *d) { SZL_GUARDED(deflater_reset(d)); }
+int szl_deflater_set_level(szl_deflater *d, int level) { SZL_GUARDED(deflater_set_level(d, level)); }
+int szl_deflater_set_strategy(szl_deflater *d, int s) { SZL_GUARDED(deflater_set_strategy(d, s)); }
+int szl_deflater_enable_crc32(szl_deflater *d, int on) {
+    if (!d) return SZL_E_ARG;
+    if (d->total_in != 0 && (on != 0) != d->want_crc) { set_error("the CRC-32 is switched before the first SetInput (or after Reset)"); return SZL_E_STATE; }
+    d->want_crc = on != 0;
+    return 0;
+}
+uint32_t szl_deflater_crc32(const szl_deflater *d) {   // of all the input given so far (compressed or still pending), like TotalIn counts it
+    if (!d || !d->want_crc) return 0;
+    uint32_t v = d->crc;
+    if (!d->pend.empty() && szl_crc32(d->crc, d->pend.data(), d->pend.size(), &v) != 0) return d->crc;
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------

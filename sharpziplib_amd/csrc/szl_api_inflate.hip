@@ -165,20 +165,45 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             ps[k].first_bit = 16;
         }
     }
-    // ---- 1. candidate starts: one finder job per chunk (chunk 0 starts at the member's first block)
-    std::vector<FindJob> fj(nstart_total, FindJob{0, 0, 0, 0});
+    // ---- 1. candidate starts: the first header in every chunk (chunk 0 starts at the member's first block).  A finder job is one
+    // wavefront testing 64 bit positions per step; a chunk without a header in its first kilobytes is scanned far — the blocks of a
+    // reference-made stream are ~45 KiB — and the scan of ONE such chunk is what the pass costs: 5.9 ms for a 16 MiB piece of a stream
+    // (512 chunks of 32 KiB on 2048 wavefront slots; profiles/r05/read_path_second_version.log) — as much as for a 1 GiB member.  While the
+    // call leaves slots empty a chunk's range is therefore cut into `fsub` sub-ranges, a finder job each; the chunk's start is the lowest
+    // hit (the same position a scan from the chunk's beginning finds: every bit position is tested on its own).  A call that fills
+    // the slots keeps one job per chunk (round 4 measured the split there: slower, it only adds scanned bytes).
+    uint32_t fsub = 1;
+    if (nstart_total * 2 <= slots) fsub = (uint32_t)std::min<uint64_t>(16, slots / std::max<uint64_t>(nstart_total, 1));   // (the finder jobs of the call: one round of the slots at most)
+    {
+        uint64_t cb_min = ~0ull;
+        for (auto &p : ps) if (p.alive) cb_min = std::min(cb_min, p.chunk_bytes);
+        while (fsub > 1 && cb_min / fsub < 2048) fsub--;            // (sub-ranges of at least 2 KiB)
+    }
+    const uint64_t nfind = nstart_total * fsub;
+    std::vector<FindJob> fj(nfind, FindJob{0, 0, 0, 0});
     for (auto &p : ps) {
         if (!p.alive) continue;
-        for (uint32_t c = 1; c < p.nchunks; c++)
-            fj[p.start_off + c] = FindJob{streams[p.si].in_off, streams[p.si].in_len, (uint64_t)c * p.chunk_bytes * 8, (uint64_t)(c + 1) * p.chunk_bytes * 8};
+        for (uint32_t c = 1; c < p.nchunks; c++) {
+            const uint64_t lo = (uint64_t)c * p.chunk_bytes * 8, hi = (uint64_t)(c + 1) * p.chunk_bytes * 8;
+            for (uint32_t q = 0; q < fsub; q++)
+                fj[(p.start_off + c) * fsub + q] = FindJob{streams[p.si].in_off, streams[p.si].in_len, lo + (hi - lo) * q / fsub, lo + (hi - lo) * (q + 1) / fsub};
+        }
     }
-    if (nstart_total > 0x7FFFFFFFull) return SZL_E_ARG;
-    if ((rc = E.inf_misc.ensure(nstart_total * 8 + 64)) || (rc = E.inf_jobs.ensure(nstart_total * sizeof(FindJob)))) return rc;
+    if (nfind > 0x7FFFFFFFull) return SZL_E_ARG;
+    if ((rc = E.inf_misc.ensure(nfind * 8 + 64)) || (rc = E.inf_jobs.ensure(nfind * sizeof(FindJob)))) return rc;
     uint64_t *d_start = (uint64_t *)E.inf_misc.p;
-    HIPCHK(hipMemcpyAsync(E.inf_jobs.p, fj.data(), nstart_total * sizeof(FindJob), hipMemcpyHostToDevice, st));
-    launch_find_blocks(d_in, (const FindJob *)E.inf_jobs.p, (uint32_t)nstart_total, d_start, st);   // (jobs with an empty range report "none")
-    std::vector<uint64_t> starts(nstart_total);
-    HIPCHK(hipMemcpyAsync(starts.data(), d_start, nstart_total * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpyAsync(E.inf_jobs.p, fj.data(), nfind * sizeof(FindJob), hipMemcpyHostToDevice, st));
+    launch_find_blocks(d_in, (const FindJob *)E.inf_jobs.p, (uint32_t)nfind, d_start, st);   // (jobs with an empty range report "none")
+    std::vector<uint64_t> starts(nfind);
+    HIPCHK(hipMemcpyAsync(starts.data(), d_start, nfind * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+    if (fsub > 1) {
+        for (uint64_t c = 0; c < nstart_total; c++) {
+            uint64_t best = ~0ull;
+            for (uint32_t q = 0; q < fsub; q++) best = std::min(best, starts[c * fsub + q]);
+            starts[c] = best;
+        }
+        starts.resize(nstart_total);
+    }
     lap("find block starts");
     uint64_t reg_total = 0;              // single pass: symbols of staging handed out so far
     for (auto &p : ps) {

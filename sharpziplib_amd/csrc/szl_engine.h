@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdint>
+#include <cstring>
+#include <new>
 #include <vector>
 #include "../../include/szl.h"
 #include "szl_internal.h"
@@ -22,6 +24,35 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int ensure(size_t n);   // grow-only; contents are NOT preserved
+    int ensure_keep(size_t n, size_t keep, hipStream_t st);   // grow-only; the first `keep` bytes are preserved (copied on `st`, which is synchronised)
+    void release();
+};
+
+// Bytes in pinned host memory with the few members of std::vector<uint8_t> the streaming objects use (szl_api.hip): what the caller
+// gives is copied here once and goes to the device by DMA while he is still writing; what the device produces comes back the same
+// way.  No zero fill on growth, no page faults on reuse.  Allocation failure throws std::bad_alloc like the vector it replaces (the
+// C entry points catch it).
+struct PinVec {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    hipStream_t busy = nullptr;                       // a stream with copies out of this memory in flight (synchronised before it moves)
+    PinVec() = default;
+    PinVec(const PinVec &) = delete;
+    PinVec &operator=(const PinVec &) = delete;
+    ~PinVec() { release(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    uint8_t *begin() { return p; }
+    uint8_t *end() { return p + n; }
+    uint8_t &operator[](size_t i) { return p[i]; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+    void reserve(size_t want);
+    void resize(size_t k) { reserve(k); n = k; }   // (new bytes are uninitialised)
+    void push_back(uint8_t b) { reserve(n + 1); p[n++] = b; }
+    void append(const uint8_t *src, size_t k);
+    void erase_front(size_t k);
     void release();
 };
 

@@ -189,7 +189,39 @@ int DevBuf::ensure(size_t n) {
     cap = want;
     return 0;
 }
+int DevBuf::ensure_keep(size_t n, size_t keep, hipStream_t st) {
+    if (n <= cap) return 0;
+    const size_t want = std::max(n + (n >> 3) + 256, cap + cap / 2);
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return SZL_E_NOMEM; }
+    if (p && keep) {
+        if (hipMemcpyAsync(q, p, std::min(keep, cap), hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(q); set_error("device copy failed"); return SZL_E_DEVICE; }
+    } else if (p) (void)hipStreamSynchronize(st);
+    if (p) (void)hipFree(p);
+    p = q; cap = want;
+    return 0;
+}
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+void PinVec::reserve(size_t want) {
+    if (want <= cap) return;
+    size_t ncap = std::max(want, cap + cap / 2);
+    ncap = (ncap + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+    uint8_t *q = nullptr;
+    if (hipHostMalloc((void **)&q, ncap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+    if (busy) (void)hipStreamSynchronize(busy);       // copies out of the old memory
+    if (n) memcpy(q, p, n);
+    if (p) (void)hipHostFree(p);
+    p = q; cap = ncap;
+}
+void PinVec::append(const uint8_t *src, size_t k) { reserve(n + k); if (k) memcpy(p + n, src, k); n += k; }
+void PinVec::erase_front(size_t k) {
+    if (busy) (void)hipStreamSynchronize(busy);
+    if (k >= n) { n = 0; return; }
+    memmove(p, p + k, n - k); n -= k;
+}
+void PinVec::release() { if (busy) (void)hipStreamSynchronize(busy); if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
 
 Engine::Engine() {
     for (auto &e : ev) e = nullptr;

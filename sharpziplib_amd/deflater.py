@@ -137,3 +137,13 @@ class Deflater:
     @property
     def Adler(self):
         return self._L.szl_deflater_adler(self._h)
+
+    # device-side CRC-32 of the input (include/szl.h: what GZipOutputStream / ZipOutputStream keep on the CPU over every Write)
+    def EnableCrc32(self, on=True):
+        s = self._L.szl_deflater_enable_crc32(self._h, 1 if on else 0)
+        if s < 0:
+            _raise(s, "EnableCrc32")
+
+    @property
+    def Crc32(self):
+        return self._L.szl_deflater_crc32(self._h)

@@ -32,6 +32,8 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		[DllImport(Lib)] internal static extern long szl_deflater_total_in(IntPtr d);
 		[DllImport(Lib)] internal static extern long szl_deflater_total_out(IntPtr d);
 		[DllImport(Lib)] internal static extern uint szl_deflater_adler(IntPtr d);
+		[DllImport(Lib)] internal static extern int szl_deflater_enable_crc32(IntPtr d, int on);
+		[DllImport(Lib)] internal static extern uint szl_deflater_crc32(IntPtr d);
 
 		[DllImport(Lib)] internal static extern IntPtr szl_inflater_create(int noHeader);
 		[DllImport(Lib)] internal static extern void szl_inflater_destroy(IntPtr s);
@@ -107,6 +109,11 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 
 		public void Reset() { Check(SzlNative.szl_deflater_reset(h), nameof(Reset)); }                 // :204
 		public int Adler => unchecked((int)SzlNative.szl_deflater_adler(h));                              // :215
+		/// <summary>CRC-32 of the input given so far, kept on the device beside the compression (include/szl.h): a device-aware
+		/// GZipOutputStream / ZipOutputStream switches it on before the first SetInput and reads it where the reference reads crc.Value
+		/// (S/GZip/GzipOutputStream.cs:210,330; S/Zip/ZipOutputStream.cs:700).</summary>
+		internal void EnableCrc32(bool on = true) { Check(SzlNative.szl_deflater_enable_crc32(h, on ? 1 : 0), nameof(EnableCrc32)); }
+		internal long Crc32 => SzlNative.szl_deflater_crc32(h);
 		public long TotalIn => SzlNative.szl_deflater_total_in(h);                                       // :226
 		public long TotalOut => SzlNative.szl_deflater_total_out(h);                                     // :237
 		public void Flush() { SzlNative.szl_deflater_flush(h); }                                         // :252

@@ -51,10 +51,15 @@ class GZipOutputStream(DeflaterOutputStream):
     """new GZipOutputStream(stream[, size]); FileName / ModifiedTime / SetLevel; Write; Finish — the header goes out with the
     first Write or at Finish (:263-271, :384-392), the CRC runs over what was written (:203-214)."""
 
-    def __init__(self, baseOutputStream, size=4096):
+    def __init__(self, baseOutputStream, size=4096, deviceCrc=True):
         super().__init__(baseOutputStream, Deflater(Deflater.DEFAULT_COMPRESSION, True), size)
         self._state = "Header"
         self._crc = 0
+        # deviceCrc (default): the CRC-32 of what is written is kept by the Deflater on the device beside the compression
+        # (include/szl.h szl_deflater_crc32) instead of a pass over every Write on the host (:210); False: the reference's arrangement
+        self._device_crc = bool(deviceCrc)
+        if self._device_crc:
+            self.deflater_.EnableCrc32()
         self._flags = 0
         self._file_name = None
         self.ModifiedTime = None                          # seconds since the epoch; None: now (:343)
@@ -91,7 +96,8 @@ class GZipOutputStream(DeflaterOutputStream):
             raise RuntimeError("Write not permitted in current state")
         a = np.frombuffer(buffer, dtype=np.uint8) if not isinstance(buffer, np.ndarray) else buffer
         count = a.size - offset if count is None else count
-        self._crc = _crc32(self._crc, a[offset:offset + count])
+        if not self._device_crc:
+            self._crc = _crc32(self._crc, a[offset:offset + count])
         super().Write(a, offset, count)
 
     def Finish(self):                                     # :259-281
@@ -100,7 +106,7 @@ class GZipOutputStream(DeflaterOutputStream):
         if self._state == "Footer":
             self._state = "Finished"
             super().Finish()
-            self.baseOutputStream_.write(member_footer(self._crc, self.deflater_.TotalIn))
+            self.baseOutputStream_.write(member_footer(self.deflater_.Crc32 if self._device_crc else self._crc, self.deflater_.TotalIn))
 
     def Dispose(self):                                    # :170-188
         if not self.isClosed_:

@@ -100,8 +100,10 @@ def suite_deflater_object():
                              ([1, 2, 3, 4, 5, 6, 7, 9], 41, dict(flush_p=0.4, cross_kind_at_flush=True)),
                              ([1, 2, 3, 4, 5, 6, 7, 9], 51, dict(cross_p=0.7)), ([0, 1, 3, 4, 5, 6, 9], 61, dict(cross_p=0.8)),
                              ([0, 2, 6], 81, dict(cross_p=0.9, flush_p=0.05))):
+        _knobs(SZL_UP_SLAB_KIB=1 if seed % 20 == 1 else FORGET)     # (the pending bytes travel to the device as they arrive, here in 1 KiB slabs: every other configuration)
         TS._run(levels, seed, total=7000, chunk_sizes=small, **kw)
         n += 1
+    _knobs(SZL_UP_SLAB_KIB=FORGET)
     for level, nowrap in ((6, True), (1, False)):
         d, o = Deflater(level, nowrap), O.Deflater(level, nowrap)
         a = C.generate("enwik", 3, 0, 1234)
