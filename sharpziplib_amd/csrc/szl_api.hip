@@ -1439,19 +1439,20 @@ bool host_is_pinned(const void *p, size_t n) {
 }
 extern "C" void *szl_host_alloc(size_t n) {
     if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return nullptr; }
-    void *p = nullptr;
-    if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("pinned host memory (%zu bytes)", n); return nullptr; }
+    size_t cap = 0;
+    uint8_t *p = pin_alloc(n ? n : 1, &cap);              // (the process-wide pool of pinned blocks: a stream's buffer is the next stream's)
+    if (!p) { set_error("pinned host memory (%zu bytes)", n); return nullptr; }
     std::lock_guard<std::mutex> lk(g_pin_mu);
-    g_pinned.push_back(PinnedRange{(const uint8_t *)p, n, true});
+    g_pinned.push_back(PinnedRange{p, cap, true});
     return p;
 }
-static bool pinned_forget(void *p, bool ours) {
+static bool pinned_forget(void *p, bool ours, size_t *cap = nullptr) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pinned.size(); i++)
-        if (g_pinned[i].p == (const uint8_t *)p && g_pinned[i].ours == ours) { g_pinned.erase(g_pinned.begin() + (ptrdiff_t)i); return true; }
+        if (g_pinned[i].p == (const uint8_t *)p && g_pinned[i].ours == ours) { if (cap) *cap = g_pinned[i].n; g_pinned.erase(g_pinned.begin() + (ptrdiff_t)i); return true; }
     return false;
 }
-extern "C" void szl_host_free(void *p) { if (p && pinned_forget(p, true)) (void)hipHostFree(p); }
+extern "C" void szl_host_free(void *p) { size_t cap = 0; if (p && pinned_forget(p, true, &cap)) pin_free((uint8_t *)p, cap); }
 extern "C" int szl_host_register(void *p, size_t n) {
     if (!p || !n) return SZL_E_ARG;
     if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }

@@ -661,19 +661,18 @@ struct HostBuf {
     void clear() { n = 0; }
     int reserve(size_t want) {                    // contents [0, n) are kept
         if (want <= cap) return 0;
-        size_t ncap = std::max(want, cap + cap / 2);
-        ncap = (ncap + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
-        uint8_t *q = nullptr;
-        if (hipHostMalloc((void **)&q, ncap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("pinned host memory (%zu bytes)", ncap); return SZL_E_NOMEM; }
+        size_t ncap = 0;
+        uint8_t *q = pin_alloc(std::max(want, cap + cap / 2), &ncap);     // (out of the process-wide pool of pinned blocks, szl_engine.h)
+        if (!q) { set_error("pinned host memory (%zu bytes)", want); return SZL_E_NOMEM; }
         if (n) memcpy(q, p, n);
-        if (p) (void)hipHostFree(p);
+        pin_free(p, cap);
         p = q; cap = ncap;
         return 0;
     }
     int append(const uint8_t *src, size_t k) { int rc = reserve(n + k); if (rc) return rc; if (k) memcpy(p + n, src, k); n += k; return 0; }
     int grow(size_t k) { int rc = reserve(n + k); if (rc) return rc; n += k; return 0; }   // k more bytes, uninitialised
     void erase_front(size_t k) { if (k >= n) { n = 0; return; } memmove(p, p + k, n - k); n -= k; }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+    void release() { pin_free(p, cap); p = nullptr; n = cap = 0; }
 };
 // The compressed bytes the object holds: its own pinned bytes, then — while `borrowed()` — the caller's pinned buffer behind them (a long
 // SetInput out of the device-aware InflaterInputBuffer is not copied: the pointer is kept, as CS/StreamManipulator.cs:244-262 keeps

@@ -32,6 +32,13 @@ struct DevBuf {
 // gives is copied here once and goes to the device by DMA while he is still writing; what the device produces comes back the same
 // way.  No zero fill on growth, no page faults on reuse.  Allocation failure throws std::bad_alloc like the vector it replaces (the
 // C entry points catch it).
+// Pinned host memory is expensive to get (the pages are locked and mapped into the device's address space: a gigabyte costs hundreds of
+// milliseconds) and the streaming objects are short-lived (GZipOutputStream makes a new Deflater per stream, S/GZip/GzipOutputStream.cs:87;
+// InflaterPool resets and reuses).  Blocks a buffer outgrows or leaves behind go to a process-wide pool (SZL_PIN_POOL_MIB, default 4096:
+// what it may hold; 0 = none) and are handed out again, best fit, to whoever asks next.
+uint8_t *pin_alloc(size_t want, size_t *cap_out);    // nullptr: no pinned memory of that size
+void pin_free(uint8_t *p, size_t cap);
+
 struct PinVec {
     uint8_t *p = nullptr; size_t n = 0, cap = 0;
     hipStream_t busy = nullptr;                       // a stream with copies out of this memory in flight (synchronised before it moves)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
+#include <mutex>
 #include <thread>
 #include <cstring>
 #include <vector>
@@ -204,15 +205,50 @@ int DevBuf::ensure_keep(size_t n, size_t keep, hipStream_t st) {
 }
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
+namespace {
+struct PinBlock { uint8_t *p; size_t cap; };
+std::mutex g_pool_mu;
+std::vector<PinBlock> g_pool;
+size_t g_pool_bytes = 0;
+}
+uint8_t *pin_alloc(size_t want, size_t *cap_out) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].cap >= want && g_pool[i].cap <= 4 * want + (1u << 20) && (best == g_pool.size() || g_pool[i].cap < g_pool[best].cap)) best = i;
+        if (best != g_pool.size()) {
+            const PinBlock b = g_pool[best];
+            g_pool.erase(g_pool.begin() + (ptrdiff_t)best);
+            g_pool_bytes -= b.cap;
+            *cap_out = b.cap;
+            return b.p;
+        }
+    }
+    const size_t ncap = (want + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+    uint8_t *q = nullptr;
+    if (hipHostMalloc((void **)&q, ncap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *cap_out = ncap;
+    return q;
+}
+void pin_free(uint8_t *p, size_t cap) {
+    if (!p) return;
+    const size_t limit = (size_t)std::max(0, knob("SZL_PIN_POOL_MIB", 4096)) << 20;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (cap >= (1u << 20) && g_pool_bytes + cap <= limit && g_pool.size() < 64) { g_pool.push_back(PinBlock{p, cap}); g_pool_bytes += cap; return; }
+    }
+    (void)hipHostFree(p);
+}
+
 void PinVec::reserve(size_t want) {
     if (want <= cap) return;
-    size_t ncap = std::max(want, cap + cap / 2);
-    ncap = (ncap + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
-    uint8_t *q = nullptr;
-    if (hipHostMalloc((void **)&q, ncap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+    size_t ncap = 0;
+    uint8_t *q = pin_alloc(std::max(want, 2 * cap), &ncap);
+    if (!q) throw std::bad_alloc();
     if (busy) (void)hipStreamSynchronize(busy);       // copies out of the old memory
     if (n) memcpy(q, p, n);
-    if (p) (void)hipHostFree(p);
+    pin_free(p, cap);
     p = q; cap = ncap;
 }
 void PinVec::append(const uint8_t *src, size_t k) { reserve(n + k); if (k) memcpy(p + n, src, k); n += k; }
@@ -221,7 +257,7 @@ void PinVec::erase_front(size_t k) {
     if (k >= n) { n = 0; return; }
     memmove(p, p + k, n - k); n -= k;
 }
-void PinVec::release() { if (busy) (void)hipStreamSynchronize(busy); if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+void PinVec::release() { if (busy) (void)hipStreamSynchronize(busy); pin_free(p, cap); p = nullptr; n = cap = 0; }
 
 Engine::Engine() {
     for (auto &e : ev) e = nullptr;

@@ -117,7 +117,7 @@ def test_buffer_class_members_keep_their_meaning_on_the_long_buffer():
     got = 0
     while not inf.IsFinished:
         k = inf.Inflate(out, got, min(1 << 20, out.size - got))
-        assert k > 0
+        assert k > 0 or inf.IsFinished                    # (the call that learns of the stream's end may have nothing left to hand out)
         got += k
     assert got == plain.size and out[:got].tobytes() == plain.tobytes() and _bulk(inf) >= 1
     assert inf.RemainingInput == len(tail)

@@ -17,6 +17,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 constexpr int W = 54016;            // window positions of a k_match9 tile (32512 history + 21504 tile)
+constexpr int WP = 40944;           // form (b): what 160 KiB hold at 4 B per position (32512 history + 8432 tile)
 constexpr int STEPS = 2048;
 
 __device__ __forceinline__ uint32_t lds_u8(uint32_t a) { uint32_t v; asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
@@ -28,6 +29,7 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k_steps(const uint16_t *g_link, const uint8_t *g_byte, uint32_t *sink, int nwin) {
     extern __shared__ uint8_t lds[];
     const int tid = threadIdx.x;
+    constexpr int W = MODE == 1 ? WP : ::W;
     const uint16_t *lk = g_link + (size_t)(blockIdx.x % nwin) * W;
     const uint8_t *by = g_byte + (size_t)(blockIdx.x % nwin) * W;
     // stage the window
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(1024) void k_steps(const uint16_t *g_link, const ui
         for (int i = tid; i < W; i += 1024) lds[i] = by[i];
     }
     __syncthreads();
-    uint32_t xa = W - 1 - (uint32_t)((tid * 37u) % 20000u), xb = W - 1 - (uint32_t)((tid * 53u + 11u) % 20000u), acc = 0;
+    uint32_t xa = W - 1 - (uint32_t)((tid * 37u) % 8000u), xb = W - 1 - (uint32_t)((tid * 53u + 11u) % 8000u), acc = 0;
     for (int s = 0; s < STEPS; s++) {
         uint32_t ha, hb, fa, fb;
         if (MODE == 0) {
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(1024) void k_steps(const uint16_t *g_link, const ui
         }
         asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
         acc += (fa == 0x00410042u) + (fb == 0x00410042u);
-        xa = xa > ha + 64 ? xa - ha : W - 1 - ((xa * 2654435761u) >> 17);     // the chain ends: a new walk starts near the tile
-        xb = xb > hb + 64 ? xb - hb : W - 1 - ((xb * 2246822519u) >> 17);
+        xa = xa > ha + 64 ? xa - ha : W - 1 - ((xa * 2654435761u) >> 19);     // the chain ends: a new walk starts near the tile
+        xb = xb > hb + 64 ? xb - hb : W - 1 - ((xb * 2246822519u) >> 19);
     }
     if (acc == 0xFFFFFFFFu) sink[0] = acc;
 }
@@ -100,7 +102,7 @@ int main() {
     CK(hipMemcpy(d_byte, byte.data(), byte.size(), hipMemcpyHostToDevice));
     printf("chain steps of two contexts per lane, %d dependent steps per context, %d CUs\n", STEPS, cus);
     run<0>("lds3   (k_match9 today)", d_link, d_byte, d_sink, nwin, cus, 1, 54336 + 2 * W + 64);
-    run<1>("packed (form b: one dword)", d_link, d_byte, d_sink, nwin, cus, 1, 4 * (size_t)W + 64);
+    run<1>("packed (form b: one dword)", d_link, d_byte, d_sink, nwin, cus, 1, 4 * (size_t)WP + 64);
     run<2>("l2link (form a: links from L2)", d_link, d_byte, d_sink, nwin, cus, 1, (size_t)W + 64);
     run<2>("l2link (form a: links from L2)", d_link, d_byte, d_sink, nwin, cus, 2, (size_t)W + 64);
     return 0;
