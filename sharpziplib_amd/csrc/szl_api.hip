@@ -284,7 +284,7 @@ int szl_deflate_batch_host(szl_engine *e, const void *h_in, void *h_out, szl_str
     // One long stream that will go through the window pipeline: the input is copied by a second host thread, 32 MiB at a time
     // on its own stream, while the engine already works on the windows that have arrived (Engine::in_ready).
     const int lv = level == -1 ? 6 : level;
-    if (Engine::uses_window_pipeline(n_streams, lv >= 5, n_streams == 1 ? streams[0].in_len : 0, nullptr) && szl::knob("SZL_H2D_OVERLAP", 1)) {
+    if (Engine::uses_window_pipeline(n_streams, lv >= 5, n_streams == 1 ? streams[0].in_len : 0, nullptr) && SZL_LABKNOB("SZL_H2D_OVERLAP", 1)) {
         volatile uint64_t ready = 0;
         int copy_rc = 0, dev = 0;
         (void)hipGetDevice(&dev);

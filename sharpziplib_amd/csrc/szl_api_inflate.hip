@@ -535,7 +535,7 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
-    if (n_all <= (size_t)std::max(1, knob("SZL_INF_PAR_MAX_STREAMS", 1024))) {
+    if (n_all <= (size_t)std::max(1, SZL_LABKNOB("SZL_INF_PAR_MAX_STREAMS", 1024))) {
         // groups of at most ~4 GiB of compressed input keep the 2-byte-per-output-byte staging bounded
         std::vector<size_t> cand;
         uint64_t grp = 0;
@@ -1014,7 +1014,7 @@ static int inflater_step(szl_inflater *s) {
     const size_t nin = s->hin.size() - s->hin_pos;
     // a long input: bring the stream to a block header (stop_at_header), then the chunk-parallel decoder
     const size_t bulk_min = (size_t)std::max(64, knob("SZL_INF_STREAM_BULK_KIB", (int)BULK_MIN_DEFAULT_KIB)) * 1024;
-    const bool bulk = nin >= bulk_min && s->given > s->bulk_skip_given && !s->err && s->dec_status != INF_NEED_DICT && !s->exact_live && knob("SZL_INF_STREAM_BULK", 1) != 0;
+    const bool bulk = nin >= bulk_min && s->given > s->bulk_skip_given && !s->err && s->dec_status != INF_NEED_DICT && !s->exact_live && SZL_LABKNOB("SZL_INF_STREAM_BULK", 1) != 0;
     s->tail_deferred = false;              // (whatever runs now takes the remainder along)
     if (bulk && s->st.mode == INF_M_HEADER && !s->st.last && s->dec_status == INF_CHUNK_END) {
         rc = inflater_bulk(s);

@@ -16,6 +16,7 @@ const char *last_error();
 int level_params(int level, int strategy, LevelParams *P);
 int knob(const char *name, int dflt);   // szl_debug_set() value, else environment variable, else dflt
 int knob_set(const char *name, int value);
+
 enum : int { SZL_MATCH_KERNEL_DEFAULT = 2 };   // form of stage B's full search (SZL_MATCH_KERNEL): 2 k_match4 (prev[] walks), 5 k_match5 (bucket order)
 
 bool host_is_pinned(const void *p, size_t n);   // [p, p+n) lies in memory handed out by szl_host_alloc / named by szl_host_register

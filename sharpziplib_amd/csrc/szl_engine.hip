@@ -67,7 +67,7 @@ static int match_form(const LevelParams &P, bool hist_flags) {
 #if !SZL_LAB
     return 2;   // the product library holds one form of the full search: k_match4
 #endif
-    const int which = knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT);
+    const int which = SZL_LABKNOB("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT);
     if (which == 5 && (P.fast || P.strategy == 2 || P.max_chain < 4 || hist_flags)) return 2;
     return which;
 }
@@ -77,25 +77,25 @@ static int match_form(const LevelParams &P, bool hist_flags) {
 static int64_t full_search_len(uint64_t emit, int64_t tile_len, int which) {
     if (which == 5) {
         int64_t len = match5_tile();
-        if (knob("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+        if (SZL_LABKNOB("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, SZL_LABKNOB("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
         while (len > 8192 && emit / (uint64_t)len < 128) len >>= 1;     // a small call gets shorter tiles: more workgroups (a tile's sort has a fixed cost: not below 8 Ki)
         return len;
     }
     if (which == 2) {
         int64_t len = match2_tile();
-        if (knob("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
-        const int64_t floor_len = std::max(2048, knob("SZL_TILE_FLOOR", 2048));   // (lab / tools/gfxsim: full-length tiles on a small input — the steady state of a long stream)
+        if (SZL_LABKNOB("SZL_TILE_LEN", 0) >= 1024) len = std::min<int64_t>(len, SZL_LABKNOB("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+        const int64_t floor_len = std::max(2048, SZL_LABKNOB("SZL_TILE_FLOOR", 2048));   // (lab / tools/gfxsim: full-length tiles on a small input — the steady state of a long stream)
         while (len > floor_len && emit / (uint64_t)len < 128) len >>= 1;     // a small call gets shorter tiles (see tile_len)
         return len;
     }
     if (which != 4) return 0;
-    const uint64_t min_stripes = (uint64_t)std::max(1, knob("SZL_STRIPE_MIN", 512));   // (1: tests — long stripes on small inputs)
+    const uint64_t min_stripes = (uint64_t)std::max(1, SZL_LABKNOB("SZL_STRIPE_MIN", 512));   // (1: tests — long stripes on small inputs)
     if (tile_len < B_TILE && min_stripes > 1) return 0;
-    int64_t len = (int64_t)std::max(16, knob("SZL_STRIPE_KIB", 256)) << 10;
+    int64_t len = (int64_t)std::max(16, SZL_LABKNOB("SZL_STRIPE_KIB", 256)) << 10;
     while (len > B_TILE && emit / (uint64_t)len < min_stripes) len >>= 1;
     return len;
 }
-static bool use_match3(const LevelParams &P) { return SZL_LAB && knob("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
+static bool use_match3(const LevelParams &P) { return SZL_LAB && SZL_LABKNOB("SZL_MATCH_KERNEL", SZL_MATCH_KERNEL_DEFAULT) == 3 && P.max_chain >= 4 && P.max_chain <= 128 && P.strategy != 2; }
 void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
                             hipStream_t st);
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
@@ -336,7 +336,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     // Stage C walks each range serially (one lane per range): a small call gets shorter ranges, i.e. more lanes and shorter
     // walks — the latency of ONE 64 KiB entry through the streaming object is dominated by that walk otherwise (2.1 of 3.2 ms)
     uint32_t range_len = C_RANGE;
-    if (knob("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)knob("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
+    if (SZL_LABKNOB("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)SZL_LABKNOB("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
     else while (range_len > 256 && total_emit / range_len < 65536) range_len >>= 1;   // (≈64 Ki ranges fill the device: 256 CUs x 64 lanes x a few waves)
     // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
     bool m3 = !P.fast && use_match3(P);
@@ -346,7 +346,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         m3 = false;
     } else for (auto &s : segs) { s.sw_cnt = 0; s.sw_pos = nullptr; s.sw_P = nullptr; }
     int64_t tile_len = m3 ? match3_tile() : B_TILE;
-    if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+    if (SZL_LABKNOB("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, SZL_LABKNOB("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
     while (tile_len > 2048 && total_emit / (uint64_t)tile_len < 128) tile_len >>= 1;
     const bool hist_flags = !P.fast && !fast_hist_in.empty() && nseg == 1 && segs[0].seg_start > 0;
     const int form = match_form(P, hist_flags);
@@ -487,7 +487,11 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
     HIPCHK(hipMemsetAsync(blk_counts.p, 0, (nseg + 2) * 4, st));
     // checksums (also seeds so[].adler32 / crc32 with the running values when not requested)
+#if SZL_LAB
     static const bool ck_overlap = !(getenv("SZL_CK_OVERLAP") && atoi(getenv("SZL_CK_OVERLAP")) == 0);
+#else
+    const bool ck_overlap = true;
+#endif
     const bool forked = want_ck && ck_overlap;
     if (forked) {
         if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -546,14 +550,23 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     // full search wins everywhere, by 1.3x (logs) to 5x (four-symbol text) — k_match4 is 1.5x the search the 0.25 threshold was set
     // against — so the default is the full search, without the pilot (0.75 ms of the 1 GiB pass; config 5, 1 GiB of logs at level 9,
     // 261 -> 190 ms).  The on-demand form and the pilot stay behind SZL_MATCH_MODE = 1 / 2 and the tests that force them.
+    // Round 5: the product library holds ONE form of stage B; the on-demand form (k_match_lazy) and its pilot live in the laboratory library.
+#if SZL_LAB
     static const int match_mode_env = getenv("SZL_MATCH_MODE") ? atoi(getenv("SZL_MATCH_MODE")) : 0; // 0 full, 1 on demand, 2 pilot
     const int match_mode = has_switch ? 0 : (match_mode_override >= 0 ? match_mode_override : match_mode_env);
+#else
+    const int match_mode = 0;
+#endif
+#if SZL_LAB
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25; // break-even was 0.36-0.40 against k_match; the full search is 1.4-1.55x faster now
+#else
+    const double lazy_max_frac = 0.25;
+#endif
     last_pilot_frac = -1.0;
     bool b_event = false; // ev[7]: start of the stage-B search proper (after the pilot)
     // (the pilot is one on-demand walk of a tile sample, ~0.5 ms whatever the input: more than the whole search of a few MiB — calls of
     // 256 KiB-1 MiB spent 0.46-0.56 ms in it and 0.1-0.15 ms in the search it was to speed up)
-    const bool pilot_worth = total_emit >= ((uint64_t)std::max(1, knob("SZL_PILOT_MIN_MIB", 8)) << 20) && ntiles >= 64;
+    const bool pilot_worth = total_emit >= ((uint64_t)std::max(1, SZL_LABKNOB("SZL_PILOT_MIN_MIB", 8)) << 20) && ntiles >= 64;
     if (match_mode == 1 || (match_mode == 2 && pilot_worth)) {
         if (match_mode == 2) { // the pilot's own entries are overwritten by whichever form runs afterwards
             const uint64_t step = ntiles >= 16384 ? 256 : (ntiles >= 4096 ? 128 : (ntiles >= 1024 ? 64 : 8)); // >= 64 sampled tiles
@@ -802,8 +815,16 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(max_ranges + 1), st));
     if ((rc = cubtmp.ensure(cub_bytes + 256))) return rc;
 
-    const int match_mode = match_mode_override >= 0 ? match_mode_override : knob("SZL_MATCH_MODE", 0);
+#if SZL_LAB
+    const int match_mode = match_mode_override >= 0 ? match_mode_override : SZL_LABKNOB("SZL_MATCH_MODE", 0);
+#else
+    const int match_mode = 0;      // (the product library holds one form of stage B)
+#endif
+#if SZL_LAB
     static const double lazy_max_frac = getenv("SZL_LAZY_FRAC") ? atof(getenv("SZL_LAZY_FRAC")) : 0.25;
+#else
+    const double lazy_max_frac = 0.25;
+#endif
     const bool emit_copy = emit_copy_enabled();
     bool lazy = match_mode == 1;
     last_pilot_frac = -1.0;
@@ -842,7 +863,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         for (int64_t a = lo; a < hi; a += (int64_t)span_len) spans.push_back(SpanDev{1, 0, a, std::min<int64_t>(a + (int64_t)span_len, hi)});
         const bool m3 = use_match3(P);
         int64_t tile_len = m3 ? match3_tile() : B_TILE;
-        if (knob("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, knob("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
+        if (SZL_LABKNOB("SZL_TILE_LEN", 0) >= 1024) tile_len = std::min<int64_t>(tile_len, SZL_LABKNOB("SZL_TILE_LEN", 0) / 64 * 64);   // (lab)
         for (int64_t a = e; a < wend; a += tile_len) tiles.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(tile_len, wend - a), 0});
         const uint64_t ntiles = tiles.size();
         std::vector<TileDev> stripes;

@@ -13,6 +13,15 @@
 #pragma once
 #include <stdint.h>
 
+namespace szl { int knob(const char *name, int dflt); }
+// A tuning value whose sweep is over (DESIGN_HISTORY.md names the logs): the product library compiles the measured best in, the laboratory
+// library (-DSZL_LAB=1, libszl_amd_lab.so: tools/gpu_matchlab.py, tests/test_gpu_stage_b_forms.py) still reads the knob.
+#if SZL_LAB
+#define SZL_LABKNOB(name, dflt) (szl::knob(name, dflt))
+#else
+#define SZL_LABKNOB(name, dflt) (dflt)
+#endif
+
 namespace szl {
 
 enum : int { WSIZE = 32768, MAX_DIST = 32506, MAX_MATCH = 258, MIN_MATCH = 3, TOO_FAR = 4096, BLOCK_TOKENS = 16384,

@@ -867,7 +867,11 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
 
 // one_shot: every job starts at outpos 0, has no saved window / dictionary and owns one contiguous output region
 void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *states, uint32_t njobs, bool one_shot, hipStream_t st) {
+#if SZL_LAB
     static const bool allow_short = !(getenv("SZL_INF_SHORT") && atoi(getenv("SZL_INF_SHORT")) == 0);
+#else
+    const bool allow_short = true;
+#endif
     if (!njobs) return;
     if (one_shot && allow_short) hipLaunchKernelGGL((k_inflate<true, 0>), dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);
     else hipLaunchKernelGGL((k_inflate<false, 0>), dim3(njobs), dim3(64), 0, st, in, out, jobs, states, njobs);

@@ -740,6 +740,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match(const uint8_t *__restrict__
 #endif
 
 // ============================================================================================
+#if SZL_LAB   // (laboratory library only: the on-demand form of stage B — measured slower than the full search on every data class, profiles/r03/forms_by_class.log)
 // Stage B, on-demand form: k_match_lazy.
 // The parse of stage C only ever reads M2/Mq at the positions it visits — a clean iteration, or the lazy look at the
 // position after a match start; everything inside an emitted match is skipped (C/DeflaterEngine.cs:802-828).  On
@@ -1025,6 +1026,7 @@ __global__ __launch_bounds__(B_THREADS) void k_match_lazy(const uint8_t *__restr
         if (lane == 0) atomicAdd(dbg + 6, n_eval);
     }
 }
+#endif   // SZL_LAB
 
 // hflags (optional, single streaming segment): bit q = buffer position q of the history was inserted into the hash chains
 static std::atomic<int> g_links3_distrusted{0};   // the guard caught k_links3 storing a wrong link: this process uses k_links2 from then on
@@ -1092,13 +1094,13 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
 #else
     // SZL_MATCH_KERNEL (lab library): 5 = bucket order and 4 = ring-fed engine (own launches: the engine calls them), 3 = chain compression
     // (szl_kernels_match3.hip, the engine passes the four-byte links in mtab), 2 = k_match4 (default), 1 = k_match below
-    const int which = knob("SZL_MATCH_KERNEL", 2);
+    const int which = SZL_LABKNOB("SZL_MATCH_KERNEL", 2);
     if (mtab.link4) return launch_match3(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // the engine set the call up for k_match6
     if (which >= 2) return launch_match2(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
-    const int fth = knob("SZL_FTH", 16), vth = knob("SZL_VTH", 20);
+    const int fth = SZL_LABKNOB("SZL_FTH", 16), vth = SZL_LABKNOB("SZL_VTH", 20);
     if (lds_attr_needed(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1115,8 +1117,13 @@ hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *ti
 }
 
 // On-demand stage B over the tiles tile_first, tile_first + tile_step, ... (count of them = nblocks).
+
 hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int nblocks, int tile_first, int tile_step,
                              const uint16_t *link, MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
+#if !SZL_LAB
+    (void)in; (void)segs; (void)tiles; (void)nblocks; (void)tile_first; (void)tile_step;
+    return hipErrorNotSupported;          // (never reached: the product's engine does not select this form)
+#else
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     static const int fth = getenv("SZL_LAZY_FTH") ? atoi(getenv("SZL_LAZY_FTH")) : 4, vth = getenv("SZL_VTH") ? atoi(getenv("SZL_VTH")) : 20;
@@ -1140,6 +1147,7 @@ hipError_t launch_match_lazy(const uint8_t *in, const SegDev *segs, const TileDe
         else hipLaunchKernelGGL((k_match_lazy<16, false>), dim3(nblocks), dim3(B_THREADS), lds, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, tile_first, tile_step);
     }
     return hipGetLastError();
+#endif
 }
 
 } // namespace szl

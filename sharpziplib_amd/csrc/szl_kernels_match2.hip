@@ -56,6 +56,8 @@ enum : int { B2_DATA_BYTES = B_HIST + B2_TILE + B_TAIL + 8, B2_LINKS = B_HIST + 
 enum : int { B2_LDS_BYTES = B2_DATA_BYTES + B2_LINKS * 2 + 32 };   // (+ the tile counter and, in the debug build, two time stamps)
 static_assert(B2_LDS_BYTES <= 160 * 1024 && B2_DATA_BYTES % 16 == 0 && B2_TILE % 64 == 0, "the window must fit the CU's LDS");
 
+#if SZL_LAB   // (laboratory library only from here to launch_match2: k_match4 — stage B's engine of rounds 2-3, superseded by k_match9 — and the ring k_match8.
+              // Round 5 took k_match4 out of the product library: the only form of the full search that ships is k_match9, szl_kernels_match9.hip)
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
 // ---- the hand-written engine ---------------------------------------------------------------------------------------------
@@ -342,7 +344,6 @@ __device__ __forceinline__ void b2_stage_window(uint32_t *sdata32, uint16_t *sli
 
 #include "szl_match4_body.inc"
 
-#if SZL_LAB   // (lab library only)
 // ---- k_match8: the same engine fed from a RING ----------------------------------------------------------------------------------
 // A tile costs k_match4 ~67 us beyond its walks (profiles/r02/lab_s46_tile_length.log: 52.5 / 69.8 / 101.7 ms per GiB with 16 / 8 / 4 Ki
 // tiles): it stages 48 Ki positions to search 16 Ki, and it ends with the workgroup waiting for its longest walks with most lanes
@@ -663,25 +664,30 @@ __global__ __launch_bounds__(B2_THREADS) void k_match8(const uint8_t *__restrict
 
 #endif   // SZL_LAB
 
+#if SZL_LAB
 static bool lds_attr_needed2(std::atomic<uint64_t> &mask, uint64_t &bit) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     bit = 1ull << (dev & 63);
     return (mask.load(std::memory_order_acquire) & bit) == 0;
 }
+#endif
 
 hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab, LevelParams P,
                          unsigned long long *dbg, hipStream_t st);
 
 hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link,
                          MTab mtab, LevelParams P, unsigned long long *dbg, hipStream_t st) {
-    // SZL_B9: the all-assembly engine of szl_kernels_match9.hip (same tiles, same tables); 0 = k_match4 below
-    if (knob("SZL_B9", SZL_B9_DEFAULT) != 0) return launch_match9(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
+#if !SZL_LAB
+    return launch_match9(in, segs, tiles, ntiles, link, mtab, P, dbg, st);   // the all-assembly engine of szl_kernels_match9.hip
+#else
+    // SZL_B9 (laboratory): 1 = k_match9 (same tiles, same tables); 0 = k_match4
+    if (SZL_LABKNOB("SZL_B9", SZL_B9_DEFAULT) != 0) return launch_match9(in, segs, tiles, ntiles, link, mtab, P, dbg, st);
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
     // thresholds count CONTEXTS (two per lane, 128 per wavefront)
-    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2); // swept: profiles/r02/lab_s6_k_match4_sweep.log, lab_s15_two_byte_filter.log, lab_s37_slice_and_thresholds.log
+    int fth = SZL_LABKNOB("SZL_FTH2", 32), vth = SZL_LABKNOB("SZL_VTH2", 2), qkeep = SZL_LABKNOB("SZL_QKEEP", 64), vkeep = SZL_LABKNOB("SZL_VKEEP", 2); // swept: profiles/r02/lab_s6_k_match4_sweep.log, lab_s15_two_byte_filter.log, lab_s37_slice_and_thresholds.log
     auto attr = [&](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); };
     if (lds_attr_needed2(attr_mask, attr_bit)) {
         hipError_t e = attr((const void *)k_match4<false>);
@@ -689,14 +695,14 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
-    if (want_dbg && knob("SZL_B_EXP", 0) == 1) fth = -1;      // lab: stage-only timing experiment (results are garbage)
+    if (want_dbg && SZL_LABKNOB("SZL_B_EXP", 0) == 1) fth = -1;      // lab: stage-only timing experiment (results are garbage)
     else if (fth < 1) fth = 1;
     if (fth > 128) fth = 128;
-    if (knob("SZL_B_CHAIN", 0) > 0) P.max_chain = knob("SZL_B_CHAIN", 0); // lab: shorter chains (results differ from the reference)
+    if (SZL_LABKNOB("SZL_B_CHAIN", 0) > 0) P.max_chain = SZL_LABKNOB("SZL_B_CHAIN", 0); // lab: shorter chains (results differ from the reference)
     if (vth < 1) vth = 1;
     if (qkeep < 1) qkeep = 1;
     if (vkeep < 1) vkeep = 1;
-    int slice = knob("SZL_SLICE", 128);   // tile positions a wavefront takes from the tile counter at a time (512: 63.5, 128: 61.6 ms per GiB — a shorter tail per tile)
+    int slice = SZL_LABKNOB("SZL_SLICE", 128);   // tile positions a wavefront takes from the tile counter at a time (512: 63.5, 128: 61.6 ms per GiB — a shorter tail per tile)
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B2_THREADS);
@@ -704,6 +710,7 @@ hipError_t launch_match2(const uint8_t *in, const SegDev *segs, const TileDev *t
         else hipLaunchKernelGGL((k_match4<false>), g, b, B2_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, vkeep, slice);
     }
     return hipGetLastError();
+#endif
 }
 
 #if SZL_LAB
@@ -712,7 +719,7 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
                              unsigned long long *dbg, hipStream_t st) {
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
-    int fth = knob("SZL_FTH2", 32), vth = knob("SZL_VTH2", 2), qkeep = knob("SZL_QKEEP", 64), vkeep = knob("SZL_VKEEP", 2), slice = knob("SZL_SLICE", 128);
+    int fth = SZL_LABKNOB("SZL_FTH2", 32), vth = SZL_LABKNOB("SZL_VTH2", 2), qkeep = SZL_LABKNOB("SZL_QKEEP", 64), vkeep = SZL_LABKNOB("SZL_VKEEP", 2), slice = SZL_LABKNOB("SZL_SLICE", 128);
     if (lds_attr_needed2(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match8, hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -720,7 +727,7 @@ hipError_t launch_match_ring(const uint8_t *in, const SegDev *segs, const TileDe
     }
     fth = fth < 1 ? 1 : (fth > 128 ? 128 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; vkeep = vkeep < 1 ? 1 : vkeep;
     slice = slice < 64 ? 64 : (slice > 1024 ? 1024 : slice);
-    int lowwater = knob("SZL_LOWWATER", 6144);
+    int lowwater = SZL_LABKNOB("SZL_LOWWATER", 6144);
     lowwater = lowwater < 512 ? 512 : (lowwater > 16384 ? 16384 : lowwater);
     // (fewer than 16 waves per workgroup — the timing model's suggestion, DESIGN §8 of round 2 — measured: 12 / 10 / 8 / 6 waves take 57.6 / 62.3 /
     // 68.3 / 84.2 ms per GiB against 54.9 with 16, profiles/r03/lab_r3a_ring_waves_256.log; the variant was removed)

@@ -538,7 +538,7 @@ int match3_tile() { return B6_TILE; }
 void launch_links4(const uint8_t *in, const uint16_t *link, int64_t lo, int64_t hi, int64_t n_end, uint16_t *link4, uint8_t *skip4, uint16_t *e3d,
                    uint8_t *e3h, hipStream_t st) {
     if (hi <= lo) return;
-    if (knob("SZL_LINKS4", 1) == 0) {   // (lab) the walk out of global memory: 90 ms per GiB on text
+    if (SZL_LABKNOB("SZL_LINKS4", 1) == 0) {   // (lab) the walk out of global memory: 90 ms per GiB on text
         hipLaunchKernelGGL(k_links4, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, in, link, lo, hi, n_end, link4, skip4, e3d, e3h);
         return;
     }
@@ -548,7 +548,7 @@ void launch_links4(const uint8_t *in, const uint16_t *link, int64_t lo, int64_t 
         if (hipFuncSetAttribute((const void *)k_links4t, hipFuncAttributeMaxDynamicSharedMemorySize, L4_LDS_BYTES) != hipSuccess) return;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
-    int refill = knob("SZL_L4_REFILL", 16);
+    int refill = SZL_LABKNOB("SZL_L4_REFILL", 16);
     refill = refill < 1 ? 1 : (refill > 64 ? 64 : refill);
     hipLaunchKernelGGL(k_links4t, dim3((unsigned)((hi - lo + L4_TILE - 1) / L4_TILE)), dim3(L4_THREADS), L4_LDS_BYTES, st, in, link, lo, hi, n_end, link4, skip4,
                        e3d, e3h, refill);
@@ -559,7 +559,7 @@ hipError_t launch_match3(const uint8_t *in, const SegDev *segs, const TileDev *t
     static std::atomic<uint64_t> attr_mask{0};
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
-    int fth = knob("SZL_FTH6", 32), vth = knob("SZL_VTH6", 2), qkeep = knob("SZL_QKEEP6", 64), vkeep = knob("SZL_VKEEP6", 2), slice = knob("SZL_SLICE6", 128);
+    int fth = SZL_LABKNOB("SZL_FTH6", 32), vth = SZL_LABKNOB("SZL_VTH6", 2), qkeep = SZL_LABKNOB("SZL_QKEEP6", 64), vkeep = SZL_LABKNOB("SZL_VKEEP6", 2), slice = SZL_LABKNOB("SZL_SLICE6", 128);
     if (lds_attr_needed3(attr_mask, attr_bit)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_match6<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B6_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match6<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B6_LDS_BYTES);

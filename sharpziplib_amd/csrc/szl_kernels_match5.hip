@@ -664,8 +664,8 @@ hipError_t launch_match5(const uint8_t *in, uint64_t in_total, const SegDev *seg
     hipError_t e = hipMemsetAsync(counter, 0, 4, st);
     if (e != hipSuccess) return e;
     const int grid = ntiles < nslots ? ntiles : nslots;
-    if (knob("SZL_DEBUG", 0)) hipLaunchKernelGGL((k_match5<true>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg, knob("SZL_B5_LAB", 0));
-    else hipLaunchKernelGGL((k_match5<false>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg, knob("SZL_B5_LAB", 0));
+    if (knob("SZL_DEBUG", 0)) hipLaunchKernelGGL((k_match5<true>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg, SZL_LABKNOB("SZL_B5_LAB", 0));
+    else hipLaunchKernelGGL((k_match5<false>), dim3(grid), dim3(B5_THREADS), B5_LDS_BYTES, st, in, in_total, segs, bnds, tiles, ntiles, mtab, P, scratch, counter, dbg, SZL_LABKNOB("SZL_B5_LAB", 0));
     return hipGetLastError();
 }
 

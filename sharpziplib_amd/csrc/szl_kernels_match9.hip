@@ -181,12 +181,12 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     uint64_t attr_bit = 0;
     const bool want_dbg = knob("SZL_DEBUG", 0) != 0;
     // thresholds (tools/sim_match9.py counts instructions per position for any of them on the CPU)
-    int fth = knob("SZL9_FTH", 16), vth = knob("SZL9_VTH", 2), qkeep = knob("SZL9_QKEEP", 64), ktail = knob("SZL9_KTAIL", 2), vtht = knob("SZL9_VTHT", 1);
+    int fth = SZL_LABKNOB("SZL9_FTH", 16), vth = SZL_LABKNOB("SZL9_VTH", 2), qkeep = SZL_LABKNOB("SZL9_QKEEP", 64), ktail = SZL_LABKNOB("SZL9_KTAIL", 2), vtht = SZL_LABKNOB("SZL9_VTHT", 1);
     // the tail program (szl_match9_asm.h): 0 = the main loop to the end (laboratory); walks of both contexts move into one once they are
     // at most `mth` (<= 64; -1: never); iterations of the one-context walk between two looks at who left
-    int tailp = knob("SZL9_TAILP", 1), mth = knob("SZL9_MTH", 64), ktail1 = knob("SZL9_KTAIL1", 1), vtht1 = knob("SZL9_VTHT1", 1);
+    int tailp = SZL_LABKNOB("SZL9_TAILP", 1), mth = SZL_LABKNOB("SZL9_MTH", 64), ktail1 = SZL_LABKNOB("SZL9_KTAIL1", 1), vtht1 = SZL_LABKNOB("SZL9_VTHT1", 1);
     mth = mth > 64 ? 64 : mth; ktail1 = ktail1 < 1 ? 1 : ktail1; vtht1 = vtht1 < 1 ? 1 : vtht1;
-    int slice = knob("SZL_SLICE", 128);
+    int slice = SZL_LABKNOB("SZL_SLICE", 128);
     fth = fth < 1 ? 1 : (fth > 64 ? 64 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; ktail = ktail < 1 ? 1 : ktail; vtht = vtht < 1 ? 1 : vtht;
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
     if (lds_attr_needed9(attr_mask, attr_bit)) {

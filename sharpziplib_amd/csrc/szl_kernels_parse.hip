@@ -200,6 +200,7 @@ __device__ __forceinline__ ParseCtx make_ctx(const uint8_t *in, const uint16_t *
 }
 
 // C1: speculative walk of each range from a clean state at its first position.
+#if SZL_LAB   // (laboratory library only)
 __global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                               uint32_t nseg, uint64_t nranges, LevelParams P, RangeDev *ranges,
                                               uint32_t *visited, unsigned long long *counters) {
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void k_spec(const uint8_t *in, const uint16_t 
     rd.exit_spec = x; rd.exit_true = x; rd.entry = rs; rd.spec_count = count; rd.true_count = count; rd.merged = 1; rd.pad = 0;
     ranges[r] = rd;
 }
+#endif   // SZL_LAB
 
 __device__ __forceinline__ bool is_visited(const uint32_t *vis /* segment bitmap */, uint64_t i) { return (vis[i >> 5] >> (i & 31)) & 1u; }
 
@@ -576,6 +578,7 @@ __global__ void k_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *
 }
 
 // C5: replay the true path of each range and write its tokens; record block edges.
+#if SZL_LAB   // (laboratory library only)
 __global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs,
                                               uint32_t nseg, uint64_t nranges, LevelParams P, const RangeDev *ranges,
                                               const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t *in, const uint16_t 
     }
     (void)counters;
 }
+#endif   // SZL_LAB
 
 // ============================================================================================
 // Windowed variants of C1 / C5.  The per-lane walks above touch 4 bytes of a cache line per step and
@@ -905,8 +909,12 @@ int knob(const char *name, int dflt);
 static int cwin_mode() {
     // (measured again in round 3, after the match tables were packed: 32 positions of window per lane — 1 GiB: parse 6.7 -> 5.8 ms, a
     // 64 KiB call 0.38 -> 0.34 ms; 64 is better still for small calls and worse for large ones)
+#if SZL_LAB
     static const int m = getenv("SZL_CWIN") ? atoi(getenv("SZL_CWIN")) : 32;
     return m;
+#else
+    return 32;    // (round 5: the other window lengths, the per-lane global walks k_spec / k_emit and the second-walk emit live in the laboratory library)
+#endif
 }
 
 void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg,
@@ -915,16 +923,20 @@ void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDe
     if (nranges == 0) return;
     const int cw = cwin_mode();
     const dim3 wg((unsigned)((nranges + 63) / 64));
+#if SZL_LAB
     if (cw == 64) { hipLaunchKernelGGL(k_spec_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+#endif
 #if SZL_LAB   // (laboratory library only: one more instantiation in this unit changes the inliner's decisions for the kernels next to it —
               // compared instruction by instruction against the build the device has verified; the product's code stays what it was)
-    if (cw == 32 && knob("SZL_SPEC_WB", 0) != 0) { hipLaunchKernelGGL((k_spec_win<32, true>), wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+    if (cw == 32 && SZL_LABKNOB("SZL_SPEC_WB", 0) != 0) { hipLaunchKernelGGL((k_spec_win<32, true>), wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
 #endif
     if (cw == 32) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+#if SZL_LAB
     if (cw == 16) { hipLaunchKernelGGL(k_spec_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
     if (cw == 8) { hipLaunchKernelGGL(k_spec_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
     hipLaunchKernelGGL(k_spec, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, visited, counters);
+#endif
 }
 void launch_fix(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                 LevelParams P, RangeDev *ranges, const uint32_t *visited, unsigned long long *counters, uint32_t *bad_slot,
@@ -971,8 +983,12 @@ void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_
     hipLaunchKernelGGL(k_seg_tokens, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, range_tok, so, blk_counts);
 }
 bool emit_copy_enabled() {
+#if SZL_LAB
     static const bool on = cwin_mode() != 0 && !(getenv("SZL_EMIT_COPY") && atoi(getenv("SZL_EMIT_COPY")) == 0);
     return on;
+#else
+    return true;
+#endif
 }
 void launch_emit_copy(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                       LevelParams P, const RangeDev *ranges, const uint32_t *visited, const uint32_t *spec_tok,
@@ -986,6 +1002,7 @@ void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDe
                  LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
                  const uint64_t *blk_off, int64_t *blk_start_pos, int64_t *blk_lasttok_pos, unsigned long long *counters,
                  hipStream_t st) {
+#if SZL_LAB
     if (nranges == 0) return;
     const int cw = cwin_mode();
     const dim3 wg((unsigned)((nranges + 63) / 64));
@@ -995,6 +1012,10 @@ void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDe
     if (cw == 8) { hipLaunchKernelGGL(k_emit_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos); return; }
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, in, link, mtab, segs, nseg, nranges, P,
                        ranges, range_tok, so, tokens, blk_off, blk_start_pos, blk_lasttok_pos, counters);
+#else
+    (void)in; (void)link; (void)mtab; (void)segs; (void)nseg; (void)nranges; (void)P; (void)ranges; (void)range_tok; (void)so; (void)tokens; (void)blk_off;
+    (void)blk_start_pos; (void)blk_lasttok_pos; (void)counters; (void)st;   // (never reached: emit_copy_enabled() is true in the product library)
+#endif
 }
 
 

@@ -40,3 +40,16 @@ def pytest_sessionfinish(session, exitstatus):
         T.stop_all()
     except Exception:
         pass
+
+
+@pytest.fixture()
+def lab_eng(monkeypatch):
+    """An Engine on the LABORATORY library (libszl_amd_lab.so): the forms round 5 took out of the product library — the on-demand form of
+    stage B and its pilot, k_match4, the second-walk emit — stay bit-exact there (tests/test_gpu_stage_b_forms.py has the other lab forms)."""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    monkeypatch.setattr(_lib, "_lib", _lib.lab_lib())
+    e = Engine()
+    yield e
+    e.debug_match_mode(-1)
+    e.close()

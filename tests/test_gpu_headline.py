@@ -47,7 +47,7 @@ def _one_stream(eng, data, level, flags_crc=True):
     arr, in_total, out_total = Engine.layout([data.size])
     hout = np.zeros(out_total + 8, np.uint8)
     flags = _lib.F_NOWRAP | (_lib.F_CRC32 if flags_crc else 0)
-    _lib.check(_lib.lib().szl_deflate_batch_host(eng._h, data.ctypes.data, hout.ctypes.data, arr, 1, level, 0, flags), "batch")
+    _lib.check(eng._L.szl_deflate_batch_host(eng._h, data.ctypes.data, hout.ctypes.data, arr, 1, level, 0, flags), "batch")   # (the library the engine was made by)
     assert arr[0].status == 0
     return hout[:arr[0].out_len], int(arr[0].crc32)
 
@@ -65,22 +65,19 @@ def test_config2_1gib_level6_bit_exact(eng):
     assert tm["tokens"] > 0 and tm["blocks"] >= tm["tokens"] // 16384
 
 
-def test_config5_512mib_level9_logs_bit_exact(eng):
-    """configs[4] at 1/8 size: level 9 (max_chain 4096) on repetitive logs, with the stage-B form the pilot selects."""
+def test_config5_512mib_level9_logs_bit_exact(eng, lab_eng):
+    """configs[4] at 1/8 size: level 9 (max_chain 4096) on repetitive logs — the product library's one form of stage B, and the
+    on-demand form (laboratory library) on the same stream: results must not depend on the form."""
     c, data = _case_input("cfg5_logs_512m_l9")
-    eng.debug_match_mode(-1)                      # library default: the pilot decides
     got, crc = _one_stream(eng, data, c["level"])
-    used_on_demand = eng.debug_match_mode()
+    assert not eng.debug_match_mode()             # (the product library holds the full search only)
     assert got.size == c["out_len"]
     assert hashlib.sha256(got.tobytes()).hexdigest() == c["out_sha256"]
     assert crc == c["crc32"]
     assert got.tobytes() == O.deflate(data, c["level"])
-    # and the other form of stage B on the same stream (results must not depend on the form)
-    eng.debug_match_mode(0 if used_on_demand else 1)
-    try:
-        got2, _ = _one_stream(eng, data, c["level"])
-    finally:
-        eng.debug_match_mode(-1)
+    lab_eng.debug_match_mode(1)
+    got2, _ = _one_stream(lab_eng, data, c["level"])
+    assert lab_eng.debug_match_mode()
     assert hashlib.sha256(got2.tobytes()).hexdigest() == c["out_sha256"]
 
 

@@ -51,9 +51,13 @@ def test_windowed_stream_is_bit_exact(small_windows, name, kib, level):
     assert ws_small < 16 * data.size          # side arrays follow the window, not the stream (an unwindowed call holds ~19 B per byte)
 
 
-def test_both_forms_of_stage_b_and_zlib_framing(small_windows):
+def test_both_forms_of_stage_b_and_zlib_framing(monkeypatch):
+    from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
-    small_windows(96)
+    L = _lib.lab_lib()                                   # (the on-demand form lives in the laboratory library since round 5)
+    monkeypatch.setattr(_lib, "_lib", L)
+    L.szl_debug_set(b"SZL_WINDOW_KIB", 96)
+    L.szl_debug_set(b"SZL_WINDOW_FROM_KIB", 0)
     data = C.generate("logs", 7, 0, 2500000)
     eng = Engine()
     try:
@@ -66,6 +70,8 @@ def test_both_forms_of_stage_b_and_zlib_framing(small_windows):
         assert r.data == O.deflate(data, 6, flush=True)
     finally:
         eng.close()
+        L.szl_debug_set(b"SZL_WINDOW_KIB", -2147483648)
+        L.szl_debug_set(b"SZL_WINDOW_FROM_KIB", -2147483648)
 
 
 def test_streaming_deflater_with_history_goes_through_windows(small_windows):

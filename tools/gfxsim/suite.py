@@ -225,7 +225,7 @@ FORGET = -2147483648
 
 def suite_forms():
     """the forms the defaults do not take at small sizes: the window pipeline of long streams (64 KiB windows), stage B's other
-    forms (k_match4, the on-demand walk), stage A's bucketed form (k_links2), ranges that never merge (zeros / periodic data)"""
+    form kept in the product library — stage A's bucketed form k_links2, the fallback of the ticket form —, ranges that never merge (zeros / periodic data)"""
     import oracle_ffi as O
     from sharpziplib_amd.batch import Engine
     from sharpziplib_amd import corpus as C
@@ -242,12 +242,10 @@ def suite_forms():
     finally:
         _knobs(SZL_WINDOW_KIB=256 * 1024, SZL_WINDOW_FROM_KIB=2048 * 1024)
     small = C.generate("dickens", 3, 0, 24000)
-    for knobs, levels in ((dict(SZL_B9=0), (6, 9)), (dict(SZL_LINKS=2), (6,)), (dict(SZL_MATCH_MODE=1), (9,))):
+    for knobs, levels in ((dict(SZL_LINKS=2), (6, 9)),):   # (k_match4 and the on-demand walk moved to the laboratory library in round 5: suite lab_forms)
         try:
             _knobs(**knobs)
             e = Engine()
-            if "SZL_MATCH_MODE" in knobs:
-                e.debug_match_mode(1)                      # the on-demand walk (k_match_lazy), forced
             for lv in levels:
                 r = e.deflate([small], level=lv)[0]
                 assert r.status == 0 and r.data == O.deflate(small, lv), (knobs, lv)
@@ -599,7 +597,7 @@ def suite_framing():
 
 def suite_lab_forms():
     """the LABORATORY library (GFXSIM_LAB=1: libszl_amd_lab.so's objects) on the interpreter: stage B's dropped forms — chain compression
-    (SZL_MATCH_KERNEL=3), the ring (4), the bucket-order search (5) — and k_spec_win's four-ranges-per-store write-back (SZL_SPEC_WB=1),
+    (SZL_MATCH_KERNEL=3), the ring (4), the bucket-order search (5), k_match4 (SZL_B9=0), the on-demand walk k_match_lazy — and k_spec_win's four-ranges-per-store write-back (SZL_SPEC_WB=1),
     each against the oracle (tests/test_gpu_stage_b_forms.py's subject, small)"""
     import oracle_ffi as O
     from sharpziplib_amd.batch import Engine
@@ -608,17 +606,20 @@ def suite_lab_forms():
     n = 0
     data = C.generate("dickens", 3, 0, 12000)
     for knobs, levels in ((dict(SZL_MATCH_KERNEL=3), (6,)), (dict(SZL_MATCH_KERNEL=4, SZL_STRIPE_MIN=1, SZL_STRIPE_KIB=64), (9,)),
-                          (dict(SZL_MATCH_KERNEL=5), (6,)), (dict(SZL_SPEC_WB=1), (5, 9))):
+                          (dict(SZL_MATCH_KERNEL=5), (6,)), (dict(SZL_SPEC_WB=1), (5, 9)), (dict(SZL_B9=0), (6, 9)), (dict(SZL_MATCH_MODE=1), (9,)),
+                          (dict(SZL_EMIT_COPY_LAB=0), (6,))):
         try:
-            _knobs(**knobs)
+            _knobs(**{k: v for k, v in knobs.items() if k != "SZL_EMIT_COPY_LAB"})
             e = Engine()
+            if "SZL_MATCH_MODE" in knobs:
+                e.debug_match_mode(1)                      # the on-demand walk (k_match_lazy), forced
             for lv in levels:
                 r = e.deflate([data], level=lv)[0]
                 assert r.status == 0 and r.data == O.deflate(data, lv), (knobs, lv)
                 n += 1
             e.close()
         finally:
-            _knobs(**{k: FORGET for k in knobs})
+            _knobs(**{k: FORGET for k in knobs if k != "SZL_EMIT_COPY_LAB"})
     e = Engine()
     _knobs(SZL_SPEC_WB=1)
     try:
