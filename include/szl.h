@@ -214,6 +214,11 @@ uint64_t szl_engine_debug_workspace(const szl_engine *e);
  * bytes (16 KiB .. SZL_INF_CHUNK_KIB, default 128). */
 uint32_t szl_engine_debug_par_jobs(const szl_engine *e);
 
+/* Parity tap: the code lengths DeflaterHuffman.Tree.BuildTree + BuildLength (C/DeflaterHuffman.cs:196-329, :475-579) give `n` frequency
+ * vectors of `num_symbols` entries each (min_codes / max_length as the three trees have them: 257 / 15, 1 / 15, 4 / 7), as stage D's
+ * wavefront-per-tree build computes them — compared with the oracle on histograms no token stream would produce. */
+int szl_debug_tree_lengths(const int32_t *freqs, int n, int num_symbols, int min_codes, int max_length, uint8_t *lengths_out, int32_t *num_codes_out);
+
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);
 

@@ -294,6 +294,19 @@ static void tree_build_tree(Tree *t) { /* :196 */
     tree_build_length(t, childs, childsLen);
 }
 
+/* test tap: the code lengths DeflaterHuffman.Tree.BuildTree (:196-329) + BuildLength (:475-579) give a frequency vector (the device's
+ * wave-parallel build is checked against this on random histograms, tests/test_gpu_tree_build.py) */
+int szo_tree_lengths(const int16_t *freqs, int nsyms, int minCodes, int maxLen, uint8_t *len_out, int *numCodes_out) {
+    static Tree t;
+    if (nsyms < 1 || nsyms > LITERAL_NUM) return -1;
+    tree_init(&t, nsyms, minCodes, maxLen);
+    memcpy(t.freqs, freqs, sizeof(int16_t) * (size_t)nsyms);
+    tree_build_tree(&t);
+    memcpy(len_out, t.length_own, (size_t)nsyms);
+    if (numCodes_out) *numCodes_out = t.numCodes;
+    return 0;
+}
+
 static int tree_encoded_length(const Tree *t) { /* :331 */
     int len = 0;
     for (int i = 0; i < t->nsyms; i++) len += t->freqs[i] * t->length[i];

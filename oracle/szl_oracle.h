@@ -122,6 +122,7 @@ int64_t szo_inflate_oneshot(const uint8_t *in, size_t n, int no_header, uint8_t 
 /* bench infrastructure (szl_parallel.c): n_slices independent one-shot raw Deflaters on `threads` host threads */
 int64_t szo_deflate_slices_mt(const uint8_t *in, size_t slice_len, int n_slices, int level, int threads, uint64_t *out_lens);
 int szo_quirk_sets_seen(int reset);
+int szo_tree_lengths(const int16_t *freqs, int nsyms, int minCodes, int maxLen, uint8_t *len_out, int *numCodes_out);   /* test tap: Tree.BuildTree + BuildLength */
 /* test hooks: BuildTree's table (returns treeSize or an error) and one GetSymbol with `avail` bits of input left */
 int szo_iht_table(const uint8_t *codeLengths, int n, int16_t *out, int cap);
 int szo_iht_symbol(const int16_t *tree, int treeSize, uint32_t bits, int avail, int *dropped);

@@ -84,6 +84,7 @@ def _load(path):
         "szl_engine_debug_par_jobs": (ctypes.c_uint32, [vp]),
         "szl_inflater_debug_bulk_calls": (ctypes.c_uint32, [vp]), "szl_inflater_debug_times": (i32, [vp, vp]),
         "szl_debug_stored_layout": (i32, [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]),
+        "szl_debug_tree_lengths": (i32, [vp, i32, i32, i32, i32, vp, vp]),
         "szl_inflater_create": (vp, [i32]), "szl_inflater_destroy": (None, [vp]), "szl_inflater_reset": (i32, [vp]),
         "szl_inflater_set_input": (i32, [vp, vp, i32]), "szl_inflater_set_dictionary": (i32, [vp, vp, i32]),
         "szl_inflater_inflate": (i32, [vp, vp, i32]), "szl_inflater_needs_input": (i32, [vp]),

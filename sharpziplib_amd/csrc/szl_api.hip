@@ -540,7 +540,8 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
         const int sd = devices[x.slot];
         int can = 1;
         if (sd != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], sd) != hipSuccess) can = 0;
-        if (sd == devices[0] || can) {
+        if (knob("SZL_PART_HOST_GATHER", 0) != 0) can = 0;     // (tools/gpu_two_device_check.sh: the host-staged form on a box whose devices do reach each other)
+        if ((sd == devices[0] && knob("SZL_PART_HOST_GATHER", 0) == 0) || can) {
             if (hipMemcpyPeerAsync((uint32_t *)nt.p + at, devices[0], x.toks.p, sd, x.ntok * 4, gst) != hipSuccess) return false;
         } else {
             bounce.resize(x.ntok * 4);
@@ -1424,6 +1425,24 @@ static int checksum_host(unsigned want, uint32_t value, const void *data, size_t
     if (C.din.cap > (64u << 20)) C.din.release();        // (do not sit on a large input copy)
     return 0;
 }
+namespace szl { void launch_tree_probe(const int *freqs, int n, int numSymbols, int minCodes, int maxLength, unsigned char *len_out, int *ncodes_out, hipStream_t st); }
+extern "C" int szl_debug_tree_lengths(const int32_t *freqs, int n, int num_symbols, int min_codes, int max_length, uint8_t *lengths_out, int32_t *num_codes_out) {
+    if (!freqs || !lengths_out || !num_codes_out || n < 0 || num_symbols < 1 || num_symbols > LIT_NUM || max_length < 1 || max_length > 15) return SZL_E_ARG;
+    if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return SZL_E_DEVICE; }
+    if (!n) return 0;
+    DevBuf df, dl, dn;
+    int rc = 0;
+    const size_t cells = (size_t)n * (size_t)num_symbols;
+    if ((rc = df.ensure(cells * 4)) || (rc = dl.ensure(cells)) || (rc = dn.ensure((size_t)n * 4))) { df.release(); dl.release(); dn.release(); return rc; }
+    if (hipMemcpy(df.p, freqs, cells * 4, hipMemcpyHostToDevice) != hipSuccess) rc = SZL_E_DEVICE;
+    if (!rc) {
+        launch_tree_probe((const int *)df.p, n, num_symbols, min_codes, max_length, (unsigned char *)dl.p, (int *)dn.p, nullptr);
+        if (hipMemcpy(lengths_out, dl.p, cells, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(num_codes_out, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SZL_E_DEVICE;
+    }
+    df.release(); dl.release(); dn.release();
+    return rc;
+}
+
 // ---- pinned I/O buffers of the device-aware stream classes (include/szl.h) ---------------------------------------------------------
 namespace {
 struct PinnedRange { const uint8_t *p; size_t n; bool ours; };

@@ -481,6 +481,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     HIPCHK(hipStreamWaitEvent(side, ev_zfork, 0));
     launch_zero_regions(dsegs, nseg, (const uint64_t *)d_zoff.p, nzero, d_out, side); // only the streams' own regions (szl.h)
     HIPCHK(hipEventRecord(ev_zjoin, side));
+    // every exit between here and the join in front of stage D3 leaves that kernel in flight on `side`, reading d_zoff / dsegs and writing
+    // the caller's d_out (round-4 ADVICE): an early return waits for it, so that nothing of this call touches memory the caller may free
+    // or the next call re-uploads
+    struct SideJoin { hipStream_t s; bool armed; ~SideJoin() { if (armed && s) (void)hipStreamSynchronize(s); } } side_join{side, true};
     HIPCHK(hipMemsetAsync(visited.p, 0, (vis_words + 4) * 4, st));
     HIPCHK(hipMemsetAsync(counters.p, 0, CNT_WORDS * 8, st));
     HIPCHK(hipMemsetAsync(d_so.p, 0, nseg * sizeof(SegOut), st));
@@ -668,6 +672,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     launch_block_scan(dsegs, nseg, dso, (BlockDesc *)descs.p, st);
     HIPCHK(hipEventRecord(ev[5], st));
     HIPCHK(hipStreamWaitEvent(st, ev_zjoin, 0));
+    side_join.armed = false;
     launch_block_encode(d_in, d_out, dsegs, (const BlockDesc *)descs.p, (const uint32_t *)tokens.p, (uint32_t)blk_slots, st);
     if (forked) HIPCHK(hipStreamWaitEvent(st, ev_join, 0));
     HIPCHK(hipStreamWaitEvent(st, ev_gjoin, 0));

@@ -7,8 +7,9 @@
 //                  C/PendingBuffer.cs:168,:143 are a running bit position)
 //   k_block_encode CompressBlock (:701) / FlushStoredBlock (:766): tokens -> bits at their final position
 //   k_seg_finish   Deflater.Deflate's FLUSHING/FINISHING tails (C/Deflater.cs:486-517)
-// The Huffman construction is sequential by nature (heap with value<<8|depth keys, strict comparisons, forced
-// second symbol, overflow repair in childs[] order); it is restated verbatim and run by one lane per tree.
+// The Huffman construction is a sequence of heap operations whose tie-breaking IS the specification (value<<8|depth keys, strict
+// comparisons, forced second symbol, overflow repair in childs[] order); since round 5 a wavefront evaluates each operation level-
+// parallel and leaves the reference's heap array behind after every one of them (build_tree below).
 #include <hip/hip_runtime.h>
 #include "szl_internal.h"
 
@@ -55,7 +56,26 @@ __global__ void k_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tree construction in LDS by a single lane (verbatim control flow of Tree.BuildTree / BuildLength).
+// Tree construction in LDS by ONE WAVEFRONT per tree (round 5; through round 4 a single lane ran the reference's loops verbatim).
+//
+// Tree.BuildTree (C/DeflaterHuffman.cs:196-329) is a binary heap keyed by value << 8 | depth with strict comparisons; ties are broken
+// by heap POSITION, so the tree — and with equal frequencies the code length of each symbol — can only be reproduced by reproducing
+// the heap array after every operation.  What can be done differently is how ONE operation is evaluated.  The reference's sift
+// (:264-291, :299-323) moves the hole at the root down to a leaf along the smaller children (ties: the left one), then lets the
+// inserted value rise from that leaf while its parent is strictly greater: two dependent LDS round trips per level, 572 sifts per
+// literal tree, 0.37 ms per block on one lane.  Here (tools/heap_model.c checks the form against the reference's on 200 000 random
+// trees with heavy ties, after every sift):
+//   1. the root-to-leaf path of smaller children is read off one "winner" bit per internal node (right child exists and is strictly
+//      smaller) — the bits of nodes 32 L .. 32 L + 31 live in a register of lane L and a step of the path is a v_readlane and three
+//      scalar instructions; lane k notes the path's node at level k;
+//   2. lanes 1 .. m read their node's value and owner, its sibling's value and the value below it, all in ONE LDS round trip;
+//   3. the path's values are non-decreasing downwards, so the inserted value lands at level j = popcount(ballot(value_k <= inserted));
+//      values 1 .. j move up one level (lane k writes its parent's slot), lane j writes the inserted value;
+//   4. the winner bits of levels 0 .. j-1 follow from what the lanes hold (new path child against the sibling).
+// The heap array after a sift is the reference's, operation by operation; the leaf insertion (:205-227), BuildLength's repair of
+// over-long codes (:519-571) and everything around stay the reference's loops on lane 0.  BuildLength's depth walk (:491-510) —
+// "a node's children are one deeper than the node", in reverse creation order — is evaluated for all nodes at once from parent
+// links (the counts it produces do not depend on the order).
 template <int N> // N = number of symbols of the largest tree built in this scratch
 struct TreeScratchT {
     int heap[N];
@@ -63,133 +83,167 @@ struct TreeScratchT {
     short childs[4 * N];
     int values[2 * N];
     unsigned char lengths[2 * N];
+    short parent[2 * N];     // BuildLength: the node a node hangs under
 };
 using TreeScratch = TreeScratchT<LIT_NUM>;       // literal/length tree (286 symbols)
-using TreeScratchSmall = TreeScratchT<DIST_NUM>; // distance tree (30) and code-length tree (19): 0.8 KB instead of 7.4 KB of LDS
+using TreeScratchSmall = TreeScratchT<DIST_NUM>; // distance tree (30) and code-length tree (19)
 
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// one sift: the hole is at the root of heap[0 .. heapLen), (last, lastVal) is inserted.  `w`: this lane's 32 winner bits.
+__device__ __forceinline__ void sift_wave(int *heap, int *hval, int heapLen, int last, int lastVal, uint32_t &w, int lane) {
+    // 1. the path, in scalar registers: node + 1 at level k is the binary number "1 b0 b1 .. b(k-1)" of the winner bits met on the way,
+    //    so the deepest node's number holds the whole path and lane k reads its own node off it with a shift
+    int code = 1, m = 0;                                            // code = node + 1
+    while (2 * code - 1 < heapLen) {                                // (node has a left child: 2 * node + 1 < heapLen)
+        const int n = code - 1;
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w, n >> 5);
+        code = 2 * code + (int)((word >> (n & 31)) & 1u);
+        ++m;
+    }
+    const bool on_path = lane >= 1 && lane <= m;
+    const int mypos = lane <= m ? (code >> (m - lane)) - 1 : 0;     // the path's node at level `lane`
+    const int below = lane < m ? (code >> (m - lane - 1)) - 1 : 0;  // ... and at the level below
+    int v = 0, id = 0, sv = 0, vbelow = 0;
+    bool has_sib = false;
+    if (on_path) {                                                  // 2. one round trip
+        const int sib = (mypos & 1) ? mypos + 1 : mypos - 1;
+        has_sib = sib < heapLen;
+        v = hval[mypos]; id = heap[mypos];
+        if (has_sib) sv = hval[sib];
+        if (lane < m) vbelow = hval[below];
+    }
+    const int j = __popcll(__ballot(on_path && v <= lastVal));      // 3. where the inserted value lands
+    // 4. winner bit of my parent (levels 0 .. j-1 change): its path child now holds the value below me (k < j) or the inserted one (k == j)
+    const int newchild = lane < j ? vbelow : lastVal;
+    const bool bit = (mypos & 1) ? (has_sib && newchild > sv) : (sv > newchild);   // left child = path child : left child = sibling
+    if (on_path && lane <= j) { const int pp = (mypos - 1) >> 1; heap[pp] = id; hval[pp] = v; }
+    if (lane == j) { heap[mypos] = last; hval[mypos] = lastVal; }   // (lane 0 notes level 0: the root)
+    const uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__ballot(bit));   // (lane k's bit belongs to the path's node at level k - 1 — a shift of `code`; the path is at most 9 levels deep)
+    for (int k = 1; k <= j; k++) {
+        const int nd = __builtin_amdgcn_readfirstlane((code >> (m - k + 1)) - 1);
+        const uint32_t b = (bits >> k) & 1u;
+        if (lane == (nd >> 5)) w = (w & ~(1u << (nd & 31))) | (b << (nd & 31));
+    }
+    wave_sync();
+}
+
+// all 64 lanes of ONE wavefront call this with the same arguments; `lane` = lane id
 template <typename SCR>
 __device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, int maxLength, SCR *S,
-                           unsigned char *length /*[numSymbols]*/, int *bl_counts /*[15]*/, int *numCodesOut) {
+                           unsigned char *length /*[numSymbols]*/, int *bl_counts /*[15]*/, int *numCodesOut, int lane) {
     int *heap = S->heap, *hval = S->hval, *values = S->values;
     short *childs = S->childs;
-    int heapLen = 0, maxCode = 0;
-    for (int n = 0; n < numSymbols; n++) {
-        int freq = freqs[n];
-        if (freq != 0) {
-            int pos = heapLen++;
-            int ppos;
-            while (pos > 0 && freqs[heap[ppos = (pos - 1) / 2]] > freq) { heap[pos] = heap[ppos]; pos = ppos; }
-            heap[pos] = n;
-            maxCode = n;
+    int heapLen = 0;
+    if (lane == 0) {                                                // :205-241, the reference's loops
+        int maxCode = 0;
+        for (int n = 0; n < numSymbols; n++) {
+            int freq = freqs[n];
+            if (freq != 0) {
+                int pos = heapLen++;
+                int ppos;
+                while (pos > 0 && freqs[heap[ppos = (pos - 1) / 2]] > freq) { heap[pos] = heap[ppos]; pos = ppos; }
+                heap[pos] = n;
+                maxCode = n;
+            }
         }
+        while (heapLen < 2) {
+            int node = maxCode < 2 ? ++maxCode : 0;
+            heap[heapLen++] = node;
+        }
+        *numCodesOut = (maxCode + 1 > minNumCodes) ? maxCode + 1 : minNumCodes;
     }
-    while (heapLen < 2) {
-        int node = maxCode < 2 ? ++maxCode : 0;
-        heap[heapLen++] = node;
-    }
-    *numCodesOut = (maxCode + 1 > minNumCodes) ? maxCode + 1 : minNumCodes;
+    wave_sync();
+    heapLen = __builtin_amdgcn_readfirstlane(heapLen);
     const int numLeafs = heapLen;
     const int childsLen = 4 * heapLen - 2;
     int numNodes = numLeafs;
-    for (int i = 0; i < heapLen; i++) {
-        int node = heap[i];
+    for (int i = lane; i < heapLen; i += 64) {                       // :243-252
+        const int node = heap[i];
         childs[2 * i] = (short)node;
         childs[2 * i + 1] = -1;
-        int v = freqs[node] << 8;
+        const int v = freqs[node] << 8;
         values[i] = v;
-        heap[i] = i;
         hval[i] = v;
     }
-    do {
-        int first = heap[0];
-        int firstVal = hval[0];
+    wave_sync();
+    for (int i = lane; i < heapLen; i += 64) heap[i] = i;
+    wave_sync();
+    uint32_t w = 0;                                                  // winner bits of nodes 32 * lane ..
+    for (int c = 0; 64 * c < heapLen; c++) {
+        const int nd = 64 * c + lane, l = 2 * nd + 1, r = l + 1;
+        const bool bit = r < heapLen && hval[l] > hval[r];
+        const unsigned long long mask = __ballot(bit);
+        if (lane == 2 * c) w = (uint32_t)mask;
+        if (lane == 2 * c + 1) w = (uint32_t)(mask >> 32);
+    }
+    do {                                                             // :258-327
+        const int first = heap[0], firstVal = hval[0];
         --heapLen;
-        int last = heap[heapLen];
-        int lastVal = hval[heapLen];
-        int ppos = 0, path = 1;
-        while (path < heapLen) {
-            int pv = hval[path];
-            if (path + 1 < heapLen) { int pv1 = hval[path + 1]; if (pv > pv1) { path++; pv = pv1; } }
-            heap[ppos] = heap[path]; hval[ppos] = pv;
-            ppos = path;
-            path = path * 2 + 1;
+        int last = heap[heapLen], lastVal = hval[heapLen];
+        {   // the slot that left the heap: its parent has lost its right child, or its only one
+            const int p = (heapLen - 1) >> 1;
+            if (heapLen > 0 && lane == (p >> 5)) w &= ~(1u << (p & 31));
         }
-        while ((path = ppos) > 0) {
-            ppos = (path - 1) / 2;
-            int pv = hval[ppos];
-            if (!(pv > lastVal)) break;
-            heap[path] = heap[ppos]; hval[path] = pv;
-        }
-        heap[path] = last; hval[path] = lastVal;
-
-        int second = heap[0];
-        int secondVal = hval[0];
+        wave_sync();
+        sift_wave(heap, hval, heapLen, last, lastVal, w, lane);
+        const int second = heap[0], secondVal = hval[0];
         last = numNodes++;
-        childs[2 * last] = (short)first;
-        childs[2 * last + 1] = (short)second;
-        int d1 = firstVal & 0xff, d2 = secondVal & 0xff;
-        int mindepth = d1 < d2 ? d1 : d2;
+        const int d1 = firstVal & 0xff, d2 = secondVal & 0xff;
+        const int mindepth = d1 < d2 ? d1 : d2;
         lastVal = firstVal + secondVal - mindepth + 1;
-        values[last] = lastVal;
-
-        ppos = 0; path = 1;
-        while (path < heapLen) {
-            int pv = hval[path];
-            if (path + 1 < heapLen) { int pv1 = hval[path + 1]; if (pv > pv1) { path++; pv = pv1; } }
-            heap[ppos] = heap[path]; hval[ppos] = pv;
-            ppos = path;
-            path = ppos * 2 + 1;
-        }
-        while ((path = ppos) > 0) {
-            ppos = (path - 1) / 2;
-            int pv = hval[ppos];
-            if (!(pv > lastVal)) break;
-            heap[path] = heap[ppos]; hval[path] = pv;
-        }
-        heap[path] = last; hval[path] = lastVal;
+        if (lane == 0) { childs[2 * last] = (short)first; childs[2 * last + 1] = (short)second; values[last] = lastVal; }
+        wave_sync();
+        sift_wave(heap, hval, heapLen, last, lastVal, w, lane);
     } while (heapLen > 1);
 
     // ---- BuildLength :475
-    for (int i = 0; i < numSymbols; i++) length[i] = 0;
     const int nNodes = childsLen / 2;
-    int overflow = 0;
-    for (int i = 0; i < maxLength; i++) bl_counts[i] = 0;
     unsigned char *lengths = S->lengths;
-    lengths[nNodes - 1] = 0;
-    for (int i = nNodes - 1; i >= 0; i--) {
-        if (childs[2 * i + 1] != -1) {
-            int bitLength = lengths[i] + 1;
-            if (bitLength > maxLength) { bitLength = maxLength; overflow++; }
-            lengths[childs[2 * i]] = lengths[childs[2 * i + 1]] = (unsigned char)bitLength;
-        } else {
-            int bitLength = lengths[i];
-            bl_counts[bitLength - 1]++;
-            length[childs[2 * i]] = (unsigned char)bitLength;
-        }
+    short *parent = S->parent;
+    for (int i = lane; i < numSymbols; i += 64) length[i] = 0;
+    if (lane < maxLength) bl_counts[lane] = 0;
+    for (int i = lane; i < nNodes; i += 64) if (childs[2 * i + 1] != -1) { parent[childs[2 * i]] = (short)i; parent[childs[2 * i + 1]] = (short)i; }
+    if (lane == 0) parent[nNodes - 1] = -1;
+    wave_sync();
+    // depth of every node (:491-510: lengths[child] = min(lengths[node] + 1, maxLength)): walk up the parent links, all nodes at once
+    int overflow = 0;
+    for (int i = lane; i < nNodes; i += 64) {
+        int d = 0;
+        for (int q = parent[i]; q >= 0; q = parent[q]) d++;
+        const int bitLength = d > maxLength ? maxLength : d;
+        lengths[i] = (unsigned char)bitLength;
+        if (childs[2 * i + 1] != -1) { if (d + 1 > maxLength) overflow++; }                       // an inner node whose children are clamped
+        else { atomicAdd(&bl_counts[bitLength - 1], 1); length[childs[2 * i]] = (unsigned char)bitLength; }
     }
+    for (int o = 32; o > 0; o >>= 1) overflow += __shfl_xor(overflow, o);
+    wave_sync();
     if (overflow == 0) return;
-    int incrBitLen = maxLength - 1;
-    do {
-        while (bl_counts[--incrBitLen] == 0) { }
+    if (lane == 0) {                                                 // :519-571, the reference's loops
+        int incrBitLen = maxLength - 1;
         do {
-            bl_counts[incrBitLen]--;
-            bl_counts[++incrBitLen]++;
-            overflow -= 1 << (maxLength - 1 - incrBitLen);
-        } while (overflow > 0 && incrBitLen < maxLength - 1);
-    } while (overflow > 0);
-    bl_counts[maxLength - 1] += overflow;
-    bl_counts[maxLength - 2] -= overflow;
-    int nodePtr = 2 * numLeafs;
-    for (int bits = maxLength; bits != 0; bits--) {
-        int n = bl_counts[bits - 1];
-        while (n > 0) {
-            int childPtr = 2 * childs[nodePtr++];
-            if (childs[childPtr + 1] == -1) {
-                length[childs[childPtr]] = (unsigned char)bits;
-                n--;
+            while (bl_counts[--incrBitLen] == 0) { }
+            do {
+                bl_counts[incrBitLen]--;
+                bl_counts[++incrBitLen]++;
+                overflow -= 1 << (maxLength - 1 - incrBitLen);
+            } while (overflow > 0 && incrBitLen < maxLength - 1);
+        } while (overflow > 0);
+        bl_counts[maxLength - 1] += overflow;
+        bl_counts[maxLength - 2] -= overflow;
+        int nodePtr = 2 * numLeafs;
+        for (int bits = maxLength; bits != 0; bits--) {
+            int n = bl_counts[bits - 1];
+            while (n > 0) {
+                int childPtr = 2 * childs[nodePtr++];
+                if (childs[childPtr + 1] == -1) {
+                    length[childs[childPtr]] = (unsigned char)bits;
+                    n--;
+                }
             }
         }
     }
+    wave_sync();
 }
 
 // CalcBLFreq :349 / WriteTree :411 share this scanner; `emit(sym, extra_val, extra_bits)` is called per bl symbol.
@@ -233,7 +287,7 @@ struct BitW { // LSB-first bit writer into an LDS byte array
 
 __constant__ int c_bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; // :37
 
-enum : int { D_THREADS = 128 }; // the trees are built by single lanes: small workgroups keep more blocks in flight per CU
+enum : int { D_THREADS = 128 }; // two wavefronts: one per tree (literal/length, distance); small workgroups keep more blocks in flight per CU
 
 __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restrict__ segs, uint32_t nseg,
                                                            const SegOut *__restrict__ so, const uint64_t *__restrict__ blk_off,
@@ -291,14 +345,16 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     __syncthreads();
     if (tid == 0) lfreq[256]++; // EOF_SYMBOL :790
     __syncthreads();
-    if (tid == 0) build_tree(lfreq, LIT_NUM, 257, 15, &scrL, llen, lblc, &lnum);
-    if (tid == 64) build_tree(dfreq, DIST_NUM, 1, 15, &scrD, dlen, dblc, &dnum);
+    // the two wavefronts of the workgroup build the two trees side by side, a wavefront per tree (build_tree)
+    if (tid < 64) build_tree(lfreq, LIT_NUM, 257, 15, &scrL, llen, lblc, &lnum, tid);
+    else build_tree(dfreq, DIST_NUM, 1, 15, &scrD, dlen, dblc, &dnum, tid - 64);
     __syncthreads();
     if (tid == 0) {
         scan_code_lengths(llen, lnum, [&](int sym, int, int) { blfreq[sym]++; });
         scan_code_lengths(dlen, dnum, [&](int sym, int, int) { blfreq[sym]++; });
-        build_tree(blfreq, BL_NUM, 4, 7, &scrD, bllen, blblc, &blnum);
     }
+    __syncthreads();
+    if (tid < 64) build_tree(blfreq, BL_NUM, 4, 7, &scrD, bllen, blblc, &blnum, tid);
     __syncthreads();
     // encoded lengths (GetEncodedLength :331) and static_len (:815-823) in parallel
     int a = 0, st = 0, abl = 0;
@@ -676,6 +732,27 @@ void launch_seg_blocks(const SegDev *segs, uint32_t nseg, const uint32_t *tokens
                        int fast, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, tokens, blk_off, so, fast);
 }
+// test tap (szl_debug_tree_lengths): the code lengths of n frequency vectors, one wavefront each — build_tree against the oracle's
+// Tree.BuildTree on histograms no token stream would produce (ties everywhere, over-long codes)
+__global__ __launch_bounds__(64) void k_tree_probe(const int *freqs, int n, int numSymbols, int minCodes, int maxLength, unsigned char *len_out, int *ncodes_out) {
+    __shared__ int f[LIT_NUM + 2];
+    __shared__ unsigned char len[LIT_NUM + 2];
+    __shared__ int blc[15];
+    __shared__ int ncodes;
+    __shared__ TreeScratch scr;
+    if ((int)blockIdx.x >= n) return;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < LIT_NUM + 2; i += 64) f[i] = i < numSymbols ? freqs[(size_t)blockIdx.x * numSymbols + i] : 0;
+    __syncthreads();
+    build_tree(f, numSymbols, minCodes, maxLength, &scr, len, blc, &ncodes, lane);
+    __syncthreads();
+    for (int i = lane; i < numSymbols; i += 64) len_out[(size_t)blockIdx.x * numSymbols + i] = len[i];
+    if (lane == 0) ncodes_out[blockIdx.x] = ncodes;
+}
+void launch_tree_probe(const int *freqs, int n, int numSymbols, int minCodes, int maxLength, unsigned char *len_out, int *ncodes_out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_tree_probe, dim3(n), dim3(64), 0, st, freqs, n, numSymbols, minCodes, maxLength, len_out, ncodes_out);
+}
+
 void launch_block_build(const SegDev *segs, uint32_t nseg, const SegOut *so, const uint64_t *blk_off, const uint32_t *tokens,
                         const int64_t *bsp, const int64_t *blp, BlockDesc *descs, uint32_t nslots, int fast, hipStream_t st) {
     if (nslots) hipLaunchKernelGGL(k_block_build, dim3(nslots), dim3(D_THREADS), 0, st, segs, nseg, so, blk_off, tokens, bsp, blp, descs, nslots, fast);

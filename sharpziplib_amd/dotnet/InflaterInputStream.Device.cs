@@ -33,6 +33,9 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 	{
 		/// <summary>Bytes read from the base stream per Fill() unless the constructor asks for more; 0 = the reference's sizes.</summary>
 		public static int ReadAheadBytes { get; set; } = 16 << 20;
+		/// <summary>What a base stream that can tell it holds eight read-aheads or more gets instead (a piece of 64 MiB costs the device
+		/// little more than one of 16 MiB: 2.8 -> 5.2 GiB/s, profiles/r05/read_path.log).</summary>
+		public static int ReadAheadLongBytes { get; set; } = 64 << 20;
 
 		public InflaterInputBuffer(Stream stream) : this(stream, 4096) { }                       // :22
 
@@ -45,6 +48,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			{
 				// no more than the base stream still holds (+1: the Fill() that meets the end sees it)
 				long left = stream.Length - stream.Position;
+				if (left >= 8L * ReadAheadBytes) size = Math.Max(size, ReadAheadLongBytes);
 				size = Math.Max(bufferSize, Math.Min(size, left + 1));
 			}
 			rawData = NewBuffer((int)size, out rawPin);

@@ -354,3 +354,15 @@ class Model:
         t = np.concatenate([tok, np.zeros(1, np.uint32)])
         nb = self.L.szm_block_table(t.ctypes.data, tok.size, 1 if finish else 0, first.ctypes.data, cnt.ctypes.data, last.ctypes.data)
         return first[:nb], cnt[:nb], last[:nb]
+
+
+def tree_lengths(freqs, min_codes, max_len):
+    """(code lengths, numCodes) the oracle's Tree.BuildTree + BuildLength give one frequency vector (C/DeflaterHuffman.cs:196-329, :475-579)."""
+    f = np.ascontiguousarray(np.asarray(freqs, dtype=np.int16))
+    out = np.zeros(f.size, dtype=np.uint8)
+    nc = ctypes.c_int(0)
+    L = lib()
+    L.szo_tree_lengths.restype = ctypes.c_int
+    L.szo_tree_lengths.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    assert L.szo_tree_lengths(f.ctypes.data, f.size, min_codes, max_len, out.ctypes.data, ctypes.byref(nc)) == 0
+    return out, nc.value

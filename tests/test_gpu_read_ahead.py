@@ -225,7 +225,7 @@ def test_a_hostile_expansion_does_not_turn_into_gigabytes(out_mib):
         tot = 0
         while not inf.IsFinished:
             k = inf.Inflate(buf)
-            assert k > 0 and not buf[:k].any()
+            assert (k > 0 or inf.IsFinished) and not buf[:k].any()
             tot += k
         assert tot == n and inf.TotalIn == len(comp)
         # ordinary text under the same bound: cut into pieces, same bytes
@@ -235,7 +235,7 @@ def test_a_hostile_expansion_does_not_turn_into_gigabytes(out_mib):
         got = bytearray()
         while not inf.IsFinished:
             k = inf.Inflate(buf)
-            assert k > 0
+            assert k > 0 or inf.IsFinished
             got += buf[:k].tobytes()
         assert bytes(got) == text.tobytes() * 12 and _bulk(inf) >= (2 if out_mib == 16 else 1)
     finally:
