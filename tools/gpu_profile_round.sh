@@ -46,5 +46,8 @@ python $R/tools/gpu_inflate_ab.py libszl_amd.so 2>&1 | grep -v "^\[szl\]" > $O/i
 python $R/tools/gpu_inflate_big.py 1024 2>&1 | grep -v "stage B\|links\|match_ms" >> $O/inflate_round.log
 python $R/tools/gpu_inflate_big.py 1024 logs 2>&1 | tail -1 >> $O/inflate_round.log
 python $R/tools/gpu_small_call.py 200 > $O/small_calls.log 2>&1
-python $R/tools/gpu_fast.py 4 4000 > $O/levels_1_4.log 2>&1
-tail -n 30 $O/inflate_round.log $O/small_calls.log $O/levels_1_4.log
+timeout 300 python $R/tools/gpu_lab.py read_path --mib 512 > $O/read_path.log 2>&1     # the drop-in read path by constructor (round 5)
+timeout 300 python $R/tools/gpu_lab.py write_path > $O/write_path.log 2>&1             # GZipOutputStream by write size
+timeout 300 python $R/tools/gpu_stream_latency.py > $O/stream_latency.log 2>&1
+if [ -n "${SZL_PROFILE_LEVELS_1_4:-}" ]; then python $R/tools/gpu_fast.py 4 4000 > $O/levels_1_4.log 2>&1; fi   # (unchanged since round 3: on request)
+tail -n 30 $O/inflate_round.log $O/small_calls.log $O/read_path.log $O/write_path.log
