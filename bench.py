@@ -665,7 +665,7 @@ def run_weak(args, rank, local_rank, world, dist):
         traffic = None
         # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 --pmc passes of this
         # same command (tools/gpu_traffic.sh -> profiles/rNN/*traffic_pmc.json); `traffic_source` says which file
-        tpath = next((t for t in ([os.path.join(ROOT, "profiles", r, "traffic_pmc.json") for r in ("r04", "r03", "r02")] +
+        tpath = next((t for t in ([os.path.join(ROOT, "profiles", r, "traffic_pmc.json") for r in ("r05", "r04", "r03", "r02")] +
                                   [os.path.join(ROOT, "profiles", "r01", "g_traffic_pmc.json")]) if os.path.exists(t)), "")
         if args.mib == 1024 and args.level == 6 and tpath:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units) of this same command, per launch of k_match;

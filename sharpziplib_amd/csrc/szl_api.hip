@@ -936,6 +936,9 @@ static void eager_upload(szl_deflater *d) {
 // the rest of the pending bytes (and the history in front of them) at a flush; afterwards d_in = [hist | pend]
 static int finish_upload(szl_deflater *d, uint64_t H, uint64_t n) {
     int rc;
+    // (the object's own stream: its uploads, and since round 5 its kernels too — streaming Deflaters driven by several host threads
+    // overlap on the device instead of queueing on the default stream)
+    if (!d->up_stream && hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) { d->up_stream = nullptr; (void)hipGetLastError(); }
     if (d->up_done > n || d->up_H != H) d->up_done = 0;
     if ((rc = d->d_in.ensure_keep(H + n + 64, d->up_done ? H + d->up_done : 0, d->up_stream))) return rc;
     if (H && hipMemcpyAsync(d->d_in.p, d->hist.data(), H, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) { set_error("H2D failed"); return SZL_E_DEVICE; }
@@ -1135,7 +1138,7 @@ static int run_segment(szl_deflater *d, bool finish) {
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = !finish; /* (the inserted bits of the tail are history for a next segment only) */ }
     else if (d->hist_has_gaps && H) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); }   // stage A must skip what DeflateFast skipped
-    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, (d->nowrap ? 0u : 2u) | (d->want_crc ? 1u : 0u), res, nullptr);
+    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, (d->nowrap ? 0u : 2u) | (d->want_crc ? 1u : 0u), res, d->up_stream);
     E.fast_hist_in.clear(); E.fast_want_tail = false; E.sw_pos_in.clear(); E.sw_P_in.clear();
     if (rc) return rc;
     const uint64_t end_bit = res[0].end_bit;

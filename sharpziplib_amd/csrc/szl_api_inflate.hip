@@ -690,15 +690,16 @@ struct InBuf {
         if (from < own.n) { const size_t a = std::min(k, own.n - from); memcpy(dst, own.p + from, a); dst += a; from += a; k -= a; }
         if (k) memcpy(dst, ext + (from - own.n), k);
     }
-    hipError_t upload(void *d_dst, size_t from, size_t k) const {                      // the same to device memory: DMA out of pinned memory
+    hipError_t upload(void *d_dst, size_t from, size_t k, hipStream_t st) const {      // the same to device memory: DMA out of pinned memory (complete on return)
         uint8_t *d = (uint8_t *)d_dst;
         if (from < own.n && k) {
             const size_t a = std::min(k, own.n - from);
-            hipError_t e = hipMemcpy(d, own.p + from, a, hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpyAsync(d, own.p + from, a, hipMemcpyHostToDevice, st);
             if (e != hipSuccess) return e;
             d += a; from += a; k -= a;
         }
-        return k ? hipMemcpy(d, ext + (from - own.n), k, hipMemcpyHostToDevice) : hipSuccess;
+        if (k) { hipError_t e = hipMemcpyAsync(d, ext + (from - own.n), k, hipMemcpyHostToDevice, st); if (e != hipSuccess) return e; }
+        return hipStreamSynchronize(st);
     }
     void erase_front(size_t k) { own.erase_front(k); }                                 // (never while borrowed)
     int unborrow(size_t from) {                   // the bytes [from, size()) move to the front of our own memory; the caller's buffer is let go
@@ -767,6 +768,10 @@ struct szl_inflater {
     // true at once, and the next piece starts at the header the object stands on.  Without the hint, or when the shim takes it back at
     // the end of its base stream, the remainder is decoded as before — a truncated stream delivers every byte it holds.
     bool expect_more = false, tail_deferred = false;
+    // The object's own HIP stream (round 5): every copy and launch of this object runs on it, so several streaming Inflaters driven by
+    // several host threads — a server reading many gzip streams — overlap on the device instead of queueing on the default stream (a piece
+    // of 16 MiB fills a quarter of the wavefront slots).
+    hipStream_t strm = nullptr;
     uint32_t bulk_calls = 0;       // (tests / tools: how often the parallel decoder took a piece)
     double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // measurement tap (szl_inflater_debug_times): SetInput, upload, parallel decode, download, checksums, one-wavefront steps, hand-out copies
 };
@@ -799,6 +804,7 @@ void szl_inflater_destroy(szl_inflater *s) {
     if (s->eng) szl_engine_destroy(s->eng);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     s->hin.release(); s->pend.release();
+    if (s->strm) { (void)hipStreamSynchronize(s->strm); (void)hipStreamDestroy(s->strm); }
     delete s;
 }
 int szl_inflater_reset(szl_inflater *s) { if (!s) return SZL_E_ARG; inflater_clear(s); return 0; }
@@ -855,7 +861,7 @@ static int checksum_decoded(szl_inflater *s, const uint8_t *d_p, uint64_t total)
     if (!want || !total) return 0;
     std::vector<std::pair<uint64_t, uint64_t>> regs{{0, total}};
     std::vector<std::pair<uint32_t, uint32_t>> init{{s->crc_dec, s->adler_dec}}, out;
-    int rc = region_checksums(d_p, regs, want, out, &init, nullptr);
+    int rc = region_checksums(d_p, regs, want, out, &init, s->strm);
     if (rc) return rc;
     if (want & 1u) s->crc_dec = out[0].first;
     if (want & 2u) s->adler_dec = out[0].second;
@@ -933,6 +939,8 @@ static int inflater_bulk(szl_inflater *s) {
     int rc;
     const size_t nin = s->hin.size() - s->hin_pos;
     if (!s->eng && !(s->eng = szl_engine_create())) return SZL_E_NOMEM;
+    if (!s->strm) HIPCHK(hipStreamCreateWithFlags(&s->strm, hipStreamNonBlocking));
+    hipStream_t st = s->strm;
     Engine &E = s->eng->e;
     // staging of the single pass is sized from an expected expansion: what this stream has shown so far, generously (a piece that
     // overruns it goes through the count-first form below)
@@ -945,15 +953,15 @@ static int inflater_bulk(szl_inflater *s) {
     size_t take = nin;
     if ((double)take * expand > (double)out_budget) take = std::max<size_t>((size_t)((double)out_budget / expand), std::min(nin, bulk_min)) & ~(size_t)3;
     if ((rc = s->d_bulk_in.ensure(nin + 64)) || (rc = s->d_win_lin.ensure(2 * 32768)) || (rc = s->d_win.ensure(32768))) return rc;
-    { Lap lap(s->t_ms[1]); HIPCHK(s->hin.upload(s->d_bulk_in.p, s->hin_pos, std::min(nin, take + 64))); }   // (pinned source: DMA)
+    { Lap lap(s->t_ms[1]); HIPCHK(s->hin.upload(s->d_bulk_in.p, s->hin_pos, std::min(nin, take + 64), st)); }   // (pinned source: DMA)
     // the window the one-wavefront decoder keeps is a ring indexed by output position & 32767; the chunk jobs' windows are linear
     // (oldest byte first): linear[i] = ring[(outpos + i) & 32767]
     uint8_t *ring = (uint8_t *)s->d_win.p, *lin = (uint8_t *)s->d_win_lin.p, *lin_out = lin + 32768;
     const uint32_t r0 = (uint32_t)(s->st.outpos & 32767);
-    if (s->st.outpos == 0 && !s->have_dict) HIPCHK(hipMemset(lin, 0, 32768));
+    if (s->st.outpos == 0 && !s->have_dict) HIPCHK(hipMemsetAsync(lin, 0, 32768, st));
     else {
-        HIPCHK(hipMemcpy(lin, ring + r0, 32768 - r0, hipMemcpyDeviceToDevice));
-        if (r0) HIPCHK(hipMemcpy(lin + (32768 - r0), ring, r0, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpyAsync(lin, ring + r0, 32768 - r0, hipMemcpyDeviceToDevice, st));
+        if (r0) HIPCHK(hipMemcpyAsync(lin + (32768 - r0), ring, r0, hipMemcpyDeviceToDevice, st));
     }
     ParStream sm;
     std::vector<char> taken(1, 0);
@@ -973,8 +981,8 @@ static int inflater_bulk(szl_inflater *s) {
         };
         std::vector<size_t> cand{0}, retry;
         taken[0] = 0;
-        rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, cand, false, knob("SZL_INF_SINGLE_PASS", 1) != 0, nullptr, taken, res, &retry, &sm);
-        if (rc >= 0 && !taken[0] && !retry.empty() && !refused_total) rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, retry, false, false, nullptr, taken, res, nullptr, &sm);
+        rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, cand, false, knob("SZL_INF_SINGLE_PASS", 1) != 0, st, taken, res, &retry, &sm);
+        if (rc >= 0 && !taken[0] && !retry.empty() && !refused_total) rc = inflate_members_parallel(E, (const uint8_t *)s->d_bulk_in.p, nullptr, &ps, retry, false, false, st, taken, res, nullptr, &sm);
         if (rc < 0) return rc;
         if (taken[0] || !refused_total) break;
         // far more output than this stream had shown: a piece scaled to the bound by what it showed, at least the path's minimum
@@ -989,15 +997,16 @@ static int inflater_bulk(szl_inflater *s) {
     pend_recycle(s);
     const size_t old = s->pend.size();
     if ((rc = s->pend.grow(total))) return rc;
-    { Lap lap(s->t_ms[3]); if (total) HIPCHK(hipMemcpy(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost)); }
+    { Lap lap(s->t_ms[3]); if (total) { HIPCHK(hipMemcpyAsync(s->pend.data() + old, s->d_bulk_out.p, total, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); } }
     { Lap lap(s->t_ms[4]); if ((rc = checksum_decoded(s, (const uint8_t *)s->d_bulk_out.p, total))) return rc; }
     // the state the one-wavefront decoder continues from: a block header (or, behind the final block, "last block done")
     s->st.outpos += total;
     s->st.bitpos = sm.end_bit;
     s->st.mode = INF_M_HEADER; s->st.last = sm.finished ? 1u : 0u; s->st.stored_left = 0;
     const uint32_t r1 = (uint32_t)(s->st.outpos & 32767);
-    HIPCHK(hipMemcpy(ring + r1, lin_out, 32768 - r1, hipMemcpyDeviceToDevice));
-    if (r1) HIPCHK(hipMemcpy(ring, lin_out + (32768 - r1), r1, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpyAsync(ring + r1, lin_out, 32768 - r1, hipMemcpyDeviceToDevice, st));
+    if (r1) HIPCHK(hipMemcpyAsync(ring, lin_out + (32768 - r1), r1, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
     s->have_dict = true;            // (the window is to be loaded whatever the output position says)
     s->dec_status = INF_CHUNK_END;  // "running": szl_inflater_inflate goes on with the rest of the input
     s->bulk_calls++;
@@ -1023,6 +1032,8 @@ static int inflater_step(szl_inflater *s) {
         s->bulk_skip_given = s->given;     // no chain in this input (static / stored blocks only, an error ahead, ...): the ordinary decoder
     }
     Lap lap7(s->t_ms[7]);
+    if (!s->strm) HIPCHK(hipStreamCreateWithFlags(&s->strm, hipStreamNonBlocking));
+    hipStream_t st = s->strm;
     if ((rc = s->d_ctl.ensure(szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64)) || (rc = s->d_out.ensure(szl_inflater::OUT_CHUNK + 64)) ||
         (rc = s->d_win.ensure(32768))) return rc;
     if (!s->h_ctl && hipHostMalloc((void **)&s->h_ctl, szl_inflater::CTL_HDR + szl_inflater::IN_STEP + 64, hipHostMallocDefault) != hipSuccess) { set_error("pinned host memory"); return SZL_E_NOMEM; }
@@ -1038,7 +1049,7 @@ static int inflater_step(szl_inflater *s) {
     uint8_t *dctl = (uint8_t *)s->d_ctl.p;
     *hj = j; *hs = s->st;
     if (nup) s->hin.copy_out(s->h_ctl + szl_inflater::CTL_HDR, s->hin_pos, nup);
-    HIPCHK(hipMemcpyAsync(dctl, s->h_ctl, szl_inflater::CTL_HDR + nup, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(dctl, s->h_ctl, szl_inflater::CTL_HDR + nup, hipMemcpyHostToDevice, st));
     if (s->exact_live) {
         // odd-length pieces that begin behind the decoder's position: see odd_starts
         const uint64_t at = s->in_base + (s->st.bitpos >> 3);
@@ -1051,11 +1062,11 @@ static int inflater_step(szl_inflater *s) {
             return 0;
         }
         launch_inflate_exact(dctl + szl_inflater::CTL_HDR, (uint8_t *)s->d_out.p, (InfJob *)dctl, (InfState *)(dctl + sizeof(InfJob)), (ExState *)s->d_ex.p,
-                             (const uint32_t *)((uint8_t *)s->d_ex.p + sizeof(ExState)), 1, nullptr);
+                             (const uint32_t *)((uint8_t *)s->d_ex.p + sizeof(ExState)), 1, st);
     } else
-    launch_inflate(dctl + szl_inflater::CTL_HDR, (uint8_t *)s->d_out.p, (InfJob *)dctl, (InfState *)(dctl + sizeof(InfJob)), 1, false, nullptr);
-    HIPCHK(hipMemcpyAsync(s->h_ctl, dctl, sizeof(InfJob) + sizeof(InfState), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    launch_inflate(dctl + szl_inflater::CTL_HDR, (uint8_t *)s->d_out.p, (InfJob *)dctl, (InfState *)(dctl + sizeof(InfJob)), 1, false, st);
+    HIPCHK(hipMemcpyAsync(s->h_ctl, dctl, sizeof(InfJob) + sizeof(InfState), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     j = *hj; s->st = *hs;
     s->fresh_input = false;
     // A corrupt token stops the decoder, but everything it decoded before that point is still delivered (the reference hands
@@ -1073,8 +1084,8 @@ static int inflater_step(szl_inflater *s) {
         pend_recycle(s);
         const size_t old = s->pend.size();
         if ((rc = s->pend.grow(j.out_written))) return rc;
-        HIPCHK(hipMemcpyAsync(s->pend.data() + old, s->d_out.p, j.out_written, hipMemcpyDeviceToHost, nullptr));   // (pinned destination)
-        HIPCHK(hipStreamSynchronize(nullptr));
+        HIPCHK(hipMemcpyAsync(s->pend.data() + old, s->d_out.p, j.out_written, hipMemcpyDeviceToHost, st));   // (pinned destination)
+        HIPCHK(hipStreamSynchronize(st));
         if ((rc = checksum_decoded(s, (const uint8_t *)s->d_out.p, j.out_written))) return rc;   // K/Adler32.cs, K/Crc32.cs: on the device
     }
     if (s->err) return 0;

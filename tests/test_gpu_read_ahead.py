@@ -255,3 +255,44 @@ def test_python_gzip_members_and_small_reads_through_the_default_classes():
         _drain(GZipInputStream(io.BytesIO(bytes(bad))), 1 << 20)
     with pytest.raises(EOFError):
         _drain(GZipInputStream(io.BytesIO(src[:len(gzip.compress(a, 6)) - 3])), 1 << 20)       # "EOS reading GZIP footer" (:322)
+
+
+def test_streams_on_several_host_threads_overlap_and_stay_exact():
+    """every streaming object runs on a HIP stream of its own (round 5): four GZipInputStreams and four GZipOutputStreams driven by eight
+    host threads at once — a server's shape — must each produce what they produce alone"""
+    import threading
+    from sharpziplib_amd.gzipstream import GZipInputStream, GZipOutputStream, write_members
+    datas = [C.generate(k, 200 + i, 0, (24 + 4 * i) << 20) for i, k in enumerate(("enwik", "logs", "dickens", "enwik"))]
+    members = write_members(datas, level=6)
+    small = [d[:3 << 20] for d in datas]
+    want_small = [O.deflate(d, 6) for d in small]
+    results, errors = {}, []
+
+    def reader(i):
+        try:
+            results[("r", i)] = _drain(GZipInputStream(io.BytesIO(members[i])), 1 << 20)
+        except Exception as e:                             # noqa: BLE001
+            errors.append(("r", i, repr(e)))
+
+    def writer(i):
+        try:
+            bio = io.BytesIO()
+            g = GZipOutputStream(bio, 1 << 20)
+            g.IsStreamOwner = False
+            g.ModifiedTime = 0
+            for rep in range(3):                           # (three flushes: three device runs per thread, interleaved with the others')
+                a = small[i][rep << 20:(rep + 1) << 20]
+                g.Write(a)
+            g.Finish()
+            results[("w", i)] = bio.getvalue()
+        except Exception as e:                             # noqa: BLE001
+            errors.append(("w", i, repr(e)))
+    th = [threading.Thread(target=f, args=(i,)) for i in range(4) for f in (reader, writer)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        assert results[("r", i)] == datas[i].tobytes(), i
+        assert results[("w", i)][10:-8] == want_small[i], i
