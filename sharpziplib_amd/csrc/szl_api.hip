@@ -782,7 +782,7 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
 }
 void szl_deflater_destroy(szl_deflater *d) {
     if (!d) return;
-    if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); (void)hipStreamDestroy(d->up_stream); }
+    if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); d->pend.busy = nullptr; (void)hipStreamDestroy(d->up_stream); d->up_stream = nullptr; }   // (the buffers' destructors must not wait on a stream that is gone)
     d->d_in.release(); d->d_out.release();
     szl_engine_destroy(d->eng);
     delete d;

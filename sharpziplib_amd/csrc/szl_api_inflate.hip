@@ -787,6 +787,7 @@ static void inflater_clear(szl_inflater *s) {
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
     s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler_base = 1; s->adler_dec = 1; s->crc_base = 0; s->crc_dec = 0;
     s->bulk_skip_given = 0; s->exact_live = false; s->tail_deferred = false; s->odd_starts.clear();
+    s->expect_more = false;        // (the hint belongs to the stream that gave it: a pooled Inflater's next user may never give one)
 }
 
 szl_inflater *szl_inflater_create(int no_header) {
