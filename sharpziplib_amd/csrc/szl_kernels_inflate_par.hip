@@ -41,23 +41,21 @@ __device__ __forceinline__ uint64_t bits_at(const uint8_t *in, uint64_t in_len, 
     return v;
 }
 
-// Full parse of a dynamic block header (one lane).  True iff it is complete and consistent.  The header's bytes are staged in
-// LDS by the whole wavefront first (hs: 1 KiB + 16 from the byte that holds bit position p; a header is at most 563 bytes): read from
-// global memory bit by bit, with the code-length code in a dynamically indexed private array (= scratch), one attempt cost
-// ~100 us, and a chunk sees dozens of candidates that pass the cheap tests (finder of a 1 GiB member: 12.6 -> 9.2 ms).
-//   b0: bit offset of the header inside hs (0..7); left: input bits from the header's first bit to the end of the member
-__device__ bool header_ok(const uint32_t *hs, uint32_t b0, uint64_t left, uint8_t *lens /* 320 */, uint16_t *mlut /* 128 */) {
-    auto win32 = [&](uint32_t bp) -> uint32_t {                   // 32 stream bits from bit bp of the stage on
-        const uint32_t by = bp >> 3, sh = ((by & 3u) << 3) | (bp & 7u);
-        return __builtin_amdgcn_alignbit(hs[(by >> 2) + 1], hs[by >> 2], sh);
-    };
-    uint32_t rel = 0;                                             // bits consumed
-    uint32_t w = win32(b0);
+// Full parse of a dynamic block header, ONE LANE PER CANDIDATE (round 5).  True iff the header at bit position p of the member is
+// complete and consistent.  Through round 4 one lane parsed one candidate at a time out of an LDS stage the whole wavefront filled for
+// it (260 dwords per candidate), and a chunk sees ~170 candidates that pass the cheap tests before its first block header: the parses,
+// not the scan, were most of the finder's 7.5 ms for a 1 GiB member.  The parse needs no array but the 128-entry table of the
+// code-length code (one byte per entry, this lane's 128 bytes of LDS): a repeat code needs the PREVIOUS length only, completeness is two
+// running Kraft sums, the end-of-block symbol's length is noted as the run passes index 256 — so up to 64 candidates are parsed at once,
+// each lane reading its own header through bits_at (a header is at most 563 bytes: L1 / L2 resident after the first touch).
+__device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, uint8_t *mlut /* 128, this lane's */) {
+    const uint64_t left = in_len * 8 - p;                         // input bits from the header's first bit to the end of the member
+    uint32_t w = (uint32_t)bits_at(in, in_len, p);
     if ((w & 7) != 4) return false;                               // BFINAL = 0, BTYPE = 2 (the final block is left to its predecessor's decode)
     const uint32_t nl = ((w >> 3) & 31) + 257, nd = ((w >> 8) & 31) + 1, nm = ((w >> 13) & 15) + 4;
-    if (nl > 286 || nd > 30) return false;                        // :50-52
-    rel = 17;
-    const uint64_t mw = (uint64_t)win32(b0 + 17) | ((uint64_t)win32(b0 + 49) << 32);
+    if (nl > 286 || nd > 30) return false;                        // C/InflaterDynHeader.cs:50-52
+    uint32_t rel = 17;                                            // bits consumed
+    const uint64_t mw = bits_at(in, in_len, p + 17);
     constexpr int ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // C/InflaterDynHeader.cs:23-24
     uint32_t ml[19];
 #pragma unroll
@@ -72,50 +70,57 @@ __device__ bool header_ok(const uint32_t *hs, uint32_t b0, uint64_t left, uint8_
     if (kraft != 128) return false;                               // a complete code-length code (what every encoder writes)
     rel += 3 * nm;
     if ((uint64_t)rel + 64 > left) return false;
-    for (int i = 0; i < 128; i++) mlut[i] = 0;
+    for (int i = 0; i < 128; i += 4) *(uint32_t *)(mlut + i) = 0;
     int code = 0;
     for (int l = 1; l < 8; l++) {
 #pragma unroll
         for (int i = 0; i < 19; i++) {
             if (ml[i] != (uint32_t)l) continue;
             const uint32_t rev = (__builtin_bitreverse32((uint32_t)code++) >> (32 - l)) & ((1u << l) - 1);
-            for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint16_t)((i << 4) | l);
+            for (uint32_t j = rev; j < 128; j += (1u << l)) mlut[j] = (uint8_t)((i << 3) | l);      // (symbol < 19, length 1..7: never 0)
         }
         code <<= 1;
     }
-    uint32_t idx = 0;
+    uint32_t idx = 0, prev = 0, len256 = 0;
     const uint32_t total = nl + nd;
     int kl = 0, kd = 0, ndist = 0;                                // Kraft sums in units of 2^-15
     while (idx < total) {
         if ((uint64_t)rel + 16 > left) return false;
-        w = win32(b0 + rel);
+        w = (uint32_t)bits_at(in, in_len, p + rel);
         const uint32_t e = mlut[w & 127];
         if (e == 0) return false;
-        const uint32_t sl = e & 15, sym = e >> 4;
+        const uint32_t sl = e & 7, sym = e >> 3;
         rel += sl; w >>= sl;
         uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (idx == 0) return false; val = lens[idx - 1]; rep = 3 + (w & 3); rel += 2; }        // :83
+        if (sym == 16) { if (idx == 0) return false; val = prev; rep = 3 + (w & 3); rel += 2; }               // :83
         else if (sym == 17) { val = 0; rep = 3 + (w & 7); rel += 3; }
         else if (sym == 18) { val = 0; rep = 11 + (w & 127); rel += 7; }
         if (idx + rep > total) return false;                       // :106
-        for (uint32_t r = 0; r < rep; r++, idx++) {
-            lens[idx] = (uint8_t)val;
-            if (val) { if (idx < nl) kl += 32768 >> val; else { kd += 32768 >> val; ndist++; } }
+        if (val) {
+            const uint32_t in_lit = idx >= nl ? 0u : (idx + rep <= nl ? rep : nl - idx);       // how many of the run are literal/length codes
+            kl += (int)in_lit * (32768 >> val);
+            kd += (int)(rep - in_lit) * (32768 >> val);
+            ndist += (int)(rep - in_lit);
         }
+        if (idx <= 256u && 256u < idx + rep) len256 = val;
+        idx += rep;
+        prev = val;
         if (kl > 32768 || kd > 32768) return false;               // over-subscribed
     }
-    if (lens[256] == 0) return false;                              // :113
+    if (len256 == 0) return false;                                 // :113
     if (kl != 32768) return false;                                 // complete literal/length code
     if (!(kd == 32768 || ndist <= 1)) return false;               // complete distance code, or the one-code / no-code tree of zlib
     return true;
 }
 
-// One wavefront per finder job: first valid dynamic header at a bit offset in [lo_bit, hi_bit) of the job's member.
+// One wavefront per finder job: first valid dynamic header at a bit offset in [lo_bit, hi_bit) of the job's member.  The scan tests
+// 64 bit positions per step with the cheap tests and notes the positions that pass; every FIND_FLUSH steps (or with 64 of them
+// noted) they are parsed, a lane each, and the lowest one that holds is the answer.
+enum : int { FIND_FLUSH = 512, FIND_CAP = 128 };
 __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ in_base, const FindJob *__restrict__ fjobs, uint32_t njobs,
                                                     uint64_t *__restrict__ start_bit) {
-    __shared__ uint8_t s_lens[320];
-    __shared__ uint16_t s_mlut[128];
-    __shared__ uint32_t s_hdr[256 + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mlut[64][128];
+    __shared__ uint64_t s_cand[FIND_CAP];
     if (blockIdx.x >= njobs) return;
     const FindJob fj = fjobs[blockIdx.x];
     const uint8_t *in = in_base + fj.in_off;
@@ -125,6 +130,19 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     uint64_t hi = fj.hi_bit;
     if (hi + 128 > in_len * 8) hi = in_len * 8 > 128 ? in_len * 8 - 128 : 0;
     uint64_t found = ~0ull;
+    int ncand = 0, since = 0;
+    auto flush = [&]() {                                           // parse what has been noted, in position order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int off = 0; off < ncand && found == ~0ull; off += 64) {
+            const bool mine = off + lane < ncand;
+            const uint64_t p = mine ? s_cand[off + lane] : 0;
+            const bool ok = mine && header_ok_lane(in, in_len, p, s_mlut[lane]);
+            const uint64_t okm = __ballot(ok);
+            if (okm) found = s_cand[off + __builtin_ctzll(okm)];
+        }
+        ncand = 0; since = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
     for (uint64_t base = lo; base < hi && found == ~0ull; base += 64) {
         const uint64_t p = base + lane;
         bool cand = false;
@@ -138,27 +156,14 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                 cand = kraft == 128;
             }
         }
-        uint64_t mm = __ballot(cand);
-        while (mm) {                                               // candidates in bit order; the full parse runs on one lane
-            const int l = __builtin_ctzll(mm);
-            mm &= mm - 1;
-            int ok = 0;
-            {   // stage the candidate's bytes (whole dwords from its byte on; zeros past the end of the member)
-                const uint64_t cb = (base + (uint64_t)l) >> 3;
-                for (int i = lane; i < 256 + 4; i += 64) {
-                    const uint64_t q = cb + 4ull * (uint64_t)i;
-                    uint32_t v = 0;
-                    if (q + 4 <= in_len) __builtin_memcpy(&v, in + q, 4);
-                    else for (int kb = 0; kb < 4; kb++) if (q + kb < in_len) v |= (uint32_t)in[q + kb] << (8 * kb);
-                    s_hdr[i] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            }
-            if (lane == 0) ok = header_ok(s_hdr, (uint32_t)((base + (uint64_t)l) & 7), in_len * 8 - (base + (uint64_t)l), s_lens, s_mlut) ? 1 : 0;
-            ok = __builtin_amdgcn_readfirstlane(ok);
-            if (ok) { found = base + (uint64_t)l; break; }
+        const uint64_t mm = __ballot(cand);
+        if (mm) {
+            if (cand) s_cand[ncand + __builtin_popcountll(mm & ((1ull << lane) - 1ull))] = p;
+            ncand += __builtin_popcountll(mm);
         }
+        if (++since >= FIND_FLUSH || ncand >= 64) flush();
     }
+    if (found == ~0ull && ncand) flush();
     if (lane == 0) start_bit[blockIdx.x] = found;
 }
 
