@@ -84,17 +84,24 @@ __device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
     uint32_t idx = 0, prev = 0, len256 = 0;
     const uint32_t total = nl + nd;
     int kl = 0, kd = 0, ndist = 0;                                // Kraft sums in units of 2^-15
+    // (the symbols come out of a 64-bit window that is fetched again when fewer than 16 bits of it are left — a symbol takes at most
+    // 7 + 7 — so the parse of a true header, 316 symbols, is ~35 dependent global loads instead of 316)
+    uint64_t buf = 0;
+    int have = 0;
     while (idx < total) {
         if ((uint64_t)rel + 16 > left) return false;
-        w = (uint32_t)bits_at(in, in_len, p + rel);
+        if (have < 16) { buf = bits_at(in, in_len, p + rel); have = 64; }
+        w = (uint32_t)buf;
         const uint32_t e = mlut[w & 127];
         if (e == 0) return false;
         const uint32_t sl = e & 7, sym = e >> 3;
-        rel += sl; w >>= sl;
+        w >>= sl;
+        uint32_t used = sl;
         uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (idx == 0) return false; val = prev; rep = 3 + (w & 3); rel += 2; }               // :83
-        else if (sym == 17) { val = 0; rep = 3 + (w & 7); rel += 3; }
-        else if (sym == 18) { val = 0; rep = 11 + (w & 127); rel += 7; }
+        if (sym == 16) { if (idx == 0) return false; val = prev; rep = 3 + (w & 3); used += 2; }               // :83
+        else if (sym == 17) { val = 0; rep = 3 + (w & 7); used += 3; }
+        else if (sym == 18) { val = 0; rep = 11 + (w & 127); used += 7; }
+        rel += used; buf >>= used; have -= (int)used;
         if (idx + rep > total) return false;                       // :106
         if (val) {
             const uint32_t in_lit = idx >= nl ? 0u : (idx + rep <= nl ? rep : nl - idx);       // how many of the run are literal/length codes
