@@ -129,7 +129,13 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     __shared__ __attribute__((aligned(16))) uint8_t s_mlut[64][128];
     __shared__ uint64_t s_cand[FIND_CAP];
     __shared__ uint32_t s_stage[FIND_STAGE_DW];
+    __shared__ uint8_t s_k9[512];                                  // Kraft weight (units of 2^-7) of three 3-bit code lengths at once
     if (blockIdx.x >= njobs) return;
+    for (int i = threadIdx.x; i < 512; i += 64) {
+        int k = 0;
+        for (int f = 0; f < 3; f++) { const int l = (i >> (3 * f)) & 7; if (l) k += 128 >> l; }
+        s_k9[i] = (uint8_t)k;
+    }
     const FindJob fj = fjobs[blockIdx.x];
     const uint8_t *in = in_base + fj.in_off;
     const uint64_t in_len = fj.in_len;
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     if (hi + 128 > in_len * 8) hi = in_len * 8 > 128 ? in_len * 8 - 128 : 0;
     uint64_t found = ~0ull;
     int ncand = 0, since = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // (s_k9)
     auto flush = [&]() {                                           // parse what has been noted, in position order
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int off = 0; off < ncand && found == ~0ull; off += 64) {
@@ -173,12 +180,17 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                 const uint32_t dw = off >> 5, sh = off & 31u;
                 const uint32_t w = __builtin_amdgcn_alignbit(s_stage[dw + 1], s_stage[dw], sh);
                 if ((w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29) {
+                    // the code-length code's own lengths (nm x 3 bits) must be a complete code: their Kraft sum, three lengths per table
+                    // look-up (round 5: a loop over the 19 fields, entered by some lane in nearly every step, was 2/3 of the scan's
+                    // 288 instructions per step — the finder is bound by them, 4.5 ms for a chunk's 45 KiB to its first header)
                     const uint32_t nm = ((w >> 13) & 15) + 4;
-                    const uint32_t o2 = off + 17u, d2 = o2 >> 5, s2 = o2 & 31u;      // the 57 bits of the code-length code's lengths
-                    const uint64_t m = (uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 1], s_stage[d2], s2) |
-                                       ((uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 2], s_stage[d2 + 1], s2) << 32);
-                    int kraft = 0;
-                    for (uint32_t i = 0; i < nm; i++) { const uint32_t l = (uint32_t)(m >> (3 * i)) & 7; if (l) kraft += 128 >> l; }
+                    const uint32_t o2 = off + 17u, d2 = o2 >> 5, s2 = o2 & 31u;      // the 57 bits of the lengths
+                    uint64_t m = (uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 1], s_stage[d2], s2) |
+                                 ((uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 2], s_stage[d2 + 1], s2) << 32);
+                    m &= (1ull << (3 * nm)) - 1ull;                                  // (nm <= 19: at most 57 bits)
+                    const int kraft = (int)s_k9[(uint32_t)m & 511u] + (int)s_k9[(uint32_t)(m >> 9) & 511u] + (int)s_k9[(uint32_t)(m >> 18) & 511u] +
+                                      (int)s_k9[(uint32_t)(m >> 27) & 511u] + (int)s_k9[(uint32_t)(m >> 36) & 511u] + (int)s_k9[(uint32_t)(m >> 45) & 511u] +
+                                      (int)s_k9[(uint32_t)(m >> 54) & 511u];
                     cand = kraft == 128;
                 }
             }
