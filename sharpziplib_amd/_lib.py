@@ -66,6 +66,7 @@ def _load(path):
         "szl_deflater_set_strategy": (i32, [vp, i32]), "szl_deflater_set_dictionary": (i32, [vp, vp, i32]),
         "szl_deflater_set_input": (i32, [vp, vp, i32]), "szl_deflater_flush": (i32, [vp]), "szl_deflater_finish": (i32, [vp]),
         "szl_deflater_deflate": (i32, [vp, vp, i32]), "szl_deflater_needs_input": (i32, [vp]),
+        "szl_deflater_deflate_view": (i32, [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]),
         "szl_deflater_is_finished": (i32, [vp]), "szl_deflater_total_in": (i64, [vp]), "szl_deflater_total_out": (i64, [vp]),
         "szl_deflater_adler": (u32, [vp]), "szl_deflater_enable_crc32": (i32, [vp, i32]), "szl_deflater_crc32": (u32, [vp]),
         "szl_deflate_bound": (u64, [u64]), "szl_engine_create": (vp, []), "szl_engine_destroy": (None, [vp]),

@@ -1371,10 +1371,32 @@ static int deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/De
     return orig - length;
 }
 
+// Deflate() without the copy (include/szl.h: szl_deflater_deflate_view): the same state machine, but the bytes stay where they are — in
+// the object's pinned queue, which the device filled by DMA — and the caller gets their address.  They count as handed out (TotalOut)
+// and stay readable until the next call on the object.
+static int deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n) {
+    if (!d || !p || !n) return SZL_E_ARG;
+    *p = nullptr; *n = 0;
+    if (d->state == CLOSED_STATE) return SZL_E_STATE;
+    if (d->state < BUSY_STATE) { uint8_t none; const int rc = deflater_deflate(d, &none, 0); if (rc < 0) return rc; }   // (queues the zlib header, :436-464)
+    for (;;) {
+        if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }      // (the previous view has been read)
+        const size_t avail = d->outq.size() - d->outpos;
+        if (avail) { *p = d->outq.data() + d->outpos; *n = (int64_t)avail; d->outpos += avail; d->total_out += (int64_t)avail; return 0; }
+        if (d->state == FINISHED_STATE) return 0;
+        if (d->state == BUSY_STATE) { uint8_t none; const int rc = deflater_deflate(d, &none, 1); return rc < 0 ? rc : (rc == 0 ? 0 : SZL_E_STATE); }   // "We need more input now": Deflate()'s own bookkeeping; it has nothing to hand out
+        int rc;
+        if (d->state == FLUSHING_STATE) { if ((rc = run_segment(d, false))) return rc; d->state = BUSY_STATE; }
+        else if (d->state == FINISHING_STATE) { if ((rc = run_segment(d, true))) return rc; d->state = FINISHED_STATE; }
+        else return SZL_E_STATE;
+    }
+}
+
 // The entry points proper: no C++ exception leaves the library (an allocation that fails is SZL_E_NOMEM — round-4 ADVICE)
 #define SZL_GUARDED(call) do { try { return (call); } catch (const std::bad_alloc &) { set_error("out of host memory"); return SZL_E_NOMEM; } catch (...) { set_error("internal error"); return SZL_E_STATE; } } while (0)
 int szl_deflater_set_input(szl_deflater *d, const uint8_t *p, int n) { SZL_GUARDED(deflater_set_input(d, p, n)); }
 int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int length) { SZL_GUARDED(deflater_deflate(d, out, length)); }
+int szl_deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n) { SZL_GUARDED(deflater_deflate_view(d, p, n)); }
 int szl_deflater_reset(szl_deflater *d) { SZL_GUARDED(deflater_reset(d)); }
 int szl_deflater_set_level(szl_deflater *d, int level) { SZL_GUARDED(deflater_set_level(d, level)); }
 int szl_deflater_set_strategy(szl_deflater *d, int s) { SZL_GUARDED(deflater_set_strategy(d, s)); }

@@ -5,6 +5,7 @@ the device; exceptions mirror the reference's types:
     ArgumentOutOfRangeException -> ValueError, InvalidOperationException -> InvalidOperation,
     SharpZipBaseException -> SharpZipBaseException.
 """
+import ctypes
 import numpy as np
 
 from . import _lib
@@ -117,6 +118,18 @@ class Deflater:
         if n < 0:
             _raise(n, "Deflate")
         return n
+
+    def DeflateView(self):
+        """Everything the next Deflate() calls would hand out, in place (szl_deflater_deflate_view): a memoryview over the object's pinned
+        output queue, valid until the next call on the object; None where Deflate() would return 0.  What the device-aware
+        DeflaterOutputStream writes to its base stream instead of buffer_.Length bytes at a time (CS/DeflaterOutputStream.cs:242-272)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        s = self._L.szl_deflater_deflate_view(self._h, ctypes.byref(p), ctypes.byref(n))
+        if s < 0:
+            _raise(s, "Deflate")
+        if not n.value:
+            return None
+        return memoryview((ctypes.c_uint8 * n.value).from_address(p.value)).cast("B")
 
     @property
     def IsFinished(self):

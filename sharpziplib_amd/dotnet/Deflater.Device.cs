@@ -27,6 +27,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		[DllImport(Lib)] internal static extern int szl_deflater_flush(IntPtr d);
 		[DllImport(Lib)] internal static extern int szl_deflater_finish(IntPtr d);
 		[DllImport(Lib)] internal static extern unsafe int szl_deflater_deflate(IntPtr d, byte* output, int len);
+		[DllImport(Lib)] internal static extern unsafe int szl_deflater_deflate_view(IntPtr d, byte** p, long* n);
 		[DllImport(Lib)] internal static extern int szl_deflater_needs_input(IntPtr d);
 		[DllImport(Lib)] internal static extern int szl_deflater_is_finished(IntPtr d);
 		[DllImport(Lib)] internal static extern long szl_deflater_total_in(IntPtr d);
@@ -139,6 +140,16 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 			if (output == null) throw new ArgumentNullException(nameof(output));
 			if (offset < 0 || length < 0 || offset > output.Length - length) throw new IndexOutOfRangeException();
 			fixed (byte* p = output) return Check(SzlNative.szl_deflater_deflate(h, p + offset, length), nameof(Deflate));
+		}
+		// Deflate() without its copies (include/szl.h szl_deflater_deflate_view): everything the next Deflate() calls would hand out, in place —
+		// the object's pinned output queue — valid until the next call on this object; false where Deflate() returns 0.  What the device-aware
+		// DeflaterOutputStream (DeflaterOutputStream.Device.cs) writes to its base stream from.
+		internal unsafe bool DeflateView(out byte* p, out long n)
+		{
+			byte* q; long k;
+			Check(SzlNative.szl_deflater_deflate_view(h, &q, &k), nameof(Deflate));
+			p = q; n = k;
+			return k > 0;
 		}
 		public void SetDictionary(byte[] dictionary) { SetDictionary(dictionary, 0, dictionary.Length); }
 		public unsafe void SetDictionary(byte[] dictionary, int index, int count)                        // :559

@@ -39,13 +39,30 @@ class DeflaterOutputStream:
             return
         self.cryptoTransform_.TransformBlock(buffer, 0, length, buffer, 0)
 
+    def _hand_out(self):
+        """One turn of the reference's loops (Finish :104-113, DeflateSyncOrAsync :247-266): the next compressed bytes go to the base stream;
+        False where Deflate() returned 0.  Device-aware (INTEGRATION.md file 4, dotnet/DeflaterOutputStream.Device.cs): without a crypto
+        transform the bytes are written straight out of the Deflater's pinned queue — all it has, in one Write — instead of being copied
+        into buffer_ (512 bytes by default, :26-29) and written from there; with one they pass through buffer_ as in the reference,
+        because TransformBlock works in place (:227-231)."""
+        view = getattr(self.deflater_, "DeflateView", None)
+        if self.cryptoTransform_ is None and view is not None:
+            v = view()
+            if v is None:
+                return False
+            self.baseOutputStream_.write(v)                    # (valid until the next call on the Deflater: a stream copies what it is given)
+            return True
+        n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
+        if n <= 0:
+            return False
+        self.EncryptBlock(self.buffer_, 0, n)                  # :256
+        self.baseOutputStream_.write(self.buffer_[:n].tobytes())
+        return True
+
     def _deflate(self, flushing=False):                        # DeflateSyncOrAsync :242-272
         while flushing or not self.deflater_.IsNeedingInput:
-            n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
-            if n <= 0:
+            if not self._hand_out():
                 break
-            self.EncryptBlock(self.buffer_, 0, n)              # :256
-            self.baseOutputStream_.write(self.buffer_[:n].tobytes())
         if not self.deflater_.IsNeedingInput:
             raise SharpZipBaseException("DeflaterOutputStream can't deflate all input?")
 
@@ -64,11 +81,8 @@ class DeflaterOutputStream:
     def Finish(self):                                          # :100
         self.deflater_.Finish()
         while not self.deflater_.IsFinished:
-            n = self.deflater_.Deflate(self.buffer_, 0, self.buffer_.size)
-            if n <= 0:
+            if not self._hand_out():
                 break
-            self.EncryptBlock(self.buffer_, 0, n)              # :111
-            self.baseOutputStream_.write(self.buffer_[:n].tobytes())
         if not self.deflater_.IsFinished:
             raise SharpZipBaseException("Can't deflate all input?")
         self.baseOutputStream_.flush()

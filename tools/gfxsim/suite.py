@@ -126,6 +126,24 @@ def suite_deflater_object():
         got, ref = TR._drain(d, o)
         assert got == ref, ("dictionary", level)
         n += 1
+    # Deflate() without its copies (szl_deflater_deflate_view: what the device-aware DeflaterOutputStream writes from) — tests/test_gpu_write_path.py
+    import test_gpu_write_path as TW
+    for level, nowrap in ((0, True), (1, False), (6, True), (6, False)):
+        d, o = Deflater(level, nowrap), O.Deflater(level, nowrap)
+        got, ref = bytearray(), bytearray()
+        for i, part in enumerate((C.generate("enwik", 5, 0, 3001), C.generate("logs", 6, 0, 2222), C.generate("enwik", 7, 0, 1500))):
+            d.SetInput(part); o.set_input(part)
+            got += TW._views(d); ref += TW._odrain(o)
+            if i == 1:
+                d.Flush(); o.flush()
+                got += TW._views(d); ref += TW._odrain(o)
+                assert bytes(got) == bytes(ref) and d.TotalOut == len(got), ("view at a flush", level)
+        d.Finish(); o.finish()
+        buf = np.zeros(7, np.uint8)
+        k = d.Deflate(buf)                                      # a few bytes through the copying call, the rest in place
+        got += buf[:k].tobytes() + TW._views(d); ref += TW._odrain(o)
+        assert bytes(got) == bytes(ref) and d.IsFinished and d.TotalOut == len(got) and d.DeflateView() is None, ("view", level)
+        n += 1
     return n
 
 
