@@ -37,9 +37,10 @@ struct DevBuf {
 // milliseconds) and the streaming objects are short-lived (GZipOutputStream makes a new Deflater per stream, S/GZip/GzipOutputStream.cs:87;
 // InflaterPool resets and reuses).  Blocks a buffer outgrows or leaves behind go to a process-wide pool (SZL_PIN_POOL_MIB, default 4096:
 // what it may hold; 0 = none) and are handed out again, best fit, to whoever asks next.
-uint8_t *pin_alloc(size_t want, size_t *cap_out);    // nullptr: no pinned memory of that size
+uint8_t *pin_alloc(size_t want, size_t *cap_out, bool growing = false);    // nullptr: no pinned memory of that size
 void pin_free(uint8_t *p, size_t cap);
 
+void host_copy(void *dst, const void *src, size_t k);   // memcpy, on several cores when long (szl_engine.hip)
 struct PinVec {
     uint8_t *p = nullptr; size_t n = 0, cap = 0;
     hipStream_t busy = nullptr;                       // a stream with copies out of this memory in flight (synchronised before it moves)

@@ -192,7 +192,7 @@ int DevBuf::ensure(size_t n) {
 }
 int DevBuf::ensure_keep(size_t n, size_t keep, hipStream_t st) {
     if (n <= cap) return 0;
-    const size_t want = std::max(n + (n >> 3) + 256, cap + cap / 2);
+    const size_t want = std::max(n + (n >> 3) + 256, 2 * cap);   // (a buffer that follows a stream being written: few moves)
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, want);
     if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return SZL_E_NOMEM; }
@@ -211,12 +211,18 @@ std::mutex g_pool_mu;
 std::vector<PinBlock> g_pool;
 size_t g_pool_bytes = 0;
 }
-uint8_t *pin_alloc(size_t want, size_t *cap_out) {
+// `growing`: the block is for a vector that has outgrown one already and is long (a stream somebody is still writing): the LARGEST pooled
+// block that fits, so that it does not move again — a gigabyte written through GZipOutputStream used to move six times, a copy of all it
+// held and a wait for the uploads in flight each time.  Otherwise best fit.
+uint8_t *pin_alloc(size_t want, size_t *cap_out, bool growing) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         size_t best = g_pool.size();
-        for (size_t i = 0; i < g_pool.size(); i++)
-            if (g_pool[i].cap >= want && g_pool[i].cap <= 4 * want + (1u << 20) && (best == g_pool.size() || g_pool[i].cap < g_pool[best].cap)) best = i;
+        for (size_t i = 0; i < g_pool.size(); i++) {
+            if (g_pool[i].cap < want) continue;
+            if (growing) { if (best == g_pool.size() || g_pool[i].cap > g_pool[best].cap) best = i; }
+            else if (g_pool[i].cap <= 4 * want + (1u << 20) && (best == g_pool.size() || g_pool[i].cap < g_pool[best].cap)) best = i;
+        }
         if (best != g_pool.size()) {
             const PinBlock b = g_pool[best];
             g_pool.erase(g_pool.begin() + (ptrdiff_t)best);
@@ -244,14 +250,36 @@ void pin_free(uint8_t *p, size_t cap) {
 void PinVec::reserve(size_t want) {
     if (want <= cap) return;
     size_t ncap = 0;
-    uint8_t *q = pin_alloc(std::max(want, 2 * cap), &ncap);
+    uint8_t *q = pin_alloc(std::max(want, 2 * cap), &ncap, cap != 0 && want >= (8u << 20));
     if (!q) throw std::bad_alloc();
     if (busy) (void)hipStreamSynchronize(busy);       // copies out of the old memory
-    if (n) memcpy(q, p, n);
+    host_copy(q, p, n);
     pin_free(p, cap);
     p = q; cap = ncap;
 }
-void PinVec::append(const uint8_t *src, size_t k) { reserve(n + k); if (k) memcpy(p + n, src, k); n += k; }
+// A long host copy on several cores: one core moves ~13 GB/s, which made the copy of SetInput's bytes into pinned memory the longest
+// part of GZipOutputStream over a gigabyte (82 of 190 ms, profiles/r05/write_path.log).  SZL_COPY_THREADS (4; 1 = plain memcpy), pieces of
+// 4 MiB or more only — a thread costs tens of microseconds to start.
+void host_copy(void *dst, const void *src, size_t k) {
+    const size_t MIN_PER_THREAD = 2u << 20;
+    int nt = knob("SZL_COPY_THREADS", 4);
+    if ((size_t)nt > k / MIN_PER_THREAD) nt = (int)(k / MIN_PER_THREAD);
+    if (nt < 2) { if (k) memcpy(dst, src, k); return; }
+    const size_t per = ((k / (size_t)nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    size_t done = per;                                  // (the calling thread takes the first piece)
+    try {
+        for (int t = 1; t < nt && done < k; t++, done += per) {
+            const size_t off = done, len = std::min(per, k - done);
+            th.emplace_back([=] { memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len); });
+        }
+    } catch (...) { /* no more threads: this one does the rest */ }
+    memcpy(dst, src, std::min(per, k));
+    const size_t started = std::min(k, per * (th.size() + 1));
+    if (started < k) memcpy((uint8_t *)dst + started, (const uint8_t *)src + started, k - started);
+    for (auto &t : th) t.join();
+}
+void PinVec::append(const uint8_t *src, size_t k) { reserve(n + k); host_copy(p + n, src, k); n += k; }
 void PinVec::erase_front(size_t k) {
     if (busy) (void)hipStreamSynchronize(busy);
     if (k >= n) { n = 0; return; }

@@ -163,3 +163,30 @@ def test_gzip_output_stream_default_constructor_takes_the_short_way():
     assert zlib.decompress(gz, 31) == data.tobytes()
     assert gz[10:-8] == O.deflate(data, 6, nowrap=True)
     assert len(sink.writes) == 3                             # header, body, trailer — the reference: 10 + ~700 + 8 writes of <= 4096 bytes
+
+
+@pytest.mark.parametrize("threads", [1, 3, 4, 7])
+def test_long_set_input_pieces_arrive_whole(threads):
+    """SetInput copies into pinned memory — on several cores when the piece is long (host_copy, SZL_COPY_THREADS): every byte, in order"""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.deflater import Deflater
+    L = _lib.lib()
+    rng = np.random.default_rng(threads)
+    data = np.concatenate([C.generate("enwik", 21, 0, (29 << 20) + 4099), rng.integers(0, 256, (9 << 20) + 1, dtype=np.uint8)])
+    L.szl_debug_set(b"SZL_COPY_THREADS", threads)
+    try:
+        d = Deflater(6, True)
+        d.EnableCrc32()
+        pos = 0
+        for k in ((8 << 20) + 1, (13 << 20) + 4097, 100, (16 << 20) - 5, data.size):
+            piece = data[pos:pos + k]
+            pos += piece.size
+            d.SetInput(piece)
+            assert d.DeflateView() is None
+            if pos >= data.size:
+                break
+        d.Finish()
+        out = _views(d)
+    finally:
+        L.szl_debug_set(b"SZL_COPY_THREADS", -(2 ** 31))
+    assert zlib.decompress(out, -15) == data.tobytes() and d.Crc32 == zlib.crc32(data.tobytes()) and d.TotalIn == data.size
