@@ -114,8 +114,6 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         std::vector<uint64_t> reg;       // single pass: staging region (first symbol) of each job
         uint64_t reg_cap = 0;            //              and its size in symbols
         std::vector<uint64_t> regc;      //              (per job: a job that overran its region is run again in one of the large ones)
-        std::vector<uint64_t> spare, spare_big;   // unused regions: for the jobs a chain repair adds / for jobs that overran theirs
-        uint64_t big_cap = 0;
         bool alive = true, ok = false, truncated = false;
         uint64_t trunc_bit = 0;          // (piece of a stream) start bit of the dropped last job
         std::vector<uint64_t> ooff, jbase; uint64_t total = 0, end_byte = 0; uint32_t adler_read = 0;
@@ -206,6 +204,10 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     }
     lap("find block starts");
     uint64_t reg_total = 0;              // single pass: symbols of staging handed out so far
+    // unused regions, one pool for all members of the call (round-4 ADVICE: a set per member was +60 % of staging for a member of 32
+    // chunks, and counted against the budget below): `spare` for the jobs a chain repair adds, `spare_big` for jobs that overran theirs
+    std::vector<uint64_t> spare, spare_big;
+    uint64_t spare_cap = 0, big_cap = 0, jobs_total = 0, members = 0;
     for (auto &p : ps) {
         if (!p.alive) continue;
         p.sb.push_back(p.first_bit);
@@ -229,15 +231,18 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 p.regc[j] = std::max<uint64_t>(p.reg_cap, (uint64_t)(1.5 * expand * (double)span) + 65536);
             }
             for (size_t j = 0; j < p.sb.size(); j++) { p.reg[j] = reg_total; reg_total += p.regc[j]; }
-            // a chain that needs repair (a block boundary no candidate start named) or a job whose output outgrew the estimate used to
-            // send the whole member through the count-first form — finder, count passes and symbol pass again (64 x 1 MiB members: 35
-            // of them, +21 ms).  Now the single pass repairs in place: spare regions for the jobs a repair adds, a few large ones for
-            // jobs to be run again with more room; only a member that runs out of those takes the other form.
-            const size_t nsp = p.sb.size() / 4 + 4;
-            for (size_t k = 0; k < nsp; k++) { p.spare.push_back(reg_total); reg_total += p.reg_cap; }
-            p.big_cap = 4 * p.reg_cap;
-            for (int k = 0; k < 2; k++) { p.spare_big.push_back(reg_total); reg_total += p.big_cap; }
+            spare_cap = std::max(spare_cap, p.reg_cap); jobs_total += p.sb.size(); members++;
         }
+    }
+    if (single_pass && members) {
+        // a chain that needs repair (a block boundary no candidate start named) or a job whose output outgrew the estimate used to
+        // send the whole member through the count-first form — finder, count passes and symbol pass again (64 x 1 MiB members: 35
+        // of them, +21 ms).  Now the single pass repairs in place: spare regions for the jobs a repair adds, a few large ones for
+        // jobs to be run again with more room; only a member that finds the pool empty takes the other form.
+        const size_t nsp = (size_t)(jobs_total / 8 + 8), nbig = (size_t)std::max<uint64_t>(2, members / 8);
+        big_cap = 4 * spare_cap;
+        for (size_t k = 0; k < nsp; k++) { spare.push_back(reg_total); reg_total += spare_cap; }
+        for (size_t k = 0; k < nbig; k++) { spare_big.push_back(reg_total); reg_total += big_cap; }
     }
     // Staging is sized from the CALLER's out_cap (an upper bound he chose, possibly an untrusted ISIZE trailer): a generous capacity must
     // not turn into gigabytes of device memory, let alone fail the batch.  Above a budget — 64 symbols per compressed byte plus slack, 8 GiB
@@ -311,9 +316,9 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                     p.truncated = true; p.trunc_bit = p.sb[j];
                     break;
                 }
-                if (single_pass && c.status == INF_OUTPUT_FULL && p.regc[j] < p.big_cap && !p.spare_big.empty()) {
+                if (single_pass && c.status == INF_OUTPUT_FULL && p.regc[j] < big_cap && !spare_big.empty()) {
                     // the job's output outgrew its staging region: again, in a large one; everything behind it keeps what it has
-                    nreg.back() = p.spare_big.back(); p.spare_big.pop_back(); nregc.back() = p.big_cap;
+                    nreg.back() = spare_big.back(); spare_big.pop_back(); nregc.back() = big_cap;
                     ncnt.back() = Cnt{}; nhave.back() = 0;
                     ok = false;
                     for (uint32_t m2 = j + 1; m2 < p.sb.size(); m2++) { nsb.push_back(p.sb[m2]); ncnt.push_back(p.cnt[m2]); nhave.push_back(p.have[m2]); nreg.push_back(p.reg[m2]); nregc.push_back(p.regc[m2]); }
@@ -333,9 +338,9 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 ok = false;
                 if (dbg) fprintf(stderr, "[szl] inflate par: member %zu: job %u (start bit %llu) ended at bit %llu where nobody starts (next listed start: %s%llu) — repair\n",
                                  p.si, j, (unsigned long long)p.sb[j], (unsigned long long)c.end_bit, m < p.sb.size() ? "" : "none ", m < p.sb.size() ? (unsigned long long)p.sb[m] : 0ull);
-                if (single_pass && p.spare.empty()) { p.alive = false; if (retry) retry->push_back(p.si); break; }
+                if (single_pass && spare.empty()) { p.alive = false; if (retry) retry->push_back(p.si); break; }
                 nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
-                if (single_pass) { nreg.push_back(p.spare.back()); p.spare.pop_back(); nregc.push_back(p.reg_cap); }
+                if (single_pass) { nreg.push_back(spare.back()); spare.pop_back(); nregc.push_back(spare_cap); }
                 for (; m < p.sb.size(); m++) {
                     nsb.push_back(p.sb[m]); ncnt.push_back(p.cnt[m]); nhave.push_back(p.have[m]);
                     if (single_pass) { nreg.push_back(p.reg[m]); nregc.push_back(p.regc[m]); }
@@ -1043,7 +1048,7 @@ static int inflater_step(szl_inflater *s) {
     size_t nup = std::min<size_t>(nin, szl_inflater::IN_STEP);
     if (s->exact_live && nup < nin && ((nin - nup) & 1)) nup--;   // (the exact decoder's odd-byte rule looks at the parity of the input's end, CS/StreamManipulator.cs:216-222)
     InfJob j{};
-    j.in_off = 0; j.in_len = nup; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK;
+    j.in_off = 0; j.in_len = nup; j.out_off = 0; j.out_cap = szl_inflater::OUT_CHUNK; j.in_more = nup < nin ? 1u : 0u;
     j.window = (uint8_t *)s->d_win.p; j.zlib = s->no_header ? 0 : 1; j.keep_window = 1; j.load_window = s->have_dict ? 1 : 0;
     j.stop_at_header = bulk && s->given > s->bulk_skip_given && !(s->st.mode == INF_M_HEADER && s->dec_status == INF_CHUNK_END) ? 1u : 0u;
     InfJob *hj = (InfJob *)s->h_ctl; InfState *hs = (InfState *)(s->h_ctl + sizeof(InfJob));

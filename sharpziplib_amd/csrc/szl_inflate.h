@@ -37,6 +37,9 @@ struct InfJob {
     uint32_t dbg_partok;  // [out] tokens of those rounds
     uint32_t stop_at_header; // 1: stop with INF_CHUNK_END as soon as the decoder stands at a block header (the streaming object brings the
                              // stream to a block boundary before it hands a long input to the chunk-parallel decoder)
+    uint32_t in_more;        // 1: the caller holds more input behind in_len (the streaming object uploads a bounded prefix per step): where the
+                             // reference's GetSymbol would look at bits past in_len the decoder stops with INF_NEED_INPUT instead of applying the
+                             // "fewer than 9 bits left: an empty slot reads as symbol 0, 0 bits" rule, which is for the END of the input only
 };
 
 struct InfState {

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                     // k_inflate_exact's): GetSymbol throws when it can peek 9 bits and reads the empty slot as "symbol 0, 0 bits" when it
                     // cannot (C/InflaterHuffmanTree.cs:184-193 vs :224-233).  (A chunk job of the parallel path has no output bound in its
                     // count pass: there anything odd is an error, and the member goes to the one-wavefront decoder.)
-                    if (r < 0) { if (avail >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; } r = 0; }
+                    if (r < 0) { if (avail >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; } if (job.in_more) { ev = EV_STOP; ea = INF_NEED_INPUT; break; } r = 0; }
                     const uint32_t sl = (uint32_t)r >> 16, sym = (uint32_t)r & 0xFFFF;
                     if (avail < sl) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                     if (sym < 256) {
@@ -552,6 +552,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                     if (rd < 0) {                                      // (see the literal/length code above)
                         if (avail < used) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                         if (avail - used >= 9 || PMODE) { ev = EV_STOP; ea = SZL_E_CODELEN_ZERO; break; }
+                        if (job.in_more) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }   // (only a prefix of the caller's input is here)
                         rd = 0;
                     }
                     const uint32_t dl = (uint32_t)rd >> 16, dsym = (uint32_t)rd & 0xFFFF;
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                             // no code for these bits: GetSymbol throws when it can peek 9 bits (C/InflaterHuffmanTree.cs:191-193) and reads the
                             // empty slot as "symbol 0, 0 bits" when it cannot (:224-233) — a code length of 0 that consumes nothing
                             if (e == 0 && (rem >= 9 || PMODE)) { fail = SZL_E_CODELEN_ZERO; break; }
+                            if (e == 0 && job.in_more) { fail = 1; break; }   // (the rule below is for the end of the caller's input, not of the uploaded prefix)
                             const uint32_t sl = e & 15, sym = e >> 4;
                             const uint32_t xb = sym < 16 ? 0 : (sym == 16 ? 2 : (sym == 17 ? 3 : 7));
                             if (rem < sl + xb) { fail = 1; break; }
