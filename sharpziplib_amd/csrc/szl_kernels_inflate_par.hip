@@ -323,7 +323,11 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
     }
 }
 
-// symbols -> bytes; one workgroup per 16 KiB of a member's output (blk0 = the member's first workgroup)
+// symbols -> bytes; one workgroup per 16 KiB of a member's output (blk0 = the member's first workgroup).  A thread takes 16 consecutive
+// bytes per step: two 16-byte loads of symbols (their address is only 2-byte aligned: the hardware's unaligned access mode), the low
+// bytes packed, one 16-byte store — it used to be one 2-byte load and one 1-byte store per thread and step, 0.86 TB/s of the chip's 8
+// (3.75 ms per GiB of output).  Symbols that name the window in front of their job (0x8000 | i) are looked up byte by byte, and so are
+// the 16 bytes that straddle two jobs or end the member.
 __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,
                                                  const uint64_t *__restrict__ jbase_all, const uint8_t *__restrict__ wins_all,
                                                  uint8_t *__restrict__ out_base, const ParMember *__restrict__ mem, uint32_t nmem) {
@@ -342,10 +346,39 @@ __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sy
     uint32_t lo = 0, hi = njobs;                                   // last job with out_off <= b0
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (out_off[mid] <= b0) lo = mid; else hi = mid; }
     uint32_t j = lo;
-    for (uint64_t q = b0 + threadIdx.x; q < b1; q += 256) {
+    for (uint64_t q = b0 + 16ull * threadIdx.x; q < b1; q += 16ull * 256) {
         while (j + 1 < njobs && out_off[j + 1] <= q) j++;
-        const uint32_t sv = sym[jbase[j] + (q - out_off[j])];
-        out[q] = sv < 0x8000u ? (uint8_t)sv : wins[(uint64_t)j * 32768 + (sv & 0x7FFF)];   // window in front of job j = W_{j-1}
+        const uint64_t jend = j + 1 < njobs ? out_off[j + 1] : total;      // job j's bytes end here
+        if (q + 16 <= b1 && q + 16 <= jend) {
+            const uint16_t *sp = sym + jbase[j] + (q - out_off[j]);
+            uint4 s0, s1;
+            __builtin_memcpy(&s0, sp, 16); __builtin_memcpy(&s1, sp + 8, 16);
+            uint32_t w[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            if (((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) & 0x80008000u) != 0) {
+                const uint8_t *win = wins + (uint64_t)j * 32768;          // window in front of job j = W_{j-1}
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    uint32_t sa = w[k] & 0xFFFFu, sb = w[k] >> 16;
+                    if (sa & 0x8000u) sa = win[sa & 0x7FFFu];
+                    if (sb & 0x8000u) sb = win[sb & 0x7FFFu];
+                    w[k] = sa | (sb << 16);
+                }
+            }
+            uint4 o;
+            o.x = (w[0] & 0xFFu) | ((w[0] >> 8) & 0xFF00u) | ((w[1] & 0xFFu) << 16) | ((w[1] << 8) & 0xFF000000u);
+            o.y = (w[2] & 0xFFu) | ((w[2] >> 8) & 0xFF00u) | ((w[3] & 0xFFu) << 16) | ((w[3] << 8) & 0xFF000000u);
+            o.z = (w[4] & 0xFFu) | ((w[4] >> 8) & 0xFF00u) | ((w[5] & 0xFFu) << 16) | ((w[5] << 8) & 0xFF000000u);
+            o.w = (w[6] & 0xFFu) | ((w[6] >> 8) & 0xFF00u) | ((w[7] & 0xFFu) << 16) | ((w[7] << 8) & 0xFF000000u);
+            __builtin_memcpy(out + q, &o, 16);
+        } else {
+            uint32_t jj = j;
+            const uint64_t e = q + 16 < b1 ? q + 16 : b1;
+            for (uint64_t r = q; r < e; r++) {
+                while (jj + 1 < njobs && out_off[jj + 1] <= r) jj++;
+                const uint32_t sv = sym[jbase[jj] + (r - out_off[jj])];
+                out[r] = sv < 0x8000u ? (uint8_t)sv : wins[(uint64_t)jj * 32768 + (sv & 0x7FFF)];
+            }
+        }
     }
 }
 
