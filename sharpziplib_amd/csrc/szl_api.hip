@@ -17,9 +17,46 @@
 using namespace szl;
 
 namespace szl { uint32_t links_guard_trips(); }
-struct szl_engine { Engine e; };
 
 static thread_local int g_device = 0;
+
+namespace { std::mutex g_idle_mu; std::vector<szl_engine *> g_idle; }
+namespace szl {
+szl_engine *engine_take() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_idle_mu);
+        for (size_t i = g_idle.size(); i-- > 0;)
+            if (g_idle[i]->device == dev) { szl_engine *e = g_idle[i]; g_idle.erase(g_idle.begin() + (ptrdiff_t)i); return e; }
+    }
+    return szl_engine_create();
+}
+void engine_give(szl_engine *e) {
+    if (!e) return;
+    Engine &E = e->e;                                    // what a call may have left set (the callers clear these themselves; belt and braces)
+    E.in_ready = nullptr; E.part = Engine::PartRun{}; E.sw_pos_in.clear(); E.sw_P_in.clear(); E.fast_hist_in.clear(); E.fast_tail_bits.clear();
+    E.fast_want_tail = false; E.match_mode_override = -1;
+    const int keep = knob("SZL_ENGINE_POOL", 2);
+    {
+        std::lock_guard<std::mutex> lk(g_idle_mu);
+        if ((int)g_idle.size() < keep) { g_idle.push_back(e); return; }
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != e->device) (void)hipSetDevice(e->device);
+    szl_engine_destroy(e);
+    if (cur != e->device) (void)hipSetDevice(cur);
+}
+void engine_pool_release() {
+    std::vector<szl_engine *> idle;
+    { std::lock_guard<std::mutex> lk(g_idle_mu); idle.swap(g_idle); }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (szl_engine *e : idle) { (void)hipSetDevice(e->device); szl_engine_destroy(e); }
+    (void)hipSetDevice(cur);
+}
+}
 
 extern "C" {
 
@@ -74,9 +111,15 @@ uint64_t szl_deflate_bound(uint64_t n) {
 
 szl_engine *szl_engine_create(void) {
     if (szl_device_count() <= 0) { set_error("no gfx950 device available"); return nullptr; }
-    return new (std::nothrow) szl_engine();
+    szl_engine *e = new (std::nothrow) szl_engine();
+    if (e) (void)hipGetDevice(&e->device);
+    return e;
 }
-void szl_engine_destroy(szl_engine *e) { delete e; }
+void szl_engine_destroy(szl_engine *e) {
+    if (!e) return;
+    e->io_a.release(); e->io_b.release(); e->io_c.release(); e->io_d.release();
+    delete e;
+}
 
 int szl_engine_last_timing(const szl_engine *e, szl_timing *t) {
     if (!e || !t) return SZL_E_ARG;
@@ -607,7 +650,8 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     return 0;
 }
 
-int szl_multi_release(void) {   // the engines (and their device memory) the multi-device entry points keep between calls
+int szl_multi_release(void) {   // the engines (and their device memory) the multi-device entry points and the streaming objects' pool keep between calls
+    engine_pool_release();
     std::lock_guard<std::mutex> multi_lock(g_multi_mu);
     for (auto &slot : g_multi_slots) if (slot.eng) { if (slot.device >= 0) (void)hipSetDevice(slot.device); szl_engine_destroy(slot.eng); slot.eng = nullptr; slot.device = -1; }
     (void)hipSetDevice(g_device);
@@ -774,8 +818,9 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
     else if (level < 0 || level > 9) { set_error("level out of range"); return nullptr; } // C/Deflater.cs:184-187
     szl_deflater *d = new (std::nothrow) szl_deflater();
     if (!d) return nullptr;
-    d->eng = szl_engine_create();
+    d->eng = engine_take();
     if (!d->eng) { delete d; return nullptr; }
+    std::swap(d->d_in, d->eng->io_a); std::swap(d->d_out, d->eng->io_b);   // (the last owner's device buffers come with a pooled engine)
     d->level = level; d->nowrap = nowrap ? 1 : 0;
     deflater_clear(d);
     return d;
@@ -783,8 +828,10 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
 void szl_deflater_destroy(szl_deflater *d) {
     if (!d) return;
     if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); d->pend.busy = nullptr; (void)hipStreamDestroy(d->up_stream); d->up_stream = nullptr; }   // (the buffers' destructors must not wait on a stream that is gone)
-    d->d_in.release(); d->d_out.release();
-    szl_engine_destroy(d->eng);
+    // (nothing of this object is in flight when its engine changes hands: every engine call ends with its stream synchronised, and the
+    // uploads' stream was synchronised above)
+    std::swap(d->d_in, d->eng->io_a); std::swap(d->d_out, d->eng->io_b);
+    engine_give(d->eng);
     delete d;
 }
 static int function_switch(szl_deflater *d, int level);

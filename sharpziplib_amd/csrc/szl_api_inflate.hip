@@ -29,7 +29,6 @@ int launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_
 void launch_convert(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, const uint8_t *wins, uint8_t *out_base, const ParMember *mem,
                     uint32_t nmem, uint32_t nblocks, hipStream_t st);
 }
-struct szl_engine { Engine e; };
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return SZL_E_DEVICE; } } while (0)
 
@@ -806,11 +805,15 @@ szl_inflater *szl_inflater_create(int no_header) {
 void szl_inflater_destroy(szl_inflater *s) {
     if (!s) return;
     s->d_in.release(); s->d_out.release(); s->d_win.release(); s->d_job.release(); s->d_state.release(); s->d_ctl.release();
-    s->d_bulk_in.release(); s->d_bulk_out.release(); s->d_win_lin.release(); s->d_ex.release();
-    if (s->eng) szl_engine_destroy(s->eng);
+    s->d_win_lin.release(); s->d_ex.release();
+    if (s->strm) { (void)hipStreamSynchronize(s->strm); (void)hipStreamDestroy(s->strm); }
+    if (s->eng) {   // the engine goes back to the pool with the two long device buffers of this object (szl_engine.h)
+        std::swap(s->d_bulk_in, s->eng->io_c); std::swap(s->d_bulk_out, s->eng->io_d);
+        engine_give(s->eng);
+    }
+    s->d_bulk_in.release(); s->d_bulk_out.release();
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     s->hin.release(); s->pend.release();
-    if (s->strm) { (void)hipStreamSynchronize(s->strm); (void)hipStreamDestroy(s->strm); }
     delete s;
 }
 int szl_inflater_reset(szl_inflater *s) { if (!s) return SZL_E_ARG; inflater_clear(s); return 0; }
@@ -944,7 +947,10 @@ enum : int { BULK_OUT_DEFAULT_MIB = 512 };
 static int inflater_bulk(szl_inflater *s) {
     int rc;
     const size_t nin = s->hin.size() - s->hin_pos;
-    if (!s->eng && !(s->eng = szl_engine_create())) return SZL_E_NOMEM;
+    if (!s->eng) {
+        if (!(s->eng = engine_take())) return SZL_E_NOMEM;
+        std::swap(s->d_bulk_in, s->eng->io_c); std::swap(s->d_bulk_out, s->eng->io_d);   // (a pooled engine brings the last owner's buffers)
+    }
     if (!s->strm) HIPCHK(hipStreamCreateWithFlags(&s->strm, hipStreamNonBlocking));
     hipStream_t st = s->strm;
     Engine &E = s->eng->e;

@@ -141,3 +141,22 @@ class Engine {
 };
 
 } // namespace szl
+
+// The handle behind szl_engine_create (include/szl.h): an Engine, the device it lives on, and — for the streaming objects, which take their
+// engine from a pool (szl_api.hip: engine_take / engine_give) — the object's long device buffers while no object owns it.
+struct szl_engine {
+    szl::Engine e;
+    int device = 0;
+    szl::DevBuf io_a, io_b, io_c, io_d;   // Deflater: d_in, d_out; Inflater: d_bulk_in, d_bulk_out
+};
+namespace szl {
+// A streaming Deflater / Inflater is often short-lived — GZipOutputStream makes a new Deflater per stream (S/GZip/GzipOutputStream.cs:87),
+// GZipInputStream a new Inflater (S/GZip/GzipInputStream.cs:86) — and its engine's work space is not: ~19 bytes of device memory per input
+// byte of the longest stream it has compressed, whose allocation cost a fresh object 20-800 ms of its first Finish()
+// (profiles/r05/finish_breakdown.log).  Engines the streaming objects give back are kept, work space and all — SZL_ENGINE_POOL of them per
+// process (2; 0: none); szl_multi_release() frees them.
+szl_engine *engine_take();
+void engine_give(szl_engine *e);
+void engine_pool_release();
+}
+

@@ -190,3 +190,36 @@ def test_long_set_input_pieces_arrive_whole(threads):
     finally:
         L.szl_debug_set(b"SZL_COPY_THREADS", -(2 ** 31))
     assert zlib.decompress(out, -15) == data.tobytes() and d.Crc32 == zlib.crc32(data.tobytes()) and d.TotalIn == data.size
+
+
+def test_engines_of_streaming_objects_are_pooled_and_change_hands_cleanly():
+    """A streaming object's engine (work space included) goes back to a pool when the object dies and is the next object's: streams of other
+    levels, framings, directions and sizes through a sequence of short-lived objects come out as from fresh ones; SZL_ENGINE_POOL=0 and
+    szl_multi_release() give the memory back"""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.deflater import Deflater
+    from sharpziplib_amd.inflater import Inflater
+    L = _lib.lib()
+    big = C.generate("enwik", 31, 0, 6 << 20)
+    small = C.generate("logs", 32, 0, 70000)
+    for rep in range(2):
+        for level, nowrap, data in ((6, True, big), (1, False, small), (9, True, small), (0, False, small), (6, False, big[:300000]), (4, True, big[:500000])):
+            d = Deflater(level, nowrap)                      # (takes the engine the previous object left)
+            d.SetInput(data); d.Finish()
+            out = _views(d)
+            del d
+            assert out == O.deflate(data, level, nowrap=nowrap), (rep, level, nowrap)
+            inf = Inflater(nowrap)
+            inf.SetInput(np.frombuffer(out, np.uint8))
+            back = bytearray()
+            buf = np.zeros(1 << 20, np.uint8)
+            while not inf.IsFinished:
+                k = inf.Inflate(buf)
+                assert k > 0 or inf.IsFinished
+                back += buf[:k].tobytes()
+            del inf
+            assert bytes(back) == data.tobytes()
+        if rep == 0:
+            assert L.szl_multi_release() == 0                # the pool is emptied: the second round starts from nothing
+            L.szl_debug_set(b"SZL_ENGINE_POOL", 0)           # ... and keeps nothing
+    L.szl_debug_set(b"SZL_ENGINE_POOL", -(2 ** 31))
