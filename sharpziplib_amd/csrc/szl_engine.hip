@@ -363,9 +363,13 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     span_len = (span_len + 63) & ~63ull;
     // Stage C walks each range serially (one lane per range): a small call gets shorter ranges, i.e. more lanes and shorter
     // walks — the latency of ONE 64 KiB entry through the streaming object is dominated by that walk otherwise (2.1 of 3.2 ms)
+    // (256 Ki ranges fill the device: 256 CUs x 64 lanes x 16 wavefronts.  Round 5: the rule said 64 Ki, i.e. four wavefronts per CU, and
+    // a launch is as long as ONE range's walk — 3.3 ms for 4096 positions — however few of them there are: a 256 MiB window of the window
+    // pipeline spent 3.3 ms in k_spec_win where 1 GiB in one piece spends 4.3)
+    constexpr uint64_t FILL_RANGES = 262144;
     uint32_t range_len = C_RANGE;
     if (SZL_LABKNOB("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)SZL_LABKNOB("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
-    else while (range_len > 256 && total_emit / range_len < 65536) range_len >>= 1;   // (≈64 Ki ranges fill the device: 256 CUs x 64 lanes x a few waves)
+    else while (range_len > 256 && total_emit / range_len < FILL_RANGES) range_len >>= 1;
     // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
     bool m3 = !P.fast && use_match3(P);
     if (!sw_pos_in.empty()) {   // SetLevel / SetStrategy inside the (single) segment: any number of changes, carried in device arrays
@@ -797,7 +801,9 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
     if (!pin) HIPCHK(hipHostMalloc((void **)&pin, 256, hipHostMallocDefault));
     const int64_t S0 = seg.seg_start, N = seg.seg_end;           // the real segment [S0, N) inside its stream buffer
     const uint64_t n = (uint64_t)(N - S0);
-    seg.look_end = N; seg.range_off = 0; seg.vis_word_off = 0; seg.range_len = C_RANGE;
+    uint32_t range_len = C_RANGE;                                 // (as in deflate_impl: enough ranges per window to fill the device)
+    while (range_len > 256 && window / range_len < 262144) range_len >>= 1;
+    seg.look_end = N; seg.range_off = 0; seg.vis_word_off = 0; seg.range_len = range_len;
     // part of a stream (PartRun): ranges end at NP, not at the end of the bytes the engine sees; no stage D here
     const bool is_part = part.active;
     const int64_t NP = is_part ? part.parse_end : N;
@@ -842,7 +848,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         launch_checksums(d_in, dseg_real, 1, (const uint64_t *)ckoff.p, 0, ckparts.p, dso, 0, st); // seeds the running values
     }
     size_t cub_bytes = 0;
-    const uint64_t max_ranges = (window + window / 4) / C_RANGE + 2;
+    const uint64_t max_ranges = (window + window / 4) / range_len + 2;
     if ((rc = counts.ensure((max_ranges + 2) * 4)) || (rc = range_tok.ensure((max_ranges + 2) * 8)) || (rc = ranges.ensure((max_ranges + 1) * sizeof(RangeDev))) ||
         (rc = bad_slot.ensure((max_ranges + 2) * 4)) || (rc = bad_range.ensure((max_ranges + 2) * 8))) return rc;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(max_ranges + 1), st));
@@ -884,7 +890,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         SegDev w = seg;
         w.seg_start = e; w.seg_end = wend; w.look_end = N;
         const uint64_t wn = (uint64_t)(wend - e);
-        const uint64_t nranges = (wn + C_RANGE - 1) / C_RANGE;
+        const uint64_t nranges = (wn + range_len - 1) / range_len;
         w.range_cnt = (uint32_t)nranges;
         if (nranges > max_ranges) { set_error("window bookkeeping"); return SZL_E_STATE; }
         HIPCHK(hipMemcpyAsync((void *)dseg_win, &w, sizeof w, hipMemcpyHostToDevice, st));
