@@ -204,9 +204,10 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     lap("find block starts");
     uint64_t reg_total = 0;              // single pass: symbols of staging handed out so far
     // unused regions, one pool for all members of the call (round-4 ADVICE: a set per member was +60 % of staging for a member of 32
-    // chunks, and counted against the budget below): `spare` for the jobs a chain repair adds, `spare_big` for jobs that overran theirs
-    std::vector<uint64_t> spare, spare_big;
-    uint64_t spare_cap = 0, big_cap = 0, jobs_total = 0, members = 0;
+    // chunks, and counted against the budget below) — and since the regions asked of it differ (a job a chain repair adds may span
+    // megabytes of stored blocks; a job that overran wants four times what it had) it is a heap, not a set of regions of one size
+    uint64_t heap_at = 0, heap_end = 0, spare_cap = 0, jobs_total = 0, members = 0;
+    auto heap_take = [&](uint64_t need, uint64_t *at) -> bool { if (heap_end - heap_at < need) return false; *at = heap_at; heap_at += need; return true; };
     for (auto &p : ps) {
         if (!p.alive) continue;
         p.sb.push_back(p.first_bit);
@@ -227,7 +228,12 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             for (size_t j = 0; j < p.sb.size(); j++) {
                 const uint64_t end_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : s.in_len * 8;
                 const uint64_t span = (end_bit > p.sb[j] ? end_bit - p.sb[j] : 0) / 8 + 1;
-                p.regc[j] = std::max<uint64_t>(p.reg_cap, (uint64_t)(1.5 * expand * (double)span) + 65536);
+                // ... and where a header turned up within a chunk or two, the bytes compress — text 3 x, logs 15 x — whatever the member's
+                // average says: a member of incompressible stretches (stored blocks, no dynamic header for megabytes) and text averages
+                // 1.1, its text jobs overran regions sized for that one after the other, and the member went through the count-first
+                // form after a wasted single pass (240 MiB of 4 MiB random + 1 MiB text: 99 ms; profiles/r05/stored_inflate.log)
+                const double ex = span <= 5 * p.chunk_bytes / 2 ? std::max(1.5 * expand, 4.0) : 1.5 * expand;
+                p.regc[j] = std::max<uint64_t>(p.reg_cap, (uint64_t)(ex * (double)span) + 65536);
             }
             for (size_t j = 0; j < p.sb.size(); j++) { p.reg[j] = reg_total; reg_total += p.regc[j]; }
             spare_cap = std::max(spare_cap, p.reg_cap); jobs_total += p.sb.size(); members++;
@@ -238,10 +244,9 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         // send the whole member through the count-first form — finder, count passes and symbol pass again (64 x 1 MiB members: 35
         // of them, +21 ms).  Now the single pass repairs in place: spare regions for the jobs a repair adds, a few large ones for
         // jobs to be run again with more room; only a member that finds the pool empty takes the other form.
-        const size_t nsp = (size_t)(jobs_total / 8 + 8), nbig = (size_t)std::max<uint64_t>(2, members / 8);
-        big_cap = 4 * spare_cap;
-        for (size_t k = 0; k < nsp; k++) { spare.push_back(reg_total); reg_total += spare_cap; }
-        for (size_t k = 0; k < nbig; k++) { spare_big.push_back(reg_total); reg_total += big_cap; }
+        const uint64_t nsp = jobs_total / 8 + 8, nbig = std::max<uint64_t>(2, members / 8);
+        const uint64_t heap = std::max<uint64_t>(nsp * spare_cap + nbig * 4 * spare_cap, reg_total / 4);
+        heap_at = reg_total; heap_end = reg_total + heap; reg_total += heap;
     }
     // Staging is sized from the CALLER's out_cap (an upper bound he chose, possibly an untrusted ISIZE trailer): a generous capacity must
     // not turn into gigabytes of device memory, let alone fail the batch.  Above a budget — 64 symbols per compressed byte plus slack, and
@@ -320,9 +325,10 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                     p.truncated = true; p.trunc_bit = p.sb[j];
                     break;
                 }
-                if (single_pass && c.status == INF_OUTPUT_FULL && p.regc[j] < big_cap && !spare_big.empty()) {
-                    // the job's output outgrew its staging region: again, in a large one; everything behind it keeps what it has
-                    nreg.back() = spare_big.back(); spare_big.pop_back(); nregc.back() = big_cap;
+                uint64_t bigger = 0;
+                if (single_pass && c.status == INF_OUTPUT_FULL && heap_take(4 * p.regc[j], &bigger)) {
+                    // the job's output outgrew its staging region: again, in one four times as large; everything behind it keeps what it has
+                    nreg.back() = bigger; nregc.back() = 4 * p.regc[j];
                     ncnt.back() = Cnt{}; nhave.back() = 0;
                     ok = false;
                     for (uint32_t m2 = j + 1; m2 < p.sb.size(); m2++) { nsb.push_back(p.sb[m2]); ncnt.push_back(p.cnt[m2]); nhave.push_back(p.have[m2]); nreg.push_back(p.reg[m2]); nregc.push_back(p.regc[m2]); }
@@ -342,9 +348,18 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 ok = false;
                 if (dbg) fprintf(stderr, "[szl] inflate par: member %zu: job %u (start bit %llu) ended at bit %llu where nobody starts (next listed start: %s%llu) — repair\n",
                                  p.si, j, (unsigned long long)p.sb[j], (unsigned long long)c.end_bit, m < p.sb.size() ? "" : "none ", m < p.sb.size() ? (unsigned long long)p.sb[m] : 0ull);
-                if (single_pass && spare.empty()) { p.alive = false; if (retry) retry->push_back(p.si); break; }
+                uint64_t fresh = 0, fresh_cap = 0;
+                if (single_pass) {                               // the new job's region: sized by its span like everybody's
+                    const szl_stream &sm_s = streams[p.si];
+                    const double expand = (double)sm_s.out_cap / (double)sm_s.in_len;
+                    const uint64_t nend = m < p.sb.size() ? p.sb[m] : sm_s.in_len * 8;
+                    const uint64_t span = (nend > c.end_bit ? nend - c.end_bit : 0) / 8 + 1;
+                    const double ex = span <= 5 * p.chunk_bytes / 2 ? std::max(1.5 * expand, 4.0) : 1.5 * expand;
+                    fresh_cap = std::max<uint64_t>(p.reg_cap, (uint64_t)(ex * (double)span) + 65536);
+                    if (!heap_take(fresh_cap, &fresh)) { p.alive = false; if (retry) retry->push_back(p.si); break; }
+                }
                 nsb.push_back(c.end_bit); ncnt.push_back(Cnt{}); nhave.push_back(0);
-                if (single_pass) { nreg.push_back(spare.back()); spare.pop_back(); nregc.push_back(spare_cap); }
+                if (single_pass) { nreg.push_back(fresh); nregc.push_back(fresh_cap); }
                 for (; m < p.sb.size(); m++) {
                     nsb.push_back(p.sb[m]); ncnt.push_back(p.cnt[m]); nhave.push_back(p.have[m]);
                     if (single_pass) { nreg.push_back(p.reg[m]); nregc.push_back(p.regc[m]); }

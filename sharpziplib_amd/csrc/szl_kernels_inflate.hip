@@ -575,13 +575,11 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                     const uint64_t bp = bitpos >> 3;
                     const uint64_t can_in = job.in_len > bp ? job.in_len - bp : 0;
                     const uint64_t can_out = out_limit - outpos;
-                    const uint64_t room = (SHORTWIN ? ROOM : (uint64_t)(I_WIN - 512)) - (outpos - flushed);
                     uint64_t n = stored_left;
                     if (n > can_in) n = can_in;
                     if (n > can_out) n = can_out;
                     if (n == 0) { ev = EV_STOP; ea = can_in == 0 ? INF_NEED_INPUT : INF_OUTPUT_FULL; break; }
-                    if (n > room) n = room;    // room >= 16 KiB - 512: the window is flushed whenever it is half full
-                    ev = EV_STORED; ea = (int)n; eb = 0;
+                    ev = EV_STORED; ea = (int)n; eb = 0;     // (not bounded by the window's room: the bytes go from the input to the output, see EV_STORED)
                     stored_left -= (uint32_t)n;
                     break;
                 }
@@ -815,15 +813,89 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
             load_second_level();
             break;
         case EV_STORED: {
-            const uint64_t n = (uint32_t)ea;
+            uint64_t n = (uint32_t)ea;
             uint64_t bp = 0;
             { // lane 0 holds bitpos: broadcast the byte position of the stored data
                 uint64_t v = bitpos >> 3;
                 bp = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
             }
-            if (PMODE != 1) for (uint64_t i = lane; i < n; i += 64) S.win[(outpos + i) & I_WMASK] = (WT)in[bp + i];
-            outpos += n;
-            if (lane == 0) { bitpos += 8 * n; bb = 0; nb = 0; }
+            uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_left);   // of THIS block, behind the n bytes taken now
+            uint32_t lastb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lastblk);
+            // Stored bytes go straight from the input to the output, 16 per lane and step (an incompressible member is nothing but such
+            // blocks: through the window, a byte per lane, one wavefront moved 290 MiB/s — 3.6 s per GiB); the window then takes the
+            // block's last WIN bytes, which is all a later match can reach (CS/OutputWindow.cs:98-110 CopyStored).  And a stored block
+            // that is followed by another one (data that does not compress comes as runs of them: 16 KiB each from a level 5-9 encoder)
+            // is followed at once — its header is five bytes at a known place — instead of three rounds through lane 0's careful path
+            // per block (restage, header, event): 15 us per 16 KiB block, 1 GiB/s.
+            const uint64_t run_start = outpos;
+            for (;;) {
+                const bool look = left == 0 && !lastb && bp + n + 5 <= job.in_len;   // the next header is all there
+                uint32_t hb[5] = {0, 0, 0, 0, 0};
+                if (look) {                                                 // (asked for before the copy: its latency hides behind it)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) hb[k] = in[bp + n + k];
+                }
+                if (PMODE != 1) {
+                    flush(outpos);                                         // what the window still holds comes first
+                    if (PMODE == 2) {
+                        uint16_t *dst = job.sym_out + outpos;
+                        uint64_t i = 16ull * lane;
+                        for (; i + 16 <= n; i += 1024) {
+                            uint4 v; __builtin_memcpy(&v, in + bp + i, 16);
+                            uint4 a, b;
+                            a.x = (v.x & 0xFFu) | ((v.x & 0xFF00u) << 8); a.y = ((v.x >> 16) & 0xFFu) | ((v.x >> 8) & 0xFF0000u);
+                            a.z = (v.y & 0xFFu) | ((v.y & 0xFF00u) << 8); a.w = ((v.y >> 16) & 0xFFu) | ((v.y >> 8) & 0xFF0000u);
+                            b.x = (v.z & 0xFFu) | ((v.z & 0xFF00u) << 8); b.y = ((v.z >> 16) & 0xFFu) | ((v.z >> 8) & 0xFF0000u);
+                            b.z = (v.w & 0xFFu) | ((v.w & 0xFF00u) << 8); b.w = ((v.w >> 16) & 0xFFu) | ((v.w >> 8) & 0xFF0000u);
+                            __builtin_memcpy(dst + i, &a, 16); __builtin_memcpy(dst + i + 8, &b, 16);
+                        }
+                        for (uint64_t k = (n & ~15ull) + lane; k < n; k += 64) dst[k] = (uint16_t)in[bp + k];
+                    } else {
+                        uint8_t *dst = out + (outpos - out_start);
+                        uint64_t i = 16ull * lane;
+                        for (; i + 16 + 7168 <= n; i += 8192) {            // eight loads in flight per lane (one wavefront: latency is all there is)
+                            uint4 v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) __builtin_memcpy(&v[u], in + bp + i + 1024 * u, 16);
+#pragma unroll
+                            for (int u = 0; u < 8; u++) __builtin_memcpy(dst + i + 1024 * u, &v[u], 16);
+                        }
+                        for (; i + 16 <= n; i += 1024) { uint4 v; __builtin_memcpy(&v, in + bp + i, 16); __builtin_memcpy(dst + i, &v, 16); }
+                        for (uint64_t k = (n & ~15ull) + lane; k < n; k += 64) dst[k] = in[bp + k];
+                    }
+                }
+                flushed = outpos + n;
+                outpos += n;
+                bp += n;
+                if (!look) break;
+                // the header behind the block (byte aligned: C/Inflater.cs:490 SkipToByteBoundary ... :509-512): taken here only if it is
+                // another stored block that is all there and fits; anything else is the careful path's
+                const uint32_t t = hb[0] & 7u;
+                if ((t >> 1) != 0) break;
+                if (PMODE && 8 * bp >= job.stop_bit) break;                // (a chunk job ends at its stop)
+                if (PMODE == 0 && job.stop_at_header) break;
+                const uint32_t len = hb[1] | (hb[2] << 8), nlen = hb[3] | (hb[4] << 8);
+                if (nlen != (len ^ 0xFFFFu)) break;
+                if (bp + 5 + len > job.in_len || outpos + len > out_limit) break;
+                lastb |= t & 1u;
+                bp += 5; n = len; left = 0;
+            }
+            if (PMODE != 1) {
+                // the window: the last WIN bytes of the run, read back from where they went (workgroup scope orders this wavefront's own
+                // stores and loads, as for the far reads behind flush())
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                const uint64_t run = outpos - run_start, m = run < (uint64_t)WIN ? run : (uint64_t)WIN;
+                const uint64_t p0 = outpos - m;
+#pragma unroll 8
+                for (uint64_t k = lane; k < m; k += 64) {
+                    WT v;
+                    if (PMODE == 2) v = (WT)__hip_atomic_load(job.sym_out + p0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else v = (WT)__hip_atomic_load(out + (p0 - out_start) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    S.win[(p0 + k) & I_WMASK] = v;
+                }
+            }
+            // (all lanes compute the same; lane 0's copy is the decoder's)
+            bitpos = 8 * bp; bb = 0; nb = 0; stored_left = left; lastblk = lastb;
             sbase = ~0ull; // force a restage at the new position
         } break;
         case EV_STOP:

@@ -103,6 +103,49 @@ def test_stored_and_flush_blocks(eng):
     assert rp[0].status == 0 and rp[0].data == data and rp[1] == len(stream)
 
 
+def test_runs_of_stored_blocks_are_followed_without_leaving_the_copy(eng):
+    """data that does not compress comes as runs of stored blocks — 16 KiB each from a level 5-9 encoder, 64 KiB from level 0, empty ones at
+    every sync flush: the decoder follows a run inside its copy loop (header, LEN / NLEN, the next header ...), in the chunk jobs and in the
+    one-wavefront form alike; what ends a run — a Huffman block, the final block, a damaged LEN / NLEN pair, the end of the input or of the
+    output room — is the careful path's, with the oracle's statuses"""
+    rnd = C.random_bytes(5 << 20, seed=9)
+    text = C.generate("enwik", 41, 0, 3 << 20)
+    mix = np.concatenate([rnd[:1 << 20], text[:700000], rnd[1 << 20:3 << 20], text[700000:2 << 20], rnd[3 << 20:], text[2 << 20:]])
+    for level in (0, 6, 9):
+        stream = O.deflate(mix, level)
+        rp, rs, jobs = _both(eng, stream, mix.size)
+        _same(rp, rs)
+        assert rp[0].status == 0 and rp[0].data == mix.tobytes() and rp[1] == len(stream), level
+        # the output room ends inside a run / the input does: both forms stop where the oracle's Inflater stops
+        for cap in (mix.size - 1, (1 << 20) + 12345, 40000):
+            rp, rs, _ = _both(eng, stream, cap)
+            _same(rp, rs)
+            assert rp[0].data == mix.tobytes()[:cap]
+        for cut in (len(stream) - 3, len(stream) // 2, 70000):
+            rp, rs, _ = _both(eng, stream[:cut], mix.size)
+            _same(rp, rs)
+            assert rp[0].status != 0 and mix.tobytes().startswith(rp[0].data)
+    # zlib's own: level 0 with empty stored blocks in between (sync flushes), then a damaged NLEN in the middle of a run
+    co = zlib.compressobj(0, zlib.DEFLATED, -15)
+    parts = []
+    for i in range(60):
+        parts.append(co.compress(mix[i * 100000:(i + 1) * 100000].tobytes()))
+        parts.append(co.flush(zlib.Z_SYNC_FLUSH))
+    parts.append(co.flush())
+    stream = b"".join(parts)
+    rp, rs, _ = _both(eng, stream, 6000000)
+    _same(rp, rs)
+    assert rp[0].status == 0 and rp[0].data == mix.tobytes()[:6000000]
+    bad = bytearray(stream)
+    pos = len(parts[0]) + len(parts[1]) + len(parts[2]) + len(parts[3])          # the third piece's first stored header
+    assert bad[pos] in (0, 1)
+    bad[pos + 3] ^= 0x40                                                          # NLEN no longer the complement
+    rp, rs, _ = _both(eng, bytes(bad), 6000000)
+    _same(rp, rs)
+    st, delivered, consumed = O.inflate_probe(np.frombuffer(bytes(bad), np.uint8), max_out=6000000)
+    assert st < 0 and rp[0].status != 0 and rp[0].data == delivered == mix.tobytes()[:200000]
+
+
 def test_zlib_framing_and_adler(eng):
     data = C.generate("enwik", 77, 0, 5 << 20).tobytes()
     stream = zlib.compress(data, 6)
