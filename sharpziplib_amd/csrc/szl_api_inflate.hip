@@ -109,6 +109,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         uint64_t chunk_bytes, first_bit;
         uint32_t nchunks; uint64_t start_off;   // its slice of the candidate-start array
         std::vector<uint64_t> sb;        // start bits of its jobs, ascending
+        std::vector<uint64_t> stored;    // those of them the finder named as STORED-block headers, ascending (see stored_same_header)
         std::vector<Cnt> cnt; std::vector<char> have;
         std::vector<uint64_t> reg;       // single pass: staging region (first symbol) of each job
         uint64_t reg_cap = 0;            //              and its size in symbols
@@ -196,7 +197,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     if (fsub > 1) {
         for (uint64_t c = 0; c < nstart_total; c++) {
             uint64_t best = ~0ull;
-            for (uint32_t q = 0; q < fsub; q++) best = std::min(best, starts[c * fsub + q]);
+            for (uint32_t q = 0; q < fsub; q++) { const uint64_t v = starts[c * fsub + q]; if ((v & ~(1ull << 63)) < (best & ~(1ull << 63))) best = v; }   // (by position: bit 63 is the kind)
             starts[c] = best;
         }
         starts.resize(nstart_total);
@@ -211,7 +212,12 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     for (auto &p : ps) {
         if (!p.alive) continue;
         p.sb.push_back(p.first_bit);
-        for (uint32_t c = 1; c < p.nchunks; c++) { const uint64_t v = starts[p.start_off + c]; if (v != ~0ull && v > p.sb.back()) p.sb.push_back(v); }
+        for (uint32_t c = 1; c < p.nchunks; c++) {
+            const uint64_t v = starts[p.start_off + c];
+            if (v == ~0ull) continue;
+            const uint64_t pos = v & ~(1ull << 63);               // (bit 63: a stored block's header, k_find_blocks)
+            if (pos > p.sb.back()) { p.sb.push_back(pos); if (v >> 63) p.stored.push_back(pos); }
+        }
         if (p.sb.size() < 4) { p.alive = false; continue; }
         p.cnt.assign(p.sb.size(), Cnt{}); p.have.assign(p.sb.size(), 0);
         if (single_pass) {
@@ -340,8 +346,16 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                     break;
                 }
                 uint32_t m = j + 1;
-                while (m < p.sb.size() && p.sb[m] < c.end_bit) m++;  // starts the real decode ran over: false candidates
-                if (m < p.sb.size() && p.sb[m] == c.end_bit) { j = m; continue; }
+                bool same = false;
+                while (m < p.sb.size() && p.sb[m] < c.end_bit) {     // starts the real decode ran over: false candidates —
+                    // — but for a stored block's header named a few bits early: its three type bits are zeros and so is the padding to
+                    // the byte behind them, so where the block before it ends in zero bits the finder's FIRST hit lies in front of the
+                    // true boundary.  A decode from there reads the same type, skips to the same byte and is the same decode: that job IS
+                    // the one that starts where this one ended.
+                    if (std::binary_search(p.stored.begin(), p.stored.end(), p.sb[m]) && ((p.sb[m] + 10) >> 3) == ((c.end_bit + 10) >> 3)) { same = true; break; }
+                    m++;
+                }
+                if (same || (m < p.sb.size() && p.sb[m] == c.end_bit)) { j = m; continue; }
                 // nobody starts where this job ended: a new job starts there, counted next round.  (The job that ended there
                 // ran with an earlier stop, but a decode that stops at the first block boundary >= stop also stops there for
                 // any stop in (previous boundary, end_bit]: its count stays valid.)

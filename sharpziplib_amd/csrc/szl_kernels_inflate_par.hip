@@ -120,10 +120,31 @@ __device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
     return true;
 }
 
+// A candidate start of the other kind (round 5): a non-final STORED block whose header is followed, LEN bytes on, by another block
+// header that holds — a stored one with its own LEN / NLEN pair and room for its bytes, or a dynamic one that parses.  Data that does not
+// compress is runs of such blocks (16 KiB each from a level 5-9 encoder, 64 KiB from level 0) with no dynamic header for megabytes: a
+// member of them had no candidate starts at all and was decoded by ONE wavefront (256 MiB: 123 ms, after 907), a stretch of them inside a
+// member was one job however long.  The cheap test is in the scan (three zero type bits, zero padding to the byte, NLEN == ~LEN: one bit
+// position in 2^19 + padding of random data passes); this is the second look, a lane per survivor.
+__device__ bool stored_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, uint8_t *mlut) {
+    const uint64_t b = (p + 3 + 7) >> 3;                           // LEN, NLEN at bytes b .. b+3 (C/Inflater.cs:490-512)
+    if (b + 4 > in_len) return false;
+    const uint32_t len = (uint32_t)in[b] | ((uint32_t)in[b + 1] << 8);
+    const uint64_t nb = b + 4 + len;                               // the next block's header byte
+    if (nb + 5 > in_len) return false;                             // (the member's last blocks are left to their predecessor's decode)
+    const uint32_t t = in[nb] & 7u;
+    if ((t >> 1) == 0) {
+        const uint32_t len2 = (uint32_t)in[nb + 1] | ((uint32_t)in[nb + 2] << 8), nlen2 = (uint32_t)in[nb + 3] | ((uint32_t)in[nb + 4] << 8);
+        return nlen2 == (len2 ^ 0xFFFFu) && nb + 5 + len2 <= in_len;
+    }
+    if (t == 4) return header_ok_lane(in, in_len, 8 * nb, mlut);
+    return false;
+}
+
 // One wavefront per finder job: first valid dynamic header at a bit offset in [lo_bit, hi_bit) of the job's member.  The scan tests
 // 64 bit positions per step with the cheap tests and notes the positions that pass; every FIND_FLUSH steps (or with 64 of them
 // noted) they are parsed, a lane each, and the lowest one that holds is the answer.
-enum : int { FIND_FLUSH = 512, FIND_CAP = 128, FIND_STAGE_BYTES = 256, FIND_STAGE_DW = FIND_STAGE_BYTES / 4 + 6 };
+enum : int { FIND_FLUSH = 512, FIND_CAP = 192, FIND_STAGE_BYTES = 256, FIND_STAGE_DW = FIND_STAGE_BYTES / 4 + 6 };
 __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ in_base, const FindJob *__restrict__ fjobs, uint32_t njobs,
                                                     uint64_t *__restrict__ start_bit) {
     __shared__ __attribute__((aligned(16))) uint8_t s_mlut[64][128];
@@ -146,14 +167,18 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     uint64_t found = ~0ull;
     int ncand = 0, since = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // (s_k9)
-    auto flush = [&]() {                                           // parse what has been noted, in position order
+    auto flush = [&]() {                                           // parse what has been noted; the lowest position that holds is the answer
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int off = 0; off < ncand && found == ~0ull; off += 64) {
+        const uint64_t POS = ~(1ull << 63);
+        for (int off = 0; off < ncand; off += 64) {                // (all of them: the stored-block candidates are noted ahead of the scan)
             const bool mine = off + lane < ncand;
             const uint64_t p = mine ? s_cand[off + lane] : 0;
-            const bool ok = mine && header_ok_lane(in, in_len, p, s_mlut[lane]);
-            const uint64_t okm = __ballot(ok);
-            if (okm) found = s_cand[off + __builtin_ctzll(okm)];
+            const uint64_t pp = p & POS;                           // (bit 63: a stored-block candidate)
+            const bool ok = mine && ((p >> 63) ? stored_ok_lane(in, in_len, pp, s_mlut[lane]) : header_ok_lane(in, in_len, pp, s_mlut[lane]));
+            for (uint64_t okm = __ballot(ok); okm; okm &= okm - 1) {
+                const uint64_t v = s_cand[off + __builtin_ctzll(okm)];
+                if (found == ~0ull || (v & POS) < (found & POS)) found = v;      // (bit 63 stays: the host wants to know the kind)
+            }
         }
         ncand = 0; since = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -198,6 +223,34 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
             if (mm) {
                 if (cand) s_cand[ncand + __builtin_popcountll(mm & ((1ull << lane) - 1ull))] = p;
                 ncand += __builtin_popcountll(mm);
+            }
+            // ... or a stored block's (stored_ok_lane).  Its LEN / NLEN pair is byte aligned, so the cheap test goes by BYTE, a lane each,
+            // once per eight steps (per bit position it was 16 of the scan's 127 instructions per step, +20 % on a member of text): lane l
+            // looks at the byte hb that would hold the end of the header's zero bits — NLEN == ~LEN behind it (one byte in 2^16 of random
+            // data), its top three bits or more zero — and names the first bit of that run of zeros, reaching up to two bits into the
+            // byte before: what a scan by bit position finds first.
+            if ((step & 7u) == 0) {
+                const uint32_t bo = 8u * step + (uint32_t)lane;                         // byte offset inside the stage (<= 255)
+                const uint32_t o1 = bo + 1u, d1 = o1 >> 2, s1 = (o1 & 3u) << 3;
+                const uint32_t ln = __builtin_amdgcn_alignbit(s_stage[d1 + 1], s_stage[d1], s1);
+                bool sc = (ln >> 16) == ((ln & 0xFFFFu) ^ 0xFFFFu);
+                uint64_t sp = 0;
+                if (sc) {
+                    const uint32_t hbyte = (s_stage[bo >> 2] >> ((bo & 3u) << 3)) & 0xFFu;
+                    uint32_t z = hbyte ? (uint32_t)__builtin_clz(hbyte) - 24u : 8u;    // zero bits at the top of the byte
+                    sc = z >= 3u;
+                    if (z == 8u && bo > 0) {
+                        const uint32_t pb = (s_stage[(bo - 1u) >> 2] >> (((bo - 1u) & 3u) << 3)) & 0xFFu;
+                        z += (pb & 0x80u) ? 0u : ((pb & 0x40u) ? 1u : 2u);
+                    }
+                    sp = blk_bit + 8ull * (uint64_t)bo + 8ull - (uint64_t)z;
+                    sc = sc && sp >= lo && sp < hi;
+                }
+                const uint64_t sm = __ballot(sc);
+                if (sm) {
+                    if (sc) s_cand[ncand + __builtin_popcountll(sm & ((1ull << lane) - 1ull))] = sp | (1ull << 63);
+                    ncand += __builtin_popcountll(sm);
+                }
             }
             if (++since >= FIND_FLUSH || ncand >= 64) flush();
         }
