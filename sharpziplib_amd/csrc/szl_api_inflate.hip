@@ -282,11 +282,18 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         if (n > 0x7FFFFFFFull) return SZL_E_ARG;
         jobs.assign(n, InfJob{});
         uint16_t *sym = (uint16_t *)E.inf_sym.p;
+        // the members' candidate starts on the device: a job that ran over a false one goes on to the next (InfJob.starts)
+        std::vector<uint64_t> all_sb; std::vector<size_t> sb_at(ps.size(), 0);
+        for (size_t k = 0; k < ps.size(); k++) { sb_at[k] = all_sb.size(); if (ps[k].alive) all_sb.insert(all_sb.end(), ps[k].sb.begin(), ps[k].sb.end()); }
+        { int r0; if ((r0 = E.inf_misc.ensure(all_sb.size() * 8 + 64))) return r0; }
+        HIPCHK(hipMemcpyAsync(E.inf_misc.p, all_sb.data(), all_sb.size() * 8, hipMemcpyHostToDevice, st));
         for (size_t q = 0; q < n; q++) {
             const PS &p = ps[which[q].k]; const uint32_t j = which[q].j;
             InfJob &jb = jobs[q];
             jb.in_off = streams[p.si].in_off; jb.in_len = streams[p.si].in_len;
             jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : (p.truncated ? p.trunc_bit : ~0ull);   // (a piece of a stream: the dropped job's start)
+            jb.starts = (const uint64_t *)E.inf_misc.p + sb_at[which[q].k] + (j + 1); jb.nstarts = (uint32_t)(p.sb.size() - (j + 1));
+            jb.stop_last = p.truncated ? p.trunc_bit : ~0ull;
             if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.regc[j]; }
             else { jb.sym_out = pass == 2 ? sym + p.jbase[j] : nullptr; jb.out_cap = ~0ull >> 2; }
         }

@@ -37,6 +37,11 @@ struct InfJob {
     uint32_t dbg_partok;  // [out] tokens of those rounds
     uint32_t stop_at_header; // 1: stop with INF_CHUNK_END as soon as the decoder stands at a block header (the streaming object brings the
                              // stream to a block boundary before it hands a long input to the chunk-parallel decoder)
+    // chunk jobs: the member's candidate starts behind stop_bit, ascending (starts[0] == stop_bit), and where the last job stops.  A job
+    // that stands at a block boundary PAST its stop — the candidate lay inside a block: a false one, e.g. a block header of deflate data
+    // that the member merely carries as its payload — goes on to the next candidate at or behind that boundary instead of ending where
+    // nobody starts (each such end used to cost a repair pass of its own, and a member with more than five of them the whole parallel path)
+    const uint64_t *starts; uint64_t stop_last; uint32_t nstarts; uint32_t pad0;
     uint32_t in_more;        // 1: the caller holds more input behind in_len (the streaming object uploads a bounded prefix per step): where the
                              // reference's GetSymbol would look at bits past in_len the decoder stops with INF_NEED_INPUT instead of applying the
                              // "fewer than 9 bits left: an empty slot reads as symbol 0, 0 bits" rule, which is for the END of the input only

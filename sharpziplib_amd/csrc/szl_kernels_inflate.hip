@@ -213,6 +213,8 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
     uint64_t bitpos = PMODE ? job.start_bit : st->bitpos, outpos = PMODE ? 0 : st->outpos;
     uint32_t mode = PMODE ? (uint32_t)INF_M_HEADER : st->mode, lastblk = PMODE ? 0u : st->last, stored_left = st->stored_left, btype = st->btype;
     uint32_t lnum = st->lnum, dnum = st->dnum;
+    uint64_t stop_bit = PMODE ? job.stop_bit : ~0ull;   // chunk jobs: where this job ends (moves on past false candidates: InfJob.starts)
+    uint32_t sidx = 0, moves = 0;
     const uint32_t pend_len = 0, pend_dist = 0; // a token that does not fit is simply not consumed
     const uint64_t out_start = outpos;             // stream position of out[0] for this call
     const uint64_t out_limit = PMODE == 1 ? ~0ull >> 1 : outpos + job.out_cap;   // (symbol pass: the job's staging region)
@@ -585,7 +587,21 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                 }
                 // ---------------- INF_M_HEADER
                 if (lastblk) { mode = INF_M_DONE; ev = EV_STOP; ea = INF_FINISHED; break; }
-                if (PMODE && bitpos >= job.stop_bit) { ev = EV_STOP; ea = INF_CHUNK_END; break; } // the next chunk's block starts here
+                if (PMODE && bitpos >= stop_bit) {                  // the next chunk's block starts here —
+                    bool ends = true;
+                    // — or the candidate lay inside the block that ended here: on to the next one.  (Not for a candidate within ten bits of the
+                    // boundary — a stored header named early, the host's chain walk knows it for the same start — and not more than twice: a
+                    // job that itself began at a false candidate may be following a consistent chain of its own, the blocks of a deflate
+                    // stream the member carries as payload, and must not follow it to its end.)
+                    if (bitpos - stop_bit > 10 && job.starts && moves < 2u) {
+                        moves++;
+                        uint32_t k = sidx;
+                        while (k < job.nstarts && job.starts[k] < bitpos) k++;
+                        sidx = k; stop_bit = k < job.nstarts ? job.starts[k] : job.stop_last;
+                        ends = bitpos >= stop_bit;
+                    }
+                    if (ends) { ev = EV_STOP; ea = INF_CHUNK_END; break; }
+                }
                 if (PMODE == 0 && job.stop_at_header) { ev = EV_STOP; ea = INF_CHUNK_END; break; } // (streaming object: a block boundary was asked for)
                 if (avail < 3) { ev = EV_STOP; ea = INF_NEED_INPUT; break; }
                 const uint32_t t = (uint32_t)bb & 7;
@@ -821,6 +837,8 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
             }
             uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_left);   // of THIS block, behind the n bytes taken now
             uint32_t lastb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lastblk);
+            uint64_t r_stop = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(stop_bit >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)stop_bit);
+            uint32_t r_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx), r_moves = (uint32_t)__builtin_amdgcn_readfirstlane((int)moves);
             // Stored bytes go straight from the input to the output, 16 per lane and step (an incompressible member is nothing but such
             // blocks: through the window, a byte per lane, one wavefront moved 290 MiB/s — 3.6 s per GiB); the window then takes the
             // block's last WIN bytes, which is all a later match can reach (CS/OutputWindow.cs:98-110 CopyStored).  And a stored block
@@ -872,7 +890,14 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                 // another stored block that is all there and fits; anything else is the careful path's
                 const uint32_t t = hb[0] & 7u;
                 if ((t >> 1) != 0) break;
-                if (PMODE && 8 * bp >= job.stop_bit) break;                // (a chunk job ends at its stop)
+                if (PMODE && 8 * bp >= r_stop) {                          // (a chunk job ends at its stop — or moves it, as in the careful path)
+                    if (8 * bp - r_stop <= 10 || !job.starts || r_moves >= 2u) break;
+                    r_moves++;
+                    uint32_t k = r_idx;
+                    while (k < job.nstarts && job.starts[k] < 8 * bp) k++;
+                    r_idx = k; r_stop = k < job.nstarts ? job.starts[k] : job.stop_last;
+                    if (8 * bp >= r_stop) break;
+                }
                 if (PMODE == 0 && job.stop_at_header) break;
                 const uint32_t len = hb[1] | (hb[2] << 8), nlen = hb[3] | (hb[4] << 8);
                 if (nlen != (len ^ 0xFFFFu)) break;
@@ -895,7 +920,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                 }
             }
             // (all lanes compute the same; lane 0's copy is the decoder's)
-            bitpos = 8 * bp; bb = 0; nb = 0; stored_left = left; lastblk = lastb;
+            bitpos = 8 * bp; bb = 0; nb = 0; stored_left = left; lastblk = lastb; stop_bit = r_stop; sidx = r_idx; moves = r_moves;
             sbase = ~0ull; // force a restage at the new position
         } break;
         case EV_STOP:

@@ -146,6 +146,24 @@ def test_runs_of_stored_blocks_are_followed_without_leaving_the_copy(eng):
     assert st < 0 and rp[0].status != 0 and rp[0].data == delivered == mix.tobytes()[:200000]
 
 
+def test_member_whose_payload_is_deflate_data(eng):
+    """a .tar.gz of zips / PNGs / docx: the member carries deflate streams as its payload — the outer encoder stores them (or finds a little
+    to gain), and what the block finder finds in the payload are the INNER streams' block headers, complete and consistent, every few dozen
+    KiB.  A job that stands at a boundary past such a candidate goes on to the next one; the member stays on the parallel path"""
+    inner = b"".join(O.deflate(C.generate("enwik", 400 + i, 0, 1 << 20), 6) for i in range(16))       # ~6 MiB of deflate data
+    inner = np.frombuffer(inner, np.uint8)
+    for maker in ("oracle", "zlib"):
+        if maker == "oracle":
+            stream = O.deflate(inner, 6)
+        else:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            stream = co.compress(inner.tobytes()) + co.flush()
+        rp, rs, jobs = _both(eng, stream, inner.size)
+        _same(rp, rs)
+        assert rp[0].status == 0 and rp[0].data == inner.tobytes() and rp[1] == len(stream)
+        assert jobs >= 8, (maker, jobs)                      # (not abandoned for the one-wavefront decoder)
+
+
 def test_zlib_framing_and_adler(eng):
     data = C.generate("enwik", 77, 0, 5 << 20).tobytes()
     stream = zlib.compress(data, 6)
