@@ -302,6 +302,21 @@ def suite_inflate_parallel():
             assert jobs >= 4, jobs
             assert r.status == 0 and r.data == data.tobytes() and used == len(m) and r.crc32 == zlib.crc32(data.tobytes()), name
             n += 1
+        # data that does not compress: runs of stored blocks (the finder names their headers too; a job copies a run without leaving its
+        # loop), a member of such stretches and text, and a member whose payload is deflate data — the INNER streams' block headers are
+        # false candidate starts the jobs move on past (tests/test_gpu_inflate_par.py)
+        rnd = C.random_bytes(200000, seed=3)
+        ci = zlib.compressobj(6, zlib.DEFLATED, -15, 4)
+        inner = np.frombuffer(ci.compress(data.tobytes()) + ci.flush(), np.uint8)       # a block header every ~1 KiB
+        mixed = np.concatenate([rnd[:70000], data[:80000], rnd[70000:140000], data[80000:120000]])
+        for name, plain, lv in (("stored_only_l6", rnd, 6), ("mixed", mixed, 6), ("payload_is_deflate_data", inner, 6)):
+            m = O.deflate(plain, lv)
+            _knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64)
+            (r, used), = e.inflate([m], [plain.size], crc32=True)
+            jobs = int(_lib.lib().szl_engine_debug_par_jobs(e._h))
+            assert r.status == 0 and r.data == plain.tobytes() and used == len(m) and r.crc32 == zlib.crc32(plain.tobytes()), name
+            assert jobs >= 4 or len(m) < 131072, (name, jobs, len(m))
+            n += 1
         bad = bytearray(members[0][1]); bad[90000] ^= 0x10
         (rp, up), = e.inflate([bytes(bad)], [data.size])
         _knobs(SZL_INF_PAR_MIN_KIB=1 << 22)
