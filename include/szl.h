@@ -178,7 +178,11 @@ int szl_deflate_batch_multi_host(const int *devices, int n_dev, const void *h_in
  * buffers, i.e. without PCIe in the call (bench.py --mode strong times this).  Levels 5-9; same bytes as one engine. */
 int szl_deflate_stream_multi_device(const int *devices, int n_dev, const void *const *d_in, void *d_out0, szl_stream *stream,
                                     int level, int strategy, unsigned flags);
-/* The multi-device entry points keep one engine per device slot (work space included) between calls; this frees them. */
+/* The multi-device entry points keep one engine per device slot (work space included) between calls, and the streaming objects
+ * (szl_deflater / szl_inflater) give their engine — work space and long device buffers included — to a process-wide pool when they are
+ * destroyed, from which the next object takes it (SZL_ENGINE_POOL idle engines, default 2, 0 = none: a GZipOutputStream makes a new
+ * Deflater per stream, S/GZip/GzipOutputStream.cs:87, and allocating ~19 bytes of device memory per input byte cost its first Finish()
+ * 20-800 ms).  This frees both. */
 int szl_multi_release(void);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  unsigned flags);
