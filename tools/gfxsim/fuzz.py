@@ -8,6 +8,9 @@
                                                                             strategies, framing, checksums
     python tools/gfxsim/fuzz.py inflate <seed> <rounds>                    bit flips, truncations, header-region flips, quirk code sets
                                                                             (tests/test_gpu_inflate_fuzz.py's generators), batch + streaming object
+    python tools/gfxsim/fuzz.py par <seed> <rounds>                        members of text, stored runs and deflate payload — whole, damaged,
+                                                                            truncated — through the chunk-parallel Inflater against the
+                                                                            one-wavefront decoder
 
 One process per invocation (several in parallel use several cores).  Prints one line per mismatch and a summary; exit code 1 on any.
 Test infrastructure only.  Round 4's campaign: profiles/r04/gfxsim_fuzz_campaign.log.
@@ -101,6 +104,19 @@ def fuzz_inflate(seed, rounds):
             d = C.generate(kind, int(rng.integers(1, 1 << 20)), 0, int(rng.integers(200, 3000)))
             lv = int(rng.integers(1, 10))
             valid.append(("%s_L%d" % (kind, lv), O.deflate(d, lv, flush=bool(rng.integers(0, 2)))))
+        # runs of stored blocks — the decoder follows them inside its copy loop (round 5): zlib's level 0 cut into short blocks by sync
+        # flushes (empty stored blocks in between), and incompressible bytes through the reference's own level 0 / level 6
+        import zlib
+        co = zlib.compressobj(0, zlib.DEFLATED, -15)
+        parts = []
+        for _ in range(int(rng.integers(3, 9))):
+            parts.append(co.compress(C.generate("enwik", int(rng.integers(1, 1 << 20)), 0, int(rng.integers(100, 1500))).tobytes()))
+            parts.append(co.flush(zlib.Z_SYNC_FLUSH if rng.integers(0, 2) else zlib.Z_FULL_FLUSH))
+        parts.append(co.flush())
+        valid.append(("zlib0_flushes", b"".join(parts)))
+        rb = rng.integers(0, 256, int(rng.integers(1000, 7000)), dtype=np.uint8)
+        valid.append(("random_L0", O.deflate(rb, 0)))
+        valid.append(("random_L6", O.deflate(np.concatenate([rb, C.generate("logs", 5, 0, 700), rb[::-1]]), 6)))
         cases = CS.mutations(valid, rng, n_flip=10, n_trunc=3)
         for name, s in valid:
             b = np.frombuffer(s, np.uint8)
@@ -114,6 +130,60 @@ def fuzz_inflate(seed, rounds):
         for f in fails:
             bad += 1
             print("MISMATCH seed %d round %d: %s" % (seed, rd, f), flush=True)
+    return tot, bad
+
+
+def fuzz_par(seed, rounds):
+    """members of 150-300 KB made of text in small blocks, runs of stored blocks and deflate data as payload — whole, damaged and truncated —
+    through the chunk-parallel Inflater (16 KiB chunks) against the one-wavefront decoder: status, bytes consumed, bytes out"""
+    import zlib
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd import corpus as C
+    from sharpziplib_amd.batch import Engine
+    L = _lib.lib()
+    e = Engine()
+    tot = bad = 0
+    for rd in range(rounds):
+        rng = np.random.default_rng(seed * 1000 + rd)
+        co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15, 4)       # memLevel 4: a block every 1024 tokens
+        parts, plain = [], []
+        while sum(len(x) for x in parts) < int(rng.integers(150000, 280000)):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                d = C.generate(("enwik", "logs", "dickens")[int(rng.integers(0, 3))], int(rng.integers(1, 1 << 20)), 0, int(rng.integers(20000, 90000))).tobytes()
+            elif kind == 1:
+                d = rng.integers(0, 256, int(rng.integers(10000, 80000)), dtype=np.uint8).tobytes()      # stored blocks
+            elif kind == 2:
+                ci = zlib.compressobj(6, zlib.DEFLATED, -15, 4)                                          # deflate data as payload
+                t = C.generate("enwik", int(rng.integers(1, 1 << 20)), 0, int(rng.integers(40000, 120000))).tobytes()
+                d = ci.compress(t) + ci.flush()
+            else:
+                d = bytes(int(rng.integers(1000, 30000)))                                                 # zeros
+            plain.append(d); parts.append(co.compress(d))
+            if rng.integers(0, 3) == 0:
+                parts.append(co.flush(zlib.Z_SYNC_FLUSH if rng.integers(0, 2) else zlib.Z_FULL_FLUSH))
+        parts.append(co.flush())
+        m, data = b"".join(parts), b"".join(plain)
+        cases = [("whole", m, len(data)), ("short room", m, len(data) - int(rng.integers(1, 50000)))]
+        for k in range(3):
+            b = bytearray(m); pos = int(rng.integers(0, len(m) * 8)); b[pos >> 3] ^= 1 << (pos & 7)
+            cases.append(("flip@%d" % pos, bytes(b), len(data)))
+        cases.append(("cut", m[:int(rng.integers(len(m) // 3, len(m)))], len(data)))
+        for name, st, cap in cases:
+            L.szl_debug_set(b"SZL_INF_CHUNK_KIB", 16); L.szl_debug_set(b"SZL_INF_PAR_MIN_KIB", 64)
+            (rp, up), = e.inflate([st], [cap], crc32=True)
+            jobs = int(L.szl_engine_debug_par_jobs(e._h))
+            L.szl_debug_set(b"SZL_INF_PAR_MIN_KIB", 1 << 22)
+            (rs, us), = e.inflate([st], [cap], crc32=True)
+            tot += 1
+            same = (rp.status, up, rp.data, rp.crc32) == (rs.status, us, rs.data, rs.crc32)
+            if name == "whole":
+                same = same and rp.status == 0 and rp.data == data
+            if not same:
+                bad += 1
+                print("MISMATCH seed %d round %d %s: parallel (%d, %d, %d bytes, %d jobs) one wavefront (%d, %d, %d bytes)" % (
+                    seed, rd, name, rp.status, up, len(rp.data), jobs, rs.status, us, len(rs.data)), flush=True)
+    L.szl_debug_set(b"SZL_INF_CHUNK_KIB", -(2 ** 31)); L.szl_debug_set(b"SZL_INF_PAR_MIN_KIB", -(2 ** 31))
     return tot, bad
 
 
@@ -131,6 +201,8 @@ def main(argv):
         tot, bad = fuzz_batch(a, b)
     elif what == "inflate":
         tot, bad = fuzz_inflate(a, b)
+    elif what == "par":
+        tot, bad = fuzz_par(a, b)
     else:
         print(__doc__)
         return 2
