@@ -232,6 +232,9 @@ int szl_debug_tree_lengths(const int32_t *freqs, int n, int num_symbols, int min
 
 /* Parity tap (host arithmetic only): stored-block list of a level-0 stream fed as `chunks`; rows: abs_off, len, last. */
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows);
+/* Test tap (host only, no device): the copy SetInput makes into pinned memory — on several cores when the piece is long
+ * (SZL_COPY_THREADS) — applied to plain memory. */
+int szl_debug_host_copy(void *dst, const void *src, size_t n);
 
 /* Parity tap: block table of the last call; rows of 8 x uint64:
  * type, last, ntok, bit_start, opt_len, static_len, in_len, hdr_bits. */

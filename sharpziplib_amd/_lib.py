@@ -80,7 +80,7 @@ def _load(path):
         "szl_engine_debug_fetch": (i32, [vp, vp, vp, vp, sz, vp, sz, ctypes.POINTER(sz)]),
         "szl_engine_debug_blocks": (i32, [vp, vp, sz, ctypes.POINTER(sz)]),
         "szl_engine_debug_match_mode": (i32, [vp, i32]),
-        "szl_debug_set": (i32, [ctypes.c_char_p, i32]),
+        "szl_debug_set": (i32, [ctypes.c_char_p, i32]), "szl_debug_host_copy": (i32, [vp, vp, sz]),
         "szl_engine_debug_workspace": (u64, [vp]),
         "szl_engine_debug_par_jobs": (ctypes.c_uint32, [vp]),
         "szl_inflater_debug_bulk_calls": (ctypes.c_uint32, [vp]), "szl_inflater_debug_times": (i32, [vp, vp]),

@@ -206,6 +206,11 @@ static void l0_replay(L0State &s, const std::vector<uint64_t> &chunks, size_t nd
         while (l0_engine_deflate(s, avail, true, finish, out)) { }
     }
 }
+int szl_debug_host_copy(void *dst, const void *src, size_t n) {
+    if ((!dst || !src) && n) return SZL_E_ARG;
+    try { host_copy(dst, src, n); } catch (...) { return SZL_E_NOMEM; }
+    return 0;
+}
 // Parity tap (host arithmetic only, no device): block list of a level-0 stream. rows: abs_off, len, last.
 int szl_debug_stored_layout(const uint64_t *chunks, size_t nchunks, int flush_before_finish, uint64_t *rows, size_t cap_rows, size_t *n_rows) {
     // flush_before_finish bit 0: Flush() before Finish(); bits 8..: number of chunks NOT followed by a Deflate() call (counted

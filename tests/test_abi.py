@@ -65,3 +65,21 @@ def test_argument_errors_match_reference():
     with pytest.raises(ValueError):
         Deflater(-2)
     assert _lib.lib().szl_deflate_bound(0) >= 16
+
+
+def test_long_host_copies_on_several_cores_are_exact():
+    """SetInput's copy into pinned memory runs on SZL_COPY_THREADS cores when the piece is long (host_copy, szl_engine.hip): every byte, in
+    order, whatever the length, the alignment and the number of threads (host code only: no device needed)"""
+    import numpy as np
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (40 << 20) + 12345, dtype=np.uint8)
+    try:
+        for threads in (1, 2, 4, 7, 16):
+            L.szl_debug_set(b"SZL_COPY_THREADS", threads)
+            for n, so, do in ((0, 0, 0), (1, 3, 5), (4095, 1, 2), (4 << 20, 0, 0), ((4 << 20) + 1, 7, 9), ((8 << 20) - 1, 4096, 1), (33554432 + 4097, 11, 3), (src.size - 64, 5, 0)):
+                dst = np.full(n + do + 64, 0xA5, np.uint8)
+                assert L.szl_debug_host_copy(dst[do:].ctypes.data, src[so:].ctypes.data, n) == 0
+                assert np.array_equal(dst[do:do + n], src[so:so + n]) and (dst[:do] == 0xA5).all() and (dst[do + n:] == 0xA5).all(), (threads, n)
+    finally:
+        L.szl_debug_set(b"SZL_COPY_THREADS", -(2 ** 31))
