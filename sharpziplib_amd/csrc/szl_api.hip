@@ -44,9 +44,10 @@ void engine_give(szl_engine *e) {
     }
     int cur = 0;
     (void)hipGetDevice(&cur);
-    if (cur != e->device) (void)hipSetDevice(e->device);
+    const int dev = e->device;                           // read before the engine is deleted
+    if (cur != dev) (void)hipSetDevice(dev);
     szl_engine_destroy(e);
-    if (cur != e->device) (void)hipSetDevice(cur);
+    if (cur != dev) (void)hipSetDevice(cur);
 }
 void engine_pool_release() {
     std::vector<szl_engine *> idle;

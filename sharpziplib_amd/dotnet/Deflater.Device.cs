@@ -96,6 +96,16 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 	{
 		public const int BEST_COMPRESSION = 9, BEST_SPEED = 1, DEFAULT_COMPRESSION = -1, NO_COMPRESSION = 0, DEFLATED = 8;
 
+		/// <summary>The constants again as an enum (Deflater.cs:92-122); FastZip.CompressionLevel is of this type (Zip/FastZip.cs:342,484,996).</summary>
+		public enum CompressionLevel
+		{
+			BEST_COMPRESSION = Deflater.BEST_COMPRESSION,
+			BEST_SPEED = Deflater.BEST_SPEED,
+			DEFAULT_COMPRESSION = Deflater.DEFAULT_COMPRESSION,
+			NO_COMPRESSION = Deflater.NO_COMPRESSION,
+			DEFLATED = Deflater.DEFLATED
+		}
+
 		private IntPtr h;
 
 		public Deflater() : this(DEFAULT_COMPRESSION, false) { }

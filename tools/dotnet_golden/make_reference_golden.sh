@@ -15,3 +15,14 @@ python3 "$HERE/dump_inputs.py" "$WORK/inputs" "$@"
 mkdir -p "$WORK/proj" && cp "$HERE/RefGolden.csproj" "$HERE/Program.cs" "$WORK/proj/"
 DOTNET_gcServer=0 dotnet run -c Release --project "$WORK/proj/RefGolden.csproj" -p:SharpZipLibSrc="$SRC" -- "$WORK/inputs" "$ROOT/tests/golden/reference_golden.json"
 python3 -m pytest "$ROOT/tests/test_golden.py" -q -k reference
+
+# --- the shim compiles into the reference's assembly: copy the reference project to scratch, swap the four
+# files for sharpziplib_amd/dotnet/*.cs and build it.  tests/test_dotnet_surface.py is the part of this that runs without a .NET SDK.
+SWAP="$WORK/swapped" && rm -rf "$SWAP" && mkdir -p "$SWAP" && cp -r "$SRC" "$SWAP/ICSharpCode.SharpZipLib"
+[ -d "$SRC/../../assets" ] && cp -r "$SRC/../../assets" "$SWAP/../assets" 2>/dev/null || true
+P="$SWAP/ICSharpCode.SharpZipLib"
+rm "$P/Zip/Compression/Deflater.cs" "$P/Zip/Compression/Inflater.cs" "$P/Zip/Compression/Streams/InflaterInputStream.cs" "$P/Zip/Compression/Streams/DeflaterOutputStream.cs"
+cp "$ROOT/sharpziplib_amd/dotnet/Deflater.Device.cs" "$P/Zip/Compression/"
+cp "$ROOT/sharpziplib_amd/dotnet/InflaterInputStream.Device.cs" "$ROOT/sharpziplib_amd/dotnet/DeflaterOutputStream.Device.cs" "$P/Zip/Compression/Streams/"
+dotnet build -c Release "$P/ICSharpCode.SharpZipLib.csproj" -p:AllowUnsafeBlocks=true -p:SignAssembly=false -p:TreatWarningsAsErrors=false \
+  && echo "shim: the reference's assembly builds with the four files swapped"
