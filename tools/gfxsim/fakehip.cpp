@@ -148,6 +148,8 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) { mems
 // ---- streams and events (everything is synchronous) --------------------------------------------------------------
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(16); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(16); return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(16); return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { if (least) *least = 1; if (greatest) *greatest = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

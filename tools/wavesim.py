@@ -427,6 +427,15 @@ class Wave:
             self.v[dn] = np.where(em, res, self.v[dn])
             self.fifo.append(dn)
             return
+        if op == "ds_min_u32":             # ds_min_u32 addr, data [offset:N]
+            addr = (np.broadcast_to(self.rv(o[0]), (64,)).astype(np.int64) + off)
+            data = np.broadcast_to(self.rv(o[1]), (64,))
+            for l in np.where(em)[0]:
+                a = int(addr[l])
+                old = int.from_bytes(self.lds[a:a + 4].tobytes(), "little")
+                self.lds[a:a + 4] = np.frombuffer(min(old, int(data[l]) & M32).to_bytes(4, "little"), dtype=np.uint8)
+            self.fifo.append("@write")
+            return
         raise SimError("pc %d: DS op %s not modelled" % (self.pc - 1, op))
 
     def _global(self, op, o, mods, em):
