@@ -223,7 +223,7 @@ __global__ __launch_bounds__(B9F_THREADS) void k_match9_finish(const uint8_t *__
             }
             if (L + 8 > cap) { while (L < cap && dc[L] == dp[L]) L++; }
             bool stop = false;
-            if (L > best) {
+            if (L > best && L >= MIN_MATCH) {                     // (a walk that has found nothing yet carries best = 1: szl_match9_asm.h FETCH)
                 res2 = ((uint32_t)(p - (cn + hop)) << 16) | (uint32_t)L;
                 if (left >= snapm1) resq = res2;
                 best = L;

@@ -152,13 +152,8 @@
 // best_len has anything to do: record the match and re-base cb, mincb, kk and the filter bytes on the new best_len.  The lane
 // already stands on the next candidate; whether there is one was settled by the QUICK step that sent it here (left == -1: budget
 // spent; cb < mincb: out of the window).
-#define SZL9_COMPLETE(X) \
-    "s_mov_b64 exec, %[c" #X "]\n\t" \
-    "s_cbranch_execz 39f\n\t" \
-    "v_min_i32 %[t2" #X "], %[off" #X "], %[cap" #X "]\n\t"                        /* L */ \
-    "v_cmp_gt_i32 %[sc], %[t2" #X "], %[best" #X "]\n\t"                           /* strictly longer: the new best */ \
-    "s_mov_b64 exec, %[sc]\n\t" \
-    "s_cbranch_execz 38f\n\t" \
+// (the body of COMPLETE for the lanes whose compare beat best_len; t2 = the new length; leaves sc = lanes that reached niceLength)
+#define SZL9_IMPROVE(X) \
     "v_add_u32 %[t1" #X "], %[cb" #X "], %[hop" #X "]\n\t" \
     "v_sub_u32 %[t3" #X "], %[t2" #X "], %[best" #X "]\n\t"                        /* growth of best_len */ \
     "v_sub_u32 %[t1" #X "], %[t1" #X "], %[best" #X "]\n\t"                        /* the candidate compared */ \
@@ -175,7 +170,17 @@
     "v_mul_i32_i24 %[kk" #X "], -2, %[t2" #X "]\n\t" \
     "v_cmp_ge_i32 %[sc], %[t2" #X "], %[nice" #X "]\n\t"                           /* >= niceLength: stop (:603) */ \
     "s_waitcnt lgkmcnt(0)\n\t" \
-    SZL9_PB_SET(X) "\n" \
+    SZL9_PB_SET(X)
+#define SZL9_COMPLETE(X) \
+    "s_mov_b64 exec, %[c" #X "]\n\t" \
+    "s_cbranch_execz 39f\n\t" \
+    "v_min_i32 %[t2" #X "], %[off" #X "], %[cap" #X "]\n\t"                        /* L */ \
+    "v_cmp_gt_i32 %[sc], %[t2" #X "], %[best" #X "]\n\t"                           /* strictly longer: the new best */ \
+    "v_cmp_lt_i32 vcc, 2, %[t2" #X "]\n\t"                                         /* ... and a match at all (:611; the walk starts at 1, see FETCH) */ \
+    "s_and_b64 %[sc], %[sc], vcc\n\t" \
+    "s_mov_b64 exec, %[sc]\n\t" \
+    "s_cbranch_execz 38f\n\t" \
+    SZL9_IMPROVE(X) "\n" \
     "38:\n\t"                                                                        /* (nobody improved: sc = 0, exec = 0) */ \
     "s_mov_b64 exec, %[c" #X "]\n\t" \
     "v_cmp_lt_i32 vcc, %[cb" #X "], %[mincb" #X "]\n\t"                            /* the next candidate is out of the window */ \
@@ -238,6 +243,13 @@
 //   first candidate: pl - l0 >= max(pl - MAX_DIST, basem) (:788); chain candidates: cl >= max(pl - MAX_DIST + 1, basem) (:609).
 // A slice is all on one side of `sw` except one slice per 32 Ki positions: bms is picked per visit by scalar code and the mixed
 // slice takes the per-lane select.  Lookahead clamps only matter in a tile that ends within 258 + slice of the segment's end.
+// A walk that has found nothing yet keeps best_len = 1, not the reference's 2 (:485 Math.Max(matchLen, MIN_MATCH - 1)): its filter bytes
+// are then bytes 0 and 1 of the candidate, and with the hash equal those two decide byte 2 — h = (b0 << 10 ^ b1 << 5 ^ b2) & 0x7FFF holds
+// all of b2 once b0 and b1 are given — so the filter passes exactly the candidates that share the position's three bytes.  With the
+// reference's bytes 1 and 2 it also passes the chain's hash collisions that differ in the three high bits of byte 0 ('T' / 't' / '4'):
+// 9 % of all compares on text, and at the end of a tile the walks that are ALL such compares (a trigram new to the window whose
+// collision class is common) are the ones a CU waits for: ~110 instructions per chain step instead of ~25 (profiles/r06).  COMPLETE
+// asks for a length of 3 before it records anything, so the tables are what they were.
 // The first candidate shares the position's hash, so it goes straight to the compare (no filter step); like every lane that
 // goes there it has already moved on to the candidate after it (cb, hop, left as a QUICK step would leave them).
 #define SZL9_FETCH(X) \
@@ -293,8 +305,8 @@
     "v_lshlrev_b32 %[t2" #X "], 1, %[pl" #X "]\n\t" \
     "v_and_b32 %[t5" #X "], -4, %[pl" #X "]\n\t" \
     "ds_read_u16 %[t2" #X "], %[t2" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"     /* hashHead (:782) as a distance */ \
-    "ds_read_u8 %[t3" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D1) "\n\t"      /* scan_end1, scan_end for best_len 2 */ \
-    "ds_read_u8 %[t4" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D2) "\n\t" \
+    "ds_read_u8 %[t3" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"       /* the filter bytes of a walk that has found nothing yet: bytes 0 and 1 (below) */ \
+    "ds_read_u8 %[t4" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D1) "\n\t" \
     "ds_read_b32 %[p0" #X "], %[t5" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"      /* the position's first 16 bytes */ \
     "ds_read_b32 %[p1" #X "], %[t5" #X "] offset:" SZL9_STR(SZL9_D4) "\n\t" \
     "ds_read_b32 %[p2" #X "], %[t5" #X "] offset:" SZL9_STR(SZL9_D8) "\n\t" \
@@ -320,14 +332,14 @@
     "v_add_u32 %[t0" #X "], 7, %[t0" #X "]\n\t"                                    /* pl - (MAX_DIST - 1) */ \
     "v_max_i32 %[mincb" #X "], %[t0" #X "], %[t7" #X "]\n\t"                     /* chain limit */ \
     "v_max_i32 %[t1" #X "], %[t1" #X "], %[t7" #X "]\n\t"                        /* first candidate's limit */ \
-    "v_add_u32 %[mincb" #X "], 2, %[mincb" #X "]\n\t"                            /* (+ best_len) */ \
+    "v_add_u32 %[mincb" #X "], 1, %[mincb" #X "]\n\t"                            /* (+ the filter's best_len, 1) */ \
     "s_waitcnt lgkmcnt(7)\n\t" \
     "v_sub_u32 %[cb" #X "], %[pl" #X "], %[t2" #X "]\n\t"                        /* hashHead as an index */ \
     "v_cmpx_ge_i32 vcc, %[cb" #X "], %[t1" #X "]\n\t"                            /* strstart - hashHead <= MAX_DIST (:788) */ \
     "v_lshlrev_b32 %[t0" #X "], 1, %[cb" #X "]\n\t" \
     "ds_read_u16 %[hop" #X "], %[t0" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"    /* its prev[] hop */ \
-    "v_mov_b32 %[best" #X "], 2\n\t" \
-    "v_mov_b32 %[kk" #X "], -4\n\t" \
+    "v_mov_b32 %[best" #X "], 1\n\t" \
+    "v_mov_b32 %[kk" #X "], -2\n\t" \
     "v_mov_b32 %[left" #X "], %[chainm2]\n\t"                                      /* max_chain - 1 may follow the first; one is taken below */ \
     "s_waitcnt lgkmcnt(1)\n\t" \
     SZL9_PB_FIRST(X) \
@@ -337,7 +349,7 @@
     "v_alignbyte_b32 %[p3" #X "], %[t6" #X "], %[p3" #X "], %[pl" #X "]\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
     "v_sub_u32 %[cb" #X "], %[cb" #X "], %[hop" #X "]\n\t"                       /* on to the second candidate */ \
-    "v_add_u32 %[cb" #X "], 2, %[cb" #X "]\n\t" \
+    "v_add_u32 %[cb" #X "], 1, %[cb" #X "]\n\t" \
     "s_or_b64 %[v" #X "], %[v" #X "], exec\n\t" \
     "s_andn2_b64 exec, %[sa], exec\n\t"                                            /* positions without a walk: an empty entry */ \
     "s_cbranch_execz 28f\n\t" \
@@ -439,6 +451,176 @@
     "s_mov_b64 %[q" #X "], 0\n\t" \
     "s_mov_b64 %[v" #X "], 0\n\t" \
     "s_mov_b64 %[w" #X "], 0\n\t"
+
+// ---- the one-context loop with RUN-AHEAD (tailp = 2) ------------------------------------------------------------------------------
+// In the plain one-context loop a wavefront's few walks take turns: two chain steps for the walkers, then — most rounds — a compare and
+// its completion for the one or two lanes whose candidate passed the filter, ~110 instructions a round of which the slowest walk, the
+// one the whole CU waits for, gets two steps (tools/sim_match9.py: ~11000 instructions in the tile's slowest wavefront for <= 128 steps).
+// Here a lane whose candidate passes the filter does NOT stop: it notes the event (cb, hop, left -> context B's registers, free since
+// the merge; mask qB = "event pending") and walks on with the best_len it has — most compares do not improve on it.  Every `ktail1`
+// iterations the pending events are compared in ONE pass; an event that does improve best_len takes its lane back to where the event
+// was noted (the steps since are walked again under the new best_len), any other leaves the lane where it has walked to.  A lane that
+// meets a second event before the first is compared waits with it in its live registers (vA), as every lane does in the plain loop.
+// The filter has a THIRD byte here (pbA bits 8-15; its offset relative to cb in mincbB): the offset at which the lane's last compare
+// failed.  Walks through lines that differ from the position's in one field pass the two-byte filter at every candidate and fail every
+// compare at that field (logs: 4.6 of 5.7 compares per position do not improve, 70 % of them caught by this byte; text: the last walks of
+// a tile); LDS has room for the read at the end of a tile, where the chain of rounds is what counts.
+// Masks: qA walking, vA waiting with an event in the live registers, qB event noted, vB walk over but an event noted, wB / cB / mB scratch.
+#define SZL9_RA_STEP(L) \
+    "v_add_u32 %[t4A], %[cbA], %[mincbB]\n\t"              /* the candidate's byte at the offset where the lane's last compare failed */ \
+    SZL9_Q_ISSUE(A) \
+    "ds_read_u8 %[t3A], %[t4A] offset:" SZL9_STR(SZL9_D) "\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_Q_COMBINE(A) \
+    "v_lshl_or_b32 %[t1A], %[t3A], 8, %[t1A]\n\t" \
+    "v_sub_u32 %[cbA], %[cbA], %[hopA]\n\t" \
+    "v_subrev_co_u32 %[leftA], vcc, 1, %[leftA]\n\t" \
+    "s_andn2_b64 exec, exec, vcc\n\t" \
+    "v_cmpx_ge_i32 vcc, %[cbA], %[mincbA]\n\t" \
+    "v_cmp_eq_u32 vcc, %[pbA], %[t1A]\n\t" \
+    "s_cbranch_vccz " L "f\n\t" \
+    "s_and_b64 %[sa], vcc, %[qB]\n\t"                      /* passed, an event already noted: the lane waits where it stands */ \
+    "s_andn2_b64 %[sc], vcc, %[qB]\n\t"                    /* passed, nothing noted yet */ \
+    "s_andn2_b64 exec, exec, %[sa]\n\t" \
+    "s_mov_b64 %[mB], exec\n\t" \
+    "s_mov_b64 exec, %[sc]\n\t" \
+    "v_mov_b32 %[cbB], %[cbA]\n\t" \
+    "v_mov_b32 %[hopB], %[hopA]\n\t" \
+    "v_mov_b32 %[leftB], %[leftA]\n\t" \
+    "s_or_b64 %[qB], %[qB], %[sc]\n\t" \
+    "s_mov_b64 exec, %[mB]\n" \
+    L ":\n\t"
+/* (the third filter byte = the second again: offset best_len) */
+#define SZL9_RA_KRESET \
+    "v_mov_b32 %[mincbB], 0\n\t" \
+    "v_lshrrev_b32 %[t3A], 16, %[pbA]\n\t" \
+    "v_and_b32 %[pbA], 0xffff00ff, %[pbA]\n\t" \
+    "v_lshl_or_b32 %[pbA], %[t3A], 8, %[pbA]\n\t"
+#define SZL9_RA_SWAP \
+    "v_mov_b32 %[t5A], %[cbA]\n\t" \
+    "v_mov_b32 %[t6A], %[hopA]\n\t" \
+    "v_mov_b32 %[t7A], %[leftA]\n\t" \
+    "v_mov_b32 %[cbA], %[cbB]\n\t" \
+    "v_mov_b32 %[hopA], %[hopB]\n\t" \
+    "v_mov_b32 %[leftA], %[leftB]\n\t" \
+    "v_mov_b32 %[cbB], %[t5A]\n\t" \
+    "v_mov_b32 %[hopB], %[t6A]\n\t" \
+    "v_mov_b32 %[leftB], %[t7A]\n\t"
+#define SZL9_TAIL_RA \
+    "; @phase census\n" \
+    "79:\n\t"                                              /* entry: a compare under way starts again as an event in the live registers */ \
+    "s_or_b64 %[vA], %[vA], %[wA]\n\t" \
+    "s_mov_b64 %[wA], 0\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    SZL9_RA_KRESET \
+    "\n" \
+    "80:\n\t" \
+    SZL9_BUSY(A, "n0") \
+    "s_or_b64 %[sc], %[qB], %[vB]\n\t" \
+    "s_cbranch_scc1 801f\n\t" \
+    "s_cmp_eq_u32 %[n0], 0\n\t" \
+    "s_cbranch_scc1 98f\n" \
+    "801:\n\t" \
+    "s_cmp_eq_u64 %[qA], 0\n\t"                            /* nobody walks: compare what is noted */ \
+    "s_cbranch_scc1 84f\n\t" \
+    "s_mov_b64 %[mA], %[qA]\n\t" \
+    "s_mov_b32 %[kt], %[ktail1]\n\t" \
+    "s_mov_b64 exec, %[qA]\n" \
+    "; @phase quick\n" \
+    "81:\n\t" \
+    SZL9_RA_STEP("811") \
+    "s_cbranch_execz 85f\n\t" \
+    SZL9_RA_STEP("812") \
+    "s_cbranch_execz 85f\n\t" \
+    "s_sub_u32 %[kt], %[kt], 1\n\t" \
+    "s_cmp_lg_u32 %[kt], 0\n\t" \
+    "s_cbranch_scc1 81b\n" \
+    "; @phase classify\n" \
+    "85:\n\t" \
+    "s_andn2_b64 %[sa], %[mA], exec\n\t"                   /* left the walk in this phase */ \
+    "s_mov_b64 %[qA], exec\n\t" \
+    "s_mov_b64 exec, %[sa]\n\t" \
+    "s_cbranch_execz 86f\n\t" \
+    "v_cmp_eq_u32 vcc, %[pbA], %[t1A]\n\t"                 /* the candidate they stood on passes the filter: an event in the live registers */ \
+    "s_or_b64 %[vA], %[vA], vcc\n\t" \
+    "s_andn2_b64 %[sc], exec, vcc\n\t"                     /* the others' walks are over */ \
+    "s_and_b64 %[cm], %[sc], %[qB]\n\t" \
+    "s_or_b64 %[vB], %[vB], %[cm]\n\t"                     /* ... unless what they noted turns out to improve best_len */ \
+    "s_andn2_b64 %[sc], %[sc], %[qB]\n\t" \
+    "s_or_b64 %[dA], %[dA], %[sc]\n" \
+    "86:\n\t" \
+    "s_or_b64 %[sc], %[qB], %[vA]\n\t" \
+    "s_cbranch_scc0 80b\n" \
+    /* ---- 84: one compare pass over the noted events (qB) and the events in live registers (vA) */ \
+    "; @phase verify1\n" \
+    "84:\n\t" \
+    "s_mov_b64 %[wB], %[qB]\n\t" \
+    "s_or_b64 %[cm], %[qB], %[vA]\n\t" \
+    "s_mov_b64 exec, %[qB]\n\t" \
+    "s_cbranch_execz 841f\n\t" \
+    SZL9_RA_SWAP                                             /* the noted event into the live registers, where the lane has walked to out of the way */ \
+    "\n841:\n\t" \
+    "s_mov_b64 %[cA], 0\n\t" \
+    "s_mov_b64 %[wA], 0\n\t" \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "s_cbranch_execz 843f\n\t" \
+    SZL9_VF_ISSUE(A) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    SZL9_VF_FINISH(A) \
+    "s_mov_b64 %[wA], %[mA]\n\t" \
+    "s_andn2_b64 %[cA], %[cm], %[mA]\n" \
+    "; @phase verify2\n" \
+    "842:\n\t" \
+    "s_cmp_eq_u64 %[wA], 0\n\t" \
+    "s_cbranch_scc1 843f\n\t" \
+    SZL9_W_STEP(A) \
+    "s_branch 842b\n" \
+    "; @phase complete\n" \
+    "843:\n\t" \
+    "s_mov_b64 exec, %[cm]\n\t" \
+    "v_min_i32 %[t2A], %[offA], %[capA]\n\t" \
+    "v_cmp_gt_i32 %[sc], %[t2A], %[bestA]\n\t" \
+    "v_cmp_lt_i32 vcc, 2, %[t2A]\n\t" \
+    "s_and_b64 %[sc], %[sc], vcc\n\t" \
+    "s_mov_b64 %[cB], %[sc]\n\t"                            /* improved */ \
+    "s_mov_b64 exec, %[sc]\n\t" \
+    "s_cbranch_execz 844f\n\t" \
+    SZL9_IMPROVE(A) \
+    SZL9_RA_KRESET \
+    "\n844:\n\t"                                             /* sc = improved lanes that reached niceLength (0 if nobody improved) */ \
+    "s_andn2_b64 exec, %[cm], %[cB]\n\t"                   /* compared and not improved: the offset of the mismatch becomes the third filter byte — */ \
+    "s_cbranch_execz 846f\n\t"                             /* the chain's next candidates tend to fail where this one did (a field that differs */ \
+    "v_min_i32 %[t2A], %[offA], %[bestA]\n\t"              /* between otherwise equal lines), and any byte up to best_len is a valid filter */ \
+    "v_add_u32 %[t1A], %[plA], %[t2A]\n\t" \
+    "ds_read_u8 %[t1A], %[t1A] offset:" SZL9_STR(SZL9_D) "\n\t" \
+    "v_sub_u32 %[mincbB], %[t2A], %[bestA]\n\t" \
+    "v_and_b32 %[pbA], 0xffff00ff, %[pbA]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_lshl_or_b32 %[pbA], %[t1A], 8, %[pbA]\n" \
+    "846:\n\t" \
+    "s_andn2_b64 %[sa], %[cm], %[wB]\n\t" \
+    "s_or_b64 %[sa], %[sa], %[cB]\n\t"                     /* lanes whose live registers are their walk from here on: improved, or no run-ahead */ \
+    "s_mov_b64 exec, %[sa]\n\t" \
+    "v_cmp_lt_i32 vcc, %[cbA], %[mincbA]\n\t" \
+    "s_or_b64 %[sc], %[sc], vcc\n\t" \
+    "v_cmp_gt_i32 vcc, 0, %[leftA]\n\t" \
+    "s_or_b64 %[sc], %[sc], vcc\n\t"                       /* ... of which these end here */ \
+    "s_or_b64 %[dA], %[dA], %[sc]\n\t" \
+    "s_andn2_b64 %[qA], %[qA], %[sc]\n\t" \
+    "s_andn2_b64 %[sa], %[sa], %[sc]\n\t" \
+    "s_or_b64 %[qA], %[qA], %[sa]\n\t" \
+    "s_and_b64 %[vA], %[vA], %[wB]\n\t"                    /* still waiting with a second event: noted lanes that did not improve */ \
+    "s_andn2_b64 %[vA], %[vA], %[cB]\n\t" \
+    "s_andn2_b64 %[sc], %[vB], %[cB]\n\t"                  /* walk over and the noted event did not improve: done */ \
+    "s_or_b64 %[dA], %[dA], %[sc]\n\t" \
+    "s_mov_b64 %[vB], 0\n\t" \
+    "s_andn2_b64 exec, %[wB], %[cB]\n\t" \
+    "s_cbranch_execz 845f\n\t" \
+    SZL9_RA_SWAP                                             /* back to where the lane had walked to */ \
+    "\n845:\n\t" \
+    "s_mov_b64 %[qB], 0\n\t" \
+    "s_mov_b64 %[wB], 0\n\t" \
+    "s_branch 80b\n"
 
 #define SZL9_TAIL \
     "; @phase census\n" \
@@ -603,6 +785,8 @@
     /* ---- 60: the one-context loop */ \
     "; @phase census\n" \
     "60:\n\t" \
+    "s_cmp_eq_u32 %[tailp], 2\n\t" \
+    "s_cbranch_scc1 79f\n\t" \
     SZL9_BUSY(A, "n0") \
     "s_cmp_eq_u32 %[n0], 0\n\t" \
     "s_cbranch_scc1 98f\n\t" \
@@ -658,6 +842,7 @@
     "69:\n\t" \
     SZL9_COMPLETE(A) \
     "s_branch 60b\n" \
+    SZL9_TAIL_RA \
     /* ---- 70 / 72: the last walks go to the finishing pass */ \
     "; @phase spill\n" \
     "70:\n\t" \

@@ -85,7 +85,7 @@ def finish_walks(data, link, spill, nspill, t0, seg_end, P, mt2, mtq):
                 while L < cap and d[c + L] == d[p + L]:
                     L += 1
                 stop = False
-                if L > best:
+                if L > best and L >= 3:
                     res2 = ((p - c) << 16) | L
                     if left >= snapm1:
                         resq = res2
