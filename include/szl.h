@@ -106,6 +106,13 @@ int szl_deflater_deflate(szl_deflater *d, uint8_t *out, int len);
  * streams.py) writes them to its base stream in one Write instead of buffer_.Length bytes at a time — 512 by default (:26-29) — unless a
  * crypto transform has to see them in the stream's own buffer first (:256). */
 int szl_deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n);
+/* The caller declares that it takes everything Deflate() offers before it changes a parameter — every Deflate() loop runs until
+ * IsNeedingInput, as DeflaterOutputStream.Deflate() does (CS/DeflaterOutputStream.cs:242-272).  Only then is SetLevel / SetStrategy with
+ * 16 KiB or more of input pending answered: where the reference's engine stands at such a call depends on how much output was taken
+ * (C/DeflaterEngine.cs:126-139), and this object — which compresses at Flush() / Finish() — cannot observe that.  Without the declaration
+ * such a call returns SZL_E_UNSUPPORTED (NotSupportedException) instead of bytes that may differ from the reference's; Flush() first, or
+ * declare.  The device-aware stream classes declare it for the Deflater they drive.  Survives Reset(). */
+int szl_deflater_caller_drains(szl_deflater *d, int on);
 int szl_deflater_needs_input(const szl_deflater *d);                       /* IsNeedingInput   C/Deflater.cs:285 */
 int szl_deflater_is_finished(const szl_deflater *d);                       /* IsFinished       C/Deflater.cs:271 */
 int64_t szl_deflater_total_in(const szl_deflater *d);                      /* TotalIn          C/Deflater.cs:226 */

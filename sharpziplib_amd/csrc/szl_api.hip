@@ -781,6 +781,7 @@ struct szl_deflater {
     // CRC-32 of the input, on the device beside the Adler-32 (szl_deflater_enable_crc32: what GZipOutputStream / ZipOutputStream keep on
     // the CPU over every Write, S/GZip/GzipOutputStream.cs:210, S/Zip/ZipOutputStream.cs:700)
     bool want_crc = false; uint32_t crc = 0;
+    bool caller_drains = false;     // szl_deflater_caller_drains: the caller takes all Deflate() offers before it changes a parameter
     std::vector<uint64_t> chunks;   // SetInput sizes since the last Flush() (level 0 block cuts depend on them)
     uint64_t chunk_base = 0;        // offset of chunks[0] inside `pend` (not 0 after a function switch: the lookahead the old function left)
     L0State l0;
@@ -905,14 +906,17 @@ static int deflater_reset(szl_deflater *d) {
     return rc;
 }
 // a parameter change while bytes are pending: it takes effect where the reference's engine stands
-// SZL_STRICT=1 (off by default): a parameter or function change is refused when the reference's engine could already have
-// produced a block from the pending input (16384 tokens need at least as many bytes, C/DeflaterHuffman.cs:863).  Where the reference's
-// engine stands then depends on how much output the caller has taken (it pauses while `pending` holds bytes, C/DeflaterEngine.cs:126-139);
-// this backend compresses at Flush() / Finish() and places the change where the engine stands for a caller who DRAINS Deflate() — the
-// reference's own stream classes do (CS/DeflaterOutputStream.cs:242-272).  Strict mode is for finding call sites that do not.
+// Where that is depends on how much output the caller has taken once the pending input could have filled a block (16384 tokens need at
+// least as many bytes, C/DeflaterHuffman.cs:863): the reference's engine pauses while `pending` holds bytes (C/DeflaterEngine.cs:126-139).
+// This backend compresses at Flush() / Finish(); before that Deflate() hands out nothing, so it cannot SEE whether its caller would have
+// taken everything the reference offers.  It places the change where the engine stands for a caller who does — the reference's own
+// stream classes (CS/DeflaterOutputStream.cs:242-272) — and only for a caller who has SAID so (szl_deflater_caller_drains: the stream
+// classes of sharpziplib_amd/dotnet and streams.py do); anybody else's change with 16 KiB or more pending is refused, never answered
+// with bytes that may differ from the reference's (round 6; SZL_STRICT=0 restores the silent assumption of rounds 3-5).
 static int strict_refuses(const szl_deflater *d) {
-    if (knob("SZL_STRICT", 0) == 0 || d->pend.size() < 16384) return 0;
-    set_error("SZL_STRICT: SetLevel / SetStrategy with %zu bytes pending — exact only for callers that drain Deflate() (C/DeflaterEngine.cs:126-139)", d->pend.size());
+    if (d->caller_drains || knob("SZL_STRICT", 1) == 0 || d->pend.size() < 16384) return 0;
+    set_error("SetLevel / SetStrategy with %zu bytes pending: where the reference's engine stands depends on how much of Deflate()'s output the caller took "
+              "(C/DeflaterEngine.cs:126-139); declare szl_deflater_caller_drains(d, 1) if every Deflate() loop runs until IsNeedingInput, or Flush() first", d->pend.size());
     return SZL_E_UNSUPPORTED;
 }
 static int pend_switch(szl_deflater *d, int level, int strategy) {
@@ -1453,6 +1457,11 @@ int szl_deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n) { 
 int szl_deflater_reset(szl_deflater *d) { SZL_GUARDED(deflater_reset(d)); }
 int szl_deflater_set_level(szl_deflater *d, int level) { SZL_GUARDED(deflater_set_level(d, level)); }
 int szl_deflater_set_strategy(szl_deflater *d, int s) { SZL_GUARDED(deflater_set_strategy(d, s)); }
+int szl_deflater_caller_drains(szl_deflater *d, int on) {
+    if (!d) return SZL_E_ARG;
+    d->caller_drains = on != 0;
+    return 0;
+}
 int szl_deflater_enable_crc32(szl_deflater *d, int on) {
     if (!d) return SZL_E_ARG;
     if (d->total_in != 0 && (on != 0) != d->want_crc) { set_error("the CRC-32 is switched before the first SetInput (or after Reset)"); return SZL_E_STATE; }

@@ -131,15 +131,12 @@ class Engine {
     std::vector<uint32_t> fast_hist_in, fast_tail_bits;
     bool fast_want_tail = false;
     int64_t fast_tail_start = 0;
-    DevBuf m9_spill;   // stage B's finishing pass: walk records + per-tile counts (szl_kernels_match9.hip)
     DevBuf link, link4, skip4, e3dist, e3hops, mtab, tokens, visited, ranges, counts, range_tok, descs, d_segs, d_bnds, d_spans, d_tiles, d_stripes, d_so, blk_counts, blk_off,
         bsp, blp, counters, ckparts, ckoff, cubtmp, stage_in, stage_out, bad_slot, bad_range, exmap, cnmap, chain_buf, d_stored, spec_tok, d_zoff,
         inf_sym, inf_wins, inf_jobs, inf_states, inf_misc, inf_groups, hist_flags_dev, m5_scratch, d_sw_pos, d_sw_P;   // parallel decode of one member (szl_api_inflate.hip)
     hipEvent_t ev[8];
     // checksum kernels run beside stages A-C on this stream (they only share the input bytes)
     hipStream_t side = nullptr;
-    SpillHost sph;      // stage B's finishing pass: pool halves in m9_spill, two streams, three events (attach_spill)
-    int attach_spill(MTab &mt, int64_t ntiles);
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_guard = nullptr, ev_gjoin = nullptr, ev_zfork = nullptr, ev_zjoin = nullptr;
 };
 

@@ -27,7 +27,6 @@ static int links_guard_tripped() {
                     "bucketed form (k_links2) from now on and the call is run again\n");
     return SZL_I_RETRY_LINKS;
 }
-int match9_spill_cap();
 hipError_t launch_match(const uint8_t *in, const SegDev *segs, const TileDev *tiles, int ntiles, const uint16_t *link, MTab mtab,
                         LevelParams P, unsigned long long *dbg, hipStream_t st);
 #if SZL_LAB   // laboratory forms of the full search (libszl_amd_lab.so only; Makefile)
@@ -293,7 +292,7 @@ Engine::Engine() {
 }
 Engine::~Engine() {
     for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &m9_spill, &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &chain_buf, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &chain_buf, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -303,37 +302,7 @@ Engine::~Engine() {
     if (ev_zfork) (void)hipEventDestroy(ev_zfork);
     if (ev_zjoin) (void)hipEventDestroy(ev_zjoin);
     if (side) (void)hipStreamDestroy(side);
-    for (auto &x : sph.str) if (x) (void)hipStreamDestroy((hipStream_t)x);
-    for (void *x : {sph.ev_fork, sph.ev_join[0], sph.ev_join[1], sph.ev_join[2]}) if (x) (void)hipEventDestroy((hipEvent_t)x);
-    for (auto &x : sph.ev_m) if (x) (void)hipEventDestroy((hipEvent_t)x);
-    for (auto &x : sph.ev_f) if (x) (void)hipEventDestroy((hipEvent_t)x);
     if (pin) (void)hipHostFree(pin);
-}
-
-// What stage B's finishing pass needs for a launch of `ntiles` tiles (szl_internal.h SpillHost): nothing for a short launch — there the
-// end of a tile delays nobody and the pass would only add its own latency.
-int Engine::attach_spill(MTab &mt, int64_t ntiles) {
-    if (ntiles < knob("SZL9_SPILL_MIN_TILES", 1024)) return 0;
-    const int cap = match9_spill_cap();
-    const int64_t chunk = 2048;
-    const size_t slot = (size_t)chunk * (size_t)cap * 32u, cnts = (size_t)chunk * 4u;
-    if (int rc = m9_spill.ensure(SpillHost::RING * (slot + cnts) + 64)) return rc;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);               // (numerically: hi <= lo)
-    for (int h = 0; h < SpillHost::RING; h++) {
-        sph.pool[h] = (uint32_t *)((uint8_t *)m9_spill.p + (size_t)h * (slot + cnts));
-        sph.cnt[h] = (uint32_t *)((uint8_t *)sph.pool[h] + slot);
-    }
-    for (int k = 0; k < 3; k++)
-        if (!sph.str[k]) { hipStream_t s = nullptr; HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, k < 2 ? hi : lo)); sph.str[k] = s; }
-    auto mk = [](void *&e) -> hipError_t { if (e) return hipSuccess; hipEvent_t x = nullptr; hipError_t r = hipEventCreateWithFlags(&x, hipEventDisableTiming); e = x; return r; };
-    HIPCHK(mk(sph.ev_fork));
-    for (auto &e : sph.ev_join) HIPCHK(mk(e));
-    for (auto &e : sph.ev_m) HIPCHK(mk(e));
-    for (auto &e : sph.ev_f) HIPCHK(mk(e));
-    sph.chunk_tiles = chunk; sph.cap = cap;
-    mt.sph = &sph;
-    return 0;
 }
 
 template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t st) {
@@ -671,17 +640,9 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             if ((rc = m5_scratch.ensure(match5_scratch_bytes(nslots)))) return rc;
             HIPCHK(launch_match5(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const TileDev *)d_stripes.p, (int)stripes.size(), mt, P, (uint8_t *)m5_scratch.p, nslots, dcnt, st));
         }
-        else {
-            MTab mts = mt;
-            if ((rc = attach_spill(mts, (int64_t)stripes.size()))) return rc;
-            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mts, P, dcnt, st));
-        }
+        else HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
     }
-    else if (!lazy && !has_switch) {
-        MTab mts = mt;
-        if ((rc = attach_spill(mts, (int64_t)ntiles))) return rc;
-        HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mts, P, dcnt, st));
-    }
+    else if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     if (has_switch) { // tiles are grouped by parameter set: group 0 = the call's P, group k = sw_P[k-1] of the (single) switching segment
         size_t a = 0;
         while (a < tiles.size()) {
@@ -999,14 +960,8 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
                 if ((rc = m5_scratch.ensure(match5_scratch_bytes(nslots)))) return rc;
                 HIPCHK(launch_match5(d_in, in_total, dseg_real, (const uint64_t *)d_bnds.p, (const TileDev *)d_stripes.p, (int)stripes.size(), mtw, P, (uint8_t *)m5_scratch.p, nslots, dcnt, st));
             }
-            else if (!stripes.empty()) {
-                if ((rc = attach_spill(mtw, (int64_t)stripes.size()))) return rc;
-                HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
-            }
-            else {
-                if ((rc = attach_spill(mtw, (int64_t)ntiles))) return rc;
-                HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mtw, P, dcnt, st));
-            }
+            else if (!stripes.empty()) HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_stripes.p, (int)stripes.size(), lk, mtw, P, dcnt, st));
+            else HIPCHK(launch_match(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)ntiles, lk, mtw, P, dcnt, st));
             if (!last) HIPCHK(hipMemsetAsync((uint32_t *)mtab.p + wn, 0xFF, (size_t)(hi - wend) * 4, st)); // the tail past the parse end: evaluated on demand
         }
         HIPCHK(hipEventRecord(ev[3], st));

@@ -31,22 +31,6 @@ enum : int { LIT_NUM = 286, DIST_NUM = 30, BL_NUM = 19 };
 // fast != 0: DeflateFast (levels 1-4): max_lazy is the longest match whose interior is still inserted (:697)
 struct LevelParams { int good, nice, max_chain, strategy, max_lazy, fast; };
 
-// Stage B's finishing pass (szl_kernels_match9.hip).  The full search runs in chunks of tiles that alternate between two streams of
-// HIGH priority (no drain between chunks); each chunk is followed, on a third stream of LOW priority, by k_match9_finish over the walks
-// its tiles left behind.  The finishing pass (global memory, no LDS, few registers) then runs in the wave slots the search's one
-// workgroup per CU leaves free, and the dispatcher never lets it keep a search workgroup off a CU.  pool[h]: `cap` records of 8 dwords
-// per tile of a chunk; cnt[h]: records per tile.  Owned by the engine (szl_engine.hip attach_spill); HOST side only.
-struct SpillHost {
-    enum : int { RING = 4 };           // chunks in flight: pool slots, and the events that order their reuse
-    uint32_t *pool[RING] = {};
-    uint32_t *cnt[RING] = {};
-    int64_t chunk_tiles = 0;           // tiles a pool slot has room for
-    int cap = 0;                       // records per tile
-    void *str[3] = {};                 // hipStream_t: search (two), finishing pass
-    void *ev_fork = nullptr, *ev_join[3] = {};        // hipEvent_t: the call's stream -> the three; the three -> the call's stream
-    void *ev_m[RING] = {}, *ev_f[RING] = {};          // chunk searched; chunk finished (its pool slot may be written again)
-};
-
 // Stage-B output, indexed like the input buffer.  The parse reads ~4 bytes per position of it and is HBM-bound on exactly that
 // (k_spec_win, round-2 VERDICT), so an entry is ONE packed word in `m2`:
 //   [8:0] len of M2 (0 = no match, else 3..258), [23:9] its distance (<= 32506), [25:24] what Mq is:
@@ -56,7 +40,6 @@ struct SpillHost {
 struct MTab {
     uint32_t *m2;
     uint32_t *mq;
-    const struct SpillHost *sph = nullptr;   // HOST side only: what stage B's finishing pass needs (below); kernels never read it
     const uint16_t *link4 = nullptr;   // chain compression (szl_kernels_match3.hip): set => stage B may use k_match6
     const uint8_t *skip4 = nullptr;
     const uint16_t *e3d = nullptr;     // first chain element with the same three bytes: distance, chain index

@@ -90,8 +90,7 @@ __device__ __forceinline__ void b9_stage_window(uint8_t *smem, const uint8_t *d,
 template <bool DBG>
 __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs, const TileDev *__restrict__ tiles,
                                                        const uint16_t *__restrict__ link, MTab mtab, LevelParams P, unsigned long long *dbg,
-                                                       int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1, int vtht1, int guide,
-                                                       uint32_t *spill, uint32_t *spill_n, int spill_cap, int spill_th) {
+                                                       int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1, int vtht1, int guide) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const TileDev tile = tiles[blockIdx.x];
     const SegDev seg = segs[tile.seg];
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     unsigned long long *s_t = (unsigned long long *)(smem + B9_DBG);     // (DBG) [0] first wavefront out of positions, [1] last wavefront done
     const unsigned long long t_start = DBG ? wall_clock64() : 0ull;
     b9_stage_window(smem, d, lk, dlo, seg_end, t0 + tlen);
-    if (threadIdx.x == 0) { *(uint32_t *)smem = 0u; *(uint32_t *)(smem + 4) = 0u; *(uint32_t *)(smem + 8) = ~0u; if (DBG) { s_t[0] = ~0ull; s_t[1] = 0ull; s_t[2] = 0ull; s_t[3] = 0ull; } }
+    if (threadIdx.x == 0) { *(uint32_t *)smem = 0u; if (DBG) { s_t[0] = ~0ull; s_t[1] = 0ull; s_t[2] = 0ull; s_t[3] = 0ull; } }
     __syncthreads();
     const unsigned long long t_staged = DBG ? wall_clock64() : 0ull;
 
@@ -128,9 +127,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     auto sgpr64 = [](uint64_t x) { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32); };
     const int tlen_s = sgpr(tlen), slice_s = sgpr(slice), rem0_s = sgpr(rem0), sw_s = sgpr(sw), bmlo_s = sgpr(bmlo), bmhi_s = sgpr(bmhi), nicel_s = sgpr(nicel),
               chainm2_s = sgpr(chainm2), snapm1_s = sgpr(snapm1), vtht_s = sgpr(vtht), ktail_s = sgpr(ktail), qkeept_s = sgpr(128),
-              tailp_s = sgpr(tailp), mth_s = sgpr(mth), ktail1_s = sgpr(ktail1), vtht1_s = sgpr(vtht1), wscr_s = sgpr(B9_SCR + (int)(threadIdx.x & ~63u)), guide_s = sgpr(tlen - guide), spillcap_s = sgpr(spill_cap);
-    int spillth = sgpr(spill ? spill_th : -1);
-    const uint64_t spillb_s = sgpr64((uint64_t)(uintptr_t)(spill + (size_t)blockIdx.x * (size_t)spill_cap * 8u));
+              tailp_s = sgpr(tailp), mth_s = sgpr(mth), ktail1_s = sgpr(ktail1), vtht1_s = sgpr(vtht1), wscr_s = sgpr(B9_SCR + (int)(threadIdx.x & ~63u)), guide_s = sgpr(tlen - guide);
     const uint64_t stratm_s = sgpr64(stratm), mt2b_s = sgpr64((uint64_t)(uintptr_t)mt2b), mtqb_s = sgpr64((uint64_t)(uintptr_t)mtqb);
     uint32_t vzero, vslice;   // (constants in VGPRs: 0 and the slice length; the text sets them)
 #define SZL9_CTXV(X) uint32_t pl##X = 0, cb##X = 0, kk##X = 0, mincb##X = 0, left##X = 0, pb##X = 0, best##X = 2, off##X = 0, cap##X = MAX_MATCH, \
@@ -153,17 +150,13 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
 #undef SZL9_IO
                    [sc] "=&s"(sc), [cm] "=&s"(cm), [sa] "=&s"(sa), [sv] "=&s"(sv), [texh] "+&s"(texh), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2),
                    [f0] "=&s"(f0), [f1] "=&s"(f1), [f2] "=&s"(f2), [kt] "+&s"(kt), [wnext] "+&s"(wnext), [wend] "+&s"(wend), [exh] "+&s"(exh),
-                   [bexit] "+&s"(bexit), [vth] "+&s"(vth), [qkeep] "+&s"(qkeep), [spillth] "+&s"(spillth),
+                   [bexit] "+&s"(bexit), [vth] "+&s"(vth), [qkeep] "+&s"(qkeep),
                    [vzero] "=&v"(vzero), [vslice] "=&v"(vslice)
                  : [tlen] "s"(tlen_s), [slice] "s"(slice_s), [rem0] "s"(rem0_s), [sw] "s"(sw_s), [bmlo] "s"(bmlo_s),
                    [bmhi] "s"(bmhi_s), [nicel] "s"(nicel_s), [chainm2] "s"(chainm2_s), [snapm1] "s"(snapm1_s), [qkeept] "s"(qkeept_s), [vtht] "s"(vtht_s),
                    [ktail] "s"(ktail_s), [stratm] "s"(stratm_s), [mt2b] "s"(mt2b_s), [mtqb] "s"(mtqb_s),
-                   [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s), [vtht1] "s"(vtht1_s), [guide] "s"(guide_s), [spillcap] "s"(spillcap_s), [spillb] "s"(spillb_s)
+                   [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s), [vtht1] "s"(vtht1_s), [guide] "s"(guide_s)
                  : "vcc", "scc", "memory");
-    if (spill) {                                  // walks this tile left to k_match9_finish: the slots below the lowest refused base
-        __syncthreads();
-        if (threadIdx.x == 0) { const uint32_t a = *(volatile uint32_t *)(smem + 4), b = *(volatile uint32_t *)(smem + 8); spill_n[blockIdx.x] = a < b ? a : b; }
-    }
     if (DBG) {
         const unsigned long long t_end = wall_clock64();
         if ((threadIdx.x & 63) == 0) {
@@ -177,77 +170,6 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
             atomicAdd(dbg + 45, s_t[2] - s_t[0]); atomicAdd(dbg + 46, s_t[3]);
         }
     }
-}
-
-// ---- the finishing pass: the walks k_match9's wavefronts left behind (SZL9_SPILL_* in szl_match9_asm.h), one lane per walk, out of
-// global memory.  The same walk, step for step (Q_FINISH / CLASSIFY / VERIFY / COMPLETE / RETIRE of the text), in buffer positions:
-// cn = the next candidate (cb - best), lim = the lowest candidate allowed (mincb - best); both are invariant under COMPLETE's re-basing.
-// A step costs two gathers (the candidate's link; its two filter bytes in one unaligned 16-bit load) where the search pays three LDS
-// reads — an order of magnitude more per step, for the 2-3 % of the steps whose walks would otherwise hold a CU's LDS to the end.
-enum : int { B9F_THREADS = 256 };
-__global__ __launch_bounds__(B9F_THREADS) void k_match9_finish(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs, const TileDev *__restrict__ tiles,
-                                                               const uint16_t *__restrict__ link, MTab mtab, LevelParams P, const uint32_t *__restrict__ spill,
-                                                               const uint32_t *__restrict__ spill_n, int spill_cap, int nt) {
-    const uint32_t flat = blockIdx.x * (uint32_t)B9F_THREADS + threadIdx.x;
-    const uint32_t ti = flat / (uint32_t)spill_cap, slot = flat % (uint32_t)spill_cap;
-    if (ti >= (uint32_t)nt || slot >= spill_n[ti]) return;
-    const TileDev tile = tiles[ti];
-    const SegDev seg = segs[tile.seg];
-    const uint8_t *d = in + seg.buf_off;
-    const uint16_t *lk = link + seg.buf_off;
-    const int64_t dlo = tile.start - B_HIST;
-    const int snapm1 = P.max_chain - (P.max_chain >> 2) - 1;
-    const uint4 r0 = *(const uint4 *)(spill + (size_t)flat * 8u);
-    const uint4 r1 = *(const uint4 *)(spill + (size_t)flat * 8u + 4);
-    const int64_t p = dlo + (int32_t)r0.x;
-    int best = (int)r1.x;
-    int64_t cn = dlo + (int32_t)r0.y - best;
-    const int64_t lim = dlo + (int32_t)r1.y - best;
-    int hop = (int)(r0.z & 0xFFFFu), left = (int)r0.w;
-    bool cmp = (r0.z >> 16) != 0;
-    uint32_t res2 = r1.z, resq = r1.w;
-    const int64_t rem = seg.look_end - p;
-    const int cap = rem < MAX_MATCH ? (int)rem : MAX_MATCH, nice = rem < P.nice ? (int)rem : P.nice;
-    const uint8_t *dp = d + p;
-    auto ld16 = [](const uint8_t *q) { uint16_t v; __builtin_memcpy(&v, q, 2); return (uint32_t)v; };
-    uint32_t pb = ld16(dp + best - 1);                         // scan_end1, scan_end (:505-506)
-    for (;;) {
-        if (cmp) {                                             // VERIFY + COMPLETE (:502-607)
-            const uint8_t *dc = d + cn + hop;
-            int L = 0;
-            while (L + 8 <= cap) {
-                uint64_t a, b;
-                __builtin_memcpy(&a, dc + L, 8); __builtin_memcpy(&b, dp + L, 8);
-                if (a != b) { L += (int)(__builtin_ctzll(a ^ b) >> 3); break; }
-                L += 8;
-            }
-            if (L + 8 > cap) { while (L < cap && dc[L] == dp[L]) L++; }
-            bool stop = false;
-            if (L > best && L >= MIN_MATCH) {                     // (a walk that has found nothing yet carries best = 1: szl_match9_asm.h FETCH)
-                res2 = ((uint32_t)(p - (cn + hop)) << 16) | (uint32_t)L;
-                if (left >= snapm1) resq = res2;
-                best = L;
-                stop = L >= nice;
-                if (!stop) pb = ld16(dp + best - 1);             // (best < cap here: the bytes are the stream's)
-            }
-            if (stop || cn < lim || left < 0) break;
-            cmp = false;
-        }
-        uint32_t h = lk[cn];                                   // one chain step (:609 and the scan_end test)
-        const bool match = ld16(d + cn + best - 1) == pb;
-        if (h == 0) h = 65535u;                                // "no previous position": the hop that leaves every window, as staged in LDS
-        hop = (int)h;
-        const bool spent = left == 0;
-        left -= 1;
-        cn -= (int64_t)h;
-        if (spent || cn < lim) {
-            if (!match) break;
-            cmp = true;
-        } else if (match) cmp = true;
-    }
-    const uint32_t e = mt_pack(res2, resq);
-    (mtab.m2 + seg.buf_off)[p] = e;
-    if (mt_code(e) == 2u) (mtab.mq + seg.buf_off)[p] = resq;
 }
 
 static bool lds_attr_needed9(std::atomic<uint64_t> &mask, uint64_t &bit) {
@@ -267,11 +189,13 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     int fth = SZL_LABKNOB("SZL9_FTH", 16), vth = SZL_LABKNOB("SZL9_VTH", 2), qkeep = SZL_LABKNOB("SZL9_QKEEP", 64), ktail = SZL_LABKNOB("SZL9_KTAIL", 2), vtht = SZL_LABKNOB("SZL9_VTHT", 1);
     // the tail program (szl_match9_asm.h): 0 = the main loop to the end (laboratory); walks of both contexts move into one once they are
     // at most `mth` (<= 64; -1: never); iterations of the one-context walk between two looks at who left
-    int tailp = SZL_LABKNOB("SZL9_TAILP", 1), mth = SZL_LABKNOB("SZL9_MTH", 64), ktail1 = SZL_LABKNOB("SZL9_KTAIL1", 1), vtht1 = SZL_LABKNOB("SZL9_VTHT1", 1);
+    // (2 = the one-context loop with run-ahead and a third filter byte, round 6: ktail1 = 4 iterations of two steps between compare passes;
+    // 1 = the plain one-context loop of round 4, where ktail1 = 1 measured best)
+    int tailp = SZL_LABKNOB("SZL9_TAILP", 2), mth = SZL_LABKNOB("SZL9_MTH", 64), ktail1 = SZL_LABKNOB("SZL9_KTAIL1", 4), vtht1 = SZL_LABKNOB("SZL9_VTHT1", 1);
     mth = mth > 64 ? 64 : mth; ktail1 = ktail1 < 1 ? 1 : ktail1; vtht1 = vtht1 < 1 ? 1 : vtht1;
     int slice = SZL_LABKNOB("SZL_SLICE", 128);
     // hand-out near the tile's end: within `guide` positions of it a fetch takes as many positions as it has free lanes instead of a slice
-    int guide = SZL_LABKNOB("SZL9_GUIDE", 0);
+    int guide = SZL_LABKNOB("SZL9_GUIDE", 8192);
     fth = fth < 1 ? 1 : (fth > 64 ? 64 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; ktail = ktail < 1 ? 1 : ktail; vtht = vtht < 1 ? 1 : vtht;
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
     if (lds_attr_needed9(attr_mask, attr_bit)) {
@@ -280,49 +204,14 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
-    // the finishing pass (k_match9_finish): a wavefront down to `spill_th` walks leaves them to it; the search then runs in chunks of
-    // tiles that alternate between two streams, each chunk followed by its finishing pass (SpillHost, szl_internal.h)
-    const SpillHost *sph = mtab.sph;
-    const int spill_th = SZL_LABKNOB("SZL9_SPILL", 0);
-    int64_t chunk = 0;
-    if (sph && spill_th > 0 && sph->str[0] && ntiles >= knob("SZL9_SPILL_MIN_TILES", 1024)) {
-        chunk = ((int64_t)ntiles / SZL_LABKNOB("SZL9_SPILL_CHUNKS", 6) + 255) & ~(int64_t)255;
-        if (chunk < 512) chunk = 512;
-        if (chunk > sph->chunk_tiles) chunk = sph->chunk_tiles;
+    if (ntiles > 0) {
+        const dim3 g(ntiles), b(B9_THREADS);
+        if (want_dbg) hipLaunchKernelGGL((k_match9<true>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide);
+        else hipLaunchKernelGGL((k_match9<false>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide);
     }
-    mtab.sph = nullptr;
-    const dim3 b(B9_THREADS);
-#define SZL9_LAUNCH(DBGF, G, S, TL, SP, SN, CAP, TH) hipLaunchKernelGGL((k_match9<DBGF>), G, b, B9_LDS_BYTES, S, in, segs, TL, link, mtab, P, dbg, fth, vth, qkeep, ktail, \
-                                                                   slice, vtht, tailp, mth, ktail1, vtht1, guide, SP, SN, CAP, TH)
-    if (ntiles > 0 && chunk <= 0) {
-        if (want_dbg) SZL9_LAUNCH(true, dim3(ntiles), st, tiles, (uint32_t *)nullptr, (uint32_t *)nullptr, 0, -1);
-        else SZL9_LAUNCH(false, dim3(ntiles), st, tiles, (uint32_t *)nullptr, (uint32_t *)nullptr, 0, -1);
-    } else if (ntiles > 0) {
-        hipStream_t sa[2] = {(hipStream_t)sph->str[0], (hipStream_t)sph->str[1]}, sf = (hipStream_t)sph->str[2];
-        hipError_t e = hipEventRecord((hipEvent_t)sph->ev_fork, st);
-        for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipStreamWaitEvent((hipStream_t)sph->str[k], (hipEvent_t)sph->ev_fork, 0);
-        if (e != hipSuccess) return e;
-        int c = 0;
-        for (int64_t a = 0; a < ntiles; a += chunk, c++) {
-            const int n = (int)((int64_t)ntiles - a < chunk ? (int64_t)ntiles - a : chunk), h = c % SpillHost::RING;
-            hipStream_t s = sa[c & 1];
-            if (c >= SpillHost::RING && (e = hipStreamWaitEvent(s, (hipEvent_t)sph->ev_f[h], 0)) != hipSuccess) return e;   // the slot's last chunk is finished
-            if (want_dbg) SZL9_LAUNCH(true, dim3(n), s, tiles + a, sph->pool[h], sph->cnt[h], sph->cap, spill_th);
-            else SZL9_LAUNCH(false, dim3(n), s, tiles + a, sph->pool[h], sph->cnt[h], sph->cap, spill_th);
-            if ((e = hipEventRecord((hipEvent_t)sph->ev_m[h], s)) != hipSuccess || (e = hipStreamWaitEvent(sf, (hipEvent_t)sph->ev_m[h], 0)) != hipSuccess) return e;
-            const unsigned fb = (unsigned)(((int64_t)n * sph->cap + B9F_THREADS - 1) / B9F_THREADS);
-            if (SZL_LABKNOB("SZL9_SPILL_FINISH", 1))
-                hipLaunchKernelGGL(k_match9_finish, dim3(fb), dim3(B9F_THREADS), 0, sf, in, segs, tiles + a, link, mtab, P, (const uint32_t *)sph->pool[h], (const uint32_t *)sph->cnt[h], sph->cap, n);
-            if ((e = hipEventRecord((hipEvent_t)sph->ev_f[h], sf)) != hipSuccess) return e;
-        }
-        for (int k = 0; k < 3; k++)
-            if ((e = hipEventRecord((hipEvent_t)sph->ev_join[k], (hipStream_t)sph->str[k])) != hipSuccess || (e = hipStreamWaitEvent(st, (hipEvent_t)sph->ev_join[k], 0)) != hipSuccess) return e;
-    }
-#undef SZL9_LAUNCH
     return hipGetLastError();
 }
 
 int match9_tile() { return B9_TILE; }
-int match9_spill_cap() { const int c = SZL_LABKNOB("SZL9_SPILL_CAP", 512); return c < B9F_THREADS ? B9F_THREADS : c; }   // records per tile (a multiple of nothing in particular; >= one block of the finishing pass)
 
 } // namespace szl

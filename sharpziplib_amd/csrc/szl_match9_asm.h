@@ -406,52 +406,6 @@
     "v_cndmask_b32 %[" g "A], %[" g "A], %[t6B], %[sa]\n\t" \
     "v_cndmask_b32 %[" h "A], %[" h "A], %[t7B], %[sa]\n\t"
 
-// ---- SPILL: hand the wavefront's last walks to the finishing pass -----------------------------------------------------------------
-// The end of a tile is a few walks per wavefront, each a dependent chain of up to max_chain rounds, with the CU's LDS — and so the CU —
-// held until the last one ends (profiles/r06: a wavefront's own tail 29 us on average, 45 for the tile's slowest, of a 197 us tile).
-// Once a wavefront is down to `spillth` walks it writes their state (8 dwords each) into the tile's region of the spill pool and
-// leaves; k_match9_finish continues them out of global memory (szl_kernels_match9.hip), where a walk costs more per step and nobody
-// waits for it.  Slots come from an LDS counter (LDS byte 4); a wavefront that does not get its slots (region full) records the base
-// it was refused at (LDS byte 8: the valid slots are those below the lowest such base), never asks again and runs the tail program.
-// Record: pl, cb, hop | phase << 16 (1: the candidate cb + hop - best is to be compared), left, best, mincb, res2, resq.
-#define SZL9_SPILL_ALLOC(N) \
-    "s_mov_b64 exec, 1\n\t" \
-    "v_mov_b32 %[t2A], %[" N "]\n\t" \
-    "ds_add_rtn_u32 %[t1A], %[vzero], %[t2A] offset:4\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    "v_readfirstlane_b32 %[f0], %[t1A]\n\t"                                        /* first slot */ \
-    "s_add_u32 %[f1], %[f0], %[" N "]\n\t" \
-    "s_cmp_le_u32 %[f1], %[spillcap]\n\t"
-#define SZL9_SPILL_REFUSED \
-    "v_mov_b32 %[t2A], %[f0]\n\t" \
-    "ds_min_u32 %[vzero], %[t2A] offset:8\n\t" \
-    "s_mov_b32 %[spillth], -1\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t"
-#define SZL9_SPILL_STORE(X) \
-    "s_or_b64 %[cm], %[q" #X "], %[v" #X "]\n\t" \
-    "s_or_b64 %[cm], %[cm], %[w" #X "]\n\t" \
-    "s_mov_b64 exec, %[cm]\n\t" \
-    "s_cbranch_execz 75f\n\t" \
-    "v_mbcnt_lo_u32_b32 %[t0" #X "], exec_lo, 0\n\t" \
-    "v_mbcnt_hi_u32_b32 %[t0" #X "], exec_hi, %[t0" #X "]\n\t"                  /* rank among the walks */ \
-    "v_add_u32 %[t0" #X "], %[f0], %[t0" #X "]\n\t" \
-    "v_lshlrev_b32 %[t0" #X "], 5, %[t0" #X "]\n\t"                              /* 32 bytes per record */ \
-    "s_or_b64 %[sc], %[v" #X "], %[w" #X "]\n\t"                                  /* a compare under way starts again */ \
-    "v_cndmask_b32 %[t1" #X "], 0, 1, %[sc]\n\t" \
-    "v_lshl_or_b32 %[t1" #X "], %[t1" #X "], 16, %[hop" #X "]\n\t" \
-    "global_store_dword %[t0" #X "], %[pl" #X "], %[spillb]\n\t" \
-    "global_store_dword %[t0" #X "], %[cb" #X "], %[spillb] offset:4\n\t" \
-    "global_store_dword %[t0" #X "], %[t1" #X "], %[spillb] offset:8\n\t" \
-    "global_store_dword %[t0" #X "], %[left" #X "], %[spillb] offset:12\n\t" \
-    "global_store_dword %[t0" #X "], %[best" #X "], %[spillb] offset:16\n\t" \
-    "global_store_dword %[t0" #X "], %[mincb" #X "], %[spillb] offset:20\n\t" \
-    "global_store_dword %[t0" #X "], %[res2" #X "], %[spillb] offset:24\n\t" \
-    "global_store_dword %[t0" #X "], %[resq" #X "], %[spillb] offset:28\n" \
-    "75:\n\t" \
-    "s_mov_b64 %[q" #X "], 0\n\t" \
-    "s_mov_b64 %[v" #X "], 0\n\t" \
-    "s_mov_b64 %[w" #X "], 0\n\t"
-
 // ---- the one-context loop with RUN-AHEAD (tailp = 2) ------------------------------------------------------------------------------
 // In the plain one-context loop a wavefront's few walks take turns: two chain steps for the walkers, then — most rounds — a compare and
 // its completion for the one or two lanes whose candidate passed the filter, ~110 instructions a round of which the slowest walk, the
@@ -630,8 +584,6 @@
     "s_add_u32 %[n2], %[n0], %[n1]\n\t" \
     "s_cmp_eq_u32 %[n2], 0\n\t" \
     "s_cbranch_scc1 98f\n\t" \
-    "s_cmp_le_i32 %[n2], %[spillth]\n\t"                 /* few enough to leave to the finishing pass */ \
-    "s_cbranch_scc1 72f\n\t" \
     "s_cmp_eq_u32 %[n1], 0\n\t"                          /* context B is empty: the one-context loop */ \
     "s_cbranch_scc1 60f\n\t" \
     "s_cmp_le_i32 %[n2], %[mth]\n\t"                     /* both fit one context: move B's walks over */ \
@@ -790,8 +742,6 @@
     SZL9_BUSY(A, "n0") \
     "s_cmp_eq_u32 %[n0], 0\n\t" \
     "s_cbranch_scc1 98f\n\t" \
-    "s_cmp_le_i32 %[n0], %[spillth]\n\t" \
-    "s_cbranch_scc1 70f\n\t" \
     "s_bcnt1_i32_b64 %[n2], %[vA]\n\t" \
     "s_cmp_ge_u32 %[n2], %[vtht1]\n\t" \
     "s_cbranch_scc1 64f\n\t" \
@@ -843,29 +793,6 @@
     SZL9_COMPLETE(A) \
     "s_branch 60b\n" \
     SZL9_TAIL_RA \
-    /* ---- 70 / 72: the last walks go to the finishing pass */ \
-    "; @phase spill\n" \
-    "70:\n\t" \
-    SZL9_RETIRE(A) \
-    SZL9_SPILL_ALLOC("n0") \
-    "s_cbranch_scc0 71f\n\t" \
-    SZL9_SPILL_STORE(A) \
-    "s_branch 98f\n" \
-    "71:\n\t" \
-    SZL9_SPILL_REFUSED \
-    "s_branch 60b\n" \
-    "72:\n\t" \
-    SZL9_RETIRE(A) \
-    SZL9_RETIRE(B) \
-    SZL9_SPILL_ALLOC("n2") \
-    "s_cbranch_scc0 73f\n\t" \
-    SZL9_SPILL_STORE(A) \
-    "s_add_u32 %[f0], %[f0], %[n0]\n\t" \
-    SZL9_SPILL_STORE(B) \
-    "s_branch 98f\n" \
-    "73:\n\t" \
-    SZL9_SPILL_REFUSED \
-    "s_branch 40b\n" \
     "; @phase retire\n" \
     "98:\n\t" \
     SZL9_RETIRE(A) \

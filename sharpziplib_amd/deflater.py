@@ -151,6 +151,14 @@ class Deflater:
     def Adler(self):
         return self._L.szl_deflater_adler(self._h)
 
+    def CallerDrains(self, on=True):
+        """(include/szl.h szl_deflater_caller_drains) the caller takes all Deflate() offers before it changes a parameter, as
+        DeflaterOutputStream does (CS/DeflaterOutputStream.cs:242-272); without this a SetLevel / SetStrategy with 16 KiB or more
+        pending is refused (NotSupportedOnDevice) rather than answered with bytes that depend on an assumption."""
+        s = self._L.szl_deflater_caller_drains(self._h, 1 if on else 0)
+        if s < 0:
+            _raise(s, "CallerDrains")
+
     # device-side CRC-32 of the input (include/szl.h: what GZipOutputStream / ZipOutputStream keep on the CPU over every Write)
     def EnableCrc32(self, on=True):
         s = self._L.szl_deflater_enable_crc32(self._h, 1 if on else 0)

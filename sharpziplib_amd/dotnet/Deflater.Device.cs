@@ -34,6 +34,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		[DllImport(Lib)] internal static extern long szl_deflater_total_out(IntPtr d);
 		[DllImport(Lib)] internal static extern uint szl_deflater_adler(IntPtr d);
 		[DllImport(Lib)] internal static extern int szl_deflater_enable_crc32(IntPtr d, int on);
+		[DllImport(Lib)] internal static extern int szl_deflater_caller_drains(IntPtr d, int on);
 		[DllImport(Lib)] internal static extern uint szl_deflater_crc32(IntPtr d);
 
 		[DllImport(Lib)] internal static extern IntPtr szl_inflater_create(int noHeader);
@@ -123,6 +124,9 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression
 		/// <summary>CRC-32 of the input given so far, kept on the device beside the compression (include/szl.h): a device-aware
 		/// GZipOutputStream / ZipOutputStream switches it on before the first SetInput and reads it where the reference reads crc.Value
 		/// (S/GZip/GzipOutputStream.cs:210,330; S/Zip/ZipOutputStream.cs:700).</summary>
+		/// <summary>The caller takes everything Deflate() offers before it changes a parameter (DeflaterOutputStream does, :242-272).  Only then is a
+		/// SetLevel / SetStrategy with 16 KiB or more pending answered (include/szl.h szl_deflater_caller_drains); otherwise NotSupportedException.</summary>
+		public void CallerDrains(bool on = true) { Check(SzlNative.szl_deflater_caller_drains(h, on ? 1 : 0), nameof(CallerDrains)); }
 		internal void EnableCrc32(bool on = true) { Check(SzlNative.szl_deflater_enable_crc32(h, on ? 1 : 0), nameof(EnableCrc32)); }
 		internal long Crc32 => SzlNative.szl_deflater_crc32(h);
 		public long TotalIn => SzlNative.szl_deflater_total_in(h);                                       // :226

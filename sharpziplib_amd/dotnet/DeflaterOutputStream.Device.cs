@@ -36,6 +36,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			baseOutputStream_ = baseOutputStream;
 			buffer_ = new byte[bufferSize];                   // (only a crypto transform's blocks pass through it now)
 			deflater_ = deflater ?? throw new ArgumentNullException(nameof(deflater));
+			deflater_.CallerDrains();                      // Deflate() below runs until IsNeedingInput: a SetLevel in mid-stream is exact (include/szl.h)
 		}
 
 		// One turn of the reference's two loops: the next compressed bytes go to the base stream; false where Deflate() returned <= 0.

@@ -27,6 +27,8 @@ class DeflaterOutputStream:
         self.baseOutputStream_ = baseOutputStream
         self.buffer_ = np.zeros(bufferSize, dtype=np.uint8)
         self.deflater_ = deflater if deflater is not None else Deflater()
+        if hasattr(self.deflater_, "CallerDrains"):
+            self.deflater_.CallerDrains(True)                  # Deflate() below runs until IsNeedingInput (:242-272): say so (include/szl.h)
         self.IsStreamOwner = True
         self.isClosed_ = False
         # ICryptoTransform of the reference (:200): any object with TransformBlock(in, inOff, count, out, outOff) -> count.

@@ -29,6 +29,7 @@ CASES = {
     "cfg1_dickens_64m_l6": ("dickens", 0xD1CE, 0, 64 << 20, 6, 0),  # configs[0]: raw Deflater level 6 on 64 MiB of prose
     "cfg5_logs_4g_l9": ("logs", 0x106, 0, 4 << 30, 9, 0),           # configs[4] at FULL size (bench.py times it through the window pipeline)
     "cfg3_100000x64k_enwik_l6": ("enwik", 0x21B0, 0, 100000 * 65536, 6, 65536),   # configs[2] at FULL size, the very entries bench.py compresses: every one of them hashed
+    "cfg5_64x64m_logs_l9": ("logs", 0x106, 0, 4 << 30, 9, 64 << 20),  # configs[4] as bench.py --workload cfg5 runs it over N ranks: the 4 GiB as 64 streams ("shard = stream") that change owner in the rebalance
 }
 
 
@@ -52,7 +53,7 @@ def main():
                 d = data[i * entry:(i + 1) * entry]
                 return O.deflate(d, level), int(O.crc32(d))
             with ThreadPool(len(os.sched_getaffinity(0))) as pool:
-                for comp, crc in pool.imap(one, range(n // entry), chunksize=64):
+                for comp, crc in pool.imap(one, range(n // entry), chunksize=max(1, min(64, n // entry // (4 * len(os.sched_getaffinity(0)))))):
                     h.update(comp)
                     crcs.update(crc.to_bytes(4, "little"))
                     total += len(comp)

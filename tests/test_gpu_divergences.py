@@ -5,8 +5,9 @@ has a test that constructs the pattern against the oracle:
   * a block the reference decodes non-canonically, fed in pieces of odd length (CS/StreamManipulator.cs:244-262): exact while the phase
     of the reference's 16-bit loads can be known, SZL_E_UNSUPPORTED -> NotSupportedException otherwise — never other garbage;
   * SetLevel while compressed bytes still wait in the reference's pending buffer (C/DeflaterEngine.cs:126-139): the device equals the
-    reference for a caller who drains Deflate() (the only pattern the reference's own stream classes have); the test pins what a caller
-    who does NOT drain gets from the reference, so that the difference is written down in bytes and SZL_STRICT=1 turns it into an error."""
+    reference for a caller who drains Deflate() (the only pattern the reference's own stream classes have) and has said so
+    (szl_deflater_caller_drains; the stream classes do); any other caller's change is refused (round 6: no environment variable
+    needed), since the object cannot see which of the two it is talking to; the test pins both of the reference's byte strings."""
 import numpy as np
 import pytest
 
@@ -153,7 +154,7 @@ def test_quirk_blocks_fed_in_pieces_are_exact_or_refused():
 
 
 # ---- SetLevel while compressed bytes wait in the reference's pending buffer ----------------------------------------------------------
-def test_setlevel_with_output_pending_is_pinned_and_strict_mode_refuses_it():
+def test_setlevel_with_output_pending_is_exact_for_a_declared_drainer_and_refused_otherwise():
     from sharpziplib_amd.deflater import Deflater, NotSupportedOnDevice
     data = C.generate("enwik", 64, 0, 400000)
     a, b = data[:300000], data[300000:]
@@ -180,28 +181,37 @@ def test_setlevel_with_output_pending_is_pinned_and_strict_mode_refuses_it():
         return bytes(out)
     drained, undrained = reference(True), reference(False)
     assert drained != undrained                               # the pattern exists: the reference's bytes depend on the caller's buffer
-    d = Deflater(6, True)
-    d.SetInput(a)
     buf = np.zeros(512, np.uint8)
-    assert d.Deflate(buf) == 0                                # this backend compresses at Flush() / Finish(): "nothing yet", i.e. drained
-    d.SetLevel(9)
-    d.SetInput(b); d.Finish()
-    got = bytearray()
     big = np.zeros(1 << 20, np.uint8)
-    while not d.IsFinished:
-        k = d.Deflate(big)
-        got += big[:k].tobytes()
-    assert bytes(got) == drained                              # == the reference for every caller that drains (CS/DeflaterOutputStream.cs:242-272)
-    # SZL_STRICT=1: a level change with enough input pending for the reference to have produced a block is refused, loudly
-    L = _lib.lib()
-    L.szl_debug_set(b"SZL_STRICT", 1)
-    try:
+
+    def device(declare):
         d = Deflater(6, True)
+        if declare:
+            d.CallerDrains()                                  # what the stream classes say for the Deflater they drive (include/szl.h)
         d.SetInput(a)
-        d.Deflate(buf)
-        with pytest.raises(NotSupportedOnDevice):
-            d.SetLevel(9)
-        d = Deflater(6, True)                                 # ... but not when nothing could have been produced yet
-        d.SetInput(a[:3000]); d.Deflate(buf); d.SetLevel(9)
+        assert d.Deflate(buf) == 0                            # this backend compresses at Flush() / Finish(): "nothing yet"
+        d.SetLevel(9)
+        d.SetInput(b); d.Finish()
+        got = bytearray()
+        while not d.IsFinished:
+            k = d.Deflate(big)
+            got += big[:k].tobytes()
+        return bytes(got)
+    # no environment variable, no declaration: the object cannot know which of the two callers it has, and says so instead of guessing
+    with pytest.raises(NotSupportedOnDevice):
+        device(False)
+    assert device(True) == drained                            # == the reference for the caller who drains (CS/DeflaterOutputStream.cs:242-272)
+    d = Deflater(6, True)                                     # ... and nothing is refused while nothing could have been produced yet
+    d.SetInput(a[:3000]); d.Deflate(buf); d.SetLevel(9)
+    d = Deflater(6, True)                                     # ... or after a Flush(): the engine stands at the end of the input then, whoever calls
+    d.SetInput(a); d.Flush()
+    while d.Deflate(big):
+        pass
+    d.SetLevel(9)
+    # SZL_STRICT=0: the silent assumption of rounds 3-5
+    L = _lib.lib()
+    L.szl_debug_set(b"SZL_STRICT", 0)
+    try:
+        assert device(False) == drained
     finally:
         L.szl_debug_set(b"SZL_STRICT", -2147483648)

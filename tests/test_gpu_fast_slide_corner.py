@@ -59,6 +59,7 @@ def test_device_follows_the_feeding_order(level):
         for cuts in ([], [p + 261], [p + 260], [p + 262], [1000, p + 261], [p + 261, p + 2000], [p - 40000, p + 261 - 32768 if k else 50, p + 261]):
             cuts = sorted(set(c for c in cuts if 0 < c < len(d)))
             dev = Deflater(level, True)
+            dev.CallerDrains()
             got = bytearray()
             prev = 0
             for c in cuts + [len(d)]:

@@ -44,6 +44,7 @@ def test_reset_after_flush_keeps_the_partial_byte(level, nowrap):
     from sharpziplib_amd.deflater import Deflater
     for seed, n in ((1, 5000), (2, 70000), (3, 1234), (4, 33333), (5, 9), (6, 2500)):
         d, o = Deflater(level, nowrap), O.Deflater(level, nowrap)
+        d.CallerDrains()                                      # (these drivers take all Deflate() offers before every change: include/szl.h)
         a = C.generate("enwik", seed, 0, n)
         d.SetInput(a); o.set_input(a)
         d.Flush(); o.flush()
@@ -67,6 +68,7 @@ def test_reset_with_unflushed_full_blocks(level):
     differs = 0
     for seed, total in ((11, 300000), (12, 90000), (13, 700000), (14, 20000), (15, 200000), (16, 400000)):
         d, o = Deflater(level, True), O.Deflater(level, True)
+        d.CallerDrains()                                      # (these drivers take all Deflate() offers before every change: include/szl.h)
         data = C.generate("enwik" if seed & 1 else "logs", seed, 0, total)
         buf = np.zeros(8192, np.uint8)
         for off in range(0, total, 40000):
@@ -88,11 +90,13 @@ def test_reset_twice_and_level0():
     b = C.generate("logs", 22, 0, 3000)
     # the stale byte survives a second Reset() (nothing has overwritten `bits`)
     d, o = Deflater(6, True), O.Deflater(6, True)
+    d.CallerDrains()                                      # (these drivers take all Deflate() offers before every change: include/szl.h)
     d.SetInput(a); o.set_input(a); d.Flush(); o.flush(); _drain(d, o)
     d.Reset(); o.reset()
     _second_stream(d, o, b, "reset twice")
     # level 0 behind a coded partial byte: AlignToByte writes the whole `bits` as the stored block's header byte
     d, o = Deflater(6, True), O.Deflater(6, True)
+    d.CallerDrains()                                      # (these drivers take all Deflate() offers before every change: include/szl.h)
     d.SetInput(a); o.set_input(a); d.Flush(); o.flush(); _drain(d, o)
     d.Reset(); o.reset()
     d.SetLevel(0); o.set_level(0)
@@ -101,6 +105,7 @@ def test_reset_twice_and_level0():
     assert got == ref
     # a level-0 stream that was not finished: its blocks end on a byte, `bits` is clear
     d, o = Deflater(0, True), O.Deflater(0, True)
+    d.CallerDrains()                                      # (these drivers take all Deflate() offers before every change: include/szl.h)
     big = C.generate("enwik", 23, 0, 150000)
     d.SetInput(big); o.set_input(big)
     buf = np.zeros(8192, np.uint8)

@@ -40,6 +40,7 @@ def _run(levels, seed, total=600000, strategies=(0,), flush_p=0.25, call_before_
     data = np.concatenate([C.generate("enwik", seed, 0, total // 2), C.generate("logs", seed + 1, 0, total - total // 2)])
     level = int(rng.choice(levels))
     d, o = Deflater(level, True), O.Deflater(level, True)
+    d.CallerDrains()                                      # (these drivers take all Deflate() offers before every change: include/szl.h)
     got, ref = bytearray(), bytearray()
     buf = np.zeros(8192, np.uint8)
     pos, calls = 0, 0

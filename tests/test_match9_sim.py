@@ -20,6 +20,11 @@ SIM = os.path.join(ROOT, "tools", "sim_match9.py")
     ["--kib", "96", "--tlen", "3072", "--tile", "5", "--cut", "100"],                  # the segment ends inside the tile's lookahead: clamps of cap / nice
     ["--kib", "96", "--tlen", "3072", "--tile", "3", "--tailp", "0"],                  # the main loop to the end (the laboratory form)
     ["--kind", "zeros", "--kib", "64", "--tlen", "2048", "--tile", "3"],
+    # round 6: the plain one-context loop (the default is the run-ahead loop), slices to the end, the first tile (history before the stream)
+    ["--kib", "96", "--tlen", "3072", "--tile", "3", "--tailp", "1", "--ktail1", "1", "--guide", "0"],
+    ["--kind", "logs", "--level", "9", "--kib", "64", "--tlen", "4096", "--tile", "0", "--ktail1", "2"],
+    ["--kind", "logs", "--level", "6", "--kib", "96", "--tlen", "6144", "--tile", "7", "--ktail1", "1", "--guide", "100000"],
+    ["--kind", "dickens", "--level", "8", "--kib", "128", "--tlen", "8192", "--tile", "9"],
 ])
 def test_instruction_text_reproduces_the_model(args):
     r = subprocess.run([sys.executable, SIM] + args, capture_output=True, text=True, timeout=300)

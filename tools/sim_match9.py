@@ -63,69 +63,16 @@ def pack(r2, rq):
     return (r2 & 0x1FF) | ((r2 >> 16) << 9) | (code << 24)
 
 
-def finish_walks(data, link, spill, nspill, t0, seg_end, P, mt2, mtq):
-    """k_match9_finish (szl_kernels_match9.hip) in Python: continue each spilled walk out of the stream's arrays"""
-    dlo = t0 - B_HIST
-    snapm1 = P.max_chain - (P.max_chain >> 2) - 1
-    steps = 0
-    d = data
-    s32 = lambda x: int(x) - (1 << 32) if int(x) >= (1 << 31) else int(x)   # noqa: E731
-    for slot in range(nspill):
-        r = spill[8 * slot:8 * slot + 8]
-        pl = s32(r[0]); p = dlo + pl
-        best = int(r[4]); cn = dlo + s32(r[1]) - best; lim = dlo + s32(r[5]) - best
-        hop = int(r[2]) & 0xFFFF; cmp_ = (int(r[2]) >> 16) != 0; left = s32(r[3])
-        res2, resq = int(r[6]), int(r[7])
-        rem = seg_end - p
-        cap = min(258, rem); nice = min(P.nice, rem)
-        while True:
-            if cmp_:
-                c = cn + hop
-                L = 0
-                while L < cap and d[c + L] == d[p + L]:
-                    L += 1
-                stop = False
-                if L > best and L >= 3:
-                    res2 = ((p - c) << 16) | L
-                    if left >= snapm1:
-                        resq = res2
-                    best = L
-                    stop = L >= nice
-                if stop or cn < lim or left < 0:
-                    break
-                cmp_ = False
-            h = int(link[cn]) or 65535
-            match = d[cn + best - 1] == d[p + best - 1] and d[cn + best] == d[p + best]
-            hop = h
-            spent = left == 0
-            left -= 1
-            cn -= h
-            steps += 1
-            if spent or cn < lim:
-                if not match:
-                    break
-                cmp_ = True
-            elif match:
-                cmp_ = True
-        e = pack(np.uint32(res2), np.uint32(resq))
-        mt2[pl] = e
-        if (int(e) >> 24) == 2:
-            mtq[pl] = resq
-    print("finishing pass: %d chain steps for %d walks" % (steps, nspill))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="enwik"); ap.add_argument("--kib", type=int, default=128); ap.add_argument("--tile", type=int, default=1)
     ap.add_argument("--tlen", type=int, default=21504); ap.add_argument("--level", type=int, default=6); ap.add_argument("--nq", type=int, default=3)
-    ap.add_argument("--waves", type=int, default=16); ap.add_argument("--fth", type=int, default=24); ap.add_argument("--vth", type=int, default=2)
+    ap.add_argument("--waves", type=int, default=16); ap.add_argument("--fth", type=int, default=16); ap.add_argument("--vth", type=int, default=2)
     ap.add_argument("--wth", type=int, default=2); ap.add_argument("--wkeep", type=int, default=2); ap.add_argument("--qkeep", type=int, default=64)
-    ap.add_argument("--qkeept", type=int, default=128); ap.add_argument("--vtht", type=int, default=1); ap.add_argument("--ktail", type=int, default=4); ap.add_argument("--slice", type=int, default=128); ap.add_argument("--abs0", type=int, default=0)
+    ap.add_argument("--qkeept", type=int, default=128); ap.add_argument("--vtht", type=int, default=1); ap.add_argument("--ktail", type=int, default=2); ap.add_argument("--slice", type=int, default=128); ap.add_argument("--abs0", type=int, default=0)
     ap.add_argument("--notail", action="store_true"); ap.add_argument("--strategy", type=int, default=0); ap.add_argument("--quantum", type=int, default=300)
-    ap.add_argument("--tailp", type=int, default=1); ap.add_argument("--mth", type=int, default=64); ap.add_argument("--ktail1", type=int, default=1)
-    ap.add_argument("--guide", type=int, default=0, help="within this many positions of the tile's end a fetch takes its free lanes' worth of positions")
-    ap.add_argument("--spill", type=int, default=0, help="a wavefront down to this many walks leaves them to the finishing pass (0: never)")
-    ap.add_argument("--spillcap", type=int, default=512)
+    ap.add_argument("--tailp", type=int, default=2); ap.add_argument("--mth", type=int, default=64); ap.add_argument("--ktail1", type=int, default=4)
+    ap.add_argument("--guide", type=int, default=8192, help="within this many positions of the tile's end a fetch takes its free lanes' worth of positions")
     ap.add_argument("--cut", type=int, default=0, help="segment ends this many bytes before the end of the generated data's last tile (lookahead clamps)")
     a = ap.parse_args()
     import oracle_ffi as O
@@ -153,8 +100,6 @@ def main():
     print("program: %d instructions; model %.1fs" % (len(prog.ins), time.time() - t), flush=True)
     mt2 = np.full(B_HIST + tile_cap + 64, 0xDEADBEEF, dtype=np.uint32)
     mtq = np.full(B_HIST + tile_cap + 64, 0xDEADBEEF, dtype=np.uint32)
-    spill = np.zeros(a.spillcap * 8 + 64, dtype=np.uint32)
-    lds[4:8] = 0; lds[8:12] = 255            # the spill region's slot counter and the lowest refused base (the kernel's thread 0 sets them)
     vnames = ["vzero", "vslice"] + [x + c for c in "AB" for x in
                                    ["pl", "cb", "kk", "mincb", "left", "pb", "best", "off", "cap", "nice", "res2", "resq", "p0", "p1", "p2", "p3", "hop",
                                     "t0", "t1", "t2", "t3", "t4", "t5", "t6", "t7"]]
@@ -168,17 +113,12 @@ def main():
                  wnext=0, wend=0, exh=0, tlen=tlen, slice=a.slice, rem0=K["rem0"], sw=K["sw"] & W.M32, bmlo=K["bmlo"], bmhi=K["bmhi"],
                  nicel=P.nice, chainm2=(P.max_chain - 2) & W.M32, snapm1=(P.max_chain - (P.max_chain >> 2) - 1) & W.M32, bexit=64 - a.fth, vth=a.vth, wth=a.wth,
                  wkeep=a.wkeep, qkeep=a.qkeep, qkeept=a.qkeept, vtht=a.vtht, ktail=a.ktail, kt=0, texh=0, stratm=0 if a.strategy == 2 else M64, mt2b=0, mtqb=0,
-                 tailp=a.tailp, mth=a.mth & W.M32, ktail1=a.ktail1, vtht1=1, wscr=162368 + 64 * w, guide=(tlen - a.guide) & W.M32,
-                 spillth=(a.spill if a.spill > 0 else -1) & W.M32, spillcap=a.spillcap, spillb=0)
-        waves.append(W.Wave(prog, lds, v, s, {"mt2b": mt2, "mtqb": mtq, "spillb": spill}))
+                 tailp=a.tailp, mth=a.mth & W.M32, ktail1=a.ktail1, vtht1=1, wscr=162368 + 64 * w, guide=(tlen - a.guide) & W.M32)
+        waves.append(W.Wave(prog, lds, v, s, {"mt2b": mt2, "mtqb": mtq}))
         waves[-1].tail_flag = None if a.notail else "exh"
     t = time.time()
     W.run_workgroup(waves, quantum=a.quantum)
     print("simulated in %.1fs" % (time.time() - t))
-    nspill = min(int.from_bytes(lds[4:8].tobytes(), "little"), int.from_bytes(lds[8:12].tobytes(), "little"))
-    if a.spill > 0:
-        print("spilled walks: %d (counter %d, lowest refused base %d)" % (nspill, int.from_bytes(lds[4:8].tobytes(), "little"), int.from_bytes(lds[8:12].tobytes(), "little")))
-        finish_walks(data, model.link, spill, nspill, t0, n, P, mt2, mtq)
     # ---- compare
     want2 = model.m2[t0:t0 + tlen]; wantq = model.mq[t0:t0 + tlen]
     wante = pack(want2, wantq)
