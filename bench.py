@@ -44,6 +44,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--quick-configs", action="store_true", help="the other configs at the round-3 sizes (2 GiB / 25000 entries / 1 GiB) instead of BASELINE.json's")
     ap.add_argument("--stub", action="store_true", help="CPU-only plumbing test: gloo, ranks sleep instead of compressing")
+    ap.add_argument("--workload", choices=("headline", "cfg3", "cfg5"), default="headline",
+                    help="headline: configs[1], one 1 GiB stream per GPU (the metric).  cfg3: configs[2], --entries x 64 KiB zip entries sharded by "
+                         "contiguous groups over the ranks (strong scaling; sizes all-gathered for the archive's layout).  cfg5: configs[4], "
+                         "--total-mib of logs at level 9 as 64 MiB streams that start on the ranks in a skewed split and change owner in an "
+                         "all-to-all (shard.rebalance over RCCL) before they are compressed where they land (strong scaling)")
+    ap.add_argument("--entries", type=int, default=100000, help="cfg3: zip entries in all (BASELINE: 100000)")
+    ap.add_argument("--total-mib", type=int, default=4096, help="cfg5: MiB of logs in all (BASELINE: 4096)")
+    ap.add_argument("--piece-mib", type=int, default=64, help="cfg5: MiB per stream")
     return ap.parse_args(argv)
 
 
@@ -560,10 +568,279 @@ def run_strong(args, rank, world, dist):
         dist.barrier()
 
 
+# ---- the multi-rank shapes of BASELINE configs[2] and configs[4] -------------------------------------------------------------------------
+# Same launch contract, same JSON schema (n_gpus, roofline, parity) as the headline; the total work is fixed, so "scaling" is "strong".
+# --stub runs the whole host side — sharding, the size all-gather, the archive layout, the rebalance all-to-all (gloo), the MAX
+# reduction — with a stand-in for the device call (tests/test_bench_launcher.py, world 2).
+
+def _device_setup(local_rank):
+    import torch
+    from sharpziplib_amd import _lib
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.lib().szl_set_device(local_rank), "szl_set_device")
+    dev = torch.device("cuda", local_rank)
+    return torch, dev, torch.cuda.current_stream(dev).cuda_stream
+
+
+def _timed(step, steps, warmup, dist, sync):
+    """the contract's timed region: warm-up, barrier + synchronize on both sides, MAX over ranks"""
+    from sharpziplib_amd import shard
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    return shard.max_over_ranks(time.perf_counter() - t0, dist)
+
+
+def _gather_bytes_in_order(dist, rank, world, pieces, feed):
+    """every rank's compressed streams to rank 0, in global order, for ONE sha256 over all of them (outside the timed region).
+    pieces: [(global index, uint8 tensor)] of this rank, ascending.  feed(global index, bytes) runs on rank 0."""
+    import torch
+    meta = [None] * world
+    if dist is not None:
+        dist.all_gather_object(meta, [(g, int(t.numel())) for g, t in pieces])
+    else:
+        meta = [[(g, int(t.numel())) for g, t in pieces]]
+    if rank == 0:
+        order = sorted((g, r, k) for r in range(world) for k, (g, _) in enumerate(meta[r]))
+        mine = dict((g, t) for g, t in pieces)
+        bufs = {}
+        for r in range(1, world):                               # one receive per peer: its streams back to back
+            tot = sum(n for _, n in meta[r])
+            buf = torch.empty(tot, dtype=torch.uint8, device=pieces[0][1].device if pieces else "cpu")
+            if tot:
+                dist.recv(buf, src=r)
+            offs, pos = {}, 0
+            for g, n in meta[r]:
+                offs[g] = (pos, n)
+                pos += n
+            bufs[r] = (buf.cpu().numpy(), offs)
+        for g, r, _ in order:
+            if r == 0:
+                feed(g, mine[g].cpu().numpy())
+            else:
+                b, offs = bufs[r]
+                o, n = offs[g]
+                feed(g, b[o:o + n])
+    elif pieces:
+        import torch
+        dist.send(torch.cat([t for _, t in pieces]), dst=0)
+
+
+def run_cfg3(args, rank, local_rank, world, dist):
+    """configs[2]: N entries of 64 KiB (ZipOutputStream's independent streams), contiguous groups per rank, level 6 + CRC-32 in one
+    device call per rank; sizes all-gathered -> every entry's offset in the one archive the host would write (S/Zip/ZipOutputStream.cs:
+    885-908 lays local headers, payloads and the central directory out from exactly these)."""
+    import hashlib
+    import numpy as np
+    from sharpziplib_amd import shard
+    esz = 65536
+    n3 = args.entries
+    lo, hi = shard.shard_range(n3, rank, world)
+    cnt = hi - lo
+    if args.stub:
+        sizes = [esz // 3 + (g % 7) for g in range(lo, hi)]
+        elapsed = _timed(lambda: time.sleep(0.001 * (1 + rank)), args.steps, args.warmup, dist, lambda: None)
+        k_ms, ratio, stage, parity = 0.0, 1 / 3, {}, ["stub"]
+    else:
+        import zlib
+        import oracle_ffi as O
+        from sharpziplib_amd import _lib
+        from sharpziplib_amd.batch import Engine
+        torch, dev, hip_stream = _device_setup(local_rank)
+        host = gen_parallel("enwik", 0x21B0, cnt * esz) if lo == 0 else None
+        if host is None:
+            from sharpziplib_amd import corpus
+            host = np.concatenate([corpus.generate("enwik", 0x21B0, o, min(64 << 20, hi * esz - o)) for o in range(lo * esz, hi * esz, 64 << 20)])
+        d_in = torch.empty(cnt * esz + 64, dtype=torch.uint8, device=dev)
+        d_in[:cnt * esz].copy_(torch.from_numpy(host))
+        eng = Engine()
+        st3, _, ot3 = Engine.layout([esz] * cnt)
+        d_out = torch.empty(ot3 + 64, dtype=torch.uint8, device=dev)
+        flags = _lib.F_NOWRAP | _lib.F_CRC32
+        tms = []
+
+        def step():
+            eng.deflate_device(d_in.data_ptr(), d_out.data_ptr(), st3, level=args.level, flags=flags, hip_stream=hip_stream)
+            tms.append(eng.timing())
+        elapsed = _timed(step, args.steps, args.warmup, dist, lambda: torch.cuda.synchronize(dev))
+        tms = tms[-args.steps:]
+        k_ms = sum(t["match_ms"] for t in tms) / len(tms)
+        stage = {k: round(sum(t[k] for t in tms) / len(tms), 3) for k in tms[0] if k.endswith("_ms")}
+        sizes = [int(s.out_len) for s in st3]
+        assert all(s.status == 0 for s in st3)
+        for i in sorted({0, cnt // 2, cnt - 1}):                # this rank's own spot check against the oracle run here
+            s = st3[i]
+            got = d_out[s.out_off:s.out_off + s.out_len].cpu().numpy().tobytes()
+            assert got == O.deflate(host[i * esz:(i + 1) * esz], args.level) and s.crc32 == zlib.crc32(host[i * esz:(i + 1) * esz].tobytes()), "rank %d entry %d" % (rank, lo + i)
+        parity = ["every rank: 3 of its entries == oracle bytes + CRC-32"]
+    all_sizes = shard.gather_sizes(sizes, dist)
+    offs, total = shard.member_offsets(all_sizes)               # where every entry's payload lands in the joint archive
+    crcs = shard.gather_sizes([0] * cnt if args.stub else [int(s.crc32) for s in st3], dist)
+    if not args.stub:
+        h = hashlib.sha256()
+        comp_ordered = [(lo + i, d_out[s.out_off:s.out_off + s.out_len]) for i, s in enumerate(st3)]
+        # rank 0 hashes ALL entries in archive order (peers send their payloads back to back: ~2.5 GB in all, outside the timed region)
+        packed = [(lo, torch.cat([t for _, t in comp_ordered]))] if comp_ordered else []
+        _gather_bytes_in_order(dist, rank, world, packed, lambda g, b: h.update(b))
+    if rank == 0:
+        assert sum(len(r) for r in all_sizes) == n3 and offs[-1][-1] + all_sizes[-1][-1] == total
+        comp3 = total
+        ratio = comp3 / (n3 * esz)
+        if not args.stub:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")))["cases"].get("cfg3_100000x64k_enwik_l6")
+            if gold and n3 * esz == gold["n"] and args.level == gold["level"]:
+                hc = hashlib.sha256()
+                for row in crcs:
+                    for c in row:
+                        hc.update(int(c).to_bytes(4, "little"))
+                assert comp3 == gold["out_len"] and h.hexdigest() == gold["out_sha256"] and hc.hexdigest() == gold["crc_sha256"], \
+                    "config 3 over %d rank(s): the entries differ from the oracle's frozen digests" % world
+                parity.append("ALL %d entries, gathered in archive order from %d rank(s): sha256 of their compressed bytes and of their CRC-32s == the oracle's frozen digests" % (n3, world))
+        value = n3 * esz * args.steps / elapsed / 2 ** 20
+        line = {"metric": "zip entries: raw deflate level %d + CRC-32 of %d x 64 KiB independent streams (uncompressed MiB/s consumed, whole job)" % (args.level, n3),
+                "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u8", "data": "stub" if args.stub else "synthetic", "ratio": round(ratio, 5),
+                "config": {"workload": "configs[2]: ZipOutputStream-style entries, %d x 64 KiB of enwik-style text (seed 0x21B0), contiguous groups of entries per GPU, "
+                                       "one device call per rank; the ranks exchange only the entries' compressed sizes (all-gather) for the archive's layout; "
+                                       "bit-identical to the oracle (C restatement of the reference Deflater)" % n3,
+                           "level": args.level, "entries": n3, "parallelism": "entries-per-gpu x%d" % world, "archive_payload_bytes": int(total)},
+                "roofline": {"bound": "hbm", "kernel": "k_match9", "achieved": None, "peak": HBM_PEAK, "unit": "GB/s", "frac": None, "traffic": None,
+                             "kernel_ms": round(k_ms, 3), "note": "rank 0's stage B per step"},
+                "stage_ms": stage, "parity": parity}
+        if k_ms > 0:
+            alg = (all_sizes[0] and (len(all_sizes[0]) * esz + sum(all_sizes[0]))) or 0   # rank 0's launch: its entries read once, their output written once
+            line["roofline"]["achieved"], line["roofline"]["frac"] = roofline(alg, k_ms)
+            line["roofline"]["algorithmic_bytes"] = int(alg)
+        print(json.dumps(line), flush=True)
+
+
+def run_cfg5(args, rank, local_rank, world, dist):
+    """configs[4]: level 9 on repetitive logs, "with RCCL shard rebalance".  The corpus is cut into streams of --piece-mib ("shard =
+    stream": each its own Deflater lifetime, bit-exact per stream); they START on the ranks in a skewed split (rank r holds r + 1
+    shares), every step moves them to an even split of cost in ONE all-to-all of bytes (shard.rebalance: all_to_all_single over nccl =
+    RCCL over xGMI) and compresses them where they land.  The step is the exchange plus the compression."""
+    import hashlib
+    import numpy as np
+    import torch
+    from sharpziplib_amd import shard
+    psz = args.piece_mib << 20
+    npieces = max(1, (args.total_mib << 20) // psz)
+    # the skewed start: cumulative shares 1 : 2 : ... : world
+    tri = world * (world + 1) // 2
+    bounds = [0]
+    for r in range(world):
+        bounds.append(min(npieces, round(npieces * sum(range(1, r + 2)) / tri)))
+    bounds[-1] = npieces
+    lo, hi = bounds[rank], bounds[rank + 1]
+    if args.stub:
+        dev = "cpu"
+        small = 4096
+        arena = torch.zeros((hi - lo) * small, dtype=torch.uint8)
+        for i in range(hi - lo):
+            arena[i * small:(i + 1) * small] = (lo + i) & 0xFF
+        views = [arena[i * small:(i + 1) * small] for i in range(hi - lo)]
+        sync = lambda: None   # noqa: E731
+        hip_stream = 0
+    else:
+        import zlib  # noqa: F401
+        from sharpziplib_amd import _lib, corpus
+        from sharpziplib_amd.batch import Engine
+        _, dev, hip_stream = _device_setup(local_rank)
+        arena = torch.empty((hi - lo) * psz + 64, dtype=torch.uint8, device=dev)
+        for i in range(hi - lo):
+            arena[i * psz:(i + 1) * psz].copy_(torch.from_numpy(corpus.generate("logs", 0x106, (lo + i) * psz, psz)))
+        views = [arena[i * psz:(i + 1) * psz] for i in range(hi - lo)]
+        sync = lambda: torch.cuda.synchronize(dev)   # noqa: E731
+        eng = Engine()
+        flags = _lib.F_NOWRAP | _lib.F_CRC32
+    state = {}
+    tms, xms = [], []
+
+    def step():
+        t = time.perf_counter()
+        own = shard.rebalance(views, [float(v.numel()) for v in views], dist, dev)     # [(global piece, tensor)] in global order
+        sync()
+        xms.append((time.perf_counter() - t) * 1e3)
+        if args.stub:
+            time.sleep(0.0005 * len(own))
+            state.update(own=[(lo + g if dist is None else g, t_) for g, t_ in own], sizes=[int(t_.numel()) // 3 for _, t_ in own], crcs=[0] * len(own), out=None)
+            return
+        if not own:
+            state.update(own=[], sizes=[], crcs=[], out=None)
+            return
+        # the streams that landed here lie in one buffer (the all-to-all's receive buffer, or the start arena on one rank)
+        base = min(t_.data_ptr() for _, t_ in own)
+        st5, _, ot5 = Engine.layout([int(t_.numel()) for _, t_ in own])
+        for s, (_, t_) in zip(st5, own):
+            s.in_off = t_.data_ptr() - base
+        if state.get("cap", 0) < ot5:
+            state["d_out"] = torch.empty(ot5 + 64, dtype=torch.uint8, device=dev); state["cap"] = ot5
+        eng.deflate_device(base, state["d_out"].data_ptr(), st5, level=9, flags=flags, hip_stream=hip_stream)
+        tms.append(eng.timing())
+        state.update(own=[(lo + g if dist is None else g, t_) for g, t_ in own], st=st5, sizes=[int(s.out_len) for s in st5], crcs=[int(s.crc32) for s in st5])
+    elapsed = _timed(step, args.steps, args.warmup, dist, sync)
+    own = state["own"]
+    rows = shard.gather_sizes([(g, n, c) for (g, _), n, c in zip(own, state["sizes"], state["crcs"])], dist)
+    h = hashlib.sha256()
+    if not args.stub:
+        assert all(s.status == 0 for s in state.get("st", []))
+        d_out = state.get("d_out")
+        comp = [(g, d_out[s.out_off:s.out_off + s.out_len]) for (g, _), s in zip(own, state.get("st", []))]
+        _gather_bytes_in_order(dist, rank, world, comp, lambda g, b: h.update(b))
+    if rank == 0:
+        flat = sorted(x for row in rows for x in row)
+        assert [g for g, _, _ in flat] == list(range(npieces)), "every stream compressed exactly once"
+        after = [len(row) for row in rows]
+        total_in, total_out = npieces * (4096 if args.stub else psz), sum(n for _, n, _ in flat)
+        parity = ["stub"] if args.stub else []
+        if not args.stub:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")))["cases"].get("cfg5_64x64m_logs_l9")
+            if gold and total_in == gold["n"] and psz == gold["entry"]:
+                hc = hashlib.sha256()
+                for _, _, c in flat:
+                    hc.update(int(c).to_bytes(4, "little"))
+                assert total_out == gold["out_len"] and h.hexdigest() == gold["out_sha256"] and hc.hexdigest() == gold["crc_sha256"], \
+                    "config 5 over %d rank(s): the streams differ from the oracle's frozen digests" % world
+                parity.append("ALL %d streams, gathered in order from %d rank(s) after the rebalance: sha256 of their compressed bytes and of their CRC-32s == the oracle's frozen digests" % (npieces, world))
+            else:
+                parity.append("not the golden workload (sizes only)")
+        k_ms = (sum(t["match_ms"] for t in tms[-args.steps:]) / max(1, len(tms[-args.steps:]))) if tms else 0.0
+        line = {"metric": "Deflater level 9 on %d MiB of repetitive logs as %d streams, shard rebalance + compression (uncompressed MiB/s consumed, whole job)" % (total_in >> 20, npieces),
+                "value": round(total_in * args.steps / elapsed / 2 ** 20, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u8", "data": "stub" if args.stub else "synthetic", "ratio": round(total_out / total_in, 5),
+                "config": {"workload": "configs[4]: Deflater level 9 (max_chain 4096) on %d MiB of log data (seed 0x106) as %d streams of %d MiB; skewed start "
+                                       "(rank r holds r + 1 shares), ONE all-to-all of bytes per step to an even split of cost (shard.rebalance over %s), compressed "
+                                       "where they land; bit-identical to the oracle (C restatement of the reference Deflater) per stream"
+                                       % (total_in >> 20, npieces, args.piece_mib, "gloo" if args.stub else "nccl = RCCL"),
+                           "level": 9, "parallelism": "streams-per-gpu x%d after rebalance" % world,
+                           "streams_per_rank_before": [bounds[r + 1] - bounds[r] for r in range(world)], "streams_per_rank_after": after},
+                "rebalance_ms_rank0": round(sum(xms[-args.steps:]) / max(1, len(xms[-args.steps:])), 3),
+                "roofline": {"bound": "hbm", "kernel": "k_match9", "achieved": None, "peak": HBM_PEAK, "unit": "GB/s", "frac": None, "traffic": None,
+                             "kernel_ms": round(k_ms, 3), "note": "rank 0's stage B per step"},
+                "parity": parity}
+        if k_ms > 0 and rows[0]:
+            alg = len(rows[0]) * psz + sum(n for _, n, _ in rows[0])
+            line["roofline"]["achieved"], line["roofline"]["frac"] = roofline(alg, k_ms)
+            line["roofline"]["algorithmic_bytes"] = int(alg)
+        print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse_args()
     launched = "WORLD_SIZE" in os.environ
-    if not launched and args.gpus > 1 and args.mode == "weak":
+    if not launched and args.gpus > 1 and (args.mode == "weak" or args.workload != "headline"):
         sys.exit(relaunch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -576,6 +853,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.stub else "nccl")
     try:
+        if args.workload == "cfg3":
+            return run_cfg3(args, rank, local_rank, world, dist)
+        if args.workload == "cfg5":
+            return run_cfg5(args, rank, local_rank, world, dist)
         if args.stub:
             return run_stub(args, rank, world, dist)
         if args.mode == "strong":
@@ -669,7 +950,7 @@ def run_weak(args, rank, local_rank, world, dist):
         traffic = None
         # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 --pmc passes of this
         # same command (tools/gpu_traffic.sh -> profiles/rNN/*traffic_pmc.json); `traffic_source` says which file
-        tpath = next((t for t in ([os.path.join(ROOT, "profiles", r, "traffic_pmc.json") for r in ("r05", "r04", "r03", "r02")] +
+        tpath = next((t for t in ([os.path.join(ROOT, "profiles", r, "traffic_pmc.json") for r in ("r06", "r05", "r04", "r03", "r02")] +
                                   [os.path.join(ROOT, "profiles", "r01", "g_traffic_pmc.json")]) if os.path.exists(t)), "")
         if args.mib == 1024 and args.level == 6 and tpath:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB units) of this same command, per launch of k_match;
@@ -685,7 +966,7 @@ def run_weak(args, rank, local_rank, world, dist):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "ratio": round(sum(s[0] for s in all_sizes) / (world * n), 5), "compressed_mib_s": round(value * ratio, 1),
             "config": {"workload": "configs[1]: GZip-style raw Deflater level %d + CRC-32 on one %d MiB enwik-style stream per GPU "
-                                   "(seed 0xE9, shard = rank), bit-identical to the reference Deflater" % (args.level, args.mib),
+                                   "(seed 0xE9, shard = rank), bit-identical to the oracle (C restatement of the reference Deflater; the reference itself cannot run here)" % (args.level, args.mib),
                        "level": args.level, "shard_mib": args.mib, "parallelism": "stream-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_match9", "achieved": round(achieved, 2), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,

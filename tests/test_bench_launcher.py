@@ -40,3 +40,26 @@ def test_world_size_that_contradicts_gpus_is_refused():
     """the driver starts the ranks itself and passes --gpus N: a line that says n_gpus != N must never be printed"""
     p, lines = _run(["--gpus", "4", "--stub", "--steps", "1", "--mib", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and not lines and "WORLD_SIZE" in p.stderr
+
+
+def test_cfg3_entries_shard_over_two_ranks_and_lay_out_one_archive():
+    """--workload cfg3 (BASELINE configs[2]): contiguous groups of entries per rank, sizes all-gathered, the joint layout checked on rank 0"""
+    p, lines = _run(["--gpus", "2", "--stub", "--workload", "cfg3", "--entries", "1001", "--steps", "2", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 2 and rec["unit"] == "MiB/s" and rec["value"] > 0
+    assert rec["config"]["entries"] == 1001 and rec["config"]["parallelism"] == "entries-per-gpu x2"
+    assert "roofline" in rec and "parity" in rec and rec["config"]["archive_payload_bytes"] > 0
+
+
+def test_cfg5_streams_change_owner_in_one_all_to_all():
+    """--workload cfg5 (BASELINE configs[4]): the skewed start, shard.rebalance's all-to-all (gloo here, nccl = RCCL on the GPUs), every
+    stream compressed exactly once where it landed"""
+    p, lines = _run(["--gpus", "2", "--stub", "--workload", "cfg5", "--total-mib", "1024", "--steps", "2", "--warmup", "0"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["streams_per_rank_before"] == [5, 11] and rec["config"]["streams_per_rank_after"] == [8, 8]
+    assert "roofline" in rec and "parity" in rec and rec["rebalance_ms_rank0"] >= 0

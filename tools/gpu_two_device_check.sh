@@ -20,7 +20,10 @@ tail -n 2 "$out/test_gpu_multi_host_gather.log"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --no-extra-configs --no-cpu-baseline > "$out/bench_weak_2.json" 2> "$out/bench_weak_2.err" || rc=1
 python bench.py --gpus 2 --mode strong --steps 5 --warmup 2 --no-extra-configs --no-cpu-baseline > "$out/bench_strong_2.json" 2> "$out/bench_strong_2.err" || rc=1
 SZL_PART_HOST_GATHER=1 python bench.py --gpus 2 --mode strong --steps 3 --warmup 1 --no-extra-configs --no-cpu-baseline > "$out/bench_strong_2_host_gather.json" 2> "$out/bench_strong_2_host_gather.err" || rc=1
-for f in bench_weak_2 bench_strong_2 bench_strong_2_host_gather; do python - "$out/$f.json" <<'PY' || rc=1
+# 4. the multi-rank shapes of configs[2] and configs[4]: entries sharded over the ranks; log streams that change owner in an all-to-all over RCCL
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --workload cfg3 --steps 3 --warmup 1 > "$out/bench_cfg3_2.json" 2> "$out/bench_cfg3_2.err" || rc=1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --workload cfg5 --steps 3 --warmup 1 > "$out/bench_cfg5_2.json" 2> "$out/bench_cfg5_2.err" || rc=1
+for f in bench_weak_2 bench_strong_2 bench_strong_2_host_gather bench_cfg3_2 bench_cfg5_2; do python - "$out/$f.json" <<'PY' || rc=1
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
 d = json.loads(line)
