@@ -191,6 +191,10 @@ int szl_deflate_stream_multi_device(const int *devices, int n_dev, const void *c
  * Deflater per stream, S/GZip/GzipOutputStream.cs:87, and allocating ~19 bytes of device memory per input byte cost its first Finish()
  * 20-800 ms).  This frees both. */
 int szl_multi_release(void);
+/* Memory the library holds for objects that do not exist any more (round 6).  When the last szl_deflater / szl_inflater is destroyed the
+ * idle engines' work space and the pool of pinned blocks shrink to SZL_IDLE_KEEP_MIB each (1024) by themselves; szl_trim() frees ALL of
+ * it — idle engines, the multi-device slots, the pinned pool — e.g. from a host's own idle handler.  Live objects are not touched. */
+int szl_trim(void);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,
                                  unsigned flags);
 

@@ -74,7 +74,7 @@ def _load(path):
         "szl_deflate_batch_host": (i32, [vp, vp, vp, vp, sz, i32, i32, ctypes.c_uint]),
         "szl_deflate_batch_multi_host": (i32, [vp, i32, vp, vp, vp, sz, i32, i32, ctypes.c_uint]),
         "szl_deflate_stream_multi_device": (i32, [vp, i32, vp, vp, vp, i32, i32, ctypes.c_uint]),
-        "szl_multi_release": (i32, []),
+        "szl_multi_release": (i32, []), "szl_trim": (i32, []),
         "szl_inflate_batch_multi_host": (i32, [vp, i32, vp, vp, vp, sz, ctypes.c_uint]),
         "szl_engine_last_timing": (i32, [vp, vp]),
         "szl_engine_debug_fetch": (i32, [vp, vp, vp, vp, sz, vp, sz, ctypes.POINTER(sz)]),

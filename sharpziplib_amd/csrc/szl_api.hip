@@ -49,6 +49,35 @@ void engine_give(szl_engine *e) {
     szl_engine_destroy(e);
     if (cur != dev) (void)hipSetDevice(cur);
 }
+// What the library keeps when NO streaming object is alive (round 6).  The pools exist for the caller who makes one object after
+// another — a GZipOutputStream makes a new Deflater per stream (S/GZip/GzipOutputStream.cs:87), and the ~19 bytes of device memory per
+// input byte cost its first Finish() 20-800 ms — but a host that compressed one gigabyte an hour ago should not sit on twenty.  When the
+// last szl_deflater / szl_inflater is destroyed the idle engines' side arrays and the pinned pool shrink to SZL_IDLE_KEEP_MIB each (1024;
+// largest buffers first: what stays is what many small streams need); szl_trim() gives everything back.
+static std::atomic<long> g_live_objects{0};
+void object_born() { g_live_objects.fetch_add(1, std::memory_order_relaxed); }
+static void engine_pool_trim(size_t keep) {
+    std::lock_guard<std::mutex> lk(g_idle_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t total = 0;
+    for (szl_engine *e : g_idle) total += e->e.device_bytes() + e->io_a.cap + e->io_b.cap + e->io_c.cap + e->io_d.cap;
+    for (szl_engine *e : g_idle) {
+        if (total <= keep) break;
+        (void)hipSetDevice(e->device);
+        for (szl::DevBuf *b : {&e->io_a, &e->io_b, &e->io_c, &e->io_d}) if (total > keep) { total -= b->cap; b->release(); }
+        const size_t had = e->e.device_bytes(), want = total > keep ? (had > total - keep ? had - (total - keep) : 0) : had;
+        e->e.trim(want);
+        total -= had - e->e.device_bytes();
+    }
+    (void)hipSetDevice(cur);
+}
+void object_gone() {
+    if (g_live_objects.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    const size_t keep = (size_t)std::max(0, knob("SZL_IDLE_KEEP_MIB", 1024)) << 20;
+    engine_pool_trim(keep);
+    (void)pin_pool_trim(keep);
+}
 void engine_pool_release() {
     std::vector<szl_engine *> idle;
     { std::lock_guard<std::mutex> lk(g_idle_mu); idle.swap(g_idle); }
@@ -656,6 +685,11 @@ static int stream_multi_run(const int *devices, int n_dev, const void *h_in, voi
     return 0;
 }
 
+int szl_trim(void) {            // everything the library holds for objects that do not exist any more
+    (void)szl_multi_release();
+    (void)szl::pin_pool_trim(0);
+    return 0;
+}
 int szl_multi_release(void) {   // the engines (and their device memory) the multi-device entry points and the streaming objects' pool keep between calls
     engine_pool_release();
     std::lock_guard<std::mutex> multi_lock(g_multi_mu);
@@ -830,6 +864,7 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
     std::swap(d->d_in, d->eng->io_a); std::swap(d->d_out, d->eng->io_b);   // (the last owner's device buffers come with a pooled engine)
     d->level = level; d->nowrap = nowrap ? 1 : 0;
     deflater_clear(d);
+    object_born();
     return d;
 }
 void szl_deflater_destroy(szl_deflater *d) {
@@ -840,6 +875,7 @@ void szl_deflater_destroy(szl_deflater *d) {
     std::swap(d->d_in, d->eng->io_a); std::swap(d->d_out, d->eng->io_b);
     engine_give(d->eng);
     delete d;
+    object_gone();
 }
 static int function_switch(szl_deflater *d, int level);
 static int lvl_kind(int lv) { return lv == 0 ? 0 : (lv < 5 ? 1 : 2); }   // DEFLATE_STORED / DEFLATE_FAST / DEFLATE_SLOW (C/DeflaterConstants.cs:146)

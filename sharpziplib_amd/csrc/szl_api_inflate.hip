@@ -841,6 +841,7 @@ szl_inflater *szl_inflater_create(int no_header) {
     if (!s) return nullptr;
     s->no_header = no_header ? 1 : 0;
     inflater_clear(s);
+    szl::object_born();
     return s;
 }
 void szl_inflater_destroy(szl_inflater *s) {
@@ -856,6 +857,7 @@ void szl_inflater_destroy(szl_inflater *s) {
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     s->hin.release(); s->pend.release();
     delete s;
+    szl::object_gone();
 }
 int szl_inflater_reset(szl_inflater *s) { if (!s) return SZL_E_ARG; inflater_clear(s); return 0; }
 

@@ -39,6 +39,7 @@ struct DevBuf {
 // what it may hold; 0 = none) and are handed out again, best fit, to whoever asks next.
 uint8_t *pin_alloc(size_t want, size_t *cap_out, bool growing = false);    // nullptr: no pinned memory of that size
 void pin_free(uint8_t *p, size_t cap);
+size_t pin_pool_trim(size_t keep);   // frees pooled pinned blocks (largest first) until at most `keep` bytes stay pooled
 
 void host_copy(void *dst, const void *src, size_t k);   // memcpy, on several cores when long (szl_engine.hip)
 struct PinVec {
@@ -137,6 +138,9 @@ class Engine {
     hipEvent_t ev[8];
     // checksum kernels run beside stages A-C on this stream (they only share the input bytes)
     hipStream_t side = nullptr;
+    std::vector<DevBuf *> all_bufs();
+    size_t device_bytes();
+    void trim(size_t keep);          // releases the largest side arrays until at most `keep` bytes of them are left (an idle engine)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_guard = nullptr, ev_gjoin = nullptr, ev_zfork = nullptr, ev_zjoin = nullptr;
 };
 
@@ -158,5 +162,7 @@ namespace szl {
 szl_engine *engine_take();
 void engine_give(szl_engine *e);
 void engine_pool_release();
+void object_born();                  // a streaming object (szl_deflater / szl_inflater) was created / destroyed: when the last one goes the
+void object_gone();                  // pools shrink to SZL_IDLE_KEEP_MIB (szl_api.hip)
 }
 

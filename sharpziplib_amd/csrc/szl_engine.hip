@@ -247,6 +247,21 @@ void pin_free(uint8_t *p, size_t cap) {
     (void)hipHostFree(p);
 }
 
+size_t pin_pool_trim(size_t keep) {     // frees pooled blocks, largest first, until the pool holds at most `keep` bytes; returns what it still holds
+    std::vector<PinBlock> drop;
+    size_t left;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        std::sort(g_pool.begin(), g_pool.end(), [](const PinBlock &a, const PinBlock &b) { return a.cap > b.cap; });
+        size_t k = 0;
+        while (k < g_pool.size() && g_pool_bytes > keep) { g_pool_bytes -= g_pool[k].cap; drop.push_back(g_pool[k]); k++; }
+        g_pool.erase(g_pool.begin(), g_pool.begin() + (ptrdiff_t)k);
+        left = g_pool_bytes;
+    }
+    for (auto &b : drop) (void)hipHostFree(b.p);
+    return left;
+}
+
 void PinVec::reserve(size_t want) {
     if (want <= cap) return;
     size_t ncap = 0;
@@ -290,9 +305,19 @@ void PinVec::release() { if (busy) (void)hipStreamSynchronize(busy); pin_free(p,
 Engine::Engine() {
     for (auto &e : ev) e = nullptr;
 }
+std::vector<DevBuf *> Engine::all_bufs() {
+    return {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
+                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &chain_buf, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops};
+}
+size_t Engine::device_bytes() { size_t t = 0; for (DevBuf *b : all_bufs()) t += b->cap; return t; }
+void Engine::trim(size_t keep) {
+    std::vector<DevBuf *> v = all_bufs();
+    std::sort(v.begin(), v.end(), [](DevBuf *a, DevBuf *b) { return a->cap > b->cap; });
+    size_t total = device_bytes();
+    for (DevBuf *b : v) { if (total <= keep) break; total -= b->cap; b->release(); }
+}
 Engine::~Engine() {
-    for (DevBuf *b : {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
-                      &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &chain_buf, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops})
+    for (DevBuf *b : all_bufs())
         b->release();
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);

@@ -131,10 +131,16 @@ const char *hipGetErrorName(hipError_t e) { return e == hipSuccess ? "hipSuccess
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 
 // ---- memory ------------------------------------------------------------------------------------------------------
-hipError_t hipMalloc(void **p, size_t n) { *p = arena_alloc(n ? n : 1); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }
-hipError_t hipFree(void *) { return hipSuccess; }                     // bump allocator: nothing is reused, so stale pointers stay visible to the checks
-hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = arena_alloc(n ? n : 1); shadow_set(*p, 2, n ? n : 1); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }   // (the host writes it without telling anyone: defined)
-hipError_t hipHostFree(void *) { return hipSuccess; }
+// (live bytes by kind, for tests/test_memory_trim.py: what the library holds after its objects are gone)
+static std::map<void *, size_t> g_live_dev, g_live_host;
+static void live_add(std::map<void *, size_t> &m, void *p, size_t n) { if (p) { std::lock_guard<std::mutex> lk(g_mu); m[p] = n; } }
+static void live_del(std::map<void *, size_t> &m, void *p) { std::lock_guard<std::mutex> lk(g_mu); m.erase(p); }
+size_t fakehip_live_device_bytes() { std::lock_guard<std::mutex> lk(g_mu); size_t t = 0; for (auto &kv : g_live_dev) t += kv.second; return t; }
+size_t fakehip_live_host_bytes() { std::lock_guard<std::mutex> lk(g_mu); size_t t = 0; for (auto &kv : g_live_host) t += kv.second; return t; }
+hipError_t hipMalloc(void **p, size_t n) { *p = arena_alloc(n ? n : 1); live_add(g_live_dev, *p, n); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }
+hipError_t hipFree(void *p) { live_del(g_live_dev, p); return hipSuccess; }   // bump allocator: nothing is reused, so stale pointers stay visible to the checks
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = arena_alloc(n ? n : 1); shadow_set(*p, 2, n ? n : 1); live_add(g_live_host, *p, n); return *p ? hipSuccess : (t_last = hipErrorOutOfMemory); }   // (the host writes it without telling anyone: defined)
+hipError_t hipHostFree(void *p) { live_del(g_live_host, p); return hipSuccess; }
 hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { ensure_arena(); *tot = g_arena_size; *fr = g_arena_size - g_top; return hipSuccess; }
