@@ -108,6 +108,8 @@ class Engine {
     // progress of an overlapped host->device copy of the input arena (szl_deflate_batch_host): the engine waits until the bytes a
     // window needs have arrived.  nullptr: everything is resident.
     const volatile uint64_t *in_ready = nullptr;
+    DevBuf tabs;                       // the small host-built tables of a call (segments, tiles, spans, ...) in ONE upload: tab_pin -> tabs
+    uint8_t *tab_pin = nullptr; size_t tab_pin_cap = 0;
     uint8_t *pin = nullptr;            // 256 bytes of pinned host memory: few-byte read-backs into pageable memory cost ~1 ms each
     uint32_t last_par_jobs = 0;        // chunk jobs of the last parallel single-member inflate
     uint64_t last_workspace_bytes = 0; // device bytes held by the side arrays after the last call (parity tap / DESIGN §3)

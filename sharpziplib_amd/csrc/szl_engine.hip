@@ -137,6 +137,7 @@ void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, cons
 size_t checksum_partial_bytes();
 void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint32_t n, hipStream_t st);
 void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st);
+void launch_zero_many(void *const *ptrs, const size_t *bytes, int n, hipStream_t st);
 int zero_piece_bytes();
 
 // Tuning knobs for experiments and parity taps: a value set through szl_debug_set() wins, else the environment variable of
@@ -306,7 +307,7 @@ Engine::Engine() {
     for (auto &e : ev) e = nullptr;
 }
 std::vector<DevBuf *> Engine::all_bufs() {
-    return {&link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
+    return {&tabs, &link, &mtab, &tokens, &visited, &ranges, &counts, &range_tok, &descs, &d_segs, &d_bnds, &d_spans, &d_tiles,
                       &d_so, &blk_counts, &blk_off, &bsp, &blp, &counters, &ckparts, &ckoff, &cubtmp, &stage_in, &stage_out, &bad_slot, &bad_range, &exmap, &cnmap, &chain_buf, &d_stored, &spec_tok, &d_zoff, &inf_sym, &inf_wins, &inf_jobs, &inf_states, &inf_misc, &inf_groups, &hist_flags_dev, &m5_scratch, &d_sw_pos, &d_sw_P, &d_stripes, &link4, &skip4, &e3dist, &e3hops};
 }
 size_t Engine::device_bytes() { size_t t = 0; for (DevBuf *b : all_bufs()) t += b->cap; return t; }
@@ -328,6 +329,7 @@ Engine::~Engine() {
     if (ev_zjoin) (void)hipEventDestroy(ev_zjoin);
     if (side) (void)hipStreamDestroy(side);
     if (pin) (void)hipHostFree(pin);
+    if (tab_pin) (void)hipHostFree(tab_pin);
 }
 
 template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t st) {
@@ -394,7 +396,12 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     constexpr uint64_t FILL_RANGES = 262144;
     uint32_t range_len = C_RANGE;
     if (SZL_LABKNOB("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)SZL_LABKNOB("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
-    else while (range_len > 256 && total_emit / range_len < FILL_RANGES) range_len >>= 1;
+    else {
+        // (round 6: one entry of the unchanged ZipOutputStream path — a call of a few hundred KiB at most — spent 205 of its 890 us of device
+        // time walking ranges of 256 positions on four wavefronts; a call that small gets ranges of 64)
+        const uint32_t min_range = total_emit <= (1u << 20) ? 64u : 256u;
+        while (range_len > min_range && total_emit / range_len < FILL_RANGES) range_len >>= 1;
+    }
     // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
     bool m3 = !P.fast && use_match3(P);
     if (!sw_pos_in.empty()) {   // SetLevel / SetStrategy inside the (single) segment: any number of changes, carried in device arrays
@@ -511,20 +518,36 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         if ((rc = upload(d_sw_pos, sw_pos_in, st)) || (rc = upload(d_sw_P, sw_P_in, st))) return rc;
         segs[0].sw_pos = (const int64_t *)d_sw_pos.p; segs[0].sw_P = (const LevelParams *)d_sw_P.p;
     }
-    if ((rc = upload(d_segs, segs, st))) return rc;
-    if ((rc = upload(d_bnds, bnds, st))) return rc;
-    if ((rc = upload(d_spans, spans, st))) return rc;
-    if ((rc = upload(d_tiles, tiles, st))) return rc;
+    const void *d_segs_view = nullptr;
     const bool own_list = stripe_len > 0 && !has_switch && !stripes.empty();   // the full search's own work list
-    if (own_list && (rc = upload(d_stripes, stripes, st))) return rc;
-    if ((rc = upload(ckoff, chunk_off, st))) return rc;
-    if ((rc = upload(d_zoff, zero_off, st))) return rc;
+    // the call's tables travel in ONE copy out of pinned memory (seven copies out of pageable vectors cost a small call ~60 us of
+    // device time in gaps alone, and the host a staging copy each)
+    const void *p_bnds, *p_spans, *p_tiles, *p_stripes, *p_ckoff, *p_zoff;
+    {
+        struct Part { const void *src; size_t n; size_t off; };
+        size_t total = 0;
+        auto add = [&](const void *src, size_t n) { Part q{src, n, total}; total += (std::max<size_t>(n, 1) + 255) & ~(size_t)255; return q; };
+        const Part a[7] = {add(segs.data(), segs.size() * sizeof(SegDev)), add(bnds.data(), bnds.size() * 8), add(spans.data(), spans.size() * sizeof(SpanDev)),
+                           add(tiles.data(), tiles.size() * sizeof(TileDev)), add(own_list ? stripes.data() : nullptr, own_list ? stripes.size() * sizeof(TileDev) : 0),
+                           add(chunk_off.data(), chunk_off.size() * 8), add(zero_off.data(), zero_off.size() * 8)};
+        if ((rc = tabs.ensure(total))) return rc;
+        if (tab_pin_cap < total) {
+            if (tab_pin) { (void)hipHostFree(tab_pin); tab_pin = nullptr; tab_pin_cap = 0; }
+            const size_t want = std::max<size_t>(total + total / 2, 1u << 16);
+            if (hipHostMalloc((void **)&tab_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); tab_pin = nullptr; set_error("pinned memory for the call's tables"); return SZL_E_NOMEM; }
+            tab_pin_cap = want;
+        }
+        for (const Part &q : a) if (q.n) memcpy(tab_pin + q.off, q.src, q.n);
+        HIPCHK(hipMemcpyAsync(tabs.p, tab_pin, total, hipMemcpyHostToDevice, st));
+        uint8_t *b = (uint8_t *)tabs.p;
+        d_segs_view = b + a[0].off; p_bnds = b + a[1].off; p_spans = b + a[2].off; p_tiles = b + a[3].off; p_stripes = b + a[4].off; p_ckoff = b + a[5].off; p_zoff = b + a[6].off;
+    }
     size_t cub_bytes1 = 0, cub_bytes2 = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
     if ((rc = cubtmp.ensure(std::max(cub_bytes1, cub_bytes2) + 256))) return rc;
 
-    const SegDev *dsegs = (const SegDev *)d_segs.p;
+    const SegDev *dsegs = (const SegDev *)d_segs_view;
     SegOut *dso = (SegOut *)d_so.p;
     unsigned long long *dcnt = (unsigned long long *)counters.p;
 
@@ -536,17 +559,18 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     if (!ev_zjoin) HIPCHK(hipEventCreateWithFlags(&ev_zjoin, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev_zfork, st));
     HIPCHK(hipStreamWaitEvent(side, ev_zfork, 0));
-    launch_zero_regions(dsegs, nseg, (const uint64_t *)d_zoff.p, nzero, d_out, side); // only the streams' own regions (szl.h)
+    launch_zero_regions(dsegs, nseg, (const uint64_t *)p_zoff, nzero, d_out, side); // only the streams' own regions (szl.h)
     HIPCHK(hipEventRecord(ev_zjoin, side));
     // every exit between here and the join in front of stage D3 leaves that kernel in flight on `side`, reading d_zoff / dsegs and writing
     // the caller's d_out (round-4 ADVICE): an early return waits for it, so that nothing of this call touches memory the caller may free
     // or the next call re-uploads
     struct SideJoin { hipStream_t s; bool armed; ~SideJoin() { if (armed && s) (void)hipStreamSynchronize(s); } } side_join{side, true};
-    HIPCHK(hipMemsetAsync(visited.p, 0, (vis_words + 4) * 4, st));
-    HIPCHK(hipMemsetAsync(counters.p, 0, CNT_WORDS * 8, st));
-    HIPCHK(hipMemsetAsync(d_so.p, 0, nseg * sizeof(SegOut), st));
-    HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
-    HIPCHK(hipMemsetAsync(blk_counts.p, 0, (nseg + 2) * 4, st));
+    {
+        void *const zp[5] = {visited.p, counters.p, d_so.p, counts.p, blk_counts.p};
+        const size_t zb[5] = {(size_t)(vis_words + 4) * 4, (size_t)CNT_WORDS * 8, (size_t)nseg * sizeof(SegOut), (size_t)(nranges + 2) * 4, (size_t)(nseg + 2) * 4};
+        launch_zero_many(zp, zb, 5, st);
+        HIPCHK(hipGetLastError());
+    }
     // checksums (also seeds so[].adler32 / crc32 with the running values when not requested)
 #if SZL_LAB
     static const bool ck_overlap = !(getenv("SZL_CK_OVERLAP") && atoi(getenv("SZL_CK_OVERLAP")) == 0);
@@ -560,10 +584,10 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         if (!ev_join) HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         HIPCHK(hipEventRecord(ev_fork, st));
         HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
-        launch_checksums(d_in, dsegs, nseg, (const uint64_t *)ckoff.p, nchunks, ckparts.p, dso, want_ck, side);
+        launch_checksums(d_in, dsegs, nseg, (const uint64_t *)p_ckoff, nchunks, ckparts.p, dso, want_ck, side);
         HIPCHK(hipEventRecord(ev_join, side));
     } else {
-        launch_checksums(d_in, dsegs, nseg, (const uint64_t *)ckoff.p, want_ck ? nchunks : 0, ckparts.p, dso, want_ck, st);
+        launch_checksums(d_in, dsegs, nseg, (const uint64_t *)p_ckoff, want_ck ? nchunks : 0, ckparts.p, dso, want_ck, st);
     }
     HIPCHK(hipEventRecord(ev[1], st));
     // A: hash links
@@ -579,7 +603,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     if (!ev_guard) HIPCHK(hipEventCreateWithFlags(&ev_guard, hipEventDisableTiming));
     if (!ev_gjoin) HIPCHK(hipEventCreateWithFlags(&ev_gjoin, hipEventDisableTiming));
-    launch_links(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const SpanDev *)d_spans.p, (int)spans.size(), (uint16_t *)link.p, d_hflags, dcnt + CNT_LINKS_GUARD, total_emit, st,
+    launch_links(d_in, in_total, dsegs, (const uint64_t *)p_bnds, (const SpanDev *)p_spans, (int)spans.size(), (uint16_t *)link.p, d_hflags, dcnt + CNT_LINKS_GUARD, total_emit, st,
                  side, ev_guard);
     HIPCHK(hipEventRecord(ev_gjoin, side));      // (joined in front of the read-back of the counters)
     HIPCHK(hipEventRecord(ev[2], st));
@@ -634,7 +658,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             const int nb = (int)((ntiles + step - 1) / step);
             uint64_t sampled = 0;
             for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
-            HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)d_tiles.p, nb, 0, (int)step, (const uint16_t *)link.p, mt, P, dcnt, st));
+            HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)p_tiles, nb, 0, (int)step, (const uint16_t *)link.p, mt, P, dcnt, st));
             HIPCHK(hipMemcpyAsync(pin + 192, (unsigned long long *)counters.p + 6, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             const unsigned long long ne = *(volatile unsigned long long *)(pin + 192);
@@ -645,7 +669,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         b_event = true;
         if (lazy) {
             HIPCHK(hipMemsetAsync(mt.m2, 0xFF, mt_stride * 4, st)); // M_UNSET
-            HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, 0, 1, (const uint16_t *)link.p, mt, P, dcnt, st));
+            HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)p_tiles, (int)ntiles, 0, 1, (const uint16_t *)link.p, mt, P, dcnt, st));
         }
     }
     if (!b_event) HIPCHK(hipEventRecord(ev[7], st));
@@ -657,17 +681,17 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         MTab mt3 = mt;
         mt3.link4 = (const uint16_t *)link4.p; mt3.skip4 = (const uint8_t *)skip4.p;
         mt3.e3d = (const uint16_t *)e3dist.p; mt3.e3h = (const uint8_t *)e3hops.p;
-        HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt3, P, dcnt, st));
+        HIPCHK(launch_match(d_in, dsegs, (const TileDev *)p_tiles, (int)ntiles, (const uint16_t *)link.p, mt3, P, dcnt, st));
     } else if (!lazy && own_list) {
-        if (form == 4) HIPCHK(launch_match_ring(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+        if (form == 4) HIPCHK(launch_match_ring(d_in, dsegs, (const TileDev *)p_stripes, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
         else if (form == 5) {
             const int nslots = match5_slots();
             if ((rc = m5_scratch.ensure(match5_scratch_bytes(nslots)))) return rc;
-            HIPCHK(launch_match5(d_in, in_total, dsegs, (const uint64_t *)d_bnds.p, (const TileDev *)d_stripes.p, (int)stripes.size(), mt, P, (uint8_t *)m5_scratch.p, nslots, dcnt, st));
+            HIPCHK(launch_match5(d_in, in_total, dsegs, (const uint64_t *)p_bnds, (const TileDev *)p_stripes, (int)stripes.size(), mt, P, (uint8_t *)m5_scratch.p, nslots, dcnt, st));
         }
-        else HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_stripes.p, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
+        else HIPCHK(launch_match(d_in, dsegs, (const TileDev *)p_stripes, (int)stripes.size(), (const uint16_t *)link.p, mt, P, dcnt, st));
     }
-    else if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
+    else if (!lazy && !has_switch) HIPCHK(launch_match(d_in, dsegs, (const TileDev *)p_tiles, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
     if (has_switch) { // tiles are grouped by parameter set: group 0 = the call's P, group k = sw_P[k-1] of the (single) switching segment
         size_t a = 0;
         while (a < tiles.size()) {
@@ -675,7 +699,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             while (b < tiles.size() && tiles[b].pad2 == tiles[a].pad2) b++;
             LevelParams Pk = P;
             if (tiles[a].pad2 > 0) Pk = sw_P_in[(size_t)tiles[a].pad2 - 1];
-            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p + a, (int)(b - a), (const uint16_t *)link.p, mt, Pk, dcnt, st));
+            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)p_tiles + a, (int)(b - a), (const uint16_t *)link.p, mt, Pk, dcnt, st));
             a = b;
         }
     }
@@ -692,7 +716,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         HIPCHK(hipStreamSynchronize(st));
         const unsigned long long nbad = *(volatile unsigned long long *)pin;
         if (nbad > 0 && lazy) // ranges that never re-synchronise are chained position by position: evaluate everything first
-            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)d_tiles.p, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
+            HIPCHK(launch_match(d_in, dsegs, (const TileDev *)p_tiles, (int)ntiles, (const uint16_t *)link.p, mt, P, dcnt, st));
         if (nbad > 0 && nbad <= 48) {
             launch_resolve(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, st);
         } else if (nbad > 48) {

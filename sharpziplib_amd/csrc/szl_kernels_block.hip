@@ -723,6 +723,26 @@ __global__ __launch_bounds__(256) void k_zero_regions(const SegDev *__restrict__
     }
     for (uint64_t i = (ndw << 2) + threadIdx.x; i < len; i += 256) o[i] = 0;
 }
+// Several small arrays zeroed by ONE launch (a call of the streaming object clears five: each memset of its own is a kernel and a
+// gap of ~6 us on the stream; a 64 KiB entry's call spent more time between kernels than in stage B).  Sizes in 4-byte words.
+struct ZeroMany { uint32_t *p[6]; uint32_t words[6]; int n; };
+__global__ __launch_bounds__(256) void k_zero_many(ZeroMany z) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    for (int k = 0; k < z.n; k++) {
+        if (i < z.words[k]) { z.p[k][i] = 0u; return; }
+        i -= z.words[k];
+    }
+}
+void launch_zero_many(void *const *ptrs, const size_t *bytes, int n, hipStream_t st) {
+    ZeroMany z{};
+    uint64_t total = 0;
+    for (int k = 0; k < n && z.n < 6; k++) {
+        if (!ptrs[k] || !bytes[k]) continue;
+        if (bytes[k] > (4u << 20) || (bytes[k] & 3) || ((uintptr_t)ptrs[k] & 3)) { (void)hipMemsetAsync(ptrs[k], 0, bytes[k], st); continue; }   // a long array: the runtime's own fill
+        z.p[z.n] = (uint32_t *)ptrs[k]; z.words[z.n] = (uint32_t)(bytes[k] >> 2); total += z.words[z.n]; z.n++;
+    }
+    if (total) hipLaunchKernelGGL(k_zero_many, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z);
+}
 void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st) {
     if (npieces) hipLaunchKernelGGL(k_zero_regions, dim3((unsigned)npieces), dim3(256), 0, st, segs, nseg, zoff, out);
 }
