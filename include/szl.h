@@ -113,6 +113,8 @@ int szl_deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n);
  * such a call returns SZL_E_UNSUPPORTED (NotSupportedException) instead of bytes that may differ from the reference's; Flush() first, or
  * declare.  The device-aware stream classes declare it for the Deflater they drive.  Survives Reset(). */
 int szl_deflater_caller_drains(szl_deflater *d, int on);
+/* (test tap) parts the object's last segment was parsed in while the caller was still writing; 0: compressed in one piece at Flush() / Finish() */
+int szl_deflater_debug_pipe_parts(const szl_deflater *d);
 int szl_deflater_needs_input(const szl_deflater *d);                       /* IsNeedingInput   C/Deflater.cs:285 */
 int szl_deflater_is_finished(const szl_deflater *d);                       /* IsFinished       C/Deflater.cs:271 */
 int64_t szl_deflater_total_in(const szl_deflater *d);                      /* TotalIn          C/Deflater.cs:226 */
@@ -192,7 +194,8 @@ int szl_deflate_stream_multi_device(const int *devices, int n_dev, const void *c
  * 20-800 ms).  This frees both. */
 int szl_multi_release(void);
 /* Memory the library holds for objects that do not exist any more (round 6).  When the last szl_deflater / szl_inflater is destroyed the
- * idle engines' work space and the pool of pinned blocks shrink to SZL_IDLE_KEEP_MIB each (1024) by themselves; szl_trim() frees ALL of
+ * idle engines' work space and the pool of pinned blocks shrink to SZL_IDLE_KEEP_MIB each (1024) by themselves once no object has existed
+ * for SZL_IDLE_TRIM_MS (2000; a caller who makes one Deflater per stream keeps its buffers); szl_trim() frees ALL of
  * it — idle engines, the multi-device slots, the pinned pool — e.g. from a host's own idle handler.  Live objects are not touched. */
 int szl_trim(void);
 int szl_inflate_batch_multi_host(const int *devices, int n_dev, const void *h_in, void *h_out, szl_stream *streams, size_t n_streams,

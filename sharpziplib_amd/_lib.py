@@ -68,7 +68,7 @@ def _load(path):
         "szl_deflater_deflate": (i32, [vp, vp, i32]), "szl_deflater_needs_input": (i32, [vp]),
         "szl_deflater_deflate_view": (i32, [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]),
         "szl_deflater_is_finished": (i32, [vp]), "szl_deflater_total_in": (i64, [vp]), "szl_deflater_total_out": (i64, [vp]),
-        "szl_deflater_adler": (u32, [vp]), "szl_deflater_enable_crc32": (i32, [vp, i32]), "szl_deflater_caller_drains": (i32, [vp, i32]), "szl_deflater_crc32": (u32, [vp]),
+        "szl_deflater_adler": (u32, [vp]), "szl_deflater_enable_crc32": (i32, [vp, i32]), "szl_deflater_caller_drains": (i32, [vp, i32]), "szl_deflater_debug_pipe_parts": (i32, [vp]), "szl_deflater_crc32": (u32, [vp]),
         "szl_deflate_bound": (u64, [u64]), "szl_engine_create": (vp, []), "szl_engine_destroy": (None, [vp]),
         "szl_deflate_batch_device": (i32, [vp, vp, vp, vp, sz, i32, i32, ctypes.c_uint, vp]),
         "szl_deflate_batch_host": (i32, [vp, vp, vp, vp, sz, i32, i32, ctypes.c_uint]),

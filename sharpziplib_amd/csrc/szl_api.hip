@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 #include <deque>
+#include <chrono>
 #include <condition_variable>
 #include <atomic>
 #include <new>
@@ -52,10 +53,10 @@ void engine_give(szl_engine *e) {
 // What the library keeps when NO streaming object is alive (round 6).  The pools exist for the caller who makes one object after
 // another — a GZipOutputStream makes a new Deflater per stream (S/GZip/GzipOutputStream.cs:87), and the ~19 bytes of device memory per
 // input byte cost its first Finish() 20-800 ms — but a host that compressed one gigabyte an hour ago should not sit on twenty.  When the
-// last szl_deflater / szl_inflater is destroyed the idle engines' side arrays and the pinned pool shrink to SZL_IDLE_KEEP_MIB each (1024;
-// largest buffers first: what stays is what many small streams need); szl_trim() gives everything back.
+// last szl_deflater / szl_inflater has been gone for SZL_IDLE_TRIM_MS (below) the idle engines' side arrays and the pinned pool shrink to
+// SZL_IDLE_KEEP_MIB each (1024; largest buffers first: what stays is what many small streams need); szl_trim() gives everything back.
 static std::atomic<long> g_live_objects{0};
-void object_born() { g_live_objects.fetch_add(1, std::memory_order_relaxed); }
+void object_born() { g_live_objects.fetch_add(1, std::memory_order_acq_rel); }
 static void engine_pool_trim(size_t keep) {
     std::lock_guard<std::mutex> lk(g_idle_mu);
     int cur = 0;
@@ -72,11 +73,51 @@ static void engine_pool_trim(size_t keep) {
     }
     (void)hipSetDevice(cur);
 }
-void object_gone() {
-    if (g_live_objects.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+static void idle_trim_now() {
     const size_t keep = (size_t)std::max(0, knob("SZL_IDLE_KEEP_MIB", 1024)) << 20;
     engine_pool_trim(keep);
     (void)pin_pool_trim(keep);
+}
+// ... but not at once: a caller who makes one object after another (a Deflater per stream) destroys its last object many times a
+// second, and a gigabyte of pinned memory costs hundreds of milliseconds to get back (one GZipOutputStream per GiB: 20 -> 200 ms of
+// Write() with an immediate trim).  The pools shrink when no object has existed for SZL_IDLE_TRIM_MS (2000; 0 = at once), on a thread
+// that sleeps until then and is joined when the library is unloaded.
+namespace {
+struct IdleTrimmer {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    bool quit = false, armed = false; uint64_t gen = 0;
+    void arm() {
+        std::lock_guard<std::mutex> lk(mu);
+        gen++; armed = true;
+        if (!th.joinable()) th = std::thread([this]() { run(); });
+        cv.notify_all();
+    }
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&]() { return quit || armed; });
+            if (quit) return;
+            const uint64_t g = gen;
+            armed = false;
+            const int ms = std::max(1, knob("SZL_IDLE_TRIM_MS", 2000));
+            if (cv.wait_for(lk, std::chrono::milliseconds(ms), [&]() { return quit || gen != g; })) continue;   // (somebody came: a new deadline when they leave)
+            if (g_live_objects.load(std::memory_order_acquire) != 0) continue;
+            lk.unlock();
+            idle_trim_now();
+            lk.lock();
+        }
+    }
+    ~IdleTrimmer() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+} g_idle_trimmer;
+}
+void object_gone() {
+    if (g_live_objects.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    if (knob("SZL_IDLE_TRIM_MS", 2000) <= 0) idle_trim_now();
+    else g_idle_trimmer.arm();
 }
 void engine_pool_release() {
     std::vector<szl_engine *> idle;
@@ -843,8 +884,30 @@ struct szl_deflater {
     szl_engine *eng = nullptr;
     DevBuf d_in, d_out;
     PinVec h_out;
+    // ---- stages A-C while the caller still writes (round 6).  Levels 5-9 are chunk-independent: the tokens of
+    // [0, x) do not depend on what follows x + lookahead.  Once a stream's first segment has `PIPE_PART` bytes uploaded, a worker thread
+    // runs the engine's window pipeline over them part by part — the same part runs one stream over several devices is cut into
+    // (Engine::PartRun: entered exactly where the last one left, no stage D) — and collects the tokens; Flush() / Finish() then parse
+    // what is left and run stage D over all tokens (Engine::finish_tokens).  Whatever goes wrong, or any call that changes what the
+    // engine would do (SetLevel, SetStrategy, Reset), drops the parts: the segment is then compressed in one piece as before.
+    struct Pipe {
+        std::thread th;
+        std::mutex mu, buf_mu;          // mu: avail / stop;  buf_mu: held by the worker during a part, by the caller while d_in moves
+        std::condition_variable cv;
+        bool started = false, stop = false, failed = false;
+        uint64_t avail = 0;             // pending bytes whose upload has been queued on up_stream
+        int64_t exit = 0;               // the next part enters the parse here (buffer position)
+        uint64_t ntok = 0; uint32_t parts = 0;
+        DevBuf toks;                    // the parts' tokens so far (device)
+        LevelParams P{};
+        int device = 0;
+        hipStream_t st = nullptr;       // the parts' kernels: a stream of their own (a wait on the null stream stalls the caller's uploads: 20 -> 200 ms of Write() per GiB)
+        uint32_t last_parts = 0;        // parts the last segment was parsed in (0: in one piece) — szl_deflater_debug_pipe_parts
+    } pipe;
 };
 
+static void pipe_stop(szl_deflater *d, bool keep);   // (the pipelined first segment, below)
+static void pipe_destroy(szl_deflater *d);
 static void deflater_clear(szl_deflater *d) {
     d->state = d->nowrap ? BUSY_STATE : INIT_STATE;
     d->total_in = d->total_out = 0;
@@ -869,6 +932,7 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
 }
 void szl_deflater_destroy(szl_deflater *d) {
     if (!d) return;
+    pipe_destroy(d);
     if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); d->pend.busy = nullptr; (void)hipStreamDestroy(d->up_stream); d->up_stream = nullptr; }   // (the buffers' destructors must not wait on a stream that is gone)
     // (nothing of this object is in flight when its engine changes hands: every engine call ends with its stream synchronised, and the
     // uploads' stream was synchronised above)
@@ -921,6 +985,7 @@ static int reset_stale_bits(szl_deflater *d, uint8_t *out) {
 }
 static int deflater_reset(szl_deflater *d) {
     if (!d) return SZL_E_ARG;
+    pipe_stop(d, false);
     // DeflaterEngine.Reset() does not touch inputBuf / inputOff / inputEnd (C/DeflaterEngine.cs:234-253): input the engine has not taken
     // yet — a SetInput that no Deflate() call has followed — is still there, IsNeedingInput stays false, and the first Deflate() of the
     // next stream compresses those bytes as its beginning.  (Round 4 dropped them: silently different bytes, and a second SetInput
@@ -966,6 +1031,7 @@ static int deflater_set_level(szl_deflater *d, int level) {
     else if (level < 0 || level > 9) return SZL_E_ARG;
     if (level == d->level) return 0;                       // C/Deflater.cs:357
     if (strict_refuses(d)) return SZL_E_UNSUPPORTED;
+    pipe_stop(d, false);                                   // (parts parsed under the old parameters are of no use behind the switch)
     // Another compression function (DeflateStored / DeflateFast / DeflateSlow, C/DeflaterConstants.cs:146): the reference flushes a block
     // with the OLD function where its engine stands and continues with the new one (C/DeflaterEngine.cs:319-359) — with bytes pending,
     // to or from level 0, any number of times.  The three functions leave different hash chains behind (level 0 inserts nothing,
@@ -985,6 +1051,7 @@ int szl_deflater_get_level(const szl_deflater *d) { return d ? d->level : SZL_E_
 static int deflater_set_strategy(szl_deflater *d, int s) {
     if (!d || s < 0 || s > 2) return SZL_E_ARG;
     if (s != d->strategy && strict_refuses(d)) return SZL_E_UNSUPPORTED;
+    if (s != d->strategy) pipe_stop(d, false);
     if (s != d->strategy && !d->pend.empty() && d->level != 0) { int rc = pend_switch(d, d->level, s); if (rc) return rc; }
     else if (d->pend.empty()) d->base_strategy = s;
     d->strategy = s;
@@ -1012,6 +1079,96 @@ int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n) { // C
     d->l0_dict = (uint64_t)len;
     return 0;
 }
+// ---- the pipelined first segment (szl_deflater::Pipe) ----------------------------------------------------------------------------------
+static uint64_t pipe_part_bytes() { const int k = knob("SZL_PIPE_PART_KIB", 65536); return k <= 0 ? 0 : (uint64_t)k * 1024 / B_TILE * B_TILE; }
+enum : int64_t { PIPE_LOOK = C_WIN_HALO + 1024 + MAX_MATCH + 64 };    // bytes a part sees beyond its end (stream_multi_run's LOOK)
+// one part [exit, exit + part) — or, `to_end`, everything up to the segment's end n — on the object's engine; its tokens are appended
+static int pipe_run_part(szl_deflater *d, uint64_t part, uint64_t visible, bool to_end) {
+    szl_deflater::Pipe &pp = d->pipe;
+    Engine &E = d->eng->e;
+    const int64_t first = pp.exit, pend = to_end ? (int64_t)visible : first + (int64_t)part;
+    SegDev sg{};
+    sg.buf_off = 0; sg.abs0 = d->hist_abs;
+    sg.seg_start = pp.parts == 0 ? 0 : first; sg.seg_end = (int64_t)visible;
+    sg.bnd_off = 0; sg.bnd_cnt = 1;
+    std::vector<uint64_t> bnds{to_end ? visible : visible + 64};      // the only boundary that matters is the stream's end (InsertString needs three bytes, :780)
+    sg.finish = 0; sg.flags = 0; sg.out_off = 0; sg.out_cap = 0; sg.start_bit = 0; sg.adler_init = 1; sg.crc_init = 0;
+    E.part = Engine::PartRun{};
+    E.part.active = true; E.part.first = first; E.part.parse_end = pend; E.part.warm_from = -1;
+    E.part.force_entry = pp.parts == 0 ? -1 : first;
+    std::vector<SegOut> res;
+    const auto t_part = std::chrono::steady_clock::now();
+    // (what is left at Flush() / Finish() is ONE window, as long as the window pipeline's own windows are: a part costs ~20 % more per byte
+    // than a long launch — tiles that do not fill the last round of CUs, three host round trips — which pays while the caller writes, not after)
+    uint64_t window = std::max<uint64_t>(part, B_TILE);
+    if (to_end) window = std::max<uint64_t>(window, std::min<uint64_t>((visible - (uint64_t)first + B_TILE - 1) / B_TILE * B_TILE, (uint64_t)std::max(1, knob("SZL_WINDOW_KIB", 256 * 1024)) * 1024 * 4 / B_TILE * B_TILE));
+    int rc = E.deflate_windowed((const uint8_t *)d->d_in.p, visible, nullptr, 0, sg, bnds, pp.P, 0, res, pp.st, window);
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] part %u [%lld, %lld)%s: %.2f ms wall; device: links %.2f match %.2f parse %.2f\n", pp.parts, (long long)first, (long long)pend, to_end ? " to the end" : "",
+                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_part).count(), E.timing.links_ms, E.timing.match_ms, E.timing.parse_ms);
+    const Engine::PartRun pr = E.part;
+    E.part = Engine::PartRun{};
+    if (rc) return rc;
+    if (pr.entry != first && pp.parts != 0) { set_error("pipelined segment: forced entry not honoured"); return SZL_E_STATE; }
+    if (pr.tok_count) {
+        if ((rc = pp.toks.ensure_keep((pp.ntok + pr.tok_count + 16) * 4, pp.ntok * 4, pp.st))) return rc;
+        if (hipMemcpyAsync((uint32_t *)pp.toks.p + pp.ntok, E.tokens.p, pr.tok_count * 4, hipMemcpyDeviceToDevice, pp.st) != hipSuccess || hipStreamSynchronize(pp.st) != hipSuccess) { set_error("token copy failed"); return SZL_E_DEVICE; }
+    }
+    pp.ntok += pr.tok_count; pp.exit = pr.exit; pp.parts++;
+    return 0;
+}
+static void pipe_worker(szl_deflater *d) {
+    szl_deflater::Pipe &pp = d->pipe;
+    if (hipSetDevice(pp.device) != hipSuccess) { std::lock_guard<std::mutex> lk(pp.mu); pp.failed = true; return; }
+    const uint64_t part = pipe_part_bytes();
+    for (;;) {
+        uint64_t avail;
+        {
+            std::unique_lock<std::mutex> lk(pp.mu);
+            // a part runs when its bytes and the lookahead behind them are there, and a quarter part more (the window pipeline lets no sliver
+            // stand: with less behind it the part would be taken as the segment's last)
+            pp.cv.wait(lk, [&]() { return pp.stop || pp.avail >= (uint64_t)pp.exit + part + part / 4 + (uint64_t)PIPE_LOOK; });
+            if (pp.stop) return;
+            avail = pp.avail;
+        }
+        std::lock_guard<std::mutex> bl(pp.buf_mu);
+        if (hipStreamSynchronize(d->up_stream) != hipSuccess || pipe_run_part(d, part, avail, false) != 0) {
+            std::lock_guard<std::mutex> lk(pp.mu);
+            pp.failed = true;
+            return;
+        }
+    }
+}
+// stop the worker; `keep`: its tokens stay for pipe_finish, otherwise everything is dropped
+static void pipe_stop(szl_deflater *d, bool keep) {
+    szl_deflater::Pipe &pp = d->pipe;
+    if (pp.started) {
+        { std::lock_guard<std::mutex> lk(pp.mu); pp.stop = true; }
+        pp.cv.notify_all();
+        if (pp.th.joinable()) pp.th.join();
+    }
+    if (!keep || pp.failed) { pp.toks.release(); pp.ntok = 0; pp.exit = 0; pp.parts = 0; pp.failed = pp.failed && keep; }
+    if (!keep) { pp.started = false; pp.stop = false; pp.failed = false; pp.avail = 0; }
+}
+static void pipe_destroy(szl_deflater *d) { pipe_stop(d, false); if (d->pipe.st) { (void)hipStreamSynchronize(d->pipe.st); (void)hipStreamDestroy(d->pipe.st); d->pipe.st = nullptr; } }
+static void pipe_feed(szl_deflater *d) {      // after eager_upload: tell the worker, or start it
+    szl_deflater::Pipe &pp = d->pipe;
+    const uint64_t part = pipe_part_bytes();
+    if (!part || d->level < 5 || !d->up_stream || d->up_done == 0) return;
+    if (!pp.started) {
+        if (!d->hist.empty() || !d->bounds.empty() || d->hist_has_gaps || d->l0_dict || !d->switches.empty() || d->hist_abs != 0) return;   // the stream's first segment only
+        if (d->up_done < 2 * part) return;
+        if (level_params(d->level, d->strategy, &pp.P) != 0) return;
+        (void)hipGetDevice(&pp.device);
+        if (!pp.st && hipStreamCreateWithFlags(&pp.st, hipStreamNonBlocking) != hipSuccess) { pp.st = nullptr; (void)hipGetLastError(); return; }
+        pp.stop = false; pp.failed = false; pp.exit = 0; pp.ntok = 0; pp.parts = 0; pp.avail = d->up_done;
+        try { pp.th = std::thread(pipe_worker, d); } catch (...) { return; }
+        pp.started = true;
+        return;
+    }
+    { std::lock_guard<std::mutex> lk(pp.mu); pp.avail = d->up_done; }
+    pp.cv.notify_all();
+}
+
 // Pending bytes travel to the device while the caller is still writing (coded levels; level 0 lays its blocks out on the host and
 // uploads at the flush).  Best effort: whatever fails here is simply uploaded at the flush.
 static void eager_upload(szl_deflater *d) {
@@ -1020,7 +1177,11 @@ static void eager_upload(szl_deflater *d) {
     const size_t H = d->hist.size();
     if (d->up_done && d->up_H != H) d->up_done = 0;                       // (the layout is [history | pending bytes])
     if (!d->up_stream && hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) { d->up_stream = nullptr; (void)hipGetLastError(); return; }
-    if (d->d_in.ensure_keep(H + d->pend.size() + 64, d->up_done ? H + d->up_done : 0, d->up_stream)) { d->up_done = 0; return; }
+    if (H + d->pend.size() + 64 > d->d_in.cap && d->pipe.started) {                       // (the worker's part in flight reads d_in: wait for it, then move)
+        bool moved;
+        { std::lock_guard<std::mutex> bl(d->pipe.buf_mu); moved = d->d_in.ensure_keep(H + d->pend.size() + 64, d->up_done ? H + d->up_done : 0, d->up_stream) == 0; }
+        if (!moved) { d->up_done = 0; pipe_stop(d, false); return; }
+    } else if (d->d_in.ensure_keep(H + d->pend.size() + 64, d->up_done ? H + d->up_done : 0, d->up_stream)) { d->up_done = 0; return; }
     d->up_H = H;
     d->pend.busy = d->up_stream;
     if (hipMemcpyAsync((uint8_t *)d->d_in.p + H + d->up_done, d->pend.data() + d->up_done, d->pend.size() - d->up_done, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) { (void)hipGetLastError(); d->up_done = 0; return; }
@@ -1047,6 +1208,7 @@ static int deflater_set_input(szl_deflater *d, const uint8_t *p, int n) {
     if (d->chunks_drained != d->chunks.size()) { set_error("Old input was not completely processed"); return SZL_E_STATE; } // C/DeflaterEngine.cs:163-166
     d->pend.append(p, (size_t)n);
     eager_upload(d);
+    pipe_feed(d);
     d->chunks.push_back((uint64_t)n);
     d->total_in += n;
     return 0;
@@ -1231,7 +1393,28 @@ static int run_segment(szl_deflater *d, bool finish) {
     E.fast_hist_in.clear(); E.fast_want_tail = false;
     if (P.fast) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); E.fast_want_tail = !finish; /* (the inserted bits of the tail are history for a next segment only) */ }
     else if (d->hist_has_gaps && H) { E.fast_hist_in = d->hist_flags; E.fast_hist_in.resize((H + 31) / 32, 0u); }   // stage A must skip what DeflateFast skipped
-    rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, (d->nowrap ? 0u : 2u) | (d->want_crc ? 1u : 0u), res, d->up_stream);
+    const unsigned want_ck = (d->nowrap ? 0u : 2u) | (d->want_crc ? 1u : 0u);
+    bool piped = false;
+    d->pipe.last_parts = 0;
+    if (d->pipe.started) {   // parts of this segment were parsed while the caller wrote (szl_deflater::Pipe): parse the rest, then stage D over all tokens
+        szl_deflater::Pipe &pp = d->pipe;
+        pipe_stop(d, true);
+        const bool usable = !pp.failed && pp.parts > 0 && H == 0 && sw_pos.empty() && !P.fast && E.fast_hist_in.empty() &&
+                            pp.P.good == P.good && pp.P.nice == P.nice && pp.P.max_chain == P.max_chain && pp.P.strategy == P.strategy && (uint64_t)pp.exit < n;
+        if (usable && pipe_run_part(d, pipe_part_bytes(), n, true) == 0) {
+            const uint64_t ntok = pp.ntok;
+            E.tokens.release();
+            E.tokens = pp.toks;                            // (DevBuf is a pointer and a capacity: the engine owns the tokens from here)
+            pp.toks = DevBuf{};
+            E.sw_pos_in.clear(); E.sw_P_in.clear();
+            rc = E.finish_tokens((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, s, ntok, want_ck, res, d->up_stream);
+            piped = rc == 0;
+            pp.last_parts = piped ? pp.parts : 0;
+            if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] pipelined segment: %u parts, %llu tokens, rc %d\n", pp.parts, (unsigned long long)ntok, rc);
+        }
+        pipe_stop(d, false);                               // (also forgets a failed attempt: the segment is then compressed in one piece, below)
+    }
+    if (!piped) rc = E.deflate((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, cap, segs, bnds, P, want_ck, res, d->up_stream);
     E.fast_hist_in.clear(); E.fast_want_tail = false; E.sw_pos_in.clear(); E.sw_P_in.clear();
     if (rc) return rc;
     const uint64_t end_bit = res[0].end_bit;
@@ -1493,6 +1676,7 @@ int szl_deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n) { 
 int szl_deflater_reset(szl_deflater *d) { SZL_GUARDED(deflater_reset(d)); }
 int szl_deflater_set_level(szl_deflater *d, int level) { SZL_GUARDED(deflater_set_level(d, level)); }
 int szl_deflater_set_strategy(szl_deflater *d, int s) { SZL_GUARDED(deflater_set_strategy(d, s)); }
+int szl_deflater_debug_pipe_parts(const szl_deflater *d) { return d ? (int)d->pipe.last_parts : SZL_E_ARG; }
 int szl_deflater_caller_drains(szl_deflater *d, int on) {
     if (!d) return SZL_E_ARG;
     d->caller_drains = on != 0;

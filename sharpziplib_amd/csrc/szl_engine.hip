@@ -316,6 +316,7 @@ void Engine::trim(size_t keep) {
     std::sort(v.begin(), v.end(), [](DevBuf *a, DevBuf *b) { return a->cap > b->cap; });
     size_t total = device_bytes();
     for (DevBuf *b : v) { if (total <= keep) break; total -= b->cap; b->release(); }
+    if (tab_pin && total + tab_pin_cap > keep) { (void)hipHostFree(tab_pin); tab_pin = nullptr; tab_pin_cap = 0; }   // (the tables' pinned staging comes back with the first call)
 }
 Engine::~Engine() {
     for (DevBuf *b : all_bufs())

@@ -47,7 +47,8 @@ buf = np.zeros(1 << 16, np.uint8)
 one_round()                                               # (per-process tables the first call leaves for good: probes, constant tables)
 L.szl_trim()
 base = live()
-L.szl_debug_set(b"SZL_IDLE_KEEP_MIB", 0)                 # the idle state keeps nothing
+L.szl_debug_set(b"SZL_IDLE_KEEP_MIB", 0)                 # the idle state keeps nothing ...
+L.szl_debug_set(b"SZL_IDLE_TRIM_MS", 0)                  # ... and begins at once (default: after two seconds without an object)
 for k in range(3):                                        # one object after another
     held = one_round()
     after = live()
