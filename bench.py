@@ -40,7 +40,7 @@ def parse_args(argv=None):
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--mode", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=int, default=384)
+    ap.add_argument("--cpu-sample-mib", type=int, default=320)
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--quick-configs", action="store_true", help="the other configs at the round-3 sizes (2 GiB / 25000 entries / 1 GiB) instead of BASELINE.json's")
     ap.add_argument("--stub", action="store_true", help="CPU-only plumbing test: gloo, ranks sleep instead of compressing")
@@ -304,6 +304,31 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
                 checked = "ALL %d entries: sha256 of their compressed bytes and of their CRC-32s == the oracle's frozen digests; all inflated back below" % n3
             entry("3_zip_%d_x_64KiB_deflate" % n3, n3 * esz, comp3, tm["total_ms"], checked,
                   ratio=round(comp3 / (n3 * esz), 4), stage_ms={k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")})
+            # the same entries ONE AT A TIME through the streaming object, as the unchanged ZipOutputStream drives it: PutNextEntry ->
+            # deflater_.Reset() + SetLevel (S/Zip/ZipOutputStream.cs:494-495), Write -> SetInput + Deflate() until IsNeedingInput,
+            # CloseEntry -> Finish() + the Deflate() loop (CS/DeflaterOutputStream.cs:100-118); wall clock per entry, bytes == the batch call's
+            from sharpziplib_amd.deflater import Deflater
+            n3s = min(2000, n3)
+            ho3 = o3[:int(st3[n3s - 1].out_off + st3[n3s - 1].out_len)].cpu().numpy()
+            dz = Deflater(level, True)
+            buf = np.zeros(1 << 17, np.uint8)
+            for timed in (False, True):
+                t_e = time.perf_counter()
+                for i in range(n3s if timed else 50):
+                    dz.Reset(); dz.SetLevel(level)
+                    dz.SetInput(host_big[i * esz:(i + 1) * esz])
+                    k = dz.Deflate(buf)
+                    dz.Finish()
+                    while not dz.IsFinished:
+                        k += dz.Deflate(buf[k:])
+                    if timed and (i % 16 == 0 or i == n3s - 1):
+                        s = st3[i]
+                        assert buf[:k].tobytes() == ho3[s.out_off:s.out_off + s.out_len].tobytes(), "per-entry path: entry %d differs from the batch call's" % i
+                dt_e = time.perf_counter() - t_e
+            del dz
+            out["3s_ZipOutputStream_per_entry_%d" % n3s] = {"ms_per_entry": round(dt_e / n3s * 1e3, 3), "mib_s": round(n3s * esz / 2 ** 20 / dt_e, 1),
+                                                          "checked": "every 16th entry == the batch call's bytes (which are checked against the oracle's frozen digests)",
+                                                          "note": "one Reset / SetInput / Finish per 64 KiB entry: ~20 dependent kernels per entry; wall clock incl. the Python mirror's calls"}
             ist, oo = inflate_table(st3, [esz] * n3)
             b3 = alloc(oo)
             for _ in range(2):
@@ -370,6 +395,40 @@ def extra_configs(eng, torch, dev, hip_stream, d_in, n, d_out, out_len, level, q
             ims = e2.timing()["inflate_ms"]
             assert ist[0].status == 0 and bool(torch.equal(b5[:n5], d5[:n5])), "round trip"
             checked.append("device round trip == input")
+            # the same stream through DeflaterOutputStream (host mirror of CS/DeflaterOutputStream.cs over the streaming Deflater): Write() in
+            # 16 MiB pieces, Finish(); parts of it are parsed while the pieces still arrive.  Wall clock, host buffers both ways.
+            if g and n5 == g["n"]:
+                from sharpziplib_amd.deflater import Deflater
+                from sharpziplib_amd.streams import DeflaterOutputStream
+
+                class Sink5:
+                    def __init__(self):
+                        self.h, self.n = hashlib.sha256(), 0
+
+                    def writable(self):
+                        return True
+
+                    def write(self, b):
+                        self.h.update(b); self.n += len(b)
+
+                    def flush(self):
+                        pass
+
+                    def close(self):
+                        pass
+                sink = Sink5()
+                t_s = time.perf_counter()
+                dos = DeflaterOutputStream(sink, Deflater(9, True), 1 << 20)
+                for o in range(0, n5, 16 << 20):
+                    dos.Write(host5[o:o + (16 << 20)])
+                t_w = time.perf_counter()
+                dos.Finish()
+                t_f = time.perf_counter()
+                assert sink.n == g["out_len"] and sink.h.hexdigest() == g["out_sha256"], "DeflaterOutputStream over the 4 GiB stream != the oracle's frozen bytes"
+                out["5s_DeflaterOutputStream_%dGiB_level9_wall" % (n5 // GiB)] = {"wall_ms": round((t_f - t_s) * 1e3, 1), "writes_ms": round((t_w - t_s) * 1e3, 1), "finish_ms": round((t_f - t_w) * 1e3, 1),
+                                                                               "mib_s": round(n5 / 2 ** 20 / (t_f - t_s), 1), "write_bytes": 16 << 20,
+                                                                               "checked": "sha256 of everything written to the base stream == oracle golden (the sink hashes inside the timed region)"}
+                del dos
             entry("5_level9_logs_%dGiB_deflate" % (n5 // GiB), n5, c5n, tm["total_ms"], "; ".join(checked), ratio=round(c5n / n5, 4),
                   stage_ms={k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")}, workspace_gib=round(e2._L.szl_engine_debug_workspace(e2._h) / GiB, 2),
                   inflate_back_ms=round(ims, 1))
