@@ -1,7 +1,6 @@
 // szl_engine.hip — host side of the device pipeline: workspace, work tables, launches, timing.
 // Product code: never includes or links anything from oracle/.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
@@ -138,6 +137,8 @@ size_t checksum_partial_bytes();
 void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint32_t n, hipStream_t st);
 void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st);
 void launch_zero_many(void *const *ptrs, const size_t *bytes, int n, hipStream_t st);
+size_t exscan_tmp_bytes(uint64_t n);
+hipError_t launch_exscan(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, hipStream_t st);
 int zero_piece_bytes();
 
 // Tuning knobs for experiments and parity taps: a value set through szl_debug_set() wins, else the environment variable of
@@ -543,10 +544,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         uint8_t *b = (uint8_t *)tabs.p;
         d_segs_view = b + a[0].off; p_bnds = b + a[1].off; p_spans = b + a[2].off; p_tiles = b + a[3].off; p_stripes = b + a[4].off; p_ckoff = b + a[5].off; p_zoff = b + a[6].off;
     }
-    size_t cub_bytes1 = 0, cub_bytes2 = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
-    if ((rc = cubtmp.ensure(std::max(cub_bytes1, cub_bytes2) + 256))) return rc;
+    if ((rc = cubtmp.ensure(std::max(exscan_tmp_bytes(nranges + 1), exscan_tmp_bytes(nseg + 1)) + 256))) return rc;
 
     const SegDev *dsegs = (const SegDev *)d_segs_view;
     SegOut *dso = (SegOut *)d_so.p;
@@ -731,9 +729,9 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         }
     }
     launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes1, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
+    HIPCHK(launch_exscan((const uint32_t *)counts.p, (uint64_t *)range_tok.p, nranges + 1, cubtmp.p, st));
     launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes2, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (int)(nseg + 1), st));
+    HIPCHK(launch_exscan((const uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (uint64_t)nseg + 1, cubtmp.p, st));
     if (emit_copy)
         launch_emit_copy(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p, (const uint32_t *)visited.p,
                          (const uint32_t *)spec_tok.p, (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p,
@@ -899,12 +897,10 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
     } else if (!want_ck) {
         launch_checksums(d_in, dseg_real, 1, (const uint64_t *)ckoff.p, 0, ckparts.p, dso, 0, st); // seeds the running values
     }
-    size_t cub_bytes = 0;
     const uint64_t max_ranges = (window + window / 4) / range_len + 2;
     if ((rc = counts.ensure((max_ranges + 2) * 4)) || (rc = range_tok.ensure((max_ranges + 2) * 8)) || (rc = ranges.ensure((max_ranges + 1) * sizeof(RangeDev))) ||
         (rc = bad_slot.ensure((max_ranges + 2) * 4)) || (rc = bad_range.ensure((max_ranges + 2) * 8))) return rc;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(max_ranges + 1), st));
-    if ((rc = cubtmp.ensure(cub_bytes + 256))) return rc;
+    if ((rc = cubtmp.ensure(exscan_tmp_bytes(max_ranges + 1) + 256))) return rc;
 
 #if SZL_LAB
     const int match_mode = match_mode_override >= 0 ? match_mode_override : SZL_LABKNOB("SZL_MATCH_MODE", 0);
@@ -1033,7 +1029,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
                             nbad, (uint16_t *)exmap.p, (uint16_t *)cnmap.p, dcnt, st, chain_buf.p, (uint32_t)nranges);
         }
         launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp.p, cub_bytes, (uint32_t *)counts.p, (uint64_t *)range_tok.p, (int)(nranges + 1), st));
+        HIPCHK(launch_exscan((const uint32_t *)counts.p, (uint64_t *)range_tok.p, nranges + 1, cubtmp.p, st));
         hipLaunchKernelGGL(k_add_base, dim3((unsigned)((nranges + 1 + 255) / 256)), dim3(256), 0, st, (uint64_t *)range_tok.p, nranges + 1, tok_base);
         // window's end: the clean iteration the true parse leaves it on, and its token count
         HIPCHK(hipMemcpyAsync(pin + 64, (RangeDev *)ranges.p + (nranges - 1), sizeof(RangeDev), hipMemcpyDeviceToHost, st));

@@ -974,6 +974,88 @@ size_t exitchain_scratch_bytes(uint64_t range_cnt) {
     const uint64_t nch = (range_cnt + CH_RANGES - 1) / CH_RANGES + 1;
     return (size_t)(((nch * X_W * 4 + 63) & ~63ull) + nch * 8 + 64);
 }
+// ---- exclusive prefix sum of 32-bit counts into 64-bit offsets (tokens in front of every range; block slots in front of every segment).
+// Through round 5 this was hipcub::DeviceScan::ExclusiveSum — the one library kernel on the path.  A block scans tiles of 8192 counts
+// (1024 threads x 8: serial in the thread, __shfl_up inside the wavefront, the sixteen wavefront totals through LDS); up to eight tiles
+// one block does alone with a running carry (a small call: one launch); more go tile sums -> their scan (one block) -> tiles again.
+enum : int { SCAN_T = 1024, SCAN_I = 8, SCAN_TILE = SCAN_T * SCAN_I };
+__device__ __forceinline__ uint64_t scan_tile(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t base, uint64_t n, uint64_t carry, uint64_t *wsum) {
+    // exclusive scan of in[base .. base + SCAN_TILE) (clipped at n) + carry into out (if out); returns the tile's total
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t v[SCAN_I];
+    uint64_t mine = 0;
+    const uint64_t i0 = base + (uint64_t)t * SCAN_I;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0u; mine += v[k]; }
+    uint64_t inc = mine;                                       // inclusive over the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint64_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_T / 64; k++) { const uint64_t x = wsum[k]; if (k < w) before += x; total += x; }
+    __syncthreads();
+    if (out) {
+        uint64_t run = carry + before + inc - mine;
+#pragma unroll
+        for (int k = 0; k < SCAN_I; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+    }
+    return total;
+}
+__global__ __launch_bounds__(SCAN_T) void k_exscan_small(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n) {
+    __shared__ uint64_t wsum[SCAN_T / 64];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += SCAN_TILE) carry += scan_tile(in, out, base, n, carry, wsum);
+}
+__global__ __launch_bounds__(SCAN_T) void k_exscan_sums(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ sums) {
+    __shared__ uint64_t wsum[SCAN_T / 64];
+    const uint64_t total = scan_tile(in, nullptr, (uint64_t)blockIdx.x * SCAN_TILE, n, 0, wsum);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(SCAN_T) void k_exscan_top(uint64_t *__restrict__ sums, uint32_t nb) {     // exclusive scan of the tile sums, in place (nb <= 65536)
+    __shared__ uint64_t wsum[SCAN_T / 64];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += SCAN_T) {
+        const uint32_t i = base + threadIdx.x;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint64_t x = i < nb ? sums[i] : 0;
+        uint64_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint64_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_T / 64; k++) { const uint64_t y = wsum[k]; if (k < w) before += y; total += y; }
+        const uint64_t carry = s_carry;
+        if (i < nb) sums[i] = carry + before + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + total;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(SCAN_T) void k_exscan_apply(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n, const uint64_t *__restrict__ sums) {
+    __shared__ uint64_t wsum[SCAN_T / 64];
+    (void)scan_tile(in, out, (uint64_t)blockIdx.x * SCAN_TILE, n, sums[blockIdx.x], wsum);
+}
+size_t exscan_tmp_bytes(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
+// out[i] = in[0] + ... + in[i - 1] for i in [0, n); tmp: exscan_tmp_bytes(n)
+hipError_t launch_exscan(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb <= 8) hipLaunchKernelGGL(k_exscan_small, dim3(1), dim3(SCAN_T), 0, st, in, out, n);
+    else {
+        if (nb > 65536ull * 1024ull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_exscan_sums, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, (uint64_t *)tmp);
+        hipLaunchKernelGGL(k_exscan_top, dim3(1), dim3(SCAN_T), 0, st, (uint64_t *)tmp, (uint32_t)nb);
+        hipLaunchKernelGGL(k_exscan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, out, n, (const uint64_t *)tmp);
+    }
+    return hipGetLastError();
+}
+
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st) {
     if (nranges == 0) return;
     hipLaunchKernelGGL(k_range_counts, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, ranges, nranges, counts);
