@@ -21,8 +21,8 @@ void launch_inflate_exact(const uint8_t *in, uint8_t *out, InfJob *jobs, InfStat
 void launch_checksums(const uint8_t *in, const SegDev *segs, uint32_t nseg, const uint64_t *chunk_off, uint64_t nchunks, void *parts,
                       SegOut *so, unsigned want, hipStream_t st);
 size_t checksum_partial_bytes();
-void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st);
-int inflate_slots_per_cu();
+void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st, bool dense);
+int inflate_slots_per_cu(bool dense);
 void launch_find_blocks(const uint8_t *in_base, const FindJob *fjobs, uint32_t njobs, uint64_t *start_bit, hipStream_t st);
 int launch_resolve_wins(const uint16_t *sym, const uint64_t *ooff, const uint64_t *jbase, uint8_t *wins, const ParMember *mem, uint32_t nmem,
                         const ResGroup *groups, uint32_t ngroups, const uint32_t *gfirst, bool chained, uint16_t *gmaps, uint8_t *ewins, hipStream_t st);
@@ -132,7 +132,13 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const uint64_t slots = (uint64_t)inflate_slots_per_cu() * (uint64_t)cus;
+    // ONE long member of ordinary data (128 MiB of compressed bytes or more, expanding less than six times) runs its symbol pass three
+    // wavefronts to a SIMD, ten chunk jobs to a CU: a 1 GiB text member 34.9 -> 30.9 ms.  Several members together and the pieces of a
+    // stream do not (they lose up to 50 % that way: szl_kernels_inflate.hip), nor does data that expands 15 times (a 1 GiB log member:
+    // 14.0 -> 16.0 ms — its time is in the copies, which gain nothing from a third wavefront and lose registers to it)
+    const bool dense = cand.size() == 1 && streams[cand[0]].in_len >= (128ull << 20) && streams[cand[0]].out_cap / 6 <= streams[cand[0]].in_len &&
+                       knob("SZL_INF_DENSE_ONE", 1) != 0;
+    const uint64_t slots = (uint64_t)inflate_slots_per_cu(dense) * (uint64_t)cus;
     const bool auto_size = knob("SZL_INF_CHUNK_KIB", 0) == 0;
     std::vector<uint64_t> in_lens;
     for (size_t ci : cand) in_lens.push_back(streams[ci].in_len);
@@ -301,7 +307,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         if ((r = E.inf_jobs.ensure(n * sizeof(InfJob))) || (r = E.inf_states.ensure(n * sizeof(InfState)))) return r;
         HIPCHK(hipMemcpyAsync(E.inf_jobs.p, jobs.data(), n * sizeof(InfJob), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(E.inf_states.p, 0, n * sizeof(InfState), st));
-        launch_inflate_chunks(d_in, (InfJob *)E.inf_jobs.p, (InfState *)E.inf_states.p, (uint32_t)n, pass, st);
+        launch_inflate_chunks(d_in, (InfJob *)E.inf_jobs.p, (InfState *)E.inf_states.p, (uint32_t)n, pass, st, dense);
         HIPCHK(hipMemcpyAsync(jobs.data(), E.inf_jobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         return 0;

@@ -977,21 +977,18 @@ void launch_inflate(const uint8_t *in, uint8_t *out, InfJob *jobs, InfState *sta
 }
 // chunk jobs of one member: pass 1 (count) or 2 (symbols); `in` = first byte of the member
 int knob(const char *name, int dflt);
-// chunk jobs of the symbol pass per CU the chunks are sized for in inflate_members_parallel: 8 (10 with SZL_INF_DENSE's register budget)
-// (Round 5 measured the 3-wavefronts-per-SIMD build with chunks cut for 10 jobs per CU on every shape, profiles/r05/dense_ab.log: one
-// 1 GiB member 46.7 -> 43.3 ms, 64 x 4 MiB members 17.6 -> 26.9 ms, everything else within 3 %: not a default; the laboratory library
-// keeps it — SZL_LAB — the product library does not.)
-#if SZL_LAB
-int inflate_slots_per_cu() { const int v = knob("SZL_INF_SLOTS_PER_CU", 8); return v < 1 ? 1 : v; }
-#else
-int inflate_slots_per_cu() { return 8; }
-#endif
-void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st) {
+// chunk jobs of the symbol pass per CU the chunks are sized for in inflate_members_parallel: 8, or 10 with the DENSE register budget
+// (three wavefronts per SIMD).  Round 5 measured the dense build with chunks cut for 10 jobs per CU on every shape
+// (profiles/r05/dense_ab.log): one 1 GiB member 46.7 -> 43.3 ms, 64 x 4 MiB members 17.6 -> 26.9 ms, everything else within 3 % — so it is
+// the form of ONE long member and of nothing else (round 6: `dense` below; inflate_members_parallel decides).
+int inflate_slots_per_cu(bool dense) {
+    const int v = SZL_LABKNOB("SZL_INF_SLOTS_PER_CU", 0);
+    return v >= 1 ? v : (dense ? 10 : 8);
+}
+void launch_inflate_chunks(const uint8_t *in, InfJob *jobs, InfState *states, uint32_t njobs, int pass, hipStream_t st, bool dense) {
     if (!njobs) return;
     if (pass == 1) hipLaunchKernelGGL((k_inflate<true, 1>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
-#if SZL_LAB
-    else if (knob("SZL_INF_DENSE", 0) != 0) hipLaunchKernelGGL((k_inflate<true, 2, true>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
-#endif
+    else if (dense || SZL_LABKNOB("SZL_INF_DENSE", 0) != 0) hipLaunchKernelGGL((k_inflate<true, 2, true>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
     else hipLaunchKernelGGL((k_inflate<true, 2>), dim3(njobs), dim3(64), 0, st, in, (uint8_t *)nullptr, jobs, states, njobs);
 }
 
