@@ -38,12 +38,16 @@ __device__ __forceinline__ uint32_t nolink(uint32_t w) {   // "no previous posit
     return w;
 }
 
+__device__ __forceinline__ uint32_t short_hops(uint32_t w) { return ((w & 0xFF00u) == 0) + ((w & 0xFF000000u) == 0); }   // of two staged links: hops below 256
+
 // Stage the window of one tile: bytes of history + tile + lookahead tail at smem + B9_D, links of history + tile at smem + B9_LB.
 // 16-byte pieces; a thread first issues all its loads (4 of bytes, 7 of links), then stores.  Pieces that straddle the stream's
 // start, the lookahead's end or the tile's end (links) are assembled byte by byte.
-__device__ __forceinline__ void b9_stage_window(uint8_t *smem, const uint8_t *d, const uint16_t *lk, int64_t dlo, int64_t seg_end, int64_t link_end) {
+// Returns how many of the links this thread staged are hops below 256 (the tile picks the form of its text by their share).
+__device__ __forceinline__ uint32_t b9_stage_window(uint8_t *smem, const uint8_t *d, const uint16_t *lk, int64_t dlo, int64_t seg_end, int64_t link_end) {
     enum : int { ND = B9_DATA_BYTES / 16, NL = 2 * B9_LINKS / 16, KD = (ND + B9_THREADS - 1) / B9_THREADS, KL = (NL + B9_THREADS - 1) / B9_THREADS };
     uint4 vd[KD], vl[KL];
+    uint32_t nshort = 0;
 #pragma unroll
     for (int k = 0; k < KD; k++) {
         const int i = threadIdx.x + k * B9_THREADS;
@@ -84,13 +88,15 @@ __device__ __forceinline__ void b9_stage_window(uint8_t *smem, const uint8_t *d,
         }
         v.x = nolink(v.x); v.y = nolink(v.y); v.z = nolink(v.z); v.w = nolink(v.w);
         *(uint4 *)(smem + B9_LB + 16 * i) = v;
+        nshort += short_hops(v.x) + short_hops(v.y) + short_hops(v.z) + short_hops(v.w);
     }
+    return nshort;
 }
 
 template <bool DBG>
 __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs, const TileDev *__restrict__ tiles,
                                                        const uint16_t *__restrict__ link, MTab mtab, LevelParams P, unsigned long long *dbg,
-                                                       int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1, int vtht1, int guide) {
+                                                       int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1, int vtht1, int guide, int form) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const TileDev tile = tiles[blockIdx.x];
     const SegDev seg = segs[tile.seg];
@@ -104,10 +110,27 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
 
     unsigned long long *s_t = (unsigned long long *)(smem + B9_DBG);     // (DBG) [0] first wavefront out of positions, [1] last wavefront done
     const unsigned long long t_start = DBG ? wall_clock64() : 0ull;
-    b9_stage_window(smem, d, lk, dlo, seg_end, t0 + tlen);
+    uint32_t nshort = b9_stage_window(smem, d, lk, dlo, seg_end, t0 + tlen);
+    if (form == 2) {   // per wavefront: its threads' short hops (summed over the tile below)
+#pragma unroll
+        for (int o = 32; o; o >>= 1) nshort += __shfl_xor(nshort, o);
+        if ((threadIdx.x & 63) == 0) *(uint32_t *)(smem + B9_SCR + (threadIdx.x & ~63u)) = nshort;
+    }
     if (threadIdx.x == 0) { *(uint32_t *)smem = 0u; if (DBG) { s_t[0] = ~0ull; s_t[1] = 0ull; s_t[2] = 0ull; s_t[3] = 0ull; } }
     __syncthreads();
     const unsigned long long t_staged = DBG ? wall_clock64() : 0ull;
+    // The form of the text this tile runs (szl_match9_asm.h, SZL9_V): form 1 pays one instruction per chain step for a filter byte that
+    // follows the walk's failed compares, and wins where chains are dense — lines of a log, records of a table: most hops of prev[]
+    // are short there (generated logs: 92 % below 256; text: 23 %) and most compares fail where the one before did.  Both forms
+    // store the same tables; the choice is the tile's own (form == 2) or the caller's (SZL9_FORM 0 / 1, laboratory and tests).
+    if (form == 2) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < B9_THREADS / 64; w++) tot += *(const uint32_t *)(smem + B9_SCR + 64 * w);
+        form = 2u * tot > (uint32_t)(B_HIST + tlen) ? 1 : 0;
+        __syncthreads();   // (the slots are the tail program's scratch)
+    }
+    const int form_s = __builtin_amdgcn_readfirstlane(form);
 
     // window bases of the tile (see k_match4): positions from `sw` on belong to base_hi
     const int64_t base_lo = base_of9((int64_t)seg.abs0 + t0), base_hi = base_of9((int64_t)seg.abs0 + t0 + tlen - 1);
@@ -131,7 +154,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     const uint64_t stratm_s = sgpr64(stratm), mt2b_s = sgpr64((uint64_t)(uintptr_t)mt2b), mtqb_s = sgpr64((uint64_t)(uintptr_t)mtqb);
     uint32_t vzero, vslice;   // (constants in VGPRs: 0 and the slice length; the text sets them)
 #define SZL9_CTXV(X) uint32_t pl##X = 0, cb##X = 0, kk##X = 0, mincb##X = 0, left##X = 0, pb##X = 0, best##X = 2, off##X = 0, cap##X = MAX_MATCH, \
-    nice##X = (uint32_t)nicel, res2##X = 0, resq##X = 0, p0##X = 0, p1##X = 0, p2##X = 0, p3##X = 0, hop##X = 0, t0##X, t1##X, t2##X, t3##X, t4##X, t5##X, t6##X, t7##X; \
+    nice##X = (uint32_t)nicel, res2##X = 0, resq##X = 0, p0##X = 0, p1##X = 0, p2##X = 0, p3##X = 0, hop##X = 0, kd##X = 0, t0##X, t1##X, t2##X, t3##X, t4##X, t5##X, t6##X, t7##X; \
     uint64_t q##X = 0, v##X = 0, w##X = 0, d##X = 0, m##X = 0, c##X = 0;
     SZL9_CTXV(A)
     SZL9_CTXV(B)
@@ -140,23 +163,34 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     uint32_t n0, n1, n2, f0, f1, f2, kt = 0;
     int wnext = 0, wend = 0, exh = 0;
     int bexit = sgpr(64 - fth), vth = sgpr(vth_in), qkeep = sgpr(qkeep_in);
-    asm volatile(SZL9_TEXT
 #define SZL9_IO(X) [pl##X] "+&v"(pl##X), [cb##X] "+&v"(cb##X), [kk##X] "+&v"(kk##X), [mincb##X] "+&v"(mincb##X), [left##X] "+&v"(left##X), [pb##X] "+&v"(pb##X), \
     [best##X] "+&v"(best##X), [off##X] "+&v"(off##X), [cap##X] "+&v"(cap##X), [nice##X] "+&v"(nice##X), [res2##X] "+&v"(res2##X), [resq##X] "+&v"(resq##X), \
-    [p0##X] "+&v"(p0##X), [p1##X] "+&v"(p1##X), [p2##X] "+&v"(p2##X), [p3##X] "+&v"(p3##X), [hop##X] "+&v"(hop##X), \
+    [p0##X] "+&v"(p0##X), [p1##X] "+&v"(p1##X), [p2##X] "+&v"(p2##X), [p3##X] "+&v"(p3##X), [hop##X] "+&v"(hop##X), [kd##X] "+&v"(kd##X), \
     [t0##X] "=&v"(t0##X), [t1##X] "=&v"(t1##X), [t2##X] "=&v"(t2##X), [t3##X] "=&v"(t3##X), [t4##X] "=&v"(t4##X), [t5##X] "=&v"(t5##X), [t6##X] "=&v"(t6##X), [t7##X] "=&v"(t7##X), \
     [q##X] "+&s"(q##X), [v##X] "+&s"(v##X), [w##X] "+&s"(w##X), [d##X] "+&s"(d##X), [m##X] "+&s"(m##X), [c##X] "+&s"(c##X)
-                 : SZL9_IO(A), SZL9_IO(B),
-#undef SZL9_IO
-                   [sc] "=&s"(sc), [cm] "=&s"(cm), [sa] "=&s"(sa), [sv] "=&s"(sv), [texh] "+&s"(texh), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2),
-                   [f0] "=&s"(f0), [f1] "=&s"(f1), [f2] "=&s"(f2), [kt] "+&s"(kt), [wnext] "+&s"(wnext), [wend] "+&s"(wend), [exh] "+&s"(exh),
-                   [bexit] "+&s"(bexit), [vth] "+&s"(vth), [qkeep] "+&s"(qkeep),
-                   [vzero] "=&v"(vzero), [vslice] "=&v"(vslice)
-                 : [tlen] "s"(tlen_s), [slice] "s"(slice_s), [rem0] "s"(rem0_s), [sw] "s"(sw_s), [bmlo] "s"(bmlo_s),
-                   [bmhi] "s"(bmhi_s), [nicel] "s"(nicel_s), [chainm2] "s"(chainm2_s), [snapm1] "s"(snapm1_s), [qkeept] "s"(qkeept_s), [vtht] "s"(vtht_s),
-                   [ktail] "s"(ktail_s), [stratm] "s"(stratm_s), [mt2b] "s"(mt2b_s), [mtqb] "s"(mtqb_s),
-                   [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s), [vtht1] "s"(vtht1_s), [guide] "s"(guide_s)
+#define SZL9_RUN_TEXT() \
+    asm volatile(SZL9_TEXT \
+                 : SZL9_IO(A), SZL9_IO(B), \
+                   [sc] "=&s"(sc), [cm] "=&s"(cm), [sa] "=&s"(sa), [sv] "=&s"(sv), [texh] "+&s"(texh), [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2), \
+                   [f0] "=&s"(f0), [f1] "=&s"(f1), [f2] "=&s"(f2), [kt] "+&s"(kt), [wnext] "+&s"(wnext), [wend] "+&s"(wend), [exh] "+&s"(exh), \
+                   [bexit] "+&s"(bexit), [vth] "+&s"(vth), [qkeep] "+&s"(qkeep), \
+                   [vzero] "=&v"(vzero), [vslice] "=&v"(vslice) \
+                 : [tlen] "s"(tlen_s), [slice] "s"(slice_s), [rem0] "s"(rem0_s), [sw] "s"(sw_s), [bmlo] "s"(bmlo_s), \
+                   [bmhi] "s"(bmhi_s), [nicel] "s"(nicel_s), [chainm2] "s"(chainm2_s), [snapm1] "s"(snapm1_s), [qkeept] "s"(qkeept_s), [vtht] "s"(vtht_s), \
+                   [ktail] "s"(ktail_s), [stratm] "s"(stratm_s), [mt2b] "s"(mt2b_s), [mtqb] "s"(mtqb_s), \
+                   [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s), [vtht1] "s"(vtht1_s), [guide] "s"(guide_s) \
                  : "vcc", "scc", "memory");
+    if (form_s == 0) {
+        SZL9_RUN_TEXT();
+    } else {
+#undef SZL9_V
+#define SZL9_V 1
+        SZL9_RUN_TEXT();
+#undef SZL9_V
+#define SZL9_V 0
+    }
+#undef SZL9_RUN_TEXT
+#undef SZL9_IO
     if (DBG) {
         const unsigned long long t_end = wall_clock64();
         if ((threadIdx.x & 63) == 0) {
@@ -196,6 +230,9 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     int slice = SZL_LABKNOB("SZL_SLICE", 128);
     // hand-out near the tile's end: within `guide` positions of it a fetch takes as many positions as it has free lanes instead of a slice
     int guide = SZL_LABKNOB("SZL9_GUIDE", 8192);
+    // form of the text: 2 = each tile picks (k_match9), 0 / 1 = every tile runs that form
+    int form = SZL_LABKNOB("SZL9_FORM", 2);
+    form = form < 0 || form > 2 ? 2 : form;
     fth = fth < 1 ? 1 : (fth > 64 ? 64 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; ktail = ktail < 1 ? 1 : ktail; vtht = vtht < 1 ? 1 : vtht;
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
     if (lds_attr_needed9(attr_mask, attr_bit)) {
@@ -206,8 +243,8 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     }
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B9_THREADS);
-        if (want_dbg) hipLaunchKernelGGL((k_match9<true>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide);
-        else hipLaunchKernelGGL((k_match9<false>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide);
+        if (want_dbg) hipLaunchKernelGGL((k_match9<true>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide, form);
+        else hipLaunchKernelGGL((k_match9<false>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide, form);
     }
     return hipGetLastError();
 }

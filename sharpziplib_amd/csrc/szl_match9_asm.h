@@ -27,6 +27,16 @@
 #define SZL9_XSTR(x) #x
 #define SZL9_STR(x) SZL9_XSTR(x)
 
+// The text has two FORMS, picked where SZL9_TEXT is expanded by the value SZL9_V has there (every macro below is expanded only then):
+//   SZL9_V 0  the filter bytes are the reference's, scan_end1 and scan_end (C/DeflaterEngine.cs:512-515);
+//   SZL9_V 1  the filter's FIRST byte follows the lane's last failed compare (SZL9_Q_ISSUE_1): the form for tiles whose chains are dense.
+// k_match9 holds both and a tile takes one (szl_kernels_match9.hip: the share of short prev[] hops in the tile's window decides).
+#ifndef SZL9_V
+#define SZL9_V 0
+#endif
+#define SZL9_CAT_(a, b) a##b
+#define SZL9_CAT(a, b) SZL9_CAT_(a, b)
+#define SZL9_FORM(name) SZL9_CAT(name, SZL9_V)
 #ifndef SZL9_NQ
 #define SZL9_NQ 3              // LDS reads per QUICK step: 3 = two filter bytes (scan_end1, scan_end), 2 = scan_end only
 #endif
@@ -50,7 +60,20 @@
 // loop (exec) when the budget is spent (:609 --chainLength), the next candidate is out of the window (:609 curMatch > limit) or
 // the filter bytes match (:505-506; the candidate to compare is then cb + hop - best_len).
 #if SZL9_NQ == 3
-#define SZL9_Q_ISSUE(X) \
+// Form 1: the first filter byte is the candidate's byte at offset best_len + kd: kd = -1 (scan_end1, the reference's) until a compare of
+// this walk fails without improving best_len; from then on the offset at which it failed (COMPLETE).  Any byte in front of best_len is
+// a valid filter — a candidate that differs there cannot beat best_len — and on data whose lines differ from the position's in one
+// field the next candidates of the chain fail where the last one did: 4.6 of 5.7 compares per position at level 9 on logs do not
+// improve, 70 % of them are caught by this byte (tools/lab/walkstat.c).  One VALU instruction more per chain step (+1 % on text, where
+// it catches a third of 14 %): a tile takes this form where its chains are dense.
+#define SZL9_Q_ISSUE_1(X) \
+    "v_lshl_add_u32 %[t0" #X "], %[cb" #X "], 1, %[kk" #X "]\n\t" \
+    "v_add_u32 %[t3" #X "], %[cb" #X "], %[kd" #X "]\n\t" \
+    "ds_read_u16 %[hop" #X "], %[t0" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"     /* prev[] hop of the candidate */ \
+    "ds_read_u8 %[t2" #X "], %[t3" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"        /* candidate[best_len + kd] */ \
+    "ds_read_u8 %[t1" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"        /* candidate[best_len] */
+#define SZL9_Q_ISSUE(X) SZL9_FORM(SZL9_Q_ISSUE_)(X)
+#define SZL9_Q_ISSUE_0(X) \
     "v_lshl_add_u32 %[t0" #X "], %[cb" #X "], 1, %[kk" #X "]\n\t" \
     "ds_read_u16 %[hop" #X "], %[t0" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"     /* prev[] hop of the candidate */ \
     "ds_read_u8 %[t2" #X "], %[cb" #X "] offset:" SZL9_STR(SZL9_DM1) "\n\t"      /* candidate[best_len - 1] */ \
@@ -170,7 +193,32 @@
     "v_mul_i32_i24 %[kk" #X "], -2, %[t2" #X "]\n\t" \
     "v_cmp_ge_i32 %[sc], %[t2" #X "], %[nice" #X "]\n\t"                           /* >= niceLength: stop (:603) */ \
     "s_waitcnt lgkmcnt(0)\n\t" \
-    SZL9_PB_SET(X)
+    SZL9_PB_SET(X) \
+    SZL9_KD_RESET(X)
+#define SZL9_KD_RESET_0(X)
+#define SZL9_KD_RESET_1(X) "v_mov_b32 %[kd" #X "], -1\n\t"
+/* lanes in exec: their compare did not improve best_len; off = where it failed (t2 = min(off, cap) of COMPLETE).  The first filter byte
+ * moves there when that is in front of best_len - 1 (else it stays where it is: nothing learnt) */
+#define SZL9_KD_SET_1(X) \
+    "v_sub_u32 %[t1" #X "], %[t2" #X "], %[best" #X "]\n\t"                        /* off - best_len */ \
+    "v_cmpx_gt_i32 vcc, -1, %[t1" #X "]\n\t" \
+    "s_cbranch_execz 36f\n\t" \
+    "v_add_u32 %[t3" #X "], %[pl" #X "], %[t2" #X "]\n\t" \
+    "ds_read_u8 %[t3" #X "], %[t3" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"       /* the position's byte there */ \
+    "v_mov_b32 %[kd" #X "], %[t1" #X "]\n\t" \
+    "v_and_b32 %[pb" #X "], 0xffff0000, %[pb" #X "]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_or_b32 %[pb" #X "], %[pb" #X "], %[t3" #X "]\n" \
+    "36:\n\t"
+#define SZL9_KD_RESET(X) SZL9_FORM(SZL9_KD_RESET_)(X)
+/* (sc = improved lanes that reached niceLength; the improved set itself is gone by here: a lane improved iff its best_len == t2 now) */
+#define SZL9_COMPLETE_LEARN_1(X) \
+    "s_mov_b64 exec, %[c" #X "]\n\t" \
+    "v_cmpx_ne_u32 vcc, %[t2" #X "], %[best" #X "]\n\t" \
+    "s_cbranch_execz 36f\n\t" \
+    SZL9_KD_SET_1(X)
+#define SZL9_COMPLETE_LEARN_0(X)
+#define SZL9_COMPLETE_LEARN(X) SZL9_FORM(SZL9_COMPLETE_LEARN_)(X)
 #define SZL9_COMPLETE(X) \
     "s_mov_b64 exec, %[c" #X "]\n\t" \
     "s_cbranch_execz 39f\n\t" \
@@ -182,6 +230,7 @@
     "s_cbranch_execz 38f\n\t" \
     SZL9_IMPROVE(X) "\n" \
     "38:\n\t"                                                                        /* (nobody improved: sc = 0, exec = 0) */ \
+    SZL9_COMPLETE_LEARN(X) \
     "s_mov_b64 exec, %[c" #X "]\n\t" \
     "v_cmp_lt_i32 vcc, %[cb" #X "], %[mincb" #X "]\n\t"                            /* the next candidate is out of the window */ \
     "s_or_b64 %[sc], %[sc], vcc\n\t" \
@@ -339,6 +388,7 @@
     "v_lshlrev_b32 %[t0" #X "], 1, %[cb" #X "]\n\t" \
     "ds_read_u16 %[hop" #X "], %[t0" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"    /* its prev[] hop */ \
     "v_mov_b32 %[best" #X "], 1\n\t" \
+    SZL9_KD_RESET(X) \
     "v_mov_b32 %[kk" #X "], -2\n\t" \
     "v_mov_b32 %[left" #X "], %[chainm2]\n\t"                                      /* max_chain - 1 may follow the first; one is taken below */ \
     "s_waitcnt lgkmcnt(1)\n\t" \
@@ -576,6 +626,12 @@
     "s_mov_b64 %[wB], 0\n\t" \
     "s_branch 80b\n"
 
+#define SZL9_MOVE_KD_0
+#define SZL9_MOVE_KD_1 \
+    "ds_bpermute_b32 %[t2B], %[t3A], %[kdB]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_cndmask_b32 %[kdA], %[kdA], %[t2B], %[sa]\n\t"
+#define SZL9_MOVE_KD SZL9_FORM(SZL9_MOVE_KD_)
 #define SZL9_TAIL \
     "; @phase census\n" \
     "40:\n\t" \
@@ -719,6 +775,7 @@
     SZL9_MOVE8("cap", "nice", "res2", "resq", "p0", "p1", "p2", "p3") \
     "ds_bpermute_b32 %[t0B], %[t3A], %[hopB]\n\t" \
     "ds_bpermute_b32 %[t1B], %[t3A], %[t4A]\n\t" \
+    SZL9_MOVE_KD \
     "s_waitcnt lgkmcnt(0)\n\t" \
     "v_cndmask_b32 %[hopA], %[hopA], %[t0B], %[sa]\n\t" \
     "s_mov_b64 exec, %[sa]\n\t" \

@@ -25,6 +25,13 @@ SIM = os.path.join(ROOT, "tools", "sim_match9.py")
     ["--kind", "logs", "--level", "9", "--kib", "64", "--tlen", "4096", "--tile", "0", "--ktail1", "2"],
     ["--kind", "logs", "--level", "6", "--kib", "96", "--tlen", "6144", "--tile", "7", "--ktail1", "1", "--guide", "100000"],
     ["--kind", "dickens", "--level", "8", "--kib", "128", "--tlen", "8192", "--tile", "9"],
+    # form 1 of the text (SZL9_V 1: the first filter byte follows the walk's last failed compare)
+    ["--adapt", "--kind", "logs", "--level", "9", "--kib", "64", "--tlen", "4096", "--tile", "5"],
+    ["--adapt", "--kind", "logs", "--level", "6", "--kib", "64", "--tlen", "4096", "--tile", "0"],
+    ["--adapt", "--kib", "96", "--tlen", "3072", "--tile", "5", "--cut", "100"],
+    ["--adapt", "--kind", "dickens", "--level", "7", "--kib", "96", "--tlen", "4096", "--tile", "2", "--mth", "-1"],
+    ["--adapt", "--kib", "96", "--tlen", "3072", "--tile", "3", "--tailp", "1", "--ktail1", "1"],
+    ["--adapt", "--kind", "zeros", "--kib", "64", "--tlen", "2048", "--tile", "3"],
 ])
 def test_instruction_text_reproduces_the_model(args):
     r = subprocess.run([sys.executable, SIM] + args, capture_output=True, text=True, timeout=300)

@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--notail", action="store_true"); ap.add_argument("--strategy", type=int, default=0); ap.add_argument("--quantum", type=int, default=300)
     ap.add_argument("--tailp", type=int, default=2); ap.add_argument("--mth", type=int, default=64); ap.add_argument("--ktail1", type=int, default=4)
     ap.add_argument("--guide", type=int, default=8192, help="within this many positions of the tile's end a fetch takes its free lanes' worth of positions")
+    ap.add_argument("--adapt", action="store_true", help="form 1 of the text (SZL9_V 1: the first filter byte follows the last failed compare)")
     ap.add_argument("--cut", type=int, default=0, help="segment ends this many bytes before the end of the generated data's last tile (lookahead clamps)")
     a = ap.parse_args()
     import oracle_ffi as O
@@ -95,13 +96,13 @@ def main():
     lds, lb = stage_tile(data, model.link, t0, tlen, n, tile_cap)
     assert lb == 54304
     K = tile_consts(a.abs0, t0, tlen, n, tile_cap)
-    text = engine_text(a.nq)
+    text = engine_text(a.nq, defs=["SZL9_V=1"] if a.adapt else [])
     prog = W.Program(text)
     print("program: %d instructions; model %.1fs" % (len(prog.ins), time.time() - t), flush=True)
     mt2 = np.full(B_HIST + tile_cap + 64, 0xDEADBEEF, dtype=np.uint32)
     mtq = np.full(B_HIST + tile_cap + 64, 0xDEADBEEF, dtype=np.uint32)
     vnames = ["vzero", "vslice"] + [x + c for c in "AB" for x in
-                                   ["pl", "cb", "kk", "mincb", "left", "pb", "best", "off", "cap", "nice", "res2", "resq", "p0", "p1", "p2", "p3", "hop",
+                                   ["pl", "cb", "kk", "mincb", "left", "pb", "best", "off", "cap", "nice", "res2", "resq", "p0", "p1", "p2", "p3", "hop", "kd",
                                     "t0", "t1", "t2", "t3", "t4", "t5", "t6", "t7"]]
     waves = []
     for w in range(a.waves):
