@@ -464,7 +464,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     for (size_t g = 0; g < good.size(); g++) {
         const PS &p = ps[good[g]];
         mem[g] = ParMember{p.ooff_off, p.win_off, sm ? 0 : streams[p.si].out_off, p.total, (uint32_t)p.sb.size(), (uint32_t)nblk, sm ? sm->win0 : nullptr};
-        nblk += (p.total + 16383) / 16384;
+        nblk += (p.total + CONV_BLOCK - 1) / CONV_BLOCK;
     }
     if (nblk > 0x7FFFFFFFull) return SZL_E_ARG;
     if ((rc = E.inf_states.ensure(mem.size() * sizeof(ParMember)))) return rc;

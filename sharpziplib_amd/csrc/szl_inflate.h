@@ -67,6 +67,7 @@ struct ExState {
 
 // chunk-parallel decode of whole members (szl_kernels_inflate_par.hip)
 struct FindJob { uint64_t in_off, in_len, lo_bit, hi_bit; };     // look for a block header of the member at in_off in [lo_bit, hi_bit)
+enum : uint32_t { CONV_BLOCK = 65536 };   // bytes of a member's output to a workgroup of k_convert
 struct ParMember {                                               // one member being assembled from its chunk jobs
     uint64_t ooff_off;  // first of its njobs + 1 output offsets (and of its jobs' staging offsets)
     uint64_t win_off;   // its (njobs + 1) windows of 32 KiB (bytes)

@@ -144,11 +144,12 @@ __device__ bool stored_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
 // One wavefront per finder job: first valid dynamic header at a bit offset in [lo_bit, hi_bit) of the job's member.  The scan tests
 // 64 bit positions per step with the cheap tests and notes the positions that pass; every FIND_FLUSH steps (or with 64 of them
 // noted) they are parsed, a lane each, and the lowest one that holds is the answer.
-enum : int { FIND_FLUSH = 512, FIND_CAP = 192, FIND_STAGE_BYTES = 256, FIND_STAGE_DW = FIND_STAGE_BYTES / 4 + 6 };
+enum : int { FIND_FLUSH = 1536, FIND_CAP = 256 /* 63 left by the step before + a Kraft round + a step's stored candidates + what is noted, drained before a flush */, FIND_STAGE_BYTES = 256, FIND_STAGE_DW = FIND_STAGE_BYTES / 4 + 6 };
 __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ in_base, const FindJob *__restrict__ fjobs, uint32_t njobs,
                                                     uint64_t *__restrict__ start_bit) {
     __shared__ __attribute__((aligned(16))) uint8_t s_mlut[64][128];
     __shared__ uint64_t s_cand[FIND_CAP];
+    __shared__ uint16_t s_pre[128];                                // stage offsets that passed the first test, in order
     __shared__ uint32_t s_stage[FIND_STAGE_DW];
     __shared__ uint8_t s_k9[512];                                  // Kraft weight (units of 2^-7) of three 3-bit code lengths at once
     if (blockIdx.x >= njobs) return;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     uint64_t hi = fj.hi_bit;
     if (hi + 128 > in_len * 8) hi = in_len * 8 > 128 ? in_len * 8 - 128 : 0;
     uint64_t found = ~0ull;
-    int ncand = 0, since = 0;
+    int ncand = 0, since = 0, npre = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // (s_k9)
     auto flush = [&]() {                                           // parse what has been noted; the lowest position that holds is the answer
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -197,32 +198,54 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint64_t blk_bit = blk * 8;
-        for (uint32_t step = 0; step < FIND_STAGE_BYTES * 8 / 64 && found == ~0ull; step++) {
-            const uint64_t p = blk_bit + 64ull * step + (uint64_t)lane;
+        // Round 6: the two tests of a bit position are run apart.  One position in nine passes the first (type bits, HLIT, HDIST) and
+        // some lane did in nearly every step, so every step paid for the second — the Kraft sum of the code-length code's lengths, 64-bit
+        // shifts and seven table look-ups, most of the scan's instructions — with seven lanes in it.  Now a step notes the offsets that pass
+        // the first test (s_pre, in order), and the second runs on 64 noted offsets at a time: once in nine steps.
+        auto kraft_round = [&](int take) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             bool cand = false;
-            if (p >= lo && p < hi) {
-                const uint32_t off = 64u * step + (uint32_t)lane;                  // bit offset inside the stage
+            uint32_t off = 0;
+            if (lane < take) {
+                off = s_pre[lane];
                 const uint32_t dw = off >> 5, sh = off & 31u;
                 const uint32_t w = __builtin_amdgcn_alignbit(s_stage[dw + 1], s_stage[dw], sh);
-                if ((w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29) {
-                    // the code-length code's own lengths (nm x 3 bits) must be a complete code: their Kraft sum, three lengths per table
-                    // look-up (round 5: a loop over the 19 fields, entered by some lane in nearly every step, was 2/3 of the scan's
-                    // 288 instructions per step — the finder is bound by them, 4.5 ms for a chunk's 45 KiB to its first header)
-                    const uint32_t nm = ((w >> 13) & 15) + 4;
-                    const uint32_t o2 = off + 17u, d2 = o2 >> 5, s2 = o2 & 31u;      // the 57 bits of the lengths
-                    uint64_t m = (uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 1], s_stage[d2], s2) |
-                                 ((uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 2], s_stage[d2 + 1], s2) << 32);
-                    m &= (1ull << (3 * nm)) - 1ull;                                  // (nm <= 19: at most 57 bits)
-                    const int kraft = (int)s_k9[(uint32_t)m & 511u] + (int)s_k9[(uint32_t)(m >> 9) & 511u] + (int)s_k9[(uint32_t)(m >> 18) & 511u] +
-                                      (int)s_k9[(uint32_t)(m >> 27) & 511u] + (int)s_k9[(uint32_t)(m >> 36) & 511u] + (int)s_k9[(uint32_t)(m >> 45) & 511u] +
-                                      (int)s_k9[(uint32_t)(m >> 54) & 511u];
-                    cand = kraft == 128;
-                }
+                // the code-length code's own lengths (nm x 3 bits) must be a complete code: their Kraft sum, three lengths per table look-up
+                const uint32_t nm = ((w >> 13) & 15) + 4;
+                const uint32_t o2 = off + 17u, d2 = o2 >> 5, s2 = o2 & 31u;          // the 57 bits of the lengths
+                uint64_t m = (uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 1], s_stage[d2], s2) |
+                             ((uint64_t)__builtin_amdgcn_alignbit(s_stage[d2 + 2], s_stage[d2 + 1], s2) << 32);
+                m &= (1ull << (3 * nm)) - 1ull;                                      // (nm <= 19: at most 57 bits)
+                const int kraft = (int)s_k9[(uint32_t)m & 511u] + (int)s_k9[(uint32_t)(m >> 9) & 511u] + (int)s_k9[(uint32_t)(m >> 18) & 511u] +
+                                  (int)s_k9[(uint32_t)(m >> 27) & 511u] + (int)s_k9[(uint32_t)(m >> 36) & 511u] + (int)s_k9[(uint32_t)(m >> 45) & 511u] +
+                                  (int)s_k9[(uint32_t)(m >> 54) & 511u];
+                cand = kraft == 128;
             }
             const uint64_t mm = __ballot(cand);
             if (mm) {
-                if (cand) s_cand[ncand + __builtin_popcountll(mm & ((1ull << lane) - 1ull))] = p;
+                if (cand) s_cand[ncand + __builtin_popcountll(mm & ((1ull << lane) - 1ull))] = blk_bit + (uint64_t)off;
                 ncand += __builtin_popcountll(mm);
+            }
+            const int rest = npre - take;                                            // (< 64: a round runs as soon as 64 are noted)
+            const uint16_t mv = lane < rest ? s_pre[lane + take] : (uint16_t)0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < rest) s_pre[lane] = mv;
+            npre = rest;
+        };
+        for (uint32_t step = 0; step < FIND_STAGE_BYTES * 8 / 64 && found == ~0ull; step++) {
+            const uint64_t p = blk_bit + 64ull * step + (uint64_t)lane;
+            const uint32_t off = 64u * step + (uint32_t)lane;                      // bit offset inside the stage
+            bool pre = false;
+            if (p >= lo && p < hi) {
+                const uint32_t dw = off >> 5, sh = off & 31u;
+                const uint32_t w = __builtin_amdgcn_alignbit(s_stage[dw + 1], s_stage[dw], sh);
+                pre = (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+            }
+            const uint64_t pm = __ballot(pre);
+            if (pm) {
+                if (pre) s_pre[npre + __builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (uint16_t)off;
+                npre += __builtin_popcountll(pm);
+                if (npre >= 64) kraft_round(64);
             }
             // ... or a stored block's (stored_ok_lane).  Its LEN / NLEN pair is byte aligned, so the cheap test goes by BYTE, a lane each,
             // once per eight steps (per bit position it was 16 of the scan's 127 instructions per step, +20 % on a member of text): lane l
@@ -252,8 +275,13 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                     ncand += __builtin_popcountll(sm);
                 }
             }
-            if (++since >= FIND_FLUSH || ncand >= 64) flush();
+            if (++since >= FIND_FLUSH || ncand >= 64) {
+                while (npre) kraft_round(npre < 64 ? npre : 64);   // (what is noted lies in front of a stored candidate of this step)
+                flush();
+            }
         }
+        while (npre) kraft_round(npre < 64 ? npre : 64);           // (offsets are the stage's)
+        if (ncand >= 64) flush();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (found == ~0ull && ncand) flush();
@@ -376,14 +404,20 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
     }
 }
 
-// symbols -> bytes; one workgroup per 16 KiB of a member's output (blk0 = the member's first workgroup).  A thread takes 16 consecutive
-// bytes per step: two 16-byte loads of symbols (their address is only 2-byte aligned: the hardware's unaligned access mode), the low
-// bytes packed, one 16-byte store — it used to be one 2-byte load and one 1-byte store per thread and step, 0.86 TB/s of the chip's 8
-// (3.75 ms per GiB of output).  Symbols that name the window in front of their job (0x8000 | i) are looked up byte by byte, and so are
-// the 16 bytes that straddle two jobs or end the member.
+// symbols -> bytes; one workgroup per CONV_BLOCK (64 KiB) of a member's output (blk0 = the member's first workgroup), 16 KiB at a time.
+// A thread takes 16 consecutive bytes per step: two 16-byte loads of symbols (their address is only 2-byte aligned: the hardware's
+// unaligned access mode), the low bytes packed (v_perm_b32), one 16-byte store — it used to be one 2-byte load and one 1-byte store per
+// thread and step, 0.86 TB/s of the chip's 8 (3.75 ms per GiB of output).  Nearly every 16 KiB lie inside ONE job (a job's output is
+// hundreds of KiB): a thread then issues all eight of its loads before it looks at any of them.
+// Symbols that name the window in front of their job (0x8000 | i) — a tenth of a text member's, but some in most groups of sixteen —
+// were looked up with a byte load from global memory each: 1.0 of the kernel's 1.6 ms per GiB went there, whether the loads waited for
+// each other or were issued together (round 6, profiles/r06/inflate_convert.log: the texture path takes a wave's 64 byte addresses as 64
+// accesses).  Now the first 16 KiB of a workgroup that meet such a symbol copy the job's 32 KiB window into LDS, and the look-ups are
+// ds_read_u8.  The 16 KiB that straddle two jobs or end the member go symbol by symbol as before.
 __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,
                                                  const uint64_t *__restrict__ jbase_all, const uint8_t *__restrict__ wins_all,
                                                  uint8_t *__restrict__ out_base, const ParMember *__restrict__ mem, uint32_t nmem) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[32768];
     uint32_t a = 0, z = nmem;                                      // last member with blk0 <= blockIdx.x
     while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if (mem[mid].blk0 <= blockIdx.x) a = mid; else z = mid; }
     const ParMember m = mem[a];
@@ -393,43 +427,59 @@ __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sy
     uint8_t *out = out_base + m.out_off;
     const uint32_t njobs = m.njobs;
     const uint64_t total = m.total;
-    const uint64_t b0 = (uint64_t)(blockIdx.x - m.blk0) * 16384;
-    if (b0 >= total) return;
-    const uint64_t b1 = b0 + 16384 < total ? b0 + 16384 : total;
-    uint32_t lo = 0, hi = njobs;                                   // last job with out_off <= b0
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (out_off[mid] <= b0) lo = mid; else hi = mid; }
-    uint32_t j = lo;
-    for (uint64_t q = b0 + 16ull * threadIdx.x; q < b1; q += 16ull * 256) {
-        while (j + 1 < njobs && out_off[j + 1] <= q) j++;
-        const uint64_t jend = j + 1 < njobs ? out_off[j + 1] : total;      // job j's bytes end here
-        if (q + 16 <= b1 && q + 16 <= jend) {
-            const uint16_t *sp = sym + jbase[j] + (q - out_off[j]);
-            uint4 s0, s1;
-            __builtin_memcpy(&s0, sp, 16); __builtin_memcpy(&s1, sp + 8, 16);
-            uint32_t w[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            if (((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) & 0x80008000u) != 0) {
-                const uint8_t *win = wins + (uint64_t)j * 32768;          // window in front of job j = W_{j-1}
+    const uint64_t c0 = (uint64_t)(blockIdx.x - m.blk0) * CONV_BLOCK;
+    if (c0 >= total) return;
+    const uint64_t c1 = c0 + CONV_BLOCK < total ? c0 + CONV_BLOCK : total;
+    uint32_t lo = 0, hi = njobs;                                   // last job with out_off <= c0
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (out_off[mid] <= c0) lo = mid; else hi = mid; }
+    uint32_t staged = ~0u;                                         // the job whose window is in s_win
+    for (uint64_t b0 = c0; b0 < c1; b0 += 16384) {                 // (every condition on b0, b1, lo is the workgroup's: the barriers below are met by all)
+        const uint64_t b1 = b0 + 16384 < c1 ? b0 + 16384 : c1;
+        while (lo + 1 < njobs && out_off[lo + 1] <= b0) lo++;
+        if (b1 - b0 == 16384 && (lo + 1 >= njobs || out_off[lo + 1] >= b1)) {
+            const uint16_t *sp0 = sym + jbase[lo] + (b0 - out_off[lo]) + 16u * threadIdx.x;
+            uint4 s[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    uint32_t sa = w[k] & 0xFFFFu, sb = w[k] >> 16;
-                    if (sa & 0x8000u) sa = win[sa & 0x7FFFu];
-                    if (sb & 0x8000u) sb = win[sb & 0x7FFFu];
-                    w[k] = sa | (sb << 16);
-                }
+            for (int k = 0; k < 4; k++) { __builtin_memcpy(&s[2 * k], sp0 + 4096 * k, 16); __builtin_memcpy(&s[2 * k + 1], sp0 + 4096 * k + 8, 16); }
+            uint32_t fl = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) fl |= s[k].x | s[k].y | s[k].z | s[k].w;
+            fl &= 0x80008000u;
+            if (__syncthreads_or((int)fl) && staged != lo) {   // (the vote is a barrier: nobody still reads the window staged before)
+                const uint4 *src = (const uint4 *)(wins + (uint64_t)lo * 32768);
+                uint4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = src[threadIdx.x + 256 * k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ((uint4 *)s_win)[threadIdx.x + 256 * k] = v[k];
+                staged = lo;
+                __syncthreads();
             }
-            uint4 o;
-            o.x = (w[0] & 0xFFu) | ((w[0] >> 8) & 0xFF00u) | ((w[1] & 0xFFu) << 16) | ((w[1] << 8) & 0xFF000000u);
-            o.y = (w[2] & 0xFFu) | ((w[2] >> 8) & 0xFF00u) | ((w[3] & 0xFFu) << 16) | ((w[3] << 8) & 0xFF000000u);
-            o.z = (w[4] & 0xFFu) | ((w[4] >> 8) & 0xFF00u) | ((w[5] & 0xFFu) << 16) | ((w[5] << 8) & 0xFF000000u);
-            o.w = (w[6] & 0xFFu) | ((w[6] >> 8) & 0xFF00u) | ((w[7] & 0xFFu) << 16) | ((w[7] << 8) & 0xFF000000u);
-            __builtin_memcpy(out + q, &o, 16);
-        } else {
-            uint32_t jj = j;
-            const uint64_t e = q + 16 < b1 ? q + 16 : b1;
-            for (uint64_t r = q; r < e; r++) {
-                while (jj + 1 < njobs && out_off[jj + 1] <= r) jj++;
-                const uint32_t sv = sym[jbase[jj] + (r - out_off[jj])];
-                out[r] = sv < 0x8000u ? (uint8_t)sv : wins[(uint64_t)jj * 32768 + (sv & 0x7FFF)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t w[8] = {s[2 * k].x, s[2 * k].y, s[2 * k].z, s[2 * k].w, s[2 * k + 1].x, s[2 * k + 1].y, s[2 * k + 1].z, s[2 * k + 1].w};
+                if (((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) & 0x80008000u) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        uint32_t sa = w[i] & 0xFFFFu, sb = w[i] >> 16;
+                        if (sa & 0x8000u) sa = s_win[sa & 0x7FFFu];
+                        if (sb & 0x8000u) sb = s_win[sb & 0x7FFFu];
+                        w[i] = sa | (sb << 16);
+                    }
+                }
+                uint4 o;   // the low bytes of eight pairs of symbols (v_perm_b32: bytes 0 and 2 of the second operand, then of the first)
+                o.x = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u); o.y = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
+                o.z = __builtin_amdgcn_perm(w[5], w[4], 0x06040200u); o.w = __builtin_amdgcn_perm(w[7], w[6], 0x06040200u);
+                __builtin_memcpy(out + b0 + 16u * threadIdx.x + 4096u * k, &o, 16);
+            }
+            continue;
+        }
+        uint32_t j = lo;
+        for (uint64_t q = b0 + 16ull * threadIdx.x; q < b1; q += 16ull * 256) {
+            for (uint64_t r = q; r < (q + 16 < b1 ? q + 16 : b1); r++) {
+                while (j + 1 < njobs && out_off[j + 1] <= r) j++;
+                const uint32_t sv = sym[jbase[j] + (r - out_off[j])];
+                out[r] = sv < 0x8000u ? (uint8_t)sv : wins[(uint64_t)j * 32768 + (sv & 0x7FFF)];
             }
         }
     }
