@@ -189,6 +189,8 @@ szl_engine *szl_engine_create(void) {
 void szl_engine_destroy(szl_engine *e) {
     if (!e) return;
     e->io_a.release(); e->io_b.release(); e->io_c.release(); e->io_d.release();
+    if (e->st_a) (void)hipStreamDestroy(e->st_a);
+    if (e->st_b) (void)hipStreamDestroy(e->st_b);
     delete e;
 }
 
@@ -864,6 +866,14 @@ struct szl_deflater {
     uint64_t l0_dict = 0;           // bytes of preset dictionary in front of the stream (window positions, not TotalIn)
     PinVec outq;                    // compressed bytes not yet handed out (pinned: filled by DMA)
     size_t outpos = 0;
+    // The bytes of a Finish() come back in pieces (run_segment): outq has its final size at once, out_pieces names the pieces still on
+    // their way, in order (end offset in outq, the event behind the piece's copy), out_confirmed the prefix known to have arrived.
+    // Deflate() / DeflateView() hand out what is there and wait for the next piece only when nothing is (out_ready): the caller's copy —
+    // or his write to the base stream — runs beside the DMA, 13 ms per GiB of text that used to be spent before the first byte was offered.
+    struct OutPiece { size_t end; hipEvent_t ev; };
+    std::deque<OutPiece> out_pieces;
+    size_t out_confirmed = 0;
+    std::vector<hipEvent_t> out_events;   // spare events
     uint32_t carry_bits = 0; uint8_t carry_byte = 0;
     // PendingBuffer.Reset() clears bitCount but not `bits` (C/PendingBuffer.cs:43): what an unfinished stream left in the bit buffer
     // is OR'ed into the first byte the next stream writes bit by bit (WriteBits :168-189, AlignToByte :143-155).  Survives
@@ -896,9 +906,11 @@ struct szl_deflater {
         std::condition_variable cv;
         bool started = false, stop = false, failed = false;
         uint64_t avail = 0;             // pending bytes whose upload has been queued on up_stream
+        struct Mark { uint64_t upto; hipEvent_t ev; };   // an upload that ends at pending byte `upto` and the event behind it: a part waits for the first
+        std::deque<Mark> marks;                           // mark that covers what it reads, not for everything the caller has queued since (mu)
+        std::vector<hipEvent_t> spare_events;             // (mu)
         int64_t exit = 0;               // the next part enters the parse here (buffer position)
         uint64_t ntok = 0; uint32_t parts = 0;
-        DevBuf toks;                    // the parts' tokens so far (device)
         LevelParams P{};
         int device = 0;
         hipStream_t st = nullptr;       // the parts' kernels: a stream of their own (a wait on the null stream stalls the caller's uploads: 20 -> 200 ms of Write() per GiB)
@@ -925,15 +937,25 @@ szl_deflater *szl_deflater_create(int level, int nowrap) {
     d->eng = engine_take();
     if (!d->eng) { delete d; return nullptr; }
     std::swap(d->d_in, d->eng->io_a); std::swap(d->d_out, d->eng->io_b);   // (the last owner's device buffers come with a pooled engine)
+    d->up_stream = d->eng->st_a; d->eng->st_a = nullptr; d->pipe.st = d->eng->st_b; d->eng->st_b = nullptr;   // (... and its streams)
     d->level = level; d->nowrap = nowrap ? 1 : 0;
     deflater_clear(d);
     object_born();
     return d;
 }
+static void out_drain(szl_deflater *d);
 void szl_deflater_destroy(szl_deflater *d) {
     if (!d) return;
     pipe_destroy(d);
-    if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); d->pend.busy = nullptr; (void)hipStreamDestroy(d->up_stream); d->up_stream = nullptr; }   // (the buffers' destructors must not wait on a stream that is gone)
+    out_drain(d);
+    for (hipEvent_t ev : d->out_events) (void)hipEventDestroy(ev);
+    d->out_events.clear(); d->outq.busy = nullptr;
+    if (d->up_stream) {   // (the buffers' destructors must not wait on a stream that is gone; the stream itself stays with the engine)
+        (void)hipStreamSynchronize(d->up_stream); d->pend.busy = nullptr; d->outq.busy = nullptr;
+        if (!d->eng->st_a) d->eng->st_a = d->up_stream; else (void)hipStreamDestroy(d->up_stream);
+        d->up_stream = nullptr;
+    }
+    if (d->pipe.st) { if (!d->eng->st_b) d->eng->st_b = d->pipe.st; else (void)hipStreamDestroy(d->pipe.st); d->pipe.st = nullptr; }   // (synchronised by pipe_destroy's caller below)
     // (nothing of this object is in flight when its engine changes hands: every engine call ends with its stream synchronised, and the
     // uploads' stream was synchronised above)
     std::swap(d->d_in, d->eng->io_a); std::swap(d->d_out, d->eng->io_b);
@@ -986,6 +1008,7 @@ static int reset_stale_bits(szl_deflater *d, uint8_t *out) {
 static int deflater_reset(szl_deflater *d) {
     if (!d) return SZL_E_ARG;
     pipe_stop(d, false);
+    out_drain(d);
     // DeflaterEngine.Reset() does not touch inputBuf / inputOff / inputEnd (C/DeflaterEngine.cs:234-253): input the engine has not taken
     // yet — a SetInput that no Deflate() call has followed — is still there, IsNeedingInput stays false, and the first Deflate() of the
     // next stream compresses those bytes as its beginning.  (Round 4 dropped them: silently different bytes, and a second SetInput
@@ -1080,7 +1103,33 @@ int szl_deflater_set_dictionary(szl_deflater *d, const uint8_t *p, int n) { // C
     return 0;
 }
 // ---- the pipelined first segment (szl_deflater::Pipe) ----------------------------------------------------------------------------------
+// every piece of an asynchronous download has arrived (before anything else touches outq)
+static void out_drain(szl_deflater *d) {
+    for (auto &pc : d->out_pieces) { (void)hipEventSynchronize(pc.ev); d->out_events.push_back(pc.ev); }
+    d->out_pieces.clear();
+}
+// bytes of outq that may be handed out; `block`: wait for the next piece if nothing beyond outpos is there yet
+static size_t out_ready(szl_deflater *d, bool block) {
+    while (!d->out_pieces.empty()) {
+        szl_deflater::OutPiece &pc = d->out_pieces.front();
+        hipError_t q = hipEventQuery(pc.ev);
+        if (q != hipSuccess && block && d->out_confirmed <= d->outpos) q = hipEventSynchronize(pc.ev);
+        if (q != hipSuccess) { if (q != hipErrorNotReady) { (void)hipGetLastError(); (void)hipEventSynchronize(pc.ev); } else break; }
+        d->out_confirmed = pc.end;
+        d->out_events.push_back(pc.ev);
+        d->out_pieces.pop_front();
+    }
+    return d->out_pieces.empty() ? d->outq.size() : d->out_confirmed;
+}
+static double dbg_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static uint64_t pipe_part_bytes() { const int k = knob("SZL_PIPE_PART_KIB", 65536); return k <= 0 ? 0 : (uint64_t)k * 1024 / B_TILE * B_TILE; }
+// the stream's first parts are short — a quarter of a part, then half — so that the device starts on the caller's bytes when 20 MiB of them
+// are there, not 80: the device is what a caller who writes at memcpy speed waits for, and it was idle for the first 8 of his 27 ms per GiB
+static uint64_t pipe_part_bytes(uint32_t k) {
+    const uint64_t part = pipe_part_bytes();
+    if (k >= 2 || knob("SZL_PIPE_RAMP", 1) == 0) return part;
+    return std::max<uint64_t>((part >> (2 - k)) / B_TILE * B_TILE, std::min<uint64_t>(part, (uint64_t)B_TILE));
+}
 enum : int64_t { PIPE_LOOK = C_WIN_HALO + 1024 + MAX_MATCH + 64 };    // bytes a part sees beyond its end (stream_multi_run's LOOK)
 // one part [exit, exit + part) — or, `to_end`, everything up to the segment's end n — on the object's engine; its tokens are appended
 static int pipe_run_part(szl_deflater *d, uint64_t part, uint64_t visible, bool to_end) {
@@ -1096,42 +1145,54 @@ static int pipe_run_part(szl_deflater *d, uint64_t part, uint64_t visible, bool 
     E.part = Engine::PartRun{};
     E.part.active = true; E.part.first = first; E.part.parse_end = pend; E.part.warm_from = -1;
     E.part.force_entry = pp.parts == 0 ? -1 : first;
+    E.part.tok_start = pp.ntok;            // the engine's token buffer gathers the parts' tokens (a copy per part into a buffer of the object's own
+                                           // meant a hipMalloc / hipFree on the worker's path whenever that buffer grew: 15 ms in which no part ran)
     std::vector<SegOut> res;
     const auto t_part = std::chrono::steady_clock::now();
     // (what is left at Flush() / Finish() is ONE window, as long as the window pipeline's own windows are: a part costs ~20 % more per byte
     // than a long launch — tiles that do not fill the last round of CUs, three host round trips — which pays while the caller writes, not after)
     uint64_t window = std::max<uint64_t>(part, B_TILE);
-    if (to_end) window = std::max<uint64_t>(window, std::min<uint64_t>((visible - (uint64_t)first + B_TILE - 1) / B_TILE * B_TILE, (uint64_t)std::max(1, knob("SZL_WINDOW_KIB", 256 * 1024)) * 1024 * 4 / B_TILE * B_TILE));
+    // (... and no longer: the side arrays follow the window, 19 bytes per byte of it, and how much is left at Finish() depends on how far the
+    // worker got — a remainder longer than any before it cost a Finish() 400 ms of hipMalloc / hipFree for 5 GB of tables)
+    if (to_end) window = std::max<uint64_t>(window, std::min<uint64_t>((visible - (uint64_t)first + B_TILE - 1) / B_TILE * B_TILE, (uint64_t)std::max(1, knob("SZL_WINDOW_KIB", 256 * 1024)) * 1024 / B_TILE * B_TILE));
     int rc = E.deflate_windowed((const uint8_t *)d->d_in.p, visible, nullptr, 0, sg, bnds, pp.P, 0, res, pp.st, window);
-    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] part %u [%lld, %lld)%s: %.2f ms wall; device: links %.2f match %.2f parse %.2f\n", pp.parts, (long long)first, (long long)pend, to_end ? " to the end" : "",
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f part %u [%lld, %lld)%s: %.2f ms wall; device: links %.2f match %.2f parse %.2f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), pp.parts, (long long)first, (long long)pend, to_end ? " to the end" : "",
                                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_part).count(), E.timing.links_ms, E.timing.match_ms, E.timing.parse_ms);
     const Engine::PartRun pr = E.part;
     E.part = Engine::PartRun{};
     if (rc) return rc;
     if (pr.entry != first && pp.parts != 0) { set_error("pipelined segment: forced entry not honoured"); return SZL_E_STATE; }
-    if (pr.tok_count) {
-        if ((rc = pp.toks.ensure_keep((pp.ntok + pr.tok_count + 16) * 4, pp.ntok * 4, pp.st))) return rc;
-        if (hipMemcpyAsync((uint32_t *)pp.toks.p + pp.ntok, E.tokens.p, pr.tok_count * 4, hipMemcpyDeviceToDevice, pp.st) != hipSuccess || hipStreamSynchronize(pp.st) != hipSuccess) { set_error("token copy failed"); return SZL_E_DEVICE; }
-    }
     pp.ntok += pr.tok_count; pp.exit = pr.exit; pp.parts++;
     return 0;
 }
 static void pipe_worker(szl_deflater *d) {
     szl_deflater::Pipe &pp = d->pipe;
     if (hipSetDevice(pp.device) != hipSuccess) { std::lock_guard<std::mutex> lk(pp.mu); pp.failed = true; return; }
-    const uint64_t part = pipe_part_bytes();
     for (;;) {
         uint64_t avail;
+        hipEvent_t wait_ev = nullptr;
+        const uint64_t part = pipe_part_bytes(pp.parts);
         {
             std::unique_lock<std::mutex> lk(pp.mu);
             // a part runs when its bytes and the lookahead behind them are there, and a quarter part more (the window pipeline lets no sliver
             // stand: with less behind it the part would be taken as the segment's last)
-            pp.cv.wait(lk, [&]() { return pp.stop || pp.avail >= (uint64_t)pp.exit + part + part / 4 + (uint64_t)PIPE_LOOK; });
+            const uint64_t need = (uint64_t)pp.exit + part + part / 4 + (uint64_t)PIPE_LOOK;
+            pp.cv.wait(lk, [&]() { return pp.stop || pp.avail >= need; });
             if (pp.stop) return;
             avail = pp.avail;
+            // the bytes the part sees end with the first upload that covers what it needs (the caller may be many uploads ahead of the copy
+            // engine: waiting for all of them idled the device for up to 9 ms per part)
+            while (!pp.marks.empty() && pp.marks.front().upto < need) { pp.spare_events.push_back(pp.marks.front().ev); pp.marks.pop_front(); }
+            if (!pp.marks.empty()) { avail = pp.marks.front().upto; wait_ev = pp.marks.front().ev; pp.marks.pop_front(); }
         }
+        const auto tw0 = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> bl(pp.buf_mu);
-        if (hipStreamSynchronize(d->up_stream) != hipSuccess || pipe_run_part(d, part, avail, false) != 0) {
+        const auto tw1 = std::chrono::steady_clock::now();
+        const hipError_t upe = wait_ev ? hipEventSynchronize(wait_ev) : hipStreamSynchronize(d->up_stream);
+        if (wait_ev) { std::lock_guard<std::mutex> lk(pp.mu); pp.spare_events.push_back(wait_ev); }
+        if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f worker woke with avail %llu; buf_mu %.2f ms, upload sync %.2f ms\n", std::chrono::duration<double, std::milli>(tw0.time_since_epoch()).count(), (unsigned long long)avail,
+                                      std::chrono::duration<double, std::milli>(tw1 - tw0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
+        if (upe != hipSuccess || pipe_run_part(d, part, avail, false) != 0) {
             std::lock_guard<std::mutex> lk(pp.mu);
             pp.failed = true;
             return;
@@ -1146,26 +1207,37 @@ static void pipe_stop(szl_deflater *d, bool keep) {
         pp.cv.notify_all();
         if (pp.th.joinable()) pp.th.join();
     }
-    if (!keep || pp.failed) { pp.toks.release(); pp.ntok = 0; pp.exit = 0; pp.parts = 0; pp.failed = pp.failed && keep; }
-    if (!keep) { pp.started = false; pp.stop = false; pp.failed = false; pp.avail = 0; }
+    if (!keep || pp.failed) { pp.ntok = 0; pp.exit = 0; pp.parts = 0; pp.failed = pp.failed && keep; }
+    if (!keep) { pp.started = false; pp.stop = false; pp.failed = false; pp.avail = 0; for (auto &m : pp.marks) pp.spare_events.push_back(m.ev); pp.marks.clear(); }
 }
-static void pipe_destroy(szl_deflater *d) { pipe_stop(d, false); if (d->pipe.st) { (void)hipStreamSynchronize(d->pipe.st); (void)hipStreamDestroy(d->pipe.st); d->pipe.st = nullptr; } }
+static void pipe_destroy(szl_deflater *d) { pipe_stop(d, false); if (d->pipe.st) (void)hipStreamSynchronize(d->pipe.st); for (hipEvent_t ev : d->pipe.spare_events) (void)hipEventDestroy(ev); d->pipe.spare_events.clear(); }   // (the stream goes back to the engine: szl_deflater_destroy)
 static void pipe_feed(szl_deflater *d) {      // after eager_upload: tell the worker, or start it
     szl_deflater::Pipe &pp = d->pipe;
     const uint64_t part = pipe_part_bytes();
     if (!part || d->level < 5 || !d->up_stream || d->up_done == 0) return;
     if (!pp.started) {
         if (!d->hist.empty() || !d->bounds.empty() || d->hist_has_gaps || d->l0_dict || !d->switches.empty() || d->hist_abs != 0) return;   // the stream's first segment only
-        if (d->up_done < 2 * part) return;
+        if (d->up_done < pipe_part_bytes(0u) + pipe_part_bytes(0u) / 4 + (uint64_t)PIPE_LOOK) return;   // (what the first part needs: see pipe_worker)
         if (level_params(d->level, d->strategy, &pp.P) != 0) return;
         (void)hipGetDevice(&pp.device);
         if (!pp.st && hipStreamCreateWithFlags(&pp.st, hipStreamNonBlocking) != hipSuccess) { pp.st = nullptr; (void)hipGetLastError(); return; }
         pp.stop = false; pp.failed = false; pp.exit = 0; pp.ntok = 0; pp.parts = 0; pp.avail = d->up_done;
+        if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f worker starts (up_done %zu)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), (size_t)d->up_done);
         try { pp.th = std::thread(pipe_worker, d); } catch (...) { return; }
         pp.started = true;
         return;
     }
-    { std::lock_guard<std::mutex> lk(pp.mu); pp.avail = d->up_done; }
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        if (d->up_done > pp.avail) {                       // a new upload has been queued: its mark
+            hipEvent_t ev = nullptr;
+            if (!pp.spare_events.empty()) { ev = pp.spare_events.back(); pp.spare_events.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; (void)hipGetLastError(); }
+            if (ev && hipEventRecord(ev, d->up_stream) == hipSuccess) pp.marks.push_back(szl_deflater::Pipe::Mark{(uint64_t)d->up_done, ev});
+            else { if (ev) pp.spare_events.push_back(ev); for (auto &m : pp.marks) pp.spare_events.push_back(m.ev); pp.marks.clear(); }   // (no marks: the worker waits for the stream)
+        }
+        pp.avail = d->up_done;
+    }
     pp.cv.notify_all();
 }
 
@@ -1177,6 +1249,7 @@ static void eager_upload(szl_deflater *d) {
     const size_t H = d->hist.size();
     if (d->up_done && d->up_H != H) d->up_done = 0;                       // (the layout is [history | pending bytes])
     if (!d->up_stream && hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) { d->up_stream = nullptr; (void)hipGetLastError(); return; }
+    if (knob("SZL_DEBUG", 0) && H + d->pend.size() + 64 > d->d_in.cap) fprintf(stderr, "[szl] t=%.2f d_in grows: cap %zu, need %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), d->d_in.cap, H + d->pend.size() + 64);
     if (H + d->pend.size() + 64 > d->d_in.cap && d->pipe.started) {                       // (the worker's part in flight reads d_in: wait for it, then move)
         bool moved;
         { std::lock_guard<std::mutex> bl(d->pipe.buf_mu); moved = d->d_in.ensure_keep(H + d->pend.size() + 64, d->up_done ? H + d->up_done : 0, d->up_stream) == 0; }
@@ -1374,8 +1447,10 @@ static int run_segment(szl_deflater *d, bool finish) {
     const uint64_t H = d->hist.size(), n = d->pend.size();
     const uint64_t in_total = H + n;
     const uint64_t cap = (szl_deflate_bound(n) + 16 + 3) & ~3ull;
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f run_segment: %llu bytes\n", dbg_now_ms(), (unsigned long long)n);
     if ((rc = finish_upload(d, H, n))) return rc;                        // (most of the pending bytes are there already: eager_upload)
     if ((rc = d->d_out.ensure(cap + 64))) return rc;
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f input on the device, output buffer there\n", dbg_now_ms());
     std::vector<SegDev> segs(1);
     std::vector<uint64_t> bnds;
     for (uint64_t b : d->bounds) if (b > d->hist_abs) bnds.push_back(b - d->hist_abs);
@@ -1398,16 +1473,15 @@ static int run_segment(szl_deflater *d, bool finish) {
     d->pipe.last_parts = 0;
     if (d->pipe.started) {   // parts of this segment were parsed while the caller wrote (szl_deflater::Pipe): parse the rest, then stage D over all tokens
         szl_deflater::Pipe &pp = d->pipe;
+        if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f flush: worker stop\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
         pipe_stop(d, true);
         const bool usable = !pp.failed && pp.parts > 0 && H == 0 && sw_pos.empty() && !P.fast && E.fast_hist_in.empty() &&
                             pp.P.good == P.good && pp.P.nice == P.nice && pp.P.max_chain == P.max_chain && pp.P.strategy == P.strategy && (uint64_t)pp.exit < n;
         if (usable && pipe_run_part(d, pipe_part_bytes(), n, true) == 0) {
-            const uint64_t ntok = pp.ntok;
-            E.tokens.release();
-            E.tokens = pp.toks;                            // (DevBuf is a pointer and a capacity: the engine owns the tokens from here)
-            pp.toks = DevBuf{};
+            const uint64_t ntok = pp.ntok;                 // (all in the engine's token buffer, part behind part)
             E.sw_pos_in.clear(); E.sw_P_in.clear();
             rc = E.finish_tokens((const uint8_t *)d->d_in.p, in_total, (uint8_t *)d->d_out.p, s, ntok, want_ck, res, d->up_stream);
+            if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f stage D done\n", dbg_now_ms());
             piped = rc == 0;
             pp.last_parts = piped ? pp.parts : 0;
             if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] pipelined segment: %u parts, %llu tokens, rc %d\n", pp.parts, (unsigned long long)ntok, rc);
@@ -1421,9 +1495,35 @@ static int run_segment(szl_deflater *d, bool finish) {
     const uint64_t bytes = (end_bit + 7) >> 3;
     // the segment's bytes come straight into the output queue (pinned: one DMA, no second host copy)
     const size_t q0 = d->outq.size();
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f segment compressed: %llu bytes\n", dbg_now_ms(), (unsigned long long)bytes);
     d->outq.resize(q0 + (size_t)bytes + 1);
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f output queue has room\n", dbg_now_ms());
     uint8_t *ho = d->outq.data() + q0;
-    if (bytes && hipMemcpy(ho, d->d_out.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    // a Finish() of many megabytes: the first piece now, the rest on its way while the caller takes what is there (szl_deflater::out_pieces)
+    const uint64_t PIECE = (uint64_t)std::max(1, knob("SZL_OUT_PIECE_KIB", 16384)) << 10;
+    uint64_t sync_bytes = bytes;
+    if (finish && d->up_stream && bytes >= 2 * PIECE) sync_bytes = PIECE;
+    if (sync_bytes && hipMemcpy(ho, d->d_out.p, sync_bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+    if (sync_bytes < bytes) {
+        d->out_confirmed = q0 + (size_t)sync_bytes;
+        d->outq.busy = d->up_stream;
+        for (uint64_t at = sync_bytes; at < bytes; at += PIECE) {
+            const uint64_t k = std::min<uint64_t>(PIECE, bytes - at);
+            hipEvent_t ev = nullptr;
+            if (!d->out_events.empty()) { ev = d->out_events.back(); d->out_events.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+            if (!ev || hipMemcpyAsync(ho + at, (const uint8_t *)d->d_out.p + at, k, hipMemcpyDeviceToHost, d->up_stream) != hipSuccess || hipEventRecord(ev, d->up_stream) != hipSuccess) {
+                // (no event / no queue slot: the rest in one synchronous copy)
+                (void)hipGetLastError();
+                if (ev) d->out_events.push_back(ev);
+                out_drain(d);
+                if (hipMemcpy(ho + at, (const uint8_t *)d->d_out.p + at, bytes - at, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); return SZL_E_DEVICE; }
+                break;
+            }
+            d->out_pieces.push_back(szl_deflater::OutPiece{q0 + (size_t)(at + k), ev});
+        }
+    }
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] t=%.2f bytes on the host (%zu pieces on their way)\n", dbg_now_ms(), d->out_pieces.size());
     if (d->carry_bits && bytes) ho[0] |= d->carry_byte;
     if (d->stale && bytes) { ho[0] |= d->stale; d->stale = 0; }
     if (!d->nowrap) d->adler = res[0].adler32;
@@ -1625,7 +1725,7 @@ static int deflater_deflate(szl_deflater *d, uint8_t *out, int length) { // C/De
         d->state = BUSY_STATE | (d->state & (IS_FLUSHING | IS_FINISHING));
     }
     for (;;) {
-        size_t avail = d->outq.size() - d->outpos;
+        size_t avail = out_ready(d, length > 0) - d->outpos;
         size_t k = std::min<size_t>(avail, (size_t)length);
         if (k) { memcpy(out, d->outq.data() + d->outpos, k); d->outpos += k; out += k; length -= (int)k; d->total_out += (int64_t)k; }
         if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }
@@ -1657,7 +1757,7 @@ static int deflater_deflate_view(szl_deflater *d, const uint8_t **p, int64_t *n)
     if (d->state < BUSY_STATE) { uint8_t none; const int rc = deflater_deflate(d, &none, 0); if (rc < 0) return rc; }   // (queues the zlib header, :436-464)
     for (;;) {
         if (d->outpos == d->outq.size()) { d->outq.clear(); d->outpos = 0; }      // (the previous view has been read)
-        const size_t avail = d->outq.size() - d->outpos;
+        const size_t avail = out_ready(d, true) - d->outpos;
         if (avail) { *p = d->outq.data() + d->outpos; *n = (int64_t)avail; d->outpos += avail; d->total_out += (int64_t)avail; return 0; }
         if (d->state == FINISHED_STATE) return 0;
         if (d->state == BUSY_STATE) { uint8_t none; const int rc = deflater_deflate(d, &none, 1); return rc < 0 ? rc : (rc == 0 ? 0 : SZL_E_STATE); }   // "We need more input now": Deflate()'s own bookkeeping; it has nothing to hand out

@@ -213,7 +213,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     // unused regions, one pool for all members of the call (round-4 ADVICE: a set per member was +60 % of staging for a member of 32
     // chunks, and counted against the budget below) — and since the regions asked of it differ (a job a chain repair adds may span
     // megabytes of stored blocks; a job that overran wants four times what it had) it is a heap, not a set of regions of one size
-    uint64_t heap_at = 0, heap_end = 0, spare_cap = 0, jobs_total = 0, members = 0;
+    uint64_t heap_at = 0, heap_end = 0, spare_cap = 0, jobs_total = 0, members = 0, spill_at = 0, spill_end = 0;
     auto heap_take = [&](uint64_t need, uint64_t *at) -> bool { if (heap_end - heap_at < need) return false; *at = heap_at; heap_at += need; return true; };
     for (auto &p : ps) {
         if (!p.alive) continue;
@@ -259,6 +259,8 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         const uint64_t nsp = jobs_total / 8 + 8, nbig = std::max<uint64_t>(2, members / 8);
         const uint64_t heap = std::max<uint64_t>(nsp * spare_cap + nbig * 4 * spare_cap, reg_total / 4);
         heap_at = reg_total; heap_end = reg_total + heap; reg_total += heap;
+        // the upper half of it is the DEVICE's: regions for jobs that outgrow theirs while they run (InfJob.spill_cursor)
+        spill_at = heap_at + heap / 2; spill_end = heap_end; heap_end = spill_at;
     }
     // Staging is sized from the CALLER's out_cap (an upper bound he chose, possibly an untrusted ISIZE trailer): a generous capacity must
     // not turn into gigabytes of device memory, let alone fail the batch.  Above a budget — 64 symbols per compressed byte plus slack, and
@@ -291,7 +293,10 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         // the members' candidate starts on the device: a job that ran over a false one goes on to the next (InfJob.starts)
         std::vector<uint64_t> all_sb; std::vector<size_t> sb_at(ps.size(), 0);
         for (size_t k = 0; k < ps.size(); k++) { sb_at[k] = all_sb.size(); if (ps[k].alive) all_sb.insert(all_sb.end(), ps[k].sb.begin(), ps[k].sb.end()); }
+        const bool spill = pass == 2 && single_pass && spill_end > spill_at && knob("SZL_INF_SPILL", 1) != 0;
+        all_sb.push_back(spill_at);                                   // (the spill cursor, behind the starts)
         { int r0; if ((r0 = E.inf_misc.ensure(all_sb.size() * 8 + 64))) return r0; }
+        uint64_t *d_cursor = (uint64_t *)E.inf_misc.p + (all_sb.size() - 1);
         HIPCHK(hipMemcpyAsync(E.inf_misc.p, all_sb.data(), all_sb.size() * 8, hipMemcpyHostToDevice, st));
         for (size_t q = 0; q < n; q++) {
             const PS &p = ps[which[q].k]; const uint32_t j = which[q].j;
@@ -300,7 +305,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             jb.start_bit = p.sb[j]; jb.stop_bit = j + 1 < p.sb.size() ? p.sb[j + 1] : (p.truncated ? p.trunc_bit : ~0ull);   // (a piece of a stream: the dropped job's start)
             jb.starts = (const uint64_t *)E.inf_misc.p + sb_at[which[q].k] + (j + 1); jb.nstarts = (uint32_t)(p.sb.size() - (j + 1));
             jb.stop_last = p.truncated ? p.trunc_bit : ~0ull;
-            if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.regc[j]; }
+            if (pass == 2 && single_pass) { jb.sym_out = sym + p.reg[j]; jb.out_cap = p.regc[j]; if (spill) { jb.spill_cursor = d_cursor; jb.spill_end = spill_end; jb.sym_base = sym; } }
             else { jb.sym_out = pass == 2 ? sym + p.jbase[j] : nullptr; jb.out_cap = ~0ull >> 2; }
         }
         int r;
@@ -309,7 +314,16 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
         HIPCHK(hipMemsetAsync(E.inf_states.p, 0, n * sizeof(InfState), st));
         launch_inflate_chunks(d_in, (InfJob *)E.inf_jobs.p, (InfState *)E.inf_states.p, (uint32_t)n, pass, st, dense);
         HIPCHK(hipMemcpyAsync(jobs.data(), E.inf_jobs.p, n * sizeof(InfJob), hipMemcpyDeviceToHost, st));
+        uint64_t cur = spill_at;
+        if (spill) HIPCHK(hipMemcpyAsync(&cur, d_cursor, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (spill) {
+            spill_at = std::min(cur, spill_end);
+            for (size_t q = 0; q < n; q++) {                          // regions that moved
+                PS &p = ps[which[q].k]; const uint32_t j = which[q].j;
+                if (jobs[q].sym_out != sym + p.reg[j]) { if (dbg) fprintf(stderr, "[szl] inflate par: job %u moved to a region of %llu symbols while it ran\n", j, (unsigned long long)jobs[q].out_cap); p.reg[j] = (uint64_t)(jobs[q].sym_out - sym); p.regc[j] = jobs[q].out_cap; }
+            }
+        }
         return 0;
     };
     // ---- 2. first pass over every job (count, or symbols straight away) + chain check / repair (per member; the launches are shared)
@@ -347,10 +361,18 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 uint64_t bigger = 0;
                 if (single_pass && c.status == INF_OUTPUT_FULL && heap_take(4 * p.regc[j], &bigger)) {
                     // the job's output outgrew its staging region: again, in one four times as large; everything behind it keeps what it has
+                    if (dbg) fprintf(stderr, "[szl] inflate par: member %zu: job %u of %zu (bits %llu .. %llu) outgrew its region of %llu symbols\n", p.si, j, p.sb.size(), (unsigned long long)p.sb[j],
+                                     (unsigned long long)(j + 1 < p.sb.size() ? p.sb[j + 1] : 0), (unsigned long long)p.regc[j]);
                     nreg.back() = bigger; nregc.back() = 4 * p.regc[j];
                     ncnt.back() = Cnt{}; nhave.back() = 0;
                     ok = false;
-                    for (uint32_t m2 = j + 1; m2 < p.sb.size(); m2++) { nsb.push_back(p.sb[m2]); ncnt.push_back(p.cnt[m2]); nhave.push_back(p.have[m2]); nreg.push_back(p.reg[m2]); nregc.push_back(p.regc[m2]); }
+                    for (uint32_t m2 = j + 1; m2 < p.sb.size(); m2++) {
+                        nsb.push_back(p.sb[m2]); ncnt.push_back(p.cnt[m2]); nhave.push_back(p.have[m2]); nreg.push_back(p.reg[m2]); nregc.push_back(p.regc[m2]);
+                        // ... but for the jobs behind it that outgrew theirs too: all of them again in the SAME pass (one at a time, as the walk
+                        // came to them, an 8 GiB member ran three passes of one job each, a job's 30-50 ms every time: 378 of its 378 - 260 ms)
+                        uint64_t b2 = 0;
+                        if (p.have[m2] && p.cnt[m2].status == INF_OUTPUT_FULL && heap_take(4 * p.regc[m2], &b2)) { nreg.back() = b2; nregc.back() = 4 * p.regc[m2]; ncnt.back() = Cnt{}; nhave.back() = 0; }
+                    }
                     break;
                 }
                 if (c.status != INF_CHUNK_END) {                   // an error on the chain is a real error of the stream —

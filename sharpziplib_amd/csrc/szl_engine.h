@@ -99,6 +99,7 @@ class Engine {
         int64_t warm_from = -1;                // >= 0: warm-up from here
         int64_t force_entry = -1;              // >= 0: start exactly here (no warm-up)
         int64_t entry = 0, exit = 0;           // [out] the part's tokens cover [entry, exit)
+        uint64_t tok_start = 0;                // the part's tokens go to tokens[tok_start ..) (what is in front of them is kept)
         uint64_t tok_count = 0;                // [out]
     } part;
     // Stage D (and the checksums) of one stream whose tokens[0 .. tok_total) are in `tokens`: block positions are recomputed
@@ -111,6 +112,9 @@ class Engine {
     DevBuf tabs;                       // the small host-built tables of a call (segments, tiles, spans, ...) in ONE upload: tab_pin -> tabs
     uint8_t *tab_pin = nullptr; size_t tab_pin_cap = 0;
     uint8_t *pin = nullptr;            // 256 bytes of pinned host memory: few-byte read-backs into pageable memory cost ~1 ms each
+    uint8_t *ring = nullptr; size_t ring_at = 0; hipStream_t ring_st = nullptr;   // mapped pinned staging of h2d_small (szl_engine.hip)
+    int h2d_small(void *dst, const void *src, size_t n, hipStream_t st);
+    int d2h_small(void *pin_dst, const void *src, size_t n, hipStream_t st);
     uint32_t last_par_jobs = 0;        // chunk jobs of the last parallel single-member inflate
     uint64_t last_workspace_bytes = 0; // device bytes held by the side arrays after the last call (parity tap / DESIGN §3)
 
@@ -154,6 +158,8 @@ struct szl_engine {
     szl::Engine e;
     int device = 0;
     szl::DevBuf io_a, io_b, io_c, io_d;   // Deflater: d_in, d_out; Inflater: d_bulk_in, d_bulk_out
+    hipStream_t st_a = nullptr, st_b = nullptr;   // Deflater: its upload stream and its parts' stream, kept with the engine between objects (a stream costs ~5 ms to make:
+                                                  // the first two SetInput calls of every GZipOutputStream paid that)
 };
 namespace szl {
 // A streaming Deflater / Inflater is often short-lived — GZipOutputStream makes a new Deflater per stream (S/GZip/GzipOutputStream.cs:87),

@@ -1,6 +1,7 @@
 // szl_engine.hip — host side of the device pipeline: workspace, work tables, launches, timing.
 // Product code: never includes or links anything from oracle/.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
@@ -137,6 +138,7 @@ size_t checksum_partial_bytes();
 void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint32_t n, hipStream_t st);
 void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st);
 void launch_zero_many(void *const *ptrs, const size_t *bytes, int n, hipStream_t st);
+void launch_copy_small(void *dst, const void *src, size_t bytes, hipStream_t st);
 size_t exscan_tmp_bytes(uint64_t n);
 hipError_t launch_exscan(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, hipStream_t st);
 int zero_piece_bytes();
@@ -318,6 +320,7 @@ void Engine::trim(size_t keep) {
     size_t total = device_bytes();
     for (DevBuf *b : v) { if (total <= keep) break; total -= b->cap; b->release(); }
     if (tab_pin && total + tab_pin_cap > keep) { (void)hipHostFree(tab_pin); tab_pin = nullptr; tab_pin_cap = 0; }   // (the tables' pinned staging comes back with the first call)
+    if (ring && keep == 0) { if (ring_st) (void)hipStreamSynchronize(ring_st); (void)hipHostFree(ring); ring = nullptr; ring_at = 0; ring_st = nullptr; }
 }
 Engine::~Engine() {
     for (DevBuf *b : all_bufs())
@@ -332,13 +335,42 @@ Engine::~Engine() {
     if (side) (void)hipStreamDestroy(side);
     if (pin) (void)hipHostFree(pin);
     if (tab_pin) (void)hipHostFree(tab_pin);
+    if (ring) (void)hipHostFree(ring);
 }
 
-template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t st) {
+// Small tables and structs go to the device — and a few counters come back — through k_copy_small, out of / into a ring of mapped pinned
+// memory: no copy engine, whose queue they would share with the long uploads of a caller who is still writing (szl_kernels_block.hip).
+// Anything longer, misaligned, or with SZL_SMALL_BY_KERNEL=0: hipMemcpyAsync as before.
+int Engine::h2d_small(void *dst, const void *src, size_t n, hipStream_t st) {
+    if (!n) return 0;
+    const size_t RING = 1u << 20;
+    if (n > RING / 4 || (n & 3) || ((uintptr_t)dst & 3) || knob("SZL_SMALL_BY_KERNEL", 1) == 0) {
+        if (hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("H2D table copy failed"); return SZL_E_DEVICE; }
+        return 0;
+    }
+    if (!ring) { if (hipHostMalloc((void **)&ring, RING, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ring = nullptr; set_error("pinned memory for the tables' ring"); return SZL_E_NOMEM; } ring_at = 0; ring_st = st; }
+    const size_t n16 = (n + 15) & ~(size_t)15;
+    if (ring_st != st) { if (ring_st) (void)hipStreamSynchronize(ring_st); ring_st = st; ring_at = 0; }     // (another stream's kernels may still read the ring)
+    if (ring_at + n16 > RING) { if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream"); return SZL_E_DEVICE; } ring_at = 0; }
+    memcpy(ring + ring_at, src, n);
+    launch_copy_small(dst, ring + ring_at, n, st);
+    ring_at += n16;
+    return 0;
+}
+// device -> the engine's pinned page `pin` (read after the stream is synchronised)
+int Engine::d2h_small(void *pin_dst, const void *src, size_t n, hipStream_t st) {
+    if (!n) return 0;
+    if ((n & 3) || ((uintptr_t)src & 3) || ((uintptr_t)pin_dst & 3) || knob("SZL_SMALL_BY_KERNEL", 1) == 0) {
+        if (hipMemcpyAsync(pin_dst, src, n, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("D2H copy failed"); return SZL_E_DEVICE; }
+        return 0;
+    }
+    launch_copy_small(pin_dst, src, n, st);
+    return 0;
+}
+template <typename T> static int upload(Engine &E, DevBuf &b, const std::vector<T> &v, hipStream_t st) {
     int rc = b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
     if (rc) return rc;
-    if (!v.empty()) { hipError_t e = hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("H2D table copy failed: %s", hipGetErrorString(e)); return SZL_E_DEVICE; } }
-    return 0;
+    return v.empty() ? 0 : E.h2d_small(b.p, v.data(), v.size() * sizeof(T), st);
 }
 
 // THE decision "this call goes through the window pipeline" — Engine::deflate takes it, and szl_deflate_batch_host asks the same
@@ -517,7 +549,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     if ((rc = counters.ensure(CNT_WORDS * 8))) return rc;
     if (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) return rc;
     if (!sw_pos_in.empty()) {
-        if ((rc = upload(d_sw_pos, sw_pos_in, st)) || (rc = upload(d_sw_P, sw_P_in, st))) return rc;
+        if ((rc = upload(*this, d_sw_pos, sw_pos_in, st)) || (rc = upload(*this, d_sw_P, sw_P_in, st))) return rc;
         segs[0].sw_pos = (const int64_t *)d_sw_pos.p; segs[0].sw_P = (const LevelParams *)d_sw_P.p;
     }
     const void *d_segs_view = nullptr;
@@ -540,7 +572,8 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             tab_pin_cap = want;
         }
         for (const Part &q : a) if (q.n) memcpy(tab_pin + q.off, q.src, q.n);
-        HIPCHK(hipMemcpyAsync(tabs.p, tab_pin, total, hipMemcpyHostToDevice, st));
+        if (total <= (1u << 18) && knob("SZL_SMALL_BY_KERNEL", 1) != 0) launch_copy_small(tabs.p, tab_pin, total, st);   // (no copy engine: h2d_small)
+        else HIPCHK(hipMemcpyAsync(tabs.p, tab_pin, total, hipMemcpyHostToDevice, st));
         uint8_t *b = (uint8_t *)tabs.p;
         d_segs_view = b + a[0].off; p_bnds = b + a[1].off; p_spans = b + a[2].off; p_tiles = b + a[3].off; p_stripes = b + a[4].off; p_ckoff = b + a[5].off; p_zoff = b + a[6].off;
     }
@@ -596,7 +629,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
         // inserted are in the hash chains (C/DeflaterEngine.cs:697-712); bit q = buffer position q
         std::vector<uint32_t> hf(fast_hist_in);
         hf.resize(((size_t)segs[0].seg_start + 31) / 32 + 1, 0u);
-        if ((rc = upload(hist_flags_dev, hf, st))) return rc;
+        if ((rc = upload(*this, hist_flags_dev, hf, st))) return rc;
         d_hflags = (const uint32_t *)hist_flags_dev.p;
     }
     if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -608,7 +641,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     HIPCHK(hipEventRecord(ev[2], st));
     if (fast) {
         // B+C for DeflateFast: sequential greedy parse, one wavefront per segment (szl_kernels_fast.hip)
-        if ((rc = upload(blk_off, fast_blk_off, st))) return rc;
+        if ((rc = upload(*this, blk_off, fast_blk_off, st))) return rc;
         if (!fast_hist_in.empty() && nseg == 1) // inserted bits of the history (streaming Deflater / preset dictionary)
             HIPCHK(hipMemcpyAsync((uint32_t *)visited.p + segs[0].vis_word_off, fast_hist_in.data(),
                                   std::min<size_t>(fast_hist_in.size(), ((size_t)segs[0].seg_start + 31) / 32) * 4, hipMemcpyHostToDevice, st));
@@ -847,6 +880,9 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
                              uint64_t window) {
     (void)out_total;
     memset(&timing, 0, sizeof timing);
+    const bool dbg_lap = part.active && knob("SZL_DEBUG", 0) > 1;
+    auto lap_t0 = std::chrono::steady_clock::now();
+    auto LAP = [&](const char *w) { if (dbg_lap) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[szl]    lap %-28s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - lap_t0).count()); lap_t0 = t; } };
     for (auto &e : ev) if (!e) HIPCHK(hipEventCreate(&e));
     if (!pin) HIPCHK(hipHostMalloc((void **)&pin, 256, hipHostMallocDefault));
     const int64_t S0 = seg.seg_start, N = seg.seg_end;           // the real segment [S0, N) inside its stream buffer
@@ -867,11 +903,12 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
     if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc))) || (rc = d_so.ensure(2 * sizeof(SegOut))) || (rc = blk_counts.ensure(16)) ||
         (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(CNT_WORDS * 8)) ||
         (want_ck && (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes()))) ||
-        (rc = upload(d_bnds, bnds, st)) || (rc = upload(ckoff, chunk_off, st)) || (rc = upload(d_zoff, zero_off, st)) || (rc = upload(blk_off, fixed_blk_off, st)))
+        (rc = upload(*this, d_bnds, bnds, st)) || (rc = upload(*this, ckoff, chunk_off, st)) || (rc = upload(*this, d_zoff, zero_off, st)) || (rc = upload(*this, blk_off, fixed_blk_off, st)))
         return rc;
+    LAP("whole-stream tables");
     // d_segs: [0] = the real segment (checksums, zeroing, stage D), [1] = the current window's pseudo-segment (stages A-C)
     if ((rc = d_segs.ensure(2 * sizeof(SegDev)))) return rc;
-    HIPCHK(hipMemcpyAsync(d_segs.p, &seg, sizeof seg, hipMemcpyHostToDevice, st));
+    if ((rc = h2d_small(d_segs.p, &seg, sizeof seg, st))) return rc;
     const SegDev *dseg_real = (const SegDev *)d_segs.p, *dseg_win = dseg_real + 1;
     SegOut *dso = (SegOut *)d_so.p;                               // [0] real, [1] window view (token indices are global: tok_first 0)
     unsigned long long *dcnt = (unsigned long long *)counters.p;
@@ -941,7 +978,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         const uint64_t nranges = (wn + range_len - 1) / range_len;
         w.range_cnt = (uint32_t)nranges;
         if (nranges > max_ranges) { set_error("window bookkeeping"); return SZL_E_STATE; }
-        HIPCHK(hipMemcpyAsync((void *)dseg_win, &w, sizeof w, hipMemcpyHostToDevice, st));
+        if ((rc = h2d_small((void *)dseg_win, &w, sizeof w, st))) return rc;
         std::vector<SpanDev> spans;
         std::vector<TileDev> tiles;
         uint64_t span_len = ((uint64_t)(hi - lo) + 511) / 512;
@@ -957,16 +994,18 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         const int form = match_form(P, false);
         const int64_t stripe_len = m3 ? 0 : full_search_len((uint64_t)(wend - e), tile_len, form);
         for (int64_t a = e; stripe_len && a < wend; a += stripe_len) stripes.push_back(TileDev{1, 0, a, (int32_t)std::min<int64_t>(stripe_len, wend - a), 0});
-        if (!stripes.empty() && (rc = upload(d_stripes, stripes, st))) return rc;
+        if (!stripes.empty() && (rc = upload(*this, d_stripes, stripes, st))) return rc;
         // side arrays of this window, addressed with the stream's own indices (pointer minus the window's first index)
         const uint64_t nlink = (uint64_t)(hi - lo), ntab = (uint64_t)(hi - e);
         const size_t mt_stride = (ntab + 63) & ~(size_t)63;
         if ((rc = link.ensure(nlink * 2 + 64)) || (rc = mtab.ensure(mt_stride * 8 + 64)) || (rc = visited.ensure((wn / 32 + 8) * 4)) ||
-            (emit_copy && (rc = spec_tok.ensure(ntab * 4 + 1024))) || (rc = upload(d_spans, spans, st)) || (rc = upload(d_tiles, tiles, st))) return rc;
+            (emit_copy && (rc = spec_tok.ensure(ntab * 4 + 1024))) || (rc = upload(*this, d_spans, spans, st)) || (rc = upload(*this, d_tiles, tiles, st))) return rc;
         uint16_t *lk = (uint16_t *)link.p - (seg.buf_off + (uint64_t)lo);
         const MTab mt = {(uint32_t *)mtab.p - (seg.buf_off + (uint64_t)e), (uint32_t *)mtab.p + mt_stride - (seg.buf_off + (uint64_t)e)};
         uint32_t *stok = emit_copy ? (uint32_t *)spec_tok.p - (seg.buf_off + (uint64_t)e) : nullptr;
-        if ((rc = grow_preserve(tokens, (tok_base + wn + 16) * 4, tok_base * 4, st))) return rc;
+        LAP("window: side arrays");
+        const uint64_t tok0 = is_part ? part.tok_start : 0;        // a part's tokens follow those of the parts before it (same buffer; indices are the part's own)
+        if ((rc = grow_preserve(tokens, (tok0 + tok_base + wn + 16) * 4, (tok0 + tok_base) * 4, st))) return rc;
         HIPCHK(hipMemsetAsync(visited.p, 0, (wn / 32 + 8) * 4, st));
         HIPCHK(hipMemsetAsync(counts.p, 0, (nranges + 2) * 4, st));
         HIPCHK(hipMemsetAsync(counters.p, 0, 8, st));             // counter 0: ranges of THIS window that never merged
@@ -979,7 +1018,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
             uint64_t sampled = 0;
             for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
             HIPCHK(launch_match_lazy(d_in, dseg_real, (const TileDev *)d_tiles.p, (int)((ntiles + step - 1) / step), 0, (int)step, lk, mt, P, dcnt, st));
-            HIPCHK(hipMemcpyAsync(pin + 192, (unsigned long long *)counters.p + 6, 8, hipMemcpyDeviceToHost, st));
+            if ((rc = d2h_small(pin + 192, (unsigned long long *)counters.p + 6, 8, st))) return rc;
             HIPCHK(hipStreamSynchronize(st));
             const unsigned long long ne = *(volatile unsigned long long *)(pin + 192);
             last_pilot_frac = sampled ? (double)ne / (double)sampled : 1.0;
@@ -1014,8 +1053,8 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         // ---- stage C on the window's ranges (as in deflate(); the window is "a segment with history" that starts on a clean iteration)
         launch_spec(d_in, lk, mt, dseg_win, 1, nranges, P, (RangeDev *)ranges.p, (uint32_t *)visited.p, dcnt, stok, st);
         launch_fix(d_in, lk, mt, dseg_win, 1, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt, (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
-        HIPCHK(hipMemcpyAsync(pin, counters.p, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(pin + 8, (unsigned long long *)counters.p + CNT_LINKS_GUARD, 8, hipMemcpyDeviceToHost, st));
+        if ((rc = d2h_small(pin, counters.p, 8, st))) return rc;
+        if ((rc = d2h_small(pin + 8, (unsigned long long *)counters.p + CNT_LINKS_GUARD, 8, st))) return rc;
         HIPCHK(hipStreamSynchronize(st));
         if (*(volatile unsigned long long *)(pin + 8)) return links_guard_tripped();      // (the window's links: see launch_links)
         const unsigned long long nbad = *(volatile unsigned long long *)pin;
@@ -1032,24 +1071,26 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         HIPCHK(launch_exscan((const uint32_t *)counts.p, (uint64_t *)range_tok.p, nranges + 1, cubtmp.p, st));
         hipLaunchKernelGGL(k_add_base, dim3((unsigned)((nranges + 1 + 255) / 256)), dim3(256), 0, st, (uint64_t *)range_tok.p, nranges + 1, tok_base);
         // window's end: the clean iteration the true parse leaves it on, and its token count
-        HIPCHK(hipMemcpyAsync(pin + 64, (RangeDev *)ranges.p + (nranges - 1), sizeof(RangeDev), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(pin + 128, (uint64_t *)range_tok.p + nranges, 8, hipMemcpyDeviceToHost, st));
+        if ((rc = d2h_small(pin + 64, (RangeDev *)ranges.p + (nranges - 1), sizeof(RangeDev), st))) return rc;
+        if ((rc = d2h_small(pin + 128, (uint64_t *)range_tok.p + nranges, 8, st))) return rc;
         HIPCHK(hipStreamSynchronize(st));
         RangeDev lastr;
         memcpy(&lastr, pin + 64, sizeof lastr);
         const uint64_t tok_after = *(volatile uint64_t *)(pin + 128);
+        LAP("window: A-C, counts back");
         // emission view of the window: global token indices; only the stream's very last token closes a block early
         SegOut view{};
         view.tok_first = 0; view.tok_count = last ? tok_after : ~0ull >> 2;
-        HIPCHK(hipMemcpyAsync(dso + 1, &view, sizeof view, hipMemcpyHostToDevice, st));
+        if ((rc = h2d_small(dso + 1, &view, sizeof view, st))) return rc;
         if (emit_copy)
             launch_emit_copy(d_in, lk, mt, dseg_win, 1, nranges, P, (const RangeDev *)ranges.p, (const uint32_t *)visited.p, stok, (const uint64_t *)range_tok.p,
-                             dso + 1, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, st);
+                             dso + 1, (uint32_t *)tokens.p + tok0, (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, st);
         else
-            launch_emit(d_in, lk, mt, dseg_win, 1, nranges, P, (const RangeDev *)ranges.p, (const uint64_t *)range_tok.p, dso + 1, (uint32_t *)tokens.p,
+            launch_emit(d_in, lk, mt, dseg_win, 1, nranges, P, (const RangeDev *)ranges.p, (const uint64_t *)range_tok.p, dso + 1, (uint32_t *)tokens.p + tok0,
                         (const uint64_t *)blk_off.p, (int64_t *)bsp.p, (int64_t *)blp.p, dcnt, st);
         HIPCHK(hipEventRecord(ev[4], st));
         HIPCHK(hipStreamSynchronize(st));
+        LAP("window: emit");
         float a = 0, b = 0, c = 0, pm = 0;
         (void)hipEventElapsedTime(&a, ev[1], ev[2]); (void)hipEventElapsedTime(&pm, ev[2], ev[7]); (void)hipEventElapsedTime(&b, ev[7], ev[3]); (void)hipEventElapsedTime(&c, ev[3], ev[4]);
         ms_links += a; ms_pilot += pm; ms_match += b; ms_parse += c;
@@ -1121,7 +1162,7 @@ int Engine::finish_tokens(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out
     if ((rc = descs.ensure((blk_slots + 1) * sizeof(BlockDesc))) || (rc = d_so.ensure(2 * sizeof(SegOut))) || (rc = blk_counts.ensure(16)) ||
         (rc = bsp.ensure((blk_slots + 1) * 8)) || (rc = blp.ensure((blk_slots + 1) * 8)) || (rc = counters.ensure(CNT_WORDS * 8)) ||
         (rc = ckparts.ensure((nchunks + 1) * checksum_partial_bytes())) || (rc = cubtmp.ensure((blk_slots + 1) * 12 + 256)) ||
-        (rc = upload(ckoff, chunk_off, st)) || (rc = upload(d_zoff, zero_off, st)) || (rc = upload(blk_off, fixed_blk_off, st)) ||
+        (rc = upload(*this, ckoff, chunk_off, st)) || (rc = upload(*this, d_zoff, zero_off, st)) || (rc = upload(*this, blk_off, fixed_blk_off, st)) ||
         (rc = d_segs.ensure(2 * sizeof(SegDev))))
         return rc;
     HIPCHK(hipMemcpyAsync(d_segs.p, &seg, sizeof seg, hipMemcpyHostToDevice, st));
@@ -1160,14 +1201,14 @@ int Engine::finish_tokens(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out
 int Engine::deflate_stored(const uint8_t *d_in, uint8_t *d_out, const std::vector<StoredBlk> &blks, unsigned want_ck, uint64_t ck_off,
                            uint64_t ck_len, uint32_t crc_init, uint32_t adler_init, uint32_t *crc_out, uint32_t *adler_out, hipStream_t st) {
     int rc;
-    if ((rc = upload(d_stored, blks, st))) return rc;
+    if ((rc = upload(*this, d_stored, blks, st))) return rc;
     launch_stored(d_in, d_out, (const StoredBlk *)d_stored.p, (uint32_t)blks.size(), st);
     if (want_ck) {
         std::vector<SegDev> segs(1);
         segs[0] = SegDev{};
         segs[0].buf_off = ck_off; segs[0].seg_start = 0; segs[0].seg_end = (int64_t)ck_len; segs[0].crc_init = crc_init; segs[0].adler_init = adler_init;
         std::vector<uint64_t> coff{0, (ck_len + 4095) / 4096};
-        if ((rc = upload(d_segs, segs, st)) || (rc = upload(ckoff, coff, st)) || (rc = ckparts.ensure((coff[1] + 1) * checksum_partial_bytes())) ||
+        if ((rc = upload(*this, d_segs, segs, st)) || (rc = upload(*this, ckoff, coff, st)) || (rc = ckparts.ensure((coff[1] + 1) * checksum_partial_bytes())) ||
             (rc = d_so.ensure(sizeof(SegOut)))) return rc;
         launch_checksums(d_in, (const SegDev *)d_segs.p, 1, (const uint64_t *)ckoff.p, coff[1], ckparts.p, (SegOut *)d_so.p, want_ck, st);
         SegOut so{};

@@ -42,6 +42,10 @@ struct InfJob {
     // that the member merely carries as its payload — goes on to the next candidate at or behind that boundary instead of ending where
     // nobody starts (each such end used to cost a repair pass of its own, and a member with more than five of them the whole parallel path)
     const uint64_t *starts; uint64_t stop_last; uint32_t nstarts; uint32_t pad0;
+    // symbol pass, single-pass form: a job whose output outgrows its staging region takes one four times as long from the call's spill area —
+    // symbols [*spill_cursor, spill_end) of sym_base, handed out by atomic add —, moves what it has there and goes on; sym_out / out_cap
+    // come back changed.  (The host used to run such a job again in a pass of its own: one job's 30-50 ms with the device idle.)
+    uint64_t *spill_cursor; uint64_t spill_end; uint16_t *sym_base;
     uint32_t in_more;        // 1: the caller holds more input behind in_len (the streaming object uploads a bounded prefix per step): where the
                              // reference's GetSymbol would look at bits past in_len the decoder stops with INF_NEED_INPUT instead of applying the
                              // "fewer than 9 bits left: an empty slot reads as symbol 0, 0 bits" rule, which is for the END of the input only

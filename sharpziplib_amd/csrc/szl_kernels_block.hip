@@ -726,6 +726,19 @@ __global__ __launch_bounds__(256) void k_zero_regions(const SegDev *__restrict__
 // Several small arrays zeroed by ONE launch (a call of the streaming object clears five: each memset of its own is a kernel and a
 // gap of ~6 us on the stream; a 64 KiB entry's call spent more time between kernels than in stage B).  Sizes in 4-byte words.
 struct ZeroMany { uint32_t *p[6]; uint32_t words[6]; int n; };
+// A few bytes between mapped pinned host memory and device memory, either way, WITHOUT the copy engine (szl_engine.hip, copy_small): the
+// engine's queue is one per direction for the whole process, and a table of a streaming Deflater's part waited there behind every 16 MiB
+// upload the caller had in flight — three host round trips of a 3.9 ms part took 35 ms when the caller wrote faster than PCIe carries.
+__global__ __launch_bounds__(256) void k_copy_small(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t nwords) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nwords) dst[i] = src[i];
+    __threadfence_system();
+}
+void launch_copy_small(void *dst, const void *src, size_t bytes, hipStream_t st) {   // 4-byte aligned, bytes % 4 == 0
+    const uint32_t nw = (uint32_t)(bytes / 4);
+    if (nw) hipLaunchKernelGGL(k_copy_small, dim3((nw + 255) / 256), dim3(256), 0, st, (uint32_t *)dst, (const uint32_t *)src, nw);
+}
+
 __global__ __launch_bounds__(256) void k_zero_many(ZeroMany z) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     for (int k = 0; k < z.n; k++) {
@@ -808,18 +821,33 @@ __global__ __launch_bounds__(256) void k_block_tok_sums(const uint32_t *__restri
         lastlen[b] = t1 > t0 ? ((t >> 16) ? (t & 0xFFFFu) : 1u) : 0u;
     }
 }
-__global__ void k_block_positions(const uint64_t *__restrict__ sums, const uint32_t *__restrict__ lastlen, uint64_t nblk, int64_t seg_start,
-                                  int64_t *__restrict__ bsp, int64_t *__restrict__ blp) {
-    if (blockIdx.x || threadIdx.x) return;
-    int64_t pos = seg_start;
-    for (uint64_t b = 0; b < nblk; b++) { bsp[b] = pos; blp[b] = pos + (int64_t)sums[b] - (int64_t)lastlen[b]; pos += (int64_t)sums[b]; }
+// (one workgroup: a thread sums a run of consecutive blocks, the runs' totals are scanned in LDS — one thread walking the 14000 blocks of
+// a 1 GiB stream with a global round trip each was 1.6 ms of every Finish())
+__global__ __launch_bounds__(1024) void k_block_positions(const uint64_t *__restrict__ sums, const uint32_t *__restrict__ lastlen, uint64_t nblk, int64_t seg_start,
+                                                          int64_t *__restrict__ bsp, int64_t *__restrict__ blp) {
+    __shared__ int64_t s_tot[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (nblk + 1023) / 1024;
+    const uint64_t b0 = (uint64_t)tid * per < nblk ? (uint64_t)tid * per : nblk, b1 = b0 + per < nblk ? b0 + per : nblk;
+    int64_t acc = 0;
+    for (uint64_t b = b0; b < b1; b++) acc += (int64_t)sums[b];
+    s_tot[tid] = acc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {          // inclusive scan
+        const int64_t v = tid >= o ? s_tot[tid - o] : 0;
+        __syncthreads();
+        s_tot[tid] += v;
+        __syncthreads();
+    }
+    int64_t pos = seg_start + s_tot[tid] - acc;
+    for (uint64_t b = b0; b < b1; b++) { bsp[b] = pos; blp[b] = pos + (int64_t)sums[b] - (int64_t)lastlen[b]; pos += (int64_t)sums[b]; }
 }
 void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_start, uint64_t *sums, uint32_t *lastlen, int64_t *bsp, int64_t *blp,
                             hipStream_t st) {
     const uint64_t nblk = (ntok + BLOCK_TOKENS - 1) / BLOCK_TOKENS;
     if (!nblk) return;
     hipLaunchKernelGGL(k_block_tok_sums, dim3((unsigned)nblk), dim3(256), 0, st, tokens, ntok, sums, lastlen);
-    hipLaunchKernelGGL(k_block_positions, dim3(1), dim3(1), 0, st, sums, lastlen, nblk, seg_start, bsp, blp);
+    hipLaunchKernelGGL(k_block_positions, dim3(1), dim3(1024), 0, st, sums, lastlen, nblk, seg_start, bsp, blp);
 }
 
 } // namespace szl

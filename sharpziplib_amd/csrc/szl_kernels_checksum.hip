@@ -115,6 +115,7 @@ __global__ __launch_bounds__(CK_THREADS) void k_ck_fold(const SegDev *__restrict
     __shared__ uint32_t s_crc[CK_THREADS];
     __shared__ uint64_t s_len[CK_THREADS];
     __shared__ unsigned long long s_s1, s_s2;
+    __shared__ uint32_t s_mt[4][256];
     uint32_t si = blockIdx.x;
     if (si >= nseg) return;
     const SegDev s = segs[si];
@@ -141,11 +142,17 @@ __global__ __launch_bounds__(CK_THREADS) void k_ck_fold(const SegDev *__restrict
     if (want & 1) {
         uint64_t per = (nc + CK_THREADS - 1) / CK_THREADS;
         uint64_t j0 = (uint64_t)tid * per, j1 = j0 + per < nc ? j0 + per : nc;
+        // every full chunk is folded with the same operator, x^(8 * CK_CHUNK): the product with a CONSTANT is linear in the other factor,
+        // so it is four table look-ups (the operator times every byte value at every byte position) instead of multmodp's 32 rounds — the
+        // fold of a 1 GiB segment, 1024 chunks to a thread, took 3.5 ms with the whole device idle but for this one workgroup
         const uint32_t opfull = x2nmodp(CK_CHUNK, 3);
+        for (int i = tid; i < 1024; i += CK_THREADS) s_mt[i >> 8][i & 255] = multmodp(opfull, (uint32_t)(i & 255) << (8 * (i >> 8)));
+        __syncthreads();
         for (uint64_t j = j0; j < j1; j++) {
             CkPartial p = parts[c0 + j];
-            uint32_t op = p.len == CK_CHUNK ? opfull : x2nmodp(p.len, 3);
-            mycrc = mylen ? (multmodp(op, mycrc) ^ p.crc) : p.crc;
+            if (!mylen) mycrc = p.crc;
+            else if (p.len == CK_CHUNK) mycrc = s_mt[0][mycrc & 0xFF] ^ s_mt[1][(mycrc >> 8) & 0xFF] ^ s_mt[2][(mycrc >> 16) & 0xFF] ^ s_mt[3][mycrc >> 24] ^ p.crc;
+            else mycrc = multmodp(x2nmodp(p.len, 3), mycrc) ^ p.crc;
             mylen += p.len;
         }
     }

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
     uint32_t sidx = 0, moves = 0;
     const uint32_t pend_len = 0, pend_dist = 0; // a token that does not fit is simply not consumed
     const uint64_t out_start = outpos;             // stream position of out[0] for this call
-    const uint64_t out_limit = PMODE == 1 ? ~0ull >> 1 : outpos + job.out_cap;   // (symbol pass: the job's staging region)
+    uint64_t out_limit = PMODE == 1 ? ~0ull >> 1 : outpos + job.out_cap;         // (symbol pass: the job's staging region — which may grow: EV_STOP)
     uint64_t flushed = outpos;
     int status = INF_RUNNING;
 
@@ -924,6 +924,22 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
             sbase = ~0ull; // force a restage at the new position
         } break;
         case EV_STOP:
+            if (PMODE == 2 && ea == INF_OUTPUT_FULL && job.spill_cursor) {
+                // the staging region is full: a larger one from the spill area (InfJob.spill_cursor), the symbols so far moved there, and on
+                const uint64_t want = 4 * job.out_cap;
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd((unsigned long long *)job.spill_cursor, (unsigned long long)want);
+                at = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                if (at + want <= job.spill_end) {
+                    flush(outpos);                                          // (what the window holds fits the old region: the token that did not was not queued)
+                    uint16_t *nd = job.sym_base + at;
+                    const uint64_t have = outpos - out_start;
+                    for (uint64_t i = lane; i < have; i += 64) nd[i] = job.sym_out[i];
+                    job.sym_out = nd; job.out_cap = want; out_limit = out_start + want;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (far reads of this wavefront come from the new region, as behind flush())
+                    break;
+                }
+            }
             status = ea;
             break;
         default: break;
@@ -960,6 +976,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
         jobs[ji].status = status;
         jobs[ji].consumed = (bitpos + 7) >> 3 > job.in_len ? job.in_len : (bitpos + 7) >> 3;   // (exact-table mode can drop bits past the input's end, like the reference)
         jobs[ji].end_bit = bitpos;
+        if (PMODE == 2) { jobs[ji].sym_out = job.sym_out; jobs[ji].out_cap = job.out_cap; }   // (the region may have moved: EV_STOP)
         jobs[ji].dbg_rounds = dbg_rounds; jobs[ji].dbg_par = dbg_par; jobs[ji].dbg_partok = dbg_partok;
     }
 }

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_resolve_wins(const uint16_t *__restric
 // hundreds of KiB): a thread then issues all eight of its loads before it looks at any of them.
 // Symbols that name the window in front of their job (0x8000 | i) — a tenth of a text member's, but some in most groups of sixteen —
 // were looked up with a byte load from global memory each: 1.0 of the kernel's 1.6 ms per GiB went there, whether the loads waited for
-// each other or were issued together (round 6, profiles/r06/inflate_convert.log: the texture path takes a wave's 64 byte addresses as 64
+// each other or were issued together (round 6, profiles/r06/inflate_finder_convert.log: the texture path takes a wave's 64 byte addresses as 64
 // accesses).  Now the first 16 KiB of a workgroup that meet such a symbol copy the job's 32 KiB window into LDS, and the look-ups are
 // ds_read_u8.  The 16 KiB that straddle two jobs or end the member go symbol by symbol as before.
 __global__ __launch_bounds__(256) void k_convert(const uint16_t *__restrict__ sym, const uint64_t *__restrict__ ooff_all,

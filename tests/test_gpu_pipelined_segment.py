@@ -32,7 +32,7 @@ def _drain(d, buf):
     ("logs", 9, 6 << 20, 1 << 20, 512),
     ("enwik", 5, 5 << 20, 123457, 256),               # many small parts
     ("mixed", 7, 6 << 20, 2 << 20, 1024),             # stretches of zeros / periodic bytes: ranges that never merge inside a part
-    ("enwik", 6, 3 << 20, 1 << 20, 4096),             # never enough bytes for a part: the plain path
+    ("enwik", 6, 3 << 20, 1 << 20, 16384),            # never enough bytes for a part (the first is a quarter of SZL_PIPE_PART_KIB): the plain path
 ])
 def test_pipelined_first_segment_equals_the_oracle(kind, level, total, write, part_kib):
     from sharpziplib_amd.deflater import Deflater
