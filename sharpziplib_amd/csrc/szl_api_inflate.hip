@@ -136,8 +136,16 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     // wavefronts to a SIMD, ten chunk jobs to a CU: a 1 GiB text member 34.9 -> 30.9 ms.  Several members together and the pieces of a
     // stream do not (they lose up to 50 % that way: szl_kernels_inflate.hip), nor does data that expands 15 times (a 1 GiB log member:
     // 14.0 -> 16.0 ms — its time is in the copies, which gain nothing from a third wavefront and lose registers to it)
-    const bool dense = cand.size() == 1 && streams[cand[0]].in_len >= (128ull << 20) && streams[cand[0]].out_cap / 6 <= streams[cand[0]].in_len &&
-                       knob("SZL_INF_DENSE_ONE", 1) != 0;
+    bool dense = cand.size() == 1 && streams[cand[0]].in_len >= (128ull << 20) && streams[cand[0]].out_cap / 6 <= streams[cand[0]].in_len &&
+                 knob("SZL_INF_DENSE_ONE", 1) != 0;
+    // ... and so does a call of many members once it is many rounds of the slots (SZL_INF_DENSE_MANY: MiB of compressed bytes, 0 = never):
+    // 256 x 4 MiB members 46.5 -> 41.8 ms, 1024 of them 162 -> 142, 64 x 16 MiB 37.9 -> 35.4; 128 x 4 MiB — two rounds of 2048 slots — lose
+    // 5 % and stay as they were (profiles/r06/inflate_dense_many.log)
+    if (cand.size() > 1 && knob("SZL_INF_DENSE_MANY", 256) != 0) {
+        uint64_t ti = 0, to = 0;
+        for (size_t ci : cand) { ti += streams[ci].in_len; to += streams[ci].out_cap; }
+        dense = ti >= (uint64_t)knob("SZL_INF_DENSE_MANY", 256) << 20 && to / 6 <= ti;
+    }
     const uint64_t slots = (uint64_t)inflate_slots_per_cu(dense) * (uint64_t)cus;
     const bool auto_size = knob("SZL_INF_CHUNK_KIB", 0) == 0;
     std::vector<uint64_t> in_lens;

@@ -134,19 +134,30 @@ __device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, in
                            unsigned char *length /*[numSymbols]*/, int *bl_counts /*[15]*/, int *numCodesOut, int lane) {
     int *heap = S->heap, *hval = S->hval, *values = S->values;
     short *childs = S->childs;
-    int heapLen = 0;
-    if (lane == 0) {                                                // :205-241, the reference's loops
-        int maxCode = 0;
-        for (int n = 0; n < numSymbols; n++) {
-            int freq = freqs[n];
-            if (freq != 0) {
-                int pos = heapLen++;
-                int ppos;
-                while (pos > 0 && freqs[heap[ppos = (pos - 1) / 2]] > freq) { heap[pos] = heap[ppos]; pos = ppos; }
-                heap[pos] = n;
-                maxCode = n;
-            }
+    int heapLen = 0, maxCode = 0;
+    // :205-241 — the leaves enter the heap one after the other, in symbol order, each sifted UP from the end of the array.  The nodes it may
+    // pass are its ancestors, whose positions follow from its own: lane k reads the ancestor k levels up (one round trip for all of them),
+    // the ones with a larger frequency — the lower end of the path, by the heap's own order — each move down a level and the leaf takes the
+    // place of the topmost.  (One lane walking up level by level, two dependent LDS reads a level, was 90 of a literal tree's 300 us.)
+    for (int base = 0; base < numSymbols; base += 64) {
+        const int myf = base + lane < numSymbols ? freqs[base + lane] : 0;
+        for (unsigned long long nz = __ballot(myf != 0); nz; nz &= nz - 1) {
+            const int b = __builtin_ctzll(nz);
+            const int freq = __builtin_amdgcn_readlane(myf, b);
+            const int code = heapLen + 1;                           // position + 1: the ancestors' are its right shifts
+            heapLen++;
+            const bool valid = lane >= 1 && lane < 31 && (code >> lane) >= 1;
+            const int anc = valid ? (code >> lane) - 1 : 0;
+            const int av = valid ? hval[anc] : 0, an = valid ? heap[anc] : 0;
+            const bool gt = valid && av > freq;                     // :219 "freqs[heap[ppos]] > freq"
+            const int cnt = __popcll(__ballot(gt));
+            if (gt) { const int to = (code >> (lane - 1)) - 1; heap[to] = an; hval[to] = av; }
+            if (lane == 0) { const int at = (code >> cnt) - 1; heap[at] = base + b; hval[at] = freq; }
+            maxCode = base + b;
+            wave_sync();
         }
+    }
+    if (lane == 0) {
         while (heapLen < 2) {
             int node = maxCode < 2 ? ++maxCode : 0;
             heap[heapLen++] = node;
