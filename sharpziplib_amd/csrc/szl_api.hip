@@ -1171,9 +1171,14 @@ static void pipe_worker(szl_deflater *d) {
     for (;;) {
         uint64_t avail;
         hipEvent_t wait_ev = nullptr;
-        const uint64_t part = pipe_part_bytes(pp.parts);
+        uint64_t part = pipe_part_bytes(pp.parts);
         {
             std::unique_lock<std::mutex> lk(pp.mu);
+            // a caller who is far ahead (he copies at memcpy speed, the device compresses at half of that) gets longer parts: two, then four
+            // times the length — a 64 MiB part is twelve rounds of tiles, the last a fifth full, and three host round trips; 256 MiB is one
+            // window of the pipeline as it runs for a resident stream
+            if (pp.parts >= 2 && knob("SZL_PIPE_GROW", 1) != 0)
+                for (int g = 0; g < 2 && pp.avail >= (uint64_t)pp.exit + 2 * part + part / 2 + (uint64_t)PIPE_LOOK; g++) part *= 2;
             // a part runs when its bytes and the lookahead behind them are there, and a quarter part more (the window pipeline lets no sliver
             // stand: with less behind it the part would be taken as the segment's last)
             const uint64_t need = (uint64_t)pp.exit + part + part / 4 + (uint64_t)PIPE_LOOK;

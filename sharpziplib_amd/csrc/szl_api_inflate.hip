@@ -395,7 +395,14 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                     // the byte behind them, so where the block before it ends in zero bits the finder's FIRST hit lies in front of the
                     // true boundary.  A decode from there reads the same type, skips to the same byte and is the same decode: that job IS
                     // the one that starts where this one ended.
-                    if (std::binary_search(p.stored.begin(), p.stored.end(), p.sb[m]) && ((p.sb[m] + 10) >> 3) == ((c.end_bit + 10) >> 3)) { same = true; break; }
+                    if (std::binary_search(p.stored.begin(), p.stored.end(), p.sb[m]) && ((p.sb[m] + 10) >> 3) == ((c.end_bit + 10) >> 3)) {
+                        // (... unless the TRUE header's first bit, BFINAL, is set: the job that started early read a zero in front of it and
+                        // would take the member's last block for one with a successor — round-5 ADVICE.  A byte of the input, read here.)
+                        uint8_t hb = 0;
+                        const uint64_t at = streams[p.si].in_off + (c.end_bit >> 3);
+                        if ((c.end_bit >> 3) < streams[p.si].in_len && hipMemcpy(&hb, d_in + at, 1, hipMemcpyDeviceToHost) == hipSuccess && ((hb >> (c.end_bit & 7)) & 1u) == 0) same = true;
+                        break;
+                    }
                     m++;
                 }
                 if (same || (m < p.sb.size() && p.sb[m] == c.end_bit)) { j = m; continue; }
@@ -812,6 +819,7 @@ struct szl_inflater {
     // evaluated when asked for, on the device; nothing is copied per Inflate() call.  `*_dec` run over everything decoded so far, piece by
     // piece on the device, and become the base whenever `pend` has been drained (decoded == handed out at that moment).
     uint32_t adler_base = 1, crc_base = 0;
+    mutable size_t ck_pos[2] = {0, 0}; mutable uint32_t ck_val[2] = {0, 1};   // handed_out_checksum's last answer: the CRC-32 / Adler-32 continued over pend[0 .. ck_pos) (ck_pos 0: the base)
     uint32_t adler_dec = 1, crc_dec = 0;
     bool want_crc = false;         // szl_inflater_enable_crc32
     size_t hin_pos = 0;            // bytes at the front of hin that are consumed already (dropped in bulk, not per step)
@@ -866,7 +874,7 @@ static void inflater_clear(szl_inflater *s) {
     s->hin.clear(); s->hin_pos = 0; s->given = 0; s->in_base = 0; s->pend.clear(); s->pend_pos = 0; s->total_out = 0;
     s->st = InfState{};
     s->st.mode = s->no_header ? INF_M_HEADER : INF_M_ZHEADER;
-    s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler_base = 1; s->adler_dec = 1; s->crc_base = 0; s->crc_dec = 0;
+    s->dec_status = INF_NEED_INPUT; s->err = 0; s->fresh_input = false; s->have_dict = false; s->adler_base = 1; s->adler_dec = 1; s->crc_base = 0; s->crc_dec = 0; s->ck_pos[0] = s->ck_pos[1] = 0;
     s->bulk_skip_given = 0; s->exact_live = false; s->tail_deferred = false; s->odd_starts.clear();
     s->expect_more = false;        // (the hint belongs to the stream that gave it: a pooled Inflater's next user may never give one)
 }
@@ -918,11 +926,18 @@ int64_t szl_inflater_total_in(const szl_inflater *s) { return s ? (int64_t)s->gi
 int64_t szl_inflater_total_out(const szl_inflater *s) { return s ? s->total_out : 0; }
 // checksum of the bytes handed out so far: the base continued over the handed-out front of `pend` (which == 1: CRC-32, 2: Adler-32)
 static uint32_t handed_out_checksum(const szl_inflater *s, unsigned which) {
+    // (continued from the last answer: a caller who asks after every small Inflate() — the reference's getter is O(1) — used to pay an upload
+    // and a pass over everything handed out of the piece so far, each time)
+    const int c = which == 1 ? 0 : 1;
+    size_t from = 0;
     uint32_t v = which == 1 ? s->crc_base : s->adler_base;
-    if (s->pend_pos) {
+    if (s->ck_pos[c] && s->ck_pos[c] <= s->pend_pos) { from = s->ck_pos[c]; v = s->ck_val[c]; }
+    if (s->pend_pos > from) {
         uint32_t w = v;
-        if ((which == 1 ? szl_crc32(v, s->pend.data(), s->pend_pos, &w) : szl_adler32(v, s->pend.data(), s->pend_pos, &w)) == 0) v = w;
+        if ((which == 1 ? szl_crc32(v, s->pend.data() + from, s->pend_pos - from, &w) : szl_adler32(v, s->pend.data() + from, s->pend_pos - from, &w)) != 0) return v;
+        v = w;
     }
+    s->ck_pos[c] = s->pend_pos; s->ck_val[c] = v;
     return v;
 }
 uint32_t szl_inflater_adler(const szl_inflater *s) { // :823
@@ -941,7 +956,7 @@ uint32_t szl_inflater_crc32(const szl_inflater *s) { return s && s->want_crc ? h
 // `pend` is about to receive a piece: if everything in it has been handed out, drop it — decoded == handed out at this moment, so the
 // running checksums of the decoded bytes become the base of the handed-out ones
 static void pend_recycle(szl_inflater *s) {
-    if (s->pend_pos == s->pend.size()) { s->pend.clear(); s->pend_pos = 0; s->adler_base = s->adler_dec; s->crc_base = s->crc_dec; }
+    if (s->pend_pos == s->pend.size()) { s->pend.clear(); s->pend_pos = 0; s->adler_base = s->adler_dec; s->crc_base = s->crc_dec; s->ck_pos[0] = s->ck_pos[1] = 0; }
 }
 // the piece of `total` bytes at d_p (device) has just been decoded: running checksums of the decoded bytes
 static int checksum_decoded(szl_inflater *s, const uint8_t *d_p, uint64_t total) {

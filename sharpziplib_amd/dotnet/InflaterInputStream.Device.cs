@@ -56,7 +56,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 		}
 
 		// A pinned array the device can read by DMA.  GC.AllocateUninitializedArray(pinned: true) keeps its address for life;
-		// registration tells the HIP runtime about it.  Unregistered by the finalizer — the array itself stays valid for as long
+		// registration tells the HIP runtime about it.  Unregistered by Dispose() (below) — the array itself stays valid for as long
 		// as anybody (an Inflater that still reads it) refers to it, so a late SetInput merely goes through the copying path.
 		private static unsafe byte[] NewBuffer(int size, out bool registered)
 		{
@@ -67,10 +67,22 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			return a;
 		}
 
-		unsafe ~InflaterInputBuffer()
+		// Unregistered by Dispose() only (InflaterInputStream.Dispose calls it), after the Inflater this buffer last fed has let go of the
+		// borrowed pointer.  There is NO finalizer: a finalizer runs on its own thread in no order relative to that Inflater's, and an
+		// unregister there would pull the pages from under a native object that still reads them by DMA (round-5 ADVICE).  A stream that is
+		// dropped without Dispose() leaves its two registrations in place: the arrays live on the pinned object heap, whose memory the
+		// runtime does not return, so the cost is two entries in the HIP runtime's table.
+		private Inflater lastFed;
+		private bool disposed;
+		public unsafe void Dispose()
 		{
+			if (disposed) return;
+			disposed = true;
+			lastFed?.DetachInput();
+			lastFed = null;
 			if (rawPin) fixed (byte* p = rawData) SzlHost.szl_host_unregister(p);
 			if (clearPin) fixed (byte* p = internalClearText) SzlHost.szl_host_unregister(p);
+			rawPin = clearPin = false;
 		}
 
 		public int RawLength => rawLength;                                                      // :47
@@ -84,6 +96,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			if (available > 0)
 			{
 				inflater.SetInput(clearText, clearTextLength - available, available);
+				lastFed = inflater;
 				available = 0;
 				inflater.ExpectMoreInput(rawLength == rawData.Length);   // a buffer filled to the brim promises more (include/szl.h)
 			}
@@ -174,7 +187,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 		private int available;
 		private ICryptoTransform cryptoTransform;
 		private readonly Stream inputStream;
-		private readonly bool rawPin;
+		private bool rawPin;
 		private bool clearPin;
 	}
 
@@ -259,6 +272,7 @@ namespace ICSharpCode.SharpZipLib.Zip.Compression.Streams
 			}
 			// (a pooled Inflater lives on: it must stop referring to this stream's buffer — Inflater.DetachInput, Deflater.Device.cs)
 			inf?.DetachInput();
+			inputBuffer?.Dispose();                                                            // (unregisters its arrays: InflaterInputBuffer.Dispose)
 			if (inf is PooledInflater inflater) InflaterPool.Instance.Return(inflater);
 			inf = null;
 		}
