@@ -390,6 +390,7 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
                 }
                 uint32_t m = j + 1;
                 bool same = false;
+                if (dbg && m < p.sb.size() && p.sb[m] < c.end_bit) fprintf(stderr, "[szl] inflate par: job %u (start bit %llu) ran over the candidate at bit %llu (a false one, %s) and ended at %llu\n", j, (unsigned long long)p.sb[j], (unsigned long long)p.sb[m], std::binary_search(p.stored.begin(), p.stored.end(), p.sb[m]) ? "a stored header" : "a dynamic header", (unsigned long long)c.end_bit);
                 while (m < p.sb.size() && p.sb[m] < c.end_bit) {     // starts the real decode ran over: false candidates —
                     // — but for a stored block's header named a few bits early: its three type bits are zeros and so is the padding to
                     // the byte behind them, so where the block before it ends in zero bits the finder's FIRST hit lies in front of the
@@ -435,7 +436,15 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
             if (single_pass) { p.reg.swap(nreg); p.regc.swap(nregc); }
             if (ok) p.ok = true; else pending = true;
         }
-        if (dbg) fprintf(stderr, "[szl] inflate par: %s pass %d over %zu jobs\n", single_pass ? "symbol" : "count", iter, which.size());
+        if (dbg) {
+            uint64_t omax = 0, osum = 0, rmax = 0, rsum = 0, cmax = 0; size_t jmax = 0;
+            for (size_t q = 0; q < which.size(); q++) {
+                osum += jobs[q].out_written; rsum += jobs[q].dbg_rounds; rmax = std::max<uint64_t>(rmax, jobs[q].dbg_rounds); cmax = std::max<uint64_t>(cmax, jobs[q].dbg_rounds - jobs[q].dbg_par);
+                if (jobs[q].out_written > omax) { omax = jobs[q].out_written; jmax = q; }
+            }
+            fprintf(stderr, "[szl] inflate par: %s pass %d over %zu jobs: output per job mean %llu max %llu (job %zu); decode rounds mean %llu max %llu, most careful-path rounds in one job %llu\n", single_pass ? "symbol" : "count", iter, which.size(),
+                    (unsigned long long)(osum / std::max<size_t>(which.size(), 1)), (unsigned long long)omax, jmax, (unsigned long long)(rsum / std::max<size_t>(which.size(), 1)), (unsigned long long)rmax, (unsigned long long)cmax);
+        }
         if (!pending) break;
     }
     if (single_pass && retry) for (auto &p : ps) if (p.alive && !p.ok) { p.alive = false; retry->push_back(p.si); }   // (out of repair rounds: the count-first form)
