@@ -81,7 +81,7 @@ __device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
         }
         code <<= 1;
     }
-    uint32_t idx = 0, prev = 0, len256 = 0;
+    uint32_t idx = 0, prev = 0, len256 = 0, lastlit = 0;
     const uint32_t total = nl + nd;
     int kl = 0, kd = 0, ndist = 0;                                // Kraft sums in units of 2^-15
     // (the symbols come out of a 64-bit window that is fetched again when fewer than 16 bits of it are left — a symbol takes at most
@@ -110,11 +110,19 @@ __device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
             ndist += (int)(rep - in_lit);
         }
         if (idx <= 256u && 256u < idx + rep) len256 = val;
+        if (idx < nl && nl <= idx + rep) lastlit = val;             // (the length of symbol nl - 1)
         idx += rep;
         prev = val;
         if (kl > 32768 || kd > 32768) return false;               // over-subscribed
     }
     if (len256 == 0) return false;                                 // :113
+    // HLIT / HDIST / HCLEN exist to drop trailing zero lengths, and every encoder uses them so (DeflaterHuffman.BuildCodes: numCodes =
+    // maxCode + 1, :803-810 for the code-length code; zlib's max_code): a header whose last literal/length, distance or code-length entry
+    // is zero is one of the accidents — complete codes in random bits, about one per gigabyte, each of which costs the job in front of it a
+    // second chunk (a zlib-made 1 GiB member: 52 instead of 31 ms).  An encoder that does not trim merely loses that block as a start.
+    if (nl > 257 && lastlit == 0) return false;
+    if (nd > 1 && prev == 0) return false;
+    if (nm > 4 && ((uint32_t)(mw >> (3 * (nm - 1))) & 7u) == 0) return false;
     if (kl != 32768) return false;                                 // complete literal/length code
     if (!(kd == 32768 || ndist <= 1)) return false;               // complete distance code, or the one-code / no-code tree of zlib
     return true;
