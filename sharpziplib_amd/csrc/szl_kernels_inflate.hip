@@ -275,12 +275,16 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         (void)rebuild_tables(); // a resumed block: these lengths were accepted when its header was read (never a set of k_inflate_exact's)
     }
-    // second level of the literal/length code for the wave-parallel decode: lane l holds first | count << 16 and the offset of length l
+    // second level of the literal/length code for the wave-parallel decode.  The codes of a canonical set, left-aligned to 15 bits, lie in
+    // consecutive intervals by length: those of length l in [limit(l - 1), limit(l)), limit(l) = (first[l] + count[l]) << (15 - l).  Lane l
+    // holds limit(l) and offs[l] - first[l]: a code's length is I_LPB + 1 + the number of limits it has reached, its place in `sorted` its
+    // top l bits plus that difference (round 6: four compares and an add where five compare-and-select steps per offset were 11 % of the
+    // symbol pass's instructions, tools/gfxsim/srcprof.py)
     uint32_t l2a = 0, l2b = 0;
     auto load_second_level = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        l2a = lane < 16 ? ((uint32_t)S.lt.first[lane] | ((uint32_t)S.lt.count[lane] << 16)) : 0u;
-        l2b = lane < 16 ? (uint32_t)S.lt.offs[lane] : 0u;
+        l2a = lane < 16 && lane >= 1 ? ((uint32_t)S.lt.first[lane] + (uint32_t)S.lt.count[lane]) << (15 - lane) : 0u;
+        l2b = lane < 16 ? (uint32_t)S.lt.offs[lane] - (uint32_t)S.lt.first[lane] : 0u;
     };
     load_second_level();
 
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                 const uint32_t p7 = (uint32_t)P & 7u, so0 = (uint32_t)((P >> 3) - sbase);
                 uint32_t fa2[16], of2[16];                                   // second level of the literal/length code (uniform)
 #pragma unroll
-                for (int l = I_LPB + 1; l <= 15; l++) { fa2[l] = (uint32_t)__builtin_amdgcn_readlane((int)l2a, l); of2[l] = (uint32_t)__builtin_amdgcn_readlane((int)l2b, l); }
+                for (int l = I_LPB; l <= 15; l++) { fa2[l] = (uint32_t)__builtin_amdgcn_readlane((int)l2a, l); of2[l] = (uint32_t)__builtin_amdgcn_readlane((int)l2b, l); }
                 // (written as phases over all NPO offsets so that each phase's LDS reads are in flight together)
                 uint32_t lo[NPO], hi[NPO], ev_[NPO], si_[NPO], sl2_[NPO], sr_[NPO], t2_[NPO], de_[NPO];
                 {
@@ -392,13 +396,14 @@ __global__ __launch_bounds__(64, (SHORTWIN && PMODE != 2) ? 3 : (SHORTWIN ? (DEN
                     // own through lane 0): the canonical second level (decode_sym) — first code, count and offset of the lengths
                     // I_LPB+1..15 come out of two registers (l2a, l2b), the symbol is one LDS read (made by every lane: no branch)
                     const uint32_t rev15 = __builtin_bitreverse32(lo[jj]) >> 17;
-                    uint32_t si = 0, sl2 = 0;
+                    uint32_t len2 = I_LPB + 1, base2 = of2[I_LPB + 1];
 #pragma unroll
-                    for (int l = 15; l > I_LPB; l--) {                   // (descending: the shortest length that fits wins, as in decode_sym)
-                        const uint32_t idx = (rev15 >> (15 - l)) - (fa2[l] & 0xFFFFu);
-                        const bool hit = idx < (fa2[l] >> 16);
-                        si = hit ? of2[l] + idx : si; sl2 = hit ? (uint32_t)l : sl2;
+                    for (int l = I_LPB + 1; l < 15; l++) {                // (the limits ascend: the code's length is the first whose limit it is below)
+                        const bool ge = rev15 >= fa2[l];
+                        len2 += ge ? 1u : 0u; base2 = ge ? of2[l + 1] : base2;
                     }
+                    const bool long_code = rev15 >= fa2[I_LPB] && rev15 < fa2[15];   // (a code of I_LPB + 1 .. 15 bits at all: `sorted` is read by every lane)
+                    const uint32_t si = long_code ? (rev15 >> (15u - len2)) + base2 : 0u, sl2 = long_code ? len2 : 0u;
                     si_[jj] = si; sl2_[jj] = sl2;
                     uint32_t sr = S.lt.sorted[si];
                     asm volatile("" : "+v"(sr));                           // (keeps the read out of a conditional region)
