@@ -3,7 +3,6 @@
     python tools/gfxsim/srcprof.py inflate [bytes=500000]        the symbol pass of the chunk-parallel Inflater on one text member
     python tools/gfxsim/srcprof.py parse [bytes=262144]          k_spec_win on a text stream at level 6
     python tools/gfxsim/srcprof.py blocks [bytes=262144]         k_block_build
-    python tools/gfxsim/srcprof.py find [bytes=1500000]          k_find_blocks on a text member in 128 KiB chunks
 
 The unit is compiled a second time with -gline-tables-only (same code, plus .loc directives); instruction k of the interpreted assembly is
 instruction k of that listing.  Counts are wave-instructions (the device's SQ_INSTS_*, tools/gfxsim/phases.py has the calibration); for a
@@ -24,7 +23,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 WORK = {"inflate": ("szl_kernels_inflate", "k_inflateILb1ELi2ELb0", 500000), "parse": ("szl_kernels_parse", "k_spec_winILi32", 262144),
-        "blocks": ("szl_kernels_block", "k_block_build", 262144), "find": ("szl_kernels_inflate_par", "k_find_blocks", 1500000)}
+        "blocks": ("szl_kernels_block", "k_block_build", 262144)}
 
 
 def listing_with_lines(unit):
@@ -75,9 +74,9 @@ def main(argv):
     from sharpziplib_amd import corpus as C
     e = Engine()
     data = C.generate("enwik", 0xE9, 0, nbytes)
-    if what in ("inflate", "find"):
+    if what == "inflate":
         m = O.deflate(data, 6)
-        suite._knobs(SZL_INF_CHUNK_KIB=16 if what == "inflate" else 128, SZL_INF_PAR_MIN_KIB=64)
+        suite._knobs(SZL_INF_CHUNK_KIB=16, SZL_INF_PAR_MIN_KIB=64)
         (r, used), = e.inflate([m], [data.size])
         assert r.data == data.tobytes() and e._L.szl_engine_debug_par_jobs(e._h) >= 4
     else:
