@@ -238,6 +238,10 @@ uint64_t szl_engine_debug_workspace(const szl_engine *e);
  * SZL_INF_PAR_MIN_KIB (default 512) compressed KiB or more is decoded by one wavefront per chunk of 1/32 of its compressed
  * bytes (16 KiB .. SZL_INF_CHUNK_KIB, default 128). */
 uint32_t szl_engine_debug_par_jobs(const szl_engine *e);
+/* test tap: the form of stage B's instruction text the engine's last launch of the full search ran (0 / 1, 2 = every tile chose): the engine
+ * picks it per launch from a sample of the call's prev[] hops (csrc/szl_engine.hip Engine::pick_text_form; no counterpart in the reference,
+ * whose FindLongestMatch, C/DeflaterEngine.cs:474-612, both forms restate bit for bit). */
+int szl_engine_debug_text_form(const szl_engine *e);
 
 /* Parity tap: the code lengths DeflaterHuffman.Tree.BuildTree + BuildLength (C/DeflaterHuffman.cs:196-329, :475-579) give `n` frequency
  * vectors of `num_symbols` entries each (min_codes / max_length as the three trees have them: 257 / 15, 1 / 15, 4 / 7), as stage D's

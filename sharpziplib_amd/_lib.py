@@ -83,6 +83,7 @@ def _load(path):
         "szl_debug_set": (i32, [ctypes.c_char_p, i32]), "szl_debug_host_copy": (i32, [vp, vp, sz]),
         "szl_engine_debug_workspace": (u64, [vp]),
         "szl_engine_debug_par_jobs": (ctypes.c_uint32, [vp]),
+        "szl_engine_debug_text_form": (ctypes.c_int, [vp]),
         "szl_inflater_debug_bulk_calls": (ctypes.c_uint32, [vp]), "szl_inflater_debug_times": (i32, [vp, vp]),
         "szl_debug_stored_layout": (i32, [vp, sz, i32, vp, sz, ctypes.POINTER(sz)]),
         "szl_debug_tree_lengths": (i32, [vp, i32, i32, i32, i32, vp, vp]),

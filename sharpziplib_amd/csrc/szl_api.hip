@@ -815,6 +815,7 @@ int szl_debug_set(const char *name, int value) { return name ? szl::knob_set(nam
 // Parity tap: device bytes held by the per-position side arrays (links, match tables, tokens, ...) at the peak of the last call.
 uint64_t szl_engine_debug_workspace(const szl_engine *e) { return e ? e->e.last_workspace_bytes : 0; }
 uint32_t szl_engine_debug_par_jobs(const szl_engine *e) { return e ? e->e.last_par_jobs : 0; }
+int szl_engine_debug_text_form(const szl_engine *e) { return e ? e->e.last_text_form : SZL_E_ARG; }
 
 // Parity tap: block table of the last call. rows of 8 x uint64: type,last,ntok,bit_start,opt_len,static_len,in_len,hdr_bits
 int szl_engine_debug_blocks(szl_engine *e, uint64_t *rows, size_t cap_rows, size_t *n_rows) {

@@ -114,6 +114,9 @@ class Engine {
     uint8_t *pin = nullptr;            // 256 bytes of pinned host memory: few-byte read-backs into pageable memory cost ~1 ms each
     uint8_t *ring = nullptr; size_t ring_at = 0; hipStream_t ring_st = nullptr;   // mapped pinned staging of h2d_small (szl_engine.hip)
     int h2d_small(void *dst, const void *src, size_t n, hipStream_t st);
+    uint32_t *stat_pin = nullptr;      // 512 bytes of mapped pinned memory: k_hop_stat's per-workgroup counts
+    int pick_text_form(const uint16_t *lk, int64_t lo, int64_t n, hipStream_t st);   // which form of k_match9's text a launch over link[lo, lo + n) runs (MTab::form)
+    int last_text_form = 0;            // (parity tap / debug line)
     int d2h_small(void *pin_dst, const void *src, size_t n, hipStream_t st);
     uint32_t last_par_jobs = 0;        // chunk jobs of the last parallel single-member inflate
     uint64_t last_workspace_bytes = 0; // device bytes held by the side arrays after the last call (parity tap / DESIGN §3)

@@ -139,6 +139,7 @@ void launch_stored(const uint8_t *in, uint8_t *out, const StoredBlk *blks, uint3
 void launch_zero_regions(const SegDev *segs, uint32_t nseg, const uint64_t *zoff, uint64_t npieces, uint8_t *out, hipStream_t st);
 void launch_zero_many(void *const *ptrs, const size_t *bytes, int n, hipStream_t st);
 void launch_copy_small(void *dst, const void *src, size_t bytes, hipStream_t st);
+void launch_hop_stat(const uint16_t *link, int64_t lo, int64_t n, uint32_t *out_pinned, hipStream_t st);
 size_t exscan_tmp_bytes(uint64_t n);
 hipError_t launch_exscan(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, hipStream_t st);
 int zero_piece_bytes();
@@ -320,6 +321,7 @@ void Engine::trim(size_t keep) {
     size_t total = device_bytes();
     for (DevBuf *b : v) { if (total <= keep) break; total -= b->cap; b->release(); }
     if (tab_pin && total + tab_pin_cap > keep) { (void)hipHostFree(tab_pin); tab_pin = nullptr; tab_pin_cap = 0; }   // (the tables' pinned staging comes back with the first call)
+    if (stat_pin && keep == 0) { (void)hipHostFree(stat_pin); stat_pin = nullptr; }
     if (ring && keep == 0) { if (ring_st) (void)hipStreamSynchronize(ring_st); (void)hipHostFree(ring); ring = nullptr; ring_at = 0; ring_st = nullptr; }
 }
 Engine::~Engine() {
@@ -336,6 +338,7 @@ Engine::~Engine() {
     if (pin) (void)hipHostFree(pin);
     if (tab_pin) (void)hipHostFree(tab_pin);
     if (ring) (void)hipHostFree(ring);
+    if (stat_pin) (void)hipHostFree(stat_pin);
 }
 
 // Small tables and structs go to the device — and a few counters come back — through k_copy_small, out of / into a ring of mapped pinned
@@ -356,6 +359,29 @@ int Engine::h2d_small(void *dst, const void *src, size_t n, hipStream_t st) {
     launch_copy_small(dst, ring + ring_at, n, st);
     ring_at += n16;
     return 0;
+}
+// Which form of k_match9's instruction text a launch runs (szl_match9_asm.h SZL9_V; szl_kernels_match9.hip).  Form 1 — the first filter
+// byte follows the walk's last failed compare — is 9 % faster where chains are dense (logs) and 1 % slower on text, and a kernel that
+// holds both forms and lets every tile choose costs text that 1 % too (33.72 -> 34.01 ms per GiB, A/B of two builds in one process,
+// profiles/r06/stage_b_forms_per_launch.log).  So the LAUNCH chooses: a sample of the prev[] hops stage A has just written (131072 links
+// at evenly spaced places, ~5 us and one synchronisation of the stream: calls of 8 MiB or more only, shorter ones run form 0) — the share of
+// hops below 256 is 0.23 on text, 0.92 on logs: below 0.35 form 0, above 0.65 form 1, between them the kernel whose tiles choose.
+int Engine::pick_text_form(const uint16_t *lk, int64_t lo, int64_t n, hipStream_t st) {
+    last_text_form = 0;
+    const int force = knob("SZL_TEXT_FORM", -1);                     // (0 / 1 / 2: no sample)
+    if (force >= 0 && force <= 2) return last_text_form = force;
+    if (n < (8 << 20)) return 0;
+    if (!stat_pin && hipHostMalloc((void **)&stat_pin, 512, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); stat_pin = nullptr; return 0; }
+    memset(stat_pin, 0, 512);
+    launch_hop_stat(lk, lo, n, stat_pin, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return 0;
+    uint64_t seen = 0, sh = 0;
+    for (int b = 0; b < 64; b++) { seen += ((volatile uint32_t *)stat_pin)[b]; sh += ((volatile uint32_t *)stat_pin)[64 + b]; }
+    if (!seen) return 0;
+    const double share = (double)sh / (double)seen;
+    last_text_form = share < 0.35 ? 0 : (share > 0.65 ? 1 : 2);
+    if (knob("SZL_DEBUG", 0)) fprintf(stderr, "[szl] stage B: %.3f of %llu sampled prev[] hops are below 256: form %d of the text\n", share, (unsigned long long)seen, last_text_form);
+    return last_text_form;
 }
 // device -> the engine's pinned page `pin` (read after the stream is synchronised)
 int Engine::d2h_small(void *pin_dst, const void *src, size_t n, hipStream_t st) {
@@ -531,7 +557,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     if ((rc = link.ensure(in_total * 2 + 64))) return rc;
     const size_t mt_stride = (in_total + 63) & ~(size_t)63; // M2 array, then Mq array
     if (!fast && (rc = mtab.ensure(mt_stride * 8 + 64))) return rc;
-    const MTab mt = {(uint32_t *)mtab.p, (uint32_t *)mtab.p + mt_stride};
+    MTab mt = {(uint32_t *)mtab.p, (uint32_t *)mtab.p + mt_stride};
     last_mt_stride = fast ? 0 : mt_stride;
     if ((rc = tokens.ensure((seg_bytes + 16) * 4))) return rc;
     if ((rc = visited.ensure((vis_words + 4) * 4))) return rc;
@@ -704,6 +730,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)p_tiles, (int)ntiles, 0, 1, (const uint16_t *)link.p, mt, P, dcnt, st));
         }
     }
+    if (!lazy) mt.form = pick_text_form((const uint16_t *)link.p, 0, (int64_t)in_total, st);   // (one synchronisation, calls of 8 MiB or more)
     if (!b_event) HIPCHK(hipEventRecord(ev[7], st));
     if (!lazy && m3) {
         if ((rc = link4.ensure(in_total * 2 + 64)) || (rc = skip4.ensure(in_total + 64)) || (rc = e3dist.ensure(in_total * 2 + 64)) ||
@@ -1001,7 +1028,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
         if ((rc = link.ensure(nlink * 2 + 64)) || (rc = mtab.ensure(mt_stride * 8 + 64)) || (rc = visited.ensure((wn / 32 + 8) * 4)) ||
             (emit_copy && (rc = spec_tok.ensure(ntab * 4 + 1024))) || (rc = upload(*this, d_spans, spans, st)) || (rc = upload(*this, d_tiles, tiles, st))) return rc;
         uint16_t *lk = (uint16_t *)link.p - (seg.buf_off + (uint64_t)lo);
-        const MTab mt = {(uint32_t *)mtab.p - (seg.buf_off + (uint64_t)e), (uint32_t *)mtab.p + mt_stride - (seg.buf_off + (uint64_t)e)};
+        MTab mt = {(uint32_t *)mtab.p - (seg.buf_off + (uint64_t)e), (uint32_t *)mtab.p + mt_stride - (seg.buf_off + (uint64_t)e)};
         uint32_t *stok = emit_copy ? (uint32_t *)spec_tok.p - (seg.buf_off + (uint64_t)e) : nullptr;
         LAP("window: side arrays");
         const uint64_t tok0 = is_part ? part.tok_start : 0;        // a part's tokens follow those of the parts before it (same buffer; indices are the part's own)
@@ -1024,6 +1051,7 @@ int Engine::deflate_windowed_impl(const uint8_t *d_in, uint64_t in_total, uint8_
             last_pilot_frac = sampled ? (double)ne / (double)sampled : 1.0;
             lazy = last_pilot_frac < lazy_max_frac;
         }
+        if (!lazy) mt.form = pick_text_form(lk + seg.buf_off, e, wend - e, st);   // (the window's own links: every window chooses)
         HIPCHK(hipEventRecord(ev[7], st));
         if (lazy) {
             HIPCHK(hipMemsetAsync(mtab.p, 0xFF, mt_stride * 4, st)); // M_UNSET

@@ -44,6 +44,7 @@ struct MTab {
     const uint8_t *skip4 = nullptr;
     const uint16_t *e3d = nullptr;     // first chain element with the same three bytes: distance, chain index
     const uint8_t *e3h = nullptr;
+    int form = 0;                      // which form of k_match9's text the launch runs: 0 / 1, 2 = every tile picks its own (launch_match9)
 };
 
 enum : uint32_t { M_UNSET = 0xFFFFFFFFu }; // M2 entry of a position no stage-B walker evaluated (valid entries have len <= 258)

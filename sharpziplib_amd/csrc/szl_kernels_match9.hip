@@ -16,7 +16,7 @@
 namespace szl {
 int knob(const char *name, int dflt);
 
-enum : int { B9_THREADS = 1024, B9_TILE = 21504 };
+enum : int { B9_THREADS = 1024, B9_TILE = 21504, HOP_BLOCKS = 64 };
 enum : int { B9_DATA_BYTES = B_HIST + B9_TILE + B_TAIL + 8, B9_LINKS = B_HIST + B9_TILE };
 enum : int { B9_D = SZL9_D, B9_LB = B9_D + B9_DATA_BYTES, B9_DBG = B9_LB + 2 * B9_LINKS, B9_SCR = B9_DBG + 32 /* 64 bytes per wavefront: lane ids while walks move between contexts (the tail program) */,
              B9_LDS_BYTES = B9_SCR + B9_THREADS };
@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t b9_stage_window(uint8_t *smem, const uint8_t
     return nshort;
 }
 
-template <bool DBG>
+template <bool DBG, int FORMS>   // FORMS: 0 / 1 = the launch runs that form of the text (and holds no other), 2 = both, a tile picks
 __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict__ in, const SegDev *__restrict__ segs, const TileDev *__restrict__ tiles,
                                                        const uint16_t *__restrict__ link, MTab mtab, LevelParams P, unsigned long long *dbg,
                                                        int fth, int vth_in, int qkeep_in, int ktail, int slice, int vtht, int tailp, int mth, int ktail1, int vtht1, int guide, int form) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     unsigned long long *s_t = (unsigned long long *)(smem + B9_DBG);     // (DBG) [0] first wavefront out of positions, [1] last wavefront done
     const unsigned long long t_start = DBG ? wall_clock64() : 0ull;
     uint32_t nshort = b9_stage_window(smem, d, lk, dlo, seg_end, t0 + tlen);
-    if (form == 2) {   // per wavefront: its threads' short hops (summed over the tile below)
+    if (FORMS == 2 && form == 2) {   // per wavefront: its threads' short hops (summed over the tile below)
 #pragma unroll
         for (int o = 32; o; o >>= 1) nshort += __shfl_xor(nshort, o);
         if ((threadIdx.x & 63) == 0) *(uint32_t *)(smem + B9_SCR + (threadIdx.x & ~63u)) = nshort;
@@ -123,14 +123,14 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
     // follows the walk's failed compares, and wins where chains are dense — lines of a log, records of a table: most hops of prev[]
     // are short there (generated logs: 92 % below 256; text: 23 %) and most compares fail where the one before did.  Both forms
     // store the same tables; the choice is the tile's own (form == 2) or the caller's (SZL9_FORM 0 / 1, laboratory and tests).
-    if (form == 2) {
+    if (FORMS == 2 && form == 2) {
         uint32_t tot = 0;
 #pragma unroll
         for (int w = 0; w < B9_THREADS / 64; w++) tot += *(const uint32_t *)(smem + B9_SCR + 64 * w);
         form = 2u * tot > (uint32_t)(B_HIST + tlen) ? 1 : 0;
         __syncthreads();   // (the slots are the tail program's scratch)
     }
-    const int form_s = __builtin_amdgcn_readfirstlane(form);
+    const int form_s = FORMS == 2 ? __builtin_amdgcn_readfirstlane(form) : FORMS;
 
     // window bases of the tile (see k_match4): positions from `sw` on belong to base_hi
     const int64_t base_lo = base_of9((int64_t)seg.abs0 + t0), base_hi = base_of9((int64_t)seg.abs0 + t0 + tlen - 1);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
                    [ktail] "s"(ktail_s), [stratm] "s"(stratm_s), [mt2b] "s"(mt2b_s), [mtqb] "s"(mtqb_s), \
                    [tailp] "s"(tailp_s), [mth] "s"(mth_s), [ktail1] "s"(ktail1_s), [wscr] "s"(wscr_s), [vtht1] "s"(vtht1_s), [guide] "s"(guide_s) \
                  : "vcc", "scc", "memory");
-    if (form_s == 0) {
+    if (FORMS == 0 || (FORMS == 2 && form_s == 0)) {
         SZL9_RUN_TEXT();
     } else {
 #undef SZL9_V
@@ -204,6 +204,33 @@ __global__ __launch_bounds__(B9_THREADS) void k_match9(const uint8_t *__restrict
             atomicAdd(dbg + 45, s_t[2] - s_t[0]); atomicAdd(dbg + 46, s_t[3]);
         }
     }
+}
+
+// A sample of a call's prev[] hops for the choice of the text's form (Engine::pick_text_form): HOP_BLOCKS workgroups read 16 links per thread
+// at evenly spaced places of link[lo, lo + n) and leave, per workgroup, how many links they saw (out[b]) and how many of them are hops
+// below 256 (out[HOP_BLOCKS + b]) in mapped pinned memory.  ~5 us; the host adds them up behind the stream's synchronisation.
+__global__ __launch_bounds__(256) void k_hop_stat(const uint16_t *__restrict__ link, int64_t lo, int64_t n, uint32_t *out) {
+    __shared__ uint32_t s_c[2];
+    if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t slots = (int64_t)HOP_BLOCKS * 256;
+    const int64_t step = n / slots;                                   // (n >= 16 * slots: the caller's business)
+    const int64_t at = (lo + ((int64_t)blockIdx.x * 256 + threadIdx.x) * step) & ~(int64_t)7;
+    uint32_t seen = 0, sh = 0;
+    if (at >= lo && at + 8 <= lo + n) {
+        const uint4 v = ld16u(link + at);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t x = nolink(w[k]); sh += short_hops(x); }
+        seen = 8;
+    }
+    for (int o = 32; o; o >>= 1) { seen += __shfl_xor(seen, o); sh += __shfl_xor(sh, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_c[0], seen); atomicAdd(&s_c[1], sh); }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[blockIdx.x] = s_c[0]; out[HOP_BLOCKS + blockIdx.x] = s_c[1]; __threadfence_system(); }
+}
+void launch_hop_stat(const uint16_t *link, int64_t lo, int64_t n, uint32_t *out_pinned, hipStream_t st) {
+    hipLaunchKernelGGL(k_hop_stat, dim3(HOP_BLOCKS), dim3(256), 0, st, link, lo, n, out_pinned);
 }
 
 static bool lds_attr_needed9(std::atomic<uint64_t> &mask, uint64_t &bit) {
@@ -230,21 +257,26 @@ hipError_t launch_match9(const uint8_t *in, const SegDev *segs, const TileDev *t
     int slice = SZL_LABKNOB("SZL_SLICE", 128);
     // hand-out near the tile's end: within `guide` positions of it a fetch takes as many positions as it has free lanes instead of a slice
     int guide = SZL_LABKNOB("SZL9_GUIDE", 8192);
-    // form of the text: 2 = each tile picks (k_match9), 0 / 1 = every tile runs that form
-    int form = SZL_LABKNOB("SZL9_FORM", 2);
-    form = form < 0 || form > 2 ? 2 : form;
+    // form of the text: 0 / 1 = every tile runs that form, 2 = each tile picks (k_match9).  The engine says which (MTab::form, from a sample
+    // of the call's prev[] hops: Engine::pick_text_form); SZL9_FORM (laboratory library, tests) overrides it.
+    int form = SZL_LABKNOB("SZL9_FORM", -1);
+    if (form < 0 || form > 2) form = mtab.form < 0 || mtab.form > 2 ? 0 : mtab.form;
     fth = fth < 1 ? 1 : (fth > 64 ? 64 : fth); vth = vth < 1 ? 1 : vth; qkeep = qkeep < 1 ? 1 : qkeep; ktail = ktail < 1 ? 1 : ktail; vtht = vtht < 1 ? 1 : vtht;
     slice = slice < 64 ? 64 : (slice > 4096 ? 4096 : slice);
     if (lds_attr_needed9(attr_mask, attr_bit)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_match9<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B9_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_match9<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B9_LDS_BYTES);
+        hipError_t e = hipSuccess;
+        const void *fs[6] = {(const void *)k_match9<false, 0>, (const void *)k_match9<false, 1>, (const void *)k_match9<false, 2>,
+                             (const void *)k_match9<true, 0>, (const void *)k_match9<true, 1>, (const void *)k_match9<true, 2>};
+        for (const void *f : fs) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B9_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(attr_bit, std::memory_order_release);
     }
     if (ntiles > 0) {
         const dim3 g(ntiles), b(B9_THREADS);
-        if (want_dbg) hipLaunchKernelGGL((k_match9<true>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide, form);
-        else hipLaunchKernelGGL((k_match9<false>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide, form);
+#define SZL9_LAUNCH(D, F) hipLaunchKernelGGL((k_match9<D, F>), g, b, B9_LDS_BYTES, st, in, segs, tiles, link, mtab, P, dbg, fth, vth, qkeep, ktail, slice, vtht, tailp, mth, ktail1, vtht1, guide, 2)
+        if (want_dbg) { if (form == 0) SZL9_LAUNCH(true, 0); else if (form == 1) SZL9_LAUNCH(true, 1); else SZL9_LAUNCH(true, 2); }
+        else { if (form == 0) SZL9_LAUNCH(false, 0); else if (form == 1) SZL9_LAUNCH(false, 1); else SZL9_LAUNCH(false, 2); }
+#undef SZL9_LAUNCH
     }
     return hipGetLastError();
 }

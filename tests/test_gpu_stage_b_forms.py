@@ -129,11 +129,11 @@ def test_streaming_deflater_through_the_lab_forms(knobs):
         assert d.TotalIn == tin and d.TotalOut == tout
 
 
-@pytest.mark.parametrize("text_form", [0, 1])
+@pytest.mark.parametrize("text_form", [0, 1, 2])
 @pytest.mark.parametrize("level", [5, 6, 8, 9])
 def test_both_forms_of_the_k_match9_text_are_bit_exact(knobs, text_form, level):
-    """k_match9 holds two forms of its instruction text and every tile takes one by the share of short prev[] hops in its window
-    (csrc/szl_match9_asm.h, SZL9_V).  Here every tile is made to run form 0 / form 1, whatever its data: same bytes either way."""
+    """k_match9 has two forms of its instruction text (csrc/szl_match9_asm.h, SZL9_V) and three builds: form 0, form 1, and both with every
+    tile choosing by the share of short prev[] hops in its window (2).  Here a launch is made to run each, whatever its data: same bytes."""
     from sharpziplib_amd.batch import Engine
     knobs(SZL9_FORM=text_form)
     data = _streams()
@@ -143,5 +143,39 @@ def test_both_forms_of_the_k_match9_text_are_bit_exact(knobs, text_form, level):
         res = eng.deflate(data, level=level)
         for d, r in zip(data, res):
             assert r.status == 0 and r.data == O.deflate(d, level), (text_form, level, d.size)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("text_form", [1, 2])
+def test_the_product_library_runs_the_forms_the_engine_picks(text_form):
+    """In the product the ENGINE picks the form per launch from a sample of the call's prev[] hops (Engine::pick_text_form; calls of 8 MiB or
+    more).  SZL_TEXT_FORM stands in for the sample here, so that small streams of every class go through forms 1 and 2 of the shipped kernel."""
+    from sharpziplib_amd import _lib
+    from sharpziplib_amd.batch import Engine
+    L = _lib.lib()
+    data = _streams()
+    try:
+        L.szl_debug_set(b"SZL_TEXT_FORM", text_form)
+        eng = Engine()
+        try:
+            for level in (6, 9):
+                for d, r in zip(data, eng.deflate(data, level=level)):
+                    assert r.status == 0 and r.data == O.deflate(d, level), (text_form, level, d.size)
+        finally:
+            eng.close()
+    finally:
+        L.szl_debug_set(b"SZL_TEXT_FORM", -2147483648)
+
+
+def test_the_engine_picks_form_1_for_logs_and_form_0_for_text():
+    from sharpziplib_amd.batch import Engine
+    eng = Engine()
+    try:
+        for kind, want_form in (("logs", 1), ("enwik", 0)):
+            d = C.generate(kind, 0x106, 0, 24 << 20)
+            r = eng.deflate([d], level=6)[0]
+            assert r.status == 0 and r.data == O.deflate(d, 6)
+            assert eng._L.szl_engine_debug_text_form(eng._h) == want_form, kind
     finally:
         eng.close()
