@@ -354,8 +354,7 @@
     "v_lshlrev_b32 %[t2" #X "], 1, %[pl" #X "]\n\t" \
     "v_and_b32 %[t5" #X "], -4, %[pl" #X "]\n\t" \
     "ds_read_u16 %[t2" #X "], %[t2" #X "] offset:" SZL9_STR(SZL9_LB) "\n\t"     /* hashHead (:782) as a distance */ \
-    "ds_read_u8 %[t3" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"       /* the filter bytes of a walk that has found nothing yet: bytes 0 and 1 (below) */ \
-    "ds_read_u8 %[t4" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D1) "\n\t" \
+    SZL9_FETCH_PB_READS(X) \
     "ds_read_b32 %[p0" #X "], %[t5" #X "] offset:" SZL9_STR(SZL9_D) "\n\t"      /* the position's first 16 bytes */ \
     "ds_read_b32 %[p1" #X "], %[t5" #X "] offset:" SZL9_STR(SZL9_D4) "\n\t" \
     "ds_read_b32 %[p2" #X "], %[t5" #X "] offset:" SZL9_STR(SZL9_D8) "\n\t" \
@@ -382,7 +381,7 @@
     "v_max_i32 %[mincb" #X "], %[t0" #X "], %[t7" #X "]\n\t"                     /* chain limit */ \
     "v_max_i32 %[t1" #X "], %[t1" #X "], %[t7" #X "]\n\t"                        /* first candidate's limit */ \
     "v_add_u32 %[mincb" #X "], 1, %[mincb" #X "]\n\t"                            /* (+ the filter's best_len, 1) */ \
-    "s_waitcnt lgkmcnt(7)\n\t" \
+    "s_waitcnt lgkmcnt(" SZL9_FETCH_HEAD_WAIT ")\n\t" \
     "v_sub_u32 %[cb" #X "], %[pl" #X "], %[t2" #X "]\n\t"                        /* hashHead as an index */ \
     "v_cmpx_ge_i32 vcc, %[cb" #X "], %[t1" #X "]\n\t"                            /* strstart - hashHead <= MAX_DIST (:788) */ \
     "v_lshlrev_b32 %[t0" #X "], 1, %[cb" #X "]\n\t" \
@@ -392,8 +391,8 @@
     "v_mov_b32 %[kk" #X "], -2\n\t" \
     "v_mov_b32 %[left" #X "], %[chainm2]\n\t"                                      /* max_chain - 1 may follow the first; one is taken below */ \
     "s_waitcnt lgkmcnt(1)\n\t" \
-    SZL9_PB_FIRST(X) \
     "v_alignbyte_b32 %[p0" #X "], %[p1" #X "], %[p0" #X "], %[pl" #X "]\n\t" \
+    SZL9_PB_FIRST(X) \
     "v_alignbyte_b32 %[p1" #X "], %[p2" #X "], %[p1" #X "], %[pl" #X "]\n\t" \
     "v_alignbyte_b32 %[p2" #X "], %[p3" #X "], %[p2" #X "], %[pl" #X "]\n\t" \
     "v_alignbyte_b32 %[p3" #X "], %[t6" #X "], %[p3" #X "], %[pl" #X "]\n\t" \
@@ -410,8 +409,17 @@
     "s_add_i32 %[wnext], %[wnext], %[f0]\n" \
     "29:\n\t"
 #if SZL9_NQ == 3
-#define SZL9_PB_FIRST(X) "v_lshl_or_b32 %[pb" #X "], %[t4" #X "], 16, %[t3" #X "]\n\t"
+/* the filter bytes of a walk that has found nothing yet, bytes 0 and 1 of the position (above), come out of its first dword once that is
+ * aligned — p[0] into bits 0-7, p[1] into bits 16-23, v_perm_b32 — instead of two more LDS reads per fetched position (round 6) */
+#define SZL9_FETCH_PB_READS(X)
+#define SZL9_FETCH_HEAD_WAIT "5"
+#define SZL9_PB_FIRST(X) \
+    "s_mov_b32 %[f1], 0x0c010c00\n\t" \
+    "v_perm_b32 %[pb" #X "], %[p0" #X "], %[p0" #X "], %[f1]\n\t"
 #else
+#define SZL9_FETCH_PB_READS(X) \
+    "ds_read_u8 %[t4" #X "], %[pl" #X "] offset:" SZL9_STR(SZL9_D1) "\n\t"
+#define SZL9_FETCH_HEAD_WAIT "6"
 #define SZL9_PB_FIRST(X) "v_mov_b32 %[pb" #X "], %[t4" #X "]\n\t"
 #endif
 
