@@ -717,7 +717,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
             uint64_t sampled = 0;
             for (uint64_t t = 0; t < ntiles; t += step) sampled += (uint64_t)tiles[t].len;
             HIPCHK(launch_match_lazy(d_in, dsegs, (const TileDev *)p_tiles, nb, 0, (int)step, (const uint16_t *)link.p, mt, P, dcnt, st));
-            HIPCHK(hipMemcpyAsync(pin + 192, (unsigned long long *)counters.p + 6, 8, hipMemcpyDeviceToHost, st));
+            if ((rc = d2h_small(pin + 192, (unsigned long long *)counters.p + 6, 8, st))) return rc;
             HIPCHK(hipStreamSynchronize(st));
             const unsigned long long ne = *(volatile unsigned long long *)(pin + 192);
             last_pilot_frac = sampled ? (double)ne / (double)sampled : 1.0;
@@ -771,7 +771,7 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     launch_fix(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (RangeDev *)ranges.p, (const uint32_t *)visited.p, dcnt,
                (uint32_t *)bad_slot.p, (uint64_t *)bad_range.p, st);
     {   // how many ranges never merged?  (one 8-byte read-back; the common answer is 0)
-        HIPCHK(hipMemcpyAsync(pin, counters.p, 8, hipMemcpyDeviceToHost, st));
+        if ((rc = d2h_small(pin, counters.p, 8, st))) return rc;   // (by kernel into mapped pinned memory: no copy engine between the device and the host's wait)
         HIPCHK(hipStreamSynchronize(st));
         const unsigned long long nbad = *(volatile unsigned long long *)pin;
         if (nbad > 0 && lazy) // ranges that never re-synchronise are chained position by position: evaluate everything first
