@@ -153,9 +153,9 @@ static int inflate_members_parallel(Engine &E, const uint8_t *d_in, uint8_t *d_o
     if (auto_size) {
         uint64_t total_in = 0;
         for (uint64_t v : in_lens) total_in += v;
-        chunk_max = inflate_chunk_max(total_in, slots);
+        chunk_max = inflate_chunk_max(total_in, slots, knob("SZL_INF_CM_MEMBERS", 0) ? in_lens.size() : 1);
     }
-    const std::vector<ChunkPlan> plans = inflate_chunk_plans(in_lens, chunk_max);   // (szl_inflate_sizing.h)
+    const std::vector<ChunkPlan> plans = inflate_chunk_plans(in_lens, chunk_max, knob("SZL_INF_MIN_CHUNKS", 0) > 0 ? (uint64_t)knob("SZL_INF_MIN_CHUNKS", 0) : inflate_min_chunks(chunk_max));   // (the knob: 32 = round 5's rule)   // (szl_inflate_sizing.h)
     uint64_t nstart_total = 0;
     for (size_t k = 0; k < cand.size(); k++) {
         if (!plans[k].chunk_bytes) continue;

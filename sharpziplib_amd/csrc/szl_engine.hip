@@ -119,6 +119,9 @@ void launch_exitmaps(const uint8_t *in, const uint16_t *link, MTab mtab, const S
                      uint16_t *exmap, uint16_t *cnmap, unsigned long long *counters, hipStream_t st, void *chain_scratch, uint32_t range_cnt0);
 size_t exitchain_scratch_bytes(uint64_t range_cnt);
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st);
+bool counts_to_blocks_fits(uint64_t nranges, uint32_t nseg);
+void launch_counts_to_blocks(const RangeDev *ranges, uint64_t nranges, const SegDev *segs, uint32_t nseg, uint32_t *counts, uint64_t *range_tok, SegOut *so,
+                             uint32_t *blk_counts, uint64_t *blk_off, hipStream_t st);
 void launch_seg_tokens(const SegDev *segs, uint32_t nseg, const uint64_t *range_tok, SegOut *so, uint32_t *blk_counts, hipStream_t st);
 void launch_emit(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDev *segs, uint32_t nseg, uint64_t nranges,
                  LevelParams P, const RangeDev *ranges, const uint64_t *range_tok, const SegOut *so, uint32_t *tokens,
@@ -788,10 +791,14 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
                             nseg == 1 ? chain_buf.p : nullptr, segs[0].range_cnt);
         }
     }
-    launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
-    HIPCHK(launch_exscan((const uint32_t *)counts.p, (uint64_t *)range_tok.p, nranges + 1, cubtmp.p, st));
-    launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);
-    HIPCHK(launch_exscan((const uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (uint64_t)nseg + 1, cubtmp.p, st));
+    if (nranges > 0 && counts_to_blocks_fits(nranges, nseg) && knob("SZL_SMALL_TAIL", 1) != 0)   // (a small call: the four steps in one launch)
+        launch_counts_to_blocks((const RangeDev *)ranges.p, nranges, dsegs, nseg, (uint32_t *)counts.p, (uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, st);
+    else {
+        launch_range_counts((const RangeDev *)ranges.p, nranges, (uint32_t *)counts.p, st);
+        HIPCHK(launch_exscan((const uint32_t *)counts.p, (uint64_t *)range_tok.p, nranges + 1, cubtmp.p, st));
+        launch_seg_tokens(dsegs, nseg, (const uint64_t *)range_tok.p, dso, (uint32_t *)blk_counts.p, st);
+        HIPCHK(launch_exscan((const uint32_t *)blk_counts.p, (uint64_t *)blk_off.p, (uint64_t)nseg + 1, cubtmp.p, st));
+    }
     if (emit_copy)
         launch_emit_copy(d_in, (const uint16_t *)link.p, mt, dsegs, nseg, nranges, P, (const RangeDev *)ranges.p, (const uint32_t *)visited.p,
                          (const uint32_t *)spec_tok.p, (const uint64_t *)range_tok.p, dso, (uint32_t *)tokens.p, (const uint64_t *)blk_off.p,

@@ -16,10 +16,18 @@ namespace szl {
 
 struct ChunkPlan { uint64_t chunk_bytes = 0; uint32_t nchunks = 0; };   // chunk_bytes 0: the member is not decoded in chunks
 
-inline uint64_t inflate_chunk_max(uint64_t total_in, uint64_t slots) {   // r whole rounds of the slots with chunks of at most ~192 KiB, at least 32 KiB
+inline uint64_t inflate_chunk_max(uint64_t total_in, uint64_t slots, uint64_t members = 1) {   // r whole rounds of the slots with chunks of at most ~192 KiB, at least 32 KiB
     const uint64_t rounds = std::max<uint64_t>(1, (total_in + slots * (192ull << 10) - 1) / (slots * (192ull << 10)));
-    return std::min<uint64_t>(std::max<uint64_t>((total_in / (slots * rounds) + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
+    uint64_t jobs = slots * rounds;
+    if (members > 1 && members * 2 < jobs) jobs -= members;      // (every member's last chunk is a short one: a job more than its bytes ask for)
+    return std::min<uint64_t>(std::max<uint64_t>((total_in / jobs + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
 }
+
+// How many chunks a short member is cut into at least.  32 while the call leaves slots empty (a few short members: more, smaller jobs);
+// a call that fills the slots at chunk_max — chunk_max above its 32 KiB floor — keeps chunk_max for every member that holds eight of
+// them: round 6 measured 256 x 4 MiB members 40.2 -> 34.9 ms, 1024 of them 140 -> 129, 512 x 1 MiB 26.0 -> 23.4 that way (32 chunks
+// a member there are three partial rounds of jobs a quarter the size; profiles/r06/inflate_min_chunks.log).
+inline uint64_t inflate_min_chunks(uint64_t chunk_max) { return chunk_max > (32ull << 10) ? 8 : 32; }
 
 inline ChunkPlan inflate_chunk_plan_one(uint64_t in_len, uint64_t cb) {
     ChunkPlan p;
@@ -30,10 +38,10 @@ inline ChunkPlan inflate_chunk_plan_one(uint64_t in_len, uint64_t cb) {
 }
 
 // in_len of every candidate member -> its plan.  chunk_max: the cap on a chunk (from inflate_chunk_max, or the SZL_INF_CHUNK_KIB knob).
-inline std::vector<ChunkPlan> inflate_chunk_plans(const std::vector<uint64_t> &in_len, uint64_t chunk_max) {
+inline std::vector<ChunkPlan> inflate_chunk_plans(const std::vector<uint64_t> &in_len, uint64_t chunk_max, uint64_t min_chunks = 32) {
     std::vector<ChunkPlan> plan(in_len.size());
     for (size_t i = 0; i < in_len.size(); i++) {
-        uint64_t cb = in_len[i] / 32;                             // short members get smaller chunks: at least ~32 of them
+        uint64_t cb = in_len[i] / std::max<uint64_t>(min_chunks, 8);   // short members get smaller chunks: at least ~32 of them
         cb = std::min<uint64_t>(std::max<uint64_t>(cb & ~1023ull, 16384), chunk_max);
         plan[i] = inflate_chunk_plan_one(in_len[i], cb);
     }

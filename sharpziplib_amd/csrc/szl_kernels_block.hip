@@ -296,6 +296,81 @@ struct BitW { // LSB-first bit writer into an LDS byte array
     __device__ void flush() { if (nacc > 0) { *p++ = (unsigned char)acc; acc = 0; nacc = 0; } }
 };
 
+// ---- CalcBLFreq / WriteTree by runs (round 6).  scan_code_lengths above is the reference's loop: one code length per step, each an
+// LDS read the next step waits for, four passes over ~316 lengths on one thread — 68 of the 340 us k_block_build takes when the call is
+// ONE block.  What the loop emits for a run of `len` equal lengths `v` depends on nothing but (v, len) (curlen differs from the run's
+// value when the run begins: runs are maximal, and each of the two scans starts at curlen = -1):
+//   v == 0: the run is cut into pieces of 138 (max_count), each one symbol 18 with count - 11; the rest r: r < 3 -> r symbols 0,
+//           r <= 10 -> symbol 17 (r - 3), else symbol 18 (r - 11);
+//   v != 0: symbol v, then the other len - 1 in pieces of 6, each symbol 16 with count - 3; the rest r: r < 3 -> r symbols v, else 16 (r - 3).
+// So a wavefront finds the runs with a ballot, a lane takes a run, and the bit offsets of the header are a prefix sum over the runs.
+template <typename F>
+__device__ __forceinline__ void run_emit(int v, int len, F emit) {
+    if (v == 0) {
+        const int full = len / 138, r = len - full * 138;
+        for (int k = 0; k < full; k++) emit(18, 127, 7);
+        if (r >= 11) emit(18, r - 11, 7);
+        else if (r >= 3) emit(17, r - 3, 3);
+        else for (int k = 0; k < r; k++) emit(0, 0, 0);
+    } else {
+        emit(v, 0, 0);
+        const int rest = len - 1, full = rest / 6, r = rest - full * 6;
+        for (int k = 0; k < full; k++) emit(16, 3, 2);
+        if (r >= 3) emit(16, r - 3, 2);
+        else for (int k = 0; k < r; k++) emit(v, 0, 0);
+    }
+}
+// all 64 lanes of one wavefront: rs[0 .. R) = first index of every run of length[0 .. n), rs[R] = n; returns R
+__device__ __forceinline__ int find_runs(const unsigned char *length, int n, unsigned short *rs, int lane) {
+    int R = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < n;
+        const int v = valid ? (int)length[p] : -1, pv = (valid && p > 0) ? (int)length[p - 1] : -2;
+        const bool st = valid && v != pv;
+        const unsigned long long m = __ballot(st);
+        if (st) rs[R + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+        R += __popcll(m);
+    }
+    if (lane == 0) rs[R] = (unsigned short)n;
+    wave_sync();
+    return R;
+}
+__device__ __forceinline__ void count_runs(const unsigned char *length, const unsigned short *rs, int R, int *blfreq, int lane) {
+    for (int r = lane; r < R; r += 64) {
+        const int s = rs[r], e = rs[r + 1];
+        run_emit((int)length[s], e - s, [&](int sym, int, int) { atomicAdd(&blfreq[sym], 1); });
+    }
+}
+// n bits of v at bit `pos` of a zeroed LSB-first bit string held in 32-bit words (n <= 16)
+__device__ __forceinline__ void or_bits(uint32_t *words, int pos, uint32_t v, int n) {
+    if (n == 0) return;
+    const unsigned long long x = (unsigned long long)v << (pos & 31);
+    atomicOr(&words[pos >> 5], (uint32_t)x);
+    if ((pos & 31) + n > 32) atomicOr(&words[(pos >> 5) + 1], (uint32_t)(x >> 32));
+}
+// the runs' symbols as bits from `bitpos` on; returns the position behind them (all 64 lanes, the same value)
+__device__ __forceinline__ int write_runs(const unsigned char *length, const unsigned short *rs, int R, const unsigned short *blcode,
+                                          const unsigned char *bllen, uint32_t *words, int bitpos, int lane) {
+    for (int rb = 0; rb < R; rb += 64) {
+        const int r = rb + lane;
+        const bool valid = r < R;
+        const int s = valid ? (int)rs[r] : 0, len = valid ? (int)rs[r + 1] - s : 0, v = valid ? (int)length[s] : 0;
+        int nb = 0;
+        if (valid) run_emit(v, len, [&](int sym, int, int xb) { nb += bllen[sym] + xb; });
+        int inc = nb;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        int off = bitpos + inc - nb;
+        if (valid) run_emit(v, len, [&](int sym, int xv, int xb) {
+            const int cl = bllen[sym];
+            or_bits(words, off, (uint32_t)blcode[sym] | ((uint32_t)xv << cl), cl + xb);
+            off += cl + xb;
+        });
+        bitpos += __shfl(inc, 63);
+    }
+    return bitpos;
+}
+
 __constant__ int c_bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; // :37
 
 enum : int { D_THREADS = 128 }; // two wavefronts: one per tree (literal/length, distance); small workgroups keep more blocks in flight per CU
@@ -313,8 +388,9 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     __shared__ unsigned short blcode[BL_NUM + 1];
     __shared__ TreeScratch scrL;
     __shared__ TreeScratchSmall scrD;
-    __shared__ unsigned char hdr[640];
-    __shared__ int s_type, s_hdrbits;
+    __shared__ uint32_t hdrw[164];                // the rendered header, LSB-first (640 bytes of BlockDesc.hdr and a word to spill into)
+    __shared__ unsigned short rsL[LIT_NUM + 4], rsD[DIST_NUM + 4];   // first index of every run of equal code lengths
+    __shared__ int s_type, s_hdrbits, s_RL, s_RD, s_bltc;
 
     const uint32_t gb = blockIdx.x;
     if (gb >= nblk_slots) return;
@@ -339,16 +415,26 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     if (tid == 0) extra_bits = 0;
     __syncthreads();
     int ex = 0;
-    for (int i = tid; i < ntok; i += D_THREADS) {
-        uint32_t t = tokens[tfirst + i];
-        uint32_t dist = t >> 16;
-        if (dist == 0) atomicAdd(&lfreq[t & 0xFF], 1);
-        else {
-            int lc = lcode_of((int)(t & 0xFFFF) - 3), dc = dcode_of((int)dist - 1);
-            atomicAdd(&lfreq[lc], 1);
-            atomicAdd(&dfreq[dc], 1);
-            if (lc >= 265 && lc < 285) ex += (lc - 261) / 4; // :903-906
-            if (dc >= 4) ex += dc / 2 - 1;                   // :910-913
+    // (eight loads in flight per thread: one load and its wait per step was 128 round trips to memory for a full block — a quarter of the
+    // kernel's 340 us when the call is ONE block, round 6)
+    constexpr int HB = 8;
+    for (int i0 = tid; i0 < ntok; i0 += D_THREADS * HB) {
+        uint32_t tk[HB];
+#pragma unroll
+        for (int u = 0; u < HB; u++) { const int i = i0 + u * D_THREADS; tk[u] = i < ntok ? tokens[tfirst + i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            if (i0 + u * D_THREADS >= ntok) break;
+            const uint32_t t = tk[u];
+            const uint32_t dist = t >> 16;
+            if (dist == 0) atomicAdd(&lfreq[t & 0xFF], 1);
+            else {
+                int lc = lcode_of((int)(t & 0xFFFF) - 3), dc = dcode_of((int)dist - 1);
+                atomicAdd(&lfreq[lc], 1);
+                atomicAdd(&dfreq[dc], 1);
+                if (lc >= 265 && lc < 285) ex += (lc - 261) / 4; // :903-906
+                if (dc >= 4) ex += dc / 2 - 1;                   // :910-913
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
@@ -360,9 +446,11 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     if (tid < 64) build_tree(lfreq, LIT_NUM, 257, 15, &scrL, llen, lblc, &lnum, tid);
     else build_tree(dfreq, DIST_NUM, 1, 15, &scrD, dlen, dblc, &dnum, tid - 64);
     __syncthreads();
-    if (tid == 0) {
-        scan_code_lengths(llen, lnum, [&](int sym, int, int) { blfreq[sym]++; });
-        scan_code_lengths(dlen, dnum, [&](int sym, int, int) { blfreq[sym]++; });
+    {   // CalcBLFreq :349 for both trees, a wavefront each, a lane per run (run_emit)
+        const int lane = tid & 63;
+        if (tid < 64) { const int R = find_runs(llen, lnum, rsL, lane); count_runs(llen, rsL, R, blfreq, lane); if (lane == 0) s_RL = R; }
+        else { const int R = find_runs(dlen, dnum, rsD, lane); count_runs(dlen, rsD, R, blfreq, lane); if (lane == 0) s_RD = R; }
+        for (int i = tid; i < 164; i += D_THREADS) hdrw[i] = 0u;
     }
     __syncthreads();
     if (tid < 64) build_tree(blfreq, BL_NUM, 4, 7, &scrD, bllen, blblc, &blnum, tid);
@@ -409,37 +497,40 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
         if (storedOffsetOk && in_len + 4 < (opt_len >> 3)) type = 0;
         else if (opt_len == static_len) type = 1;
         else type = 2;
-        s_type = type;
-        BitW w; w.p = hdr; w.acc = 0; w.nacc = 0; w.total = 0;
-        w.put((unsigned)((type << 1) + last), 3); // :773,:843,:852
-        if (type == 2) { // SendAllTrees :676
-            // bl codes (BuildCodes :151 for the 19-symbol tree)
+        s_type = type; s_bltc = blTreeCodes;
+        if (type == 2) { // bl codes (BuildCodes :151 for the 19-symbol tree)
             int nextCode[7], code = 0;
             for (int bits = 0; bits < 7; bits++) { nextCode[bits] = code; code += blblc[bits] << (15 - bits); }
             for (int i = 0; i < blnum; i++) {
                 int bits = bllen[i];
                 if (bits > 0) { blcode[i] = (unsigned short)bitrev16((uint32_t)nextCode[bits - 1]); nextCode[bits - 1] += 1 << (16 - bits); }
             }
-            w.put((unsigned)(lnum - 257), 5);
-            w.put((unsigned)(dnum - 1), 5);
-            w.put((unsigned)(blTreeCodes - 4), 4);
-            for (int rank = 0; rank < blTreeCodes; rank++) w.put(bllen[c_bl_order[rank]], 3);
-            auto emit = [&](int sym, int xv, int xb) { w.put(blcode[sym], bllen[sym]); if (xb) w.put((unsigned)xv, xb); };
-            scan_code_lengths(llen, lnum, emit);
-            scan_code_lengths(dlen, dnum, emit);
         }
-        w.flush();
-        s_hdrbits = w.total;
         bd->seg = si; bd->type = (uint32_t)type; bd->last = (uint32_t)last; bd->ntok = (uint32_t)ntok;
         bd->tok_first = tfirst; bd->in_start = in_start; bd->in_len = (uint32_t)in_len;
-        bd->hdr_bits = (uint32_t)w.total;
         bd->opt_len = (uint32_t)opt_len; bd->static_len = (uint32_t)static_len;
-        // body_bits: everything this block writes when it starts at a byte-agnostic position
-        // body_bits = bits actually written.  opt_len is only the reference's *estimate*: GetEncodedLength (:331)
-        // does not count the 2/3/7 extra bits of bl symbols 16/17/18, so a dynamic block is longer than 3+opt_len.
-        if (type == 0) bd->body_bits = 3;                                  // + alignment + 32 + 8*len, added by the scan
-        else if (type == 1) bd->body_bits = 3 + (uint64_t)static_len;
-        else bd->body_bits = (uint64_t)w.total + (uint64_t)s_sums[0] + (uint64_t)extra_bits;
+    }
+    __syncthreads();
+    if (tid < 64) {   // the header's bits: :773,:843,:852, SendAllTrees :676 — WriteTree :411 a lane per run (write_runs)
+        const int type = s_type;
+        int total = 3;
+        if (tid == 0) or_bits(hdrw, 0, (uint32_t)((type << 1) + last), 3);
+        if (type == 2) {
+            const int bltc = s_bltc;
+            if (tid == 0) { or_bits(hdrw, 3, (uint32_t)(lnum - 257), 5); or_bits(hdrw, 8, (uint32_t)(dnum - 1), 5); or_bits(hdrw, 13, (uint32_t)(bltc - 4), 4); }
+            if (tid < bltc) or_bits(hdrw, 17 + 3 * tid, bllen[c_bl_order[tid]], 3);
+            total = write_runs(llen, rsL, s_RL, blcode, bllen, hdrw, 17 + 3 * bltc, tid);
+            total = write_runs(dlen, rsD, s_RD, blcode, bllen, hdrw, total, tid);
+        }
+        if (tid == 0) {
+            s_hdrbits = total;
+            bd->hdr_bits = (uint32_t)total;
+            // body_bits = bits actually written.  opt_len is only the reference's *estimate*: GetEncodedLength (:331)
+            // does not count the 2/3/7 extra bits of bl symbols 16/17/18, so a dynamic block is longer than 3+opt_len.
+            if (type == 0) bd->body_bits = 3;                                  // + alignment + 32 + 8*len, added by the scan
+            else if (type == 1) bd->body_bits = 3 + (uint64_t)(extra_bits + s_sums[1]);
+            else bd->body_bits = (uint64_t)total + (uint64_t)s_sums[0] + (uint64_t)extra_bits;
+        }
     }
     __syncthreads();
     const int type = s_type;
@@ -475,7 +566,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
         bd->dcode[tid] = (uint16_t)code; bd->dlen[tid] = (uint8_t)len;
     }
     const int hb = (s_hdrbits + 7) >> 3;
-    for (int i = tid; i < hb; i += D_THREADS) bd->hdr[i] = hdr[i];
+    for (int i = tid; i < hb; i += D_THREADS) bd->hdr[i] = ((const unsigned char *)hdrw)[i];
 }
 
 // Bit position of every block: one wavefront per segment, 64 blocks per step.  Stored blocks align to a byte
@@ -527,7 +618,7 @@ __global__ __launch_bounds__(64) void k_block_scan(const SegDev *segs, uint32_t 
 // with LDS atomic OR (each token code is <= 48 bits at an arbitrary bit offset) and flushed with plain
 // dword stores; only the first and last dword of a step can be shared with a neighbour step/block and
 // use a global atomic OR into the pre-zeroed output.
-enum : int { E_THREADS = 256, E_STAGE_DW = 400 };
+enum : int { E_THREADS = 256, E_TPT = 4, E_STAGE_DW = (31 + E_THREADS * E_TPT * 48) / 32 + 3 };   // E_TPT tokens of at most 48 bits per thread and round
 
 __device__ __forceinline__ void lds_or_bits(uint32_t *stage, uint32_t bitoff, unsigned long long v, int nbits) {
     if (nbits == 0) return;
@@ -550,6 +641,16 @@ __device__ void flush_stage(uint32_t *stage, uint32_t *out32, uint64_t bit_lo, u
         if (i == 0 || i == n - 1) { if (v) atomicOr(&out32[w0 + i], v); }
         else out32[w0 + i] = v;
     }
+}
+
+// A barrier that orders LDS only.  __syncthreads() is also a fence for global memory, i.e. a wait for every store in flight, and
+// k_block_encode stores a round's words to the output between two barriers: 64 rounds of a full block each waited out their stores'
+// trip to memory (71 us for ONE block, round 6).  Nothing a round writes to global memory is read again by this kernel, and two rounds
+// share at most the word between them, which both OR into atomically.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 __global__ __launch_bounds__(E_THREADS) void k_block_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
@@ -593,7 +694,7 @@ __global__ __launch_bounds__(E_THREADS) void k_block_encode(const uint8_t *__res
         const uint32_t hb = bd->hdr_bits;
         for (uint32_t base = 0; base < hb; base += E_THREADS * 8) {
             for (int i = tid; i < E_STAGE_DW + 4; i += E_THREADS) stage[i] = 0;
-            __syncthreads();
+            lds_barrier();
             uint32_t chunk = hb - base < (uint32_t)E_THREADS * 8 ? hb - base : (uint32_t)E_THREADS * 8;
             uint32_t mybit = (uint32_t)tid * 8;
             if (mybit < chunk) {
@@ -601,48 +702,61 @@ __global__ __launch_bounds__(E_THREADS) void k_block_encode(const uint8_t *__res
                 unsigned v = bd->hdr[(base >> 3) + tid] & ((1u << nb) - 1);
                 lds_or_bits(stage, (uint32_t)(pos & 31) + mybit, v, nb);
             }
-            __syncthreads();
+            lds_barrier();
             flush_stage(stage, out32, pos, pos + chunk, tid);
-            __syncthreads();
+            lds_barrier();
             pos += chunk;
         }
     }
     // ---- tokens (CompressBlock :701)
     const uint32_t ntok = bd->ntok;
     const uint64_t tfirst = bd->tok_first;
-    for (uint32_t t0 = 0; t0 < ntok + 1; t0 += E_THREADS) { // +1: the EOB symbol rides as a pseudo token
+    // (E_TPT consecutive tokens per thread and round: a round ends with stores that the next round's loads queue behind — one counter
+    // for both on this chip — so a round costs a trip to memory whatever it holds; 64 rounds of 256 tokens were 71-84 us for ONE full
+    // block, round 6)
+    for (uint32_t t0 = 0; t0 < ntok + 1; t0 += E_THREADS * E_TPT) { // +1: the EOB symbol rides as a pseudo token
         for (int i = tid; i < E_STAGE_DW + 4; i += E_THREADS) stage[i] = 0;
-        unsigned long long v = 0; int nb = 0;
-        uint32_t ti = t0 + tid;
-        if (ti < ntok) {
-            uint32_t t = tokens[tfirst + ti];
-            uint32_t dist = t >> 16;
-            if (dist == 0) { v = s_lcode[t & 0xFF]; nb = s_llen[t & 0xFF]; }
-            else {
-                int l = (int)(t & 0xFFFF) - 3;
-                int lc = lcode_of(l);
-                v = s_lcode[lc]; nb = s_llen[lc];
-                int bits = (lc - 261) / 4;                       // :716
-                if (bits > 0 && bits <= 5) { v |= (unsigned long long)(l & ((1 << bits) - 1)) << nb; nb += bits; }
-                int dd = (int)dist - 1;
-                int dc = dcode_of(dd);
-                v |= (unsigned long long)s_dcode[dc] << nb; nb += s_dlen[dc];
-                bits = dc / 2 - 1;                               // :725
-                if (bits > 0) { v |= (unsigned long long)(dd & ((1 << bits) - 1)) << nb; nb += bits; }
-            }
-        } else if (ti == ntok) { v = s_lcode[256]; nb = s_llen[256]; } // EOF_SYMBOL :749
-        // exclusive scan of nb over the workgroup
-        int incl = nb;
+        uint32_t tk[E_TPT];
+#pragma unroll
+        for (int u = 0; u < E_TPT; u++) { const uint32_t ti = t0 + (uint32_t)tid * E_TPT + u; tk[u] = ti < ntok ? tokens[tfirst + ti] : 0u; }
+        unsigned long long v[E_TPT]; int nb[E_TPT];
+        int mine = 0;
+#pragma unroll
+        for (int u = 0; u < E_TPT; u++) {
+            const uint32_t ti = t0 + (uint32_t)tid * E_TPT + u;
+            v[u] = 0; nb[u] = 0;
+            if (ti < ntok) {
+                const uint32_t t = tk[u];
+                const uint32_t dist = t >> 16;
+                if (dist == 0) { v[u] = s_lcode[t & 0xFF]; nb[u] = s_llen[t & 0xFF]; }
+                else {
+                    int l = (int)(t & 0xFFFF) - 3;
+                    int lc = lcode_of(l);
+                    v[u] = s_lcode[lc]; nb[u] = s_llen[lc];
+                    int bits = (lc - 261) / 4;                       // :716
+                    if (bits > 0 && bits <= 5) { v[u] |= (unsigned long long)(l & ((1 << bits) - 1)) << nb[u]; nb[u] += bits; }
+                    int dd = (int)dist - 1;
+                    int dc = dcode_of(dd);
+                    v[u] |= (unsigned long long)s_dcode[dc] << nb[u]; nb[u] += s_dlen[dc];
+                    bits = dc / 2 - 1;                               // :725
+                    if (bits > 0) { v[u] |= (unsigned long long)(dd & ((1 << bits) - 1)) << nb[u]; nb[u] += bits; }
+                }
+            } else if (ti == ntok) { v[u] = s_lcode[256]; nb[u] = s_llen[256]; } // EOF_SYMBOL :749
+            mine += nb[u];
+        }
+        // exclusive scan of the threads' bits over the workgroup
+        int incl = mine;
         for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
         if ((tid & 63) == 63) wsum[tid >> 6] = (uint32_t)incl;
-        __syncthreads();
+        lds_barrier();
         uint32_t woff = 0, total = 0;
         for (int w = 0; w < E_THREADS / 64; w++) { uint32_t x = wsum[w]; if (w < (tid >> 6)) woff += x; total += x; }
-        uint32_t myoff = woff + (uint32_t)(incl - nb);
-        lds_or_bits(stage, (uint32_t)(pos & 31) + myoff, v, nb);
-        __syncthreads();
+        uint32_t off = (uint32_t)(pos & 31) + woff + (uint32_t)(incl - mine);
+#pragma unroll
+        for (int u = 0; u < E_TPT; u++) { lds_or_bits(stage, off, v[u], nb[u]); off += (uint32_t)nb[u]; }
+        lds_barrier();
         flush_stage(stage, out32, pos, pos + total, tid);
-        __syncthreads();
+        lds_barrier();
         pos += total;
     }
 }

@@ -875,34 +875,55 @@ __global__ __launch_bounds__(64) void k_emit_copy(const uint8_t *in, const uint1
             ncopy = rd.spec_count - skip;
         }
     }
-    // ---- the wave: copy each range's speculative tokens from y on
-    for (uint64_t m = __ballot(ncopy > 0); m; m &= m - 1) {
-        const int j = __builtin_ctzll(m);
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ncopy, j);
-        const uint32_t *src = spec_tok + readlane64((int64_t)(s.buf_off + (uint64_t)rs + skip), j);
-        const uint64_t dst0 = (uint64_t)readlane64((int64_t)ti, j);
-        int64_t pos = readlane64(y, j);                                   // input position of the next token
-        const uint8_t *dj = (const uint8_t *)readlane64((int64_t)c.d, j);
-        const uint64_t j_tok0 = (uint64_t)readlane64((int64_t)seg_tok0, j), j_ntok = (uint64_t)readlane64((int64_t)seg_ntok, j);
-        const uint64_t j_b0 = (uint64_t)readlane64((int64_t)b0, j);
-        for (uint32_t k0 = 0; k0 < n; k0 += 64) {
-            const bool on = k0 + lane < n;
-            uint32_t t = on ? src[k0 + lane] : 0u;
-            const uint32_t len = on ? ((t >> 16) ? (t & 0xFFFF) : 1u) : 0u;
-            uint32_t incl = len;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-            const int64_t tpos = pos + (incl - len);
-            if (on) {
-                if ((t >> 16) == 0) t = dj[tpos];                          // literal placeholder -> the byte
-                const uint64_t tindex = dst0 + k0 + lane;
-                tokens[tindex] = t;
-                const uint64_t li = tindex - j_tok0;
-                if ((li & (BLOCK_TOKENS - 1)) == 0) blk_start_pos[j_b0 + li / BLOCK_TOKENS] = tpos;
-                if ((li & (BLOCK_TOKENS - 1)) == BLOCK_TOKENS - 1 || li == j_ntok - 1) blk_lasttok_pos[j_b0 + li / BLOCK_TOKENS] = tpos;
-            }
-            pos += (int64_t)__builtin_amdgcn_readlane((int)incl, 63);
+    // ---- the wave: copy each range's speculative tokens from y on, 64 tokens a step.  A step's two trips to memory — its tokens, then
+    // the bytes of its literals at positions that follow from the tokens — used to be waited for one after the other, 64 ranges of ~20
+    // tokens one after the other when the call is ONE 64 KiB entry (77 us, round 6): now the tokens of the step after it are on their way
+    // before a step begins, and a step's tokens are stored at the end of the step after it, when its bytes have arrived.
+    uint64_t m = __ballot(ncopy > 0);
+    int j = 0; uint32_t n = 0, k0 = 0; const uint32_t *src = nullptr; bool more = false;   // the step the iterator stands on (all uniform)
+    auto next = [&]() {
+        if (more && k0 + 64 < n) { k0 += 64; return; }
+        if (!m) { more = false; return; }
+        j = __builtin_ctzll(m); m &= m - 1;
+        n = (uint32_t)__builtin_amdgcn_readlane((int)ncopy, j);
+        src = spec_tok + readlane64((int64_t)(s.buf_off + (uint64_t)rs + skip), j);
+        k0 = 0; more = true;
+    };
+    next();
+    uint32_t t_pre = (more && k0 + lane < n) ? src[k0 + lane] : 0u;
+    bool p_on = false, p_lit = false; uint32_t p_t = 0, p_byte = 0; uint64_t p_tindex = 0;      // the step whose store is pending
+    uint64_t dst0 = 0, j_tok0 = 0, j_ntok = 0, j_b0 = 0; int64_t pos = 0; const uint8_t *dj = nullptr;   // the current range (uniform)
+    while (more) {
+        const int cj = j; const uint32_t cn = n, ck0 = k0;
+        uint32_t t = t_pre;
+        next();
+        if (more) t_pre = (k0 + lane < n) ? src[k0 + lane] : 0u;
+        if (ck0 == 0) {
+            dst0 = (uint64_t)readlane64((int64_t)ti, cj);
+            pos = readlane64(y, cj);                                        // input position of the next token
+            dj = (const uint8_t *)readlane64((int64_t)c.d, cj);
+            j_tok0 = (uint64_t)readlane64((int64_t)seg_tok0, cj); j_ntok = (uint64_t)readlane64((int64_t)seg_ntok, cj);
+            j_b0 = (uint64_t)readlane64((int64_t)b0, cj);
         }
+        const bool on = ck0 + lane < cn;
+        if (!on) t = 0u;
+        const uint32_t len = on ? ((t >> 16) ? (t & 0xFFFF) : 1u) : 0u;
+        uint32_t incl = len;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        const int64_t tpos = pos + (incl - len);
+        const bool lit = on && (t >> 16) == 0;
+        const uint32_t byte = lit ? (uint32_t)dj[tpos] : 0u;               // literal placeholder -> the byte
+        if (p_on) tokens[p_tindex] = p_lit ? p_byte : p_t;
+        const uint64_t tindex = dst0 + ck0 + lane;
+        if (on) {
+            const uint64_t li = tindex - j_tok0;
+            if ((li & (BLOCK_TOKENS - 1)) == 0) blk_start_pos[j_b0 + li / BLOCK_TOKENS] = tpos;
+            if ((li & (BLOCK_TOKENS - 1)) == BLOCK_TOKENS - 1 || li == j_ntok - 1) blk_lasttok_pos[j_b0 + li / BLOCK_TOKENS] = tpos;
+        }
+        p_on = on; p_lit = lit; p_t = t; p_byte = byte; p_tindex = tindex;
+        pos += (int64_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
+    if (p_on) tokens[p_tindex] = p_lit ? p_byte : p_t;
 }
 
 int knob(const char *name, int dflt);
@@ -1056,6 +1077,36 @@ hipError_t launch_exscan(const uint32_t *in, uint64_t *out, uint64_t n, void *tm
     return hipGetLastError();
 }
 
+// A small call's four steps from the ranges' token counts to the block slots — k_range_counts, the scan, k_seg_tokens, the scan — in one
+// workgroup (round 6: each of them was 2-3 us of work and 5-8 us of launch for ONE 64 KiB entry).  counts[nranges] and blk_counts[nseg]
+// are zero (the call's memsets), as the scans of the separate launches expect.
+__global__ __launch_bounds__(SCAN_T) void k_counts_to_blocks(const RangeDev *__restrict__ ranges, uint64_t nranges, const SegDev *__restrict__ segs, uint32_t nseg,
+                                                             uint32_t *counts, uint64_t *range_tok, SegOut *so, uint32_t *blk_counts, uint64_t *blk_off) {
+    __shared__ uint64_t wsum[SCAN_T / 64];
+    for (uint64_t r = threadIdx.x; r < nranges; r += SCAN_T) counts[r] = ranges[r].true_count;
+    __threadfence_block();
+    __syncthreads();
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nranges + 1; base += SCAN_TILE) carry += scan_tile(counts, range_tok, base, nranges + 1, carry, wsum);
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t si = threadIdx.x; si < nseg; si += SCAN_T) {     // (k_seg_tokens)
+        const uint64_t off = segs[si].range_off;
+        const uint64_t first = range_tok[off], cnt = range_tok[off + segs[si].range_cnt] - first;
+        so[si].tok_first = first;
+        so[si].tok_count = cnt;
+        blk_counts[si] = (uint32_t)(cnt / BLOCK_TOKENS) + 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    carry = 0;
+    for (uint64_t base = 0; base < (uint64_t)nseg + 1; base += SCAN_TILE) carry += scan_tile(blk_counts, blk_off, base, (uint64_t)nseg + 1, carry, wsum);
+}
+bool counts_to_blocks_fits(uint64_t nranges, uint32_t nseg) { return nranges + 1 <= 4ull * SCAN_TILE && (uint64_t)nseg + 1 <= 4ull * SCAN_TILE; }
+void launch_counts_to_blocks(const RangeDev *ranges, uint64_t nranges, const SegDev *segs, uint32_t nseg, uint32_t *counts, uint64_t *range_tok, SegOut *so,
+                             uint32_t *blk_counts, uint64_t *blk_off, hipStream_t st) {
+    hipLaunchKernelGGL(k_counts_to_blocks, dim3(1), dim3(SCAN_T), 0, st, ranges, nranges, segs, nseg, counts, range_tok, so, blk_counts, blk_off);
+}
 void launch_range_counts(const RangeDev *ranges, uint64_t nranges, uint32_t *counts, hipStream_t st) {
     if (nranges == 0) return;
     hipLaunchKernelGGL(k_range_counts, dim3((unsigned)((nranges + 255) / 256)), dim3(256), 0, st, ranges, nranges, counts);

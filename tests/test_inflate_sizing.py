@@ -19,6 +19,10 @@ def S(tmp_path_factory):
     L = ctypes.CDLL(so)
     L.sz_chunk_max.restype = ctypes.c_ulonglong
     L.sz_chunk_max.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong]
+    L.sz_plans_auto.restype = ctypes.c_ulonglong
+    L.sz_plans_auto.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.sz_min_chunks.restype = ctypes.c_ulonglong
+    L.sz_min_chunks.argtypes = [ctypes.c_ulonglong]
     L.sz_plans.restype = ctypes.c_ulonglong
     L.sz_plans.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
     return L
@@ -65,3 +69,39 @@ def test_a_fixed_chunk_size_is_left_alone(S):
     lens = [3 << 20] * 100
     j0, cb0, n0, _ = plans(S, lens, 2048, chunk_max=16384)
     assert (cb0 == 16384).all() and j0 == 100 * 192
+
+
+def plans_auto(S, lens, slots):
+    lens = np.asarray(lens, dtype=np.uint64)
+    cb = np.zeros(lens.size, np.uint64)
+    n = np.zeros(lens.size, np.uint32)
+    cm = ctypes.c_ulonglong(0)
+    jobs = S.sz_plans_auto(lens.ctypes.data, lens.size, slots, cb.ctypes.data, n.ctypes.data, ctypes.byref(cm))
+    return jobs, cb, n, cm.value
+
+
+def test_a_call_that_fills_the_slots_is_whole_rounds_of_them(S):
+    """Round 6 (profiles/r06/inflate_min_chunks.log): 256 x 4 MiB text members were 8191 jobs of 47 KiB — 3.2 rounds of 2560 slots, 40.2 ms —
+    and are one round of ~150 KiB jobs, 34.9 ms.  The rule: a call whose bytes fill the slots at chunk_max cuts every member at chunk_max."""
+    assert S.sz_min_chunks(32 << 10) == 32 and S.sz_min_chunks(33 << 10) == 8
+    for k, ln, slots in ((256, 1553699, 2560), (1024, 1553699, 2560), (128, 1553699, 2048)):
+        j, cb, n, cm = plans_auto(S, [ln] * k, slots)
+        rounds = -(-j // slots)
+        assert (cb == cm).all() and j <= rounds * slots and j > (rounds - 1) * slots + slots // 2, (k, j, cm)
+    j, cb, n, cm = plans_auto(S, [390000] * 512, 2560)          # members that do not hold eight chunks of chunk_max: eight or nine chunks each
+    assert cm == 96 << 10 and (cb == 47 << 10).all() and j == 512 * 9
+    # a few short members leave the slots empty: the 32 chunks a member of round 5
+    j, cb, n, cm = plans_auto(S, [1553699] * 8, 2048)
+    assert cm == 32 << 10 and (n >= 32).all()
+    # one long member: nothing changes
+    assert plans_auto(S, [380 << 20], 2048)[0] == plans(S, [380 << 20], 2048)[0]
+    rng = np.random.default_rng(5)
+    for case in range(2000):
+        k = int(rng.integers(1, 1025))
+        lens = rng.integers(100000, 8 << 20, k)
+        slots = int(rng.choice([2048, 2560]))
+        j, cb, n, cm = plans_auto(S, lens, slots)
+        assert 32 << 10 <= cm <= 256 << 10 and cm % 1024 == 0
+        for L, c, m in zip(lens, cb, n):
+            if c:
+                assert 16384 <= c <= cm and c % 1024 == 0 and m >= 8 and (m - 1) * c < L <= m * c
