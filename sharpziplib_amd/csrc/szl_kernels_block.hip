@@ -88,6 +88,12 @@ struct TreeScratchT {
 using TreeScratch = TreeScratchT<LIT_NUM>;       // literal/length tree (286 symbols)
 using TreeScratchSmall = TreeScratchT<DIST_NUM>; // distance tree (30) and code-length tree (19)
 
+#if SZL_LAB   // (laboratory library: where one block's k_block_build spends its time — 100 MHz stamps of workgroup 0, tools/lab/block_build_phases.py)
+__device__ unsigned long long g_bb_stamps[16];
+#define BB_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (k) >= 0) g_bb_stamps[(k)] = wall_clock64(); } while (0)
+#else
+#define BB_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // one sift: the hole is at the root of heap[0 .. heapLen), (last, lastVal) is inserted.  `w`: this lane's 32 winner bits.
@@ -131,7 +137,7 @@ __device__ __forceinline__ void sift_wave(int *heap, int *hval, int heapLen, int
 // all 64 lanes of ONE wavefront call this with the same arguments; `lane` = lane id
 template <typename SCR>
 __device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, int maxLength, SCR *S,
-                           unsigned char *length /*[numSymbols]*/, int *bl_counts /*[15]*/, int *numCodesOut, int lane) {
+                           unsigned char *length /*[numSymbols]*/, int *bl_counts /*[15]*/, int *numCodesOut, int lane, int sb = -1) {
     int *heap = S->heap, *hval = S->hval, *values = S->values;
     short *childs = S->childs;
     int heapLen = 0, maxCode = 0;
@@ -157,6 +163,7 @@ __device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, in
             wave_sync();
         }
     }
+    BB_STAMP(sb);
     if (lane == 0) {
         while (heapLen < 2) {
             int node = maxCode < 2 ? ++maxCode : 0;
@@ -207,6 +214,7 @@ __device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, in
         wave_sync();
         sift_wave(heap, hval, heapLen, last, lastVal, w, lane);
     } while (heapLen > 1);
+    BB_STAMP(sb < 0 ? sb : sb + 1);
 
     // ---- BuildLength :475
     const int nNodes = childsLen / 2;
@@ -229,6 +237,7 @@ __device__ void build_tree(const int *freqs, int numSymbols, int minNumCodes, in
     }
     for (int o = 32; o > 0; o >>= 1) overflow += __shfl_xor(overflow, o);
     wave_sync();
+    BB_STAMP(sb < 0 ? sb : sb + 2);
     if (overflow == 0) return;
     if (lane == 0) {                                                 // :519-571, the reference's loops
         int incrBitLen = maxLength - 1;
@@ -409,6 +418,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     const int ntok = (int)(T > tdone ? (T - tdone < BLOCK_TOKENS ? T - tdone : BLOCK_TOKENS) : 0);
     const int last = (s.finish && lb == so[si].blk_count - 1) ? 1 : 0;
 
+    BB_STAMP(0);
     for (int i = tid; i < LIT_NUM + 2; i += D_THREADS) lfreq[i] = 0;
     if (tid < DIST_NUM + 2) dfreq[tid] = 0;
     if (tid < BL_NUM + 1) blfreq[tid] = 0;
@@ -443,9 +453,11 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     if (tid == 0) lfreq[256]++; // EOF_SYMBOL :790
     __syncthreads();
     // the two wavefronts of the workgroup build the two trees side by side, a wavefront per tree (build_tree)
-    if (tid < 64) build_tree(lfreq, LIT_NUM, 257, 15, &scrL, llen, lblc, &lnum, tid);
+    BB_STAMP(1);
+    if (tid < 64) build_tree(lfreq, LIT_NUM, 257, 15, &scrL, llen, lblc, &lnum, tid, 8);
     else build_tree(dfreq, DIST_NUM, 1, 15, &scrD, dlen, dblc, &dnum, tid - 64);
     __syncthreads();
+    BB_STAMP(2);
     {   // CalcBLFreq :349 for both trees, a wavefront each, a lane per run (run_emit)
         const int lane = tid & 63;
         if (tid < 64) { const int R = find_runs(llen, lnum, rsL, lane); count_runs(llen, rsL, R, blfreq, lane); if (lane == 0) s_RL = R; }
@@ -453,8 +465,10 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
         for (int i = tid; i < 164; i += D_THREADS) hdrw[i] = 0u;
     }
     __syncthreads();
+    BB_STAMP(3);
     if (tid < 64) build_tree(blfreq, BL_NUM, 4, 7, &scrD, bllen, blblc, &blnum, tid);
     __syncthreads();
+    BB_STAMP(4);
     // encoded lengths (GetEncodedLength :331) and static_len (:815-823) in parallel
     int a = 0, st = 0, abl = 0;
     for (int i = tid; i < LIT_NUM; i += D_THREADS) {
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
         bd->opt_len = (uint32_t)opt_len; bd->static_len = (uint32_t)static_len;
     }
     __syncthreads();
+    BB_STAMP(5);
     if (tid < 64) {   // the header's bits: :773,:843,:852, SendAllTrees :676 — WriteTree :411 a lane per run (write_runs)
         const int type = s_type;
         int total = 3;
@@ -533,6 +548,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
         }
     }
     __syncthreads();
+    BB_STAMP(6);
     const int type = s_type;
     // code tables (BuildCodes :151) — canonical code of symbol i = nextCode[len] + (#earlier symbols of equal length)
     for (int i = tid; i < LIT_NUM; i += D_THREADS) {
@@ -567,6 +583,7 @@ __global__ __launch_bounds__(D_THREADS) void k_block_build(const SegDev *__restr
     }
     const int hb = (s_hdrbits + 7) >> 3;
     for (int i = tid; i < hb; i += D_THREADS) bd->hdr[i] = ((const unsigned char *)hdrw)[i];
+    BB_STAMP(7);
 }
 
 // Bit position of every block: one wavefront per segment, 64 blocks per step.  Stored blocks align to a byte
@@ -975,4 +992,9 @@ void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_s
     hipLaunchKernelGGL(k_block_positions, dim3(1), dim3(1024), 0, st, sums, lastlen, nblk, seg_start, bsp, blp);
 }
 
+#if SZL_LAB
+} // namespace szl
+extern "C" int szl_lab_bb_stamps(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(szl::g_bb_stamps), 16 * 8) == hipSuccess ? 0 : -1; }
+namespace szl {
+#endif
 } // namespace szl

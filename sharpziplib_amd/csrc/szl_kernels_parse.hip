@@ -678,7 +678,7 @@ __device__ __forceinline__ void win_refill(const ParseCtx &c, int64_t x, bool ac
     }
 }
 
-// WB4 (SZL_SPEC_WB=1 in the LABORATORY library, libszl_amd_lab.so; unmeasured on the device): the write-back of a round's tokens takes four ranges per store instruction
+// WB4 (the product's form since round 6; SZL_SPEC_WB=0 in the laboratory library is the other): the write-back of a round's tokens takes four ranges per store instruction
 // (16 lanes each) out of a compacted list instead of one range per iteration of a loop over up to 64 of them — on the interpreter the loop
 // is 17-20 % of this kernel's instructions (profiles/r04/gfxsim_srcprof_k_spec_win.log).
 template <int W, bool WB4 = false>
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
         __syncthreads();
         if (spec_tok) { // the k-th token of this range's speculative path goes to spec_tok[range start + k] (k_emit_copy reads them back)
             if constexpr (WB4) {
-                __shared__ uint32_t wb_j[64], wb_n[64];           // (inside the discarded branch of the default build: its LDS layout is untouched)
+                __shared__ uint32_t wb_j[64], wb_n[64];
                 __shared__ uint64_t wb_dst[64];
                 const uint64_t m = __ballot(nt > 0);
                 const int nact = __builtin_popcountll(m);
@@ -947,11 +947,13 @@ void launch_spec(const uint8_t *in, const uint16_t *link, MTab mtab, const SegDe
 #if SZL_LAB
     if (cw == 64) { hipLaunchKernelGGL(k_spec_win<64>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
 #endif
-#if SZL_LAB   // (laboratory library only: one more instantiation in this unit changes the inliner's decisions for the kernels next to it —
-              // compared instruction by instruction against the build the device has verified; the product's code stays what it was)
-    if (cw == 32 && SZL_LABKNOB("SZL_SPEC_WB", 0) != 0) { hipLaunchKernelGGL((k_spec_win<32, true>), wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+    // (round 6, measured at last — alternating calls in one process, tools/lab/knob_ab.py: the write-back that takes four ranges per store
+    // instruction, stage C of 1 GiB of text 5.46 -> 5.07 ms, of logs 2.16 -> 1.97; the product holds that form only, the laboratory
+    // library both: SZL_SPEC_WB=0 is the loop over the ranges)
+#if SZL_LAB
+    if (cw == 32 && SZL_LABKNOB("SZL_SPEC_WB", 1) == 0) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
 #endif
-    if (cw == 32) { hipLaunchKernelGGL(k_spec_win<32>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
+    if (cw == 32) { hipLaunchKernelGGL((k_spec_win<32, true>), wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
 #if SZL_LAB
     if (cw == 16) { hipLaunchKernelGGL(k_spec_win<16>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }
     if (cw == 8) { hipLaunchKernelGGL(k_spec_win<8>, wg, dim3(64), 0, st, in, link, mtab, segs, nseg, nranges, P, ranges, visited, counters, spec_tok); return; }

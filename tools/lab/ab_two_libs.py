@@ -26,12 +26,13 @@ engs = []
 for L in libs:
     _lib._lib = L
     engs.append(Engine())
-best = [1e9, 1e9]; tot = [1e9, 1e9]
+best = [1e9, 1e9]; tot = [1e9, 1e9]; st = [dict(), dict()]
 for rep in range(6):
     for k in (0, 1):
         _lib._lib = libs[k]
         r = engs[k].deflate([d], level=lv)[0]; tm = engs[k].timing()
         best[k] = min(best[k], tm['match_ms']); tot[k] = min(tot[k], tm['total_ms'])
+        for n in ('links_ms', 'parse_ms', 'blocks_ms', 'encode_ms'): st[k][n] = min(st[k].get(n, 1e9), tm[n])
         if rep == 0 and k == 0: ref = r.data
         assert r.data == ref
-for k in (0, 1): print("%-32s stage B %.2f ms  total %.2f ms (best of 6, %d MiB %s level %d)" % (sys.argv[1 + k], best[k], tot[k], mb, kind, lv))
+for k in (0, 1): print("%-32s stage B %.2f ms  total %.2f ms  A %.2f C %.2f D %.2f E %.2f (best of 6, %d MiB %s level %d)" % (sys.argv[1 + k], best[k], tot[k], st[k]['links_ms'], st[k]['parse_ms'], st[k]['blocks_ms'], st[k]['encode_ms'], mb, kind, lv))
