@@ -993,8 +993,16 @@ void launch_block_positions(const uint32_t *tokens, uint64_t ntok, int64_t seg_s
 }
 
 #if SZL_LAB
+__global__ void k_bb_stamps_out(unsigned long long *out) { out[threadIdx.x] = g_bb_stamps[threadIdx.x]; }
 } // namespace szl
-extern "C" int szl_lab_bb_stamps(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(szl::g_bb_stamps), 16 * 8) == hipSuccess ? 0 : -1; }
+extern "C" int szl_lab_bb_stamps(unsigned long long *out) {   // (a copy kernel, not hipMemcpyFromSymbol: the fake runtime of tools/gfxsim has no symbols)
+    unsigned long long *d = nullptr;
+    if (hipMalloc((void **)&d, 16 * 8) != hipSuccess) return -1;
+    hipLaunchKernelGGL(szl::k_bb_stamps_out, dim3(1), dim3(16), 0, 0, d);
+    const bool ok = hipMemcpy(out, d, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? 0 : -1;
+}
 namespace szl {
 #endif
 } // namespace szl
