@@ -632,7 +632,18 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
-    if (n_all <= (size_t)std::max(1, SZL_LABKNOB("SZL_INF_PAR_MAX_STREAMS", 1024))) {
+    // (round 6: the limit was 1024 streams.  One wavefront per member is at its best in MANY rounds of the 8 x CUs slots — 8192 x 1.5 MiB
+    // members 36 GiB/s against 31 in chunks — and at its worst in one: 2048 x 4 MiB members are ONE round of 4 MiB decodes, 271 ms, where
+    // the chunked form — since it cuts a call of many members at chunk_max — takes 225, and 1536 of them 233 against 172.  So the chunked
+    // form takes calls of up to 1.75 rounds' worth of streams; 4096 x 2 MiB, two full rounds: 249 against 261.  profiles/r06/inflate_many_paths.log)
+    size_t par_max_streams = (size_t)std::max(0, SZL_LABKNOB("SZL_INF_PAR_MAX_STREAMS", 0));
+    if (!par_max_streams) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        par_max_streams = (size_t)cus * 8 * 7 / 4;
+    }
+    if (n_all <= par_max_streams) {
         // groups of at most ~4 GiB of compressed input keep the 2-byte-per-output-byte staging bounded
         std::vector<size_t> cand;
         uint64_t grp = 0;

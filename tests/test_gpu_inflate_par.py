@@ -278,3 +278,22 @@ def test_default_knobs_256mib_member(eng):
     assert r.data == data.tobytes()
     ms = eng.timing()["inflate_ms"]
     print("parallel inflate of a 256 MiB member: %.2f ms = %.0f MiB/s (%d chunk jobs)" % (ms, 256e3 / ms, _par_jobs(eng)))
+
+
+def test_a_call_of_up_to_1_75_rounds_of_streams_is_decoded_in_chunks(eng):
+    """round 6: one wavefront per member is at its worst in ONE round of the 8 x CUs slots (2048 x 4 MiB members: 271 ms, in chunks 225), so
+    calls of up to 1.75 rounds' worth of streams (3584 on 256 CUs; 1024 through the round's second third) take the chunked form; more
+    streams than that go one wavefront per member as before (csrc/szl_api_inflate.hip, szl_inflate_batch_device)"""
+    data = C.generate("enwik", 0x51, 0, 1200 * (384 << 10))
+    parts = [data[i * (384 << 10):(i + 1) * (384 << 10)] for i in range(1200)]
+    comps = [r.data for r in eng.deflate(parts, level=6)]
+    _knobs(16, 64)
+    out = eng.inflate(comps, [p.size for p in parts], crc32=True)
+    jobs = _par_jobs(eng)
+    assert jobs >= 2 * 1200          # (a job per chunk in which a block starts: blocks are ~45 KiB of compressed bytes, chunks 16)
+    for (r, consumed), p, c in zip(out, parts, comps):
+        assert r.status == 0 and consumed == len(c) and r.data == p.tobytes() and r.crc32 == zlib.crc32(p.tobytes())
+    many = [comps[i % 1200] for i in range(4000)]
+    out = eng.inflate(many, [384 << 10] * 4000)
+    assert _par_jobs(eng) == 0
+    assert all(r.status == 0 for r, _ in out) and out[3999][0].data == parts[3999 % 1200].tobytes()
