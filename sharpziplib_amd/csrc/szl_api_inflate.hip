@@ -628,7 +628,6 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     // (members of 128-512 KiB compressed: chunked only while the call has few streams — 64 x 1 MiB members 56 -> 34 -> 15.4 ms over the
     // rounds; 512 of them were 57 -> 100 ms in round 2, when every member cost a second symbol pass; with regions sized by span they are
     // 51.6 -> 40.4 ms in chunks, profiles/r05/r5_ab.log: the limit moved from 128 to 512 streams, a quarter of the wavefront slots)
-    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", n_all <= 512 ? 128 : 512)) * 1024;
     std::vector<size_t> idx;             // streams for the one-wavefront-per-stream decoder
     std::vector<char> par_done(n_all, 0);
     std::vector<ParResult> par_res(n_all);
@@ -636,13 +635,15 @@ int szl_inflate_batch_device(szl_engine *e, const void *d_in, void *d_out, szl_s
     // members 36 GiB/s against 31 in chunks — and at its worst in one: 2048 x 4 MiB members are ONE round of 4 MiB decodes, 271 ms, where
     // the chunked form — since it cuts a call of many members at chunk_max — takes 225, and 1536 of them 233 against 172.  So the chunked
     // form takes calls of up to 1.75 rounds' worth of streams; 4096 x 2 MiB, two full rounds: 249 against 261.  profiles/r06/inflate_many_paths.log)
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     size_t par_max_streams = (size_t)std::max(0, SZL_LABKNOB("SZL_INF_PAR_MAX_STREAMS", 0));
-    if (!par_max_streams) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        par_max_streams = (size_t)cus * 8 * 7 / 4;
-    }
+    if (!par_max_streams) par_max_streams = (size_t)cus * 8 * 7 / 4;
+    // ... and members of 128-512 KiB of compressed bytes, which a call of more than 512 streams used to leave to the one-wavefront decoder,
+    // are chunked while the streams would fill less than three quarters of ITS slots: 600 x 1 MiB members 56 -> 28 ms, 1024 of them 58 -> 39,
+    // 700 x 512 KiB 28.5 -> 19.4; from 1536 streams on the two forms are within 5 % of each other (profiles/r06/inflate_many_paths.log)
+    const uint64_t par_min = (uint64_t)std::max(64, knob("SZL_INF_PAR_MIN_KIB", n_all <= (size_t)cus * 8 * 3 / 4 ? 128 : 512)) * 1024;
     if (n_all <= par_max_streams) {
         // groups of at most ~4 GiB of compressed input keep the 2-byte-per-output-byte staging bounded
         std::vector<size_t> cand;
