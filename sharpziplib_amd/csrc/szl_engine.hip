@@ -458,11 +458,14 @@ int Engine::deflate_impl(const uint8_t *d_in, uint64_t in_total, uint8_t *d_out,
     // pipeline spent 3.3 ms in k_spec_win where 1 GiB in one piece spends 4.3)
     constexpr uint64_t FILL_RANGES = 262144;
     uint32_t range_len = C_RANGE;
-    if (SZL_LABKNOB("SZL_RANGE_LEN", 0) >= 256) range_len = (uint32_t)SZL_LABKNOB("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
+    if (SZL_LABKNOB("SZL_RANGE_LEN", 0) >= 32) range_len = (uint32_t)SZL_LABKNOB("SZL_RANGE_LEN", 0) / 32 * 32;   // (lab)
     else {
         // (round 6: one entry of the unchanged ZipOutputStream path — a call of a few hundred KiB at most — spent 205 of its 890 us of device
         // time walking ranges of 256 positions on four wavefronts; a call that small gets ranges of 64)
-        const uint32_t min_range = total_emit <= (1u << 20) ? 64u : 256u;
+        // (by data class, tools/lab/small_call_ranges.py, profiles/r06/small_call_ranges.log: text gains from 64 up to 256 KiB — 0.156 against 0.194 /
+        // 0.297 ms with 128 / 256 — and from 128 at 1 MiB, 0.207 against 0.267 / 0.304; logs, whose matches are as long as such a range, never
+        // merge in ranges of 64 — 4693 unmerged ranges in 1 MiB, 0.407 ms against 0.293 / 0.179 — and from 2 MiB on 128 costs them 2-8 x)
+        const uint32_t min_range = total_emit <= (1u << 18) ? 64u : (total_emit <= (1u << 20) ? 128u : 256u);
         while (range_len > min_range && total_emit / range_len < FILL_RANGES) range_len >>= 1;
     }
     // Stage B: a small call gets shorter tiles (a tile is one workgroup; its lanes walk 16 positions each, one after the other)
