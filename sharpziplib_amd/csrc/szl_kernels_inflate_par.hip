@@ -82,6 +82,7 @@ __device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
         code <<= 1;
     }
     uint32_t idx = 0, prev = 0, len256 = 0, lastlit = 0;
+    uint32_t pk = 0, prep = 0, eq = 0, zl = 0;                       // the symbol before: 0 none, 1 a length, 2 / 3 / 4 = 16 / 17 / 18 and its count; equal lengths / zeros written out in a row
     const uint32_t total = nl + nd;
     int kl = 0, kd = 0, ndist = 0;                                // Kraft sums in units of 2^-15
     // (the symbols come out of a 64-bit window that is fetched again when fewer than 16 bits of it are left — a symbol takes at most
@@ -103,6 +104,37 @@ __device__ bool header_ok_lane(const uint8_t *in, uint64_t in_len, uint64_t p, u
         else if (sym == 18) { val = 0; rep = 11 + (w & 127); used += 7; }
         rel += used; buf >>= used; have -= (int)used;
         if (idx + rep > total) return false;                       // :106
+        // The code lengths as an encoder writes them (round 6, last third: three false headers in thirty calls of the laboratory scans —
+        // complete codes, trimmed counts and all, each costing the job in front of it a second chunk, i.e. the pass half its time again).
+        // DeflaterHuffman.CalcBLFreq / WriteTree (C/DeflaterHuffman.cs:349-473) and zlib's scan_tree / send_tree emit a run of equal lengths
+        // greedily and each of the two code sets on its own: a zero run is [18 x 138]* and then nothing, one or two 0s, one 17 or one 18;
+        // a run of v != 0 is v, [16 x 6]*, and then nothing, one or two v, or one 16.  So: no repeat across the literal/distance border and
+        // no 16 at the start of either set; nothing zero-valued behind a 17, behind an 18 shorter than 138 or behind two 0s, and no 17 / 18
+        // behind a 0; behind a 16 shorter than 6 nothing of the same length; a 16 only behind the run's first length or a full 16; at most
+        // three equal lengths written out.  Accidents break these within a few symbols; an encoder that writes its runs otherwise (zopfli,
+        // 7-zip's optimiser) merely loses its blocks as starts.
+        if (idx < nl && idx + rep > nl) return false;
+        if (idx == 0 || idx == nl) { pk = 0; eq = 0; zl = 0; if (sym == 16) return false; }
+        if (sym == 16) {
+            if (prev == 0) return false;
+            if (pk == 2 && prep < 6) return false;
+            if (pk == 1 && eq >= 2) return false;
+            pk = 2; prep = rep;
+        } else if (sym >= 17) {
+            if (pk != 0 && prev == 0 && !(pk == 4 && prep == 138)) return false;
+            pk = sym == 17 ? 3 : 4; prep = rep;
+        } else if (sym == 0) {
+            if (pk == 3 || (pk == 4 && prep < 138)) return false;
+            zl = (pk == 1 && prev == 0) ? zl + 1 : 1;
+            if (zl > 2) return false;
+            pk = 1;
+        } else {
+            if (pk == 2 && prep < 6 && sym == prev) return false;
+            if (pk == 1 && sym == prev) eq++;
+            else eq = (pk == 2 && sym == prev) ? 2 : 1;                 // (behind full 16s at most two more of the same length)
+            if (eq > 3) return false;
+            pk = 1;
+        }
         if (val) {
             const uint32_t in_lit = idx >= nl ? 0u : (idx + rep <= nl ? rep : nl - idx);       // how many of the run are literal/length codes
             kl += (int)in_lit * (32768 >> val);
