@@ -16,15 +16,18 @@ namespace szl {
 
 struct ChunkPlan { uint64_t chunk_bytes = 0; uint32_t nchunks = 0; };   // chunk_bytes 0: the member is not decoded in chunks
 
-inline uint64_t inflate_chunk_max(uint64_t total_in, uint64_t slots, uint64_t members = 1) {   // r whole rounds of the slots with chunks of at most ~192 KiB, at least 32 KiB
+inline uint64_t inflate_chunk_max(uint64_t total_in, uint64_t slots, uint64_t members = 1) {   // r whole rounds of the slots with chunks of at most ~192 KiB, at least 16 KiB
     const uint64_t rounds = std::max<uint64_t>(1, (total_in + slots * (192ull << 10) - 1) / (slots * (192ull << 10)));
     uint64_t jobs = slots * rounds;
     if (members > 1 && members * 2 < jobs) jobs -= members;      // (every member's last chunk is a short one: a job more than its bytes ask for)
-    return std::min<uint64_t>(std::max<uint64_t>((total_in / jobs + 1023) & ~1023ull, 32ull << 10), 256ull << 10);
+    // (the floor was 32 KiB through round 6's second third.  A block of a level-6 stream is ~20 KiB of compressed bytes, a job is at least a
+    // block, and a call that leaves slots empty is as fast as its LONGEST job: ONE 32 MiB text member 8.4 -> 4.9 ms with chunks of 16 KiB,
+    // 64 MiB 12.1 -> 8.4, 4 MiB 7.8 -> 5.7; logs 64 MiB 9.6 -> 5.4 — profiles/r06/inflate_one_chunk_floor.log)
+    return std::min<uint64_t>(std::max<uint64_t>((total_in / jobs + 1023) & ~1023ull, 16ull << 10), 256ull << 10);
 }
 
 // How many chunks a short member is cut into at least.  32 while the call leaves slots empty (a few short members: more, smaller jobs);
-// a call that fills the slots at chunk_max — chunk_max above its 32 KiB floor — keeps chunk_max for every member that holds eight of
+// a call that fills the slots at chunk_max — chunk_max above 32 KiB — keeps chunk_max for every member that holds eight of
 // them: round 6 measured 256 x 4 MiB members 40.2 -> 34.9 ms, 1024 of them 140 -> 129, 512 x 1 MiB 26.0 -> 23.4 that way (32 chunks
 // a member there are three partial rounds of jobs a quarter the size; profiles/r06/inflate_min_chunks.log).
 inline uint64_t inflate_min_chunks(uint64_t chunk_max) { return chunk_max > (32ull << 10) ? 8 : 32; }

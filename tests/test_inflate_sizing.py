@@ -59,7 +59,7 @@ def test_properties_on_random_calls(S):
         slots = int(rng.choice([2048, 2560, 1024, 304 * 8]))
         j0, cb0, n0, cm = plans(S, lens, slots)
         assert [(int(a), int(b)) for a, b in zip(cb0, n0)] == formula(lens, cm)
-        assert 32 << 10 <= cm <= 256 << 10 and cm % 1024 == 0
+        assert 16 << 10 <= cm <= 256 << 10 and cm % 1024 == 0
         for L, c, m in zip(lens, cb0, n0):
             if c:
                 assert 16384 <= c <= (256 << 10) and c % 1024 == 0 and m >= 8 and (m - 1) * c < L <= m * c
@@ -92,7 +92,7 @@ def test_a_call_that_fills_the_slots_is_whole_rounds_of_them(S):
     assert cm == 96 << 10 and (cb == 47 << 10).all() and j == 512 * 9
     # a few short members leave the slots empty: the 32 chunks a member of round 5
     j, cb, n, cm = plans_auto(S, [1553699] * 8, 2048)
-    assert cm == 32 << 10 and (n >= 32).all()
+    assert cm == 16 << 10 and (n >= 32).all()
     # one long member: nothing changes
     assert plans_auto(S, [380 << 20], 2048)[0] == plans(S, [380 << 20], 2048)[0]
     rng = np.random.default_rng(5)
@@ -101,7 +101,7 @@ def test_a_call_that_fills_the_slots_is_whole_rounds_of_them(S):
         lens = rng.integers(100000, 8 << 20, k)
         slots = int(rng.choice([2048, 2560]))
         j, cb, n, cm = plans_auto(S, lens, slots)
-        assert 32 << 10 <= cm <= 256 << 10 and cm % 1024 == 0
+        assert 16 << 10 <= cm <= 256 << 10 and cm % 1024 == 0
         for L, c, m in zip(lens, cb, n):
             if c:
                 assert 16384 <= c <= cm and c % 1024 == 0 and m >= 8 and (m - 1) * c < L <= m * c
