@@ -726,6 +726,13 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
         if (active && L == 0 && x >= re) active = false;
         __syncthreads();
         if (spec_tok) { // the k-th token of this range's speculative path goes to spec_tok[range start + k] (k_emit_copy reads them back)
+            // A range has range_len slots and its path can hold MORE tokens than that: literals at (nearly) every position and then
+            // a run of lazy literals past the range's end (a node that starts in the range belongs to it to its last token).  Such a
+            // range's surplus is not stored — it would land in the next range's slots, and whichever lane stored last would win — and
+            // k_emit_copy walks a range whose spec_count exceeds range_len instead of copying it (found by tools/lab/small_call_soak.py:
+            // level 7, Filtered, ranges of 64, 66 tokens in one of them; ranges of 4096 need 4095 literals and the run at the end).
+            const int nt_all = nt;
+            nt = (int)min((uint32_t)nt, s.range_len - min(s.range_len, count));
             if constexpr (WB4) {
                 __shared__ uint32_t wb_j[64], wb_n[64];
                 __shared__ uint64_t wb_dst[64];
@@ -755,6 +762,7 @@ __global__ __launch_bounds__(64) void k_spec_win(const uint8_t *in, const uint16
                 }
             }
             __syncthreads();
+            nt = nt_all;
         }
         count += (uint32_t)nt;
     }
@@ -857,10 +865,11 @@ __global__ __launch_bounds__(64) void k_emit_copy(const uint8_t *in, const uint1
     if (mine && rs < re) {
         int64_t x = lr == 0 ? rs : rd.entry, tp;
         int L = 0, D = 0;
+        const bool fits = rd.spec_count <= s.range_len;   // (k_spec_win stored no more than range_len tokens: the rest of such a path is walked here)
         for (;;) {
             if (L == 0) {
                 if (x >= re) break;
-                if (x >= rs && is_visited(vis, (uint64_t)(x - s.seg_start))) { y = x; break; }
+                if (x >= rs && fits && is_visited(vis, (uint64_t)(x - s.seg_start))) { y = x; break; }
             }
             const uint32_t t = parse_step(c, x, L, D, &tp, true, nullptr);
             if (t != 0xFFFFFFFFu) { tokens[ti] = t; edges(ti, tp); ti++; }

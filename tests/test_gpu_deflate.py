@@ -376,6 +376,40 @@ def test_never_merging_ranges_use_exit_maps(eng):
         assert eng.deflate([z], level=6)[0].data == O.deflate(z, 6)
 
 
+def _lazy_runs_at_range_ends(n, range_len, every, seed):
+    """Random bytes (a literal at every position) with, at the end of every `every`-th range, a run of lazy literals: the position in front
+    of the range's end has a match of 6, the next one of 7, the next one of 8 (their sources lie nine runs back, between two runs) — the node that starts in
+    the range holds two literals and a match, so the range's path holds range_len + 2 tokens."""
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 256, n, dtype=np.uint8)
+    for re_ in range(10 * every * range_len, n - 64, every * range_len):
+        p = re_ - 1
+        t = d[p:p + 24].copy()
+        src = p - 9 * every * range_len - 2 * range_len - 20   # (two ranges in front of an earlier run's range: no run's range is touched)
+        d[src:src + 6] = t[0:6]; d[src + 6] = t[6] ^ 0x55                    # t0..t5, then something else: 6 at p
+        d[src + 40:src + 47] = t[1:8]; d[src + 47] = t[8] ^ 0x55              # t1..t7: 7 at p + 1
+        d[src + 80:src + 88] = t[2:10]; d[src + 88] = t[10] ^ 0x55            # t2..t9: 8 at p + 2
+    return d
+
+
+def test_a_range_whose_path_holds_more_tokens_than_positions(eng):
+    """Stage C keeps each range's speculative tokens in the range's own range_len slots (k_spec_win -> spec_tok) and k_emit_copy copies them.
+    A path can hold MORE tokens than the range has positions — literals everywhere and a run of lazy literals across the range's end
+    (C/DeflaterEngine.cs:741-855: the node belongs to the range it starts in) — and the surplus used to land in the next range's slots.
+    Found by tools/lab/small_call_soak.py at level 7 / Filtered in a 188 KiB call (ranges of 64, one with 66 tokens: the fixture, which
+    the library of the time got wrong by two bytes); the constructed inputs do the same to ranges of 64, 128 and 256."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_call_range_overflow.npz"))["data"]
+    for lv, sg in ((7, 1), (7, 0), (5, 1), (9, 1)):
+        assert eng.deflate([fx], level=lv, strategy=sg)[0].data == O.deflate(fx, lv, strategy=sg), (lv, sg)
+    assert eng.deflate([fx, fx[1000:], fx[:150000]], level=7, strategy=1)[1].data == O.deflate(fx[1000:], 7, strategy=1)
+    for n, rl in ((200000, 64), (900000, 128), (3 << 20, 256)):       # the call's size picks the range length (Engine::deflate_impl)
+        d = _lazy_runs_at_range_ends(n, rl, 5, seed=rl)
+        for lv, sg in ((6, 0), (7, 1), (9, 0)):
+            want, tr = O.deflate(d, lv, strategy=sg, trace=True)
+            assert tr["tokens"].size > d.size - 40 * (n // (5 * rl))  # (nearly every position a literal: the premise)
+            assert eng.deflate([d], level=lv, strategy=sg)[0].data == want, (n, rl, lv, sg)
+
+
 # ---- level 0 (DeflateStored): block cuts replayed on the host, bytes moved by the device
 @pytest.mark.parametrize("n", [0, 1, 65530, 65531, 65532, 100000, 32506, 32507, 300000])
 def test_level0_batch(eng, n):

@@ -34,7 +34,7 @@ def data(n):
     return a
 
 
-t0 = time.time(); calls = 0; streams = 0; total = 0
+t0 = time.time(); calls = 0; streams = 0; total = 0; bad = 0
 while time.time() - t0 < budget:
     k = int(rng.choice([1, 1, 1, 2, 3, 7]))
     bufs = [data(size()) for _ in range(k)]
@@ -43,7 +43,16 @@ while time.time() - t0 < budget:
     for b, g in zip(bufs, got):
         want = O.deflate(b, level=level, nowrap=nowrap, strategy=strategy)
         want = want[0] if isinstance(want, tuple) else want
-        assert g.status == 0 and g.data == bytes(want), (calls, b.size, level, strategy, nowrap)
+        if not (g.status == 0 and g.data == bytes(want)):
+            bad += 1
+            w = np.frombuffer(bytes(want), np.uint8); q = np.frombuffer(g.data, np.uint8); m = min(w.size, q.size)
+            d = np.flatnonzero(w[:m] != q[:m])
+            print("MISMATCH call %d (batch of %d) size %d level %d strategy %d nowrap %s: status %d, %d bytes against the oracle's %d, first difference at byte %s"
+                  % (calls, k, b.size, level, strategy, nowrap, g.status, q.size, w.size, d[0] if d.size else "-"), flush=True)
+            np.save(os.path.join(R, "gpurun_out", "small_call_mismatch_%d.npy" % bad), b)
+            for lv, sg in ((level, strategy), (level, 0), (6, strategy), (9, strategy)):
+                a1 = eng.deflate([b], level=lv, strategy=sg, nowrap=nowrap)[0]
+                print("   alone, level %d strategy %d: %s" % (lv, sg, "equal" if a1.data == O.deflate(b, level=lv, nowrap=nowrap, strategy=sg) else "DIFFERENT"), flush=True)
         total += b.size; streams += 1
     calls += 1
-print("small-call soak: %d calls, %d streams, %.1f MiB, levels 5-9 x strategies x raw/zlib, all equal to the oracle, %.0f s" % (calls, streams, total / 2**20, time.time() - t0), flush=True)
+print("small-call soak: %d calls, %d streams, %.1f MiB, levels 5-9 x strategies x raw/zlib, %s, %.0f s" % (calls, streams, total / 2**20, "all equal to the oracle" if not bad else "%d MISMATCHES" % bad, time.time() - t0), flush=True)
