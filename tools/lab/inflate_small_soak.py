@@ -1,7 +1,7 @@
 """A randomised soak of the Inflater on SMALL members: batches of 1-3000 members of 0 bytes .. 3 MiB (clustered around the sizes where the
 call's form changes: one wavefront per member, chunked members), every data class, made by this library at levels 0-9 / every strategy or by
 zlib at levels 1-9 (with sync flushes), raw and zlib-framed; every member must come back equal to its input with in_consumed exact.
-python tools/lab/inflate_small_soak.py [seconds=240] [seed=1]"""
+python tools/lab/inflate_small_soak.py [seconds=240] [seed=1] [foreign]   (foreign: zlib only, random level x memLevel x wbits x strategy, members of up to 40 MiB)"""
 import sys, os, time, zlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np
@@ -10,6 +10,7 @@ from sharpziplib_amd.batch import Engine
 eng = Engine()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+FOREIGN = len(sys.argv) > 3 and sys.argv[3] == "foreign"
 
 
 def data(n):
@@ -29,7 +30,7 @@ def size(big):
     if k == 0: return int(rng.integers(0, 3000))
     if k == 1: return int(rng.integers(3000, 200000))
     if k == 2: return int(rng.choice([65536, 131072, 262144, 524288, 1 << 20])) + int(rng.integers(-5, 6))
-    return int(rng.integers(200000, (3 << 20) if big else 400000))
+    return int(rng.integers(200000, ((40 << 20) if FOREIGN and rng.random() < 0.3 else (3 << 20)) if big else 400000))
 
 
 t0 = time.time(); calls = 0; members = 0; total = 0; bad = 0
@@ -37,11 +38,13 @@ while time.time() - t0 < budget:
     k = int(rng.choice([1, 2, 5, 17, 100, 700, 3000]))
     nowrap = bool(rng.integers(0, 2))
     pool = [data(size(k <= 17)) for _ in range(min(k, 24))]
-    by_zlib = rng.random() < 0.35
+    by_zlib = FOREIGN or rng.random() < 0.35
     if by_zlib:
         comp = []
         for d in pool:
-            co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15 if nowrap else 15)
+            wb = int(rng.integers(9, 16)) if FOREIGN else 15       # ("foreign": every shape zlib can be asked for — blocks of 127 symbols at
+            co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -wb if nowrap else wb,   # memLevel 1, static-only, RLE, Huffman-only)
+                                  int(rng.integers(1, 10)) if FOREIGN else 8, int(rng.integers(0, 5)) if FOREIGN else 0)
             out = b""; step = int(rng.integers(1 << 12, 1 << 20))
             for o in range(0, max(1, d.size), step):
                 out += co.compress(d[o:o + step].tobytes())
