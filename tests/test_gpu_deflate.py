@@ -376,13 +376,13 @@ def test_never_merging_ranges_use_exit_maps(eng):
         assert eng.deflate([z], level=6)[0].data == O.deflate(z, 6)
 
 
-def _lazy_runs_at_range_ends(n, range_len, every, seed):
+def _lazy_runs_at_range_ends(n, range_len, every, seed, drift=0):
     """Random bytes (a literal at every position) with, at the end of every `every`-th range, a run of lazy literals: the position in front
     of the range's end has a match of 6, the next one of 7, the next one of 8 (their sources lie nine runs back, between two runs) — the node that starts in
     the range holds two literals and a match, so the range's path holds range_len + 2 tokens."""
     rng = np.random.default_rng(seed)
     d = rng.integers(0, 256, n, dtype=np.uint8)
-    for re_ in range(10 * every * range_len, n - 64, every * range_len):
+    for re_ in range(10 * every * range_len, n - 64, every * range_len + drift):   # (drift 1: the runs' ends take every phase of a range in turn)
         p = re_ - 1
         t = d[p:p + 24].copy()
         src = p - 9 * every * range_len - 2 * range_len - 20   # (two ranges in front of an earlier run's range: no run's range is touched)

@@ -51,6 +51,37 @@ def test_windowed_stream_is_bit_exact(small_windows, name, kib, level):
     assert ws_small < 16 * data.size          # side arrays follow the window, not the stream (an unwindowed call holds ~19 B per byte)
 
 
+def test_ranges_whose_paths_hold_more_tokens_than_positions_in_every_window(small_windows):
+    """The stage C parity bug of round 6 (tests/test_gpu_deflate.py::test_a_range_whose_path_holds_more_tokens_than_positions) through the
+    window pipeline and through the streaming Deflater's parts: a window's ranges (256 positions) start wherever the window in front of it
+    ended, so the runs of lazy literals end on every phase of a range in turn."""
+    from test_gpu_deflate import _lazy_runs_at_range_ends
+    from sharpziplib_amd.batch import Engine
+    from sharpziplib_amd.deflater import Deflater
+    data = np.concatenate([_lazy_runs_at_range_ends(1 << 20, 256, 5, seed=11), _lazy_runs_at_range_ends(5 << 19, 256, 5, seed=12, drift=1)])
+    for kib, level, strategy in ((256, 7, 1), (1024, 6, 0), (336, 9, 1)):
+        small_windows(kib)
+        eng = Engine()
+        try:
+            assert eng.deflate([data], level=level, strategy=strategy)[0].data == O.deflate(data, level, strategy=strategy), (kib, level, strategy)
+        finally:
+            eng.close()
+    d = Deflater(7, True)
+    d.SetStrategy(1)
+    out = bytearray(); buf = np.zeros(1 << 20, np.uint8)
+    for o in range(0, data.size, 700001):
+        d.SetInput(data[o:o + 700001])
+        while not d.IsNeedingInput:
+            k = d.Deflate(buf)
+            out += buf[:k].tobytes()
+            if k == 0: break
+    d.Finish()
+    while not d.IsFinished:
+        k = d.Deflate(buf)
+        out += buf[:k].tobytes()
+    assert bytes(out) == O.deflate(data, 7, strategy=1)
+
+
 def test_both_forms_of_stage_b_and_zlib_framing(monkeypatch):
     from sharpziplib_amd import _lib
     from sharpziplib_amd.batch import Engine
