@@ -397,7 +397,9 @@ def test_a_range_whose_path_holds_more_tokens_than_positions(eng):
     A path can hold MORE tokens than the range has positions — literals everywhere and a run of lazy literals across the range's end
     (C/DeflaterEngine.cs:741-855: the node belongs to the range it starts in) — and the surplus used to land in the next range's slots.
     Found by tools/lab/small_call_soak.py at level 7 / Filtered in a 188 KiB call (ranges of 64, one with 66 tokens: the fixture, which
-    the library of the time got wrong by two bytes); the constructed inputs do the same to ranges of 64, 128 and 256."""
+    the library of the time got wrong by two bytes — the discriminating case); the constructed inputs overflow every fifth range of 64, 128
+    and 256 positions (checked on the CPU model), though there the surplus — the literal at the range's end and the match behind it — is what
+    the next range's own path begins with, so they exercise the bounded stores and the walked emission rather than prove the old fault."""
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_call_range_overflow.npz"))["data"]
     for lv, sg in ((7, 1), (7, 0), (5, 1), (9, 1)):
         assert eng.deflate([fx], level=lv, strategy=sg)[0].data == O.deflate(fx, lv, strategy=sg), (lv, sg)
